@@ -1,0 +1,174 @@
+"""Pin the CPU oracle (oracle/) to the golden vectors captured from the reference.
+
+CPU only.  If these pass, the oracle is a faithful restatement of the reference's
+PyTorch path on the recorded inputs, and the GPU parity tests may use it as the checker.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import render_ref as R
+from oracle import ops_ref as O
+
+RENDER_CASES = ['render_s12.npz', 'render_s48.npz', 'render_misc.npz', 'render_nofine.npz']
+
+
+def _t(a, dt=torch.float32):
+    return torch.from_numpy(np.asarray(a)).to(dt)
+
+
+def _options(g):
+    return dict(depth_resolution=int(g['depth_resolution']), depth_resolution_importance=int(g['depth_resolution_importance']),
+                ray_start=float(g['ray_start']), ray_end=float(g['ray_end']), box_warp=float(g['box_warp']),
+                clamp_mode='softplus', white_back=bool(g['white_back']), disparity_space_sampling=bool(g['disparity']))
+
+
+def _run(g, dt):
+    dec = R.fold_decoder(_t(g['w1'], dt), _t(g['b1'], dt), _t(g['w2'], dt), _t(g['b2'], dt), float(g['lr_mul']))
+    stages = {}
+    noise_f = _t(g['noise_fine'], dt) if 'noise_fine' in g else None
+    out = R.render(_t(g['planes'], dt), dec, _t(g['ray_origins'], dt), _t(g['ray_dirs'], dt), _options(g),
+                   _t(g['noise_coarse'], dt), noise_f, stages)
+    return out, stages
+
+
+@pytest.mark.parametrize('case', RENDER_CASES)
+def test_render_matches_reference(golden, case):
+    g = golden(case)
+    (rgb, depth, wsum), st = _run(g, torch.float32)
+    N, M = g['out_rgb'].shape[:2]
+    # depth proposals are pure arithmetic on recorded noise: expect (near) bit-exactness
+    np.testing.assert_allclose(st['depths_coarse'].reshape(N, M, -1).numpy(), g['depths_coarse'], rtol=0, atol=2.4e-7)
+    np.testing.assert_allclose(st['sigma_coarse'].reshape(N, M, -1).numpy(), g['sigma_coarse'], rtol=1e-4, atol=2e-5)
+    if 'depths_fine' in g:
+        np.testing.assert_allclose(st['weights_coarse'].reshape(N, M, -1).numpy(), g['weights_coarse'], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(st['depths_fine'].reshape(N, M, -1).numpy(), g['depths_fine'], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(st['depths_all'].reshape(N, M, -1).numpy(), g['depths_all'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(rgb.numpy(), g['out_rgb'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(depth.numpy(), g['out_depth'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(wsum.numpy(), g['out_wsum'], rtol=0, atol=2e-5)
+    mse = float(((rgb.numpy() - g['out_rgb']) ** 2).mean())
+    assert mse < 1e-9            # north_star bound is 1e-4; the oracle sits 5 orders below it
+
+
+@pytest.mark.parametrize('case', RENDER_CASES)
+def test_render_fp64_truth_is_close(golden, case):
+    """The float64 run of the oracle is the tie-breaker 'truth'; it must agree with the fp32 reference to fp32 noise."""
+    g = golden(case)
+    (rgb, depth, wsum), _ = _run(g, torch.float64)
+    assert float(((rgb.numpy() - g['out_rgb']) ** 2).mean()) < 1e-8
+    np.testing.assert_allclose(wsum.numpy(), g['out_wsum'], atol=1e-4)
+
+
+def test_make_rays(golden):
+    g = golden('camera.npz')
+    o, d = R.make_rays(_t(g['rs_cam2world']), _t(g['rs_intrinsics']), int(g['rs_res']))
+    np.testing.assert_allclose(o.numpy(), g['rs_origins'], rtol=0, atol=0)
+    np.testing.assert_allclose(d.numpy(), g['rs_dirs'], rtol=0, atol=1.2e-7)
+    for case in RENDER_CASES[:2]:
+        gg = golden(case)
+        o, d = R.make_rays(_t(gg['cam2world']), _t(gg['intrinsics']), int(gg['res']))
+        np.testing.assert_allclose(o.numpy(), gg['ray_origins'], atol=0)
+        np.testing.assert_allclose(d.numpy(), gg['ray_dirs'], atol=1.2e-7)
+
+
+def test_orbit_cameras(golden):
+    g = golden('camera.npz')
+    for i, ref in zip(g['orbit_frames'], g['orbit_cam2world']):
+        yaw = 3.14 / 2 + 0.7 * np.sin(2 * 3.14 * i / 120)
+        pitch = 3.14 / 2 - 0.05 + 0.3 * np.cos(2 * 3.14 * i / 120)
+        m = R.lookat_pose(yaw, pitch, 2.7)
+        np.testing.assert_allclose(m[0].numpy(), ref, atol=3e-7)
+
+
+def test_importance_depths_edge_cases(golden):
+    g = golden('stages.npz')
+    out = R.importance_depths(_t(g['pdf_depths']), _t(g['pdf_weights']), _t(g['pdf_noise']))
+    np.testing.assert_allclose(out.numpy(), g['pdf_out'], rtol=0, atol=3e-6)
+
+
+def test_composite_edge_cases(golden):
+    g = golden('stages.npz')
+    col, sig, dep = _t(g['march_colors'])[0], _t(g['march_sigma'])[0, :, :, 0], _t(g['march_depths'])[0, :, :, 0]
+    for wb in (0, 1):
+        rgb, depth, w = R.composite(col, sig, dep, bool(wb), (dep.min(), dep.max()))
+        np.testing.assert_allclose(w.numpy(), g[f'march_w_wb{wb}'][0, :, :, 0], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(rgb.numpy(), g[f'march_rgb_wb{wb}'][0], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(depth.numpy(), g[f'march_depth_wb{wb}'][0, :, 0], rtol=0, atol=1e-6)
+    # the underflow ray: zero total weight -> NaN -> +inf -> clamped to the GLOBAL max depth (ray_marcher.py:49-50)
+    assert g['march_w_wb0'][0, 1].sum() == 0.0
+    assert g['march_depth_wb0'][0, 1, 0] == g['march_depths'].max()
+
+
+def test_plane_projection_and_lookup(golden):
+    g = golden('stages.npz')
+    pts = _t(g['proj_points'])[0]
+    uv = R.plane_uv(pts, 1.0)
+    np.testing.assert_allclose(uv.numpy(), g['proj_uv'], atol=0)
+    planes = _t(g['lookup_planes'])[0]
+    for p in range(3):
+        f = R.bilinear_zeros(planes[p], uv[p])
+        np.testing.assert_allclose(f.numpy(), g['lookup_out'][0, p], rtol=0, atol=1e-6)
+    assert (np.abs(g['proj_uv']) > 1).any()      # the fixture does exercise zero padding
+
+
+# ----------------------------------------------------------------------------
+# ops
+
+
+@pytest.mark.parametrize('act', list(O.ACTIVATIONS))
+@pytest.mark.parametrize('clamp', [None, 0.9])
+def test_bias_act_all_orders(golden, act, clamp):
+    g = golden('ops.npz')
+    tag = f'ba_{act}_{"c" if clamp else "n"}'
+    x, b, dy, ddx = g['ba_x'], g['ba_b'], g['ba_dy'], g['ba_ddx']
+    np.testing.assert_allclose(O.bias_act(x, b, 1, act, clamp=clamp), g[tag + '_y'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(O.bias_act_grad(dy, x, b, 1, act, clamp=clamp), g[tag + '_dx'], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(O.bias_act_grad2(ddx, dy, x, b, 1, act, clamp=clamp), g[tag + '_d2'], rtol=1e-9, atol=1e-12)
+
+
+def test_bias_act_dim0(golden):
+    g = golden('ops.npz')
+    y = O.bias_act(g['ba2_x'], g['ba2_b'], dim=0, act='lrelu', alpha=0.1, gain=0.7)
+    np.testing.assert_allclose(y, g['ba2_y'], rtol=1e-6, atol=1e-7)
+
+
+UP_CASES = {
+    'blur':      dict(f='f4', up=1, down=1, padding=[1, 1, 1, 1], gain=4.0),
+    'up2':       dict(f='f4', up=2, down=1, padding=[2, 1, 2, 1], gain=4.0),
+    'down2':     dict(f='f4', up=1, down=2, padding=[1, 1, 1, 1], gain=1.0),
+    'asym':      dict(f='fa', up=[2, 1], down=[1, 2], padding=[1, 2, 3, 0], gain=1.5),
+    'asym_flip': dict(f='fa', up=[2, 1], down=[1, 2], padding=[1, 2, 3, 0], gain=1.5, flip_filter=True),
+    'crop':      dict(f='f4', up=2, down=1, padding=[-1, 2, 3, -2], gain=1.0),
+    'sep':       dict(f='fs', up=2, down=3, padding=[4, 3, 5, 2], gain=2.0),
+    'sep_flip':  dict(f='fs', up=1, down=1, padding=[4, 3, 4, 3], gain=1.0, flip_filter=True),
+    'none':      dict(f=None, up=2, down=1, padding=0, gain=1.0),
+}
+
+
+@pytest.mark.parametrize('name', list(UP_CASES))
+def test_upfirdn2d(golden, name):
+    g = golden('ops.npz')
+    kw = dict(UP_CASES[name])
+    f = kw.pop('f')
+    f = None if f is None else g['up_' + f]
+    y = O.upfirdn2d(g['up_x'], f, **kw)
+    assert y.shape == g['up_' + name].shape
+    np.testing.assert_allclose(y, g['up_' + name], rtol=1e-5, atol=2e-6)
+
+
+def test_setup_filter(golden):
+    g = golden('ops.npz')
+    np.testing.assert_allclose(O.setup_filter([1, 3, 3, 1]), g['up_f4'], rtol=1e-7)
+    np.testing.assert_allclose(O.setup_filter([1., 2., 3., 4., 3., 2., 1., 0.5]), g['up_fs'], rtol=1e-7)
+
+
+def test_filtered_lrelu(golden):
+    g = golden('ops.npz')
+    x, b, fu, fd = g['fl_x'], g['fl_b'], g['fl_fu'], g['fl_fd']
+    y = O.filtered_lrelu(x, fu, fd, b, up=2, down=2, padding=[10, 10, 10, 10], gain=1.3, slope=0.1, clamp=0.8)
+    np.testing.assert_allclose(y, g['fl_up2_down2'], rtol=1e-4, atol=2e-6)
+    y = O.filtered_lrelu(x, fu, fd, b, up=4, down=2, padding=[11, 10, 9, 12], flip_filter=True)
+    np.testing.assert_allclose(y, g['fl_up4_down2'], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(O.filtered_lrelu(x, b=b), g['fl_plain'], rtol=1e-5, atol=1e-6)
