@@ -1,0 +1,179 @@
+// bias_act for gfx950: y = clamp(act(x + b) * gain) and its 1st/2nd-order gradient forms.
+//
+// Replaces bias_act_plugin.bias_act (reference torch_utils/ops/bias_act.cpp:36, bias_act.cu:27-151);
+// semantics follow torch_utils/ops/bias_act.py:92-122 (forward) and the autograd wrappers :128-209.
+//
+// The op is a pure HBM stream (2-5 tensors in, 1 out), so the kernel is organised around 16-byte
+// per-lane accesses: every lane moves one 16-B vector per tensor per step (1 KiB per wave
+// instruction), a grid of <= 8 workgroups per CU strides over the tensor, and the bias index is
+// resolved once per vector whenever the bias stride allows it.
+
+#include "common.h"
+
+namespace {
+
+using namespace gnerf;
+
+constexpr int kThreads = 256;
+
+template <class A> struct Consts;
+template <> struct Consts<float>  { static __device__ float  exp_range() { return 80.f; } };
+template <> struct Consts<double> { static __device__ double exp_range() { return 80.0; } };
+
+template <class A> __device__ __forceinline__ A act_exp(A v);
+template <> __device__ __forceinline__ float  act_exp<float>(float v)   { return expf(v); }
+template <> __device__ __forceinline__ double act_exp<double>(double v) { return exp(v); }
+template <class A> __device__ __forceinline__ A act_log1p(A v);
+template <> __device__ __forceinline__ float  act_log1p<float>(float v)   { return log1pf(v); }
+template <> __device__ __forceinline__ double act_log1p<double>(double v) { return log1p(v); }
+template <class A> __device__ __forceinline__ A act_tanh(A v);
+template <> __device__ __forceinline__ float  act_tanh<float>(float v)   { return tanhf(v); }
+template <> __device__ __forceinline__ double act_tanh<double>(double v) { return tanh(v); }
+
+struct Args {
+    const void* x; const void* b; const void* xref; const void* yref; const void* dy; void* y;
+    int64_t numel; unsigned size_b; unsigned step_b;
+    int grad; float alpha, gain, clamp;
+};
+
+// One element.  `in` is x (grad 0), dy (grad 1) or d_dx (grad 2); `pre` is xref + b (or unused);
+// `yy` is the saved forward output divided by gain; `dy2` multiplies the result (1 when absent).
+template <class A, int ACT>
+__device__ __forceinline__ A eval(A in, A bias, A xref, A yref, A dy2, int grad, A alpha, A gain, A clamp) {
+    const A one = A(1), two = A(2), zero = A(0);
+    const A selu_scale = A(1.0507009873554804934193349852946);
+    const A selu_alpha = A(1.6732632423543772848170429916717);
+    const A yy = (gain != zero) ? yref / gain : zero;
+    A out = zero;
+    if (grad == 0) {
+        const A v = in + bias;
+        if (ACT == 1) out = v;
+        if (ACT == 2) out = v > zero ? v : zero;
+        if (ACT == 3) out = v > zero ? v : v * alpha;
+        if (ACT == 4) out = act_tanh<A>(v);
+        if (ACT == 5) out = one / (one + act_exp<A>(-v));
+        if (ACT == 6) out = v >= zero ? v : act_exp<A>(v) - one;
+        if (ACT == 7) out = v >= zero ? selu_scale * v : (selu_scale * selu_alpha) * (act_exp<A>(v) - one);
+        if (ACT == 8) out = v > A(20) ? v : act_log1p<A>(act_exp<A>(v));
+        if (ACT == 9) out = v / (one + act_exp<A>(-v));
+    } else {
+        const A pre = xref + bias;      // only meaningful for swish (its gradient is written in terms of x)
+        if (grad == 1) {
+            if (ACT == 1) out = in;
+            if (ACT == 2) out = yy > zero ? in : zero;
+            if (ACT == 3) out = yy > zero ? in : in * alpha;
+            if (ACT == 4) out = in * (one - yy * yy);
+            if (ACT == 5) out = in * yy * (one - yy);
+            if (ACT == 6) out = yy >= zero ? in : in * (yy + one);
+            if (ACT == 7) out = yy >= zero ? in * selu_scale : in * (yy + selu_scale * selu_alpha);
+            if (ACT == 8) out = in * (one - act_exp<A>(-yy));
+        } else {
+            if (ACT == 4) out = in * (one - yy * yy) * (-two * yy);
+            if (ACT == 5) out = in * yy * (one - yy) * (one - two * yy);
+            if (ACT == 6) out = yy >= zero ? zero : in * (yy + one);
+            if (ACT == 7) out = yy >= zero ? zero : in * (yy + selu_scale * selu_alpha);
+            if (ACT == 8) { const A e = act_exp<A>(-yy); out = in * e * (one - e); }
+        }
+        if (ACT == 9) {
+            // sigmoid s = 1/(1+exp(-pre));  swish' = s + pre*s*(1-s);  swish'' = s*(1-s)*(2 + pre*(1-2s))
+            const A s = one / (one + act_exp<A>(-pre));
+            const A ds = s * (one - s);
+            out = (grad == 1) ? in * (s + pre * ds) : in * ds * (two + pre * (one - two * s));
+            yref = pre * s * gain;      // the clamp mask below needs the forward output
+        }
+    }
+    out *= gain * dy2;
+    if (clamp >= zero) {
+        if (grad == 0) out = out > clamp ? clamp : (out < -clamp ? -clamp : out);
+        else           out = (yref > -clamp && yref < clamp) ? out : zero;
+    }
+    return out;
+}
+
+template <class T, int VEC> struct alignas(sizeof(T) * VEC) Pack { T v[VEC]; };
+
+template <class T, int ACT, int VEC>
+__global__ __launch_bounds__(kThreads) void bias_act_kernel(Args a) {
+    typedef typename Arith<T>::type A;
+    typedef Pack<T, VEC> P;
+    const A alpha = A(a.alpha), gain = A(a.gain), clamp = A(a.clamp);
+    const T* x = static_cast<const T*>(a.x);
+    const T* b = static_cast<const T*>(a.b);
+    const T* xref = static_cast<const T*>(a.xref);
+    const T* yref = static_cast<const T*>(a.yref);
+    const T* dy = static_cast<const T*>(a.dy);
+    T* y = static_cast<T*>(a.y);
+    const int64_t nvec = a.numel / VEC;
+    const bool bias_per_vec = (b != nullptr) && (a.step_b % VEC == 0);
+    const int64_t stride = int64_t(gridDim.x) * kThreads;
+    for (int64_t iv = int64_t(blockIdx.x) * kThreads + threadIdx.x; iv < nvec; iv += stride) {
+        const int64_t i0 = iv * VEC;
+        P px = *reinterpret_cast<const P*>(x + i0), pxr, pyr, pdy, po;
+        if (xref) pxr = *reinterpret_cast<const P*>(xref + i0);
+        if (yref) pyr = *reinterpret_cast<const P*>(yref + i0);
+        if (dy)   pdy = *reinterpret_cast<const P*>(dy + i0);
+        A bv = A(0);
+        if (bias_per_vec) bv = load_as<T>(b, (unsigned(i0) / a.step_b) % a.size_b);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+            if (b && !bias_per_vec) bv = load_as<T>(b, (unsigned(i0 + k) / a.step_b) % a.size_b);
+            const A r = eval<A, ACT>(load_as<T>(px.v, k), bv,
+                                     xref ? load_as<T>(pxr.v, k) : A(0), yref ? load_as<T>(pyr.v, k) : A(0),
+                                     dy ? load_as<T>(pdy.v, k) : A(1), a.grad, alpha, gain, clamp);
+            store_as<T>(po.v, k, r);
+        }
+        *reinterpret_cast<P*>(y + i0) = po;
+    }
+    // ragged tail (fewer than VEC elements), one lane each
+    const int64_t tail0 = nvec * VEC;
+    const int64_t it = tail0 + int64_t(blockIdx.x) * kThreads + threadIdx.x;
+    if (it < a.numel) {
+        const A bv = b ? load_as<T>(b, (unsigned(it) / a.step_b) % a.size_b) : A(0);
+        const A r = eval<A, ACT>(load_as<T>(x, it), bv, xref ? load_as<T>(xref, it) : A(0), yref ? load_as<T>(yref, it) : A(0),
+                                 dy ? load_as<T>(dy, it) : A(1), a.grad, alpha, gain, clamp);
+        store_as<T>(y, it, r);
+    }
+}
+
+template <class T, int VEC>
+int launch_act(const Args& a, int act, hipStream_t stream) {
+    const int64_t nvec = (a.numel + VEC - 1) / VEC;
+    int64_t blocks = (nvec + kThreads - 1) / kThreads;
+    const int64_t cap = int64_t(kNumCU) * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    dim3 g((unsigned)blocks), t(kThreads);
+    switch (act) {
+#define GNERF_CASE(A_) case A_: hipLaunchKernelGGL((bias_act_kernel<T, A_, VEC>), g, t, 0, stream, a); break;
+        GNERF_CASE(1) GNERF_CASE(2) GNERF_CASE(3) GNERF_CASE(4) GNERF_CASE(5)
+        GNERF_CASE(6) GNERF_CASE(7) GNERF_CASE(8) GNERF_CASE(9)
+#undef GNERF_CASE
+        default: return fail(GNERF_E_ARG, "bias_act: unknown activation %d", act);
+    }
+    return check_launch("bias_act");
+}
+
+bool aligned16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int gnerf_bias_act(const void* x, const void* b, const void* xref, const void* yref, const void* dy,
+                              void* y, int dtype, int64_t numel, int size_b, int64_t step_b,
+                              int grad, int act, float alpha, float gain, float clamp, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (numel == 0) return GNERF_OK;
+    if (!x || !y) return fail(GNERF_E_ARG, "bias_act: x and y must not be null");
+    if (numel < 0 || numel > INT32_MAX) return fail(GNERF_E_ARG, "bias_act: x is too large (%lld elements)", (long long)numel);
+    if (grad < 0 || grad > 2) return fail(GNERF_E_ARG, "bias_act: grad must be 0, 1 or 2");
+    if (b && (size_b <= 0 || step_b <= 0)) return fail(GNERF_E_ARG, "bias_act: bias given with size %d, step %lld", size_b, (long long)step_b);
+    if (act < 1 || act > 9) return fail(GNERF_E_ARG, "bias_act: unknown activation %d", act);
+    Args a{x, b, xref, yref, dy, y, numel, b ? unsigned(size_b) : 1u, b ? unsigned(step_b) : 1u, grad, alpha, gain, clamp};
+    const bool vec_ok = aligned16(x) && aligned16(y) && aligned16(xref) && aligned16(yref) && aligned16(dy);
+    hipStream_t s = as_stream(stream);
+    switch (dtype) {
+        case GNERF_F32: return vec_ok ? launch_act<float, 4>(a, act, s) : launch_act<float, 1>(a, act, s);
+        case GNERF_F16: return vec_ok ? launch_act<__half, 8>(a, act, s) : launch_act<__half, 1>(a, act, s);
+        case GNERF_F64: return vec_ok ? launch_act<double, 2>(a, act, s) : launch_act<double, 1>(a, act, s);
+        default: return fail(GNERF_E_ARG, "bias_act: unsupported dtype code %d", dtype);
+    }
+}

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Build libgnerf_hip.so for gfx950 in-tree (next to the sources' parent: g-nerf_amd/gnerf_hip/).
+# hipcc cross-compiles without a GPU, so this runs in the build container and on the GPU box alike.
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"
+root="$(cd "$here/../.." && pwd)"
+out="$here/../gnerf_hip/libgnerf_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$root/include -I$here -Wall -Wno-unused-function ${GNERF_EXTRA_FLAGS:-}"
+objs=()
+for src in capi bias_act upfirdn2d filtered_lrelu planes render; do
+    [ -f "$here/$src.hip" ] || continue
+    obj="$here/$src.o"
+    if [ ! -f "$obj" ] || [ "$here/$src.hip" -nt "$obj" ] || [ "$here/common.h" -nt "$obj" ] || [ "$root/include/gnerf_hip.h" -nt "$obj" ]; then
+        echo "[build] $src.hip"
+        $HIPCC $FLAGS -c "$here/$src.hip" -o "$obj" &
+    fi
+    objs+=("$obj")
+done
+wait
+$HIPCC -shared -fPIC --offload-arch=gfx950 "${objs[@]}" -o "$out"
+echo "[build] $out"

@@ -1,0 +1,108 @@
+// Layout change and ray generation feeding the fused renderer.
+//
+// gnerf_planes_to_nhwc: the reference keeps tri-planes NCHW (training/triplane.py:74), where the 32 channels
+// of one texel are 256 KB apart.  The renderer wants one texel = one 128-byte line, so planes are
+// transposed once per batch to [plane, y, x, channel] through a 32x64 LDS tile: reads are coalesced
+// along x, writes are whole texels.
+//
+// gnerf_make_rays: RaySampler.forward (training/volumetric_rendering/ray_sampler.py:24-63).
+
+#include "common.h"
+
+namespace {
+
+using namespace gnerf;
+
+constexpr int CT = 32, PT = 64;   // channel x pixel tile
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int c, int64_t hw, int tiles_p, int tiles_c) {
+    __shared__ float tile[CT][PT + 1];
+    int64_t t = blockIdx.x;
+    const int tp = int(t % tiles_p); t /= tiles_p;
+    const int tc = int(t % tiles_c); t /= tiles_c;
+    const int64_t plane = t;
+    const int64_t p0 = int64_t(tp) * PT;
+    const int c0 = tc * CT;
+    const float* s = src + plane * c * hw;
+    float* d = dst + plane * hw * c;
+    for (int e = threadIdx.x; e < CT * PT; e += 256) {
+        const int ch = e / PT, px = e % PT;
+        float v = 0.f;
+        if (c0 + ch < c && p0 + px < hw) v = s[int64_t(c0 + ch) * hw + p0 + px];
+        tile[ch][px] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < CT * PT; e += 256) {
+        const int px = e / CT, ch = e % CT;
+        if (c0 + ch < c && p0 + px < hw) d[(p0 + px) * c + c0 + ch] = tile[ch][px];
+    }
+}
+
+// One lane per ray.  Arithmetic order follows ray_sampler.py:43-59 (no fused multiply-adds, so that
+// the directions agree with the reference to the last bit or two).
+__global__ __launch_bounds__(256) void make_rays_kernel(const float* __restrict__ c2w, const float* __restrict__ intr,
+                                                        int n, int res, float* __restrict__ origins, float* __restrict__ dirs) {
+    const int64_t m_total = int64_t(res) * res;
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= m_total * n) return;
+    const int item = int(i / m_total);
+    const int m = int(i % m_total);
+    const int row = m / res, col = m % res;
+    const float* M = c2w + item * 16;
+    const float* K = intr + item * 9;
+    const float fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
+    const float inv = 1.0f / float(res), half = 0.5f / float(res);
+    const float xc = __fadd_rn(__fmul_rn(float(col), inv), half);
+    const float yc = __fadd_rn(__fmul_rn(float(row), inv), half);
+    // x_lift = (x - cx + cy*sk/fy - sk*y/fy) / fx ;  y_lift = (y - cy) / fy          ray_sampler.py:51-52
+    float xl = __fsub_rn(xc, cx);
+    xl = __fadd_rn(xl, __fdiv_rn(__fmul_rn(cy, sk), fy));
+    xl = __fsub_rn(xl, __fdiv_rn(__fmul_rn(sk, yc), fy));
+    xl = __fdiv_rn(xl, fx);
+    const float yl = __fdiv_rn(__fsub_rn(yc, cy), fy);
+    float w[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        // row r of cam2world times (xl, yl, 1, 1)
+        float acc = __fmul_rn(M[r * 4 + 0], xl);
+        acc = __fadd_rn(acc, __fmul_rn(M[r * 4 + 1], yl));
+        acc = __fadd_rn(acc, M[r * 4 + 2]);
+        acc = __fadd_rn(acc, M[r * 4 + 3]);
+        w[r] = __fsub_rn(acc, M[r * 4 + 3]);
+    }
+    float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(w[0], w[0]), __fmul_rn(w[1], w[1])), __fmul_rn(w[2], w[2])));
+    nrm = fmaxf(nrm, 1e-12f);       // F.normalize eps
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        dirs[i * 3 + r] = __fdiv_rn(w[r], nrm);
+        origins[i * 3 + r] = M[r * 4 + 3];
+    }
+}
+
+}  // namespace
+
+extern "C" int gnerf_planes_to_nhwc(const float* planes_nchw, float* planes_nhwc, int np, int c, int h, int w,
+                                    gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!planes_nchw || !planes_nhwc) return fail(GNERF_E_ARG, "planes_to_nhwc: null pointer");
+    if (np < 1 || c < 1 || h < 1 || w < 1) return fail(GNERF_E_ARG, "planes_to_nhwc: empty tensor");
+    const int64_t hw = int64_t(h) * w;
+    const int tiles_p = int((hw + PT - 1) / PT), tiles_c = (c + CT - 1) / CT;
+    const int64_t blocks = int64_t(tiles_p) * tiles_c * np;
+    if (blocks > INT32_MAX) return fail(GNERF_E_ARG, "planes_to_nhwc: tensor too large");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                       planes_nchw, planes_nhwc, c, hw, tiles_p, tiles_c);
+    return check_launch("planes_to_nhwc");
+}
+
+extern "C" int gnerf_make_rays(const float* cam2world, const float* intrinsics, int n, int res,
+                               float* origins, float* dirs, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!cam2world || !intrinsics || !origins || !dirs) return fail(GNERF_E_ARG, "make_rays: null pointer");
+    if (n < 1 || res < 1) return fail(GNERF_E_ARG, "make_rays: n and res must be positive");
+    const int64_t total = int64_t(n) * res * res;
+    hipLaunchKernelGGL(make_rays_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       cam2world, intrinsics, n, res, origins, dirs);
+    return check_launch("make_rays");
+}

@@ -1,0 +1,647 @@
+// Fused tri-plane importance renderer for gfx950 (MI355X).
+//
+// One kernel does, per ray, everything ImportanceRenderer.forward does with a dozen whole-tensor PyTorch
+// ops and ~4 GB of intermediates (reference training/volumetric_rendering/renderer.py:88-140,
+// ray_marcher.py:25-57, triplane.py:113-136):
+//
+//   depth proposals -> tri-plane bilinear lookup -> 32->64->33 MLP -> coarse march -> importance
+//   resampling -> fine lookup + MLP -> depth merge -> final composite.
+//
+// Work decomposition: ONE WAVE (a 64-lane workgroup) owns a ray at a time and walks a small tile of rays
+// (4x4 pixels when the rays form an image).  Nothing but the three outputs is ever written to HBM.
+//
+//  * Lookup ("gather") layout: 8 adjacent lanes read one whole 128-byte texel (32 fp32 channels of the NHWC
+//    planes) with one global_load_dwordx4 each, so a wave instruction touches 8 cache lines, the minimum.
+//    A wave does 8 samples per step, two steps per 16-sample MLP tile.
+//  * MLP on the matrix cores in exact fp32: v_mfma_f32_16x16x4_f32.  Layer 1 is computed transposed
+//    (hidden on the accumulator rows, samples on the lanes) so that its accumulator registers are directly
+//    the A operand of layer 2 (which sums over hidden) -- no data movement between the layers.  Layer 2
+//    puts samples on accumulator rows and colour channels on lanes, which is what compositing wants
+//    (a per-lane sum over registers).  The density row of layer 2 is a 16-term per-lane dot product plus
+//    two cross-lane adds: a 33rd column would cost a third more MFMAs.
+//  * Per-sample scalars (depth, density, weights, cdf, ranks) live in a few hundred bytes of LDS per wave;
+//    colours of all samples (needed until the final weights are known) live in LDS as a lane-private
+//    spill, 1 KiB per 16 samples.
+//  * The call-wide depth clamp of ray_marcher.py:49-50 needs min/max over every depth of the call: waves
+//    publish their extrema with two integer atomics, and a tiny second kernel applies the clamp.
+
+#include "common.h"
+
+namespace {
+
+using namespace gnerf;
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kHidden = 64;
+constexpr int kStagePitch = 36;        // dwords per staged sample row (32 channels + pad)
+constexpr int kRaysPerWave = 16;
+
+struct Params {
+    gnerf_render_params p;
+    float box_scale;        // 2 / box_warp
+    float delta;            // (ray_end - ray_start) / (S - 1)
+    float inv_start, inv_end, disp_delta;
+    int tiles_c, tiles_f;   // 16-sample MLP tiles
+    int n_tiles;            // ray tiles in the grid
+    int tiles_per_item, tiles_y;   // image tiling (0 when rays are not an image)
+    int total_rays;
+};
+
+// ---- order-preserving float <-> uint so that integer atomics give float min/max
+__device__ __forceinline__ unsigned ord_encode(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_decode(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__device__ __forceinline__ float softplus_f(float x) {          // torch softplus, beta 1, threshold 20
+    return x > 20.f ? x : log1pf(expf(x));
+}
+// MLP activations: these run once per hidden unit per sample, so they use the hardware exp2/log2.
+__device__ __forceinline__ float softplus_fast(float x) {
+    const float e = __expf(-fabsf(x));
+    return fmaxf(x, 0.f) + __logf(1.f + e);
+}
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    return __frcp_rn(1.f + __expf(-x));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// inclusive scans over the 64 lanes
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(v, o); if (lane >= o) v *= t; }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(v, o); if (lane >= o) v += t; }
+    return v;
+}
+
+// Per-wave LDS carve-up (all float/int, 16-byte aligned pieces)
+struct Scratch {
+    float* t_e;      // [S_pad]  element depths: coarse k at k, fine i at 16*tiles_c + i
+    float* sig_e;    // [S_pad]  densities, same indexing
+    float* v_e;      // [S_pad]  final colour weight of each element (0 for padding)
+    int*   rank_e;   // [S_pad]
+    float* s_t;      // [S_pad]  depths in sorted order
+    float* s_sig;    // [S_pad]
+    float* w_s;      // [S_pad]  weights (coarse march, then final march)
+    float* cdf;      // [S_pad]
+    float* stage;    // [16 * kStagePitch]
+    float* colors;   // [(tiles_c + tiles_f) * 2 * 256]
+};
+
+__host__ __device__ inline size_t scratch_floats(int s_pad, int tiles) {
+    return size_t(8) * s_pad + 16 * kStagePitch + size_t(tiles) * 512;
+}
+
+// The per-lane weight fragments (see the layout notes above).
+struct Weights {
+    float a1[4][8];     // layer 1 A operand: W1[16m + (lane&15)][8*(lane>>4) + s]
+    float b1[4][4];     // layer 1 bias as accumulator init: b1[16m + 4*(lane>>4) + r]
+    float w2s[4][4];    // density row of layer 2: W2[0][16m + 4*(lane>>4) + r]
+    float b2w[2][16];   // layer 2 B operand: W2[1 + 16n + (lane&15)][16m + 4*(lane>>4) + r]  (index m*4+r)
+    float b2c[2];       // b2[1 + 16n + (lane&15)]
+    float b2s;          // b2[0]
+};
+
+__device__ __forceinline__ void load_weights(Weights& w, const gnerf_render_params& p, int lane) {
+    const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+#pragma unroll
+        for (int s = 0; s < 8; s++) w.a1[m][s] = p.w1[(16 * m + j) * 32 + 8 * g + s];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            w.b1[m][r] = p.b1[16 * m + 4 * g + r];
+            w.w2s[m][r] = p.w2[16 * m + 4 * g + r];
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) w.b2w[n][k] = p.w2[(1 + 16 * n + j) * kHidden + 16 * (k >> 2) + 4 * g + (k & 3)];
+        w.b2c[n] = p.b2[1 + 16 * n + j];
+    }
+    w.b2s = p.b2[0];
+}
+
+// Bilinear lookup of one plane for this lane's sample; adds (weight * 4 channels) into acc.
+// u indexes W, v indexes H (grid_sample, align_corners=False, zero padding; renderer.py:64).
+__device__ __forceinline__ void lookup_plane(v4f& acc, const float* __restrict__ plane, int H, int W, float u, float v, int cq) {
+    float ix = ((u + 1.f) * float(W) - 1.f) * 0.5f;
+    float iy = ((v + 1.f) * float(H) - 1.f) * 0.5f;
+    ix = fminf(fmaxf(ix, -1.5f), float(W) + 0.5f);     // keeps "everything out of range" out of range, and int conversion safe
+    iy = fminf(fmaxf(iy, -1.5f), float(H) + 0.5f);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float fx = ix - x0f, fy = iy - y0f;
+    const int x0 = int(x0f), y0 = int(y0f), x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    const float w00 = (vx0 && vy0) ? (1.f - fx) * (1.f - fy) : 0.f;
+    const float w01 = (vx1 && vy0) ? fx * (1.f - fy) : 0.f;
+    const float w10 = (vx0 && vy1) ? (1.f - fx) * fy : 0.f;
+    const float w11 = (vx1 && vy1) ? fx * fy : 0.f;
+    const v4f* base = reinterpret_cast<const v4f*>(plane) + cq;
+    const v4f t00 = base[(cy0 * W + cx0) * 8];
+    const v4f t01 = base[(cy0 * W + cx1) * 8];
+    const v4f t10 = base[(cy1 * W + cx0) * 8];
+    const v4f t11 = base[(cy1 * W + cx1) * 8];
+    acc += t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11;
+}
+
+// Shade `count` samples whose depths sit in lds.t_e[e0 ...]: densities -> lds.sig_e[e0 ...], colours ->
+// lds.colors tiles tile0 ...
+__device__ __forceinline__ void shade(const Params& P, const Weights& w, const Scratch& lds, const float* __restrict__ planes_item,
+                                      float ox, float oy, float oz, float dx, float dy, float dz,
+                                      int e0, int count, int ntiles, int tile0, int lane) {
+    const int H = P.p.plane_h, W = P.p.plane_w;
+    const int64_t plane_stride = int64_t(H) * W * 32;
+    const int b = lane >> 3, cq = lane & 7;     // lookup layout: sample-in-step, channel quad
+    const int j = lane & 15, g = lane >> 4;     // MFMA layout: sample-in-tile, k group
+    for (int t = 0; t < ntiles; t++) {
+        // ---- lookup: 2 steps x 8 samples, staged through LDS into the MFMA layout
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const int js = 8 * a + b;
+            const int idx = min(16 * t + js, count - 1);          // padding lanes re-shade the last sample
+            const float depth = lds.t_e[e0 + idx];
+            const float px = __fadd_rn(ox, __fmul_rn(depth, dx)) * P.box_scale;
+            const float py = __fadd_rn(oy, __fmul_rn(depth, dy)) * P.box_scale;
+            const float pz = __fadd_rn(oz, __fmul_rn(depth, dz)) * P.box_scale;
+            v4f acc = {0.f, 0.f, 0.f, 0.f};
+            lookup_plane(acc, planes_item, H, W, px, py, cq);                          // plane 0: (x, y)
+            lookup_plane(acc, planes_item + plane_stride, H, W, px, pz, cq);           // plane 1: (x, z)
+            lookup_plane(acc, planes_item + 2 * plane_stride, H, W, pz, px, cq);       // plane 2: (z, x)
+            acc *= (1.f / 3.f);                                                         // mean over planes, triplane.py:126
+            *reinterpret_cast<v4f*>(lds.stage + js * kStagePitch + 4 * cq) = acc;
+        }
+        __syncthreads();
+        const v4f f_lo = *reinterpret_cast<const v4f*>(lds.stage + j * kStagePitch + 8 * g);
+        const v4f f_hi = *reinterpret_cast<const v4f*>(lds.stage + j * kStagePitch + 8 * g + 4);
+        __syncthreads();
+        const float f[8] = {f_lo[0], f_lo[1], f_lo[2], f_lo[3], f_hi[0], f_hi[1], f_hi[2], f_hi[3]};
+        // ---- layer 1: H^T[64 x 16] = W1[64 x 32] . X^T[32 x 16], bias preloaded
+        v4f h[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) h[m] = (v4f){w.b1[m][0], w.b1[m][1], w.b1[m][2], w.b1[m][3]};
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) h[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.a1[m][s], f[s], h[m], 0, 0, 0);
+        }
+        float sig = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                h[m][r] = softplus_fast(h[m][r]);
+                sig += w.w2s[m][r] * h[m][r];
+            }
+        }
+        sig += __shfl_xor(sig, 16);
+        sig += __shfl_xor(sig, 32);
+        sig += w.b2s;
+        if (g == 0 && 16 * t + j < count) lds.sig_e[e0 + 16 * t + j] = sig;
+        // ---- layer 2: O[16 x 32] = H[16 x 64] . W2^T[64 x 32]
+        v4f o[2];
+#pragma unroll
+        for (int n = 0; n < 2; n++) o[n] = (v4f){w.b2c[n], w.b2c[n], w.b2c[n], w.b2c[n]};
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+#pragma unroll
+                for (int n = 0; n < 2; n++) o[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[m][r], w.b2w[n][m * 4 + r], o[n], 0, 0, 0);
+            }
+        }
+        // rgb = sigmoid(o) * 1.002 - 0.001 (triplane.py:134); lane (channel j of block n, samples 4g..4g+3)
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            v4f c;
+#pragma unroll
+            for (int r = 0; r < 4; r++) c[r] = sigmoid_fast(o[n][r]) * 1.002f - 0.001f;
+            *reinterpret_cast<v4f*>(lds.colors + ((size_t(tile0 + t) * 2 + n) * 4 + g) * 64 + 4 * j) = c;
+        }
+    }
+    __syncthreads();
+}
+
+// Ray-march weights over n sorted samples (depth/density in LDS): writes w[0..n-2], returns sum(w) and
+// sum(w * t_mid) in all lanes.  ray_marcher.py:26-42.
+__device__ __forceinline__ void march(const float* t, const float* sig, float* w, int n, int lane, float& w_sum, float& wt_sum) {
+    float carry = 1.f, acc_w = 0.f, acc_wt = 0.f;
+    for (int base = 0; base < n - 1; base += 64) {
+        const int k = base + lane;
+        const bool ok = k < n - 1;
+        float alpha = 0.f, tmid = 0.f;
+        if (ok) {
+            const float t0 = t[k], t1 = t[k + 1];
+            const float delta = t1 - t0;
+            const float smid = softplus_f((sig[k] + sig[k + 1]) * 0.5f - 1.f);
+            tmid = (t0 + t1) * 0.5f;
+            alpha = 1.f - expf(-(smid * delta));
+        }
+        const float x = ok ? (1.f - alpha + 1e-10f) : 1.f;
+        const float incl = wave_scan_mul(x, lane);
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.f;
+        const float wk = alpha * (excl * carry);
+        carry *= __shfl(incl, 63);
+        if (ok) { w[k] = wk; acc_w += wk; acc_wt += wk * tmid; }
+    }
+    w_sum = wave_sum(acc_w);
+    wt_sum = wave_sum(acc_wt);
+}
+
+__global__ __launch_bounds__(64, 2) void render_kernel(Params P) {
+    extern __shared__ __align__(16) float smem[];
+    const gnerf_render_params& p = P.p;
+    const int lane = threadIdx.x;
+    const int S = p.depth_resolution, F = p.depth_resolution_importance;
+    const int s_pad = 16 * (P.tiles_c + P.tiles_f);
+    Scratch lds;
+    lds.t_e = smem;
+    lds.sig_e = lds.t_e + s_pad;
+    lds.v_e = lds.sig_e + s_pad;
+    lds.rank_e = reinterpret_cast<int*>(lds.v_e + s_pad);
+    lds.s_t = lds.v_e + 2 * s_pad;
+    lds.s_sig = lds.s_t + s_pad;
+    lds.w_s = lds.s_sig + s_pad;
+    lds.cdf = lds.w_s + s_pad;
+    lds.stage = lds.cdf + s_pad;
+    lds.colors = lds.stage + 16 * kStagePitch;
+
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+    // contiguous run of ray tiles (its L2 then sees neighbouring rays).  Speed only.
+    const int per_xcd = (P.n_tiles + kNumXCD - 1) / kNumXCD;
+    const int tile = (blockIdx.x % kNumXCD) * per_xcd + blockIdx.x / kNumXCD;
+    if (tile >= P.n_tiles) return;
+
+    Weights w;
+    load_weights(w, p, lane);
+    const int fine_e0 = 16 * P.tiles_c;
+    const int n_all = S + F;
+    float blk_min = INFINITY, blk_max = -INFINITY;
+
+    for (int rr = 0; rr < kRaysPerWave; rr++) {
+        // ---- which ray
+        int64_t ray;
+        if (P.tiles_per_item > 0) {             // 4x4 pixel tiles, walked down image columns
+            const int item = tile / P.tiles_per_item, tt = tile % P.tiles_per_item;
+            const int tx = tt / P.tiles_y, ty = tt % P.tiles_y;
+            const int x = tx * 4 + (rr & 3), y = ty * 4 + (rr >> 2);
+            ray = int64_t(item) * p.rays_per_item + int64_t(y) * p.image_width + x;
+        } else {
+            ray = int64_t(tile) * kRaysPerWave + rr;
+            if (ray >= P.total_rays) break;
+        }
+        const int item = int(ray / p.rays_per_item);
+        const float ox = p.ray_origins[ray * 3 + 0], oy = p.ray_origins[ray * 3 + 1], oz = p.ray_origins[ray * 3 + 2];
+        const float dx = p.ray_dirs[ray * 3 + 0], dy = p.ray_dirs[ray * 3 + 1], dz = p.ray_dirs[ray * 3 + 2];
+        const float* planes_item = p.planes_nhwc + int64_t(item) * 3 * p.plane_h * p.plane_w * 32;
+        float* dbg = p.debug ? p.debug + ray * GNERF_DEBUG_SLOTS * n_all : nullptr;
+
+        // ---- stratified depth proposals (renderer.py:169-192)
+        for (int k = lane; k < S; k += 64) {
+            const float u = p.noise_coarse[ray * S + k];
+            float d;
+            if (p.disparity_space_sampling) {
+                const float step = 1.0f / float(S - 1);
+                const float lin = (k < S / 2) ? __fmul_rn(step, float(k)) : __fsub_rn(1.0f, __fmul_rn(step, float(S - 1 - k)));
+                const float q = __fadd_rn(lin, __fmul_rn(u, P.disp_delta));
+                d = __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(P.inv_start, __fsub_rn(1.0f, q)), __fmul_rn(P.inv_end, q)));
+            } else if (p.ray_start_per_ray) {
+                const float rs = p.ray_start_per_ray[ray], re = p.ray_end_per_ray[ray];
+                const float span = __fsub_rn(re, rs);
+                const float lin = __fadd_rn(rs, __fmul_rn(__fdiv_rn(float(k), float(S - 1)), span));      // math_utils.py:107-116
+                d = __fadd_rn(lin, __fmul_rn(u, __fdiv_rn(span, float(S - 1))));
+            } else {
+                const float step = __fdiv_rn(__fsub_rn(p.ray_end, p.ray_start), float(S - 1));            // torch.linspace
+                const float lin = (k < S / 2) ? __fadd_rn(p.ray_start, __fmul_rn(step, float(k)))
+                                              : __fsub_rn(p.ray_end, __fmul_rn(step, float(S - 1 - k)));
+                d = __fadd_rn(lin, __fmul_rn(u, P.delta));
+            }
+            lds.t_e[k] = d;
+            if (dbg) dbg[GNERF_DBG_DEPTH_COARSE * n_all + k] = d;
+        }
+        for (int k = lane; k < s_pad; k += 64) lds.v_e[k] = 0.f;
+        __syncthreads();
+
+        // ---- coarse pass
+        shade(P, w, lds, planes_item, ox, oy, oz, dx, dy, dz, 0, S, P.tiles_c, 0, lane);
+        if (dbg) for (int k = lane; k < S; k += 64) dbg[GNERF_DBG_SIGMA_COARSE * n_all + k] = lds.sig_e[k];
+
+        float w_sum, wt_sum;
+        if (F > 0) {
+            march(lds.t_e, lds.sig_e, lds.w_s, S, lane, w_sum, wt_sum);
+            __syncthreads();
+            if (dbg) for (int k = lane; k < S - 1; k += 64) dbg[GNERF_DBG_WEIGHT_COARSE * n_all + k] = lds.w_s[k];
+
+            // ---- importance resampling (renderer.py:194-253).  n_w = S-3 pdf entries, cdf has n_w+1.
+            const int n_w = S - 3;
+            float part = 0.f;
+            for (int i = lane; i < n_w; i += 64) {
+                // smoothed weight a_{i+1} = (max(w_i, w_{i+1}) + max(w_{i+1}, w_{i+2})) / 2 + 0.01, then + 1e-5
+                const float w0 = lds.w_s[i], w1 = lds.w_s[i + 1], w2 = lds.w_s[i + 2];
+                const float a = (fmaxf(w0, w1) + fmaxf(w1, w2)) * 0.5f + 0.01f;
+                const float pw = a + 1e-5f;
+                lds.s_sig[i] = pw;              // s_sig is free until the merge
+                part += pw;
+            }
+            const float total = wave_sum(part);
+            __syncthreads();
+            float carry = 0.f;
+            for (int base = 0; base < n_w; base += 64) {
+                const int i = base + lane;
+                const float pdf = (i < n_w) ? lds.s_sig[i] / total : 0.f;
+                const float incl = wave_scan_add(pdf, lane) + carry;
+                if (i < n_w) lds.cdf[i + 1] = incl;
+                carry = __shfl(incl, 63);
+            }
+            if (lane == 0) lds.cdf[0] = 0.f;
+            __syncthreads();
+            for (int i = lane; i < F; i += 64) {
+                const float u = p.noise_fine[ray * F + i];
+                // searchsorted(cdf[0..n_w], u, right=True): number of entries <= u
+                int lo = 0, hi = n_w + 1;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (lds.cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+                const int below = max(lo - 1, 0), above = min(lo, n_w);
+                const float cb = lds.cdf[below], ca = lds.cdf[above];
+                const float bb = (lds.t_e[below] + lds.t_e[below + 1]) * 0.5f;
+                const float ba = (lds.t_e[above] + lds.t_e[above + 1]) * 0.5f;
+                float denom = ca - cb;
+                if (denom < 1e-5f) denom = 1.f;
+                const float d = bb + (u - cb) / denom * (ba - bb);
+                lds.t_e[fine_e0 + i] = d;
+                if (dbg) dbg[GNERF_DBG_DEPTH_FINE * n_all + i] = d;
+            }
+            __syncthreads();
+
+            // ---- fine pass
+            shade(P, w, lds, planes_item, ox, oy, oz, dx, dy, dz, fine_e0, F, P.tiles_f, P.tiles_c, lane);
+            if (dbg) for (int k = lane; k < F; k += 64) dbg[GNERF_DBG_SIGMA_FINE * n_all + k] = lds.sig_e[fine_e0 + k];
+
+            // ---- merge by depth (renderer.py:157-167): rank = number of elements ordered before this one,
+            // ties broken by position in cat([coarse, fine]) like a stable sort.
+            for (int q = lane; q < n_all; q += 64) {
+                const int e = q < S ? q : fine_e0 + (q - S);
+                const float key = lds.t_e[e];
+                int rank = 0;
+                for (int o = 0; o < S; o++) { const float tk = lds.t_e[o]; rank += (tk < key || (tk == key && o < q)) ? 1 : 0; }
+                for (int o = 0; o < F; o++) { const float tk = lds.t_e[fine_e0 + o]; rank += (tk < key || (tk == key && S + o < q)) ? 1 : 0; }
+                lds.rank_e[e] = rank;
+                lds.s_t[rank] = key;
+                lds.s_sig[rank] = lds.sig_e[e];
+            }
+            __syncthreads();
+            march(lds.s_t, lds.s_sig, lds.w_s, n_all, lane, w_sum, wt_sum);
+            __syncthreads();
+            // colour weight of the sample at sorted position r: (w[r-1] + w[r]) / 2  (midpoint colours, ray_marcher.py:27)
+            for (int q = lane; q < n_all; q += 64) {
+                const int e = q < S ? q : fine_e0 + (q - S);
+                const int r = lds.rank_e[e];
+                const float wl = r > 0 ? lds.w_s[r - 1] : 0.f, wr = r < n_all - 1 ? lds.w_s[r] : 0.f;
+                lds.v_e[e] = (wl + wr) * 0.5f;
+            }
+            if (dbg) {
+                for (int k = lane; k < n_all; k += 64) { dbg[GNERF_DBG_DEPTH_SORTED * n_all + k] = lds.s_t[k]; dbg[GNERF_DBG_SIGMA_SORTED * n_all + k] = lds.s_sig[k]; }
+                for (int k = lane; k < n_all - 1; k += 64) dbg[GNERF_DBG_WEIGHT_FINAL * n_all + k] = lds.w_s[k];
+            }
+            blk_min = fminf(blk_min, lds.s_t[0]);
+            blk_max = fmaxf(blk_max, lds.s_t[n_all - 1]);
+        } else {
+            march(lds.t_e, lds.sig_e, lds.w_s, S, lane, w_sum, wt_sum);
+            __syncthreads();
+            for (int k = lane; k < S; k += 64) {
+                const float wl = k > 0 ? lds.w_s[k - 1] : 0.f, wr = k < S - 1 ? lds.w_s[k] : 0.f;
+                lds.v_e[k] = (wl + wr) * 0.5f;
+            }
+            if (dbg) for (int k = lane; k < S - 1; k += 64) dbg[GNERF_DBG_WEIGHT_FINAL * n_all + k] = lds.w_s[k];
+            // the reference takes min/max over the depths tensor; coarse depths ascend (up to rounding ties)
+            float mn = INFINITY, mx = -INFINITY;
+            for (int k = lane; k < S; k += 64) { mn = fminf(mn, lds.t_e[k]); mx = fmaxf(mx, lds.t_e[k]); }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+            blk_min = fminf(blk_min, mn);
+            blk_max = fmaxf(blk_max, mx);
+        }
+        __syncthreads();
+
+        // ---- colours: rgb[c] = sum_e v_e * colour_e[c]; lane = (channel j of block n, samples 4g..4g+3 of each tile)
+        const int j = lane & 15, g = lane >> 4;
+        float acc[2] = {0.f, 0.f};
+        const int ntile_all = P.tiles_c + P.tiles_f;
+        for (int t = 0; t < ntile_all; t++) {
+            const v4f v = *reinterpret_cast<const v4f*>(lds.v_e + 16 * t + 4 * g);
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                const v4f c = *reinterpret_cast<const v4f*>(lds.colors + ((size_t(t) * 2 + n) * 4 + g) * 64 + 4 * j);
+                acc[n] += v[0] * c[0] + v[1] * c[1] + v[2] * c[2] + v[3] * c[3];
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            acc[n] += __shfl_xor(acc[n], 16);
+            acc[n] += __shfl_xor(acc[n], 32);
+            if (p.white_back) acc[n] = acc[n] + 1.f - w_sum;
+            acc[n] = acc[n] * 2.f - 1.f;
+        }
+        if (g < 2) p.out_rgb[ray * 32 + 16 * g + j] = g == 0 ? acc[0] : acc[1];
+        if (lane == 0) {
+            float depth = wt_sum / w_sum;
+            if (depth != depth) depth = INFINITY;        // nan_to_num(nan=inf), ray_marcher.py:49; clamp applied by clamp_depth_kernel
+            p.out_depth[ray] = depth;
+            p.out_wsum[ray] = w_sum;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        unsigned* range = static_cast<unsigned*>(p.workspace);
+        atomicMin(range + 0, ord_encode(blk_min));
+        atomicMax(range + 1, ord_encode(blk_max));
+    }
+}
+
+__global__ void init_range_kernel(unsigned* range) {
+    range[0] = 0xffffffffu;
+    range[1] = 0u;
+}
+
+__global__ __launch_bounds__(256) void clamp_depth_kernel(float* depth, const unsigned* range, int64_t n) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float lo = ord_decode(range[0]), hi = ord_decode(range[1]);
+    depth[i] = fminf(fmaxf(depth[i], lo), hi);       // torch.clamp(x, min, max)
+}
+
+// ---------------------------------------------------------------------------------------------
+// run_model for arbitrary points (renderer.py:142-148): same lookup + MLP, 16 points per step.
+
+__global__ __launch_bounds__(64) void query_kernel(gnerf_render_params p, float box_scale, int n_points, int n_tiles,
+                                                   const float* __restrict__ points, float* __restrict__ out_sigma, float* __restrict__ out_rgb) {
+    __shared__ __align__(16) float stage[16 * kStagePitch];
+    const int lane = threadIdx.x;
+    const int H = p.plane_h, W = p.plane_w;
+    const int64_t plane_stride = int64_t(H) * W * 32;
+    const int b = lane >> 3, cq = lane & 7, j = lane & 15, g = lane >> 4;
+    Weights w;
+    load_weights(w, p, lane);
+    const int tiles_per_item = (n_points + 15) / 16;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int item = tile / tiles_per_item, t = tile % tiles_per_item;
+        const float* planes_item = p.planes_nhwc + int64_t(item) * 3 * plane_stride;
+        const float* pts = points + int64_t(item) * n_points * 3;
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const int js = 8 * a + b;
+            const int idx = min(16 * t + js, n_points - 1);
+            const float px = pts[idx * 3 + 0] * box_scale, py = pts[idx * 3 + 1] * box_scale, pz = pts[idx * 3 + 2] * box_scale;
+            v4f acc = {0.f, 0.f, 0.f, 0.f};
+            lookup_plane(acc, planes_item, H, W, px, py, cq);
+            lookup_plane(acc, planes_item + plane_stride, H, W, px, pz, cq);
+            lookup_plane(acc, planes_item + 2 * plane_stride, H, W, pz, px, cq);
+            acc *= (1.f / 3.f);
+            *reinterpret_cast<v4f*>(stage + js * kStagePitch + 4 * cq) = acc;
+        }
+        __syncthreads();
+        const v4f f_lo = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g);
+        const v4f f_hi = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g + 4);
+        __syncthreads();
+        const float f[8] = {f_lo[0], f_lo[1], f_lo[2], f_lo[3], f_hi[0], f_hi[1], f_hi[2], f_hi[3]};
+        v4f h[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) h[m] = (v4f){w.b1[m][0], w.b1[m][1], w.b1[m][2], w.b1[m][3]};
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) h[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.a1[m][s], f[s], h[m], 0, 0, 0);
+        }
+        float sig = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) { h[m][r] = softplus_fast(h[m][r]); sig += w.w2s[m][r] * h[m][r]; }
+        }
+        sig += __shfl_xor(sig, 16);
+        sig += __shfl_xor(sig, 32);
+        sig += w.b2s;
+        const int pt = 16 * t + j;
+        if (g == 0 && pt < n_points) out_sigma[int64_t(item) * n_points + pt] = sig;
+        v4f o[2];
+#pragma unroll
+        for (int n = 0; n < 2; n++) o[n] = (v4f){w.b2c[n], w.b2c[n], w.b2c[n], w.b2c[n]};
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+#pragma unroll
+                for (int n = 0; n < 2; n++) o[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[m][r], w.b2w[n][m * 4 + r], o[n], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int q = 16 * t + 4 * g + r;
+                if (q < n_points) out_rgb[(int64_t(item) * n_points + q) * 32 + 16 * n + j] = sigmoid_fast(o[n][r]) * 1.002f - 0.001f;
+            }
+        }
+    }
+}
+
+int check_common(const gnerf_render_params* p) {
+    if (!p) return fail(GNERF_E_ARG, "render: params is null");
+    if (!p->planes_nhwc || !p->w1 || !p->b1 || !p->w2 || !p->b2) return fail(GNERF_E_ARG, "render: planes and decoder weights must not be null");
+    if (p->n_items < 1 || p->plane_h < 1 || p->plane_w < 1) return fail(GNERF_E_ARG, "render: bad plane shape");
+    if (int64_t(p->n_items) * 3 * p->plane_h * p->plane_w * 32 > INT32_MAX * int64_t(4))
+        return fail(GNERF_E_ARG, "render: planes too large");
+    if (!(p->box_warp > 0.f)) return fail(GNERF_E_ARG, "render: box_warp must be positive");
+    return GNERF_OK;
+}
+
+}  // namespace
+
+extern "C" size_t gnerf_render_workspace_bytes(void) { return 64; }
+
+extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (int e = check_common(p)) return e;
+    if (!p->ray_origins || !p->ray_dirs || !p->noise_coarse || !p->out_rgb || !p->out_depth || !p->out_wsum || !p->workspace)
+        return fail(GNERF_E_ARG, "render: rays, noise_coarse, outputs and workspace must not be null");
+    const int S = p->depth_resolution, F = p->depth_resolution_importance;
+    if (S < 2 || S > GNERF_MAX_SAMPLES) return fail(GNERF_E_ARG, "render: depth_resolution %d outside [2, %d]", S, GNERF_MAX_SAMPLES);
+    if (F < 0 || F > GNERF_MAX_SAMPLES) return fail(GNERF_E_ARG, "render: depth_resolution_importance %d outside [0, %d]", F, GNERF_MAX_SAMPLES);
+    if (F > 0 && S < 4) return fail(GNERF_E_ARG, "render: importance sampling needs depth_resolution >= 4");
+    if (F > 0 && !p->noise_fine) return fail(GNERF_E_ARG, "render: noise_fine is null but depth_resolution_importance > 0");
+    if (p->rays_per_item < 1) return fail(GNERF_E_ARG, "render: rays_per_item must be positive");
+    if ((p->ray_start_per_ray == nullptr) != (p->ray_end_per_ray == nullptr)) return fail(GNERF_E_ARG, "render: per-ray start and end must be given together");
+    const int64_t total = int64_t(p->n_items) * p->rays_per_item;
+    if (total * (S + F) > INT32_MAX * int64_t(8)) return fail(GNERF_E_ARG, "render: too many samples in one call");
+
+    Params P;
+    P.p = *p;
+    P.box_scale = float(2.0 / double(p->box_warp));
+    P.delta = float((double(p->ray_end) - double(p->ray_start)) / double(S - 1));
+    P.inv_start = float(1.0 / double(p->ray_start));
+    P.inv_end = float(1.0 / double(p->ray_end));
+    P.disp_delta = float(1.0 / double(S - 1));
+    P.tiles_c = (S + 15) / 16;
+    P.tiles_f = (F + 15) / 16;
+    P.total_rays = int(total);
+    const int iw = p->image_width;
+    if (iw > 0 && iw % 4 == 0 && p->rays_per_item % iw == 0 && (p->rays_per_item / iw) % 4 == 0) {
+        P.tiles_y = p->rays_per_item / iw / 4;
+        P.tiles_per_item = (iw / 4) * P.tiles_y;
+        P.n_tiles = P.tiles_per_item * p->n_items;
+    } else {
+        P.tiles_y = 0;
+        P.tiles_per_item = 0;
+        P.n_tiles = int((total + kRaysPerWave - 1) / kRaysPerWave);
+    }
+    const size_t lds_bytes = scratch_floats(16 * (P.tiles_c + P.tiles_f), P.tiles_c + P.tiles_f) * sizeof(float);
+    if (lds_bytes > 160 * 1024) return fail(GNERF_E_ARG, "render: %d+%d samples need %zu bytes of LDS (> 160 KiB)", S, F, lds_bytes);
+    hipStream_t s = as_stream(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return fail(GNERF_E_LAUNCH, "render: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(init_range_kernel, dim3(1), dim3(1), 0, s, static_cast<unsigned*>(p->workspace));
+    const int per_xcd = (P.n_tiles + kNumXCD - 1) / kNumXCD;
+    hipLaunchKernelGGL(render_kernel, dim3(per_xcd * kNumXCD), dim3(64), lds_bytes, s, P);
+    if (int e = check_launch("render_kernel")) return e;
+    hipLaunchKernelGGL(clamp_depth_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       p->out_depth, static_cast<const unsigned*>(p->workspace), total);
+    return check_launch("clamp_depth_kernel");
+}
+
+extern "C" int gnerf_query_points(const float* planes_nhwc, int n_items, int plane_h, int plane_w,
+                                  const float* points, int n_points, float box_warp,
+                                  const float* w1, const float* b1, const float* w2, const float* b2,
+                                  float* out_sigma, float* out_rgb, gnerf_stream_t stream) {
+    using namespace gnerf;
+    gnerf_render_params p = {};
+    p.planes_nhwc = planes_nhwc; p.n_items = n_items; p.plane_h = plane_h; p.plane_w = plane_w;
+    p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.box_warp = box_warp;
+    if (int e = check_common(&p)) return e;
+    if (!points || !out_sigma || !out_rgb) return fail(GNERF_E_ARG, "query_points: null pointer");
+    if (n_points < 1) return fail(GNERF_E_ARG, "query_points: n_points must be positive");
+    const int64_t tiles = int64_t(n_items) * ((n_points + 15) / 16);
+    if (tiles > INT32_MAX) return fail(GNERF_E_ARG, "query_points: too many points");
+    const int blocks = int(tiles < int64_t(kNumCU) * 16 ? tiles : int64_t(kNumCU) * 16);
+    hipLaunchKernelGGL(query_kernel, dim3(blocks), dim3(64), 0, as_stream(stream), p, float(2.0 / double(box_warp)), n_points, int(tiles),
+                       points, out_sigma, out_rgb);
+    return check_launch("query_kernel");
+}

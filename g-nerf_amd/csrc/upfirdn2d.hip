@@ -1,0 +1,193 @@
+// upfirdn2d for gfx950: zero-insert upsample -> pad/crop -> 2-D FIR -> decimate.
+//
+// Replaces upfirdn2d_plugin.upfirdn2d (reference torch_utils/ops/upfirdn2d.cpp:20, upfirdn2d.cu:33-379);
+// semantics follow torch_utils/ops/upfirdn2d.py:168-213:
+//     y[oy,ox] = gain * sum_{ky,kx} k[ky,kx] * z[oy*downy + ky, ox*downx + kx]
+// where z is x zero-upsampled by (upx,upy) and padded by (padx0,pady0) on the low side (negative =
+// crop), and k is f flipped in both axes unless `flip` (flip=0 is a true convolution).
+//
+// Two kernels:
+//   * upfirdn_tile_kernel  -- NCHW-contiguous images and filters up to 8x8 (G-NeRF only ever uses the
+//     4x4 [1,3,3,1] filter): a workgroup owns a TILE_W x TILE_H output tile of one (n,c) image, stages
+//     the input window it needs in LDS with coalesced row reads ("line buffer"), keeps the filter in
+//     LDS too, and each lane produces OUT_PER_LANE horizontally adjacent outputs so that LDS reads are
+//     shared between them.  HBM traffic is the algorithmic in+out plus the halo.
+//   * upfirdn_any_kernel   -- any strides (channels_last), any filter size, straight from global memory
+//     (L1/L2 absorb the tap re-reads).
+
+#include "common.h"
+
+namespace {
+
+using namespace gnerf;
+
+struct UpArgs {
+    const void* x; const float* f; void* y;
+    int n, c, in_h, in_w;
+    int64_t xs_n, xs_c, xs_h, xs_w;
+    int fh, fw; int64_t fs_h, fs_w;
+    int out_h, out_w;
+    int64_t ys_n, ys_c, ys_h, ys_w;
+    int upx, upy, downx, downy, padx0, pady0, flip;
+    float gain;
+};
+
+__device__ __forceinline__ int floor_div_pos(int a, int b) {   // floor(a / b) for b > 0, any a
+    int q = a / b;
+    return (a % b < 0) ? q - 1 : q;
+}
+__device__ __forceinline__ int ceil_div_pos(int a, int b) { return -floor_div_pos(-a, b); }
+
+// ---------------------------------------------------------------------------------------------
+// Generic kernel: one output element per lane, lanes ordered like y's memory.
+
+template <class T>
+__global__ __launch_bounds__(256) void upfirdn_any_kernel(UpArgs a, int channels_last) {
+    typedef typename Arith<T>::type A;
+    const T* x = static_cast<const T*>(a.x);
+    T* y = static_cast<T*>(a.y);
+    const int64_t total = int64_t(a.n) * a.c * a.out_h * a.out_w;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int ox, oy, ch, img;
+        int64_t r = i;
+        if (channels_last) { ch = int(r % a.c); r /= a.c; ox = int(r % a.out_w); r /= a.out_w; oy = int(r % a.out_h); img = int(r / a.out_h); }
+        else               { ox = int(r % a.out_w); r /= a.out_w; oy = int(r % a.out_h); r /= a.out_h; ch = int(r % a.c); img = int(r / a.c); }
+        // taps ky with (oy*downy + ky - pady0) = iy*upy, 0 <= iy < in_h
+        const int by = oy * a.downy - a.pady0, bx = ox * a.downx - a.padx0;
+        int iy_lo = ceil_div_pos(by, a.upy);            if (iy_lo < 0) iy_lo = 0;
+        int iy_hi = floor_div_pos(by + a.fh - 1, a.upy); if (iy_hi > a.in_h - 1) iy_hi = a.in_h - 1;
+        int ix_lo = ceil_div_pos(bx, a.upx);            if (ix_lo < 0) ix_lo = 0;
+        int ix_hi = floor_div_pos(bx + a.fw - 1, a.upx); if (ix_hi > a.in_w - 1) ix_hi = a.in_w - 1;
+        const T* xp = x + img * a.xs_n + ch * a.xs_c;
+        A acc = A(0);
+        for (int iy = iy_lo; iy <= iy_hi; iy++) {
+            const int ky = iy * a.upy - by;
+            const int fy = a.flip ? ky : a.fh - 1 - ky;
+            for (int ix = ix_lo; ix <= ix_hi; ix++) {
+                const int kx = ix * a.upx - bx;
+                const int fx = a.flip ? kx : a.fw - 1 - kx;
+                acc += load_as<T>(xp, iy * a.xs_h + ix * a.xs_w) * A(a.f[fy * a.fs_h + fx * a.fs_w]);
+            }
+        }
+        store_as<T>(y, img * a.ys_n + ch * a.ys_c + oy * a.ys_h + ox * a.ys_w, acc * A(a.gain));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tiled kernel for contiguous NCHW.
+
+constexpr int TILE_W = 64, TILE_H = 16, OUT_PER_LANE = 4;    // 256 lanes: 16 column groups x 16 rows
+constexpr int MAX_TAPS = 8;
+// worst-case input window: ceil((TILE-1)*down + taps) / up) + 1, bounded here for down <= 2, up >= 1
+constexpr int WIN_W = (TILE_W - 1) * 2 + MAX_TAPS + 1, WIN_H = (TILE_H - 1) * 2 + MAX_TAPS + 1;
+
+template <class T>
+__global__ __launch_bounds__(256) void upfirdn_tile_kernel(UpArgs a, int tiles_x, int tiles_y) {
+    typedef typename Arith<T>::type A;
+    __shared__ float s_f[MAX_TAPS * MAX_TAPS];
+    __shared__ float s_x[WIN_H * (WIN_W + 1)];
+    const T* x = static_cast<const T*>(a.x);
+    T* y = static_cast<T*>(a.y);
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    const int64_t img = t;                                     // n*c + ch
+    const int ox0 = tx * TILE_W, oy0 = ty * TILE_H;
+    const int tw = min(TILE_W, a.out_w - ox0), th = min(TILE_H, a.out_h - oy0);
+    // input window needed by this output tile
+    const int by0 = oy0 * a.downy - a.pady0, bx0 = ox0 * a.downx - a.padx0;
+    int iy_lo = max(ceil_div_pos(by0, a.upy), 0);
+    int iy_hi = min(floor_div_pos(by0 + (th - 1) * a.downy + a.fh - 1, a.upy), a.in_h - 1);
+    int ix_lo = max(ceil_div_pos(bx0, a.upx), 0);
+    int ix_hi = min(floor_div_pos(bx0 + (tw - 1) * a.downx + a.fw - 1, a.upx), a.in_w - 1);
+    const int ww = ix_hi - ix_lo + 1, wh = iy_hi - iy_lo + 1;  // may be <= 0 (tile entirely in the padding)
+    const int pitch = WIN_W + 1;
+    // stage filter (already flipped as needed, gain folded in) and the window
+    for (int i = threadIdx.x; i < a.fh * a.fw; i += 256) {
+        const int ky = i / a.fw, kx = i % a.fw;
+        const int fy = a.flip ? ky : a.fh - 1 - ky, fx = a.flip ? kx : a.fw - 1 - kx;
+        s_f[ky * MAX_TAPS + kx] = a.f[fy * a.fs_h + fx * a.fs_w] * a.gain;
+    }
+    const T* xp = x + img * int64_t(a.in_h) * a.in_w;
+    if (ww > 0 && wh > 0) {
+        for (int i = threadIdx.x; i < wh * ww; i += 256) {
+            const int r = i / ww, cidx = i % ww;
+            s_x[r * pitch + cidx] = float(load_as<T>(xp, int64_t(iy_lo + r) * a.in_w + ix_lo + cidx));
+        }
+    }
+    __syncthreads();
+    const int lx = (threadIdx.x & 15) * OUT_PER_LANE, ly = threadIdx.x >> 4;
+    if (ly >= th) return;
+    const int oy = oy0 + ly;
+    const int by = oy * a.downy - a.pady0;
+    const int iy_a = max(ceil_div_pos(by, a.upy), 0), iy_b = min(floor_div_pos(by + a.fh - 1, a.upy), a.in_h - 1);
+    A acc[OUT_PER_LANE];
+#pragma unroll
+    for (int q = 0; q < OUT_PER_LANE; q++) acc[q] = A(0);
+    for (int iy = iy_a; iy <= iy_b; iy++) {
+        const int ky = iy * a.upy - by;
+        const float* frow = s_f + ky * MAX_TAPS;
+        const float* xrow = s_x + (iy - iy_lo) * pitch - ix_lo;
+#pragma unroll
+        for (int q = 0; q < OUT_PER_LANE; q++) {
+            const int ox = ox0 + lx + q;
+            const int bx = ox * a.downx - a.padx0;
+            const int ix_a = max(ceil_div_pos(bx, a.upx), 0), ix_b = min(floor_div_pos(bx + a.fw - 1, a.upx), a.in_w - 1);
+            for (int ix = ix_a; ix <= ix_b; ix++) acc[q] += A(xrow[ix]) * A(frow[ix * a.upx - bx]);
+        }
+    }
+    T* yp = y + img * int64_t(a.out_h) * a.out_w + int64_t(oy) * a.out_w + ox0 + lx;
+#pragma unroll
+    for (int q = 0; q < OUT_PER_LANE; q++)
+        if (lx + q < tw) store_as<T>(yp, q, acc[q]);
+}
+
+template <class T>
+int launch_up(const UpArgs& a, hipStream_t stream) {
+    const bool nchw = a.xs_w == 1 && a.xs_h == a.in_w && a.xs_c == int64_t(a.in_h) * a.in_w && a.xs_n == a.xs_c * a.c &&
+                      a.ys_w == 1 && a.ys_h == a.out_w && a.ys_c == int64_t(a.out_h) * a.out_w && a.ys_n == a.ys_c * a.c;
+    const bool small = a.fh <= MAX_TAPS && a.fw <= MAX_TAPS && a.downx <= 2 && a.downy <= 2;
+    if (nchw && small && sizeof(typename Arith<T>::type) == 4) {      // LDS window is float: keep double on the direct kernel
+        const int tiles_x = (a.out_w + TILE_W - 1) / TILE_W, tiles_y = (a.out_h + TILE_H - 1) / TILE_H;
+        const int64_t blocks = int64_t(tiles_x) * tiles_y * a.n * a.c;
+        if (blocks <= INT32_MAX) {
+            hipLaunchKernelGGL((upfirdn_tile_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream, a, tiles_x, tiles_y);
+            return check_launch("upfirdn2d(tile)");
+        }
+    }
+    const int64_t total = int64_t(a.n) * a.c * a.out_h * a.out_w;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > int64_t(kNumCU) * 16) blocks = int64_t(kNumCU) * 16;
+    const int channels_last = (a.ys_c == 1 && a.c > 1) ? 1 : 0;
+    hipLaunchKernelGGL((upfirdn_any_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream, a, channels_last);
+    return check_launch("upfirdn2d(any)");
+}
+
+}  // namespace
+
+extern "C" int gnerf_upfirdn2d(const void* x, const float* f, void* y, int dtype,
+                               int n, int c, int in_h, int in_w, const int64_t xs[4],
+                               int fh, int fw, const int64_t fs[2],
+                               int out_h, int out_w, const int64_t ys[4],
+                               int upx, int upy, int downx, int downy, int padx0, int pady0,
+                               int flip, float gain, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!x || !f || !y || !xs || !fs || !ys) return fail(GNERF_E_ARG, "upfirdn2d: null pointer argument");
+    if (n < 1 || c < 1 || in_h < 1 || in_w < 1) return fail(GNERF_E_ARG, "upfirdn2d: x has zero size");
+    if (fh < 1 || fw < 1) return fail(GNERF_E_ARG, "upfirdn2d: f must be at least 1x1");
+    if (upx < 1 || upy < 1) return fail(GNERF_E_ARG, "upfirdn2d: upsampling factor must be at least 1");
+    if (downx < 1 || downy < 1) return fail(GNERF_E_ARG, "upfirdn2d: downsampling factor must be at least 1");
+    if (out_h < 1 || out_w < 1) return fail(GNERF_E_ARG, "upfirdn2d: output must be at least 1x1");
+    if (int64_t(n) * c * out_h * out_w > INT32_MAX || int64_t(n) * c * in_h * in_w > INT32_MAX)
+        return fail(GNERF_E_ARG, "upfirdn2d: tensor is too large");
+    UpArgs a{x, f, y, n, c, in_h, in_w, xs[0], xs[1], xs[2], xs[3], fh, fw, fs[0], fs[1], out_h, out_w,
+             ys[0], ys[1], ys[2], ys[3], upx, upy, downx, downy, padx0, pady0, flip ? 1 : 0, gain};
+    hipStream_t s = as_stream(stream);
+    switch (dtype) {
+        case GNERF_F32: return launch_up<float>(a, s);
+        case GNERF_F16: return launch_up<__half>(a, s);
+        case GNERF_F64: return launch_up<double>(a, s);
+        default: return fail(GNERF_E_ARG, "upfirdn2d: unsupported dtype code %d", dtype);
+    }
+}

@@ -1,0 +1,321 @@
+"""ctypes binding of libgnerf_hip.so (C ABI in include/gnerf_hip.h).
+
+This is the only place that touches the native library.  PyTorch is used for what it is
+good at here -- device memory, the current HIP stream, dtypes -- and nothing else: every
+function below hands raw device pointers to a hand-written gfx950 kernel.
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgnerf_hip.so')
+
+_lib = None
+
+F32, F16, F64 = 0, 1, 2
+_DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.float64: F64}
+
+MAX_SAMPLES = 256
+DEBUG_SLOTS = 8
+
+_c_p = ctypes.c_void_p
+_c_i = ctypes.c_int
+_c_i64 = ctypes.c_int64
+_c_f = ctypes.c_float
+
+
+class RenderParams(ctypes.Structure):
+    """struct gnerf_render_params (include/gnerf_hip.h)."""
+    _fields_ = [
+        ('planes_nhwc', _c_p), ('n_items', ctypes.c_int32), ('plane_h', ctypes.c_int32), ('plane_w', ctypes.c_int32),
+        ('ray_origins', _c_p), ('ray_dirs', _c_p), ('rays_per_item', ctypes.c_int32), ('image_width', ctypes.c_int32),
+        ('w1', _c_p), ('b1', _c_p), ('w2', _c_p), ('b2', _c_p),
+        ('depth_resolution', ctypes.c_int32), ('depth_resolution_importance', ctypes.c_int32),
+        ('ray_start', _c_f), ('ray_end', _c_f),
+        ('ray_start_per_ray', _c_p), ('ray_end_per_ray', _c_p),
+        ('box_warp', _c_f), ('white_back', ctypes.c_int32), ('disparity_space_sampling', ctypes.c_int32),
+        ('noise_coarse', _c_p), ('noise_fine', _c_p),
+        ('out_rgb', _c_p), ('out_depth', _c_p), ('out_wsum', _c_p),
+        ('workspace', _c_p), ('debug', _c_p),
+    ]
+
+
+# name -> (restype, argtypes); must list every function include/gnerf_hip.h declares (tests check this).
+SIGNATURES = {
+    'gnerf_abi_version': (_c_i, []),
+    'gnerf_last_error': (ctypes.c_char_p, []),
+    'gnerf_build_info': (ctypes.c_char_p, []),
+    'gnerf_bias_act': (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i64, _c_i, _c_i64, _c_i, _c_i, _c_f, _c_f, _c_f, _c_p]),
+    'gnerf_upfirdn2d': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, ctypes.POINTER(_c_i64), _c_i, _c_i, ctypes.POINTER(_c_i64),
+                               _c_i, _c_i, ctypes.POINTER(_c_i64), _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_p]),
+    'gnerf_filtered_lrelu_act': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, ctypes.POINTER(_c_i64), _c_i, _c_i, _c_i, _c_i,
+                                        _c_f, _c_f, _c_f, _c_i, _c_p]),
+    'gnerf_planes_to_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
+    'gnerf_make_rays': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_p, _c_p, _c_p]),
+    'gnerf_render_workspace_bytes': (ctypes.c_size_t, []),
+    'gnerf_render_forward': (_c_i, [ctypes.POINTER(RenderParams), _c_p]),
+    'gnerf_query_points': (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
+}
+
+
+def load():
+    """Load the library once.  Raises RuntimeError (never falls back) if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(f'{LIB_PATH} is missing: build it with g-nerf_amd/csrc/build.sh '
+                           f'(or python -c "import __graft_entry__ as g; g.build()"). There is no fallback path.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gnerf_abi_version() != 1:
+        raise RuntimeError(f'libgnerf_hip.so ABI version {lib.gnerf_abi_version()} != 1')
+    _lib = lib
+    return lib
+
+
+def is_available():
+    return os.path.isfile(LIB_PATH)
+
+
+def _check(code, what):
+    if code != 0:
+        msg = load().gnerf_last_error().decode('utf-8', 'replace')
+        raise RuntimeError(f'{what} failed ({code}): {msg}')
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _strides(t):
+    return (ctypes.c_int64 * t.ndim)(*t.stride())
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and t.device.type != 'cuda':
+            raise RuntimeError('gnerf_hip: tensor is not on a GPU device')
+
+
+# ----------------------------------------------------------------------------
+
+
+def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
+    """Same contract as bias_act_plugin.bias_act (reference bias_act.cpp:36): absent tensors are
+    empty tensors (numel 0) or None; returns a new tensor laid out like x."""
+    def opt(t):
+        return None if t is None or t.numel() == 0 else t
+    b, xref, yref, dy = opt(b), opt(xref), opt(yref), opt(dy)
+    _require_cuda(x, b, xref, yref, dy)
+    if x.dtype not in _DTYPE_CODE:
+        raise RuntimeError(f'bias_act: unsupported dtype {x.dtype}')
+    if not x.is_non_overlapping_and_dense():
+        raise RuntimeError('bias_act: x must be non-overlapping and dense')
+    for name, t in (('xref', xref), ('yref', yref), ('dy', dy)):
+        if t is not None and (t.shape != x.shape or t.dtype != x.dtype or t.stride() != x.stride()):
+            raise RuntimeError(f'bias_act: {name} must have the same shape, dtype and layout as x')
+    size_b, step_b = 0, 1
+    if b is not None:
+        if b.ndim != 1 or b.dtype != x.dtype or not b.is_contiguous():
+            raise RuntimeError('bias_act: b must be a contiguous 1-D tensor of the same dtype as x')
+        if not 0 <= dim < x.ndim or b.numel() != x.shape[dim]:
+            raise RuntimeError('bias_act: b has the wrong number of elements or dim is out of bounds')
+        size_b, step_b = b.numel(), x.stride(dim)
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        code = load().gnerf_bias_act(_ptr(x), _ptr(b), _ptr(xref), _ptr(yref), _ptr(dy), _ptr(y), _DTYPE_CODE[x.dtype],
+                                     x.numel(), size_b, step_b, int(grad), int(act), float(alpha), float(gain), float(clamp), _stream(x))
+    _check(code, 'gnerf_bias_act')
+    return y
+
+
+def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
+    """Same contract as upfirdn2d_plugin.upfirdn2d (reference upfirdn2d.cpp:20): x [N,C,H,W] in NCHW or
+    channels_last, f float32 [fh,fw] on x's device; returns y in x's memory format."""
+    _require_cuda(x, f)
+    if x.ndim != 4 or f.ndim != 2 or f.dtype != torch.float32:
+        raise RuntimeError('upfirdn2d: x must be rank 4 and f a rank-2 float32 tensor')
+    if x.dtype not in _DTYPE_CODE:
+        raise RuntimeError(f'upfirdn2d: unsupported dtype {x.dtype}')
+    if x.numel() == 0 or f.numel() == 0:
+        raise RuntimeError('upfirdn2d: x and f must not be empty')
+    n, c, ih, iw = x.shape
+    fh, fw = f.shape
+    ow = (iw * upx + padx0 + padx1 - fw + downx) // downx
+    oh = (ih * upy + pady0 + pady1 - fh + downy) // downy
+    if ow < 1 or oh < 1:
+        raise RuntimeError('upfirdn2d: output must be at least 1x1')
+    mf = torch.channels_last if (x.stride(1) == 1 and c > 1) else torch.contiguous_format
+    y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device, memory_format=mf)
+    with torch.cuda.device(x.device):
+        code = load().gnerf_upfirdn2d(_ptr(x), _ptr(f), _ptr(y), _DTYPE_CODE[x.dtype], n, c, ih, iw, _strides(x),
+                                      fh, fw, _strides(f), oh, ow, _strides(y), upx, upy, downx, downy, padx0, pady0,
+                                      1 if flip else 0, float(gain), _stream(x))
+    _check(code, 'gnerf_upfirdn2d')
+    return y
+
+
+def filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, write_signs):
+    """Same contract as filtered_lrelu_plugin.filtered_lrelu_act_ (reference filtered_lrelu.cpp:217):
+    in-place on x; returns the sign tensor written (or an empty tensor)."""
+    _require_cuda(x)
+    if x.ndim != 4 or x.dtype not in _DTYPE_CODE:
+        raise RuntimeError('filtered_lrelu_act_: x must be a rank-4 float tensor')
+    n, c, h, w = x.shape
+    read_signs = si is not None and si.numel() > 0
+    so = torch.empty([0], dtype=torch.uint8, device=x.device)
+    s_h = s_w = 0
+    mode = 0
+    s = None
+    if read_signs:
+        _require_cuda(si)
+        if si.dtype != torch.uint8 or si.ndim != 4 or not si.is_contiguous():
+            raise RuntimeError('filtered_lrelu_act_: si must be a contiguous rank-4 uint8 tensor')
+        s, s_h, s_w, mode = si, si.shape[2], si.shape[3] * 4, 2
+    elif write_signs:
+        s_w = (w + 15) & ~15
+        s_h = h
+        so = torch.empty([n, c, s_h, s_w // 4], dtype=torch.uint8, device=x.device)
+        s, mode, sx, sy = so, 1, 0, 0
+    with torch.cuda.device(x.device):
+        code = load().gnerf_filtered_lrelu_act(_ptr(x), _ptr(s), _DTYPE_CODE[x.dtype], n, c, h, w, _strides(x), s_h, s_w, int(sx), int(sy),
+                                               float(gain), float(slope), float(clamp), mode, _stream(x))
+    _check(code, 'gnerf_filtered_lrelu_act')
+    return so
+
+
+def planes_to_nhwc(planes):
+    """[N,3,C,H,W] (or [NP,C,H,W]) float32 NCHW -> [NP,H,W,C] contiguous."""
+    _require_cuda(planes)
+    if planes.dtype != torch.float32:
+        raise RuntimeError('planes_to_nhwc: planes must be float32')
+    p = planes.reshape(-1, *planes.shape[-3:]).contiguous()
+    np_, c, h, w = p.shape
+    out = torch.empty([np_, h, w, c], dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device):
+        code = load().gnerf_planes_to_nhwc(_ptr(p), _ptr(out), np_, c, h, w, _stream(p))
+    _check(code, 'gnerf_planes_to_nhwc')
+    return out
+
+
+def make_rays(cam2world, intrinsics, resolution):
+    _require_cuda(cam2world, intrinsics)
+    c2w = cam2world.to(torch.float32).contiguous()
+    k = intrinsics.to(torch.float32).contiguous()
+    n = c2w.shape[0]
+    if c2w.shape != (n, 4, 4) or k.shape != (n, 3, 3):
+        raise RuntimeError('make_rays: expected cam2world [N,4,4] and intrinsics [N,3,3]')
+    o = torch.empty([n, resolution * resolution, 3], dtype=torch.float32, device=c2w.device)
+    d = torch.empty_like(o)
+    with torch.cuda.device(c2w.device):
+        code = load().gnerf_make_rays(_ptr(c2w), _ptr(k), n, int(resolution), _ptr(o), _ptr(d), _stream(c2w))
+    _check(code, 'gnerf_make_rays')
+    return o, d
+
+
+_workspaces = {}
+
+
+def _workspace(device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = torch.empty([max(int(load().gnerf_render_workspace_bytes()), 16)], dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine, *,
+                   depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
+                   white_back=False, disparity_space_sampling=False, image_width=0, debug=False):
+    """planes_nhwc [3N,H,W,32]; decoder = (w1,b1,w2,b2) effective fp32 weights; rays [N,M,3];
+    noise_coarse [N*M,S]; noise_fine [N*M,F] or None; ray_start/ray_end floats or [N*M] tensors.
+    Returns (rgb [N,M,32], depth [N,M,1], wsum [N,M,1][, debug [N*M,8,S+F]])."""
+    w1, b1, w2, b2 = decoder
+    _require_cuda(planes_nhwc, ray_origins, ray_dirs, noise_coarse, noise_fine, w1, b1, w2, b2)
+    dev = planes_nhwc.device
+
+    def f32c(t):
+        return t.to(torch.float32).contiguous()
+    if planes_nhwc.dtype != torch.float32 or not planes_nhwc.is_contiguous() or planes_nhwc.ndim != 4 or planes_nhwc.shape[3] != 32:
+        raise RuntimeError('render_forward: planes_nhwc must be contiguous float32 [3N,H,W,32]')
+    if planes_nhwc.shape[0] != 3 * n_items:
+        raise RuntimeError('render_forward: planes_nhwc must hold 3 planes per item')
+    if tuple(w1.shape) != (64, 32) or tuple(b1.shape) != (64,) or tuple(w2.shape) != (33, 64) or tuple(b2.shape) != (33,):
+        raise RuntimeError('render_forward: decoder must be the 32->64->33 OSGDecoder MLP')
+    o, d = f32c(ray_origins), f32c(ray_dirs)
+    if o.shape != d.shape or o.ndim != 3 or o.shape[0] != n_items or o.shape[2] != 3:
+        raise RuntimeError('render_forward: rays must be [N,M,3]')
+    m = o.shape[1]
+    S, F = int(depth_resolution), int(depth_resolution_importance)
+    nc = f32c(noise_coarse)
+    if nc.numel() != n_items * m * S:
+        raise RuntimeError('render_forward: noise_coarse must have N*M*S elements')
+    nf = None
+    if F > 0:
+        if noise_fine is None:
+            raise RuntimeError('render_forward: noise_fine required when depth_resolution_importance > 0')
+        nf = f32c(noise_fine)
+        if nf.numel() != n_items * m * F:
+            raise RuntimeError('render_forward: noise_fine must have N*M*F elements')
+    w1, b1, w2, b2 = f32c(w1), f32c(b1), f32c(w2), f32c(b2)
+    rs_t = re_t = None
+    if isinstance(ray_start, torch.Tensor) or isinstance(ray_end, torch.Tensor):
+        rs_t = f32c(torch.as_tensor(ray_start, device=dev).expand(n_items, m, 1) if not isinstance(ray_start, torch.Tensor) else ray_start).reshape(-1)
+        re_t = f32c(torch.as_tensor(ray_end, device=dev).expand(n_items, m, 1) if not isinstance(ray_end, torch.Tensor) else ray_end).reshape(-1)
+        if rs_t.numel() != n_items * m or re_t.numel() != n_items * m:
+            raise RuntimeError('render_forward: per-ray ray_start / ray_end must have N*M elements')
+        ray_start = ray_end = 0.0
+    rgb = torch.empty([n_items, m, 32], dtype=torch.float32, device=dev)
+    depth = torch.empty([n_items, m, 1], dtype=torch.float32, device=dev)
+    wsum = torch.empty([n_items, m, 1], dtype=torch.float32, device=dev)
+    dbg = torch.zeros([n_items * m, DEBUG_SLOTS, S + F], dtype=torch.float32, device=dev) if debug else None
+    ws = _workspace(dev)
+    p = RenderParams()
+    p.planes_nhwc = planes_nhwc.data_ptr(); p.n_items = n_items; p.plane_h = planes_nhwc.shape[1]; p.plane_w = planes_nhwc.shape[2]
+    p.ray_origins = o.data_ptr(); p.ray_dirs = d.data_ptr(); p.rays_per_item = m; p.image_width = int(image_width)
+    p.w1, p.b1, p.w2, p.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    p.depth_resolution = S; p.depth_resolution_importance = F
+    p.ray_start = float(ray_start); p.ray_end = float(ray_end)
+    p.ray_start_per_ray = None if rs_t is None else rs_t.data_ptr()
+    p.ray_end_per_ray = None if re_t is None else re_t.data_ptr()
+    p.box_warp = float(box_warp); p.white_back = int(bool(white_back)); p.disparity_space_sampling = int(bool(disparity_space_sampling))
+    p.noise_coarse = nc.data_ptr(); p.noise_fine = None if nf is None else nf.data_ptr()
+    p.out_rgb, p.out_depth, p.out_wsum = rgb.data_ptr(), depth.data_ptr(), wsum.data_ptr()
+    p.workspace = ws.data_ptr(); p.debug = None if dbg is None else dbg.data_ptr()
+    with torch.cuda.device(dev):
+        code = load().gnerf_render_forward(ctypes.byref(p), _stream(planes_nhwc))
+    _check(code, 'gnerf_render_forward')
+    if debug:
+        return rgb, depth, wsum, dbg
+    return rgb, depth, wsum
+
+
+def query_points(planes_nhwc, n_items, decoder, points, box_warp):
+    """run_model for arbitrary points [N,P,3] -> sigma [N,P,1], rgb [N,P,32]."""
+    w1, b1, w2, b2 = [t.to(torch.float32).contiguous() for t in decoder]
+    _require_cuda(planes_nhwc, points, w1)
+    pts = points.to(torch.float32).contiguous()
+    if pts.ndim != 3 or pts.shape[0] != n_items or pts.shape[2] != 3:
+        raise RuntimeError('query_points: points must be [N,P,3]')
+    n_pts = pts.shape[1]
+    sigma = torch.empty([n_items, n_pts, 1], dtype=torch.float32, device=pts.device)
+    rgb = torch.empty([n_items, n_pts, 32], dtype=torch.float32, device=pts.device)
+    with torch.cuda.device(pts.device):
+        code = load().gnerf_query_points(_ptr(planes_nhwc), n_items, planes_nhwc.shape[1], planes_nhwc.shape[2], _ptr(pts), n_pts,
+                                         float(box_warp), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(sigma), _ptr(rgb), _stream(pts))
+    _check(code, 'gnerf_query_points')
+    return sigma, rgb

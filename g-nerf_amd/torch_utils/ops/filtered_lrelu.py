@@ -1,0 +1,174 @@
+"""Filtered leaky ReLU (bias -> upsample FIR -> lrelu/clamp -> downsample FIR) with the reference's
+interface (torch_utils/ops/filtered_lrelu.py: filtered_lrelu :58, _filtered_lrelu_ref :122,
+_filtered_lrelu_cuda :161).
+
+G-NeRF never executes this op (only StyleGAN3's SynthesisLayer calls it and G-NeRF never builds one);
+it is kept API-complete.  On a GPU it runs as three hand-written gfx950 launches -- upfirdn2d,
+filtered_lrelu_act_ (which also records the 2-bit sign tensor), upfirdn2d -- i.e. the path the
+reference itself takes whenever its fused kernel has no specialisation (filtered_lrelu.py:225-231).
+Only the packed sign tensor is kept for the backward pass, which is the same op with up and down
+swapped reading the signs back."""
+
+import os
+import warnings
+
+import numpy as np
+import torch
+
+from .. import custom_ops
+from . import upfirdn2d
+from . import bias_act
+
+_plugin = None
+
+
+def _init():
+    global _plugin
+    if _plugin is None:
+        _plugin = custom_ops.get_plugin(
+            module_name='filtered_lrelu_plugin',
+            sources=['filtered_lrelu.hip'],
+            headers=['common.h'],
+            source_dir=os.path.join(os.path.dirname(__file__), '..', '..', 'csrc'),
+        )
+    return True
+
+
+def _get_filter_size(f):
+    if f is None:
+        return 1, 1
+    assert isinstance(f, torch.Tensor)
+    assert 1 <= f.ndim <= 2
+    return f.shape[-1], f.shape[0]      # width, height
+
+
+def _parse_padding(padding):
+    if isinstance(padding, int):
+        padding = [padding, padding]
+    assert isinstance(padding, (list, tuple))
+    assert all(isinstance(x, (int, np.integer)) for x in padding)
+    padding = [int(x) for x in padding]
+    if len(padding) == 2:
+        px, py = padding
+        padding = [px, px, py, py]
+    px0, px1, py0, py1 = padding
+    return px0, px1, py0, py1
+
+
+def _check_scalars(up, down, gain, slope, clamp):
+    assert isinstance(up, int) and up >= 1
+    assert isinstance(down, int) and down >= 1
+    assert gain == float(gain) and gain > 0
+    assert slope == float(slope) and slope >= 0
+    assert clamp is None or (clamp == float(clamp) and clamp >= 0)
+
+
+def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, clamp=None, flip_filter=False, impl='cuda'):
+    """x [N,C,H,W] -> add bias b, zero-upsample by `up`, pad, filter with fu (gain up**2), multiply by
+    `gain`, leaky ReLU with `slope`, clamp to +-clamp, filter with fd, keep every `down`-th pixel.
+    Output size per axis: (in*up + pad0 + pad1 - (fu_taps-1) - (fd_taps-1) + (down-1)) // down."""
+    assert isinstance(x, torch.Tensor)
+    assert impl in ['ref', 'cuda']
+    if impl == 'cuda' and x.device.type == 'cuda' and _init():
+        return _filtered_lrelu_cuda(up=up, down=down, padding=padding, gain=gain, slope=slope, clamp=clamp,
+                                    flip_filter=flip_filter).apply(x, fu, fd, b, None, 0, 0)
+    return _filtered_lrelu_ref(x, fu=fu, fd=fd, b=b, up=up, down=down, padding=padding, gain=gain, slope=slope, clamp=clamp, flip_filter=flip_filter)
+
+
+def _filtered_lrelu_ref(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, clamp=None, flip_filter=False):
+    """Composition of bias_act() and upfirdn2d()."""
+    assert isinstance(x, torch.Tensor) and x.ndim == 4
+    fu_w, fu_h = _get_filter_size(fu)
+    fd_w, fd_h = _get_filter_size(fd)
+    if b is not None:
+        assert isinstance(b, torch.Tensor) and b.dtype == x.dtype
+        assert list(b.shape) == [x.shape[1]]
+    _check_scalars(up, down, gain, slope, clamp)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    N, C, in_h, in_w = x.shape
+    in_dtype = x.dtype
+    out_w = (in_w * up + (px0 + px1) - (fu_w - 1) - (fd_w - 1) + (down - 1)) // down
+    out_h = (in_h * up + (py0 + py1) - (fu_h - 1) - (fd_h - 1) + (down - 1)) // down
+    with torch.autograd.profiler.record_function('_filtered_lrelu_ref'):
+        x = bias_act.bias_act(x=x, b=b)
+        x = upfirdn2d.upfirdn2d(x=x, f=fu, up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter)
+        x = bias_act.bias_act(x=x, act='lrelu', alpha=slope, gain=gain, clamp=clamp)
+        x = upfirdn2d.upfirdn2d(x=x, f=fd, down=down, flip_filter=flip_filter)
+    assert list(x.shape) == [N, C, out_h, out_w]
+    assert x.dtype == in_dtype
+    return x
+
+
+_filtered_lrelu_cuda_cache = dict()
+
+
+def _filtered_lrelu_cuda(up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, clamp=None, flip_filter=False):
+    """autograd.Function (cached per static-argument tuple)."""
+    _check_scalars(up, down, gain, slope, clamp)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    gain, slope = float(gain), float(slope)
+    clamp = float(clamp if clamp is not None else 'inf')
+    key = (up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter)
+    if key in _filtered_lrelu_cuda_cache:
+        return _filtered_lrelu_cuda_cache[key]
+
+    class FilteredLReluCuda(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, fu, fd, b, si, sx, sy):
+            assert isinstance(x, torch.Tensor) and x.ndim == 4
+            if fu is None:
+                fu = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+            if fd is None:
+                fd = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+            assert 1 <= fu.ndim <= 2 and 1 <= fd.ndim <= 2
+            if up == 1 and fu.ndim == 1 and fu.shape[0] == 1:
+                fu = fu.square()[None]
+            if down == 1 and fd.ndim == 1 and fd.shape[0] == 1:
+                fd = fd.square()[None]
+            if si is None:
+                si = torch.empty([0])
+            if b is None:
+                b = torch.zeros([x.shape[1]], dtype=x.dtype, device=x.device)
+            write_signs = (si.numel() == 0) and (x.requires_grad or b.requires_grad)
+            strides = [x.stride(i) for i in range(x.ndim) if x.size(i) > 1]
+            if any(a < c for a, c in zip(strides[:-1], strides[1:])):
+                warnings.warn("low-performance memory layout detected in filtered_lrelu input", RuntimeWarning)
+            # A fused single-kernel variant would be tried here first (plugin.filtered_lrelu, return code < 0 =
+            # not available); this build always takes the three-launch route.
+            y, so, return_code = _plugin.filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy,
+                                                        gain, slope, clamp, flip_filter, write_signs)
+            if return_code < 0:
+                y = x.add(b.unsqueeze(-1).unsqueeze(-1))
+                y = upfirdn2d.upfirdn2d(x=y, f=fu, up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter)
+                so = _plugin.filtered_lrelu_act_(y, si, sx, sy, gain, slope, clamp, write_signs)    # in place on y
+                y = upfirdn2d.upfirdn2d(x=y, f=fd, down=down, flip_filter=flip_filter)
+            ctx.save_for_backward(fu, fd, (si if si.numel() else so))
+            ctx.x_shape = x.shape
+            ctx.y_shape = y.shape
+            ctx.s_ofs = sx, sy
+            return y
+
+        @staticmethod
+        def backward(ctx, dy):
+            fu, fd, si = ctx.saved_tensors
+            _, _, xh, xw = ctx.x_shape
+            _, _, yh, yw = ctx.y_shape
+            sx, sy = ctx.s_ofs
+            dx = db = None
+            for i in (1, 2, 4, 5, 6):
+                assert not ctx.needs_input_grad[i]
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
+                # transposed op: swap the filters and factors; the sign tensor is read at an offset
+                pp = [(fu.shape[-1] - 1) + (fd.shape[-1] - 1) - px0, xw * up - yw * down + px0 - (up - 1),
+                      (fu.shape[0] - 1) + (fd.shape[0] - 1) - py0, xh * up - yh * down + py0 - (up - 1)]
+                gg = gain * (up ** 2) / (down ** 2)
+                sx = sx - (fu.shape[-1] - 1) + px0
+                sy = sy - (fu.shape[0] - 1) + py0
+                dx = _filtered_lrelu_cuda(up=down, down=up, padding=pp, gain=gg, slope=slope, clamp=None,
+                                          flip_filter=(not flip_filter)).apply(dy, fd, fu, None, si, sx, sy)
+            if ctx.needs_input_grad[3]:
+                db = dx.sum([0, 2, 3])
+            return dx, None, None, db, None, None, None
+
+    _filtered_lrelu_cuda_cache[key] = FilteredLReluCuda
+    return FilteredLReluCuda

@@ -1,0 +1,208 @@
+"""2-D resampling (upsample -> pad -> FIR -> downsample) with the reference's interface
+(torch_utils/ops/upfirdn2d.py: setup_filter :72, upfirdn2d :120, _upfirdn2d_ref :168,
+_upfirdn2d_cuda :219, filter2d :279, upsample2d :315, downsample2d :354; the underscore helpers
+_parse_scaling / _parse_padding / _get_filter_size are imported by conv2d_resample.py:18-19).
+
+GPU tensors run the hand-written gfx950 kernels (csrc/upfirdn2d.hip); the gradient is the same op with
+up and down swapped and the filter flipped, so it runs on the same kernels.  CPU tensors, or
+impl='ref', use PyTorch ops like the reference."""
+
+import os
+
+import numpy as np
+import torch
+
+from .. import custom_ops
+
+_plugin = None
+
+
+def _init():
+    global _plugin
+    if _plugin is None:
+        _plugin = custom_ops.get_plugin(
+            module_name='upfirdn2d_plugin',
+            sources=['upfirdn2d.hip'],
+            headers=['common.h'],
+            source_dir=os.path.join(os.path.dirname(__file__), '..', '..', 'csrc'),
+        )
+    return True
+
+
+def _parse_scaling(scaling):
+    if isinstance(scaling, int):
+        scaling = [scaling, scaling]
+    assert isinstance(scaling, (list, tuple))
+    assert all(isinstance(x, int) for x in scaling)
+    sx, sy = scaling
+    assert sx >= 1 and sy >= 1
+    return sx, sy
+
+
+def _parse_padding(padding):
+    if isinstance(padding, int):
+        padding = [padding, padding]
+    assert isinstance(padding, (list, tuple))
+    assert all(isinstance(x, int) for x in padding)
+    if len(padding) == 2:
+        px, py = padding
+        padding = [px, px, py, py]
+    padx0, padx1, pady0, pady1 = padding
+    return padx0, padx1, pady0, pady1
+
+
+def _get_filter_size(f):
+    if f is None:
+        return 1, 1
+    assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
+    fw, fh = int(f.shape[-1]), int(f.shape[0])
+    assert fw >= 1 and fh >= 1
+    return fw, fh
+
+
+def setup_filter(f, device=torch.device('cpu'), normalize=True, flip_filter=False, gain=1, separable=None):
+    """Build a float32 FIR filter for upfirdn2d().
+
+    f: list / array / tensor of shape [taps] (expanded to its outer product unless it has >= 8 taps or
+    `separable` is set), [fh, fw], [] (impulse) or None (identity).  normalize makes the taps sum to 1;
+    gain scales the signal (applied as gain**(ndim/2) so a separable filter gets sqrt(gain) per pass)."""
+    if f is None:
+        f = 1
+    f = torch.as_tensor(f, dtype=torch.float32)
+    assert f.ndim in [0, 1, 2]
+    assert f.numel() > 0
+    if f.ndim == 0:
+        f = f[np.newaxis]
+    if separable is None:
+        separable = (f.ndim == 1 and f.numel() >= 8)
+    if f.ndim == 1 and not separable:
+        f = f.ger(f)
+    assert f.ndim == (1 if separable else 2)
+    if normalize:
+        f /= f.sum()
+    if flip_filter:
+        f = f.flip(list(range(f.ndim)))
+    f = f * (gain ** (f.ndim / 2))
+    return f.to(device=device)
+
+
+def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cuda'):
+    """Per channel: insert up-1 zeros after each pixel, pad (negative = crop), filter with f (a true
+    convolution unless flip_filter), keep every down-th pixel.
+
+    x: [N,C,H,W] float16/32/64; f: [fh,fw], [taps] (separable) or None; up, down: int or [x, y];
+    padding: int, [x, y] or [x0, x1, y0, y1], relative to the upsampled image.
+    Output size per axis: (in*up + pad0 + pad1 - taps + down) // down.  Differentiable to any order."""
+    assert isinstance(x, torch.Tensor)
+    assert impl in ['ref', 'cuda']
+    if impl == 'cuda' and x.device.type == 'cuda' and _init():
+        return _upfirdn2d_cuda(up=up, down=down, padding=padding, flip_filter=flip_filter, gain=gain).apply(x, f)
+    return _upfirdn2d_ref(x, f, up=up, down=down, padding=padding, flip_filter=flip_filter, gain=gain)
+
+
+def _upfirdn2d_ref(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
+    """PyTorch-op implementation: explicit zero insertion, F.pad, grouped conv2d, strided slice."""
+    assert isinstance(x, torch.Tensor) and x.ndim == 4
+    if f is None:
+        f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+    assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
+    assert f.dtype == torch.float32 and not f.requires_grad
+    N, C, H, W = x.shape
+    upx, upy = _parse_scaling(up)
+    downx, downy = _parse_scaling(down)
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    assert W * upx + padx0 + padx1 >= f.shape[-1] and H * upy + pady0 + pady1 >= f.shape[0]
+    with torch.autograd.profiler.record_function('_upfirdn2d_ref'):
+        x = x.reshape([N, C, H, 1, W, 1])
+        x = torch.nn.functional.pad(x, [0, upx - 1, 0, 0, 0, upy - 1])
+        x = x.reshape([N, C, H * upy, W * upx])
+        x = torch.nn.functional.pad(x, [max(padx0, 0), max(padx1, 0), max(pady0, 0), max(pady1, 0)])
+        x = x[:, :, max(-pady0, 0): x.shape[2] - max(-pady1, 0), max(-padx0, 0): x.shape[3] - max(-padx1, 0)]
+        k = (f * (gain ** (f.ndim / 2))).to(x.dtype)
+        if not flip_filter:
+            k = k.flip(list(range(k.ndim)))
+        k = k[np.newaxis, np.newaxis].repeat([C, 1] + [1] * k.ndim)
+        if k.ndim == 4:
+            x = torch.nn.functional.conv2d(x, k, groups=C)
+        else:
+            x = torch.nn.functional.conv2d(x, k.unsqueeze(2), groups=C)
+            x = torch.nn.functional.conv2d(x, k.unsqueeze(3), groups=C)
+        x = x[:, :, ::downy, ::downx]
+    return x
+
+
+_upfirdn2d_cuda_cache = dict()
+
+
+def _upfirdn2d_cuda(up=1, down=1, padding=0, flip_filter=False, gain=1):
+    """autograd.Function (cached per static-argument tuple) around the plugin's upfirdn2d entry point."""
+    upx, upy = _parse_scaling(up)
+    downx, downy = _parse_scaling(down)
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    key = (upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain)
+    if key in _upfirdn2d_cuda_cache:
+        return _upfirdn2d_cuda_cache[key]
+
+    class Upfirdn2dCuda(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, f):
+            assert isinstance(x, torch.Tensor) and x.ndim == 4
+            if f is None:
+                f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+            if f.ndim == 1 and f.shape[0] == 1:
+                f = f.square().unsqueeze(0)         # one separable tap == a 1x1 filter
+            assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
+            if f.ndim == 2:
+                y = _plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain)
+            else:                                   # separable: a row pass then a column pass
+                y = _plugin.upfirdn2d(x, f.unsqueeze(0), upx, 1, downx, 1, padx0, padx1, 0, 0, flip_filter, 1.0)
+                y = _plugin.upfirdn2d(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, pady0, pady1, flip_filter, gain)
+            ctx.save_for_backward(f)
+            ctx.x_shape = x.shape
+            return y
+
+        @staticmethod
+        def backward(ctx, dy):
+            f, = ctx.saved_tensors
+            _, _, ih, iw = ctx.x_shape
+            _, _, oh, ow = dy.shape
+            fw, fh = _get_filter_size(f)
+            # transpose of the forward op: swap up/down, flip the filter, and pad so that the result has x's shape
+            p = [fw - padx0 - 1, iw * upx - ow * downx + padx0 - upx + 1,
+                 fh - pady0 - 1, ih * upy - oh * downy + pady0 - upy + 1]
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = _upfirdn2d_cuda(up=down, down=up, padding=p, flip_filter=(not flip_filter), gain=gain).apply(dy, f)
+            assert not ctx.needs_input_grad[1]
+            return dx, None
+
+    _upfirdn2d_cuda_cache[key] = Upfirdn2dCuda
+    return Upfirdn2dCuda
+
+
+def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl='cuda'):
+    """Filter without resampling; by default the output has the input's size (zeros outside the image).
+    `padding` is applied on top (negative crops)."""
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    fw, fh = _get_filter_size(f)
+    p = [padx0 + fw // 2, padx1 + (fw - 1) // 2, pady0 + fh // 2, pady1 + (fh - 1) // 2]
+    return upfirdn2d(x, f, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)
+
+
+def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1, impl='cuda'):
+    """Upsample by `up`; by default the output is exactly `up` times the input size.  The gain is
+    multiplied by upx*upy to keep the signal magnitude."""
+    upx, upy = _parse_scaling(up)
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    fw, fh = _get_filter_size(f)
+    p = [padx0 + (fw + upx - 1) // 2, padx1 + (fw - upx) // 2, pady0 + (fh + upy - 1) // 2, pady1 + (fh - upy) // 2]
+    return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * upx * upy, impl=impl)
+
+
+def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1, impl='cuda'):
+    """Downsample by `down`; by default the output is exactly 1/down of the input size."""
+    downx, downy = _parse_scaling(down)
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    fw, fh = _get_filter_size(f)
+    p = [padx0 + (fw - downx + 1) // 2, padx1 + (fw - downx) // 2, pady0 + (fh - downy + 1) // 2, pady1 + (fh - downy) // 2]
+    return upfirdn2d(x, f, down=down, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)

@@ -1,0 +1,284 @@
+"""ImportanceRenderer with the reference's interface
+(training/volumetric_rendering/renderer.py: generate_planes :23, project_onto_planes :39,
+sample_from_planes :55, sample_from_3dgrid :67, ImportanceRenderer :82-253).
+
+On a GPU the whole of `forward` -- depth proposals, tri-plane lookups, the decoder MLP, both ray
+marches, importance resampling, the depth merge and the composite -- is ONE hand-written gfx950
+kernel (csrc/render.hip through gnerf_hip.render_forward).  The random draws are still made by
+torch, in the reference's order and shapes (rand_like([N,M,S,1]) then rand(N*M, F)), so a seeded
+run consumes the generator exactly like the reference and produces the same image.
+
+The PyTorch-op form below is what runs for CPU tensors (the reference's own behaviour: all of its
+renderer is PyTorch ops), when autograd needs a graph (the backward kernel is the next milestone),
+or when `decoder` is not the OSGDecoder 32->64->33 MLP.  A GPU call never silently degrades because
+the native library is absent: gnerf_hip raises.
+"""
+
+import math
+import warnings
+import weakref
+
+import torch
+import torch.nn as nn
+
+from training.volumetric_rendering.ray_marcher import MipRayMarcher2
+from training.volumetric_rendering import math_utils
+
+import gnerf_hip
+
+
+def generate_planes():
+    """The three plane frames [3,3,3]; rows are the plane's axes.  With project_onto_planes they make
+    plane 0 read (x,y), plane 1 (x,z) and plane 2 (z,x) -- EG3D's original choice, kept bit for bit."""
+    return torch.tensor([[[1, 0, 0], [0, 1, 0], [0, 0, 1]],
+                         [[1, 0, 0], [0, 0, 1], [0, 1, 0]],
+                         [[0, 0, 1], [1, 0, 0], [0, 1, 0]]], dtype=torch.float32)
+
+
+def project_onto_planes(planes, coordinates):
+    """planes [P,3,3], coordinates [N,M,3] -> [N*P, M, 2]: coordinates expressed in each plane's frame,
+    first two components."""
+    N, M, _ = coordinates.shape
+    P = planes.shape[0]
+    pts = coordinates.unsqueeze(1).expand(-1, P, -1, -1).reshape(N * P, M, 3)
+    frames = torch.linalg.inv(planes).unsqueeze(0).expand(N, -1, -1, -1).reshape(N * P, 3, 3)
+    return torch.bmm(pts, frames)[..., :2]
+
+
+def sample_from_planes(plane_axes, plane_features, coordinates, mode='bilinear', padding_mode='zeros', box_warp=None):
+    """plane_features [N,P,C,H,W], coordinates [N,M,3] in world units -> [N,P,M,C]."""
+    assert padding_mode == 'zeros'
+    N, P, C, H, W = plane_features.shape
+    M = coordinates.shape[1]
+    grid = project_onto_planes(plane_axes, (2 / box_warp) * coordinates).unsqueeze(1)
+    out = torch.nn.functional.grid_sample(plane_features.view(N * P, C, H, W), grid.float(), mode=mode,
+                                          padding_mode=padding_mode, align_corners=False)
+    return out.permute(0, 3, 2, 1).reshape(N, P, M, C)
+
+
+def sample_from_3dgrid(grid, coordinates):
+    """grid [1 or B,C,H,W,D], coordinates [B,P,3] -> [B,P,C] (trilinear, zero padding)."""
+    B, P, nd = coordinates.shape
+    out = torch.nn.functional.grid_sample(grid.expand(B, -1, -1, -1, -1), coordinates.reshape(B, 1, 1, -1, nd),
+                                          mode='bilinear', padding_mode='zeros', align_corners=False)
+    N, C, H, W, D = out.shape
+    return out.permute(0, 4, 3, 2, 1).reshape(N, H * W * D, C)
+
+
+def _osg_decoder_weights(decoder):
+    """Return the effective (w1,b1,w2,b2) of an OSGDecoder-shaped module (triplane.py:113-122:
+    FullyConnectedLayer(32,64) -> Softplus -> FullyConnectedLayer(64,33), both 'linear' with bias),
+    or None if `decoder` is anything else."""
+    net = getattr(decoder, 'net', None)
+    if not isinstance(net, nn.Sequential) or len(net) != 3 or not isinstance(net[1], nn.Softplus):
+        return None
+    if net[1].beta != 1 or net[1].threshold != 20:
+        return None
+    fc1, fc2 = net[0], net[2]
+    for fc in (fc1, fc2):
+        if getattr(fc, 'activation', None) != 'linear' or getattr(fc, 'bias', None) is None or not hasattr(fc, 'weight_gain'):
+            return None
+    if tuple(fc1.weight.shape) != (64, 32) or tuple(fc2.weight.shape) != (33, 64):
+        return None
+    return fc1, fc2
+
+
+class ImportanceRenderer(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.ray_marcher = MipRayMarcher2()
+        self.plane_axes = generate_planes()
+
+    # ------------------------------------------------------------------ dispatch
+
+    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options):
+        """planes [N,3,32,H,W]; decoder(sampled_features [N,3,P,32], ray_directions) -> {'rgb','sigma'};
+        rays [N,M,3]; rendering_options: the generator's rendering_kwargs dict (unknown keys ignored).
+        Returns rgb [N,M,32], depth [N,M,1], weight_sum [N,M,1]."""
+        self.plane_axes = self.plane_axes.to(ray_origins.device)
+        if planes.device.type == 'cuda':
+            fcs = _osg_decoder_weights(decoder)
+            needs_graph = torch.is_grad_enabled() and (
+                planes.requires_grad or ray_origins.requires_grad or ray_directions.requires_grad
+                or any(p.requires_grad for p in decoder.parameters()))
+            if fcs is not None and not needs_graph and planes.ndim == 5 and planes.shape[1] == 3 and planes.shape[2] == 32 \
+                    and rendering_options.get('density_noise', 0) == 0:
+                return self._forward_hip(planes, fcs, ray_origins, ray_directions, rendering_options)
+            if fcs is None:
+                warnings.warn('ImportanceRenderer: decoder is not the OSGDecoder MLP; using PyTorch ops', RuntimeWarning)
+        return self._forward_torch(planes, decoder, ray_origins, ray_directions, rendering_options)
+
+    # ------------------------------------------------------------------ fused gfx950 path
+
+    def _decoder_cache(self, fcs):
+        fc1, fc2 = fcs
+        params = (fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+        key = tuple((id(p), p._version, p.device) for p in params) + (float(fc1.weight_gain), float(fc1.bias_gain),
+                                                                        float(fc2.weight_gain), float(fc2.bias_gain))
+        cache = self.__dict__.get('_gnerf_decoder_cache')
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                eff = (fc1.weight.float() * fc1.weight_gain, fc1.bias.float() * fc1.bias_gain,        # networks_stylegan2.py:121-127
+                       fc2.weight.float() * fc2.weight_gain, fc2.bias.float() * fc2.bias_gain)
+                eff = tuple(t.contiguous() for t in eff)
+            cache = (key, eff, params)      # keep params alive so ids stay unique
+            self.__dict__['_gnerf_decoder_cache'] = cache
+        return cache[1]
+
+    def _planes_nhwc(self, planes):
+        base = planes._base if planes._base is not None else planes
+        cache = self.__dict__.get('_gnerf_planes_cache')
+        if cache is not None:
+            ref, version, ptr, shape, nhwc = cache
+            if ref() is base and version == base._version and ptr == planes.data_ptr() and shape == tuple(planes.shape):
+                return nhwc
+        nhwc = gnerf_hip.planes_to_nhwc(planes.detach().float())
+        self.__dict__['_gnerf_planes_cache'] = (weakref.ref(base), base._version, planes.data_ptr(), tuple(planes.shape), nhwc)
+        return nhwc
+
+    def _forward_hip(self, planes, fcs, ray_origins, ray_directions, opts):
+        N, M, _ = ray_origins.shape
+        S = int(opts['depth_resolution'])
+        F = int(opts['depth_resolution_importance'])
+        if S > gnerf_hip.MAX_SAMPLES or F > gnerf_hip.MAX_SAMPLES:
+            raise RuntimeError(f'ImportanceRenderer: at most {gnerf_hip.MAX_SAMPLES} coarse and fine samples per ray are supported')
+        dev = ray_origins.device
+        if opts['ray_start'] == opts['ray_end'] == 'auto':
+            ray_start, ray_end = math_utils.get_ray_limits_box(ray_origins, ray_directions, box_side_length=opts['box_warp'])
+            ok = ray_end > ray_start
+            if torch.any(ok).item():                                     # renderer.py:94-96
+                ray_start[~ok] = ray_start[ok].min()
+                ray_end[~ok] = ray_start[ok].max()
+        else:
+            ray_start, ray_end = opts['ray_start'], opts['ray_end']
+        # the reference's two draws, same shapes, same order (renderer.py:176/186/190 then :241)
+        noise_c = torch.rand([N, M, S, 1], device=dev, dtype=torch.float32)
+        noise_f = torch.rand(N * M, F, device=dev) if F > 0 else None
+        side = math.isqrt(M)
+        rgb, depth, wsum = gnerf_hip.render_forward(
+            self._planes_nhwc(planes), N, self._decoder_cache(fcs), ray_origins.detach(), ray_directions.detach(), noise_c, noise_f,
+            depth_resolution=S, depth_resolution_importance=F, ray_start=ray_start, ray_end=ray_end, box_warp=opts['box_warp'],
+            white_back=bool(opts.get('white_back', False)), disparity_space_sampling=bool(opts.get('disparity_space_sampling', False)),
+            image_width=side if side * side == M else 0)
+        if opts['clamp_mode'] != 'softplus':
+            assert False, "MipRayMarcher only supports `clamp_mode`=`softplus`!"
+        return rgb, depth, wsum
+
+    # ------------------------------------------------------------------ PyTorch-op path
+
+    def _forward_torch(self, planes, decoder, ray_origins, ray_directions, rendering_options):
+        if rendering_options['ray_start'] == rendering_options['ray_end'] == 'auto':
+            ray_start, ray_end = math_utils.get_ray_limits_box(ray_origins, ray_directions, box_side_length=rendering_options['box_warp'])
+            ok = ray_end > ray_start
+            if torch.any(ok).item():
+                ray_start[~ok] = ray_start[ok].min()
+                ray_end[~ok] = ray_start[ok].max()
+        else:
+            ray_start, ray_end = rendering_options['ray_start'], rendering_options['ray_end']
+        depths_coarse = self.sample_stratified(ray_origins, ray_start, ray_end, rendering_options['depth_resolution'],
+                                               rendering_options['disparity_space_sampling'])
+        N, M, S, _ = depths_coarse.shape
+
+        def shade(depths):
+            count = depths.shape[2]
+            pts = (ray_origins.unsqueeze(-2) + depths * ray_directions.unsqueeze(-2)).reshape(N, -1, 3)
+            dirs = ray_directions.unsqueeze(-2).expand(-1, -1, count, -1).reshape(N, -1, 3)
+            out = self.run_model(planes, decoder, pts, dirs, rendering_options)
+            return out['rgb'].reshape(N, M, count, out['rgb'].shape[-1]), out['sigma'].reshape(N, M, count, 1)
+
+        colors_coarse, densities_coarse = shade(depths_coarse)
+        n_fine = rendering_options['depth_resolution_importance']
+        if n_fine > 0:
+            _, _, weights = self.ray_marcher(colors_coarse, densities_coarse, depths_coarse, rendering_options)
+            depths_fine = self.sample_importance(depths_coarse, weights, n_fine)
+            colors_fine, densities_fine = shade(depths_fine)
+            all_depths, all_colors, all_densities = self.unify_samples(depths_coarse, colors_coarse, densities_coarse,
+                                                                       depths_fine, colors_fine, densities_fine)
+            rgb_final, depth_final, weights = self.ray_marcher(all_colors, all_densities, all_depths, rendering_options)
+        else:
+            rgb_final, depth_final, weights = self.ray_marcher(colors_coarse, densities_coarse, depths_coarse, rendering_options)
+        return rgb_final, depth_final, weights.sum(2)
+
+    def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):
+        """Decoder outputs at arbitrary points [N,P,3] -> {'rgb' [N,P,32], 'sigma' [N,P,1]}
+        (entry point of TriPlaneGenerator.sample / sample_mixed, triplane.py:91-102)."""
+        self.plane_axes = self.plane_axes.to(sample_coordinates.device)
+        density_noise = options.get('density_noise', 0)
+        if planes.device.type == 'cuda' and planes.ndim == 5 and planes.shape[1] == 3 and planes.shape[2] == 32:
+            fcs = _osg_decoder_weights(decoder)
+            needs_graph = torch.is_grad_enabled() and (planes.requires_grad or sample_coordinates.requires_grad
+                                                       or any(p.requires_grad for p in decoder.parameters()))
+            if fcs is not None and not needs_graph:
+                sigma, rgb = gnerf_hip.query_points(self._planes_nhwc(planes), planes.shape[0], self._decoder_cache(fcs),
+                                                    sample_coordinates.detach(), options['box_warp'])
+                out = {'rgb': rgb, 'sigma': sigma}
+                if density_noise > 0:
+                    out['sigma'] += torch.randn_like(out['sigma']) * density_noise
+                return out
+        feats = sample_from_planes(self.plane_axes, planes, sample_coordinates, padding_mode='zeros', box_warp=options['box_warp'])
+        out = decoder(feats, sample_directions)
+        if density_noise > 0:
+            out['sigma'] += torch.randn_like(out['sigma']) * density_noise
+        return out
+
+    def sort_samples(self, all_depths, all_colors, all_densities):
+        _, order = torch.sort(all_depths, dim=-2)
+        all_depths = torch.gather(all_depths, -2, order)
+        all_colors = torch.gather(all_colors, -2, order.expand(-1, -1, -1, all_colors.shape[-1]))
+        all_densities = torch.gather(all_densities, -2, order.expand(-1, -1, -1, 1))
+        return all_depths, all_colors, all_densities
+
+    def unify_samples(self, depths1, colors1, densities1, depths2, colors2, densities2):
+        return self.sort_samples(torch.cat([depths1, depths2], dim=-2), torch.cat([colors1, colors2], dim=-2),
+                                 torch.cat([densities1, densities2], dim=-2))
+
+    def sample_stratified(self, ray_origins, ray_start, ray_end, depth_resolution, disparity_space_sampling=False):
+        """Jittered, roughly uniform depths [N,M,S,1] along each ray."""
+        N, M, _ = ray_origins.shape
+        dev = ray_origins.device
+        if disparity_space_sampling:
+            d = torch.linspace(0, 1, depth_resolution, device=dev).reshape(1, 1, depth_resolution, 1).repeat(N, M, 1, 1)
+            d += torch.rand_like(d) * (1 / (depth_resolution - 1))
+            return 1. / (1. / ray_start * (1. - d) + 1. / ray_end * d)
+        if type(ray_start) == torch.Tensor:
+            depths = math_utils.linspace(ray_start, ray_end, depth_resolution).permute(1, 2, 0, 3)
+            step = (ray_end - ray_start) / (depth_resolution - 1)
+            depths += torch.rand_like(depths) * step[..., None]
+            return depths
+        depths = torch.linspace(ray_start, ray_end, depth_resolution, device=dev).reshape(1, 1, depth_resolution, 1).repeat(N, M, 1, 1)
+        depths += torch.rand_like(depths) * ((ray_end - ray_start) / (depth_resolution - 1))
+        return depths
+
+    def sample_importance(self, z_vals, weights, N_importance):
+        """Depths [N,M,F,1] drawn from the smoothed coarse weights (NeRF-style hierarchical sampling)."""
+        with torch.no_grad():
+            N, M, S, _ = z_vals.shape
+            z = z_vals.reshape(N * M, S)
+            w = weights.reshape(N * M, -1)          # S-1 interval weights
+            w = torch.nn.functional.max_pool1d(w.unsqueeze(1).float(), 2, 1, padding=1)
+            w = torch.nn.functional.avg_pool1d(w, 2, 1).squeeze() + 0.01
+            mids = 0.5 * (z[:, :-1] + z[:, 1:])
+            fine = self.sample_pdf(mids, w[:, 1:-1], N_importance).detach()
+        return fine.reshape(N, M, N_importance, 1)
+
+    def sample_pdf(self, bins, weights, N_importance, det=False, eps=1e-5):
+        """Inverse-transform sampling: bins [R,K+1], weights [R,K] -> samples [R,N_importance]."""
+        R, K = weights.shape
+        weights = weights + eps
+        pdf = weights / torch.sum(weights, -1, keepdim=True)
+        cdf = torch.cumsum(pdf, -1)
+        cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
+        if det:
+            u = torch.linspace(0, 1, N_importance, device=bins.device).expand(R, N_importance)
+        else:
+            u = torch.rand(R, N_importance, device=bins.device)
+        u = u.contiguous()
+        idx = torch.searchsorted(cdf, u, right=True)
+        lo = torch.clamp_min(idx - 1, 0)
+        hi = torch.clamp_max(idx, K)
+        pair = torch.stack([lo, hi], -1).view(R, 2 * N_importance)
+        cdf_g = torch.gather(cdf, 1, pair).view(R, N_importance, 2)
+        bins_g = torch.gather(bins, 1, pair).view(R, N_importance, 2)
+        denom = cdf_g[..., 1] - cdf_g[..., 0]
+        denom[denom < eps] = 1          # empty bin: never drawn, any value works
+        return bins_g[..., 0] + (u - cdf_g[..., 0]) / denom * (bins_g[..., 1] - bins_g[..., 0])

@@ -1,0 +1,169 @@
+/*
+ * gnerf_hip.h -- C ABI of libgnerf_hip.so, the MI355X (gfx950) implementation of G-NeRF's
+ * hot path: the tri-plane importance renderer and the StyleGAN custom ops.
+ *
+ * Plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host".
+ * All entry points enqueue work on `stream` (a hipStream_t passed as void*) and return
+ * immediately; they return 0 on success and a negative GNERF_E_* code on failure
+ * (gnerf_last_error() then holds a message for the calling thread).  No entry point
+ * allocates, frees or synchronises, so all of them are hipGraph-capturable.
+ *
+ * Reference interfaces replaced (paths relative to the reference's g_nerf/):
+ *   gnerf_bias_act          <- bias_act_plugin.bias_act            torch_utils/ops/bias_act.cpp:36
+ *   gnerf_upfirdn2d         <- upfirdn2d_plugin.upfirdn2d          torch_utils/ops/upfirdn2d.cpp:20
+ *   gnerf_filtered_lrelu    <- filtered_lrelu_plugin.filtered_lrelu      torch_utils/ops/filtered_lrelu.cpp:20
+ *   gnerf_filtered_lrelu_act<- filtered_lrelu_plugin.filtered_lrelu_act_ torch_utils/ops/filtered_lrelu.cpp:217
+ *   gnerf_render_forward    <- ImportanceRenderer.forward          training/volumetric_rendering/renderer.py:88-140
+ *                              (pure PyTorch in the reference; there is no native counterpart)
+ *   gnerf_query_points      <- ImportanceRenderer.run_model        training/volumetric_rendering/renderer.py:142-148
+ *   gnerf_make_rays         <- RaySampler.forward                  training/volumetric_rendering/ray_sampler.py:24-63
+ *   gnerf_planes_to_nhwc    <- (layout change feeding the renderer; the reference keeps NCHW, triplane.py:74)
+ */
+#ifndef GNERF_HIP_H
+#define GNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNERF_ABI_VERSION 1
+
+/* error codes */
+#define GNERF_OK            0
+#define GNERF_E_ARG        -1   /* invalid argument (shape, size, null pointer, unsupported value) */
+#define GNERF_E_LAUNCH     -2   /* HIP reported an error at launch */
+#define GNERF_E_UNSUPPORTED -3  /* valid request, but no kernel for it (caller may use a generic path) */
+
+/* element types of activation tensors */
+#define GNERF_F32 0
+#define GNERF_F16 1
+#define GNERF_F64 2
+
+typedef void* gnerf_stream_t;   /* hipStream_t */
+
+int         gnerf_abi_version(void);
+const char* gnerf_last_error(void);          /* thread-local, host pointer */
+const char* gnerf_build_info(void);          /* e.g. "gfx950 hipcc ..." , host pointer */
+
+/* ------------------------------------------------------------------------------------------
+ * bias_act.  y = clamp(act(x + b) * gain)  and its first / second derivative forms.
+ * Same contract as bias_act.cpp:36-94: x dense with `numel` elements in any memory format;
+ * b has size_b elements and element i of x uses b[(i / step_b) % size_b] (step_b = stride of
+ * the bias dimension); absent tensors are NULL.  grad: 0 forward (x = input),
+ * 1 first order (x = dy, needs xref or yref as the activation dictates),
+ * 2 second order (x = d_dx, dy = the first-order incoming gradient).
+ * act: 1 linear 2 relu 3 lrelu 4 tanh 5 sigmoid 6 elu 7 selu 8 softplus 9 swish.
+ * clamp < 0 disables clamping. */
+int gnerf_bias_act(const void* x, const void* b, const void* xref, const void* yref, const void* dy,
+                   void* y, int dtype, int64_t numel, int size_b, int64_t step_b,
+                   int grad, int act, float alpha, float gain, float clamp, gnerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * upfirdn2d.  Zero-insert upsample, pad/crop, 2-D FIR, decimate (upfirdn2d.cpp:20-102).
+ * x: [n, c, in_h, in_w] with element strides xs[4] = {stride_n, stride_c, stride_h, stride_w}
+ * (NCHW and channels_last both allowed); y likewise with ys[4]; f: float32 [fh, fw] with
+ * element strides fs[2] = {stride_h, stride_w}.
+ * out_h = (in_h*upy + pady0 + pady1 - fh + downy) / downy, out_w likewise; the caller
+ * allocates y with that shape (only pad*0 is needed by the kernel). */
+int gnerf_upfirdn2d(const void* x, const float* f, void* y, int dtype,
+                    int n, int c, int in_h, int in_w, const int64_t xs[4],
+                    int fh, int fw, const int64_t fs[2],
+                    int out_h, int out_w, const int64_t ys[4],
+                    int upx, int upy, int downx, int downy, int padx0, int pady0,
+                    int flip, float gain, gnerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * filtered_lrelu_act_: in-place gain * lrelu * clamp on x [n,c,h,w] (strides xs) with the
+ * bit-packed 2-bit sign tensor (1 = negative, 2 = clamped; 4 pixels per byte, row pitch
+ * s_w/4 bytes, s_w a multiple of 16) -- filtered_lrelu.cpp:217-294.
+ * mode: 0 no signs, 1 write signs to s, 2 read signs from s (then x *= per-sign factor).
+ * sx, sy: offset of x inside the sign tensor. */
+int gnerf_filtered_lrelu_act(void* x, uint8_t* s, int dtype, int n, int c, int h, int w,
+                             const int64_t xs[4], int s_h, int s_w, int sx, int sy,
+                             float gain, float slope, float clamp, int mode, gnerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Tri-plane layout change: NCHW float32 [np, c, h, w] -> NHWC [np, h, w, c] (np = 3*batch).
+ * The renderer reads whole 128-byte texels (32 channels) from the NHWC copy. */
+int gnerf_planes_to_nhwc(const float* planes_nchw, float* planes_nhwc, int np, int c, int h, int w,
+                         gnerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Ray generation (ray_sampler.py:24-63): cam2world [n,4,4], intrinsics [n,3,3] row-major ->
+ * origins, dirs [n, res*res, 3]; ray m = row*res + col looks through pixel centre
+ * ((col+.5)/res, (row+.5)/res). */
+int gnerf_make_rays(const float* cam2world, const float* intrinsics, int n, int res,
+                    float* origins, float* dirs, gnerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The fused renderer (renderer.py:88-140 with MipRayMarcher2, ray_marcher.py:25-57, and the
+ * OSGDecoder MLP, triplane.py:113-136, inside).  One launch does, per ray: stratified depth
+ * proposals, tri-plane bilinear lookups, the 32->64->33 MLP on the matrix cores, the coarse
+ * ray march, importance resampling, the fine pass, the depth merge and the final composite.
+ */
+typedef struct gnerf_render_params {
+    /* planes, NHWC float32 [n_items*3, plane_h, plane_w, 32] (see gnerf_planes_to_nhwc) */
+    const float* planes_nhwc;
+    int32_t n_items, plane_h, plane_w;
+    /* rays: [n_items, rays_per_item, 3] float32 each */
+    const float* ray_origins;
+    const float* ray_dirs;
+    int32_t rays_per_item;
+    int32_t image_width;        /* >0: rays of an item form a row-major image of this width (locality hint only) */
+    /* decoder: EFFECTIVE weights (FullyConnectedLayer gains folded in, networks_stylegan2.py:118-127),
+       row-major w1 [64,32], b1 [64], w2 [33,64], b2 [33]; output 0 is the density */
+    const float* w1; const float* b1; const float* w2; const float* b2;
+    /* sampling options (rendering_kwargs, renderer.py:91-116) */
+    int32_t depth_resolution;             /* coarse samples per ray, 2..GNERF_MAX_SAMPLES */
+    int32_t depth_resolution_importance;  /* fine samples per ray, 0..GNERF_MAX_SAMPLES */
+    float   ray_start, ray_end;           /* used when ray_start_per_ray is NULL */
+    const float* ray_start_per_ray;       /* optional [n_items*rays_per_item] ('auto' box limits, renderer.py:93-98) */
+    const float* ray_end_per_ray;
+    float   box_warp;
+    int32_t white_back;                   /* ray_marcher.py:52-53 */
+    int32_t disparity_space_sampling;     /* renderer.py:174-181 */
+    /* uniform [0,1) draws, in the reference's order: noise_coarse = rand_like([n,m,S,1]) as [n*m, S],
+       noise_fine = rand(n*m, F) (renderer.py:190 and :241).  noise_fine may be NULL iff F == 0 */
+    const float* noise_coarse;
+    const float* noise_fine;
+    /* outputs */
+    float* out_rgb;      /* [n_items, rays_per_item, 32]  in (-1,1) */
+    float* out_depth;    /* [n_items, rays_per_item, 1] */
+    float* out_wsum;     /* [n_items, rays_per_item, 1]   sum of the final weights */
+    /* workspace of gnerf_render_workspace_bytes() bytes (holds the call-wide depth range used by the
+       global clamp of ray_marcher.py:49-50) */
+    void*  workspace;
+    /* optional stage dump for debugging/parity: float32 [n*m, GNERF_DEBUG_SLOTS, S+F]; NULL in production */
+    float* debug;
+} gnerf_render_params;
+
+#define GNERF_MAX_SAMPLES   256
+#define GNERF_DEBUG_SLOTS   8
+/* debug slots */
+#define GNERF_DBG_DEPTH_COARSE 0
+#define GNERF_DBG_SIGMA_COARSE 1
+#define GNERF_DBG_WEIGHT_COARSE 2
+#define GNERF_DBG_DEPTH_FINE   3
+#define GNERF_DBG_SIGMA_FINE   4
+#define GNERF_DBG_DEPTH_SORTED 5
+#define GNERF_DBG_SIGMA_SORTED 6
+#define GNERF_DBG_WEIGHT_FINAL 7
+
+size_t gnerf_render_workspace_bytes(void);
+int    gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t stream);
+
+/* Density / colour of arbitrary points (run_model, renderer.py:142-148; used by
+ * TriPlaneGenerator.sample / sample_mixed for shape extraction):
+ * points [n_items, n_points, 3] -> sigma [n_items, n_points, 1], rgb [n_items, n_points, 32]. */
+int gnerf_query_points(const float* planes_nhwc, int n_items, int plane_h, int plane_w,
+                       const float* points, int n_points, float box_warp,
+                       const float* w1, const float* b1, const float* w2, const float* b2,
+                       float* out_sigma, float* out_rgb, gnerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNERF_HIP_H */

@@ -177,6 +177,15 @@ def make_stage_cases():
     uv = project_onto_planes(generate_planes(), pts * 2.0)
     feats = sample_from_planes(generate_planes(), planes, pts, padding_mode='zeros', box_warp=1)
     out.update(proj_points=np_(pts), proj_uv=np_(uv), lookup_planes=np_(planes), lookup_out=np_(feats))
+    # ray/box limits ('auto' ray_start/ray_end, math_utils.py:47-98): hits, misses, axis-parallel rays
+    from training.volumetric_rendering import math_utils
+    bo = (torch.rand(1, 30, 3) - 0.5) * 4
+    bd = torch.nn.functional.normalize(torch.randn(1, 30, 3), dim=-1)
+    bd[0, :10] = torch.nn.functional.normalize(-bo[0, :10] + 0.2 * torch.randn(10, 3), dim=-1)   # aimed at the box
+    bd[0, 10] = torch.tensor([0., 0., 1.]); bo[0, 10] = torch.tensor([0.1, -0.2, -3.])
+    bd[0, 11] = torch.tensor([1., 0., 0.]); bo[0, 11] = torch.tensor([-3., 0.7, 0.])
+    tmin, tmax = math_utils.get_ray_limits_box(bo, bd, box_side_length=1.0)
+    out.update(box_origins=np_(bo), box_dirs=np_(bd), box_tmin=np_(tmin), box_tmax=np_(tmax))
     np.savez(os.path.join(HERE, 'stages.npz'), **out)
     print('stages.npz', sorted(out))
 

@@ -1,0 +1,253 @@
+"""CPU tests: the C-ABI library loads and exports what include/gnerf_hip.h declares; the drop-in
+Python modules (PyTorch-op paths, i.e. what the reference does for CPU tensors) reproduce the golden
+vectors; the overlay packages resolve the way the reference's imports need."""
+
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, 'include', 'gnerf_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(gnerf_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import gnerf_hip
+    names = _declared_functions()
+    assert 'gnerf_render_forward' in names and 'gnerf_bias_act' in names and 'gnerf_upfirdn2d' in names
+    lib = gnerf_hip.load()          # raises if the .so is missing: there is no fallback
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in gnerf_hip.h but not exported'
+        assert n in gnerf_hip.SIGNATURES, f'{n} has no ctypes signature'
+    assert sorted(gnerf_hip.SIGNATURES) == names
+    assert lib.gnerf_abi_version() == 1
+    assert b'gfx950' in lib.gnerf_build_info()
+
+
+def test_render_params_struct_matches_header():
+    """Field order of the ctypes mirror == field order of struct gnerf_render_params."""
+    import gnerf_hip
+    text = open(os.path.join(ROOT, 'include', 'gnerf_hip.h')).read()
+    body = text[text.index('typedef struct gnerf_render_params {'):text.index('} gnerf_render_params;')]
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    fields = []
+    for stmt in body.split('{', 1)[1].split(';'):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        for part in stmt.split(','):
+            fields.append(re.findall(r'[A-Za-z_0-9]+', part)[-1])
+    assert fields == [f[0] for f in gnerf_hip.RenderParams._fields_]
+
+
+def test_gpu_ops_refuse_cpu_tensors():
+    """The native entry points never compute on the host."""
+    import gnerf_hip
+    x = torch.zeros(4, 4)
+    with pytest.raises(RuntimeError):
+        gnerf_hip.bias_act(x, None, None, None, None, 0, 1, 1, 0.0, 1.0, -1.0)
+    with pytest.raises(RuntimeError):
+        gnerf_hip.planes_to_nhwc(torch.zeros(3, 32, 4, 4))
+
+
+# ---------------------------------------------------------------------------- drop-in modules on CPU
+
+
+class _Replay:
+    """Feed recorded noise to torch.rand_like / torch.rand (the reference's two draws)."""
+
+    def __init__(self, draws):
+        self.draws = list(draws)
+
+    def __enter__(self):
+        self._rl, self._r = torch.rand_like, torch.rand
+        torch.rand_like = lambda t, **k: self.draws.pop(0).reshape(t.shape).to(t.dtype)
+        torch.rand = lambda *a, **k: self.draws.pop(0)
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand_like, torch.rand = self._rl, self._r
+
+
+class _FC(torch.nn.Module):
+    """FullyConnectedLayer stand-in with the attributes the renderer inspects (networks_stylegan2.py:101-134)."""
+
+    def __init__(self, w, b, lr_mul):
+        super().__init__()
+        self.weight = torch.nn.Parameter(w, requires_grad=False)
+        self.bias = torch.nn.Parameter(b, requires_grad=False)
+        self.activation = 'linear'
+        self.weight_gain = lr_mul / np.sqrt(w.shape[1])
+        self.bias_gain = lr_mul
+
+    def forward(self, x):
+        return torch.addmm((self.bias * self.bias_gain).unsqueeze(0), x, (self.weight * self.weight_gain).t())
+
+
+class Decoder(torch.nn.Module):
+    """OSGDecoder stand-in (triplane.py:113-136)."""
+
+    def __init__(self, g):
+        super().__init__()
+        lr = float(g['lr_mul'])
+        self.net = torch.nn.Sequential(_FC(torch.from_numpy(g['w1']), torch.from_numpy(g['b1']), lr), torch.nn.Softplus(),
+                                       _FC(torch.from_numpy(g['w2']), torch.from_numpy(g['b2']), lr))
+
+    def forward(self, feats, dirs):
+        x = feats.mean(1)
+        N, M, C = x.shape
+        x = self.net(x.view(N * M, C)).view(N, M, -1)
+        return {'rgb': torch.sigmoid(x[..., 1:]) * (1 + 2 * 0.001) - 0.001, 'sigma': x[..., 0:1]}
+
+
+def options_of(g):
+    return dict(depth_resolution=int(g['depth_resolution']), depth_resolution_importance=int(g['depth_resolution_importance']),
+                ray_start=float(g['ray_start']), ray_end=float(g['ray_end']), box_warp=float(g['box_warp']), clamp_mode='softplus',
+                white_back=bool(g['white_back']), disparity_space_sampling=bool(g['disparity']),
+                superresolution_module='ignored', c_gen_conditioning_zero=True)     # unknown keys must be ignored
+
+
+@pytest.mark.parametrize('case', ['render_s12.npz', 'render_s48.npz', 'render_misc.npz', 'render_nofine.npz'])
+def test_renderer_torch_path_matches_reference(golden, case):
+    from training.volumetric_rendering.renderer import ImportanceRenderer
+    g = golden(case)
+    ren = ImportanceRenderer()
+    draws = [torch.from_numpy(g['noise_coarse'])] + ([torch.from_numpy(g['noise_fine'])] if 'noise_fine' in g else [])
+    with torch.no_grad(), _Replay(draws):
+        rgb, depth, wsum = ren(torch.from_numpy(g['planes']), Decoder(g), torch.from_numpy(g['ray_origins']),
+                               torch.from_numpy(g['ray_dirs']), options_of(g))
+    np.testing.assert_allclose(rgb.numpy(), g['out_rgb'], atol=2e-6)
+    np.testing.assert_allclose(depth.numpy(), g['out_depth'], atol=2e-6)
+    np.testing.assert_allclose(wsum.numpy(), g['out_wsum'], atol=2e-6)
+
+
+def test_renderer_survives_unpickling_without_init(golden):
+    """legacy.py:68-72 revives ImportanceRenderer by class name WITHOUT calling __init__: only the pickled
+    attributes exist.  The replacement must cope (lazy state only)."""
+    import pickle
+    from training.volumetric_rendering.renderer import ImportanceRenderer
+    blob = pickle.dumps(ImportanceRenderer())
+    ren = pickle.loads(blob)
+    assert '_gnerf_planes_cache' not in ren.__dict__
+    g = golden('render_nofine.npz')
+    with torch.no_grad(), _Replay([torch.from_numpy(g['noise_coarse'])]):
+        rgb, _, _ = ren(torch.from_numpy(g['planes']), Decoder(g), torch.from_numpy(g['ray_origins']), torch.from_numpy(g['ray_dirs']), options_of(g))
+    np.testing.assert_allclose(rgb.numpy(), g['out_rgb'], atol=2e-6)
+
+
+def test_ray_sampler_and_marcher_cpu(golden):
+    from training.volumetric_rendering.ray_sampler import RaySampler
+    from training.volumetric_rendering.ray_marcher import MipRayMarcher2
+    g = golden('camera.npz')
+    o, d = RaySampler()(torch.from_numpy(g['rs_cam2world']), torch.from_numpy(g['rs_intrinsics']), int(g['rs_res']))
+    np.testing.assert_allclose(o.numpy(), g['rs_origins'], atol=0)
+    np.testing.assert_allclose(d.numpy(), g['rs_dirs'], atol=1e-7)
+    s = golden('stages.npz')
+    for wb in (0, 1):
+        rgb, depth, w = MipRayMarcher2()(torch.from_numpy(s['march_colors']), torch.from_numpy(s['march_sigma']),
+                                         torch.from_numpy(s['march_depths']), {'clamp_mode': 'softplus', 'white_back': bool(wb)})
+        np.testing.assert_allclose(rgb.numpy(), s[f'march_rgb_wb{wb}'], atol=1e-6)
+        np.testing.assert_allclose(depth.numpy(), s[f'march_depth_wb{wb}'], atol=1e-6)
+        np.testing.assert_allclose(w.numpy(), s[f'march_w_wb{wb}'], atol=1e-7)
+
+
+def test_ray_limits_box(golden):
+    from training.volumetric_rendering import math_utils
+    s = golden('stages.npz')
+    lo, hi = math_utils.get_ray_limits_box(torch.from_numpy(s['box_origins']), torch.from_numpy(s['box_dirs']), box_side_length=1.0)
+    np.testing.assert_allclose(lo.numpy(), s['box_tmin'], atol=0)
+    np.testing.assert_allclose(hi.numpy(), s['box_tmax'], atol=0)
+    assert (s['box_tmin'] == -1).any() and (s['box_tmin'] > 0).any()
+    lin = math_utils.linspace(torch.tensor([1.0, 2.0]), torch.tensor([3.0, 6.0]), 5)
+    np.testing.assert_allclose(lin.numpy(), np.linspace([1, 2], [3, 6], 5), atol=1e-6)
+
+
+def test_ops_ref_paths_match_reference(golden):
+    from torch_utils.ops import bias_act, upfirdn2d, filtered_lrelu
+    g = golden('ops.npz')
+    x, b = torch.from_numpy(g['ba_x']), torch.from_numpy(g['ba_b'])
+    for act in bias_act.activation_funcs:
+        y = bias_act.bias_act(x, b, act=act, clamp=0.9)      # CPU tensor -> PyTorch ops, like the reference
+        np.testing.assert_allclose(y.numpy(), g[f'ba_{act}_c_y'], rtol=1e-12, atol=1e-12)
+    xu = torch.from_numpy(g['up_x'])
+    f4 = upfirdn2d.setup_filter([1, 3, 3, 1])
+    np.testing.assert_allclose(f4.numpy(), g['up_f4'], rtol=1e-7)
+    np.testing.assert_allclose(upfirdn2d.upfirdn2d(xu, f4, padding=[1, 1, 1, 1], gain=4).numpy(), g['up_blur'], atol=1e-6)
+    np.testing.assert_allclose(upfirdn2d.upsample2d(xu, f4).numpy(), g['up_upsample2d'], atol=1e-6)
+    np.testing.assert_allclose(upfirdn2d.downsample2d(xu, f4).numpy(), g['up_downsample2d'], atol=1e-6)
+    np.testing.assert_allclose(upfirdn2d.filter2d(xu, f4).numpy(), g['up_filter2d'], atol=1e-6)
+    fs = torch.from_numpy(g['up_fs'])
+    np.testing.assert_allclose(upfirdn2d.upfirdn2d(xu, fs, up=2, down=3, padding=[4, 3, 5, 2], gain=2.0).numpy(), g['up_sep'], atol=2e-6)
+    xf, bf = torch.from_numpy(g['fl_x']), torch.from_numpy(g['fl_b'])
+    fu, fd = torch.from_numpy(g['fl_fu']), torch.from_numpy(g['fl_fd'])
+    y = filtered_lrelu.filtered_lrelu(xf, fu=fu, fd=fd, b=bf, up=2, down=2, padding=[10, 10, 10, 10], gain=1.3, slope=0.1, clamp=0.8)
+    np.testing.assert_allclose(y.numpy(), g['fl_up2_down2'], atol=2e-6)
+    assert upfirdn2d._parse_padding(3) == (3, 3, 3, 3) and upfirdn2d._get_filter_size(f4) == (4, 4)
+
+
+def test_grid_sample_gradfix_double_backward():
+    from torch_utils.ops import grid_sample_gradfix
+    torch.manual_seed(0)
+    img = torch.randn(1, 2, 5, 6, dtype=torch.float64, requires_grad=True)
+    grid = (torch.rand(1, 3, 4, 2, dtype=torch.float64) * 2.4 - 1.2)
+    ref = torch.nn.functional.grid_sample(img, grid, mode='bilinear', padding_mode='zeros', align_corners=False)
+    grid_sample_gradfix.enabled = True
+    try:
+        out = grid_sample_gradfix.grid_sample(img, grid)
+        np.testing.assert_allclose(out.detach().numpy(), ref.detach().numpy(), atol=1e-12)
+        gout = torch.randn_like(out).requires_grad_(True)
+        (gi,) = torch.autograd.grad(out, img, gout, create_graph=True)
+        (gg,) = torch.autograd.grad(gi.square().sum(), gout)          # second order w.r.t. grad_output
+        (gi_ref,) = torch.autograd.grad(ref, img, gout.detach())
+        np.testing.assert_allclose(gi.detach().numpy(), gi_ref.numpy(), atol=1e-12)
+        assert gg.abs().sum() > 0
+    finally:
+        grid_sample_gradfix.enabled = False
+
+
+def test_custom_ops_plugin_surface():
+    from torch_utils import custom_ops
+    custom_ops.verbosity = 'none'
+    p = custom_ops.get_plugin('bias_act_plugin', sources=['x.cpp'], headers=['x.h'], source_dir='.', extra_cuda_cflags=['--use_fast_math'])
+    assert callable(p.bias_act)
+    assert callable(custom_ops.get_plugin('upfirdn2d_plugin').upfirdn2d)
+    fl = custom_ops.get_plugin('filtered_lrelu_plugin')
+    assert callable(fl.filtered_lrelu) and callable(fl.filtered_lrelu_act_)
+    with pytest.raises(RuntimeError):
+        custom_ops.get_plugin('no_such_plugin')
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/g_nerf'), reason='reference tree only exists in the build container')
+def test_overlay_resolves_reference_modules():
+    """With g-nerf_amd/ BEFORE the reference's g_nerf/ on sys.path, hot-path modules come from this repo
+    and everything else (persistence, misc, conv2d_resample, triplane ...) from the reference -- the
+    drop-in arrangement INTEGRATION.md describes.  Run in a child process to keep sys.path clean."""
+    code = r'''
+import sys, types, torch
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference/g_nerf"); sys.path.insert(0, %r)
+tvr = types.ModuleType("torchvision.models.resnet"); tvr.ResNet = type("ResNet", (torch.nn.Module,), {}); tvr.Bottleneck = type("B", (torch.nn.Module,), {})
+sys.modules.update({"torchvision": types.ModuleType("torchvision"), "torchvision.models": types.ModuleType("torchvision.models"), "torchvision.models.resnet": tvr})
+import torch_utils.ops.bias_act as ba, torch_utils.persistence as pe, torch_utils.ops.conv2d_resample as cr
+import training.volumetric_rendering.renderer as rr, training.triplane as tp
+assert "g-nerf_amd" in ba.__file__ and "g-nerf_amd" in rr.__file__, (ba.__file__, rr.__file__)
+assert "/root/reference" in pe.__file__ and "/root/reference" in cr.__file__ and "/root/reference" in tp.__file__
+assert tp.ImportanceRenderer is rr.ImportanceRenderer
+import torch_utils.ops.upfirdn2d as up
+assert cr.upfirdn2d is up and "g-nerf_amd" in up.__file__
+dec = tp.OSGDecoder(32, {"decoder_lr_mul": 1, "decoder_output_dim": 32})
+assert rr._osg_decoder_weights(dec) is not None
+print("overlay ok")
+''' % os.path.join(ROOT, 'g-nerf_amd')
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, cwd='/tmp')
+    assert out.returncode == 0 and 'overlay ok' in out.stdout, out.stderr[-2000:]
