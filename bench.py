@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/sec of the tri-plane importance renderer on BASELINE.json's config 2
+(renderer-only: 128x128 rays x (48+48) samples, 32-channel 256x256 tri-planes, batch 4 per GPU).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch, exactly what ImportanceRenderer.forward does per
+call on the GPU: ray generation from the cameras, the NCHW->NHWC plane layout change, the reference's two
+uniform draws (torch.rand, same shapes/order as renderer.py:190/:241), and the fused render kernel
+(+ its depth-clamp epilogue).  Inputs (planes, decoder, cameras) are resident in HBM before the timed
+region.  Rays shard embarrassingly: each rank renders its own batch (weak scaling, no data-path
+collective); the only collectives are the barriers bracketing the timed region and the max-reduce of
+the elapsed time.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = render_kernel, timed with HIP events
+on the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample
+of the same workload, on this host's cores).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, 'g-nerf_amd'), ROOT]
+
+import torch  # noqa: E402
+
+# config 2 (BASELINE.json / SURVEY.md section 8d)
+N_ITEMS, RES, S_COARSE, S_FINE, PLANE = 4, 128, 48, 48, 256
+RAY_START, RAY_END, BOX_WARP = 2.25, 3.3, 1.0
+
+# Algorithmic work per ray (DESIGN.md "Roofline accounting")
+FLOP_MLP_PER_SAMPLE = 2 * 32 * 64 + 2 * 64 * 33           # 8320, the MFMA-eligible contraction
+GATHER_BYTES_PER_SAMPLE = 12 * 32 * 4                     # 12 bilinear taps x 32 fp32 channels (cache-level traffic)
+PEAK_FP32_MFMA_TFLOPS = 157.3                             # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
+PEAK_HBM_GBS = 8000.0
+
+
+def hbm_bytes_per_call(n_items, rays, s, f, plane):
+    planes = n_items * 3 * 32 * plane * plane * 4
+    return planes + rays * 3 * 4 * 2 + rays * (s + f) * 4 + rays * 34 * 4 + (64 * 32 + 64 + 33 * 64 + 33) * 4
+
+
+def _scene(dev, seed, n_items=N_ITEMS, plane=PLANE):
+    """Synthetic inputs of BASELINE.md section 2: randn planes, default-init OSGDecoder (W~N(0,1), b=0, gains
+    folded), cameras LookAtPoseSampler.sample(3.14/2, 3.14/2, radius=2.7), FFHQ intrinsics."""
+    import math
+    gen = torch.Generator().manual_seed(seed)
+    planes = torch.randn(n_items, 3, 32, plane, plane, generator=gen)
+    w1 = torch.randn(64, 32, generator=gen) / math.sqrt(32)
+    w2 = torch.randn(33, 64, generator=gen) / math.sqrt(64)
+    dec = (w1, torch.zeros(64), w2, torch.zeros(33))
+    # camera_utils.py:89-106,155-174 for yaw = pitch = 3.14/2, radius 2.7 (values pinned by tests/golden/camera.npz)
+    theta, phi, r = 3.14 / 2, 3.14 / 2, 2.7
+    org = torch.tensor([r * math.sin(phi) * math.cos(math.pi - theta), r * math.cos(phi), r * math.sin(phi) * math.sin(math.pi - theta)])
+    fwd = -org / org.norm()
+    up = torch.tensor([0.0, 1.0, 0.0])
+    right = -torch.linalg.cross(up, fwd)
+    right = right / right.norm()
+    up2 = torch.linalg.cross(fwd, right)
+    up2 = up2 / up2.norm()
+    c2w = torch.eye(4)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, up2, fwd, org
+    c2w = c2w[None].repeat(n_items, 1, 1)
+    intr = torch.tensor([[4.2647, 0, 0.5], [0, 4.2647, 0.5], [0, 0, 1]])[None].repeat(n_items, 1, 1)
+    return planes.to(dev), tuple(t.to(dev) for t in dec), c2w.to(dev), intr.to(dev)
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The CPU oracle (a port of the reference's PyTorch path, pinned to it by tests/golden) on config 2 itself
+    (4 items x 128x128 rays, 48+48 samples, 256x256x32 planes), using every host core torch sees.  Bounded:
+    1 warm-up + up to 3 timed passes, stopping once `seconds_budget` is spent."""
+    from oracle import render_ref as R
+    torch.manual_seed(0)
+    planes, dec, c2w, intr = _scene(torch.device('cpu'), 0)
+    o, d = R.make_rays(c2w, intr, RES)
+    rays = N_ITEMS * RES * RES
+    opts = dict(depth_resolution=S_COARSE, depth_resolution_importance=S_FINE, ray_start=RAY_START, ray_end=RAY_END,
+                box_warp=BOX_WARP, clamp_mode='softplus')
+    times = []
+    t_all = time.time()
+    for it in range(4):
+        nc, nf = torch.rand(N_ITEMS, RES * RES, S_COARSE), torch.rand(rays, S_FINE)
+        t0 = time.time()
+        with torch.no_grad():
+            R.render(planes, dec, o, d, opts, nc, nf)
+        times.append(time.time() - t0)
+        if time.time() - t_all > seconds_budget:
+            break
+    timed = sorted(times[1:] or times)
+    return {'value': rays / timed[len(timed) // 2], 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'config 2 whole batch ({rays} rays, 48+48 samples, 4x3x32x256x256 planes); median of {len(timed)} '
+                      f'pass(es) after 1 warm-up, torch {torch.__version__} CPU fp32, {torch.get_num_threads()} threads'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N>1)'
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    import gnerf_hip
+    gnerf_hip.load()                    # raises if libgnerf_hip.so is missing: no fallback
+    planes, dec, c2w, intr = _scene(dev, seed=1000 + rank)
+    torch.manual_seed(rank)
+    rays_per_call = N_ITEMS * RES * RES
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        o, d = gnerf_hip.make_rays(c2w, intr, RES)
+        nhwc = gnerf_hip.planes_to_nhwc(planes)
+        noise_c = torch.rand([N_ITEMS, RES * RES, S_COARSE, 1], device=dev)
+        noise_f = torch.rand(N_ITEMS * RES * RES, S_FINE, device=dev)
+        if i is not None:
+            ev[i][0].record()
+        out = gnerf_hip.render_forward(nhwc, N_ITEMS, dec, o, d, noise_c, noise_f, depth_resolution=S_COARSE,
+                                       depth_resolution_importance=S_FINE, ray_start=RAY_START, ray_end=RAY_END,
+                                       box_warp=BOX_WARP, image_width=RES)
+        if i is not None:
+            ev[i][1].record()
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out[0]).all()
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps      # render_kernel (+2 one-block helpers), same stream
+
+    if rank == 0:
+        total_rays = rays_per_call * args.steps * world
+        samples = rays_per_call * (S_COARSE + S_FINE)
+        flops = samples * FLOP_MLP_PER_SAMPLE
+        k_s = kernel_ms * 1e-3
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.isfile(tpath):
+            traffic = json.load(open(tpath)).get('render_kernel_hbm_bytes_per_launch')
+        line = {
+            'metric': 'rays/sec at 128^2 neural render, 96 depth samples',
+            'value': total_rays / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'config 2: renderer-only, 128x128 rays x (48+48) samples, 3x32x256x256 fp32 tri-planes, batch 4 per GPU; '
+                                   'step = make_rays + NCHW->NHWC planes + 2 torch.rand draws + fused render kernel',
+                       'rays_per_step_per_gpu': rays_per_call, 'parallelism': f'rays sharded over {world} GPU(s), no data-path collective'},
+            'roofline': {
+                'kernel': 'render_kernel', 'bound': 'mfma',
+                'achieved': flops / k_s / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': flops / k_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                'kernel_ms': kernel_ms,
+                'note': 'exact-fp32 MLP on v_mfma_f32_16x16x4_f32: 8320 algorithmic FLOP/sample x 96 samples/ray; '
+                        'the kernel is MFMA/VALU/gather-bound, not HBM-bound (430 FLOP/B)',
+                'hbm_algorithmic_GBs': hbm_bytes_per_call(N_ITEMS, rays_per_call, S_COARSE, S_FINE, PLANE) / k_s / 1e9,
+                'hbm_frac_of_8TBs': hbm_bytes_per_call(N_ITEMS, rays_per_call, S_COARSE, S_FINE, PLANE) / k_s / 1e9 / PEAK_HBM_GBS,
+                'effective_gather_GBs': samples * GATHER_BYTES_PER_SAMPLE / k_s / 1e9,
+                'effective_gather_frac_of_8TBs': samples * GATHER_BYTES_PER_SAMPLE / k_s / 1e9 / PEAK_HBM_GBS,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline()
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

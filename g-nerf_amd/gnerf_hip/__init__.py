@@ -104,6 +104,16 @@ def _strides(t):
     return (ctypes.c_int64 * t.ndim)(*t.stride())
 
 
+def _is_dense(t):
+    """Non-overlapping and dense in SOME dimension order (what ATen's is_non_overlapping_and_dense checks)."""
+    expected = 1
+    for stride, size in sorted((st, sz) for sz, st in zip(t.shape, t.stride()) if sz != 1):
+        if stride != expected:
+            return False
+        expected *= size
+    return True
+
+
 def _require_cuda(*tensors):
     for t in tensors:
         if t is not None and t.device.type != 'cuda':
@@ -122,7 +132,7 @@ def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
     _require_cuda(x, b, xref, yref, dy)
     if x.dtype not in _DTYPE_CODE:
         raise RuntimeError(f'bias_act: unsupported dtype {x.dtype}')
-    if not x.is_non_overlapping_and_dense():
+    if not _is_dense(x):
         raise RuntimeError('bias_act: x must be non-overlapping and dense')
     for name, t in (('xref', xref), ('yref', yref), ('dy', dy)):
         if t is not None and (t.shape != x.shape or t.dtype != x.dtype or t.stride() != x.stride()):

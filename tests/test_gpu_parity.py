@@ -86,7 +86,7 @@ def test_render_golden_stage_by_stage(dev, golden, case):
     N, M = g['out_rgb'].shape[:2]
     S, F = int(g['depth_resolution']), int(g['depth_resolution_importance'])
     dbg = dbg.reshape(N, M, gnerf_hip.DEBUG_SLOTS, S + F)
-    np.testing.assert_allclose(dbg[:, :, 0, :S], g['depths_coarse'], rtol=0, atol=2.4e-7)
+    np.testing.assert_allclose(dbg[:, :, 0, :S], g['depths_coarse'], rtol=0, atol=5e-7)      # <= 2 ulp at depth ~3.5 (the disparity form divides)
     np.testing.assert_allclose(dbg[:, :, 1, :S], g['sigma_coarse'], rtol=1e-4, atol=5e-5)
     if F > 0:
         np.testing.assert_allclose(dbg[:, :, 2, :S - 1], g['weights_coarse'], rtol=1e-3, atol=2e-6)
@@ -290,6 +290,11 @@ def test_bias_act_all_activations_and_orders(dev, dtype):
             np.testing.assert_allclose(y.detach().double().cpu().numpy(), O.bias_act(xn, bn, 1, act, clamp=clamp), rtol=tol, atol=tol, err_msg=f'{act} fwd')
             dx, db = torch.autograd.grad(y, (x, b), dy0.to(dev), create_graph=True)
             ref_dx = O.bias_act_grad(dyn, xn, bn, 1, act, clamp=clamp)
+            if act == 'linear':
+                # Reference GPU-path quirk, kept for drop-in fidelity: 'linear' saves neither x nor y for backward
+                # (activation_funcs ref='', bias_act.py:23,155-158), so the plugin's clamp mask sees yref = 0 and
+                # passes every gradient (bias_act.cu:137-146) -- unlike autograd of the PyTorch-op path.
+                ref_dx = dyn.copy()
             np.testing.assert_allclose(dx.detach().double().cpu().numpy(), ref_dx, rtol=tol, atol=tol, err_msg=f'{act} dx')
             np.testing.assert_allclose(db.detach().double().cpu().numpy(), ref_dx.sum((0, 2, 3)), rtol=tol * 20, atol=tol * 20, err_msg=f'{act} db')
             if bias_act.activation_funcs[act].has_2nd_grad:
@@ -311,9 +316,11 @@ def test_bias_act_layouts_and_edges(dev):
     np.testing.assert_allclose(bias_act.bias_act(x2, b2, act='lrelu').cpu().numpy(), O.bias_act(x2.cpu().numpy(), b2.cpu().numpy(), 1, 'lrelu'), rtol=1e-6, atol=1e-6)
     x3 = torch.randn(1031, device=dev)                          # ragged tail, no bias, dim ignored
     np.testing.assert_allclose(bias_act.bias_act(x3, act='swish').cpu().numpy(), O.bias_act(x3.cpu().numpy(), None, 0, 'swish'), rtol=1e-5, atol=1e-6)
-    x4 = torch.randn(4, 3, 9, device=dev)[:, :, 1:]            # unaligned, non-dense view is rejected like the reference
-    with pytest.raises(RuntimeError):
-        bias_act.bias_act(x4, act='relu')
+    x4 = torch.randn(4, 3, 9, device=dev)[:, :, 1:]            # non-dense view: the op makes it contiguous first (bias_act.py:147)...
+    np.testing.assert_allclose(bias_act.bias_act(x4, act='relu').cpu().numpy(), np.maximum(x4.cpu().numpy(), 0) * np.sqrt(2), rtol=1e-6)
+    import gnerf_hip
+    with pytest.raises(RuntimeError):                           # ...the native entry point itself rejects it (bias_act.cpp:50)
+        gnerf_hip.bias_act(x4, None, None, None, None, 0, 1, 2, 0.0, 1.0, -1.0)
     x5 = torch.randn(40, device=dev)[1:]                       # dense but 4-byte aligned only: scalar kernel
     np.testing.assert_allclose(bias_act.bias_act(x5, act='tanh').cpu().numpy(), np.tanh(x5.cpu().numpy()), rtol=1e-5, atol=1e-6)
     assert bias_act.bias_act(torch.empty(0, 4, device=dev), act='relu').shape == (0, 4)
