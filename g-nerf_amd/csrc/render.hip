@@ -26,6 +26,8 @@
 //    publish their extrema with two integer atomics, and a tiny second kernel applies the clamp.
 
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -69,21 +71,45 @@ __device__ __forceinline__ float sigmoid_fast(float x) {
     return __frcp_rn(1.f + __expf(-x));
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// ---- wave-wide scans on the DPP network (row_shr within 16-lane rows, then row_bcast:15 / :31 across rows).
+// No LDS traffic and ALU latency only -- the ds_bpermute shuffles they replace cost an LDS round trip per step,
+// and these scans sit on the per-ray critical path (transmittance product, cdf).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_scan_add(float v, int /*lane*/) {         // inclusive
+    v += dpp_mov<0x111, 0xf>(0.f, v);
+    v += dpp_mov<0x112, 0xf>(0.f, v);
+    v += dpp_mov<0x114, 0xf>(0.f, v);
+    v += dpp_mov<0x118, 0xf>(0.f, v);
+    v += dpp_mov<0x142, 0xa>(0.f, v);
+    v += dpp_mov<0x143, 0xc>(0.f, v);
     return v;
 }
-// inclusive scans over the 64 lanes
-__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(v, o); if (lane >= o) v *= t; }
+__device__ __forceinline__ float wave_scan_mul(float v, int /*lane*/) {         // inclusive
+    v *= dpp_mov<0x111, 0xf>(1.f, v);
+    v *= dpp_mov<0x112, 0xf>(1.f, v);
+    v *= dpp_mov<0x114, 0xf>(1.f, v);
+    v *= dpp_mov<0x118, 0xf>(1.f, v);
+    v *= dpp_mov<0x142, 0xa>(1.f, v);
+    v *= dpp_mov<0x143, 0xc>(1.f, v);
     return v;
 }
-__device__ __forceinline__ float wave_scan_add(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(v, o); if (lane >= o) v += t; }
-    return v;
+__device__ __forceinline__ float wave_last(float v) {                            // lane 63's value, in every lane
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_shift_up(float v, float first) {           // lane i <- lane i-1, lane 0 <- first
+    return dpp_mov<0x138, 0xf>(first, v);
+}
+__device__ __forceinline__ float wave_sum(float v) { return wave_last(wave_scan_add(v, 0)); }
+
+// exp / softplus on the hardware exp2/log2 units (about 1 ulp each; absolute error ~1e-7 on the values used here)
+__device__ __forceinline__ float exp_hw(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float softplus_march(float x) {      // softplus with torch's threshold 20 (ray_marcher.py:33)
+    const float e = __builtin_amdgcn_exp2f(-fabsf(x) * 1.44269504088896341f);
+    const float sp = fmaf(__builtin_amdgcn_logf(1.0f + e), 0.693147180559945309f, fmaxf(x, 0.f));
+    return x > 20.f ? x : sp;
 }
 
 // Per-wave LDS carve-up (all float/int, 16-byte aligned pieces)
@@ -248,23 +274,22 @@ __device__ __forceinline__ void march(const float* t, const float* sig, float* w
         if (ok) {
             const float t0 = t[k], t1 = t[k + 1];
             const float delta = t1 - t0;
-            const float smid = softplus_f((sig[k] + sig[k + 1]) * 0.5f - 1.f);
+            const float smid = softplus_march((sig[k] + sig[k + 1]) * 0.5f - 1.f);
             tmid = (t0 + t1) * 0.5f;
-            alpha = 1.f - expf(-(smid * delta));
+            alpha = 1.f - exp_hw(-(smid * delta));
         }
         const float x = ok ? (1.f - alpha + 1e-10f) : 1.f;
         const float incl = wave_scan_mul(x, lane);
-        float excl = __shfl_up(incl, 1);
-        if (lane == 0) excl = 1.f;
+        const float excl = wave_shift_up(incl, 1.f);
         const float wk = alpha * (excl * carry);
-        carry *= __shfl(incl, 63);
+        carry *= wave_last(incl);
         if (ok) { w[k] = wk; acc_w += wk; acc_wt += wk * tmid; }
     }
     w_sum = wave_sum(acc_w);
     wt_sum = wave_sum(acc_wt);
 }
 
-__global__ __launch_bounds__(64, 2) void render_kernel(Params P) {
+__global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
     extern __shared__ __align__(16) float smem[];
     const gnerf_render_params& p = P.p;
     const int lane = threadIdx.x;
@@ -367,7 +392,7 @@ __global__ __launch_bounds__(64, 2) void render_kernel(Params P) {
                 const float pdf = (i < n_w) ? lds.s_sig[i] / total : 0.f;
                 const float incl = wave_scan_add(pdf, lane) + carry;
                 if (i < n_w) lds.cdf[i + 1] = incl;
-                carry = __shfl(incl, 63);
+                carry = wave_last(incl);
             }
             if (lane == 0) lds.cdf[0] = 0.f;
             __syncthreads();
@@ -560,6 +585,8 @@ __global__ __launch_bounds__(64) void query_kernel(gnerf_render_params p, float 
     }
 }
 
+#include "render_coop.inl"
+
 int check_common(const gnerf_render_params* p) {
     if (!p) return fail(GNERF_E_ARG, "render: params is null");
     if (!p->planes_nhwc || !p->w1 || !p->b1 || !p->w2 || !p->b2) return fail(GNERF_E_ARG, "render: planes and decoder weights must not be null");
@@ -609,19 +636,41 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         P.tiles_per_item = 0;
         P.n_tiles = int((total + kRaysPerWave - 1) / kRaysPerWave);
     }
-    const size_t lds_bytes = scratch_floats(16 * (P.tiles_c + P.tiles_f), P.tiles_c + P.tiles_f) * sizeof(float);
-    if (lds_bytes > 160 * 1024) return fail(GNERF_E_ARG, "render: %d+%d samples need %zu bytes of LDS (> 160 KiB)", S, F, lds_bytes);
     hipStream_t s = as_stream(stream);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return fail(GNERF_E_LAUNCH, "render: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
     hipLaunchKernelGGL(init_range_kernel, dim3(1), dim3(1), 0, s, static_cast<unsigned*>(p->workspace));
     const int per_xcd = (P.n_tiles + kNumXCD - 1) / kNumXCD;
-    hipLaunchKernelGGL(render_kernel, dim3(per_xcd * kNumXCD), dim3(64), lds_bytes, s, P);
-    if (int e = check_launch("render_kernel")) return e;
+    const dim3 grid(per_xcd * kNumXCD);
+    // Kernel choice: the cooperative 3-waves-per-ray kernel covers up to 96+96 samples (2 tiles per wave and
+    // pass); the one-wave-per-ray kernel covers everything else.  GNERF_RENDER_KERNEL=generic|coop forces one (A/B runs).
+    const char* force = getenv("GNERF_RENDER_KERNEL");
+    bool coop = P.tiles_c <= 2 * kCoopWaves && P.tiles_f <= 2 * kCoopWaves && int64_t(p->plane_h) * p->plane_w * 3 * 128 < (int64_t(1) << 32);
+    if (force && !strcmp(force, "generic")) coop = false;
+    if (force && !strcmp(force, "coop") && !coop) return fail(GNERF_E_UNSUPPORTED, "render: cooperative kernel does not cover %d+%d samples", S, F);
+    if (coop) {
+        const int tc1 = (P.tiles_c + kCoopWaves - 1) / kCoopWaves, tf1 = (P.tiles_f + kCoopWaves - 1) / kCoopWaves;
+        const size_t lds_bytes = coop_lds_floats(16 * (P.tiles_c + P.tiles_f)) * sizeof(float);
+        const dim3 block(kCoopThreads);
+#define GNERF_COOP(TC, TF) hipLaunchKernelGGL((render_kernel_coop<TC, TF>), grid, block, lds_bytes, s, P)
+        if (tc1 == 1 && tf1 == 0) GNERF_COOP(1, 0);
+        else if (tc1 == 1 && tf1 == 1) GNERF_COOP(1, 1);
+        else if (tc1 == 1 && tf1 == 2) GNERF_COOP(1, 2);
+        else if (tc1 == 2 && tf1 == 0) GNERF_COOP(2, 0);
+        else if (tc1 == 2 && tf1 == 1) GNERF_COOP(2, 1);
+        else GNERF_COOP(2, 2);
+#undef GNERF_COOP
+        if (int e = check_launch("render_kernel_coop")) return e;
+    } else {
+        const size_t lds_bytes = scratch_floats(16 * (P.tiles_c + P.tiles_f), P.tiles_c + P.tiles_f) * sizeof(float);
+        if (lds_bytes > 160 * 1024) return fail(GNERF_E_ARG, "render: %d+%d samples need %zu bytes of LDS (> 160 KiB)", S, F, lds_bytes);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_kernel_generic), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return fail(GNERF_E_LAUNCH, "render: cannot raise the dynamic LDS limit");
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(render_kernel_generic, grid, dim3(64), lds_bytes, s, P);
+        if (int e = check_launch("render_kernel_generic")) return e;
+    }
     hipLaunchKernelGGL(clamp_depth_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        p->out_depth, static_cast<const unsigned*>(p->workspace), total);
     return check_launch("clamp_depth_kernel");

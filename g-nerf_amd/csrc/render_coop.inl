@@ -1,0 +1,459 @@
+// Cooperative render kernel: THREE WAVES PER RAY.  Included by render.hip (inside its anonymous namespace).
+//
+// The one-wave-per-ray kernel (render_kernel_generic) is limited by what one wave must keep: ~100 VGPRs of
+// decoder weights plus 12 KiB of LDS for the colours of the 96 samples of its ray, which caps a CU at 8 waves,
+// and its instruction stream repeats the same tap-address arithmetic in all 8 lanes that share a sample.
+// Here a 192-lane workgroup owns one ray at a time and each wave shades every third 16-sample tile:
+//   * colours stay in REGISTERS (8 per tile per lane) until the final weights are known -- no LDS spill;
+//   * decoder weights live once per workgroup in LDS (padded rows, ds_read_b128 fragments right before the
+//     MFMAs that use them), so a wave needs < 128 VGPRs and a CU holds 12-15 waves;
+//   * bilinear tap addresses and weights are computed ONCE per (sample, plane) -- 48 lanes of a wave do the
+//     3 planes of 16 samples -- and handed to the 8 lanes that read a texel through a 96-byte LDS record;
+//   * plane texels are addressed as SGPR base + 32-bit VGPR offset (no 64-bit address arithmetic).
+// Per-sample scalars and the merge work exactly as in the generic kernel, spread over the 192 lanes.
+// Instantiated for <= 1 or 2 tiles per wave and pass (48+48 and 96+96 samples); anything else uses the
+// generic kernel.
+
+constexpr int kCoopWaves = 3;
+constexpr int kCoopThreads = 64 * kCoopWaves;
+constexpr int kW1Pitch = 36;        // floats per LDS row of W1 [64 x 32]
+constexpr int kW2Pitch = 68;        // floats per LDS row of W2 [33 x 64]
+constexpr int kTapDwords = 24;      // per sample: 3 planes x (4 byte offsets + 4 weights)
+
+struct CoopLds {
+    float* w1; float* w2; float* b1; float* b2;
+    float* t_e; float* sig_e; float* v_e; int* rank_e; float* s_t; float* s_sig; float* w_s; float* cdf;
+    float* taps;     // [waves][16][24]
+    float* stage;    // [waves][16][kStagePitch]
+    float* part;     // [waves][32] colour partial sums, then [4] ray scalars
+};
+
+__host__ __device__ inline size_t coop_lds_floats(int s_pad) {
+    return size_t(64) * kW1Pitch + 33 * kW2Pitch + 64 + 36 + size_t(8) * s_pad +
+           kCoopWaves * 16 * kTapDwords + kCoopWaves * 16 * kStagePitch + kCoopWaves * 32 + 4;
+}
+
+#ifdef GNERF_ABLATE_MFMA         // timing-only build: one FMA per lane instead of a matrix instruction
+#define GNERF_MFMA(a, b, c) ((c) + (a) * (b))
+#else
+#define GNERF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+#endif
+
+__device__ __forceinline__ float softplus_hw(float x) {         // max(x,0) + ln2 * log2(1 + 2^(-|x| log2 e))
+#ifdef GNERF_ABLATE_ACT
+    return x * 0.5f;
+#endif
+    const float e = __builtin_amdgcn_exp2f(-fabsf(x) * 1.44269504088896341f);
+    return fmaf(__builtin_amdgcn_logf(1.0f + e), 0.693147180559945309f, fmaxf(x, 0.f));
+}
+__device__ __forceinline__ float sigmoid_rgb_hw(float x) {      // sigmoid(x) * 1.002 - 0.001   (triplane.py:134)
+#ifdef GNERF_ABLATE_ACT
+    return x * 0.25f;
+#endif
+    const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896341f);
+    return fmaf(__builtin_amdgcn_rcpf(1.0f + e), 1.002f, -0.001f);
+}
+
+// Taps of one plane for one sample: 4 byte offsets into the plane (clamped, always safe to load) and the
+// 4 bilinear weights (zero where the tap is outside the image; the 1/3 of the plane mean folded in).
+__device__ __forceinline__ void plane_taps(int H, int W, float u, float v, unsigned plane_bytes_off, uint4& off, v4f& wgt) {
+    float ix = ((u + 1.f) * float(W) - 1.f) * 0.5f;
+    float iy = ((v + 1.f) * float(H) - 1.f) * 0.5f;
+    ix = fminf(fmaxf(ix, -1.5f), float(W) + 0.5f);
+    iy = fminf(fmaxf(iy, -1.5f), float(H) + 0.5f);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float fx = ix - x0f, fy = iy - y0f;
+    const int x0 = int(x0f), y0 = int(y0f), x1 = x0 + 1, y1 = y0 + 1;
+    const float wx0 = (x0 >= 0 && x0 < W) ? 1.f - fx : 0.f, wx1 = (x1 >= 0 && x1 < W) ? fx : 0.f;
+    const float wy0 = (y0 >= 0 && y0 < H) ? (1.f - fy) * (1.f / 3.f) : 0.f, wy1 = (y1 >= 0 && y1 < H) ? fy * (1.f / 3.f) : 0.f;
+    const unsigned cx0 = unsigned(min(max(x0, 0), W - 1)) * 128u, cx1 = unsigned(min(max(x1, 0), W - 1)) * 128u;
+    const unsigned cy0 = unsigned(min(max(y0, 0), H - 1)) * unsigned(W) * 128u + plane_bytes_off;
+    const unsigned cy1 = unsigned(min(max(y1, 0), H - 1)) * unsigned(W) * 128u + plane_bytes_off;
+    off = make_uint4(cy0 + cx0, cy0 + cx1, cy1 + cx0, cy1 + cx1);
+    wgt = (v4f){wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+}
+
+struct CoopRay {
+    const char* planes_item;    // uniform
+    float ox, oy, oz, dx, dy, dz;
+};
+
+// Shade one 16-sample tile: depths t_list[16*tile ...] (clamped to count-1) -> density into sig_list (if
+// active) and this lane's 8 colour values (channel lane&15 of block n, samples 4*(lane>>4)..+3) into col.
+// Must be called by all three waves together (it contains workgroup barriers).
+__device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& L, const CoopRay& R, const float* t_list, int count,
+                                                int tile, bool active, float* sig_list, int lane, int wv, v4f (&col)[2]) {
+#ifdef GNERF_ABLATE_SHADE       // timing-only build: no lookups, no MLP
+    if (active && lane < 16 && 16 * tile + lane < count) sig_list[16 * tile + lane] = t_list[16 * tile + lane] - 2.7f;
+    col[0] = (v4f){0.1f, 0.2f, 0.3f, 0.4f}; col[1] = col[0];
+    return;
+#endif
+    const int H = P.p.plane_h, W = P.p.plane_w;
+    float* taps = L.taps + wv * 16 * kTapDwords;
+    float* stage = L.stage + wv * 16 * kStagePitch;
+    // ---- tap setup: lane (sample j, plane pl) for lanes 0..47
+    if (lane < 48) {
+        const int j = lane & 15, pl = lane >> 4;
+        const int idx = min(16 * tile + j, count - 1);
+        const float depth = t_list[idx];
+        const float px = __fadd_rn(R.ox, __fmul_rn(depth, R.dx)) * P.box_scale;
+        const float py = __fadd_rn(R.oy, __fmul_rn(depth, R.dy)) * P.box_scale;
+        const float pz = __fadd_rn(R.oz, __fmul_rn(depth, R.dz)) * P.box_scale;
+        const float u = pl == 2 ? pz : px;                               // plane 0 (x,y), 1 (x,z), 2 (z,x)
+        const float v = pl == 0 ? py : (pl == 1 ? pz : px);
+        uint4 off; v4f wgt;
+        plane_taps(H, W, u, v, unsigned(pl) * unsigned(H) * unsigned(W) * 128u, off, wgt);
+        float* rec = taps + j * kTapDwords + pl * 8;
+        *reinterpret_cast<uint4*>(rec) = off;
+        *reinterpret_cast<v4f*>(rec + 4) = wgt;
+    }
+    __syncthreads();
+    // ---- lookup: 8 lanes per texel, 8 samples per step
+    const int b = lane >> 3, cq16 = (lane & 7) * 16;
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        const int js = 8 * a + b;
+        const float* rec = taps + js * kTapDwords;
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            const uint4 off = *reinterpret_cast<const uint4*>(rec + pl * 8);
+            const v4f wgt = *reinterpret_cast<const v4f*>(rec + pl * 8 + 4);
+#ifdef GNERF_ABLATE_GATHER      // timing-only build: no texel loads (outputs are wrong)
+            const v4f t0 = {float(off.x + cq16), 1.f, 2.f, 3.f}, t1 = {float(off.y), 1.f, 2.f, 3.f}, t2 = {float(off.z), 1.f, 2.f, 3.f}, t3 = {float(off.w), 1.f, 2.f, 3.f};
+#else
+            const v4f t0 = *reinterpret_cast<const v4f*>(R.planes_item + (off.x + cq16));
+            const v4f t1 = *reinterpret_cast<const v4f*>(R.planes_item + (off.y + cq16));
+            const v4f t2 = *reinterpret_cast<const v4f*>(R.planes_item + (off.z + cq16));
+            const v4f t3 = *reinterpret_cast<const v4f*>(R.planes_item + (off.w + cq16));
+#endif
+            acc += t0 * wgt[0] + t1 * wgt[1] + t2 * wgt[2] + t3 * wgt[3];
+        }
+        *reinterpret_cast<v4f*>(stage + js * kStagePitch + (lane & 7) * 4) = acc;
+    }
+    __syncthreads();
+    const int j = lane & 15, g = lane >> 4;
+    const v4f f_lo = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g);
+    const v4f f_hi = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g + 4);
+    const float f[8] = {f_lo[0], f_lo[1], f_lo[2], f_lo[3], f_hi[0], f_hi[1], f_hi[2], f_hi[3]};
+    // ---- layer 1 (weights: W1 rows 16m + j, columns 8g..8g+7)
+    v4f h[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) h[m] = *reinterpret_cast<const v4f*>(L.b1 + 16 * m + 4 * g);
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const v4f a_lo = *reinterpret_cast<const v4f*>(L.w1 + (16 * m + j) * kW1Pitch + 8 * g);
+        const v4f a_hi = *reinterpret_cast<const v4f*>(L.w1 + (16 * m + j) * kW1Pitch + 8 * g + 4);
+#pragma unroll
+        for (int s = 0; s < 4; s++) h[m] = GNERF_MFMA(a_lo[s], f[s], h[m]);
+#pragma unroll
+        for (int s = 0; s < 4; s++) h[m] = GNERF_MFMA(a_hi[s], f[4 + s], h[m]);
+    }
+    // ---- activation, density row, layer 2 (weights: W2 rows 1 + 16n + j, columns 16m + 4g..+3)
+    float sig = 0.f;
+    v4f o[2];
+    const float bc0 = L.b2[1 + j], bc1 = L.b2[17 + j];
+    o[0] = (v4f){bc0, bc0, bc0, bc0};
+    o[1] = (v4f){bc1, bc1, bc1, bc1};
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const v4f ws = *reinterpret_cast<const v4f*>(L.w2 + 16 * m + 4 * g);
+        const v4f w0 = *reinterpret_cast<const v4f*>(L.w2 + (1 + j) * kW2Pitch + 16 * m + 4 * g);
+        const v4f w1 = *reinterpret_cast<const v4f*>(L.w2 + (17 + j) * kW2Pitch + 16 * m + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float hv = softplus_hw(h[m][r]);
+            sig = fmaf(ws[r], hv, sig);
+            o[0] = GNERF_MFMA(hv, w0[r], o[0]);
+            o[1] = GNERF_MFMA(hv, w1[r], o[1]);
+        }
+    }
+    sig += __shfl_xor(sig, 16);
+    sig += __shfl_xor(sig, 32);
+    sig += L.b2[0];
+    if (active && g == 0 && 16 * tile + j < count) sig_list[16 * tile + j] = sig;
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) col[n][r] = sigmoid_rgb_hw(o[n][r]);
+    }
+}
+
+template <int TC1, int TF1>
+__global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) {
+    extern __shared__ __align__(16) float smem[];
+    const gnerf_render_params& p = P.p;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = p.depth_resolution, F = p.depth_resolution_importance;
+    const int s_pad = 16 * (P.tiles_c + P.tiles_f);
+    CoopLds L;
+    L.w1 = smem;
+    L.w2 = L.w1 + 64 * kW1Pitch;
+    L.b1 = L.w2 + 33 * kW2Pitch;
+    L.b2 = L.b1 + 64;
+    L.t_e = L.b2 + 36;
+    L.sig_e = L.t_e + s_pad;
+    L.v_e = L.sig_e + s_pad;
+    L.rank_e = reinterpret_cast<int*>(L.v_e + s_pad);
+    L.s_t = L.v_e + 2 * s_pad;
+    L.s_sig = L.s_t + s_pad;
+    L.w_s = L.s_sig + s_pad;
+    L.cdf = L.w_s + s_pad;
+    L.taps = L.cdf + s_pad;
+    L.stage = L.taps + kCoopWaves * 16 * kTapDwords;
+    L.part = L.stage + kCoopWaves * 16 * kStagePitch;
+
+    const int per_xcd = (P.n_tiles + kNumXCD - 1) / kNumXCD;
+    const int tile_id = (blockIdx.x % kNumXCD) * per_xcd + blockIdx.x / kNumXCD;
+    if (tile_id >= P.n_tiles) return;
+
+    // decoder -> LDS (padded rows), once per workgroup
+    for (int i = tid; i < 64 * 32; i += kCoopThreads) L.w1[(i >> 5) * kW1Pitch + (i & 31)] = p.w1[i];
+    for (int i = tid; i < 33 * 64; i += kCoopThreads) L.w2[(i >> 6) * kW2Pitch + (i & 63)] = p.w2[i];
+    if (tid < 64) L.b1[tid] = p.b1[tid];
+    if (tid < 33) L.b2[tid] = p.b2[tid];
+
+    const int fine_e0 = 16 * P.tiles_c;
+    const int n_all = S + F;
+    float blk_min = INFINITY, blk_max = -INFINITY;
+
+    for (int rr = 0; rr < kRaysPerWave; rr++) {
+        int64_t ray;
+        if (P.tiles_per_item > 0) {
+            const int item = tile_id / P.tiles_per_item, tt = tile_id % P.tiles_per_item;
+            const int tx = tt / P.tiles_y, ty = tt % P.tiles_y;
+            ray = int64_t(item) * p.rays_per_item + int64_t(ty * 4 + (rr >> 2)) * p.image_width + tx * 4 + (rr & 3);
+        } else {
+            ray = int64_t(tile_id) * kRaysPerWave + rr;
+            if (ray >= P.total_rays) break;
+        }
+        const int item = int(ray / p.rays_per_item);
+        CoopRay R;
+        R.planes_item = reinterpret_cast<const char*>(p.planes_nhwc) + int64_t(item) * 3 * p.plane_h * p.plane_w * 128;
+        R.ox = p.ray_origins[ray * 3 + 0]; R.oy = p.ray_origins[ray * 3 + 1]; R.oz = p.ray_origins[ray * 3 + 2];
+        R.dx = p.ray_dirs[ray * 3 + 0];    R.dy = p.ray_dirs[ray * 3 + 1];    R.dz = p.ray_dirs[ray * 3 + 2];
+        float* dbg = p.debug ? p.debug + ray * GNERF_DEBUG_SLOTS * n_all : nullptr;
+
+        // ---- stratified depth proposals (renderer.py:169-192)
+        for (int k = tid; k < S; k += kCoopThreads) {
+            const float u = p.noise_coarse[ray * S + k];
+            float d;
+            if (p.disparity_space_sampling) {
+                const float step = 1.0f / float(S - 1);
+                const float lin = (k < S / 2) ? __fmul_rn(step, float(k)) : __fsub_rn(1.0f, __fmul_rn(step, float(S - 1 - k)));
+                const float q = __fadd_rn(lin, __fmul_rn(u, P.disp_delta));
+                d = __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(P.inv_start, __fsub_rn(1.0f, q)), __fmul_rn(P.inv_end, q)));
+            } else if (p.ray_start_per_ray) {
+                const float rs = p.ray_start_per_ray[ray], re = p.ray_end_per_ray[ray];
+                const float span = __fsub_rn(re, rs);
+                const float lin = __fadd_rn(rs, __fmul_rn(__fdiv_rn(float(k), float(S - 1)), span));
+                d = __fadd_rn(lin, __fmul_rn(u, __fdiv_rn(span, float(S - 1))));
+            } else {
+                const float step = __fdiv_rn(__fsub_rn(p.ray_end, p.ray_start), float(S - 1));
+                const float lin = (k < S / 2) ? __fadd_rn(p.ray_start, __fmul_rn(step, float(k)))
+                                              : __fsub_rn(p.ray_end, __fmul_rn(step, float(S - 1 - k)));
+                d = __fadd_rn(lin, __fmul_rn(u, P.delta));
+            }
+            L.t_e[k] = d;
+            if (dbg) dbg[GNERF_DBG_DEPTH_COARSE * n_all + k] = d;
+        }
+        for (int k = tid; k < s_pad; k += kCoopThreads) {
+            L.v_e[k] = 0.f;
+            if ((k >= S && k < fine_e0) || k >= fine_e0 + F) L.t_e[k] = INFINITY;      // tile padding sorts last
+        }
+        __syncthreads();
+
+        // ---- coarse pass: wave wv shades tiles wv, wv+3, ...
+        v4f col_c[TC1][2], col_f[TF1 > 0 ? TF1 : 1][2];
+#pragma unroll
+        for (int i = 0; i < TC1; i++) {
+            const int t = wv + kCoopWaves * i;
+            coop_shade_tile(P, L, R, L.t_e, S, t, t < P.tiles_c, L.sig_e, lane, wv, col_c[i]);
+        }
+        __syncthreads();
+        if (dbg) for (int k = tid; k < S; k += kCoopThreads) dbg[GNERF_DBG_SIGMA_COARSE * n_all + k] = L.sig_e[k];
+
+        float w_sum = 0.f, wt_sum = 0.f;
+        if (TF1 > 0 && F > 0) {
+            const int n_w = S - 3;
+            if (wv == 0) {
+                march(L.t_e, L.sig_e, L.w_s, S, lane, w_sum, wt_sum);
+                // wave-local hand-off of w_s (LDS ops of one wave execute in order; stop the compiler reordering)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                float part = 0.f;
+                for (int i = lane; i < n_w; i += 64) {
+                    const float w0 = L.w_s[i], w1 = L.w_s[i + 1], w2 = L.w_s[i + 2];
+                    const float pw = ((fmaxf(w0, w1) + fmaxf(w1, w2)) * 0.5f + 0.01f) + 1e-5f;
+                    L.s_sig[i] = pw;
+                    part += pw;
+                }
+                const float inv_total = __builtin_amdgcn_rcpf(wave_sum(part));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                float carry = 0.f;
+                for (int base = 0; base < n_w; base += 64) {
+                    const int i = base + lane;
+                    const float pdf = (i < n_w) ? L.s_sig[i] * inv_total : 0.f;
+                    const float incl = wave_scan_add(pdf, lane) + carry;
+                    if (i < n_w) L.cdf[i + 1] = incl;
+                    carry = wave_last(incl);
+                }
+                if (lane == 0) L.cdf[0] = 0.f;
+            }
+            __syncthreads();
+            if (dbg) for (int k = tid; k < S - 1; k += kCoopThreads) dbg[GNERF_DBG_WEIGHT_COARSE * n_all + k] = L.w_s[k];
+            for (int i = tid; i < F; i += kCoopThreads) {
+                const float u = p.noise_fine[ray * F + i];
+                int lo = 0, hi = n_w + 1;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+                const int below = max(lo - 1, 0), above = min(lo, n_w);
+                const float cb = L.cdf[below], ca = L.cdf[above];
+                const float bb = (L.t_e[below] + L.t_e[below + 1]) * 0.5f;
+                const float ba = (L.t_e[above] + L.t_e[above + 1]) * 0.5f;
+                float denom = ca - cb;
+                if (denom < 1e-5f) denom = 1.f;
+                const float d = bb + (u - cb) * __builtin_amdgcn_rcpf(denom) * (ba - bb);
+                L.t_e[fine_e0 + i] = d;
+                if (dbg) dbg[GNERF_DBG_DEPTH_FINE * n_all + i] = d;
+            }
+            __syncthreads();
+
+            // ---- fine pass
+#pragma unroll
+            for (int i = 0; i < TF1; i++) {
+                const int t = wv + kCoopWaves * i;
+                coop_shade_tile(P, L, R, L.t_e + fine_e0, F, t, t < P.tiles_f, L.sig_e + fine_e0, lane, wv, col_f[i]);
+            }
+            __syncthreads();
+            if (dbg) for (int k = tid; k < F; k += kCoopThreads) dbg[GNERF_DBG_SIGMA_FINE * n_all + k] = L.sig_e[fine_e0 + k];
+
+            // ---- merge by depth (renderer.py:157-167) = stable rank of every element of cat([coarse, fine]).
+            // Coarse depths ascend by construction (lin_k + u*delta with u < 1), so a coarse sample's rank is
+            // k + #(fine before it) and a fine sample's is #(coarse <= it) [binary search] + #(fine before it).
+            // Wave 0 ranks the fine samples, wave 1 the coarse ones; both count over the fine keys, read four at
+            // a time as LDS broadcasts.  Ties: coarse before fine, lower index first (what a stable sort gives).
+#ifdef GNERF_ABLATE_RANK
+            for (int q = tid; q < n_all; q += kCoopThreads) { const int e = q < S ? q : fine_e0 + (q - S); L.rank_e[e] = q; L.s_t[q] = L.t_e[e]; L.s_sig[q] = L.sig_e[e]; }
+#else
+            if (wv == 0) {
+                for (int i = lane; i < F; i += 64) {
+                    const float key = L.t_e[fine_e0 + i];
+                    int cnt = 0;
+                    for (int o2 = 0; o2 < 16 * P.tiles_f; o2 += 4) {
+                        const v4f k4 = *reinterpret_cast<const v4f*>(L.t_e + fine_e0 + o2);
+#pragma unroll
+                        for (int c2 = 0; c2 < 4; c2++) cnt += (k4[c2] < key || (k4[c2] == key && o2 + c2 < i)) ? 1 : 0;
+                    }
+                    int lo = 0, hi = S;                                  // number of coarse depths <= key
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.t_e[mid] <= key) lo = mid + 1; else hi = mid; }
+                    const int rank = cnt + lo;
+                    L.rank_e[fine_e0 + i] = rank;
+                    L.s_t[rank] = key;
+                    L.s_sig[rank] = L.sig_e[fine_e0 + i];
+                }
+            } else if (wv == 1) {
+                for (int k = lane; k < S; k += 64) {
+                    const float key = L.t_e[k];
+                    int cnt = 0;
+                    for (int o2 = 0; o2 < 16 * P.tiles_f; o2 += 4) {
+                        const v4f k4 = *reinterpret_cast<const v4f*>(L.t_e + fine_e0 + o2);
+#pragma unroll
+                        for (int c2 = 0; c2 < 4; c2++) cnt += (k4[c2] < key) ? 1 : 0;
+                    }
+                    const int rank = k + cnt;
+                    L.rank_e[k] = rank;
+                    L.s_t[rank] = key;
+                    L.s_sig[rank] = L.sig_e[k];
+                }
+            }
+#endif
+            __syncthreads();
+            if (wv == 0) {
+                march(L.s_t, L.s_sig, L.w_s, n_all, lane, w_sum, wt_sum);
+                if (lane == 0) { L.part[kCoopWaves * 32] = w_sum; blk_min = fminf(blk_min, L.s_t[0]); blk_max = fmaxf(blk_max, L.s_t[n_all - 1]); }
+            }
+            __syncthreads();
+            for (int q = tid; q < n_all; q += kCoopThreads) {
+                const int e = q < S ? q : fine_e0 + (q - S);
+                const int r = L.rank_e[e];
+                const float wl = r > 0 ? L.w_s[r - 1] : 0.f, wr = r < n_all - 1 ? L.w_s[r] : 0.f;
+                L.v_e[e] = (wl + wr) * 0.5f;
+            }
+            if (dbg) {
+                for (int k = tid; k < n_all; k += kCoopThreads) { dbg[GNERF_DBG_DEPTH_SORTED * n_all + k] = L.s_t[k]; dbg[GNERF_DBG_SIGMA_SORTED * n_all + k] = L.s_sig[k]; }
+                for (int k = tid; k < n_all - 1; k += kCoopThreads) dbg[GNERF_DBG_WEIGHT_FINAL * n_all + k] = L.w_s[k];
+            }
+        } else {
+            if (wv == 0) {
+                march(L.t_e, L.sig_e, L.w_s, S, lane, w_sum, wt_sum);
+                float mn = INFINITY, mx = -INFINITY;
+                for (int k = lane; k < S; k += 64) { mn = fminf(mn, L.t_e[k]); mx = fmaxf(mx, L.t_e[k]); }
+#pragma unroll
+                for (int o2 = 32; o2 > 0; o2 >>= 1) { mn = fminf(mn, __shfl_xor(mn, o2)); mx = fmaxf(mx, __shfl_xor(mx, o2)); }
+                blk_min = fminf(blk_min, mn);
+                blk_max = fmaxf(blk_max, mx);
+                if (lane == 0) L.part[kCoopWaves * 32] = w_sum;
+            }
+            __syncthreads();
+            for (int k = tid; k < S; k += kCoopThreads) {
+                const float wl = k > 0 ? L.w_s[k - 1] : 0.f, wr = k < S - 1 ? L.w_s[k] : 0.f;
+                L.v_e[k] = (wl + wr) * 0.5f;
+            }
+            if (dbg) for (int k = tid; k < S - 1; k += kCoopThreads) dbg[GNERF_DBG_WEIGHT_FINAL * n_all + k] = L.w_s[k];
+        }
+        __syncthreads();
+
+        // ---- colours: each wave sums its own tiles, partials meet in LDS
+        const int j = lane & 15, g = lane >> 4;
+        float acc[2] = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TC1; i++) {
+            const int t = wv + kCoopWaves * i;
+            if (t < P.tiles_c) {
+                const v4f v = *reinterpret_cast<const v4f*>(L.v_e + 16 * t + 4 * g);
+#pragma unroll
+                for (int n = 0; n < 2; n++) acc[n] += v[0] * col_c[i][n][0] + v[1] * col_c[i][n][1] + v[2] * col_c[i][n][2] + v[3] * col_c[i][n][3];
+            }
+        }
+        if (TF1 > 0 && F > 0) {
+#pragma unroll
+            for (int i = 0; i < TF1; i++) {
+                const int t = wv + kCoopWaves * i;
+                if (t < P.tiles_f) {
+                    const v4f v = *reinterpret_cast<const v4f*>(L.v_e + fine_e0 + 16 * t + 4 * g);
+#pragma unroll
+                    for (int n = 0; n < 2; n++) acc[n] += v[0] * col_f[i][n][0] + v[1] * col_f[i][n][1] + v[2] * col_f[i][n][2] + v[3] * col_f[i][n][3];
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            acc[n] += __shfl_xor(acc[n], 16);
+            acc[n] += __shfl_xor(acc[n], 32);
+        }
+        if (g < 2) L.part[wv * 32 + 16 * g + j] = g == 0 ? acc[0] : acc[1];
+        __syncthreads();
+        if (tid < 32) {
+            float c = L.part[tid] + L.part[32 + tid] + L.part[64 + tid];
+            const float ws = L.part[kCoopWaves * 32];
+            if (p.white_back) c = c + 1.f - ws;
+            p.out_rgb[ray * 32 + tid] = c * 2.f - 1.f;
+        }
+        if (tid == 0) {
+            float depth = wt_sum / w_sum;
+            if (depth != depth) depth = INFINITY;
+            p.out_depth[ray] = depth;
+            p.out_wsum[ray] = w_sum;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        unsigned* range = static_cast<unsigned*>(p.workspace);
+        atomicMin(range + 0, ord_encode(blk_min));
+        atomicMax(range + 1, ord_encode(blk_max));
+    }
+}

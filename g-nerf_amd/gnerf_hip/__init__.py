@@ -13,7 +13,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgnerf_hip.so')
+# GNERF_HIP_LIB points tools/ablate.py at a timing-only variant build; everything else uses the in-tree library.
+LIB_PATH = os.environ.get('GNERF_HIP_LIB') or os.path.join(_HERE, 'libgnerf_hip.so')
 
 _lib = None
 

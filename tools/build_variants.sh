@@ -1,0 +1,16 @@
+#!/bin/bash
+# Timing-only ablation builds of libgnerf_hip.so (outputs are WRONG by construction; never shipped, never tested
+# for parity).  Used with tools/ablate.py to see which part of the render kernel the time goes to.
+set -euo pipefail
+root="$(cd "$(dirname "$0")/.." && pwd)"
+src="$root/g-nerf_amd/csrc"
+out="$root/g-nerf_amd/gnerf_hip/variants"
+mkdir -p "$out"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$root/include -I$src -Wno-unused-value"
+for v in "$@"; do
+  defs=""
+  IFS='+' read -ra parts <<< "$v"
+  for p in "${parts[@]}"; do [ "$p" = base ] || defs="$defs -DGNERF_ABLATE_$p"; done
+  ( /opt/rocm/bin/hipcc $FLAGS $defs -shared "$src"/capi.hip "$src"/planes.hip "$src"/render.hip "$src"/bias_act.hip "$src"/upfirdn2d.hip "$src"/filtered_lrelu.hip -o "$out/libgnerf_$v.so" && echo "[variant] $v" ) &
+done
+wait
