@@ -11,7 +11,12 @@ objs=()
 for src in capi bias_act upfirdn2d filtered_lrelu planes render; do
     [ -f "$here/$src.hip" ] || continue
     obj="$here/$src.o"
-    if [ ! -f "$obj" ] || [ "$here/$src.hip" -nt "$obj" ] || [ "$here/common.h" -nt "$obj" ] || [ "$root/include/gnerf_hip.h" -nt "$obj" ]; then
+    stale=0
+    [ -f "$obj" ] || stale=1
+    for dep in "$here/$src.hip" "$here"/*.h "$here"/*.inl "$root/include/gnerf_hip.h" "$here/build.sh"; do
+        [ "$stale" = 1 ] || { [ "$dep" -nt "$obj" ] && stale=1; } || true
+    done
+    if [ "$stale" = 1 ]; then
         echo "[build] $src.hip"
         $HIPCC $FLAGS -c "$here/$src.hip" -o "$obj" &
     fi

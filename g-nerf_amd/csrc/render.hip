@@ -586,6 +586,7 @@ __global__ __launch_bounds__(64) void query_kernel(gnerf_render_params p, float 
 }
 
 #include "render_coop.inl"
+#include "render_pipe.inl"
 
 int check_common(const gnerf_render_params* p) {
     if (!p) return fail(GNERF_E_ARG, "render: params is null");
@@ -640,12 +641,25 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
     hipLaunchKernelGGL(init_range_kernel, dim3(1), dim3(1), 0, s, static_cast<unsigned*>(p->workspace));
     const int per_xcd = (P.n_tiles + kNumXCD - 1) / kNumXCD;
     const dim3 grid(per_xcd * kNumXCD);
-    // Kernel choice: the cooperative 3-waves-per-ray kernel covers up to 96+96 samples (2 tiles per wave and
-    // pass); the one-wave-per-ray kernel covers everything else.  GNERF_RENDER_KERNEL=generic|coop forces one (A/B runs).
+    // Kernel choice (GNERF_RENDER_KERNEL=pipe|coop|generic forces one, for A/B runs):
+    //   pipe    3 shader waves + 1 scalar wave, three rays in flight: up to 48+48 samples with importance sampling
+    //   coop    3 waves per ray, phases separated by barriers: up to 96+96 samples
+    //   generic one wave per ray: everything else (up to 256+256)
     const char* force = getenv("GNERF_RENDER_KERNEL");
-    bool coop = P.tiles_c <= 2 * kCoopWaves && P.tiles_f <= 2 * kCoopWaves && int64_t(p->plane_h) * p->plane_w * 3 * 128 < (int64_t(1) << 32);
-    if (force && !strcmp(force, "generic")) coop = false;
-    if (force && !strcmp(force, "coop") && !coop) return fail(GNERF_E_UNSUPPORTED, "render: cooperative kernel does not cover %d+%d samples", S, F);
+    const bool small_planes = int64_t(p->plane_h) * p->plane_w * 3 * 128 < (int64_t(1) << 32);
+    bool pipe = P.tiles_c <= 3 && P.tiles_f >= 1 && P.tiles_f <= 3 && small_planes;
+    bool coop = P.tiles_c <= 2 * kCoopWaves && P.tiles_f <= 2 * kCoopWaves && small_planes;
+    if (force && !strcmp(force, "generic")) pipe = coop = false;
+    if (force && !strcmp(force, "coop")) { pipe = false; if (!coop) return fail(GNERF_E_UNSUPPORTED, "render: cooperative kernel does not cover %d+%d samples", S, F); }
+    if (force && !strcmp(force, "pipe") && !pipe) return fail(GNERF_E_UNSUPPORTED, "render: pipelined kernel does not cover %d+%d samples", S, F);
+    if (pipe) {
+        const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : total;
+        int64_t g = (total_seq / 24 + kNumXCD - 1) / kNumXCD * kNumXCD;         // >= ~24 rays per workgroup amortise the pipeline fill
+        if (g < kNumXCD) g = kNumXCD;
+        if (g > GNERF_PIPE_WAVES_PER_SIMD * kNumCU) g = GNERF_PIPE_WAVES_PER_SIMD * kNumCU;     // resident workgroups per CU
+        hipLaunchKernelGGL(render_kernel_pipe, dim3((unsigned)g), dim3(kPipeThreads), pipe_lds_floats() * sizeof(float), s, P);
+        if (int e = check_launch("render_kernel_pipe")) return e;
+    } else
     if (coop) {
         const int tc1 = (P.tiles_c + kCoopWaves - 1) / kCoopWaves, tf1 = (P.tiles_f + kCoopWaves - 1) / kCoopWaves;
         const size_t lds_bytes = coop_lds_floats(16 * (P.tiles_c + P.tiles_f)) * sizeof(float);

@@ -73,6 +73,40 @@ __device__ __forceinline__ void plane_taps(int H, int W, float u, float v, unsig
     wgt = (v4f){wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
 }
 
+// In-kernel stamps for the diagnostic build (-DGNERF_STAMPS, tools/build_variants.sh STAMPS): per-wave cycle
+// totals per code segment, written to the `debug` buffer instead of the stage dump.  No stamp executes in the
+// shipped library.
+#ifdef GNERF_STAMPS
+struct Stamps {
+    unsigned long long last, acc[16];
+    __device__ __forceinline__ void reset() { for (int i = 0; i < 16; i++) acc[i] = 0; last = now(); }
+    static __device__ __forceinline__ unsigned long long now() {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    }
+    __device__ __forceinline__ void mark(int i) { const unsigned long long t = now(); acc[i] += t - last; last = t; }
+};
+#define GNERF_STAMP(st, i) (st).mark(i)
+#else
+struct Stamps { __device__ __forceinline__ void reset() {} };
+#define GNERF_STAMP(st, i) ((void)0)
+#endif
+
+// v + (v from lane^16) + (v from lane^32) + (v from lane^48): sum over the four 16-lane rows, result in every lane.
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange rows between two registers; two swaps + two adds
+// replace two ds_bpermute round trips through the LDS crossbar.
+__device__ __forceinline__ float row_sum4(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);     // rows {0,1,2,3}x{0,1,2,3} -> (r0,r0,r2,r2), (r1,r1,r3,r3)
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);           // r0+r1 in rows 0,1 ; r2+r3 in rows 2,3
+    const unsigned us = __float_as_uint(s);
+    const auto b = __builtin_amdgcn_permlane32_swap(us, us, false, false);   // (lo,lo), (hi,hi)
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 struct CoopRay {
     const char* planes_item;    // uniform
     float ox, oy, oz, dx, dy, dz;
@@ -80,9 +114,17 @@ struct CoopRay {
 
 // Shade one 16-sample tile: depths t_list[16*tile ...] (clamped to count-1) -> density into sig_list (if
 // active) and this lane's 8 colour values (channel lane&15 of block n, samples 4*(lane>>4)..+3) into col.
-// Must be called by all three waves together (it contains workgroup barriers).
+// The tap records and the staging rows are private to the calling wave, so the two hand-offs inside need
+// only wave-level ordering: BLOCK_SYNC=false uses lds_wave_sync() (s_waitcnt, no s_barrier) and the call may
+// then sit in wave-divergent control flow; BLOCK_SYNC=true keeps workgroup barriers (all waves must call).
+__device__ __forceinline__ void lds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt lgkmcnt(0): this wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <bool BLOCK_SYNC>
 __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& L, const CoopRay& R, const float* t_list, int count,
-                                                int tile, bool active, float* sig_list, int lane, int wv, v4f (&col)[2]) {
+                                                int tile, bool active, float* sig_list, int lane, int wv, v4f (&col)[2], Stamps& st) {
 #ifdef GNERF_ABLATE_SHADE       // timing-only build: no lookups, no MLP
     if (active && lane < 16 && 16 * tile + lane < count) sig_list[16 * tile + lane] = t_list[16 * tile + lane] - 2.7f;
     col[0] = (v4f){0.1f, 0.2f, 0.3f, 0.4f}; col[1] = col[0];
@@ -107,31 +149,59 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
         *reinterpret_cast<uint4*>(rec) = off;
         *reinterpret_cast<v4f*>(rec + 4) = wgt;
     }
-    __syncthreads();
+    if (BLOCK_SYNC) __syncthreads(); else lds_wave_sync();
+    GNERF_STAMP(st, 1);         // tap setup
     // ---- lookup: 8 lanes per texel, 8 samples per step
     const int b = lane >> 3, cq16 = (lane & 7) * 16;
-#pragma unroll
-    for (int a = 0; a < 2; a++) {
-        const int js = 8 * a + b;
-        const float* rec = taps + js * kTapDwords;
-        v4f acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-            const uint4 off = *reinterpret_cast<const uint4*>(rec + pl * 8);
-            const v4f wgt = *reinterpret_cast<const v4f*>(rec + pl * 8 + 4);
-#ifdef GNERF_ABLATE_GATHER      // timing-only build: no texel loads (outputs are wrong)
-            const v4f t0 = {float(off.x + cq16), 1.f, 2.f, 3.f}, t1 = {float(off.y), 1.f, 2.f, 3.f}, t2 = {float(off.z), 1.f, 2.f, 3.f}, t3 = {float(off.w), 1.f, 2.f, 3.f};
+    // all 24 texel loads of the tile (2 steps x 3 planes x 4 taps) are issued before the first blend, so one
+    // memory round trip covers both steps
+    // Measured (tools/ablate.py, config 2): keeping both 8-sample steps in flight (24 loads = 96 VGPRs) halves the
+    // lookup time of a tile but costs a wave per SIMD; one step at a time (12 loads = 48 VGPRs) at 3 waves per SIMD
+    // is 14 % faster overall, so that is the default.
+#ifdef GNERF_GATHER_WHOLE_TILE
+    constexpr int kBatch = 2;
 #else
-            const v4f t0 = *reinterpret_cast<const v4f*>(R.planes_item + (off.x + cq16));
-            const v4f t1 = *reinterpret_cast<const v4f*>(R.planes_item + (off.y + cq16));
-            const v4f t2 = *reinterpret_cast<const v4f*>(R.planes_item + (off.z + cq16));
-            const v4f t3 = *reinterpret_cast<const v4f*>(R.planes_item + (off.w + cq16));
+    constexpr int kBatch = 1;
 #endif
-            acc += t0 * wgt[0] + t1 * wgt[1] + t2 * wgt[2] + t3 * wgt[3];
+#pragma unroll
+    for (int a0 = 0; a0 < 2; a0 += kBatch) {
+        uint4 off[kBatch][3];
+        v4f wgt[kBatch][3], tex[kBatch][3][4];
+#pragma unroll
+        for (int a = 0; a < kBatch; a++) {
+            const float* rec = taps + (8 * (a0 + a) + b) * kTapDwords;
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                off[a][pl] = *reinterpret_cast<const uint4*>(rec + pl * 8);
+                wgt[a][pl] = *reinterpret_cast<const v4f*>(rec + pl * 8 + 4);
+            }
         }
-        *reinterpret_cast<v4f*>(stage + js * kStagePitch + (lane & 7) * 4) = acc;
+#pragma unroll
+        for (int a = 0; a < kBatch; a++) {
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+#ifdef GNERF_ABLATE_GATHER      // timing-only build: no texel loads (outputs are wrong)
+                tex[a][pl][0] = (v4f){float(off[a][pl].x + cq16), 1.f, 2.f, 3.f}; tex[a][pl][1] = (v4f){float(off[a][pl].y), 1.f, 2.f, 3.f};
+                tex[a][pl][2] = (v4f){float(off[a][pl].z), 1.f, 2.f, 3.f};        tex[a][pl][3] = (v4f){float(off[a][pl].w), 1.f, 2.f, 3.f};
+#else
+                tex[a][pl][0] = *reinterpret_cast<const v4f*>(R.planes_item + (off[a][pl].x + cq16));
+                tex[a][pl][1] = *reinterpret_cast<const v4f*>(R.planes_item + (off[a][pl].y + cq16));
+                tex[a][pl][2] = *reinterpret_cast<const v4f*>(R.planes_item + (off[a][pl].z + cq16));
+                tex[a][pl][3] = *reinterpret_cast<const v4f*>(R.planes_item + (off[a][pl].w + cq16));
+#endif
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < kBatch; a++) {
+            v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+                acc += tex[a][pl][0] * wgt[a][pl][0] + tex[a][pl][1] * wgt[a][pl][1] + tex[a][pl][2] * wgt[a][pl][2] + tex[a][pl][3] * wgt[a][pl][3];
+            *reinterpret_cast<v4f*>(stage + (8 * (a0 + a) + b) * kStagePitch + (lane & 7) * 4) = acc;
+        }
     }
-    __syncthreads();
+    if (BLOCK_SYNC) __syncthreads(); else lds_wave_sync();
+    GNERF_STAMP(st, 2);         // lookups (tap records, texel loads, blend, staging)
     const int j = lane & 15, g = lane >> 4;
     const v4f f_lo = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g);
     const v4f f_hi = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g + 4);
@@ -149,6 +219,10 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
 #pragma unroll
         for (int s = 0; s < 4; s++) h[m] = GNERF_MFMA(a_hi[s], f[4 + s], h[m]);
     }
+#ifdef GNERF_STAMPS
+    asm volatile("" :: "v"(h[0][0]), "v"(h[1][0]), "v"(h[2][0]), "v"(h[3][0]));      // wait for layer 1 before stamping
+#endif
+    GNERF_STAMP(st, 3);         // layer 1
     // ---- activation, density row, layer 2 (weights: W2 rows 1 + 16n + j, columns 16m + 4g..+3)
     float sig = 0.f;
     v4f o[2];
@@ -168,15 +242,17 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
             o[1] = GNERF_MFMA(hv, w1[r], o[1]);
         }
     }
-    sig += __shfl_xor(sig, 16);
-    sig += __shfl_xor(sig, 32);
-    sig += L.b2[0];
+    sig = row_sum4(sig) + L.b2[0];
     if (active && g == 0 && 16 * tile + j < count) sig_list[16 * tile + j] = sig;
 #pragma unroll
     for (int n = 0; n < 2; n++) {
 #pragma unroll
         for (int r = 0; r < 4; r++) col[n][r] = sigmoid_rgb_hw(o[n][r]);
     }
+#ifdef GNERF_STAMPS
+    asm volatile("" :: "v"(col[0][0]), "v"(col[1][3]));
+#endif
+    GNERF_STAMP(st, 4);         // activations + layer 2
 }
 
 template <int TC1, int TF1>
@@ -217,6 +293,8 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
     const int fine_e0 = 16 * P.tiles_c;
     const int n_all = S + F;
     float blk_min = INFINITY, blk_max = -INFINITY;
+    Stamps st;
+    st.reset();
 
     for (int rr = 0; rr < kRaysPerWave; rr++) {
         int64_t ray;
@@ -269,7 +347,7 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
 #pragma unroll
         for (int i = 0; i < TC1; i++) {
             const int t = wv + kCoopWaves * i;
-            coop_shade_tile(P, L, R, L.t_e, S, t, t < P.tiles_c, L.sig_e, lane, wv, col_c[i]);
+            coop_shade_tile<true>(P, L, R, L.t_e, S, t, t < P.tiles_c, L.sig_e, lane, wv, col_c[i], st);
         }
         __syncthreads();
         if (dbg) for (int k = tid; k < S; k += kCoopThreads) dbg[GNERF_DBG_SIGMA_COARSE * n_all + k] = L.sig_e[k];
@@ -326,7 +404,7 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
 #pragma unroll
             for (int i = 0; i < TF1; i++) {
                 const int t = wv + kCoopWaves * i;
-                coop_shade_tile(P, L, R, L.t_e + fine_e0, F, t, t < P.tiles_f, L.sig_e + fine_e0, lane, wv, col_f[i]);
+                coop_shade_tile<true>(P, L, R, L.t_e + fine_e0, F, t, t < P.tiles_f, L.sig_e + fine_e0, lane, wv, col_f[i], st);
             }
             __syncthreads();
             if (dbg) for (int k = tid; k < F; k += kCoopThreads) dbg[GNERF_DBG_SIGMA_FINE * n_all + k] = L.sig_e[fine_e0 + k];

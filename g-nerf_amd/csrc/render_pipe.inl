@@ -1,0 +1,365 @@
+// Pipelined render kernel: 3 SHADER WAVES + 1 SCALAR WAVE per workgroup, three rays in flight.
+// Included by render.hip (inside its anonymous namespace) after render_coop.inl.
+//
+// In the cooperative kernel every ray alternates between phases that use all three waves (tri-plane lookups +
+// MLP) and phases only one wave can do (ray march, cdf, inverse-cdf, merge), with a workgroup barrier between
+// them: ablation (tools/ablate.py) shows ~35 % of its time is the single-wave phases and their bubbles.
+// Here the per-sample scalar work of a ray runs on a dedicated fourth wave WHILE the three shader waves
+// shade another ray, so shader waves never wait for it:
+//
+//   step 2k+2:  shaders  A(k+1) coarse lookups+MLP        | scalar  D(k-1) merge + final march,  out(k-2)
+//   step 2k+3:  shaders  acc(k-1) colours, C(k) fine pass  | scalar  B(k+1) coarse march + importance,  P(k+2) depth proposals
+//
+// with ONE workgroup barrier per step (the hand-offs inside a tile are wave-private, see coop_shade_tile<false>).
+// Rays r-1, r, r+1, r+2 are live at once: their per-sample scalars sit in a ring of four LDS slots, their
+// colours in shader-wave registers (3 coarse sets + 1 fine set = 32 VGPRs).  The scalar wave issues its global
+// loads (noise, ray) at the start of a step and consumes them at the end, behind the march/cdf work.
+// Workgroups are persistent-style: each takes a contiguous run of the locality-ordered ray sequence, so the
+// 3-step pipeline fill/drain is paid once per ~85 rays, not once per 16.
+// Covers depth_resolution <= 48 and 1 <= depth_resolution_importance <= 48 (one 16-sample tile per shader wave
+// and pass) -- the reference's training/inference default (48+48); other shapes use the coop / generic kernels.
+
+#ifdef GNERF_STAMPS
+#define GNERF_DBG_PTR(x) ((float*)nullptr)
+#else
+#define GNERF_DBG_PTR(x) (x)
+#endif
+
+constexpr int kPipeThreads = 256;
+constexpr int kPipeSlots = 4;
+constexpr int kPipeMaxS = 48;
+constexpr int kPipeSPad = 96;
+constexpr int kSlotFloats = 8 * kPipeSPad + kPipeMaxS + 96 + 16;
+
+struct PipeSlot {
+    float* t_e; float* sig_e; float* v_e; int* rank_e; float* s_t; float* s_sig; float* w_s; float* cdf;
+    float* nf;      // [48] fine noise of this ray
+    float* part;    // [3][32] colour partial sums of the shader waves
+    float* misc;    // [0..5] origin, direction  [6] item (int)  [7] ray (int)  [8] w_sum  [9] wt_sum
+};
+
+__device__ __forceinline__ PipeSlot pipe_slot(float* base, int slot) {
+    float* p = base + slot * kSlotFloats;
+    PipeSlot s;
+    s.t_e = p; s.sig_e = p + kPipeSPad; s.v_e = p + 2 * kPipeSPad; s.rank_e = reinterpret_cast<int*>(p + 3 * kPipeSPad);
+    s.s_t = p + 4 * kPipeSPad; s.s_sig = p + 5 * kPipeSPad; s.w_s = p + 6 * kPipeSPad; s.cdf = p + 7 * kPipeSPad;
+    s.nf = p + 8 * kPipeSPad; s.part = s.nf + kPipeMaxS; s.misc = s.part + 96;
+    return s;
+}
+
+__host__ __device__ inline size_t pipe_lds_floats() {
+    return size_t(64) * kW1Pitch + 33 * kW2Pitch + 64 + 36 + size_t(kPipeSlots) * kSlotFloats + 3 * 16 * kTapDwords + 3 * 16 * kStagePitch;
+}
+
+// position `seq` of the locality-ordered ray sequence -> ray index (or -1 past the end)
+__device__ __forceinline__ int pipe_seq_to_ray(const Params& P, int64_t seq) {
+    const gnerf_render_params& p = P.p;
+    if (P.tiles_per_item > 0) {
+        const int tile = int(seq >> 4), rr = int(seq & 15);
+        const int item = tile / P.tiles_per_item, tt = tile % P.tiles_per_item;
+        const int tx = tt / P.tiles_y, ty = tt % P.tiles_y;
+        return item * p.rays_per_item + (ty * 4 + (rr >> 2)) * p.image_width + tx * 4 + (rr & 3);
+    }
+    return seq < P.total_rays ? int(seq) : -1;
+}
+
+#ifndef GNERF_PIPE_WAVES_PER_SIMD
+#define GNERF_PIPE_WAVES_PER_SIMD 3
+#endif
+__global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void render_kernel_pipe(Params P) {
+    extern __shared__ __align__(16) float smem[];
+    const gnerf_render_params& p = P.p;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = p.depth_resolution, F = p.depth_resolution_importance;
+    // fixed slot layout: coarse samples at [0,48), fine samples at [48,96); unused entries hold +inf depths so that the
+    // fully unrolled 4-wide key scans below need no bounds checks
+    constexpr int fine_e0 = kPipeMaxS, s_pad = kPipeSPad;
+    const int n_all = S + F;
+    CoopLds L;
+    L.w1 = smem;
+    L.w2 = L.w1 + 64 * kW1Pitch;
+    L.b1 = L.w2 + 33 * kW2Pitch;
+    L.b2 = L.b1 + 64;
+    float* slots = L.b2 + 36;
+    L.taps = slots + kPipeSlots * kSlotFloats;
+    L.stage = L.taps + 3 * 16 * kTapDwords;
+
+    // this workgroup's run of the ray sequence (XCD-contiguous: workgroups b, b+8, ... share an XCD)
+    const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : int64_t(P.total_rays);
+    const int G = gridDim.x;
+    const int chunk = (blockIdx.x % kNumXCD) * (G / kNumXCD) + blockIdx.x / kNumXCD;
+    const int64_t seq0 = total_seq * chunk / G, seq1 = total_seq * (chunk + 1) / G;
+    const int nr = int(seq1 - seq0);
+
+    for (int i = tid; i < 64 * 32; i += kPipeThreads) L.w1[(i >> 5) * kW1Pitch + (i & 31)] = p.w1[i];
+    for (int i = tid; i < 33 * 64; i += kPipeThreads) L.w2[(i >> 6) * kW2Pitch + (i & 63)] = p.w2[i];
+    if (tid < 64) L.b1[tid] = p.b1[tid];
+    if (tid < 33) L.b2[tid] = p.b2[tid];
+
+    Stamps st;
+    // ------------------------------------------------------------------ scalar-wave pieces (lambdas, wave 3 only)
+    float blk_min = INFINITY, blk_max = -INFINITY;
+    float pre_uc = 0.f, pre_uf = 0.f, pre_ray = 0.f, pre_rs = 0.f, pre_re = 0.f;       // prefetched by propose_issue
+    int pre_ray_id = -1;
+
+    auto propose_issue = [&](int r) {           // P(r), first half: start the global loads
+        pre_ray_id = (r >= 0 && r < nr) ? pipe_seq_to_ray(P, seq0 + r) : -1;
+        if (pre_ray_id < 0) return;
+        const int64_t ray = pre_ray_id;
+        if (lane < S) pre_uc = p.noise_coarse[ray * S + lane];
+        if (lane < F) pre_uf = p.noise_fine[ray * F + lane];
+        if (lane < 3) pre_ray = p.ray_origins[ray * 3 + lane];
+        else if (lane < 6) pre_ray = p.ray_dirs[ray * 3 + lane - 3];
+        if (p.ray_start_per_ray) { pre_rs = p.ray_start_per_ray[ray]; pre_re = p.ray_end_per_ray[ray]; }
+    };
+    auto propose_finish = [&](int r) {          // P(r), second half: depth proposals (renderer.py:169-192) into the slot
+        if (r < 0 || r >= nr) return;
+        PipeSlot sl = pipe_slot(slots, r & (kPipeSlots - 1));
+        if (lane == 7) sl.misc[7] = __int_as_float(pre_ray_id);
+        if (pre_ray_id < 0) return;
+        const int k = lane;
+        if (k < S) {
+            const float u = pre_uc;
+            float d;
+            if (p.disparity_space_sampling) {
+                const float step = 1.0f / float(S - 1);
+                const float lin = (k < S / 2) ? __fmul_rn(step, float(k)) : __fsub_rn(1.0f, __fmul_rn(step, float(S - 1 - k)));
+                const float q = __fadd_rn(lin, __fmul_rn(u, P.disp_delta));
+                d = __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(P.inv_start, __fsub_rn(1.0f, q)), __fmul_rn(P.inv_end, q)));
+            } else if (p.ray_start_per_ray) {
+                const float span = __fsub_rn(pre_re, pre_rs);
+                const float lin = __fadd_rn(pre_rs, __fmul_rn(__fdiv_rn(float(k), float(S - 1)), span));
+                d = __fadd_rn(lin, __fmul_rn(u, __fdiv_rn(span, float(S - 1))));
+            } else {
+                const float step = __fdiv_rn(__fsub_rn(p.ray_end, p.ray_start), float(S - 1));
+                const float lin = (k < S / 2) ? __fadd_rn(p.ray_start, __fmul_rn(step, float(k)))
+                                              : __fsub_rn(p.ray_end, __fmul_rn(step, float(S - 1 - k)));
+                d = __fadd_rn(lin, __fmul_rn(u, P.delta));
+            }
+            sl.t_e[k] = d;
+            if (GNERF_DBG_PTR(p.debug)) p.debug[(int64_t(pre_ray_id) * GNERF_DEBUG_SLOTS + GNERF_DBG_DEPTH_COARSE) * n_all + k] = d;
+        }
+        if (lane < F) sl.nf[lane] = pre_uf;
+        if (lane < 6) sl.misc[lane] = pre_ray;
+        if (lane == 6) sl.misc[6] = __int_as_float(pre_ray_id / p.rays_per_item);
+        for (int e = lane; e < s_pad; e += 64) {
+            sl.v_e[e] = 0.f;
+            if ((e >= S && e < fine_e0) || e >= fine_e0 + F) sl.t_e[e] = INFINITY;      // tile padding sorts last
+        }
+    };
+    auto importance = [&](int r) {              // B(r): coarse march (ray_marcher.py:26-42) + importance depths (renderer.py:194-253)
+        if (r < 0 || r >= nr) return;
+        PipeSlot sl = pipe_slot(slots, r & (kPipeSlots - 1));
+        const int ray_id = __float_as_int(sl.misc[7]);
+        if (ray_id < 0) return;
+        float* dbg = GNERF_DBG_PTR(p.debug ? p.debug + int64_t(ray_id) * GNERF_DEBUG_SLOTS * n_all : nullptr);
+        float ws, wts;
+        march(sl.t_e, sl.sig_e, sl.w_s, S, lane, ws, wts);
+        lds_wave_sync();
+        const int n_w = S - 3;
+        float pw = 0.f;
+        if (lane < n_w) {
+            const float w0 = sl.w_s[lane], w1 = sl.w_s[lane + 1], w2 = sl.w_s[lane + 2];
+            pw = ((fmaxf(w0, w1) + fmaxf(w1, w2)) * 0.5f + 0.01f) + 1e-5f;
+        }
+        const float incl_pw = wave_scan_add(pw, lane);
+        const float inv_total = __builtin_amdgcn_rcpf(wave_last(incl_pw));
+        // cdf[i+1] = cumsum(pw * inv_total): scan the normalised terms like the reference does (pdf first, then cumsum)
+        const float incl = wave_scan_add(pw * inv_total, lane);
+        if (lane < n_w) sl.cdf[lane + 1] = incl;
+        if (lane == 0) sl.cdf[0] = 0.f;
+        if (n_w + 1 + lane < kPipeMaxS) sl.cdf[n_w + 1 + lane] = INFINITY;                  // lets the count below read 4 at a time
+        lds_wave_sync();
+        if (lane < F) {
+            const float u = sl.nf[lane];
+            int cnt = 0;                                                   // searchsorted(cdf, u, right=True) = #{cdf <= u}
+#pragma unroll 4                                       // 16 keys in flight per batch: enough to cover the LDS latency, few registers
+            for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {                    // cdf[n_w+1 ...] = +inf
+                const v4f c4 = *reinterpret_cast<const v4f*>(sl.cdf + o2);
+#pragma unroll
+                for (int c2 = 0; c2 < 4; c2++) cnt += (c4[c2] <= u) ? 1 : 0;
+            }
+            const int below = max(cnt - 1, 0), above = min(cnt, n_w);
+            const float cb = sl.cdf[below], ca = sl.cdf[above];
+            const float bb = (sl.t_e[below] + sl.t_e[below + 1]) * 0.5f;
+            const float ba = (sl.t_e[above] + sl.t_e[above + 1]) * 0.5f;
+            float denom = ca - cb;
+            if (denom < 1e-5f) denom = 1.f;
+            const float d = bb + (u - cb) * __builtin_amdgcn_rcpf(denom) * (ba - bb);
+            sl.t_e[fine_e0 + lane] = d;
+            if (dbg) dbg[GNERF_DBG_DEPTH_FINE * n_all + lane] = d;
+        }
+        if (dbg) {
+            if (lane < S) dbg[GNERF_DBG_SIGMA_COARSE * n_all + lane] = sl.sig_e[lane];
+            if (lane < S - 1) dbg[GNERF_DBG_WEIGHT_COARSE * n_all + lane] = sl.w_s[lane];
+        }
+    };
+    auto finalize = [&](int r) {                // D(r): merge by depth (renderer.py:157-167) + final march + per-sample colour weights
+        if (r < 0 || r >= nr) return;
+        PipeSlot sl = pipe_slot(slots, r & (kPipeSlots - 1));
+        const int ray_id = __float_as_int(sl.misc[7]);
+        if (ray_id < 0) return;
+        float* dbg = GNERF_DBG_PTR(p.debug ? p.debug + int64_t(ray_id) * GNERF_DEBUG_SLOTS * n_all : nullptr);
+        // stable rank in cat([coarse, fine]); coarse depths ascend by construction, ties: coarse first, lower index first
+        if (lane < F) {
+            const float key = sl.t_e[fine_e0 + lane];
+            int cnt = 0;
+#pragma unroll 4                                       // 16 keys in flight per batch: enough to cover the LDS latency, few registers
+            for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
+                const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + fine_e0 + o2);
+#pragma unroll
+                for (int c2 = 0; c2 < 4; c2++) cnt += (k4[c2] < key || (k4[c2] == key && o2 + c2 < lane)) ? 1 : 0;
+            }
+#pragma unroll 4                                       // 16 keys in flight per batch: enough to cover the LDS latency, few registers
+            for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
+                const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + o2);
+#pragma unroll
+                for (int c2 = 0; c2 < 4; c2++) cnt += (k4[c2] <= key) ? 1 : 0;
+            }
+            sl.rank_e[fine_e0 + lane] = cnt;
+            sl.s_t[cnt] = key;
+            sl.s_sig[cnt] = sl.sig_e[fine_e0 + lane];
+        }
+        if (lane < S) {
+            const float key = sl.t_e[lane];
+            int cnt = lane;
+#pragma unroll 4                                       // 16 keys in flight per batch: enough to cover the LDS latency, few registers
+            for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
+                const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + fine_e0 + o2);
+#pragma unroll
+                for (int c2 = 0; c2 < 4; c2++) cnt += (k4[c2] < key) ? 1 : 0;
+            }
+            sl.rank_e[lane] = cnt;
+            sl.s_t[cnt] = key;
+            sl.s_sig[cnt] = sl.sig_e[lane];
+        }
+        lds_wave_sync();
+        GNERF_STAMP(st, 13);    // merge ranks
+        float ws, wts;
+        march(sl.s_t, sl.s_sig, sl.w_s, n_all, lane, ws, wts);
+        lds_wave_sync();
+        GNERF_STAMP(st, 14);    // final march
+        for (int q = lane; q < n_all; q += 64) {
+            const int e = q < S ? q : fine_e0 + (q - S);
+            const int rk = sl.rank_e[e];
+            const float wl = rk > 0 ? sl.w_s[rk - 1] : 0.f, wr = rk < n_all - 1 ? sl.w_s[rk] : 0.f;
+            sl.v_e[e] = (wl + wr) * 0.5f;                       // midpoint colours (ray_marcher.py:27) regrouped per sample
+        }
+        if (lane == 0) {
+            sl.misc[8] = ws;
+            sl.misc[9] = wts;
+            blk_min = fminf(blk_min, sl.s_t[0]);
+            blk_max = fmaxf(blk_max, sl.s_t[n_all - 1]);
+        }
+        if (dbg) {
+            if (lane < F) dbg[GNERF_DBG_SIGMA_FINE * n_all + lane] = sl.sig_e[fine_e0 + lane];
+            for (int k = lane; k < n_all; k += 64) { dbg[GNERF_DBG_DEPTH_SORTED * n_all + k] = sl.s_t[k]; dbg[GNERF_DBG_SIGMA_SORTED * n_all + k] = sl.s_sig[k]; }
+            for (int k = lane; k < n_all - 1; k += 64) dbg[GNERF_DBG_WEIGHT_FINAL * n_all + k] = sl.w_s[k];
+        }
+    };
+    auto output = [&](int r) {                  // out(r): sum the shader waves' colour partials, write the three outputs
+        if (r < 0 || r >= nr) return;
+        PipeSlot sl = pipe_slot(slots, r & (kPipeSlots - 1));
+        const int ray_id = __float_as_int(sl.misc[7]);
+        if (ray_id < 0) return;
+        const float ws = sl.misc[8], wts = sl.misc[9];
+        if (lane < 32) {
+            float c = sl.part[lane] + sl.part[32 + lane] + sl.part[64 + lane];
+            if (p.white_back) c = c + 1.f - ws;
+            p.out_rgb[int64_t(ray_id) * 32 + lane] = c * 2.f - 1.f;
+        }
+        if (lane == 0) {
+            float depth = wts / ws;
+            if (depth != depth) depth = INFINITY;               // nan_to_num(nan=inf); the call-wide clamp is applied by clamp_depth_kernel
+            p.out_depth[ray_id] = depth;
+            p.out_wsum[ray_id] = ws;
+        }
+    };
+
+    // ------------------------------------------------------------------ shader-wave pieces (waves 0..2)
+    auto shade = [&](int r, bool fine, v4f (&col)[2]) {
+        if (r < 0 || r >= nr) return;
+        PipeSlot sl = pipe_slot(slots, r & (kPipeSlots - 1));
+        const int ray_id = __builtin_amdgcn_readfirstlane(__float_as_int(sl.misc[7]));
+        if (ray_id < 0) return;
+        CoopRay R;
+        const int item = __builtin_amdgcn_readfirstlane(__float_as_int(sl.misc[6]));
+        R.planes_item = reinterpret_cast<const char*>(p.planes_nhwc) + int64_t(item) * 3 * p.plane_h * p.plane_w * 128;
+        R.ox = sl.misc[0]; R.oy = sl.misc[1]; R.oz = sl.misc[2];
+        R.dx = sl.misc[3]; R.dy = sl.misc[4]; R.dz = sl.misc[5];
+        GNERF_STAMP(st, 0);     // ray parameters from the slot
+        if (!fine) coop_shade_tile<false>(P, L, R, sl.t_e, S, wv, wv < P.tiles_c, sl.sig_e, lane, wv, col, st);
+        else       coop_shade_tile<false>(P, L, R, sl.t_e + fine_e0, F, wv, wv < P.tiles_f, sl.sig_e + fine_e0, lane, wv, col, st);
+    };
+    auto accumulate = [&](int r, const v4f (&cc)[2], const v4f (&cf)[2]) {
+        if (r < 0 || r >= nr) return;
+        PipeSlot sl = pipe_slot(slots, r & (kPipeSlots - 1));
+        if (__float_as_int(sl.misc[7]) < 0) return;
+        const int j = lane & 15, g = lane >> 4;
+        float acc[2] = {0.f, 0.f};
+        if (wv < P.tiles_c) {
+            const v4f v = *reinterpret_cast<const v4f*>(sl.v_e + 16 * wv + 4 * g);
+#pragma unroll
+            for (int n = 0; n < 2; n++) acc[n] += v[0] * cc[n][0] + v[1] * cc[n][1] + v[2] * cc[n][2] + v[3] * cc[n][3];
+        }
+        if (wv < P.tiles_f) {
+            const v4f v = *reinterpret_cast<const v4f*>(sl.v_e + fine_e0 + 16 * wv + 4 * g);
+#pragma unroll
+            for (int n = 0; n < 2; n++) acc[n] += v[0] * cf[n][0] + v[1] * cf[n][1] + v[2] * cf[n][2] + v[3] * cf[n][3];
+        }
+#pragma unroll
+        for (int n = 0; n < 2; n++) acc[n] = row_sum4(acc[n]);
+        if (g < 2) sl.part[wv * 32 + 16 * g + j] = g == 0 ? acc[0] : acc[1];
+    };
+
+    // ------------------------------------------------------------------ the pipeline
+    __syncthreads();                                            // weights are in LDS
+    if (wv == 3) { propose_issue(0); propose_finish(0); }
+    __syncthreads();
+    v4f cc0[2] = {}, cc1[2] = {}, cc2[2] = {}, cf[2] = {};      // coarse colours of rays k-1, k, k+1; fine colours of ray k-1
+    st.reset();
+    for (int k = -1; k <= nr + 1; k++) {
+        // ---- step 2k+2
+        if (wv < 3) {
+            shade(k + 1, false, cc2);
+        } else {
+            finalize(k - 1);
+            GNERF_STAMP(st, 8);     // merge + final march
+            output(k - 2);
+            GNERF_STAMP(st, 9);     // outputs
+        }
+        GNERF_STAMP(st, 5);         // (shader: nothing) / scalar: rounding
+        __syncthreads();
+        GNERF_STAMP(st, 6);         // barrier wait, even step
+        // ---- step 2k+3
+        if (wv < 3) {
+            accumulate(k - 1, cc0, cf);
+            GNERF_STAMP(st, 10);    // colour accumulate
+            shade(k, true, cf);
+#pragma unroll
+            for (int n = 0; n < 2; n++) { cc0[n] = cc1[n]; cc1[n] = cc2[n]; }
+        } else {
+            propose_issue(k + 2);
+            importance(k + 1);
+            GNERF_STAMP(st, 11);    // coarse march + importance
+            propose_finish(k + 2);
+            GNERF_STAMP(st, 12);    // depth proposals
+        }
+        GNERF_STAMP(st, 5);
+        __syncthreads();
+        GNERF_STAMP(st, 7);         // barrier wait, odd step
+    }
+#ifdef GNERF_STAMPS
+    if (lane == 0 && p.debug) {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(p.debug) + (size_t(blockIdx.x) * 4 + wv) * 16;
+        for (int i = 0; i < 16; i++) out[i] = st.acc[i];
+        out[15] = nr;
+    }
+#endif
+    if (tid == 192) {
+        unsigned* range = static_cast<unsigned*>(p.workspace);
+        atomicMin(range + 0, ord_encode(blk_min));
+        atomicMax(range + 1, ord_encode(blk_max));
+    }
+}
