@@ -275,14 +275,15 @@ def test_bias_act_all_activations_and_orders(dev, dtype):
     from torch_utils.ops import bias_act
     from oracle import ops_ref as O
     torch.manual_seed(0)
-    tol = {torch.float32: 2e-5, torch.float16: 4e-3, torch.float64: 1e-12}[dtype]
+    tol = {torch.float32: 2e-5, torch.float16: 4e-3, torch.float64: 2e-7}[dtype]    # fp64: gain/alpha cross the plugin API as float32 (bias_act.cpp:36)
     x0 = (torch.randn(3, 6, 5, 7, dtype=torch.float64) * 2).to(dtype)
     b0 = torch.randn(6, dtype=torch.float64).to(dtype)
     dy0 = torch.randn(3, 6, 5, 7, dtype=torch.float64).to(dtype)
     dd0 = torch.randn(3, 6, 5, 7, dtype=torch.float64).to(dtype)
     xn, bn, dyn, ddn = [t.double().numpy() for t in (x0, b0, dy0, dd0)]
     for act in bias_act.activation_funcs:
-        for clamp in (None, 0.9):
+        for clamp in (None, 0.875):        # exactly representable in fp16/fp32/fp64 (the plugin takes clamp as a float32 and the
+            # backward mask compares the SAVED output with it, so an inexact bound would be dtype-dependent, as in the reference)
             x = x0.to(dev).requires_grad_(True)
             b = b0.to(dev).requires_grad_(True)
             y = bias_act.bias_act(x, b, act=act, clamp=clamp)
