@@ -39,6 +39,21 @@ __host__ __device__ inline size_t coop_lds_floats(int s_pad) {
 #define GNERF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
 #endif
 
+// timing-only ablation hooks (GNERF_ABLATE_ACT replaces the activations by cheap linear maps)
+__device__ __forceinline__ float act_softplus(float v, float x) {
+#ifdef GNERF_ABLATE_ACT
+    return x * 0.5f;
+#else
+    return v;
+#endif
+}
+__device__ __forceinline__ float act_sigmoid_rgb(float v, float x) {
+#ifdef GNERF_ABLATE_ACT
+    return x * 0.25f;
+#else
+    return v;
+#endif
+}
 __device__ __forceinline__ float softplus_hw(float x) {         // max(x,0) + ln2 * log2(1 + 2^(-|x| log2 e))
 #ifdef GNERF_ABLATE_ACT
     return x * 0.5f;
@@ -206,48 +221,91 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     const v4f f_lo = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g);
     const v4f f_hi = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g + 4);
     const float f[8] = {f_lo[0], f_lo[1], f_lo[2], f_lo[3], f_hi[0], f_hi[1], f_hi[2], f_hi[3]};
-    // ---- layer 1 (weights: W1 rows 16m + j, columns 8g..8g+7)
-    v4f h[4];
+    // ---- the MLP as one software-pipelined MFMA stream (64 matrix instructions back to back):
+    //   L1(0) | L1(1)+SP(0) | L1(2)+SP(1) | L1(3)+SP(2) | L2(0)+SP(3) | L2(1) | L2(2) | L2(3) | sigmoid
+    // L1(m): the 8 MFMAs of hidden block m (W1 rows 16m + j, columns 8g..8g+7; bias preloaded in the accumulator).
+    // SP(m): softplus of block m's 4 accumulator values, issued in 4-wide groups (exp x4, log x4, fma x4) in the
+    // shadow of the MFMAs of the next block -- four independent chains hide the transcendental latency, and the
+    // groups sit between MFMAs in program order because a wave issues in order.
+    // L2(m): 8 MFMAs consuming block m's activations (W2 rows 1 + 16n + j, columns 16m + 4g..+3); the density row is a
+    // 4-term FMA per block.  GNERF_SCHED() pins the interleave against the compiler's scheduler.
+    // weight fragments are fetched from LDS one block ahead of their MFMAs (a few live registers, latency covered)
+    v4f h[4], a_lo[4], a_hi[4], ws[4], w0[4], w1[4];
+    auto load_w1 = [&](int m) {
+        a_lo[m] = *reinterpret_cast<const v4f*>(L.w1 + (16 * m + j) * kW1Pitch + 8 * g);
+        a_hi[m] = *reinterpret_cast<const v4f*>(L.w1 + (16 * m + j) * kW1Pitch + 8 * g + 4);
+    };
+    auto load_w2 = [&](int m) {
+        ws[m] = *reinterpret_cast<const v4f*>(L.w2 + 16 * m + 4 * g);
+        w0[m] = *reinterpret_cast<const v4f*>(L.w2 + (1 + j) * kW2Pitch + 16 * m + 4 * g);
+        w1[m] = *reinterpret_cast<const v4f*>(L.w2 + (17 + j) * kW2Pitch + 16 * m + 4 * g);
+    };
 #pragma unroll
     for (int m = 0; m < 4; m++) h[m] = *reinterpret_cast<const v4f*>(L.b1 + 16 * m + 4 * g);
+    load_w1(0);
+    load_w1(1);
+    const float bc0 = L.b2[1 + j], bc1 = L.b2[17 + j];
+    v4f o[2] = {(v4f){bc0, bc0, bc0, bc0}, (v4f){bc1, bc1, bc1, bc1}};
+    v4f e, hv[4];
+    float sig = 0.f;
+    auto sp_exp = [&](int m) {
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const v4f a_lo = *reinterpret_cast<const v4f*>(L.w1 + (16 * m + j) * kW1Pitch + 8 * g);
-        const v4f a_hi = *reinterpret_cast<const v4f*>(L.w1 + (16 * m + j) * kW1Pitch + 8 * g + 4);
+        for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(-fabsf(h[m][r]) * 1.44269504088896341f);
+    };
+    auto sp_log = [&]() {
 #pragma unroll
-        for (int s = 0; s < 4; s++) h[m] = GNERF_MFMA(a_lo[s], f[s], h[m]);
+        for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_logf(1.0f + e[r]);
+    };
+    auto sp_fin = [&](int m) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) h[m] = GNERF_MFMA(a_hi[s], f[4 + s], h[m]);
+        for (int r = 0; r < 4; r++) hv[m][r] = act_softplus(fmaf(e[r], 0.693147180559945309f, fmaxf(h[m][r], 0.f)), h[m][r]);
+    };
+#define GNERF_SCHED() __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+    for (int s = 0; s < 4; s++) h[0] = GNERF_MFMA(a_lo[0][s], f[s], h[0]);
+#pragma unroll
+    for (int s = 0; s < 4; s++) h[0] = GNERF_MFMA(a_hi[0][s], f[4 + s], h[0]);
+#pragma unroll
+    for (int m = 1; m < 4; m++) {
+        if (m < 3) load_w1(m + 1); else load_w2(0);
+        h[m] = GNERF_MFMA(a_lo[m][0], f[0], h[m]); h[m] = GNERF_MFMA(a_lo[m][1], f[1], h[m]);
+        GNERF_SCHED(); sp_exp(m - 1); GNERF_SCHED();
+        h[m] = GNERF_MFMA(a_lo[m][2], f[2], h[m]); h[m] = GNERF_MFMA(a_lo[m][3], f[3], h[m]);
+        GNERF_SCHED(); sp_log(); GNERF_SCHED();
+        h[m] = GNERF_MFMA(a_hi[m][0], f[4], h[m]); h[m] = GNERF_MFMA(a_hi[m][1], f[5], h[m]);
+        GNERF_SCHED(); sp_fin(m - 1); GNERF_SCHED();
+        h[m] = GNERF_MFMA(a_hi[m][2], f[6], h[m]); h[m] = GNERF_MFMA(a_hi[m][3], f[7], h[m]);
     }
 #ifdef GNERF_STAMPS
-    asm volatile("" :: "v"(h[0][0]), "v"(h[1][0]), "v"(h[2][0]), "v"(h[3][0]));      // wait for layer 1 before stamping
+    asm volatile("" :: "v"(h[3][0]));      // wait for layer 1 before stamping
 #endif
-    GNERF_STAMP(st, 3);         // layer 1
-    // ---- activation, density row, layer 2 (weights: W2 rows 1 + 16n + j, columns 16m + 4g..+3)
-    float sig = 0.f;
-    v4f o[2];
-    const float bc0 = L.b2[1 + j], bc1 = L.b2[17 + j];
-    o[0] = (v4f){bc0, bc0, bc0, bc0};
-    o[1] = (v4f){bc1, bc1, bc1, bc1};
+    GNERF_STAMP(st, 3);         // layer 1 (+ softplus of blocks 0..2)
 #pragma unroll
     for (int m = 0; m < 4; m++) {
-        const v4f ws = *reinterpret_cast<const v4f*>(L.w2 + 16 * m + 4 * g);
-        const v4f w0 = *reinterpret_cast<const v4f*>(L.w2 + (1 + j) * kW2Pitch + 16 * m + 4 * g);
-        const v4f w1 = *reinterpret_cast<const v4f*>(L.w2 + (17 + j) * kW2Pitch + 16 * m + 4 * g);
+        if (m < 3) load_w2(m + 1);
+        o[0] = GNERF_MFMA(hv[m][0], w0[m][0], o[0]); o[1] = GNERF_MFMA(hv[m][0], w1[m][0], o[1]);
+        if (m == 0) { GNERF_SCHED(); sp_exp(3); GNERF_SCHED(); }
+        o[0] = GNERF_MFMA(hv[m][1], w0[m][1], o[0]); o[1] = GNERF_MFMA(hv[m][1], w1[m][1], o[1]);
+        if (m == 0) { GNERF_SCHED(); sp_log(); GNERF_SCHED(); }
+        o[0] = GNERF_MFMA(hv[m][2], w0[m][2], o[0]); o[1] = GNERF_MFMA(hv[m][2], w1[m][2], o[1]);
+        if (m == 0) { GNERF_SCHED(); sp_fin(3); GNERF_SCHED(); }
+        o[0] = GNERF_MFMA(hv[m][3], w0[m][3], o[0]); o[1] = GNERF_MFMA(hv[m][3], w1[m][3], o[1]);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float hv = softplus_hw(h[m][r]);
-            sig = fmaf(ws[r], hv, sig);
-            o[0] = GNERF_MFMA(hv, w0[r], o[0]);
-            o[1] = GNERF_MFMA(hv, w1[r], o[1]);
-        }
+        for (int r = 0; r < 4; r++) sig = fmaf(ws[m][r], hv[m][r], sig);
     }
+#undef GNERF_SCHED
     sig = row_sum4(sig) + L.b2[0];
     if (active && g == 0 && 16 * tile + j < count) sig_list[16 * tile + j] = sig;
+    // rgb = sigmoid(o) * 1.002 - 0.001 (triplane.py:134), again in 4-wide groups
 #pragma unroll
     for (int n = 0; n < 2; n++) {
+        v4f t;
 #pragma unroll
-        for (int r = 0; r < 4; r++) col[n][r] = sigmoid_rgb_hw(o[n][r]);
+        for (int r = 0; r < 4; r++) t[r] = __builtin_amdgcn_exp2f(o[n][r] * -1.44269504088896341f);
+#pragma unroll
+        for (int r = 0; r < 4; r++) t[r] = __builtin_amdgcn_rcpf(1.0f + t[r]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) col[n][r] = act_sigmoid_rgb(fmaf(t[r], 1.002f, -0.001f), o[n][r]);
     }
 #ifdef GNERF_STAMPS
     asm volatile("" :: "v"(col[0][0]), "v"(col[1][3]));

@@ -63,6 +63,9 @@ __device__ __forceinline__ int pipe_seq_to_ray(const Params& P, int64_t seq) {
     return seq < P.total_rays ? int(seq) : -1;
 }
 
+#ifndef GNERF_SCALAR_PRIO
+#define GNERF_SCALAR_PRIO 3
+#endif
 #ifndef GNERF_PIPE_WAVES_PER_SIMD
 #define GNERF_PIPE_WAVES_PER_SIMD 3
 #endif
@@ -201,39 +204,53 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
         const int ray_id = __float_as_int(sl.misc[7]);
         if (ray_id < 0) return;
         float* dbg = GNERF_DBG_PTR(p.debug ? p.debug + int64_t(ray_id) * GNERF_DEBUG_SLOTS * n_all : nullptr);
-        // stable rank in cat([coarse, fine]); coarse depths ascend by construction, ties: coarse first, lower index first
+        // Stable rank in cat([coarse, fine]).  Coarse depths ascend by construction, so
+        //   rank(coarse k) = k + #{fine < t_k}            rank(fine i) = #{coarse <= t_i} + #{fine before i}
+        // (ties: coarse first, then lower index -- what a stable sort of the concatenation gives).  All three counts are
+        // compare + add-with-carry scans over keys read four at a time as LDS broadcasts.  "#fine before i" is first taken
+        // as #{fine < t_i}; two fine samples with bit-identical depth then collide on a rank, which is detected through
+        // an owner table and repaired by a tie-broken recount (rare: needs two equal uniform draws or rounding collisions).
+        int rank_f = 0, rank_c = lane;
+        float key_f = 0.f, key_c = 0.f;
         if (lane < F) {
-            const float key = sl.t_e[fine_e0 + lane];
-            int cnt = 0;
-#pragma unroll 4                                       // 16 keys in flight per batch: enough to cover the LDS latency, few registers
+            key_f = sl.t_e[fine_e0 + lane];
+#pragma unroll 4
             for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
                 const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + fine_e0 + o2);
 #pragma unroll
-                for (int c2 = 0; c2 < 4; c2++) cnt += (k4[c2] < key || (k4[c2] == key && o2 + c2 < lane)) ? 1 : 0;
+                for (int c2 = 0; c2 < 4; c2++) rank_f += (k4[c2] < key_f) ? 1 : 0;
             }
-#pragma unroll 4                                       // 16 keys in flight per batch: enough to cover the LDS latency, few registers
+#pragma unroll 4
             for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
                 const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + o2);
 #pragma unroll
-                for (int c2 = 0; c2 < 4; c2++) cnt += (k4[c2] <= key) ? 1 : 0;
+                for (int c2 = 0; c2 < 4; c2++) rank_f += (k4[c2] <= key_f) ? 1 : 0;
             }
-            sl.rank_e[fine_e0 + lane] = cnt;
-            sl.s_t[cnt] = key;
-            sl.s_sig[cnt] = sl.sig_e[fine_e0 + lane];
+            sl.rank_e[fine_e0 + lane] = rank_f;
+            reinterpret_cast<int*>(sl.w_s)[rank_f] = lane;          // owner table (w_s is free until the final march)
         }
         if (lane < S) {
-            const float key = sl.t_e[lane];
-            int cnt = lane;
-#pragma unroll 4                                       // 16 keys in flight per batch: enough to cover the LDS latency, few registers
+            key_c = sl.t_e[lane];
+#pragma unroll 4
             for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
                 const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + fine_e0 + o2);
 #pragma unroll
-                for (int c2 = 0; c2 < 4; c2++) cnt += (k4[c2] < key) ? 1 : 0;
+                for (int c2 = 0; c2 < 4; c2++) rank_c += (k4[c2] < key_c) ? 1 : 0;
             }
-            sl.rank_e[lane] = cnt;
-            sl.s_t[cnt] = key;
-            sl.s_sig[cnt] = sl.sig_e[lane];
+            sl.rank_e[lane] = rank_c;
         }
+        lds_wave_sync();
+        const bool clash = lane < F && reinterpret_cast<const int*>(sl.w_s)[rank_f] != lane;
+        if (__any(clash)) {                                         // wave-uniform, rare
+            if (lane < F) {
+                int fix = 0;
+                for (int o2 = 0; o2 < F; o2++) fix += (sl.t_e[fine_e0 + o2] == key_f && o2 < lane) ? 1 : 0;
+                rank_f += fix;
+                sl.rank_e[fine_e0 + lane] = rank_f;
+            }
+        }
+        if (lane < F) { sl.s_t[rank_f] = key_f; sl.s_sig[rank_f] = sl.sig_e[fine_e0 + lane]; }
+        if (lane < S) { sl.s_t[rank_c] = key_c; sl.s_sig[rank_c] = sl.sig_e[lane]; }
         lds_wave_sync();
         GNERF_STAMP(st, 13);    // merge ranks
         float ws, wts;
@@ -314,6 +331,10 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
     };
 
     // ------------------------------------------------------------------ the pipeline
+    // The scalar wave is one instruction stream against three, shares its SIMD's issue port with MFMA-heavy shader
+    // waves, and every step ends when it does: give it issue priority (costs the shaders little, it is mostly waiting
+    // on LDS round trips).
+    if (wv == 3) __builtin_amdgcn_s_setprio(GNERF_SCALAR_PRIO);
     __syncthreads();                                            // weights are in LDS
     if (wv == 3) { propose_issue(0); propose_finish(0); }
     __syncthreads();

@@ -149,6 +149,28 @@ def test_render_vs_oracle(dev, cfg):
     np.testing.assert_allclose(wsum.cpu().numpy(), ref_w.numpy(), atol=2e-4)
 
 
+@pytest.mark.parametrize('S,F', [(48, 48), (24, 40), (96, 96)])
+def test_render_tied_fine_depths(dev, S, F):
+    """Equal uniform draws give bit-identical fine depths: the merge must still produce a permutation (stable order,
+    like torch.sort on the concatenation).  Exercises the tie-repair path of the merge in every kernel."""
+    import gnerf_hip
+    from oracle import render_ref as R
+    planes, dec, o, d, nc, nf = _random_scene(11, N=1, res=8, S=S, F=F, hw=(16, 16))
+    nf = nf.clone()
+    nf[:, 5] = nf[:, 9]
+    nf[:, 20] = nf[:, 21]
+    nf[:, 30] = nf[:, 21]
+    nf[3, :] = nf[3, 0]                       # one ray whose fine samples all coincide
+    opts = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, clamp_mode='softplus')
+    ref_rgb, ref_depth, ref_w = R.render(planes, dec, o, d, opts, nc, nf)
+    nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
+    rgb, depth, wsum = gnerf_hip.render_forward(nhwc, 1, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev),
+                                                depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=8)
+    assert float(((rgb.cpu() - ref_rgb) ** 2).mean()) < 1e-8
+    np.testing.assert_allclose(depth.cpu().numpy(), ref_depth.numpy(), atol=2e-4)
+    np.testing.assert_allclose(wsum.cpu().numpy(), ref_w.numpy(), atol=2e-4)
+
+
 def test_render_per_ray_limits_vs_oracle(dev):
     """'auto' ray limits: per-ray start/end tensors (renderer.py:93-98, math_utils.linspace)."""
     import gnerf_hip
