@@ -20,6 +20,21 @@ constexpr int kW1Pitch = 36;        // floats per LDS row of W1 [64 x 32]
 constexpr int kW2Pitch = 68;        // floats per LDS row of W2 [33 x 64]
 constexpr int kTapDwords = 24;      // per sample: 3 planes x (4 byte offsets + 4 weights)
 
+// Decoder weights in LDS.  Two formats:
+//  * default, "f16x3": every fp32 weight w is stored as two halves (hi = f16(w), lo = f16(w - hi)) in MFMA fragment
+//    order, and each product of the MLP is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with fp32
+//    accumulation (the dropped lo*lo term and the split's own rounding are ~2^-21 relative, i.e. fp32-grade: the
+//    renderer's pixel MSE against the reference stays ~1e-13).  24 matrix instructions x 16 cycles per 16-sample tile
+//    instead of 64 x 32 cycles of v_mfma_f32_16x16x4_f32.
+//  * -DGNERF_MLP_F32: plain fp32 rows (exact fp32 products on the fp32-input MFMA), the round-1 baseline.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr int kW1HalfPitch = 40;    // halves per LDS row of W1 hi / lo (32 + pad: conflict-free ds_read_b128)
+#ifdef GNERF_MLP_F32
+constexpr int kWeightFloats = 64 * 36 + 33 * 68;
+#else
+constexpr int kWeightFloats = (2 * 64 * kW1HalfPitch + 2 * 2048) / 2 + 64;     // W1 hi+lo, W2 hi+lo (fragment order), density row fp32
+#endif
+
 struct CoopLds {
     float* w1; float* w2; float* b1; float* b2;
     float* t_e; float* sig_e; float* v_e; int* rank_e; float* s_t; float* s_sig; float* w_s; float* cdf;
@@ -29,14 +44,16 @@ struct CoopLds {
 };
 
 __host__ __device__ inline size_t coop_lds_floats(int s_pad) {
-    return size_t(64) * kW1Pitch + 33 * kW2Pitch + 64 + 36 + size_t(8) * s_pad +
+    return size_t(kWeightFloats) + 64 + 36 + size_t(8) * s_pad +
            kCoopWaves * 16 * kTapDwords + kCoopWaves * 16 * kStagePitch + kCoopWaves * 32 + 4;
 }
 
 #ifdef GNERF_ABLATE_MFMA         // timing-only build: one FMA per lane instead of a matrix instruction
 #define GNERF_MFMA(a, b, c) ((c) + (a) * (b))
+#define GNERF_MFMA16(a, b, c) ((c) + float((a)[0]) * float((b)[0]))
 #else
 #define GNERF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+#define GNERF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 #endif
 
 // timing-only ablation hooks (GNERF_ABLATE_ACT replaces the activations by cheap linear maps)
@@ -109,6 +126,40 @@ struct Stamps {
 struct Stamps { __device__ __forceinline__ void reset() {} };
 #define GNERF_STAMP(st, i) ((void)0)
 #endif
+
+// Copy the decoder into LDS (all threads of the workgroup; a barrier must follow).  base = start of the weight area.
+__device__ __forceinline__ void stage_decoder(CoopLds& L, float* base, const gnerf_render_params& p, int tid, int nthreads) {
+    L.w1 = base;
+#ifdef GNERF_MLP_F32
+    L.w2 = L.w1 + 64 * kW1Pitch;
+    for (int i = tid; i < 64 * 32; i += nthreads) L.w1[(i >> 5) * kW1Pitch + (i & 31)] = p.w1[i];
+    for (int i = tid; i < 33 * 64; i += nthreads) L.w2[(i >> 6) * kW2Pitch + (i & 63)] = p.w2[i];
+#else
+    _Float16* w1h = reinterpret_cast<_Float16*>(base);                 // [hi|lo][64][kW1HalfPitch]
+    _Float16* w2h = w1h + 2 * 64 * kW1HalfPitch;                       // [hi|lo][n=2][s=2][j=16][g=4][8]
+    L.w2 = base + (2 * 64 * kW1HalfPitch + 2 * 2048) / 2;              // density row W2[0][:] in fp32
+    for (int i = tid; i < 64 * 32; i += nthreads) {
+        const float x = p.w1[i];
+        const _Float16 hi = (_Float16)x;
+        w1h[(i >> 5) * kW1HalfPitch + (i & 31)] = hi;
+        w1h[64 * kW1HalfPitch + (i >> 5) * kW1HalfPitch + (i & 31)] = (_Float16)(x - (float)hi);
+    }
+    for (int i = tid; i < 2048; i += nthreads) {
+        // fragment order of layer 2's B operand: lane (out column j, k-group g) of k-step s holds, at position jj,
+        // hidden unit 32 s + 16 (jj >> 2) + 4 g + (jj & 3) -- the unit whose activation that lane group carries there
+        const int jj = i & 7, g = (i >> 3) & 3, j = (i >> 5) & 15, s = (i >> 9) & 1, n = i >> 10;
+        const float x = p.w2[(1 + 16 * n + j) * 64 + 32 * s + 16 * (jj >> 2) + 4 * g + (jj & 3)];
+        const _Float16 hi = (_Float16)x;
+        w2h[i] = hi;
+        w2h[2048 + i] = (_Float16)(x - (float)hi);
+    }
+    for (int i = tid; i < 64; i += nthreads) L.w2[i] = p.w2[i];
+#endif
+    L.b1 = base + kWeightFloats;
+    L.b2 = L.b1 + 64;
+    for (int i = tid; i < 64; i += nthreads) L.b1[i] = p.b1[i];
+    for (int i = tid; i < 33; i += nthreads) L.b2[i] = p.b2[i];
+}
 
 // v + (v from lane^16) + (v from lane^32) + (v from lane^48): sum over the four 16-lane rows, result in every lane.
 // gfx950's v_permlane16_swap / v_permlane32_swap exchange rows between two registers; two swaps + two adds
@@ -221,6 +272,7 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     const v4f f_lo = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g);
     const v4f f_hi = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g + 4);
     const float f[8] = {f_lo[0], f_lo[1], f_lo[2], f_lo[3], f_hi[0], f_hi[1], f_hi[2], f_hi[3]};
+#ifdef GNERF_MLP_F32
     // ---- the MLP as one software-pipelined MFMA stream (64 matrix instructions back to back):
     //   L1(0) | L1(1)+SP(0) | L1(2)+SP(1) | L1(3)+SP(2) | L2(0)+SP(3) | L2(1) | L2(2) | L2(3) | sigmoid
     // L1(m): the 8 MFMAs of hidden block m (W1 rows 16m + j, columns 8g..8g+7; bias preloaded in the accumulator).
@@ -294,6 +346,92 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
         for (int r = 0; r < 4; r++) sig = fmaf(ws[m][r], hv[m][r], sig);
     }
 #undef GNERF_SCHED
+#else
+    // ---- the MLP on v_mfma_f32_16x16x32_f16, every product as hi*hi + hi*lo + lo*hi with fp32 accumulation.
+    // Layer 1: H^T block m [16 hidden x 16 samples] = W1 block [16 x 32] . X^T [32 x 16]: ONE k-step (K = 32 channels);
+    // A = this lane's 8 weights W1[16m + j][8g..8g+7], B = its 8 staged features (channels 8g..8g+7 of sample j).
+    const _Float16* w1h = reinterpret_cast<const _Float16*>(L.w1);
+    const _Float16* w2h = w1h + 2 * 64 * kW1HalfPitch;
+    h8 fh, fl;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const _Float16 t = (_Float16)f[i]; fh[i] = t; fl[i] = (_Float16)(f[i] - (float)t); }
+    v4f h[4];
+    h8 a_hi[4], a_lo[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        h[m] = *reinterpret_cast<const v4f*>(L.b1 + 16 * m + 4 * g);
+        a_hi[m] = *reinterpret_cast<const h8*>(w1h + (16 * m + j) * kW1HalfPitch + 8 * g);
+        a_lo[m] = *reinterpret_cast<const h8*>(w1h + 64 * kW1HalfPitch + (16 * m + j) * kW1HalfPitch + 8 * g);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) h[m] = GNERF_MFMA16(a_hi[m], fh, h[m]);
+#pragma unroll
+    for (int m = 0; m < 4; m++) h[m] = GNERF_MFMA16(a_hi[m], fl, h[m]);
+#pragma unroll
+    for (int m = 0; m < 4; m++) h[m] = GNERF_MFMA16(a_lo[m], fh, h[m]);
+    // layer-2 weight fragments (B operand) for n = 0,1 and k-step s = 0,1; fetched only now (the scheduling barrier
+    // keeps the compiler from hoisting these 32 registers above layer 1, where they would force spills)
+    __builtin_amdgcn_sched_barrier(0);
+    h8 w_hi[2][2], w_lo[2][2];
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            w_hi[n][s] = *reinterpret_cast<const h8*>(w2h + (((n * 2 + s) * 16 + j) * 4 + g) * 8);
+            w_lo[n][s] = *reinterpret_cast<const h8*>(w2h + 2048 + (((n * 2 + s) * 16 + j) * 4 + g) * 8);
+        }
+    }
+#ifdef GNERF_STAMPS
+    asm volatile("" :: "v"(h[3][0]));
+#endif
+    GNERF_STAMP(st, 3);         // layer 1
+    // softplus in 4-wide groups (four independent exp2/log2 chains), density row in fp32 on the VALU
+    float sig = 0.f;
+    v4f hv[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        v4f e;
+#pragma unroll
+        for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(-fabsf(h[m][r]) * 1.44269504088896341f);
+#pragma unroll
+        for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_logf(1.0f + e[r]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) hv[m][r] = act_softplus(fmaf(e[r], 0.693147180559945309f, fmaxf(h[m][r], 0.f)), h[m][r]);
+        const v4f ws = *reinterpret_cast<const v4f*>(L.w2 + 16 * m + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; r++) sig = fmaf(ws[r], hv[m][r], sig);
+    }
+    // Layer 2: O [16 samples x 16 outs] = H [16 x 64] . W2^T: two k-steps of 32; this lane contributes, at k-step s,
+    // its activations of blocks 2s and 2s+1 (weights were stored in the matching order by stage_decoder).
+    const float bc0 = L.b2[1 + j], bc1 = L.b2[17 + j];
+    v4f o[2] = {(v4f){bc0, bc0, bc0, bc0}, (v4f){bc1, bc1, bc1, bc1}};
+    h8 x_hi[2], x_lo[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) {
+            const float x = hv[2 * s + (jj >> 2)][jj & 3];
+            const _Float16 t = (_Float16)x;
+            x_hi[s][jj] = t;
+            x_lo[s][jj] = (_Float16)(x - (float)t);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int n = 0; n < 2; n++) o[n] = GNERF_MFMA16(x_hi[s], w_hi[n][s], o[n]);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int n = 0; n < 2; n++) o[n] = GNERF_MFMA16(x_hi[s], w_lo[n][s], o[n]);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int n = 0; n < 2; n++) o[n] = GNERF_MFMA16(x_lo[s], w_hi[n][s], o[n]);
+    }
+#endif
     sig = row_sum4(sig) + L.b2[0];
     if (active && g == 0 && 16 * tile + j < count) sig_list[16 * tile + j] = sig;
     // rgb = sigmoid(o) * 1.002 - 0.001 (triplane.py:134), again in 4-wide groups
@@ -322,11 +460,7 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
     const int S = p.depth_resolution, F = p.depth_resolution_importance;
     const int s_pad = 16 * (P.tiles_c + P.tiles_f);
     CoopLds L;
-    L.w1 = smem;
-    L.w2 = L.w1 + 64 * kW1Pitch;
-    L.b1 = L.w2 + 33 * kW2Pitch;
-    L.b2 = L.b1 + 64;
-    L.t_e = L.b2 + 36;
+    L.t_e = smem + kWeightFloats + 64 + 36;
     L.sig_e = L.t_e + s_pad;
     L.v_e = L.sig_e + s_pad;
     L.rank_e = reinterpret_cast<int*>(L.v_e + s_pad);
@@ -343,10 +477,7 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
     if (tile_id >= P.n_tiles) return;
 
     // decoder -> LDS (padded rows), once per workgroup
-    for (int i = tid; i < 64 * 32; i += kCoopThreads) L.w1[(i >> 5) * kW1Pitch + (i & 31)] = p.w1[i];
-    for (int i = tid; i < 33 * 64; i += kCoopThreads) L.w2[(i >> 6) * kW2Pitch + (i & 63)] = p.w2[i];
-    if (tid < 64) L.b1[tid] = p.b1[tid];
-    if (tid < 33) L.b2[tid] = p.b2[tid];
+    stage_decoder(L, smem, p, tid, kCoopThreads);
 
     const int fine_e0 = 16 * P.tiles_c;
     const int n_all = S + F;

@@ -48,7 +48,7 @@ __device__ __forceinline__ PipeSlot pipe_slot(float* base, int slot) {
 }
 
 __host__ __device__ inline size_t pipe_lds_floats() {
-    return size_t(64) * kW1Pitch + 33 * kW2Pitch + 64 + 36 + size_t(kPipeSlots) * kSlotFloats + 3 * 16 * kTapDwords + 3 * 16 * kStagePitch;
+    return size_t(kWeightFloats) + 64 + 36 + size_t(kPipeSlots) * kSlotFloats + 3 * 16 * kTapDwords + 3 * 16 * kStagePitch;
 }
 
 // position `seq` of the locality-ordered ray sequence -> ray index (or -1 past the end)
@@ -80,11 +80,7 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
     constexpr int fine_e0 = kPipeMaxS, s_pad = kPipeSPad;
     const int n_all = S + F;
     CoopLds L;
-    L.w1 = smem;
-    L.w2 = L.w1 + 64 * kW1Pitch;
-    L.b1 = L.w2 + 33 * kW2Pitch;
-    L.b2 = L.b1 + 64;
-    float* slots = L.b2 + 36;
+    float* slots = smem + kWeightFloats + 64 + 36;
     L.taps = slots + kPipeSlots * kSlotFloats;
     L.stage = L.taps + 3 * 16 * kTapDwords;
 
@@ -95,10 +91,7 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
     const int64_t seq0 = total_seq * chunk / G, seq1 = total_seq * (chunk + 1) / G;
     const int nr = int(seq1 - seq0);
 
-    for (int i = tid; i < 64 * 32; i += kPipeThreads) L.w1[(i >> 5) * kW1Pitch + (i & 31)] = p.w1[i];
-    for (int i = tid; i < 33 * 64; i += kPipeThreads) L.w2[(i >> 6) * kW2Pitch + (i & 63)] = p.w2[i];
-    if (tid < 64) L.b1[tid] = p.b1[tid];
-    if (tid < 33) L.b2[tid] = p.b2[tid];
+    stage_decoder(L, smem, p, tid, kPipeThreads);
 
     Stamps st;
     // ------------------------------------------------------------------ scalar-wave pieces (lambdas, wave 3 only)
