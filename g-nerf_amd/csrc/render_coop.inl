@@ -184,9 +184,11 @@ struct CoopRay {
 // only wave-level ordering: BLOCK_SYNC=false uses lds_wave_sync() (s_waitcnt, no s_barrier) and the call may
 // then sit in wave-divergent control flow; BLOCK_SYNC=true keeps workgroup barriers (all waves must call).
 __device__ __forceinline__ void lds_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt lgkmcnt(0): this wave's LDS writes have landed
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // LDS instructions of one wave execute in order, so a hand-off between lanes of the SAME wave only needs the
+    // writes to have been issued before the reads: wait for this wave's LDS queue and stop the compiler from moving
+    // memory operations across.  Deliberately NOT a fence: a workgroup-scope release would also wait for every global
+    // load/store in flight (vmcnt(0)), serialising the scalar wave's prefetches and output stores.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 template <bool BLOCK_SYNC>
 __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& L, const CoopRay& R, const float* t_list, int count,

@@ -1,0 +1,138 @@
+"""Host-side pieces of the inference harness that surround the hot path: the camera
+orbit of gen_videos.py, uint8 frame conversion, and one-process-per-GPU sharding of frames/rays with the single
+collective the path needs (a gather of uint8 frames).  No device kernels here; the renderer itself is
+training.volumetric_rendering.renderer.ImportanceRenderer.
+
+Reference behaviour reproduced (g_nerf/):
+  * camera for frame i of n: LookAtPoseSampler.sample(3.14/2 + 0.7 sin(2*3.14*i/n), 3.14/2 - 0.05 + 0.3 cos(2*3.14*i/n),
+    radius)  -- gen_videos.py:155-158 (note 3.14, not pi), camera_utils.py:89-106,155-174
+  * intrinsics [[4.2647,0,.5],[0,4.2647,.5],[0,0,1]] -- gen_videos.py:135
+  * c = cat(cam2world.reshape(16), intrinsics.reshape(9)) -- gen_videos.py:170
+  * uint8 = (img * 127.5 + 128).clamp(0, 255) -- gen_videos.py:173
+"""
+
+import math
+import os
+
+import torch
+
+FFHQ_INTRINSICS = ((4.2647, 0.0, 0.5), (0.0, 4.2647, 0.5), (0.0, 0.0, 1.0))
+
+
+def lookat_pose(yaw, pitch, radius, device='cpu'):
+    """cam2world [1,4,4] of a camera on a sphere of `radius` looking at the origin, y up, no roll."""
+    dt = torch.float32
+    theta = torch.tensor([[yaw]], dtype=dt)
+    phi = torch.tensor([[pitch]], dtype=dt)
+    org = torch.zeros(1, 3, dtype=dt)
+    org[:, 0:1] = radius * torch.sin(phi) * torch.cos(math.pi - theta)
+    org[:, 2:3] = radius * torch.sin(phi) * torch.sin(math.pi - theta)
+    org[:, 1:2] = radius * torch.cos(phi)
+
+    def unit(v):
+        return v / torch.norm(v, dim=-1, keepdim=True)
+
+    fwd = unit(unit(-org))
+    up = torch.tensor([[0.0, 1.0, 0.0]], dtype=dt)
+    right = -unit(torch.cross(up, fwd, dim=-1))
+    up2 = unit(torch.cross(fwd, right, dim=-1))
+    rot = torch.eye(4, dtype=dt)[None].clone()
+    rot[:, :3, :3] = torch.stack((right, up2, fwd), dim=-1)
+    trans = torch.eye(4, dtype=dt)[None].clone()
+    trans[:, :3, 3] = org
+    return (trans @ rot).to(device)
+
+
+def orbit_pose(i, frame_num=120, radius=2.7, yaw_range=0.7, pitch_range=0.3, device='cpu'):
+    """cam2world of frame i of gen_videos.py's orbit."""
+    yaw = 3.14 / 2 + yaw_range * math.sin(2 * 3.14 * i / frame_num)
+    pitch = 3.14 / 2 - 0.05 + pitch_range * math.cos(2 * 3.14 * i / frame_num)
+    return lookat_pose(yaw, pitch, radius, device)
+
+
+def camera_label(cam2world, intrinsics=FFHQ_INTRINSICS):
+    """The 25-float conditioning vector c the generator's synthesis() takes."""
+    k = torch.tensor(intrinsics, dtype=torch.float32, device=cam2world.device)
+    n = cam2world.shape[0]
+    return torch.cat([cam2world.reshape(n, 16), k.reshape(1, 9).expand(n, -1)], 1)
+
+
+def to_uint8(img):
+    """[-1,1] float image(s) [N,C,H,W] -> uint8 [N,H,W,C] like gen_videos.py:173."""
+    return (img * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# one process per GPU
+
+
+def init_from_env():
+    """(rank, world_size, local_rank).  Initialises torch.distributed from RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*
+    when WORLD_SIZE > 1: backend 'nccl' (= RCCL on ROCm) if a GPU is visible, else 'gloo'."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            use_gpu = torch.cuda.is_available()
+            if use_gpu:
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            else:
+                dist.init_process_group('gloo')
+    return rank, world, local_rank
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block [lo, hi) of n_items owned by `rank`: sizes differ by at most one, earlier ranks get the extras
+    (240 frames over 8 ranks -> 30 consecutive frames each, BASELINE.json config 4)."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_frames(frames, n_total, dst=0):
+    """frames: this rank's uint8 block [n_local, ...] (its shard_range of n_total).  Returns the full
+    [n_total, ...] tensor on rank `dst` (None elsewhere).  One collective: an all_gather of equal-size padded
+    blocks of uint8 (RCCL over xGMI on GPUs; 189 MB in total for 240 frames of 512x512x3)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return frames
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per = (n_total + world - 1) // world
+    pad = torch.zeros((per,) + tuple(frames.shape[1:]), dtype=frames.dtype, device=frames.device)
+    pad[:frames.shape[0]] = frames
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    if rank != dst:
+        return None
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        parts.append(out[r][:hi - lo])
+    return torch.cat(parts, 0)
+
+
+def max_over_ranks(value, device='cpu'):
+    """max of a python float over all ranks (the elapsed-time reduction of bench.py)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def render_orbit(render_frame, n_frames, rank=0, world=1, **orbit_kwargs):
+    """Render this rank's block of an n_frames orbit.  render_frame(i, cam2world) -> uint8 [H,W,3] (or [1,H,W,3]).
+    Returns (frames uint8 [n_local,H,W,3], (lo, hi))."""
+    lo, hi = shard_range(n_frames, rank, world)
+    frames = []
+    for i in range(lo, hi):
+        f = render_frame(i, orbit_pose(i, frame_num=n_frames, **orbit_kwargs))
+        frames.append(f.reshape((1,) + tuple(f.shape[-3:])))
+    if not frames:
+        return None, (lo, hi)
+    return torch.cat(frames, 0), (lo, hi)

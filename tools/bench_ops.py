@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""GB/s of the HBM-bound custom ops at the shapes a G-NeRF forward issues.
+Algorithmic bytes = tensors in + tensors out; time = HIP events on the launch stream.  Prints one JSON line per case."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, 'g-nerf_amd'), ROOT]
+import torch
+from torch_utils import custom_ops
+custom_ops.verbosity = 'none'
+from torch_utils.ops import bias_act, upfirdn2d
+import gnerf_hip
+
+dev = torch.device('cuda', 0)
+PEAK = 8000.0
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(3):
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / reps)
+    return best
+
+
+def report(name, ms, nbytes):
+    gbs = nbytes / ms / 1e6
+    print(json.dumps({'op': name, 'ms': round(ms, 4), 'algorithmic_MB': round(nbytes / 1e6, 2), 'GBs': round(gbs, 1), 'frac_of_8TBs': round(gbs / PEAK, 3)}))
+
+
+with torch.no_grad():
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device=dev)
+    for dt, nm in ((torch.float16, 'f16'), (torch.float32, 'f32')):
+        es = 2 if dt == torch.float16 else 4
+        x = torch.randn(4, 128, 512, 512, device=dev, dtype=dt)
+        b = torch.randn(128, device=dev, dtype=dt)
+        ms = timeit(lambda: bias_act.bias_act(x, b, act='lrelu', clamp=256))
+        report(f'bias_act lrelu+clamp [4,128,512,512] {nm}', ms, (2 * x.numel() + 128) * es)
+        xb = torch.randn(4, 128, 513, 513, device=dev, dtype=dt)
+        ms = timeit(lambda: upfirdn2d.upfirdn2d(xb, f, padding=[1, 1, 1, 1], gain=4))
+        report(f'upfirdn2d blur 4x4 [4,128,513,513]->512 {nm}', ms, (xb.numel() + 4 * 128 * 512 * 512) * es)
+        xu = torch.randn(4, 96, 128, 128, device=dev, dtype=dt)
+        ms = timeit(lambda: upfirdn2d.upfirdn2d(xu, f, up=2, padding=[2, 1, 2, 1], gain=4))
+        report(f'upfirdn2d up2 4x4 [4,96,128,128]->256 {nm}', ms, (xu.numel() + 4 * 96 * 256 * 256) * es)
+        xi = torch.randn(4, 3, 256, 256, device=dev, dtype=dt)
+        ms = timeit(lambda: upfirdn2d.upfirdn2d(xi, f, up=2, padding=[2, 1, 2, 1], gain=4))
+        report(f'upfirdn2d up2 4x4 [4,3,256,256]->512 {nm}', ms, (xi.numel() + 4 * 3 * 512 * 512) * es)
+    planes = torch.randn(4, 3, 32, 256, 256, device=dev)
+    ms = timeit(lambda: gnerf_hip.planes_to_nhwc(planes))
+    report('planes NCHW->NHWC [12,32,256,256] f32', ms, 2 * planes.numel() * 4)
+    # torch's own elementwise path for scale: same bytes as bias_act
+    x = torch.randn(4, 128, 512, 512, device=dev, dtype=torch.float16)
+    ms = timeit(lambda: torch.nn.functional.leaky_relu(x, 0.2))
+    report('(torch leaky_relu, same bytes, for scale) f16', ms, 2 * x.numel() * 2)
