@@ -135,6 +135,46 @@ __global__ __launch_bounds__(kThreads) void bias_act_kernel(Args a) {
     }
 }
 
+// Row form for the common NCHW case (bias stride = H*W, large and a multiple of the vector width): the tensor is
+// [rows = numel / step_b][step_b] and the bias is constant along a row, so blockIdx.y = row makes the bias index a
+// per-workgroup scalar -- no per-vector integer division, which otherwise costs as much as the activation itself
+// (measured on [4,128,512,512]: fp16 3.5 -> 4.8 TB/s, fp32 5.0 -> 5.7 TB/s).
+constexpr int kRowVecsPerLane = 4;
+
+template <class T, int ACT, int VEC>
+__global__ __launch_bounds__(kThreads) void bias_act_rows_kernel(Args a) {
+    typedef typename Arith<T>::type A;
+    typedef Pack<T, VEC> P;
+    const A alpha = A(a.alpha), gain = A(a.gain), clamp = A(a.clamp);
+    const T* x = static_cast<const T*>(a.x);
+    const T* xref = static_cast<const T*>(a.xref);
+    const T* yref = static_cast<const T*>(a.yref);
+    const T* dy = static_cast<const T*>(a.dy);
+    T* y = static_cast<T*>(a.y);
+    const unsigned row = blockIdx.y;
+    const A bv = load_as<T>(static_cast<const T*>(a.b), row % a.size_b);
+    const int64_t row0 = int64_t(row) * a.step_b;
+    const unsigned nvec_row = a.step_b / VEC;
+#pragma unroll
+    for (int it = 0; it < kRowVecsPerLane; it++) {
+        const unsigned v = (blockIdx.x * kRowVecsPerLane + it) * kThreads + threadIdx.x;
+        if (v >= nvec_row) break;
+        const int64_t i0 = row0 + int64_t(v) * VEC;
+        P px = *reinterpret_cast<const P*>(x + i0), pxr, pyr, pdy, po;
+        if (xref) pxr = *reinterpret_cast<const P*>(xref + i0);
+        if (yref) pyr = *reinterpret_cast<const P*>(yref + i0);
+        if (dy)   pdy = *reinterpret_cast<const P*>(dy + i0);
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+            const A r = eval<A, ACT>(load_as<T>(px.v, k), bv,
+                                     xref ? load_as<T>(pxr.v, k) : A(0), yref ? load_as<T>(pyr.v, k) : A(0),
+                                     dy ? load_as<T>(pdy.v, k) : A(1), a.grad, alpha, gain, clamp);
+            store_as<T>(po.v, k, r);
+        }
+        *reinterpret_cast<P*>(y + i0) = po;
+    }
+}
+
 template <class T, int VEC>
 int launch_act(const Args& a, int act, hipStream_t stream) {
     const int64_t nvec = (a.numel + VEC - 1) / VEC;
@@ -143,6 +183,18 @@ int launch_act(const Args& a, int act, hipStream_t stream) {
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     dim3 g((unsigned)blocks), t(kThreads);
+    if (VEC > 1 && a.b && a.step_b >= 2048 && a.step_b % VEC == 0 && a.numel % a.step_b == 0 && a.numel / a.step_b <= 65535) {
+        const unsigned nvec_row = a.step_b / VEC;
+        dim3 gr((nvec_row + kThreads * kRowVecsPerLane - 1) / (kThreads * kRowVecsPerLane), (unsigned)(a.numel / a.step_b));
+        switch (act) {
+#define GNERF_CASE(A_) case A_: hipLaunchKernelGGL((bias_act_rows_kernel<T, A_, VEC>), gr, t, 0, stream, a); break;
+            GNERF_CASE(1) GNERF_CASE(2) GNERF_CASE(3) GNERF_CASE(4) GNERF_CASE(5)
+            GNERF_CASE(6) GNERF_CASE(7) GNERF_CASE(8) GNERF_CASE(9)
+#undef GNERF_CASE
+            default: return fail(GNERF_E_ARG, "bias_act: unknown activation %d", act);
+        }
+        return check_launch("bias_act(rows)");
+    }
     switch (act) {
 #define GNERF_CASE(A_) case A_: hipLaunchKernelGGL((bias_act_kernel<T, A_, VEC>), g, t, 0, stream, a); break;
         GNERF_CASE(1) GNERF_CASE(2) GNERF_CASE(3) GNERF_CASE(4) GNERF_CASE(5)

@@ -21,6 +21,8 @@ namespace {
 
 using namespace gnerf;
 
+template <class T> struct alignas(16) Pack16 { T v[16 / sizeof(T)]; };
+
 struct UpArgs {
     const void* x; const float* f; void* y;
     int n, c, in_h, in_w;
@@ -143,11 +145,143 @@ __global__ __launch_bounds__(256) void upfirdn_tile_kernel(UpArgs a, int tiles_x
         if (lx + q < tw) store_as<T>(yp, q, acc[q]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Specialised kernel for what StyleGAN2 / G-NeRF actually issue: 4x4 filter, NCHW, same factor on both axes,
+// (up,down) in {(1,1) blur, (2,1) upsample, (1,2) downsample} (and their gradients, which are the same shapes).
+//   * a workgroup owns a 16-row x (16*OPL)-column output tile of one image; OPL = 16 bytes of outputs per lane
+//   * the input window is staged into LDS as fp32 with ALIGNED 16-byte global loads (the window's rows start at
+//     arbitrary element offsets -- 513-wide images -- so lanes walk the flat tensor in aligned vectors and mask);
+//     out-of-image positions are staged as zeros, so the FIR loop has no bounds checks
+//   * the polyphase structure is resolved at compile time: PX/PY = pad0 mod up fix which taps hit non-zero samples
+//     for each of the lane's OPL outputs, so the inner loops are fully unrolled FMAs on registers
+//   * one 16-byte store per lane.
+template <class T> struct Vec16 { static constexpr int N = 16 / sizeof(T); };
+
+template <class T, int UP, int DOWN, int PX, int PY>   // PY is implied by Y0 at run time; kept so launches are explicit about the phase
+__global__ __launch_bounds__(256) void upfirdn_fir4_kernel(UpArgs a, int tiles_x, int tiles_y) {
+    constexpr int OPL = Vec16<T>::N, TW = 16 * OPL, TH = 16, NT = 4 / UP;
+    constexpr int WW = ((TW - 1) * DOWN + 3) / UP + 2, WH = ((TH - 1) * DOWN + 3) / UP + 2, PITCH = WW | 1;
+    constexpr int SPAN = ((OPL - 1) * DOWN + (UP - 1)) / UP + NT;         // window columns one lane touches per row
+    __shared__ float s_x[WH * PITCH];
+    __shared__ float s_f[16];
+    const T* x = static_cast<const T*>(a.x);
+    T* y = static_cast<T*>(a.y);
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    const int64_t img = t;
+    const int ox0 = tx * TW, oy0 = ty * TH;
+    const int wx0 = floor_div_pos(ox0 * DOWN - a.padx0, UP), wy0 = floor_div_pos(oy0 * DOWN - a.pady0, UP);
+    if (threadIdx.x < 16) {
+        const int ky = threadIdx.x >> 2, kx = threadIdx.x & 3;
+        const int fy = a.flip ? ky : 3 - ky, fx = a.flip ? kx : 3 - kx;
+        s_f[threadIdx.x] = a.f[fy * a.fs_h + fx * a.fs_w] * a.gain;
+    }
+    // ---- stage the window
+    const int64_t img_base = img * int64_t(a.in_h) * a.in_w, numel = int64_t(a.n) * a.c * a.in_h * a.in_w;
+    constexpr int NV = (WW + OPL - 1) / OPL + 1;                          // aligned vectors that can overlap one window row
+    for (int i = threadIdx.x; i < WH * NV; i += 256) {
+        const int r = i / NV, v = i % NV;
+        const int iy = wy0 + r;
+        const int64_t row0 = img_base + int64_t(iy) * a.in_w + wx0;       // flat index of window column 0 (may be "virtual")
+        const int64_t vec0 = ((row0 >= 0 ? row0 : row0 - (OPL - 1)) / OPL + v) * OPL;      // aligned vector start (floor)
+        const bool row_ok = iy >= 0 && iy < a.in_h;
+        T vals[OPL];
+        const bool load_ok = row_ok && vec0 >= 0 && vec0 + OPL <= numel;
+        if (load_ok) {
+            *reinterpret_cast<Pack16<T>*>(vals) = *reinterpret_cast<const Pack16<T>*>(x + vec0);
+        }
+#pragma unroll
+        for (int e = 0; e < OPL; e++) {
+            const int pos = int(vec0 + e - row0);                         // window column of this element
+            if (pos >= 0 && pos < WW) {
+                const int ix = wx0 + pos;
+                float val = 0.f;
+                if (row_ok && ix >= 0 && ix < a.in_w) val = load_ok ? float(load_as<T>(vals, e)) : float(load_as<T>(x, vec0 + e));
+                s_x[r * PITCH + pos] = val;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- FIR on registers
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int oy = oy0 + ly, oxb = ox0 + OPL * lx;
+    // rows: Y0 = oy*DOWN - pady0 is the upsampled row of tap 0; the first tap on a real sample is k0y = (-Y0) mod UP
+    const int Y0 = oy * DOWN - a.pady0;
+    const int k0y = (UP == 1) ? 0 : ((Y0 & 1) ? 1 : 0);
+    const int row_base = ((Y0 + k0y) >> (UP == 2 ? 1 : 0)) - wy0;         // exact division
+    float acc[OPL];
+#pragma unroll
+    for (int q = 0; q < OPL; q++) acc[q] = 0.f;
+    const int X0 = oxb * DOWN - a.padx0;                                  // q = 0; oxb is a multiple of OPL (even)
+    constexpr int k0x0 = (UP == 1) ? 0 : (PX & 1);                        // k0x for q = 0: (-X0) mod 2 = padx0 mod 2
+    const int col_base = ((X0 + k0x0) >> (UP == 2 ? 1 : 0)) - wx0;
+#pragma unroll
+    for (int tyy = 0; tyy < NT; tyy++) {
+        const float* xrow = s_x + (row_base + tyy) * PITCH + col_base;
+        float xr[SPAN];
+#pragma unroll
+        for (int i = 0; i < SPAN; i++) xr[i] = xrow[i];
+        const int ky = k0y + tyy * UP;
+        float fr[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) fr[i] = s_f[ky * 4 + i];
+#pragma unroll
+        for (int q = 0; q < OPL; q++) {
+            const int k0x = (UP == 1) ? 0 : ((k0x0 + q * DOWN) & 1);      // compile-time after unrolling
+            const int rel = (q * DOWN + k0x - k0x0) / UP;                 // window column of tap 0 relative to col_base
+#pragma unroll
+            for (int txx = 0; txx < NT; txx++) acc[q] = fmaf(xr[rel + txx], fr[k0x + txx * UP], acc[q]);
+        }
+    }
+    if (oy < a.out_h) {
+        T* yp = y + img * int64_t(a.out_h) * a.out_w + int64_t(oy) * a.out_w + oxb;
+        if (oxb + OPL <= a.out_w && ((reinterpret_cast<uintptr_t>(yp) & 15) == 0)) {
+            T outv[OPL];
+#pragma unroll
+            for (int q = 0; q < OPL; q++) store_as<T>(outv, q, acc[q]);
+            *reinterpret_cast<Pack16<T>*>(yp) = *reinterpret_cast<Pack16<T>*>(outv);
+        } else {
+#pragma unroll
+            for (int q = 0; q < OPL; q++)
+                if (oxb + q < a.out_w) store_as<T>(yp, q, acc[q]);
+        }
+    }
+}
+
+template <class T, int UP, int DOWN>
+int launch_fir4(const UpArgs& a, hipStream_t stream) {
+    constexpr int TW = 16 * Vec16<T>::N, TH = 16;
+    const int tiles_x = (a.out_w + TW - 1) / TW, tiles_y = (a.out_h + TH - 1) / TH;
+    const int64_t blocks = int64_t(tiles_x) * tiles_y * a.n * a.c;
+    if (blocks > INT32_MAX) return 1;
+    const dim3 g((unsigned)blocks), b(256);
+    const int px = ((a.padx0 % UP) + UP) % UP, py = ((a.pady0 % UP) + UP) % UP;
+    if (UP == 1) hipLaunchKernelGGL((upfirdn_fir4_kernel<T, UP, DOWN, 0, 0>), g, b, 0, stream, a, tiles_x, tiles_y);
+    else if (px == 0 && py == 0) hipLaunchKernelGGL((upfirdn_fir4_kernel<T, UP, DOWN, 0, 0>), g, b, 0, stream, a, tiles_x, tiles_y);
+    else if (px == 1 && py == 0) hipLaunchKernelGGL((upfirdn_fir4_kernel<T, UP, DOWN, 1, 0>), g, b, 0, stream, a, tiles_x, tiles_y);
+    else if (px == 0 && py == 1) hipLaunchKernelGGL((upfirdn_fir4_kernel<T, UP, DOWN, 0, 1>), g, b, 0, stream, a, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((upfirdn_fir4_kernel<T, UP, DOWN, 1, 1>), g, b, 0, stream, a, tiles_x, tiles_y);
+    return check_launch("upfirdn2d(fir4)") == GNERF_OK ? 0 : -1;
+}
+
 template <class T>
 int launch_up(const UpArgs& a, hipStream_t stream) {
     const bool nchw = a.xs_w == 1 && a.xs_h == a.in_w && a.xs_c == int64_t(a.in_h) * a.in_w && a.xs_n == a.xs_c * a.c &&
                       a.ys_w == 1 && a.ys_h == a.out_w && a.ys_c == int64_t(a.out_h) * a.out_w && a.ys_n == a.ys_c * a.c;
     const bool small = a.fh <= MAX_TAPS && a.fw <= MAX_TAPS && a.downx <= 2 && a.downy <= 2;
+    if constexpr (sizeof(typename Arith<T>::type) == 4) {
+        const bool fir4 = nchw && a.fh == 4 && a.fw == 4 && a.upx == a.upy && a.downx == a.downy &&
+                          (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
+        if (fir4) {
+            int rc = 1;
+            if (a.upx == 1 && a.downx == 1) rc = launch_fir4<T, 1, 1>(a, stream);
+            else if (a.upx == 2 && a.downx == 1) rc = launch_fir4<T, 2, 1>(a, stream);
+            else if (a.upx == 1 && a.downx == 2) rc = launch_fir4<T, 1, 2>(a, stream);
+            if (rc == 0) return GNERF_OK;
+            if (rc < 0) return GNERF_E_LAUNCH;
+        }
+    }
     if (nchw && small && sizeof(typename Arith<T>::type) == 4) {      // LDS window is float: keep double on the direct kernel
         const int tiles_x = (a.out_w + TILE_W - 1) / TILE_W, tiles_y = (a.out_h + TILE_H - 1) / TILE_H;
         const int64_t blocks = int64_t(tiles_x) * tiles_y * a.n * a.c;
