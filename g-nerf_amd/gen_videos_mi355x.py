@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Counterpart of G-NeRF's gen_videos.py for MI355X (BASELINE configs 1, 3, 4).
+
+What it keeps from the reference (g_nerf/gen_videos.py:83-224): network pickle loading through the reference's own
+`legacy`/`dnnlib`, the orbit cameras and intrinsics, `ws = G.mapping(z, c=0)` once, the x2 rule on the checkpoint's
+depth resolutions, `G.synthesis(ws, c, noise_mode='const', neural_rendering_resolution=res)` per frame, the uint8
+conversion.  What it changes: no cv2/imageio/mrcfile (frames are returned / saved as a uint8 array), `torch.no_grad()`,
+the StyleGAN2 backbone runs ONCE per orbit (`cache_backbone` / `use_cached_backbone`, triplane.py:66-71; `ws` is constant),
+the device is whatever `--device` says, and frames are sharded over ranks -- one process per GPU under
+`torch.distributed.run`, a contiguous block of frames each, one gather of uint8 frames at the end.
+
+Run with this repo's g-nerf_amd/ in front of the reference's g_nerf/ on PYTHONPATH:
+
+    PYTHONPATH=.../g-nerf_amd:.../G-NeRF/g_nerf python g-nerf_amd/gen_videos_mi355x.py --network G.pkl --encoder E.pkl --id-image face.png
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 g-nerf_amd/gen_videos_mi355x.py --random-init --frames 240 ...
+
+`--random-init` builds the FFHQ-config TriPlaneGenerator with seeded random weights and a random z instead of loading
+pickles (there are no checkpoints or network access in the build environment).
+"""
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+import gnerf_harness as H
+
+
+def ffhq_generator_kwargs(depth_resolution=48, depth_resolution_importance=48):
+    """G_kwargs of the FFHQ configuration, as train.py:238-377 assembles them from its option defaults."""
+    rendering = {
+        'image_resolution': 512, 'disparity_space_sampling': False, 'clamp_mode': 'softplus',
+        'superresolution_module': 'training.superresolution.SuperresolutionHybrid8XDC',
+        'c_gen_conditioning_zero': False, 'gpc_reg_prob': 0.5, 'c_scale': 1, 'superresolution_noise_mode': 'none',
+        'density_reg': 0.25, 'density_reg_p_dist': 0.004, 'reg_type': 'l1', 'decoder_lr_mul': 1, 'sr_antialias': True,
+        'depth_resolution': depth_resolution, 'depth_resolution_importance': depth_resolution_importance,
+        'ray_start': 2.25, 'ray_end': 3.3, 'box_warp': 1, 'avg_camera_radius': 2.7, 'avg_camera_pivot': [0, 0, 0.2],
+    }
+    return dict(z_dim=512, w_dim=512, c_dim=25, img_resolution=512, img_channels=3,
+                mapping_kwargs=dict(num_layers=2), channel_base=32768, channel_max=512, fused_modconv_default='inference_only',
+                rendering_kwargs=rendering, num_fp16_res=0, conv_clamp=None, sr_num_fp16_res=4,
+                sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default='inference_only', w_dim=512))
+
+
+def build_random_generator(seed, device, **kw):
+    from training.triplane import TriPlaneGenerator          # the reference's class (its renderer/ops resolve to this repo)
+    torch.manual_seed(seed)
+    G = TriPlaneGenerator(**ffhq_generator_kwargs(**kw)).eval().requires_grad_(False)
+    return G.to(device)
+
+
+def load_generator(network_pkl, device):
+    import dnnlib
+    import legacy
+    with dnnlib.util.open_url(network_pkl) as f:
+        return legacy.load_network_pkl(f)['G_ema'].to(device).eval().requires_grad_(False)
+
+
+def identity_latent(args, device, z_dim):
+    if args.encoder and args.id_image:
+        import dnnlib
+        import legacy
+        from PIL import Image
+        with dnnlib.util.open_url(args.encoder) as f:
+            E = legacy.load_network_pkl(f)['E'].to(device).eval()
+        img = np.asarray(Image.open(args.id_image).convert('RGB')).transpose(2, 0, 1)[None]
+        return E(torch.from_numpy(img.copy()).to(device) / 127.5 - 1)                       # gen_videos.py:119,131
+    return torch.randn(1, z_dim, generator=torch.Generator().manual_seed(args.seed + 1)).to(device)
+
+
+@torch.no_grad()
+def render_orbit(G, z, n_frames, res, device, rank=0, world=1, double_depth=True, frame_seed=None):
+    """This rank's frames of the orbit: (uint8 [n_local,512,512,3], uint8 raw [n_local,res,res,3], (lo, hi))."""
+    if double_depth:                                                                        # gen_videos.py:127-128
+        G.rendering_kwargs['depth_resolution'] = int(G.rendering_kwargs['depth_resolution'] * 2)
+        G.rendering_kwargs['depth_resolution_importance'] = int(G.rendering_kwargs['depth_resolution_importance'] * 2)
+    radius = G.rendering_kwargs['avg_camera_radius']
+    c0 = H.camera_label(H.lookat_pose(3.14 / 2, 3.14 / 2, radius, device))                # gen_videos.py:147-149
+    ws = G.mapping(z=z, c=torch.zeros_like(c0).repeat(z.shape[0], 1))                       # gen_videos.py:150
+    lo, hi = H.shard_range(n_frames, rank, world)
+    frames, raws = [], []
+    for k, i in enumerate(range(lo, hi)):
+        c = H.camera_label(H.orbit_pose(i, n_frames, radius, device=device)).repeat(z.shape[0], 1)
+        if frame_seed is not None:
+            torch.manual_seed(frame_seed + i)                                               # reproducible renderer draws per frame
+        out = G.synthesis(ws=ws, c=c, noise_mode='const', neural_rendering_resolution=res,
+                          cache_backbone=(k == 0), use_cached_backbone=(k > 0))
+        frames.append(H.to_uint8(out['image']))
+        raws.append(H.to_uint8(out['image_raw']))
+    if not frames:
+        return None, None, (lo, hi)
+    return torch.cat(frames), torch.cat(raws), (lo, hi)
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('--network', help='generator pickle (G_ema)')
+    ap.add_argument('--encoder', help='identity encoder pickle (E)')
+    ap.add_argument('--id-image', help='identity reference image')
+    ap.add_argument('--random-init', action='store_true', help='seeded random generator + random z instead of pickles')
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--frames', type=int, default=120)                  # gen_videos.py:151
+    ap.add_argument('--res', type=int, default=64)                      # neural rendering resolution, gen_videos.py:81
+    ap.add_argument('--no-double-depth', action='store_true', help='keep the checkpoint depth resolutions (the reference CLI doubles them)')
+    ap.add_argument('--device', default='cuda' if torch.cuda.is_available() else 'cpu')
+    ap.add_argument('--out', default=None, help='write frames to this .npy (rank 0)')
+    args = ap.parse_args()
+
+    rank, world, local_rank = H.init_from_env()
+    device = torch.device('cuda', local_rank) if args.device == 'cuda' else torch.device(args.device)
+    if args.random_init:
+        G = build_random_generator(args.seed, device)
+    else:
+        assert args.network, 'give --network or --random-init'
+        G = load_generator(args.network, device)
+    z = identity_latent(args, device, G.z_dim)
+
+    if device.type == 'cuda':
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames, raws, (lo, hi) = render_orbit(G, z, args.frames, args.res, device, rank, world, double_depth=not args.no_double_depth)
+    full = H.gather_frames(frames, args.frames)
+    if device.type == 'cuda':
+        torch.cuda.synchronize()
+    elapsed = H.max_over_ranks(time.perf_counter() - t0, device)
+    if rank == 0:
+        print(f'{args.frames} frames on {world} rank(s): {elapsed:.3f} s = {args.frames / elapsed:.2f} frames/s '
+              f'(neural rendering {args.res}x{args.res}, {G.rendering_kwargs["depth_resolution"]}+{G.rendering_kwargs["depth_resolution_importance"]} samples)')
+        if args.out:
+            np.save(args.out, full.cpu().numpy())
+
+
+if __name__ == '__main__':
+    main()
