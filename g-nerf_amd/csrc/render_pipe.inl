@@ -25,6 +25,10 @@
 #define GNERF_DBG_PTR(x) (x)
 #endif
 
+#ifndef GNERF_PIPE_UNIT
+#define GNERF_PIPE_UNIT 8
+#endif
+constexpr int kPipeUnit = GNERF_PIPE_UNIT;      // rays dealt to a workgroup at a time (see render_kernel_pipe)
 constexpr int kPipeThreads = 256;
 constexpr int kPipeSlots = 4;
 constexpr int kPipeMaxS = 48;
@@ -84,12 +88,22 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
     L.taps = slots + kPipeSlots * kSlotFloats;
     L.stage = L.taps + 3 * 16 * kTapDwords;
 
-    // this workgroup's run of the ray sequence (XCD-contiguous: workgroups b, b+8, ... share an XCD)
+    // This workgroup's share of the locality-ordered ray sequence.  Workgroups b, b+8, ... share an XCD (round-robin
+    // dispatch), and each XCD owns a contiguous eighth of the sequence.  Inside an XCD the sequence is dealt to its W
+    // workgroups in UNITS of kPipeUnit consecutive rays, round-robin: at any moment the W workgroups are within a few
+    // units of each other, i.e. on neighbouring rays, so the XCD's 4 MB L2 holds the texels they share.  (Giving each
+    // workgroup one long contiguous run instead spreads the XCD over 96 distant image regions: measured 1.3 GB of L2
+    // misses per launch; dealing units of 8 rays is 10 % faster, 4-16 are within 3 % of each other.)  Speed only -- any assignment is correct.
     const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : int64_t(P.total_rays);
-    const int G = gridDim.x;
-    const int chunk = (blockIdx.x % kNumXCD) * (G / kNumXCD) + blockIdx.x / kNumXCD;
-    const int64_t seq0 = total_seq * chunk / G, seq1 = total_seq * (chunk + 1) / G;
-    const int nr = int(seq1 - seq0);
+    const int W = gridDim.x / kNumXCD, xcd = blockIdx.x % kNumXCD, wg = blockIdx.x / kNumXCD;
+    const int64_t x0 = total_seq * xcd / kNumXCD, x1 = total_seq * (xcd + 1) / kNumXCD;
+    const int n_units = int((x1 - x0 + kPipeUnit - 1) / kPipeUnit);
+    const int my_units = n_units > wg ? (n_units - wg + W - 1) / W : 0;
+    const int nr = my_units * kPipeUnit;
+    auto local_to_ray = [&](int r) -> int {
+        const int64_t seq = x0 + (int64_t(wg) + int64_t(r / kPipeUnit) * W) * kPipeUnit + r % kPipeUnit;
+        return seq < x1 ? pipe_seq_to_ray(P, seq) : -1;
+    };
 
     stage_decoder(L, smem, p, tid, kPipeThreads);
 
@@ -100,7 +114,7 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
     int pre_ray_id = -1;
 
     auto propose_issue = [&](int r) {           // P(r), first half: start the global loads
-        pre_ray_id = (r >= 0 && r < nr) ? pipe_seq_to_ray(P, seq0 + r) : -1;
+        pre_ray_id = (r >= 0 && r < nr) ? local_to_ray(r) : -1;
         if (pre_ray_id < 0) return;
         const int64_t ray = pre_ray_id;
         if (lane < S) pre_uc = p.noise_coarse[ray * S + lane];
