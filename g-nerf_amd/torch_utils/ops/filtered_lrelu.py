@@ -9,6 +9,7 @@ reference itself takes whenever its fused kernel has no specialisation (filtered
 Only the packed sign tensor is kept for the backward pass, which is the same op with up and down
 swapped reading the signs back."""
 
+import collections
 import os
 import warnings
 
@@ -17,6 +18,7 @@ import torch
 
 from .. import custom_ops
 from . import upfirdn2d
+from . import _fir_args
 from . import bias_act
 
 _plugin = None
@@ -35,24 +37,11 @@ def _init():
 
 
 def _get_filter_size(f):
-    if f is None:
-        return 1, 1
-    assert isinstance(f, torch.Tensor)
-    assert 1 <= f.ndim <= 2
-    return f.shape[-1], f.shape[0]      # width, height
+    return _fir_args.filter_size(f, strict=False)      # width, height
 
 
 def _parse_padding(padding):
-    if isinstance(padding, int):
-        padding = [padding, padding]
-    assert isinstance(padding, (list, tuple))
-    assert all(isinstance(x, (int, np.integer)) for x in padding)
-    padding = [int(x) for x in padding]
-    if len(padding) == 2:
-        px, py = padding
-        padding = [px, px, py, py]
-    px0, px1, py0, py1 = padding
-    return px0, px1, py0, py1
+    return _fir_args.parse_padding(padding, kinds=_fir_args.NUMPY_INTS)
 
 
 def _check_scalars(up, down, gain, slope, clamp):
@@ -99,76 +88,78 @@ def _filtered_lrelu_ref(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, ga
     return x
 
 
+# ---------------------------------------------------------------------------------------------
+# GPU path.  As in upfirdn2d.py, one Function takes its static configuration as an argument and its backward is the
+# same Function under the transposed configuration; what links forward and backward is the packed sign tensor.
+
+_Config = collections.namedtuple('_Config', 'up down px0 px1 py0 py1 gain slope clamp flip')
+
+
+class _FilteredLRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, fu, fd, b, si, sx, sy, c):
+        assert isinstance(x, torch.Tensor) and x.ndim == 4
+        dev = x.device
+        fu = torch.ones([1, 1], dtype=torch.float32, device=dev) if fu is None else fu
+        fd = torch.ones([1, 1], dtype=torch.float32, device=dev) if fd is None else fd
+        assert 1 <= fu.ndim <= 2 and 1 <= fd.ndim <= 2
+        if c.up == 1 and fu.ndim == 1 and fu.shape[0] == 1:
+            fu = fu.square()[None]
+        if c.down == 1 and fd.ndim == 1 and fd.shape[0] == 1:
+            fd = fd.square()[None]
+        si = torch.empty([0]) if si is None else si
+        b = torch.zeros([x.shape[1]], dtype=x.dtype, device=dev) if b is None else b
+        write_signs = si.numel() == 0 and (x.requires_grad or b.requires_grad)
+        strides = [x.stride(i) for i in range(x.ndim) if x.size(i) > 1]
+        if any(lo < hi for lo, hi in zip(strides[:-1], strides[1:])):
+            warnings.warn("low-performance memory layout detected in filtered_lrelu input", RuntimeWarning)
+        pad = [c.px0, c.px1, c.py0, c.py1]
+        # A fused single-kernel variant would be tried first (return code < 0 = not available); this build always takes
+        # the three-launch route, which is also the reference's route for configurations its fused kernel lacks.
+        y, so, rc = _plugin.filtered_lrelu(x, fu, fd, b, si, c.up, c.down, *pad, sx, sy, c.gain, c.slope, c.clamp, c.flip, write_signs)
+        if rc < 0:
+            y = x.add(b.unsqueeze(-1).unsqueeze(-1))
+            y = upfirdn2d.upfirdn2d(x=y, f=fu, up=c.up, padding=pad, gain=c.up ** 2, flip_filter=c.flip)
+            so = _plugin.filtered_lrelu_act_(y, si, sx, sy, c.gain, c.slope, c.clamp, write_signs)      # in place on y
+            y = upfirdn2d.upfirdn2d(x=y, f=fd, down=c.down, flip_filter=c.flip)
+        ctx.save_for_backward(fu, fd, si if si.numel() else so)
+        ctx.cfg, ctx.in_hw, ctx.out_hw, ctx.sign_offset = c, tuple(x.shape[2:]), tuple(y.shape[2:]), (sx, sy)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        fu, fd, si = ctx.saved_tensors
+        c, (xh, xw), (yh, yw), (sx, sy) = ctx.cfg, ctx.in_hw, ctx.out_hw, ctx.sign_offset
+        assert not any(ctx.needs_input_grad[i] for i in (1, 2, 4, 5, 6))
+        dx = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
+            fu_w, fu_h, fd_w, fd_h = fu.shape[-1], fu.shape[0], fd.shape[-1], fd.shape[0]
+            t = _Config(up=c.down, down=c.up,
+                        px0=(fu_w - 1) + (fd_w - 1) - c.px0, px1=xw * c.up - yw * c.down + c.px0 - (c.up - 1),
+                        py0=(fu_h - 1) + (fd_h - 1) - c.py0, py1=xh * c.up - yh * c.down + c.py0 - (c.up - 1),
+                        gain=c.gain * (c.up ** 2) / (c.down ** 2), slope=c.slope, clamp=float('inf'), flip=not c.flip)
+            dx = _FilteredLRelu.apply(dy, fd, fu, None, si, sx - (fu_w - 1) + c.px0, sy - (fu_h - 1) + c.py0, t)
+        if ctx.needs_input_grad[3]:
+            db = dx.sum([0, 2, 3])
+        return dx, None, None, db, None, None, None, None
+
+
+class _Bound:
+    """What `_filtered_lrelu_cuda(...)` returns: the Function bound to one configuration (`.apply(x, fu, fd, b, si, sx, sy)`)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    def apply(self, x, fu, fd, b, si, sx, sy):
+        return _FilteredLRelu.apply(x, fu, fd, b, si, sx, sy, self.cfg)
+
+
 _filtered_lrelu_cuda_cache = dict()
 
 
 def _filtered_lrelu_cuda(up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, clamp=None, flip_filter=False):
-    """autograd.Function (cached per static-argument tuple)."""
     _check_scalars(up, down, gain, slope, clamp)
-    px0, px1, py0, py1 = _parse_padding(padding)
-    gain, slope = float(gain), float(slope)
-    clamp = float(clamp if clamp is not None else 'inf')
-    key = (up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter)
-    if key in _filtered_lrelu_cuda_cache:
-        return _filtered_lrelu_cuda_cache[key]
-
-    class FilteredLReluCuda(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, x, fu, fd, b, si, sx, sy):
-            assert isinstance(x, torch.Tensor) and x.ndim == 4
-            if fu is None:
-                fu = torch.ones([1, 1], dtype=torch.float32, device=x.device)
-            if fd is None:
-                fd = torch.ones([1, 1], dtype=torch.float32, device=x.device)
-            assert 1 <= fu.ndim <= 2 and 1 <= fd.ndim <= 2
-            if up == 1 and fu.ndim == 1 and fu.shape[0] == 1:
-                fu = fu.square()[None]
-            if down == 1 and fd.ndim == 1 and fd.shape[0] == 1:
-                fd = fd.square()[None]
-            if si is None:
-                si = torch.empty([0])
-            if b is None:
-                b = torch.zeros([x.shape[1]], dtype=x.dtype, device=x.device)
-            write_signs = (si.numel() == 0) and (x.requires_grad or b.requires_grad)
-            strides = [x.stride(i) for i in range(x.ndim) if x.size(i) > 1]
-            if any(a < c for a, c in zip(strides[:-1], strides[1:])):
-                warnings.warn("low-performance memory layout detected in filtered_lrelu input", RuntimeWarning)
-            # A fused single-kernel variant would be tried here first (plugin.filtered_lrelu, return code < 0 =
-            # not available); this build always takes the three-launch route.
-            y, so, return_code = _plugin.filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy,
-                                                        gain, slope, clamp, flip_filter, write_signs)
-            if return_code < 0:
-                y = x.add(b.unsqueeze(-1).unsqueeze(-1))
-                y = upfirdn2d.upfirdn2d(x=y, f=fu, up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter)
-                so = _plugin.filtered_lrelu_act_(y, si, sx, sy, gain, slope, clamp, write_signs)    # in place on y
-                y = upfirdn2d.upfirdn2d(x=y, f=fd, down=down, flip_filter=flip_filter)
-            ctx.save_for_backward(fu, fd, (si if si.numel() else so))
-            ctx.x_shape = x.shape
-            ctx.y_shape = y.shape
-            ctx.s_ofs = sx, sy
-            return y
-
-        @staticmethod
-        def backward(ctx, dy):
-            fu, fd, si = ctx.saved_tensors
-            _, _, xh, xw = ctx.x_shape
-            _, _, yh, yw = ctx.y_shape
-            sx, sy = ctx.s_ofs
-            dx = db = None
-            for i in (1, 2, 4, 5, 6):
-                assert not ctx.needs_input_grad[i]
-            if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
-                # transposed op: swap the filters and factors; the sign tensor is read at an offset
-                pp = [(fu.shape[-1] - 1) + (fd.shape[-1] - 1) - px0, xw * up - yw * down + px0 - (up - 1),
-                      (fu.shape[0] - 1) + (fd.shape[0] - 1) - py0, xh * up - yh * down + py0 - (up - 1)]
-                gg = gain * (up ** 2) / (down ** 2)
-                sx = sx - (fu.shape[-1] - 1) + px0
-                sy = sy - (fu.shape[0] - 1) + py0
-                dx = _filtered_lrelu_cuda(up=down, down=up, padding=pp, gain=gg, slope=slope, clamp=None,
-                                          flip_filter=(not flip_filter)).apply(dy, fd, fu, None, si, sx, sy)
-            if ctx.needs_input_grad[3]:
-                db = dx.sum([0, 2, 3])
-            return dx, None, None, db, None, None, None
-
-    _filtered_lrelu_cuda_cache[key] = FilteredLReluCuda
-    return FilteredLReluCuda
+    cfg = _Config(up, down, *_parse_padding(padding), float(gain), float(slope), float('inf' if clamp is None else clamp), flip_filter)
+    if cfg not in _filtered_lrelu_cuda_cache:
+        _filtered_lrelu_cuda_cache[cfg] = _Bound(cfg)
+    return _filtered_lrelu_cuda_cache[cfg]

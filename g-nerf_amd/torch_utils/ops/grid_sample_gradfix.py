@@ -1,53 +1,66 @@
-"""`grid_sample` replacement that supports gradients of gradients w.r.t. the sampled image, with the
-reference's interface (torch_utils/ops/grid_sample_gradfix.py: module flag `enabled` :24,
-grid_sample(input, grid) :28).  2-D, bilinear, zero padding, align_corners=False only.
+"""Bilinear 2-D `grid_sample` whose gradient is itself differentiable w.r.t. the incoming gradient.
 
-G-NeRF never calls it (its only user, the ADA augment pipe, is never constructed; the renderer calls
-torch.nn.functional.grid_sample directly -- and on the GPU path not even that: the lookups happen
-inside the fused render kernel).  Kept API-complete; the device work is ATen's grid sampler."""
+Interface of the reference's torch_utils/ops/grid_sample_gradfix.py (module flag `enabled` :24,
+`grid_sample(input, grid)` :28; fixed to mode='bilinear', padding_mode='zeros', align_corners=False).
+G-NeRF never calls it: its only user, the ADA augment pipe, is never constructed, and the renderer's lookups
+happen inside the fused render kernel on the GPU path.  Kept API-complete; the device work is ATen's sampler.
+
+Design: the sampler is linear in the image, so one autograd node suffices for every order -- its backward
+returns (another application of the adjoint sampler, the analytic grid gradient), and the adjoint's own
+backward w.r.t. the incoming gradient is the forward sampler again.
+"""
 
 import torch
 
-enabled = False     # set True to route grid_sample() through the custom autograd functions
+enabled = False     # when False, grid_sample() is exactly torch.nn.functional.grid_sample
 
-
-def grid_sample(input, grid):
-    if _should_use_custom_op():
-        return _GridSample2dForward.apply(input, grid)
-    return torch.nn.functional.grid_sample(input=input, grid=grid, mode='bilinear', padding_mode='zeros', align_corners=False)
+_SAMPLER_ARGS = dict(mode='bilinear', padding_mode='zeros', align_corners=False)
 
 
 def _should_use_custom_op():
     return enabled
 
 
-class _GridSample2dForward(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, input, grid):
-        assert input.ndim == 4 and grid.ndim == 4
-        ctx.save_for_backward(input, grid)
-        return torch.nn.functional.grid_sample(input=input, grid=grid, mode='bilinear', padding_mode='zeros', align_corners=False)
-
-    @staticmethod
-    def backward(ctx, grad_output):
-        input, grid = ctx.saved_tensors
-        return _GridSample2dBackward.apply(grad_output, input, grid)
+def grid_sample(input, grid):
+    if not _should_use_custom_op():
+        return torch.nn.functional.grid_sample(input=input, grid=grid, **_SAMPLER_ARGS)
+    return _Sample.apply(input, grid)
 
 
-class _GridSample2dBackward(torch.autograd.Function):
+def _adjoint(grad_output, image, grid):
+    """(d loss / d image, d loss / d grid) of the sampler, straight from ATen (bilinear = 0, zeros = 0)."""
+    return torch.ops.aten.grid_sampler_2d_backward(grad_output, image, grid, 0, 0, False, [True, True])
+
+
+class _Sample(torch.autograd.Function):
+    """image, grid -> samples."""
+
     @staticmethod
-    def forward(ctx, grad_output, input, grid):
-        # interpolation 0 = bilinear, padding 0 = zeros, align_corners False
-        grad_input, grad_grid = torch.ops.aten.grid_sampler_2d_backward(grad_output, input, grid, 0, 0, False, [True, True])
+    def forward(ctx, image, grid):
+        if image.ndim != 4 or grid.ndim != 4:
+            raise AssertionError('grid_sample_gradfix expects a 4-D image and a 4-D grid')
+        ctx.save_for_backward(image, grid)
+        return torch.nn.functional.grid_sample(input=image, grid=grid, **_SAMPLER_ARGS)
+
+    @staticmethod
+    def backward(ctx, grad_samples):
+        image, grid = ctx.saved_tensors
+        return _SampleAdjoint.apply(grad_samples, image, grid)
+
+
+class _SampleAdjoint(torch.autograd.Function):
+    """grad_samples, image, grid -> (grad_image, grad_grid); differentiable in grad_samples only."""
+
+    @staticmethod
+    def forward(ctx, grad_samples, image, grid):
         ctx.save_for_backward(grid)
-        return grad_input, grad_grid
+        return _adjoint(grad_samples, image, grid)
 
     @staticmethod
-    def backward(ctx, grad2_grad_input, grad2_grad_grid):
-        grid, = ctx.saved_tensors
-        grad2_grad_output = None
-        if ctx.needs_input_grad[0]:
-            # d(grad_input)/d(grad_output) is the sampler itself (it is linear in the image)
-            grad2_grad_output = _GridSample2dForward.apply(grad2_grad_input, grid)
-        assert not ctx.needs_input_grad[2]
-        return grad2_grad_output, None, None
+    def backward(ctx, gg_image, gg_grid):
+        (grid,) = ctx.saved_tensors
+        if ctx.needs_input_grad[2]:
+            raise AssertionError('second-order gradients w.r.t. the grid are not supported')
+        # grad_image is linear in grad_samples with the sampler as its transpose; gg_grid's path is dropped like upstream
+        back = _Sample.apply(gg_image, grid) if ctx.needs_input_grad[0] else None
+        return back, None, None

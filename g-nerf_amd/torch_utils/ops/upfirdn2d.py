@@ -7,12 +7,14 @@ GPU tensors run the hand-written gfx950 kernels (csrc/upfirdn2d.hip); the gradie
 up and down swapped and the filter flipped, so it runs on the same kernels.  CPU tensors, or
 impl='ref', use PyTorch ops like the reference."""
 
+import collections
 import os
 
 import numpy as np
 import torch
 
 from .. import custom_ops
+from . import _fir_args
 
 _plugin = None
 
@@ -29,35 +31,10 @@ def _init():
     return True
 
 
-def _parse_scaling(scaling):
-    if isinstance(scaling, int):
-        scaling = [scaling, scaling]
-    assert isinstance(scaling, (list, tuple))
-    assert all(isinstance(x, int) for x in scaling)
-    sx, sy = scaling
-    assert sx >= 1 and sy >= 1
-    return sx, sy
-
-
-def _parse_padding(padding):
-    if isinstance(padding, int):
-        padding = [padding, padding]
-    assert isinstance(padding, (list, tuple))
-    assert all(isinstance(x, int) for x in padding)
-    if len(padding) == 2:
-        px, py = padding
-        padding = [px, px, py, py]
-    padx0, padx1, pady0, pady1 = padding
-    return padx0, padx1, pady0, pady1
-
-
-def _get_filter_size(f):
-    if f is None:
-        return 1, 1
-    assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
-    fw, fh = int(f.shape[-1]), int(f.shape[0])
-    assert fw >= 1 and fh >= 1
-    return fw, fh
+# private names kept because conv2d_resample.py imports them from here (conv2d_resample.py:18-19)
+_parse_scaling = _fir_args.parse_scaling
+_parse_padding = _fir_args.parse_padding
+_get_filter_size = _fir_args.filter_size
 
 
 def setup_filter(f, device=torch.device('cpu'), normalize=True, flip_filter=False, gain=1, separable=None):
@@ -131,53 +108,71 @@ def _upfirdn2d_ref(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
     return x
 
 
+# ---------------------------------------------------------------------------------------------
+# GPU path.  One autograd.Function takes the static configuration as an argument; its backward is the same
+# function under the TRANSPOSED configuration (up <-> down, filter flipped, padding chosen so that the result
+# has the input's shape), so gradients of any order run on the same kernels.
+
+_Config = collections.namedtuple('_Config', 'upx upy downx downy padx0 padx1 pady0 pady1 flip gain')
+
+
+def _run(x, f, c):
+    """Forward computation on the plugin: one 2-D pass, or a row pass then a column pass for a separable filter."""
+    if f.ndim == 2:
+        return _plugin.upfirdn2d(x, f, c.upx, c.upy, c.downx, c.downy, c.padx0, c.padx1, c.pady0, c.pady1, c.flip, c.gain)
+    y = _plugin.upfirdn2d(x, f.unsqueeze(0), c.upx, 1, c.downx, 1, c.padx0, c.padx1, 0, 0, c.flip, 1.0)
+    return _plugin.upfirdn2d(y, f.unsqueeze(1), 1, c.upy, 1, c.downy, 0, 0, c.pady0, c.pady1, c.flip, c.gain)
+
+
+def _transposed(c, f, in_hw, out_hw):
+    fw, fh = _get_filter_size(f)
+    (ih, iw), (oh, ow) = in_hw, out_hw
+    return _Config(c.downx, c.downy, c.upx, c.upy,
+                   fw - c.padx0 - 1, iw * c.upx - ow * c.downx + c.padx0 - c.upx + 1,
+                   fh - c.pady0 - 1, ih * c.upy - oh * c.downy + c.pady0 - c.upy + 1,
+                   not c.flip, c.gain)
+
+
+class _Resample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, f, cfg):
+        assert isinstance(x, torch.Tensor) and x.ndim == 4
+        if f is None:
+            f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+        if f.ndim == 1 and f.shape[0] == 1:
+            f = f.square().unsqueeze(0)             # a single separable tap is a 1x1 filter
+        assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
+        y = _run(x, f, cfg)
+        ctx.save_for_backward(f)
+        ctx.cfg_t = _transposed(cfg, f, x.shape[2:], y.shape[2:])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (f,) = ctx.saved_tensors
+        assert not ctx.needs_input_grad[1]
+        dx = _Resample.apply(dy, f, ctx.cfg_t) if ctx.needs_input_grad[0] else None
+        return dx, None, None
+
+
+class _Bound:
+    """What `_upfirdn2d_cuda(...)` returns: `_Resample` bound to one static configuration (`.apply(x, f)`)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    def apply(self, x, f):
+        return _Resample.apply(x, f, self.cfg)
+
+
 _upfirdn2d_cuda_cache = dict()
 
 
 def _upfirdn2d_cuda(up=1, down=1, padding=0, flip_filter=False, gain=1):
-    """autograd.Function (cached per static-argument tuple) around the plugin's upfirdn2d entry point."""
-    upx, upy = _parse_scaling(up)
-    downx, downy = _parse_scaling(down)
-    padx0, padx1, pady0, pady1 = _parse_padding(padding)
-    key = (upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain)
-    if key in _upfirdn2d_cuda_cache:
-        return _upfirdn2d_cuda_cache[key]
-
-    class Upfirdn2dCuda(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, x, f):
-            assert isinstance(x, torch.Tensor) and x.ndim == 4
-            if f is None:
-                f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
-            if f.ndim == 1 and f.shape[0] == 1:
-                f = f.square().unsqueeze(0)         # one separable tap == a 1x1 filter
-            assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
-            if f.ndim == 2:
-                y = _plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain)
-            else:                                   # separable: a row pass then a column pass
-                y = _plugin.upfirdn2d(x, f.unsqueeze(0), upx, 1, downx, 1, padx0, padx1, 0, 0, flip_filter, 1.0)
-                y = _plugin.upfirdn2d(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, pady0, pady1, flip_filter, gain)
-            ctx.save_for_backward(f)
-            ctx.x_shape = x.shape
-            return y
-
-        @staticmethod
-        def backward(ctx, dy):
-            f, = ctx.saved_tensors
-            _, _, ih, iw = ctx.x_shape
-            _, _, oh, ow = dy.shape
-            fw, fh = _get_filter_size(f)
-            # transpose of the forward op: swap up/down, flip the filter, and pad so that the result has x's shape
-            p = [fw - padx0 - 1, iw * upx - ow * downx + padx0 - upx + 1,
-                 fh - pady0 - 1, ih * upy - oh * downy + pady0 - upy + 1]
-            dx = None
-            if ctx.needs_input_grad[0]:
-                dx = _upfirdn2d_cuda(up=down, down=up, padding=p, flip_filter=(not flip_filter), gain=gain).apply(dy, f)
-            assert not ctx.needs_input_grad[1]
-            return dx, None
-
-    _upfirdn2d_cuda_cache[key] = Upfirdn2dCuda
-    return Upfirdn2dCuda
+    cfg = _Config(*_parse_scaling(up), *_parse_scaling(down), *_parse_padding(padding), flip_filter, gain)
+    if cfg not in _upfirdn2d_cuda_cache:
+        _upfirdn2d_cuda_cache[cfg] = _Bound(cfg)
+    return _upfirdn2d_cuda_cache[cfg]
 
 
 def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl='cuda'):
