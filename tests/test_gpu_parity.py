@@ -130,6 +130,9 @@ def _random_scene(seed, N, res, S, F, hw, scale=1.5):
     dict(N=3, res=4, S=64, F=3, hw=(16, 16)),
     dict(N=1, res=4, S=4, F=5, hw=(4, 4)),                  # smallest importance-sampled case (S-3 = 1 pdf bin)
     dict(N=1, res=4, S=2, F=0, hw=(4, 4)),                  # smallest case at all
+    dict(N=1, res=4, S=130, F=100, hw=(8, 8)),              # beyond 96+96: one-wave-per-ray kernel, ragged tiles
+    dict(N=1, res=2, S=256, F=256, hw=(8, 8)),              # GNERF_MAX_SAMPLES on both passes
+    dict(N=2, res=8, S=64, F=64, hw=(16, 12)),              # ShapeNet config's sample counts (train.py:353-354)
 ])
 def test_render_vs_oracle(dev, cfg):
     import gnerf_hip
