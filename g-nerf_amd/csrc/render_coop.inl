@@ -223,51 +223,55 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     const int b = lane >> 3, cq16 = (lane & 7) * 16;
     // all 24 texel loads of the tile (2 steps x 3 planes x 4 taps) are issued before the first blend, so one
     // memory round trip covers both steps
-    // Measured (tools/ablate.py, config 2): keeping both 8-sample steps in flight (24 loads = 96 VGPRs) halves the
-    // lookup time of a tile but costs a wave per SIMD; one step at a time (12 loads = 48 VGPRs) at 3 waves per SIMD
-    // is 14 % faster overall, so that is the default.
-#ifdef GNERF_GATHER_WHOLE_TILE
-    constexpr int kBatch = 2;
-#else
-    constexpr int kBatch = 1;
-#endif
+    // The tile's 24 texel loads (2 steps x 3 planes x 4 taps) run as a ROLLING window of three 4-load units (48 VGPRs in
+    // flight): as soon as a plane of step 0 has been blended, the same plane of step 1 is issued, so the second step's
+    // round trip overlaps the first instead of following it.  Measured alternatives (tools/ablate.py, config 2): all 24
+    // in flight (96 VGPRs) halves the lookup time but costs a wave per SIMD and is slower overall; one step after the
+    // other (the previous default) exposes two full round trips.
+    uint4 off[2][3];
+    v4f wgt[2][3], tex[2][3][4];
+    auto read_records = [&](int a) {
+        const float* rec = taps + (8 * a + b) * kTapDwords;
 #pragma unroll
-    for (int a0 = 0; a0 < 2; a0 += kBatch) {
-        uint4 off[kBatch][3];
-        v4f wgt[kBatch][3], tex[kBatch][3][4];
-#pragma unroll
-        for (int a = 0; a < kBatch; a++) {
-            const float* rec = taps + (8 * (a0 + a) + b) * kTapDwords;
-#pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
-                off[a][pl] = *reinterpret_cast<const uint4*>(rec + pl * 8);
-                wgt[a][pl] = *reinterpret_cast<const v4f*>(rec + pl * 8 + 4);
-            }
+        for (int pl = 0; pl < 3; pl++) {
+            off[a][pl] = *reinterpret_cast<const uint4*>(rec + pl * 8);
+            wgt[a][pl] = *reinterpret_cast<const v4f*>(rec + pl * 8 + 4);
         }
-#pragma unroll
-        for (int a = 0; a < kBatch; a++) {
-#pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
+    };
+    auto issue = [&](int a, int pl) {
 #ifdef GNERF_ABLATE_GATHER      // timing-only build: no texel loads (outputs are wrong)
-                tex[a][pl][0] = (v4f){float(off[a][pl].x + cq16), 1.f, 2.f, 3.f}; tex[a][pl][1] = (v4f){float(off[a][pl].y), 1.f, 2.f, 3.f};
-                tex[a][pl][2] = (v4f){float(off[a][pl].z), 1.f, 2.f, 3.f};        tex[a][pl][3] = (v4f){float(off[a][pl].w), 1.f, 2.f, 3.f};
+        tex[a][pl][0] = (v4f){float(off[a][pl].x + cq16), 1.f, 2.f, 3.f}; tex[a][pl][1] = (v4f){float(off[a][pl].y), 1.f, 2.f, 3.f};
+        tex[a][pl][2] = (v4f){float(off[a][pl].z), 1.f, 2.f, 3.f};        tex[a][pl][3] = (v4f){float(off[a][pl].w), 1.f, 2.f, 3.f};
 #else
-                tex[a][pl][0] = *reinterpret_cast<const v4f*>(R.planes_item + (off[a][pl].x + cq16));
-                tex[a][pl][1] = *reinterpret_cast<const v4f*>(R.planes_item + (off[a][pl].y + cq16));
-                tex[a][pl][2] = *reinterpret_cast<const v4f*>(R.planes_item + (off[a][pl].z + cq16));
-                tex[a][pl][3] = *reinterpret_cast<const v4f*>(R.planes_item + (off[a][pl].w + cq16));
+        tex[a][pl][0] = *reinterpret_cast<const v4f*>(R.planes_item + (off[a][pl].x + cq16));
+        tex[a][pl][1] = *reinterpret_cast<const v4f*>(R.planes_item + (off[a][pl].y + cq16));
+        tex[a][pl][2] = *reinterpret_cast<const v4f*>(R.planes_item + (off[a][pl].z + cq16));
+        tex[a][pl][3] = *reinterpret_cast<const v4f*>(R.planes_item + (off[a][pl].w + cq16));
 #endif
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < kBatch; a++) {
-            v4f acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int pl = 0; pl < 3; pl++)
-                acc += tex[a][pl][0] * wgt[a][pl][0] + tex[a][pl][1] * wgt[a][pl][1] + tex[a][pl][2] * wgt[a][pl][2] + tex[a][pl][3] * wgt[a][pl][3];
-            *reinterpret_cast<v4f*>(stage + (8 * (a0 + a) + b) * kStagePitch + (lane & 7) * 4) = acc;
-        }
-    }
+    };
+    auto blend = [&](int a, int pl, v4f& acc) {
+        acc += tex[a][pl][0] * wgt[a][pl][0] + tex[a][pl][1] * wgt[a][pl][1] + tex[a][pl][2] * wgt[a][pl][2] + tex[a][pl][3] * wgt[a][pl][3];
+    };
+    v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    read_records(0);
+    issue(0, 0); issue(0, 1); issue(0, 2);
+    read_records(1);
+#ifndef GNERF_GATHER_SEQUENTIAL
+    __builtin_amdgcn_sched_barrier(0);
+    blend(0, 0, acc0); issue(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    blend(0, 1, acc0); issue(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    blend(0, 2, acc0); issue(1, 2);
+    __builtin_amdgcn_sched_barrier(0);
+#else
+    blend(0, 0, acc0); blend(0, 1, acc0); blend(0, 2, acc0);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(1, 0); issue(1, 1); issue(1, 2);
+#endif
+    *reinterpret_cast<v4f*>(stage + b * kStagePitch + (lane & 7) * 4) = acc0;
+    blend(1, 0, acc1); blend(1, 1, acc1); blend(1, 2, acc1);
+    *reinterpret_cast<v4f*>(stage + (8 + b) * kStagePitch + (lane & 7) * 4) = acc1;
     if (BLOCK_SYNC) __syncthreads(); else lds_wave_sync();
     GNERF_STAMP(st, 2);         // lookups (tap records, texel loads, blend, staging)
     const int j = lane & 15, g = lane >> 4;
