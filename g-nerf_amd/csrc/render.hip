@@ -263,6 +263,93 @@ __device__ __forceinline__ void shade(const Params& P, const Weights& w, const S
     __syncthreads();
 }
 
+// Stratified depth proposal k of a ray (renderer.py:169-192); bit-exact with torch's linspace + jitter.
+__device__ __forceinline__ float coarse_depth(const Params& P, int64_t ray, int k) {
+    const gnerf_render_params& p = P.p;
+    const int S = p.depth_resolution;
+    const float u = p.noise_coarse[ray * S + k];
+    if (p.disparity_space_sampling) {
+        const float step = 1.0f / float(S - 1);
+        const float lin = (k < S / 2) ? __fmul_rn(step, float(k)) : __fsub_rn(1.0f, __fmul_rn(step, float(S - 1 - k)));
+        const float q = __fadd_rn(lin, __fmul_rn(u, P.disp_delta));
+        return __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(P.inv_start, __fsub_rn(1.0f, q)), __fmul_rn(P.inv_end, q)));
+    }
+    if (p.ray_start_per_ray) {
+        const float rs = p.ray_start_per_ray[ray], re = p.ray_end_per_ray[ray];
+        const float span = __fsub_rn(re, rs);
+        const float lin = __fadd_rn(rs, __fmul_rn(__fdiv_rn(float(k), float(S - 1)), span));      // math_utils.py:107-116
+        return __fadd_rn(lin, __fmul_rn(u, __fdiv_rn(span, float(S - 1))));
+    }
+    const float step = __fdiv_rn(__fsub_rn(p.ray_end, p.ray_start), float(S - 1));            // torch.linspace
+    const float lin = (k < S / 2) ? __fadd_rn(p.ray_start, __fmul_rn(step, float(k)))
+                                  : __fsub_rn(p.ray_end, __fmul_rn(step, float(S - 1 - k)));
+    return __fadd_rn(lin, __fmul_rn(u, P.delta));
+}
+
+// Importance resampling (renderer.py:194-253): fine depths from the coarse interval weights w[0..S-2].
+// n_w = S-3 pdf entries, cdf has n_w+1.  `pdf_tmp` is scratch of >= S floats; `sync` separates the phases.
+template <typename Sync>
+__device__ __forceinline__ void resample_fine(const Params& P, int64_t ray, const float* t_c, const float* w, float* pdf_tmp, float* cdf,
+                                              float* t_f, float* dbg, int n_all, int lane, Sync sync) {
+    const gnerf_render_params& p = P.p;
+    const int S = p.depth_resolution, F = p.depth_resolution_importance;
+    const int n_w = S - 3;
+    float part = 0.f;
+    for (int i = lane; i < n_w; i += 64) {
+        // smoothed weight a_{i+1} = (max(w_i, w_{i+1}) + max(w_{i+1}, w_{i+2})) / 2 + 0.01, then + 1e-5
+        const float w0 = w[i], w1 = w[i + 1], w2 = w[i + 2];
+        const float a = (fmaxf(w0, w1) + fmaxf(w1, w2)) * 0.5f + 0.01f;
+        const float pw = a + 1e-5f;
+        pdf_tmp[i] = pw;
+        part += pw;
+    }
+    const float total = wave_sum(part);
+    sync();
+    float carry = 0.f;
+    for (int base = 0; base < n_w; base += 64) {
+        const int i = base + lane;
+        const float pdf = (i < n_w) ? pdf_tmp[i] / total : 0.f;
+        const float incl = wave_scan_add(pdf, lane) + carry;
+        if (i < n_w) cdf[i + 1] = incl;
+        carry = wave_last(incl);
+    }
+    if (lane == 0) cdf[0] = 0.f;
+    sync();
+    for (int i = lane; i < F; i += 64) {
+        const float u = p.noise_fine[ray * F + i];
+        // searchsorted(cdf[0..n_w], u, right=True): number of entries <= u
+        int lo = 0, hi = n_w + 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+        const int below = max(lo - 1, 0), above = min(lo, n_w);
+        const float cb = cdf[below], ca = cdf[above];
+        const float bb = (t_c[below] + t_c[below + 1]) * 0.5f;
+        const float ba = (t_c[above] + t_c[above + 1]) * 0.5f;
+        float denom = ca - cb;
+        if (denom < 1e-5f) denom = 1.f;
+        const float d = bb + (u - cb) / denom * (ba - bb);
+        t_f[i] = d;
+        if (dbg) dbg[GNERF_DBG_DEPTH_FINE * n_all + i] = d;
+    }
+    sync();
+}
+
+// Merge by depth (renderer.py:157-167): rank = number of elements ordered before this one, ties broken by
+// position in cat([coarse, fine]) like a stable sort.  Writes rank_e and the sorted depth / density arrays.
+__device__ __forceinline__ void merge_by_depth(const float* t_e, const float* sig_e, int* rank_e, float* s_t, float* s_sig,
+                                               int S, int F, int fine_e0, int lane) {
+    const int n_all = S + F;
+    for (int q = lane; q < n_all; q += 64) {
+        const int e = q < S ? q : fine_e0 + (q - S);
+        const float key = t_e[e];
+        int rank = 0;
+        for (int o = 0; o < S; o++) { const float tk = t_e[o]; rank += (tk < key || (tk == key && o < q)) ? 1 : 0; }
+        for (int o = 0; o < F; o++) { const float tk = t_e[fine_e0 + o]; rank += (tk < key || (tk == key && S + o < q)) ? 1 : 0; }
+        rank_e[e] = rank;
+        s_t[rank] = key;
+        s_sig[rank] = sig_e[e];
+    }
+}
+
 // Ray-march weights over n sorted samples (depth/density in LDS): writes w[0..n-2], returns sum(w) and
 // sum(w * t_mid) in all lanes.  ray_marcher.py:26-42.
 __device__ __forceinline__ void march(const float* t, const float* sig, float* w, int n, int lane, float& w_sum, float& wt_sum) {
@@ -339,24 +426,7 @@ __global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
 
         // ---- stratified depth proposals (renderer.py:169-192)
         for (int k = lane; k < S; k += 64) {
-            const float u = p.noise_coarse[ray * S + k];
-            float d;
-            if (p.disparity_space_sampling) {
-                const float step = 1.0f / float(S - 1);
-                const float lin = (k < S / 2) ? __fmul_rn(step, float(k)) : __fsub_rn(1.0f, __fmul_rn(step, float(S - 1 - k)));
-                const float q = __fadd_rn(lin, __fmul_rn(u, P.disp_delta));
-                d = __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(P.inv_start, __fsub_rn(1.0f, q)), __fmul_rn(P.inv_end, q)));
-            } else if (p.ray_start_per_ray) {
-                const float rs = p.ray_start_per_ray[ray], re = p.ray_end_per_ray[ray];
-                const float span = __fsub_rn(re, rs);
-                const float lin = __fadd_rn(rs, __fmul_rn(__fdiv_rn(float(k), float(S - 1)), span));      // math_utils.py:107-116
-                d = __fadd_rn(lin, __fmul_rn(u, __fdiv_rn(span, float(S - 1))));
-            } else {
-                const float step = __fdiv_rn(__fsub_rn(p.ray_end, p.ray_start), float(S - 1));            // torch.linspace
-                const float lin = (k < S / 2) ? __fadd_rn(p.ray_start, __fmul_rn(step, float(k)))
-                                              : __fsub_rn(p.ray_end, __fmul_rn(step, float(S - 1 - k)));
-                d = __fadd_rn(lin, __fmul_rn(u, P.delta));
-            }
+            const float d = coarse_depth(P, ray, k);
             lds.t_e[k] = d;
             if (dbg) dbg[GNERF_DBG_DEPTH_COARSE * n_all + k] = d;
         }
@@ -373,62 +443,13 @@ __global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
             __syncthreads();
             if (dbg) for (int k = lane; k < S - 1; k += 64) dbg[GNERF_DBG_WEIGHT_COARSE * n_all + k] = lds.w_s[k];
 
-            // ---- importance resampling (renderer.py:194-253).  n_w = S-3 pdf entries, cdf has n_w+1.
-            const int n_w = S - 3;
-            float part = 0.f;
-            for (int i = lane; i < n_w; i += 64) {
-                // smoothed weight a_{i+1} = (max(w_i, w_{i+1}) + max(w_{i+1}, w_{i+2})) / 2 + 0.01, then + 1e-5
-                const float w0 = lds.w_s[i], w1 = lds.w_s[i + 1], w2 = lds.w_s[i + 2];
-                const float a = (fmaxf(w0, w1) + fmaxf(w1, w2)) * 0.5f + 0.01f;
-                const float pw = a + 1e-5f;
-                lds.s_sig[i] = pw;              // s_sig is free until the merge
-                part += pw;
-            }
-            const float total = wave_sum(part);
-            __syncthreads();
-            float carry = 0.f;
-            for (int base = 0; base < n_w; base += 64) {
-                const int i = base + lane;
-                const float pdf = (i < n_w) ? lds.s_sig[i] / total : 0.f;
-                const float incl = wave_scan_add(pdf, lane) + carry;
-                if (i < n_w) lds.cdf[i + 1] = incl;
-                carry = wave_last(incl);
-            }
-            if (lane == 0) lds.cdf[0] = 0.f;
-            __syncthreads();
-            for (int i = lane; i < F; i += 64) {
-                const float u = p.noise_fine[ray * F + i];
-                // searchsorted(cdf[0..n_w], u, right=True): number of entries <= u
-                int lo = 0, hi = n_w + 1;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (lds.cdf[mid] <= u) lo = mid + 1; else hi = mid; }
-                const int below = max(lo - 1, 0), above = min(lo, n_w);
-                const float cb = lds.cdf[below], ca = lds.cdf[above];
-                const float bb = (lds.t_e[below] + lds.t_e[below + 1]) * 0.5f;
-                const float ba = (lds.t_e[above] + lds.t_e[above + 1]) * 0.5f;
-                float denom = ca - cb;
-                if (denom < 1e-5f) denom = 1.f;
-                const float d = bb + (u - cb) / denom * (ba - bb);
-                lds.t_e[fine_e0 + i] = d;
-                if (dbg) dbg[GNERF_DBG_DEPTH_FINE * n_all + i] = d;
-            }
-            __syncthreads();
+            resample_fine(P, ray, lds.t_e, lds.w_s, lds.s_sig, lds.cdf, lds.t_e + fine_e0, dbg, n_all, lane, [] { __syncthreads(); });
 
             // ---- fine pass
             shade(P, w, lds, planes_item, ox, oy, oz, dx, dy, dz, fine_e0, F, P.tiles_f, P.tiles_c, lane);
             if (dbg) for (int k = lane; k < F; k += 64) dbg[GNERF_DBG_SIGMA_FINE * n_all + k] = lds.sig_e[fine_e0 + k];
 
-            // ---- merge by depth (renderer.py:157-167): rank = number of elements ordered before this one,
-            // ties broken by position in cat([coarse, fine]) like a stable sort.
-            for (int q = lane; q < n_all; q += 64) {
-                const int e = q < S ? q : fine_e0 + (q - S);
-                const float key = lds.t_e[e];
-                int rank = 0;
-                for (int o = 0; o < S; o++) { const float tk = lds.t_e[o]; rank += (tk < key || (tk == key && o < q)) ? 1 : 0; }
-                for (int o = 0; o < F; o++) { const float tk = lds.t_e[fine_e0 + o]; rank += (tk < key || (tk == key && S + o < q)) ? 1 : 0; }
-                lds.rank_e[e] = rank;
-                lds.s_t[rank] = key;
-                lds.s_sig[rank] = lds.sig_e[e];
-            }
+            merge_by_depth(lds.t_e, lds.sig_e, lds.rank_e, lds.s_t, lds.s_sig, S, F, fine_e0, lane);
             __syncthreads();
             march(lds.s_t, lds.s_sig, lds.w_s, n_all, lane, w_sum, wt_sum);
             __syncthreads();
@@ -587,6 +608,7 @@ __global__ __launch_bounds__(64) void query_kernel(gnerf_render_params p, float 
 
 #include "render_coop.inl"
 #include "render_pipe.inl"
+#include "render_bwd.inl"
 
 int check_common(const gnerf_render_params* p) {
     if (!p) return fail(GNERF_E_ARG, "render: params is null");
@@ -602,11 +624,11 @@ int check_common(const gnerf_render_params* p) {
 
 extern "C" size_t gnerf_render_workspace_bytes(void) { return 64; }
 
-extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t stream) {
+// Validation and derived launch parameters shared by the forward and backward entry points.
+static int fill_params(const gnerf_render_params* p, Params& P) {
     using namespace gnerf;
     if (int e = check_common(p)) return e;
-    if (!p->ray_origins || !p->ray_dirs || !p->noise_coarse || !p->out_rgb || !p->out_depth || !p->out_wsum || !p->workspace)
-        return fail(GNERF_E_ARG, "render: rays, noise_coarse, outputs and workspace must not be null");
+    if (!p->ray_origins || !p->ray_dirs || !p->noise_coarse) return fail(GNERF_E_ARG, "render: rays and noise_coarse must not be null");
     const int S = p->depth_resolution, F = p->depth_resolution_importance;
     if (S < 2 || S > GNERF_MAX_SAMPLES) return fail(GNERF_E_ARG, "render: depth_resolution %d outside [2, %d]", S, GNERF_MAX_SAMPLES);
     if (F < 0 || F > GNERF_MAX_SAMPLES) return fail(GNERF_E_ARG, "render: depth_resolution_importance %d outside [0, %d]", F, GNERF_MAX_SAMPLES);
@@ -617,7 +639,6 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
     const int64_t total = int64_t(p->n_items) * p->rays_per_item;
     if (total * (S + F) > INT32_MAX * int64_t(8)) return fail(GNERF_E_ARG, "render: too many samples in one call");
 
-    Params P;
     P.p = *p;
     P.box_scale = float(2.0 / double(p->box_warp));
     P.delta = float((double(p->ray_end) - double(p->ray_start)) / double(S - 1));
@@ -637,6 +658,17 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         P.tiles_per_item = 0;
         P.n_tiles = int((total + kRaysPerWave - 1) / kRaysPerWave);
     }
+    return GNERF_OK;
+}
+
+extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t stream) {
+    using namespace gnerf;
+    Params P;
+    if (int e = fill_params(p, P)) return e;
+    if (!p->out_rgb || !p->out_depth || !p->out_wsum || !p->workspace)
+        return fail(GNERF_E_ARG, "render: outputs and workspace must not be null");
+    const int S = p->depth_resolution, F = p->depth_resolution_importance;
+    const int64_t total = P.total_rays;
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(init_range_kernel, dim3(1), dim3(1), 0, s, static_cast<unsigned*>(p->workspace));
     const int per_xcd = (P.n_tiles + kNumXCD - 1) / kNumXCD;
@@ -688,6 +720,30 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
     hipLaunchKernelGGL(clamp_depth_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        p->out_depth, static_cast<const unsigned*>(p->workspace), total);
     return check_launch("clamp_depth_kernel");
+}
+
+extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_render_grads* g, gnerf_stream_t stream) {
+    using namespace gnerf;
+    Params P;
+    if (int e = fill_params(p, P)) return e;
+    if (!g) return fail(GNERF_E_ARG, "render_backward: grads is null");
+    const int n_dec = (g->grad_w1 != nullptr) + (g->grad_b1 != nullptr) + (g->grad_w2 != nullptr) + (g->grad_b2 != nullptr);
+    if (n_dec != 0 && n_dec != 4) return fail(GNERF_E_ARG, "render_backward: the four decoder gradients are given together or not at all");
+    if (!g->grad_planes_nhwc && n_dec == 0) return GNERF_OK;
+    if (!(int64_t(p->plane_h) * p->plane_w * 3 * 128 < (int64_t(1) << 32))) return fail(GNERF_E_UNSUPPORTED, "render_backward: planes too large for 32-bit tap offsets");
+    static_assert(kBwdRaysPerWave == kRaysPerWave, "ray tiles are shared with the forward launcher");
+    const size_t lds_bytes = (kBwdWeightFloats + kBwdWaves * bwd_wave_floats(16 * (P.tiles_c + P.tiles_f))) * sizeof(float);
+    if (lds_bytes > 160 * 1024) return fail(GNERF_E_ARG, "render_backward: %d+%d samples need %zu bytes of LDS (> 160 KiB)", p->depth_resolution, p->depth_resolution_importance, lds_bytes);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return fail(GNERF_E_LAUNCH, "render_backward: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    const int n_blocks = (P.n_tiles + kBwdWaves - 1) / kBwdWaves;
+    const int per_xcd = (n_blocks + kNumXCD - 1) / kNumXCD;
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(per_xcd * kNumXCD), dim3(kBwdThreads), lds_bytes, as_stream(stream), P, *g);
+    return check_launch("render_bwd_kernel");
 }
 
 extern "C" int gnerf_query_points(const float* planes_nhwc, int n_items, int plane_h, int plane_w,

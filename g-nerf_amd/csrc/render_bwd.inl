@@ -1,0 +1,481 @@
+// Backward pass of the fused renderer.  Included by render.hip (inside its anonymous namespace).
+//
+// Upstream this is autograd walking the graph of ImportanceRenderer.forward (renderer.py:88-140) backwards:
+// the composite of ray_marcher.py:25-57, the sort/gather of renderer.py:150-167, the decoder's two linear layers
+// (triplane.py:113-136) and grid_sample's backward (grid_sample_gradfix.py:62-77), with ~4 GB of saved
+// intermediates at the training shape.  Here nothing is saved: ONE WAVE OWNS A RAY and
+//   1. recomputes the forward pass of its ray (same depth proposals, lookups, MLP, coarse march, importance
+//      resampling, merge, final march) keeping only per-sample scalars in LDS -- in place of each sample's
+//      32 colours it keeps q_j = sum_c dL/drgb[c] * colour_j[c], which is all the composite's gradient needs;
+//   2. runs the composite's gradient as wave scans over the sorted intervals: dL/dw_k, the suffix sums that
+//      carry the transmittance dependence, dL/dsigma of every sample and the colour weights v_j;
+//   3. walks the sample tiles once more: lookup + MLP forward again, then dO -> dH -> dPRE -> dX on the matrix
+//      cores (exact fp32 v_mfma_f32_16x16x4_f32; operands change roles through small LDS transposes), the
+//      weight gradients dW2 += dO^T H and dW1 += dPRE^T X accumulated in registers across all rays of the wave,
+//      and dX scattered into the plane gradient with one hardware float atomic per (tap, channel).
+// Four waves (four rays) share a workgroup and one LDS copy of the decoder; the weight gradients are reduced
+// in LDS per workgroup and leave with one atomic per element.
+//
+// Conventions as in render.hip: MFMA D layout col = lane & 15, rows = 4 * (lane >> 4) + r.
+
+constexpr int kBwdWaves = 4;
+constexpr int kBwdThreads = 64 * kBwdWaves;
+constexpr int kBwdRaysPerWave = 16;
+constexpr int kTPitch = 36;          // dO [16 samples][32 colour outputs], later dX [16][32 channels]
+constexpr int kHPitch = 68;          // H, later dPRE: [16 samples][64 hidden]
+constexpr int kBwdWeightFloats = 64 * kW1Pitch + 33 * kW2Pitch + 64 + 36;      // w1, w2, b1, b2 in plain fp32 rows
+constexpr int kBwdGradFloats = 64 * 32 + 64 + 33 * 64 + 33;                    // reduction area, aliases the weights
+static_assert(kBwdGradFloats <= kBwdWeightFloats, "weight-gradient reduction area must fit in the weight area");
+
+__host__ __device__ inline size_t bwd_wave_floats(int s_pad) {
+    return size_t(12) * s_pad + 16 * kStagePitch + 16 * kTPitch + 16 * kHPitch + 16 * kTapDwords;
+}
+
+struct BwdLds {
+    const float* w1; const float* w2; const float* b1; const float* b2;     // workgroup-shared decoder
+    float* t_e; float* sig_e; float* q_e; float* v_e; float* dsig_e; int* rank_e;      // per element (coarse k at k, fine i at 16*tiles_c + i)
+    float* s_t; float* s_sig; float* s_q; float* w_s; float* trans; float* ds;         // sorted order / per interval
+    float* stage; float* tbuf; float* hbuf; float* taps;
+};
+
+// Sum over the 16 lanes of a DPP row; valid in lanes with (lane & 15) == 15.
+__device__ __forceinline__ float row_total(float v) {
+    v += dpp_mov<0x111, 0xf>(0.f, v);
+    v += dpp_mov<0x112, 0xf>(0.f, v);
+    v += dpp_mov<0x114, 0xf>(0.f, v);
+    v += dpp_mov<0x118, 0xf>(0.f, v);
+    return v;
+}
+
+struct BwdRay { float ox, oy, oz, dx, dy, dz; const char* planes; };
+
+// Tap records of the 16 samples of a tile (lanes 0..47: sample = lane & 15, plane = lane >> 4), then the lookup:
+// 8 lanes per texel, 8 samples per step, blended features staged as X[sample][channel].
+__device__ __forceinline__ void bwd_gather_tile(const Params& P, const BwdLds& L, const BwdRay& R, const float* t_list, int count, int tile, int lane) {
+    const int H = P.p.plane_h, W = P.p.plane_w;
+    if (lane < 48) {
+        const int j = lane & 15, pl = lane >> 4;
+        const int idx = min(16 * tile + j, count - 1);
+        const float depth = t_list[idx];
+        const float px = __fadd_rn(R.ox, __fmul_rn(depth, R.dx)) * P.box_scale;
+        const float py = __fadd_rn(R.oy, __fmul_rn(depth, R.dy)) * P.box_scale;
+        const float pz = __fadd_rn(R.oz, __fmul_rn(depth, R.dz)) * P.box_scale;
+        const float u = pl == 2 ? pz : px;
+        const float v = pl == 0 ? py : (pl == 1 ? pz : px);
+        uint4 off; v4f wgt;
+        plane_taps(H, W, u, v, unsigned(pl) * unsigned(H) * unsigned(W) * 128u, off, wgt);
+        float* rec = L.taps + j * kTapDwords + pl * 8;
+        *reinterpret_cast<uint4*>(rec) = off;
+        *reinterpret_cast<v4f*>(rec + 4) = wgt;
+    }
+    lds_wave_sync();
+    const int b = lane >> 3, cq16 = (lane & 7) * 16;
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        const int js = 8 * a + b;
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            const float* rec = L.taps + js * kTapDwords + pl * 8;
+            const uint4 off = *reinterpret_cast<const uint4*>(rec);
+            const v4f wgt = *reinterpret_cast<const v4f*>(rec + 4);
+            const v4f t00 = *reinterpret_cast<const v4f*>(R.planes + off.x + cq16);
+            const v4f t01 = *reinterpret_cast<const v4f*>(R.planes + off.y + cq16);
+            const v4f t10 = *reinterpret_cast<const v4f*>(R.planes + off.z + cq16);
+            const v4f t11 = *reinterpret_cast<const v4f*>(R.planes + off.w + cq16);
+            acc += t00 * wgt[0] + t01 * wgt[1] + t10 * wgt[2] + t11 * wgt[3];
+        }
+        *reinterpret_cast<v4f*>(L.stage + js * kStagePitch + (cq16 >> 2)) = acc;
+    }
+    lds_wave_sync();
+}
+
+// MLP forward on the staged tile: h = softplus(W1 x + b1) in the H^T layout (lane: sample j, hidden 16m+4g+r),
+// o = colour pre-activations (lane: sample 4g+r, output 1+16n+j), sig = density of sample j.
+__device__ __forceinline__ void bwd_mlp_forward(const BwdLds& L, int lane, v4f (&h)[4], v4f (&o)[2], float& sig) {
+    const int j = lane & 15, g = lane >> 4;
+    const v4f f_lo = *reinterpret_cast<const v4f*>(L.stage + j * kStagePitch + 8 * g);
+    const v4f f_hi = *reinterpret_cast<const v4f*>(L.stage + j * kStagePitch + 8 * g + 4);
+    const float f[8] = {f_lo[0], f_lo[1], f_lo[2], f_lo[3], f_hi[0], f_hi[1], f_hi[2], f_hi[3]};
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        h[m] = *reinterpret_cast<const v4f*>(L.b1 + 16 * m + 4 * g);
+        const v4f a_lo = *reinterpret_cast<const v4f*>(L.w1 + (16 * m + j) * kW1Pitch + 8 * g);
+        const v4f a_hi = *reinterpret_cast<const v4f*>(L.w1 + (16 * m + j) * kW1Pitch + 8 * g + 4);
+#pragma unroll
+        for (int s = 0; s < 4; s++) h[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lo[s], f[s], h[m], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; s++) h[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi[s], f[4 + s], h[m], 0, 0, 0);
+    }
+    sig = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const v4f ws = *reinterpret_cast<const v4f*>(L.w2 + 16 * m + 4 * g);          // density row W2[0][:]
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            h[m][r] = softplus_hw(h[m][r]);
+            sig += ws[r] * h[m][r];
+        }
+    }
+    sig += __shfl_xor(sig, 16);
+    sig += __shfl_xor(sig, 32);
+    sig += L.b2[0];
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        const float bias = L.b2[1 + 16 * n + j];
+        o[n] = (v4f){bias, bias, bias, bias};
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const v4f bw = *reinterpret_cast<const v4f*>(L.w2 + (1 + 16 * n + j) * kW2Pitch + 16 * m + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[m][r], bw[r], o[n], 0, 0, 0);
+        }
+    }
+}
+
+// Forward-only walk of `ntiles` tiles: densities -> sig_e[e0...], q -> q_e[e0...].
+// G[n] = dL/d(colour sum) of channel 16n + (lane & 15), i.e. 2 * grad_rgb.
+__device__ __forceinline__ void bwd_forward_tiles(const Params& P, const BwdLds& L, const BwdRay& R, int e0, int count, int ntiles,
+                                                  const float (&G)[2], int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    for (int t = 0; t < ntiles; t++) {
+        bwd_gather_tile(P, L, R, L.t_e + e0, count, t, lane);
+        v4f h[4], o[2];
+        float sig;
+        bwd_mlp_forward(L, lane, h, o, sig);
+        if (g == 0 && 16 * t + j < count) L.sig_e[e0 + 16 * t + j] = sig;
+        v4f q;
+#pragma unroll
+        for (int r = 0; r < 4; r++) q[r] = row_total(G[0] * sigmoid_rgb_hw(o[0][r]) + G[1] * sigmoid_rgb_hw(o[1][r]));
+        if (j == 15) *reinterpret_cast<v4f*>(L.q_e + e0 + 16 * t + 4 * g) = q;
+    }
+    lds_wave_sync();
+}
+
+// Per-wave accumulators of the decoder gradients (summed over every sample the wave shades).
+struct BwdAcc {
+    v4f w1[4][2];     // dW1[16m + 4g + r][16c + j]
+    v4f w2[2][4];     // dW2[1 + 16o + 4g + r][16n + j]
+    v4f w2s[4];       // dW2[0][16m + 4g + r], partial over the samples on this lane's column
+    v4f b1[4];        // db1[16m + 4g + r], partial likewise
+    float b2[2];      // db2[1 + 16n + j], partial over this lane's sample rows
+    float b2s;        // db2[0], partial
+};
+
+__device__ __forceinline__ void bwd_backward_tiles(const Params& P, const BwdLds& L, const BwdRay& R, float* grad_planes_item,
+                                                   int e0, int count, int ntiles, const float (&G)[2], BwdAcc& A, int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    for (int t = 0; t < ntiles; t++) {
+        bwd_gather_tile(P, L, R, L.t_e + e0, count, t, lane);
+        v4f h[4], o[2];
+        float sig;
+        bwd_mlp_forward(L, lane, h, o, sig);
+        // ---- dO: colour c = 1.002 * s - 0.001 with s = sigmoid(o); dL/dc = G * v_sample  (triplane.py:134, ray_marcher.py:27-45)
+        const v4f vs = *reinterpret_cast<const v4f*>(L.v_e + e0 + 16 * t + 4 * g);
+        const float dsig = L.dsig_e[e0 + 16 * t + j];
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float e = __builtin_amdgcn_exp2f(o[n][r] * -1.44269504088896341f);
+                const float s = __builtin_amdgcn_rcpf(1.0f + e);
+                const float d = G[n] * vs[r] * (1.002f * s * (1.f - s));
+                L.tbuf[(4 * g + r) * kTPitch + 16 * n + j] = d;
+                A.b2[n] += d;
+            }
+        }
+        if (g == 0) A.b2s += dsig;
+        lds_wave_sync();
+        // ---- dH^T[hidden][sample] = sum_out W2[out][hidden] dO[sample][out]  (+ the density row on the vector ALU)
+        v4f dh[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const v4f ws = *reinterpret_cast<const v4f*>(L.w2 + 16 * m + 4 * g);
+            dh[m] = ws * dsig;
+            A.w2s[m] += h[m] * dsig;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const float bT = L.tbuf[j * kTPitch + 4 * s + g];
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                dh[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(L.w2[(1 + 4 * s + g) * kW2Pitch + 16 * m + j], bT, dh[m], 0, 0, 0);
+        }
+        // ---- through softplus: d/dpre softplus(pre) = 1 - exp(-softplus(pre))
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) dh[m][r] *= 1.f - exp_hw(-h[m][r]);
+            A.b1[m] += dh[m];
+            *reinterpret_cast<v4f*>(L.hbuf + j * kHPitch + 16 * m + 4 * g) = h[m];
+        }
+        lds_wave_sync();
+        // ---- dW2[out][hidden] += sum_sample dO[sample][out] H[sample][hidden]
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float a0 = L.tbuf[(4 * g + r) * kTPitch + j], a1 = L.tbuf[(4 * g + r) * kTPitch + 16 + j];
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                const float bh = L.hbuf[(4 * g + r) * kHPitch + 16 * n + j];
+                A.w2[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bh, A.w2[0][n], 0, 0, 0);
+                A.w2[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bh, A.w2[1][n], 0, 0, 0);
+            }
+        }
+        lds_wave_sync();
+        // ---- dX^T[channel][sample] = sum_hidden W1[hidden][channel] dPRE^T[hidden][sample]
+        v4f dx[2];
+        dx[0] = dx[1] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float* row = L.w1 + (16 * m + 4 * g + r) * kW1Pitch + j;
+                dx[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(row[0], dh[m][r], dx[0], 0, 0, 0);
+                dx[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(row[16], dh[m][r], dx[1], 0, 0, 0);
+            }
+            *reinterpret_cast<v4f*>(L.hbuf + j * kHPitch + 16 * m + 4 * g) = dh[m];             // dPRE[sample][hidden]
+        }
+        *reinterpret_cast<v4f*>(L.tbuf + j * kTPitch + 4 * g) = dx[0];                            // dX[sample][channel]
+        *reinterpret_cast<v4f*>(L.tbuf + j * kTPitch + 16 + 4 * g) = dx[1];
+        lds_wave_sync();
+        // ---- dW1[hidden][channel] += sum_sample dPRE[sample][hidden] X[sample][channel]
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float b0 = L.stage[(4 * g + r) * kStagePitch + j], b1 = L.stage[(4 * g + r) * kStagePitch + 16 + j];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const float ap = L.hbuf[(4 * g + r) * kHPitch + 16 * m + j];
+                A.w1[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap, b0, A.w1[m][0], 0, 0, 0);
+                A.w1[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap, b1, A.w1[m][1], 0, 0, 0);
+            }
+        }
+        // ---- scatter dX into the plane gradient: lane = (sample parity, channel), 12 taps per sample
+        if (grad_planes_item) {
+            const int half = lane >> 5, ch = lane & 31;
+            const int live = min(16, count - 16 * t);
+#pragma unroll 2
+            for (int pstep = 0; pstep < 8; pstep++) {
+                const int smp = 2 * pstep + half;
+                if (smp < live) {
+                    const float val = L.tbuf[smp * kTPitch + ch];
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++) {
+                        const float* rec = L.taps + smp * kTapDwords + pl * 8;
+                        const uint4 off = *reinterpret_cast<const uint4*>(rec);
+                        const v4f wgt = *reinterpret_cast<const v4f*>(rec + 4);
+                        if (wgt[0] != 0.f) unsafeAtomicAdd(grad_planes_item + (off.x >> 2) + ch, val * wgt[0]);
+                        if (wgt[1] != 0.f) unsafeAtomicAdd(grad_planes_item + (off.y >> 2) + ch, val * wgt[1]);
+                        if (wgt[2] != 0.f) unsafeAtomicAdd(grad_planes_item + (off.z >> 2) + ch, val * wgt[2]);
+                        if (wgt[3] != 0.f) unsafeAtomicAdd(grad_planes_item + (off.w >> 2) + ch, val * wgt[3]);
+                    }
+                }
+            }
+        }
+        lds_wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gnerf_render_grads Gr) {
+    extern __shared__ __align__(16) float smem[];
+    const gnerf_render_params& p = P.p;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int S = p.depth_resolution, F = p.depth_resolution_importance;
+    const int s_pad = 16 * (P.tiles_c + P.tiles_f);
+    const int n_all = S + F;
+    const int fine_e0 = 16 * P.tiles_c;
+
+    // ---- decoder into LDS (plain fp32 rows; every matrix is read in two orientations)
+    float* w1 = smem;
+    float* w2 = w1 + 64 * kW1Pitch;
+    float* b1 = w2 + 33 * kW2Pitch;
+    float* b2 = b1 + 64;
+    for (int i = tid; i < 64 * 32; i += kBwdThreads) w1[(i >> 5) * kW1Pitch + (i & 31)] = p.w1[i];
+    for (int i = tid; i < 33 * 64; i += kBwdThreads) w2[(i >> 6) * kW2Pitch + (i & 63)] = p.w2[i];
+    if (tid < 64) b1[tid] = p.b1[tid];
+    if (tid < 36) b2[tid] = tid < 33 ? p.b2[tid] : 0.f;
+    __syncthreads();
+
+    BwdLds L;
+    L.w1 = w1; L.w2 = w2; L.b1 = b1; L.b2 = b2;
+    float* base = smem + kBwdWeightFloats + size_t(wv) * bwd_wave_floats(s_pad);
+    L.t_e = base;               L.sig_e = L.t_e + s_pad;   L.q_e = L.sig_e + s_pad;  L.v_e = L.q_e + s_pad;
+    L.dsig_e = L.v_e + s_pad;   L.rank_e = reinterpret_cast<int*>(L.dsig_e + s_pad);
+    L.s_t = L.dsig_e + 2 * s_pad;  L.s_sig = L.s_t + s_pad;  L.s_q = L.s_sig + s_pad;  L.w_s = L.s_q + s_pad;
+    L.trans = L.w_s + s_pad;    L.ds = L.trans + s_pad;
+    L.stage = L.ds + s_pad;     L.tbuf = L.stage + 16 * kStagePitch;  L.hbuf = L.tbuf + 16 * kTPitch;  L.taps = L.hbuf + 16 * kHPitch;
+
+    BwdAcc A;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        A.w1[m][0] = A.w1[m][1] = A.w2[0][m] = A.w2[1][m] = A.w2s[m] = A.b1[m] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+    A.b2[0] = A.b2[1] = A.b2s = 0.f;
+
+    // ray tiles: workgroup `blk` owns tiles 4*blk .. 4*blk+3 (one per wave); XCD-contiguous like the forward kernels
+    const int n_blocks = (P.n_tiles + kBwdWaves - 1) / kBwdWaves;
+    const int per_xcd = (n_blocks + kNumXCD - 1) / kNumXCD;
+    const int blk = (blockIdx.x % kNumXCD) * per_xcd + blockIdx.x / kNumXCD;
+    const int tile = blk * kBwdWaves + wv;
+    const bool have_tile = blk < n_blocks && tile < P.n_tiles;
+    const int64_t plane_floats = int64_t(3) * p.plane_h * p.plane_w * 32;
+    const int j = lane & 15;
+
+    for (int rr = 0; have_tile && rr < kBwdRaysPerWave; rr++) {
+        int64_t ray;
+        if (P.tiles_per_item > 0) {
+            const int item = tile / P.tiles_per_item, tt = tile % P.tiles_per_item;
+            const int tx = tt / P.tiles_y, ty = tt % P.tiles_y;
+            ray = int64_t(item) * p.rays_per_item + int64_t(ty * 4 + (rr >> 2)) * p.image_width + tx * 4 + (rr & 3);
+        } else {
+            ray = int64_t(tile) * kBwdRaysPerWave + rr;
+            if (ray >= P.total_rays) break;
+        }
+        const int item = int(ray / p.rays_per_item);
+        BwdRay R;
+        R.ox = p.ray_origins[ray * 3 + 0]; R.oy = p.ray_origins[ray * 3 + 1]; R.oz = p.ray_origins[ray * 3 + 2];
+        R.dx = p.ray_dirs[ray * 3 + 0]; R.dy = p.ray_dirs[ray * 3 + 1]; R.dz = p.ray_dirs[ray * 3 + 2];
+        R.planes = reinterpret_cast<const char*>(p.planes_nhwc + int64_t(item) * plane_floats);
+        float* grad_planes_item = Gr.grad_planes_nhwc ? Gr.grad_planes_nhwc + int64_t(item) * plane_floats : nullptr;
+        // incoming gradients; rgb = 2 * composite - 1 (ray_marcher.py:55)
+        float G[2];
+        G[0] = Gr.grad_rgb ? 2.f * Gr.grad_rgb[ray * 32 + j] : 0.f;
+        G[1] = Gr.grad_rgb ? 2.f * Gr.grad_rgb[ray * 32 + 16 + j] : 0.f;
+        const float g_depth = Gr.grad_depth ? Gr.grad_depth[ray] : 0.f;
+        const float g_wsum = Gr.grad_wsum ? Gr.grad_wsum[ray] : 0.f;
+        const float g_sum = wave_sum(lane < 16 ? G[0] + G[1] : 0.f);
+
+        // ---- 1. forward recomputation
+        for (int k = lane; k < S; k += 64) L.t_e[k] = coarse_depth(P, ray, k);
+        for (int k = lane; k < s_pad; k += 64) { L.v_e[k] = 0.f; L.dsig_e[k] = 0.f; L.q_e[k] = 0.f; }
+        lds_wave_sync();
+        bwd_forward_tiles(P, L, R, 0, S, P.tiles_c, G, lane);
+        if (F > 0) {
+            float w_sum, wt_sum;
+            march(L.t_e, L.sig_e, L.w_s, S, lane, w_sum, wt_sum);
+            lds_wave_sync();
+            resample_fine(P, ray, L.t_e, L.w_s, L.s_sig, L.trans, L.t_e + fine_e0, nullptr, n_all, lane, [] { lds_wave_sync(); });
+            bwd_forward_tiles(P, L, R, fine_e0, F, P.tiles_f, G, lane);
+            merge_by_depth(L.t_e, L.sig_e, L.rank_e, L.s_t, L.s_sig, S, F, fine_e0, lane);
+        } else {
+            for (int k = lane; k < S; k += 64) { L.rank_e[k] = k; L.s_t[k] = L.t_e[k]; L.s_sig[k] = L.sig_e[k]; }
+        }
+        lds_wave_sync();
+        for (int q = lane; q < n_all; q += 64) {
+            const int e = q < S ? q : fine_e0 + (q - S);
+            L.s_q[L.rank_e[e]] = L.q_e[e];
+        }
+        // final march, keeping the transmittance in front of every interval (ray_marcher.py:26-42)
+        float w_sum, wt_sum;
+        {
+            float carry = 1.f, acc_w = 0.f, acc_wt = 0.f;
+            for (int kb = 0; kb < n_all - 1; kb += 64) {
+                const int k = kb + lane;
+                const bool ok = k < n_all - 1;
+                float alpha = 0.f, tmid = 0.f;
+                if (ok) {
+                    const float t0 = L.s_t[k], t1 = L.s_t[k + 1];
+                    const float smid = softplus_march((L.s_sig[k] + L.s_sig[k + 1]) * 0.5f - 1.f);
+                    tmid = (t0 + t1) * 0.5f;
+                    alpha = 1.f - exp_hw(-(smid * (t1 - t0)));
+                }
+                const float x = ok ? (1.f - alpha + 1e-10f) : 1.f;
+                const float incl = wave_scan_mul(x, lane);
+                const float tr = wave_shift_up(incl, 1.f) * carry;
+                carry *= wave_last(incl);
+                if (ok) { const float wk = alpha * tr; L.w_s[k] = wk; L.trans[k] = tr; acc_w += wk; acc_wt += wk * tmid; }
+            }
+            w_sum = wave_sum(acc_w);
+            wt_sum = wave_sum(acc_wt);
+        }
+        lds_wave_sync();
+
+        // ---- 2. gradient of the composite.  With q_k = sum_c G[c] colour_k[c]:
+        //   dL/dw_k = (q_k + q_{k+1}) / 2 - [white_back] sum_c G[c] + g_depth (tmid_k - depth) / W + g_wsum
+        //   dL/dalpha_k = dL/dw_k T_k - (sum_{m>k} dL/dw_m w_m) / (1 - alpha_k + 1e-10)
+        const float depth = wt_sum / w_sum;
+        const float gd_scale = (w_sum > 0.f && depth == depth) ? g_depth / w_sum : 0.f;     // nan_to_num'd rays pass no depth gradient
+        const float gw_const = g_wsum - (p.white_back ? g_sum : 0.f);
+        const int n_int = n_all - 1;
+        float carry = 0.f;
+        for (int kb = 0; kb < n_int; kb += 64) {               // walk the intervals from the far end: suffix sums are prefix sums here
+            const int k = n_int - 1 - (kb + lane);
+            const bool ok = k >= 0;
+            float gw = 0.f, wk = 0.f, t0 = 0.f, t1 = 0.f, smid_in = 0.f;
+            if (ok) {
+                t0 = L.s_t[k]; t1 = L.s_t[k + 1];
+                smid_in = (L.s_sig[k] + L.s_sig[k + 1]) * 0.5f - 1.f;
+                wk = L.w_s[k];
+                gw = (L.s_q[k] + L.s_q[k + 1]) * 0.5f + gw_const + gd_scale * ((t0 + t1) * 0.5f - depth);
+            }
+            const float incl = wave_scan_add(gw * wk, lane) + carry;
+            carry = wave_last(incl);
+            if (ok) {
+                const float after = incl - gw * wk;                      // sum over m > k
+                const float delta = t1 - t0;
+                const float dens = softplus_march(smid_in);
+                const float one_minus_alpha = exp_hw(-(dens * delta));
+                const float alpha = 1.f - one_minus_alpha;
+                const float d_alpha = gw * L.trans[k] - after / (1.f - alpha + 1e-10f);
+                const float d_dens = d_alpha * delta * one_minus_alpha;
+                const float e = exp_hw(-smid_in);
+                const float d_smid = smid_in > 20.f ? d_dens : d_dens * __builtin_amdgcn_rcpf(1.f + e);      // softplus' = sigmoid
+                L.ds[k] = d_smid;
+            }
+        }
+        lds_wave_sync();
+        for (int q = lane; q < n_all; q += 64) {
+            const int e = q < S ? q : fine_e0 + (q - S);
+            const int r = L.rank_e[e];
+            const float wl = r > 0 ? L.w_s[r - 1] : 0.f, wr = r < n_int ? L.w_s[r] : 0.f;
+            const float dl = r > 0 ? L.ds[r - 1] : 0.f, dr = r < n_int ? L.ds[r] : 0.f;
+            L.v_e[e] = (wl + wr) * 0.5f;                 // colour of sample r enters intervals r-1 and r with weight 1/2 each
+            L.dsig_e[e] = (dl + dr) * 0.5f;              // so does its density
+        }
+        lds_wave_sync();
+
+        // ---- 3. decoder + lookup gradients
+        bwd_backward_tiles(P, L, R, grad_planes_item, 0, S, P.tiles_c, G, A, lane);
+        if (F > 0) bwd_backward_tiles(P, L, R, grad_planes_item, fine_e0, F, P.tiles_f, G, A, lane);
+    }
+
+    // ---- decoder gradients: wave registers -> workgroup LDS -> global atomics
+    if (!Gr.grad_w1) return;
+    __syncthreads();                                   // every wave is done with the LDS decoder
+    float* red = smem;
+    float* red_w1 = red, *red_b1 = red_w1 + 64 * 32, *red_w2 = red_b1 + 64, *red_b2 = red_w2 + 33 * 64;
+    for (int i = tid; i < kBwdGradFloats; i += kBwdThreads) red[i] = 0.f;
+    __syncthreads();
+    {
+        const int g = lane >> 4;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int hid = 16 * m + 4 * g + r;
+                atomicAdd(red_w1 + hid * 32 + j, A.w1[m][0][r]);
+                atomicAdd(red_w1 + hid * 32 + 16 + j, A.w1[m][1][r]);
+                const float s0 = row_total(A.w2s[m][r]), s1 = row_total(A.b1[m][r]);
+                if (j == 15) { atomicAdd(red_w2 + hid, s0); atomicAdd(red_b1 + hid, s1); }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) atomicAdd(red_w2 + (1 + 16 * o + 4 * g + r) * 64 + 16 * n + j, A.w2[o][n][r]);
+            }
+            float s = A.b2[o];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (g == 0) atomicAdd(red_b2 + 1 + 16 * o + j, s);
+        }
+        const float s = wave_sum(A.b2s);
+        if (lane == 0) atomicAdd(red_b2, s);
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * 32; i += kBwdThreads) unsafeAtomicAdd(Gr.grad_w1 + i, red_w1[i]);
+    for (int i = tid; i < 33 * 64; i += kBwdThreads) unsafeAtomicAdd(Gr.grad_w2 + i, red_w2[i]);
+    if (tid < 64) unsafeAtomicAdd(Gr.grad_b1 + tid, red_b1[tid]);
+    if (tid < 33) unsafeAtomicAdd(Gr.grad_b2 + tid, red_b2[tid]);
+}

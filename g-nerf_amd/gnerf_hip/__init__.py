@@ -46,6 +46,15 @@ class RenderParams(ctypes.Structure):
     ]
 
 
+class RenderGrads(ctypes.Structure):
+    """struct gnerf_render_grads (include/gnerf_hip.h)."""
+    _fields_ = [
+        ('grad_rgb', _c_p), ('grad_depth', _c_p), ('grad_wsum', _c_p),
+        ('grad_planes_nhwc', _c_p),
+        ('grad_w1', _c_p), ('grad_b1', _c_p), ('grad_w2', _c_p), ('grad_b2', _c_p),
+    ]
+
+
 # name -> (restype, argtypes); must list every function include/gnerf_hip.h declares (tests check this).
 SIGNATURES = {
     'gnerf_abi_version': (_c_i, []),
@@ -60,6 +69,7 @@ SIGNATURES = {
     'gnerf_make_rays': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_p, _c_p, _c_p]),
     'gnerf_render_workspace_bytes': (ctypes.c_size_t, []),
     'gnerf_render_forward': (_c_i, [ctypes.POINTER(RenderParams), _c_p]),
+    'gnerf_render_backward': (_c_i, [ctypes.POINTER(RenderParams), ctypes.POINTER(RenderGrads), _c_p]),
     'gnerf_query_points': (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
 }
 
@@ -249,12 +259,11 @@ def _workspace(device):
     return ws
 
 
-def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine, *,
+def _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine,
                    depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
-                   white_back=False, disparity_space_sampling=False, image_width=0, debug=False):
-    """planes_nhwc [3N,H,W,32]; decoder = (w1,b1,w2,b2) effective fp32 weights; rays [N,M,3];
-    noise_coarse [N*M,S]; noise_fine [N*M,F] or None; ray_start/ray_end floats or [N*M] tensors.
-    Returns (rgb [N,M,32], depth [N,M,1], wsum [N,M,1][, debug [N*M,8,S+F]])."""
+                   white_back, disparity_space_sampling, image_width, what):
+    """Validate the arguments shared by render_forward / render_backward and fill a RenderParams.
+    Returns (params, keepalive, rays_per_item); `keepalive` holds the converted tensors the pointers refer to."""
     w1, b1, w2, b2 = decoder
     _require_cuda(planes_nhwc, ray_origins, ray_dirs, noise_coarse, noise_fine, w1, b1, w2, b2)
     dev = planes_nhwc.device
@@ -262,39 +271,34 @@ def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
     def f32c(t):
         return t.to(torch.float32).contiguous()
     if planes_nhwc.dtype != torch.float32 or not planes_nhwc.is_contiguous() or planes_nhwc.ndim != 4 or planes_nhwc.shape[3] != 32:
-        raise RuntimeError('render_forward: planes_nhwc must be contiguous float32 [3N,H,W,32]')
+        raise RuntimeError(f'{what}: planes_nhwc must be contiguous float32 [3N,H,W,32]')
     if planes_nhwc.shape[0] != 3 * n_items:
-        raise RuntimeError('render_forward: planes_nhwc must hold 3 planes per item')
+        raise RuntimeError(f'{what}: planes_nhwc must hold 3 planes per item')
     if tuple(w1.shape) != (64, 32) or tuple(b1.shape) != (64,) or tuple(w2.shape) != (33, 64) or tuple(b2.shape) != (33,):
-        raise RuntimeError('render_forward: decoder must be the 32->64->33 OSGDecoder MLP')
+        raise RuntimeError(f'{what}: decoder must be the 32->64->33 OSGDecoder MLP')
     o, d = f32c(ray_origins), f32c(ray_dirs)
     if o.shape != d.shape or o.ndim != 3 or o.shape[0] != n_items or o.shape[2] != 3:
-        raise RuntimeError('render_forward: rays must be [N,M,3]')
+        raise RuntimeError(f'{what}: rays must be [N,M,3]')
     m = o.shape[1]
     S, F = int(depth_resolution), int(depth_resolution_importance)
     nc = f32c(noise_coarse)
     if nc.numel() != n_items * m * S:
-        raise RuntimeError('render_forward: noise_coarse must have N*M*S elements')
+        raise RuntimeError(f'{what}: noise_coarse must have N*M*S elements')
     nf = None
     if F > 0:
         if noise_fine is None:
-            raise RuntimeError('render_forward: noise_fine required when depth_resolution_importance > 0')
+            raise RuntimeError(f'{what}: noise_fine required when depth_resolution_importance > 0')
         nf = f32c(noise_fine)
         if nf.numel() != n_items * m * F:
-            raise RuntimeError('render_forward: noise_fine must have N*M*F elements')
+            raise RuntimeError(f'{what}: noise_fine must have N*M*F elements')
     w1, b1, w2, b2 = f32c(w1), f32c(b1), f32c(w2), f32c(b2)
     rs_t = re_t = None
     if isinstance(ray_start, torch.Tensor) or isinstance(ray_end, torch.Tensor):
         rs_t = f32c(torch.as_tensor(ray_start, device=dev).expand(n_items, m, 1) if not isinstance(ray_start, torch.Tensor) else ray_start).reshape(-1)
         re_t = f32c(torch.as_tensor(ray_end, device=dev).expand(n_items, m, 1) if not isinstance(ray_end, torch.Tensor) else ray_end).reshape(-1)
         if rs_t.numel() != n_items * m or re_t.numel() != n_items * m:
-            raise RuntimeError('render_forward: per-ray ray_start / ray_end must have N*M elements')
+            raise RuntimeError(f'{what}: per-ray ray_start / ray_end must have N*M elements')
         ray_start = ray_end = 0.0
-    rgb = torch.empty([n_items, m, 32], dtype=torch.float32, device=dev)
-    depth = torch.empty([n_items, m, 1], dtype=torch.float32, device=dev)
-    wsum = torch.empty([n_items, m, 1], dtype=torch.float32, device=dev)
-    dbg = torch.zeros([n_items * m, DEBUG_SLOTS, S + F], dtype=torch.float32, device=dev) if debug else None
-    ws = _workspace(dev)
     p = RenderParams()
     p.planes_nhwc = planes_nhwc.data_ptr(); p.n_items = n_items; p.plane_h = planes_nhwc.shape[1]; p.plane_w = planes_nhwc.shape[2]
     p.ray_origins = o.data_ptr(); p.ray_dirs = d.data_ptr(); p.rays_per_item = m; p.image_width = int(image_width)
@@ -305,14 +309,67 @@ def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
     p.ray_end_per_ray = None if re_t is None else re_t.data_ptr()
     p.box_warp = float(box_warp); p.white_back = int(bool(white_back)); p.disparity_space_sampling = int(bool(disparity_space_sampling))
     p.noise_coarse = nc.data_ptr(); p.noise_fine = None if nf is None else nf.data_ptr()
+    return p, (planes_nhwc, o, d, nc, nf, w1, b1, w2, b2, rs_t, re_t), m
+
+
+def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine, *,
+                   depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
+                   white_back=False, disparity_space_sampling=False, image_width=0, debug=False):
+    """planes_nhwc [3N,H,W,32]; decoder = (w1,b1,w2,b2) effective fp32 weights; rays [N,M,3];
+    noise_coarse [N*M,S]; noise_fine [N*M,F] or None; ray_start/ray_end floats or [N*M] tensors.
+    Returns (rgb [N,M,32], depth [N,M,1], wsum [N,M,1][, debug [N*M,8,S+F]])."""
+    p, keep, m = _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine,
+                                depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
+                                white_back, disparity_space_sampling, image_width, 'render_forward')
+    dev = planes_nhwc.device
+    rgb = torch.empty([n_items, m, 32], dtype=torch.float32, device=dev)
+    depth = torch.empty([n_items, m, 1], dtype=torch.float32, device=dev)
+    wsum = torch.empty([n_items, m, 1], dtype=torch.float32, device=dev)
+    dbg = torch.zeros([n_items * m, DEBUG_SLOTS, p.depth_resolution + p.depth_resolution_importance], dtype=torch.float32, device=dev) if debug else None
+    ws = _workspace(dev)
     p.out_rgb, p.out_depth, p.out_wsum = rgb.data_ptr(), depth.data_ptr(), wsum.data_ptr()
     p.workspace = ws.data_ptr(); p.debug = None if dbg is None else dbg.data_ptr()
     with torch.cuda.device(dev):
         code = load().gnerf_render_forward(ctypes.byref(p), _stream(planes_nhwc))
     _check(code, 'gnerf_render_forward')
+    del keep
     if debug:
         return rgb, depth, wsum, dbg
     return rgb, depth, wsum
+
+
+def render_backward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine, grad_rgb, grad_depth, grad_wsum, *,
+                    depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
+                    white_back=False, disparity_space_sampling=False, image_width=0, need_planes=True, need_decoder=True):
+    """Gradient of render_forward for the same arguments (the forward pass is recomputed inside the kernel).
+    grad_rgb [N,M,32], grad_depth [N,M,1], grad_wsum [N,M,1]; any of them may be None (zeros).
+    Returns (grad_planes_nhwc [3N,H,W,32] or None, (grad_w1, grad_b1, grad_w2, grad_b2) or None), all float32."""
+    p, keep, m = _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine,
+                                depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
+                                white_back, disparity_space_sampling, image_width, 'render_backward')
+    dev = planes_nhwc.device
+    _require_cuda(grad_rgb, grad_depth, grad_wsum)
+    grads_in = []
+    for t, n in ((grad_rgb, 32), (grad_depth, 1), (grad_wsum, 1)):
+        if t is not None:
+            t = t.to(torch.float32).contiguous()
+            if t.numel() != n_items * m * n:
+                raise RuntimeError('render_backward: output gradients must match the forward outputs')
+        grads_in.append(t)
+    g = RenderGrads()
+    g.grad_rgb, g.grad_depth, g.grad_wsum = [None if t is None else t.data_ptr() for t in grads_in]
+    g_planes = torch.zeros_like(planes_nhwc) if need_planes else None
+    g_dec = None
+    if need_decoder:
+        g_dec = (torch.zeros([64, 32], dtype=torch.float32, device=dev), torch.zeros([64], dtype=torch.float32, device=dev),
+                 torch.zeros([33, 64], dtype=torch.float32, device=dev), torch.zeros([33], dtype=torch.float32, device=dev))
+        g.grad_w1, g.grad_b1, g.grad_w2, g.grad_b2 = [t.data_ptr() for t in g_dec]
+    g.grad_planes_nhwc = None if g_planes is None else g_planes.data_ptr()
+    with torch.cuda.device(dev):
+        code = load().gnerf_render_backward(ctypes.byref(p), ctypes.byref(g), _stream(planes_nhwc))
+    _check(code, 'gnerf_render_backward')
+    del keep, grads_in
+    return g_planes, g_dec
 
 
 def query_points(planes_nhwc, n_items, decoder, points, box_warp):

@@ -155,6 +155,26 @@ typedef struct gnerf_render_params {
 size_t gnerf_render_workspace_bytes(void);
 int    gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t stream);
 
+/* Gradient of the renderer: what autograd computes upstream by walking the graph of
+ * renderer.py:88-140 backwards (grid_sample_gradfix.py's backward op for the planes, the decoder's
+ * linear layers, ray_marcher.py's composite).  The forward pass is recomputed per ray from the same
+ * params (same noise), nothing is saved between the two calls.  Importance depths are constants, as
+ * upstream (renderer.py:198 no_grad / :211 detach); rays and noise get no gradient.
+ * All output buffers are ACCUMULATED into (the caller zeroes them, or keeps summing across calls). */
+typedef struct gnerf_render_grads {
+    const float* grad_rgb;      /* [n_items, rays_per_item, 32] or NULL (= zeros) */
+    const float* grad_depth;    /* [n_items, rays_per_item, 1]  or NULL */
+    const float* grad_wsum;     /* [n_items, rays_per_item, 1]  or NULL */
+    float* grad_planes_nhwc;    /* [n_items*3, plane_h, plane_w, 32] or NULL (skip) */
+    float* grad_w1;             /* [64,32]; the four decoder gradients are given together or all NULL */
+    float* grad_b1;             /* [64] */
+    float* grad_w2;             /* [33,64] */
+    float* grad_b2;             /* [33] */
+} gnerf_render_grads;
+
+/* p: the forward call's params (outputs, workspace and debug are ignored). */
+int gnerf_render_backward(const gnerf_render_params* p, const gnerf_render_grads* g, gnerf_stream_t stream);
+
 /* Density / colour of arbitrary points (run_model, renderer.py:142-148; used by
  * TriPlaneGenerator.sample / sample_mixed for shape extraction):
  * points [n_items, n_points, 3] -> sigma [n_items, n_points, 1], rgb [n_items, n_points, 32]. */

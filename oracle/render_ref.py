@@ -295,7 +295,7 @@ def render(planes, decoder, origins, dirs, options, noise_c, noise_f, stages=Non
         stages.update(depths_coarse=depths_c, sigma_coarse=sig_c, colors_coarse=col_c)
     if F > 0:
         w_c, _ = march_weights(sig_c, depths_c)                              # renderer.py:118
-        depths_f = importance_depths(depths_c, w_c, noise_f.reshape(R, F))
+        depths_f = importance_depths(depths_c, w_c, noise_f.reshape(R, F)).detach()    # renderer.py:198 no_grad, :211 detach
         sig_f, col_f = shade(depths_f)
         all_d = torch.cat([depths_c, depths_f], 1)                           # renderer.py:157-167
         all_d, order = torch.sort(all_d, dim=1, stable=True)
