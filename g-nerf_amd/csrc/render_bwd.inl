@@ -47,12 +47,49 @@ __device__ __forceinline__ float row_total(float v) {
     return v;
 }
 
+#ifdef GNERF_ABLATE_ATOMIC       // timing-only build: plain stores instead of atomics (wrong results)
+#define GNERF_SCATTER_ADD(ptr, val) (*(ptr) = (val))
+#else
+#define GNERF_SCATTER_ADD(ptr, val) unsafeAtomicAdd(ptr, val)
+#endif
+
 struct BwdRay { float ox, oy, oz, dx, dy, dz; const char* planes; };
 
+// A tile's plane-gradient scatter that has not been issued yet: dX[16][32] sits in tbuf, its tap records in taps.
+// It is issued from inside the NEXT tile's lookup, after that tile's texel loads: the wave then waits only for the
+// loads, and the atomics drain while the next tile's MLP runs.  (Issued right after dX is produced, the next lookup's
+// s_waitcnt vmcnt would wait for every atomic to be acknowledged by L2 first: atomic and compute time simply add up.)
+struct BwdPending { float* base; int live; };
+
+// One sixth of a pending scatter: samples 8a..8a+7 of plane pl; lane = (sample parity, channel).
+__device__ __forceinline__ void bwd_scatter_chunk(const BwdLds& L, const BwdPending& pd, int a, int pl, int lane) {
+    const int half = lane >> 5, ch = lane & 31;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int smp = 8 * a + 2 * q + half;
+        const float val = smp < pd.live ? L.tbuf[smp * kTPitch + ch] : 0.f;
+        if (val != 0.f) {                   // exact zeros (padding, samples behind an opaque surface) cost no atomic
+            const float* rec = L.taps + smp * kTapDwords + pl * 8;
+            const uint4 off = *reinterpret_cast<const uint4*>(rec);
+            const v4f wgt = *reinterpret_cast<const v4f*>(rec + 4);
+            if (wgt[0] != 0.f) GNERF_SCATTER_ADD(pd.base + (off.x >> 2) + ch, val * wgt[0]);
+            if (wgt[1] != 0.f) GNERF_SCATTER_ADD(pd.base + (off.y >> 2) + ch, val * wgt[1]);
+            if (wgt[2] != 0.f) GNERF_SCATTER_ADD(pd.base + (off.z >> 2) + ch, val * wgt[2]);
+            if (wgt[3] != 0.f) GNERF_SCATTER_ADD(pd.base + (off.w >> 2) + ch, val * wgt[3]);
+        }
+    }
+}
+
 // Tap records of the 16 samples of a tile (lanes 0..47: sample = lane & 15, plane = lane >> 4), then the lookup:
-// 8 lanes per texel, 8 samples per step, blended features staged as X[sample][channel].
-__device__ __forceinline__ void bwd_gather_tile(const Params& P, const BwdLds& L, const BwdRay& R, const float* t_list, int count, int tile, int lane) {
+// 8 lanes per texel, 8 samples per step, blended features staged as X[sample][channel].  The records travel through
+// hbuf (free between tiles) because `taps` may still hold the pending scatter's records; with KEEP_TAPS they are
+// written to `taps` once the pending scatter has been issued.
+template <bool KEEP_TAPS>
+__device__ __forceinline__ void bwd_gather_tile(const Params& P, const BwdLds& L, const BwdRay& R, const float* t_list, int count, int tile,
+                                                BwdPending& pend, int lane) {
     const int H = P.p.plane_h, W = P.p.plane_w;
+    uint4 my_off = make_uint4(0, 0, 0, 0);
+    v4f my_wgt = {0.f, 0.f, 0.f, 0.f};
     if (lane < 48) {
         const int j = lane & 15, pl = lane >> 4;
         const int idx = min(16 * tile + j, count - 1);
@@ -62,11 +99,10 @@ __device__ __forceinline__ void bwd_gather_tile(const Params& P, const BwdLds& L
         const float pz = __fadd_rn(R.oz, __fmul_rn(depth, R.dz)) * P.box_scale;
         const float u = pl == 2 ? pz : px;
         const float v = pl == 0 ? py : (pl == 1 ? pz : px);
-        uint4 off; v4f wgt;
-        plane_taps(H, W, u, v, unsigned(pl) * unsigned(H) * unsigned(W) * 128u, off, wgt);
-        float* rec = L.taps + j * kTapDwords + pl * 8;
-        *reinterpret_cast<uint4*>(rec) = off;
-        *reinterpret_cast<v4f*>(rec + 4) = wgt;
+        plane_taps(H, W, u, v, unsigned(pl) * unsigned(H) * unsigned(W) * 128u, my_off, my_wgt);
+        float* rec = L.hbuf + j * kTapDwords + pl * 8;
+        *reinterpret_cast<uint4*>(rec) = my_off;
+        *reinterpret_cast<v4f*>(rec + 4) = my_wgt;
     }
     lds_wave_sync();
     const int b = lane >> 3, cq16 = (lane & 7) * 16;
@@ -76,16 +112,23 @@ __device__ __forceinline__ void bwd_gather_tile(const Params& P, const BwdLds& L
         v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int pl = 0; pl < 3; pl++) {
-            const float* rec = L.taps + js * kTapDwords + pl * 8;
+            const float* rec = L.hbuf + js * kTapDwords + pl * 8;
             const uint4 off = *reinterpret_cast<const uint4*>(rec);
             const v4f wgt = *reinterpret_cast<const v4f*>(rec + 4);
             const v4f t00 = *reinterpret_cast<const v4f*>(R.planes + off.x + cq16);
             const v4f t01 = *reinterpret_cast<const v4f*>(R.planes + off.y + cq16);
             const v4f t10 = *reinterpret_cast<const v4f*>(R.planes + off.z + cq16);
             const v4f t11 = *reinterpret_cast<const v4f*>(R.planes + off.w + cq16);
+            if (pend.live > 0) bwd_scatter_chunk(L, pend, a, pl, lane);
             acc += t00 * wgt[0] + t01 * wgt[1] + t10 * wgt[2] + t11 * wgt[3];
         }
         *reinterpret_cast<v4f*>(L.stage + js * kStagePitch + (cq16 >> 2)) = acc;
+    }
+    pend.live = 0;
+    if (KEEP_TAPS && lane < 48) {
+        float* rec = L.taps + (lane & 15) * kTapDwords + (lane >> 4) * 8;
+        *reinterpret_cast<uint4*>(rec) = my_off;
+        *reinterpret_cast<v4f*>(rec + 4) = my_wgt;
     }
     lds_wave_sync();
 }
@@ -136,10 +179,10 @@ __device__ __forceinline__ void bwd_mlp_forward(const BwdLds& L, int lane, v4f (
 // Forward-only walk of `ntiles` tiles: densities -> sig_e[e0...], q -> q_e[e0...].
 // G[n] = dL/d(colour sum) of channel 16n + (lane & 15), i.e. 2 * grad_rgb.
 __device__ __forceinline__ void bwd_forward_tiles(const Params& P, const BwdLds& L, const BwdRay& R, int e0, int count, int ntiles,
-                                                  const float (&G)[2], int lane) {
+                                                  const float (&G)[2], BwdPending& pend, int lane) {
     const int j = lane & 15, g = lane >> 4;
     for (int t = 0; t < ntiles; t++) {
-        bwd_gather_tile(P, L, R, L.t_e + e0, count, t, lane);
+        bwd_gather_tile<false>(P, L, R, L.t_e + e0, count, t, pend, lane);
         v4f h[4], o[2];
         float sig;
         bwd_mlp_forward(L, lane, h, o, sig);
@@ -163,10 +206,16 @@ struct BwdAcc {
 };
 
 __device__ __forceinline__ void bwd_backward_tiles(const Params& P, const BwdLds& L, const BwdRay& R, float* grad_planes_item,
-                                                   int e0, int count, int ntiles, const float (&G)[2], BwdAcc& A, int lane) {
+                                                   int e0, int count, int ntiles, const float (&G)[2], BwdAcc& A, BwdPending& pend, int lane) {
     const int j = lane & 15, g = lane >> 4;
     for (int t = 0; t < ntiles; t++) {
-        bwd_gather_tile(P, L, R, L.t_e + e0, count, t, lane);
+        bwd_gather_tile<true>(P, L, R, L.t_e + e0, count, t, pend, lane);
+#ifdef GNERF_ABLATE_BWDMLP      // timing-only build: lookup + scatter without the decoder's backward pass (wrong results)
+        for (int i = lane; i < 16 * kTPitch; i += 64) L.tbuf[i] = L.stage[i];
+        if (grad_planes_item) { pend.base = grad_planes_item; pend.live = min(16, count - 16 * t); }
+        lds_wave_sync();
+        continue;
+#endif
         v4f h[4], o[2];
         float sig;
         bwd_mlp_forward(L, lane, h, o, sig);
@@ -249,28 +298,8 @@ __device__ __forceinline__ void bwd_backward_tiles(const Params& P, const BwdLds
                 A.w1[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap, b1, A.w1[m][1], 0, 0, 0);
             }
         }
-        // ---- scatter dX into the plane gradient: lane = (sample parity, channel), 12 taps per sample
-        if (grad_planes_item) {
-            const int half = lane >> 5, ch = lane & 31;
-            const int live = min(16, count - 16 * t);
-#pragma unroll 2
-            for (int pstep = 0; pstep < 8; pstep++) {
-                const int smp = 2 * pstep + half;
-                if (smp < live) {
-                    const float val = L.tbuf[smp * kTPitch + ch];
-#pragma unroll
-                    for (int pl = 0; pl < 3; pl++) {
-                        const float* rec = L.taps + smp * kTapDwords + pl * 8;
-                        const uint4 off = *reinterpret_cast<const uint4*>(rec);
-                        const v4f wgt = *reinterpret_cast<const v4f*>(rec + 4);
-                        if (wgt[0] != 0.f) unsafeAtomicAdd(grad_planes_item + (off.x >> 2) + ch, val * wgt[0]);
-                        if (wgt[1] != 0.f) unsafeAtomicAdd(grad_planes_item + (off.y >> 2) + ch, val * wgt[1]);
-                        if (wgt[2] != 0.f) unsafeAtomicAdd(grad_planes_item + (off.z >> 2) + ch, val * wgt[2]);
-                        if (wgt[3] != 0.f) unsafeAtomicAdd(grad_planes_item + (off.w >> 2) + ch, val * wgt[3]);
-                    }
-                }
-            }
-        }
+        // ---- dX goes to the plane gradient from inside the next lookup (see BwdPending)
+        if (grad_planes_item) { pend.base = grad_planes_item; pend.live = min(16, count - 16 * t); }
         lds_wave_sync();
     }
 }
@@ -310,6 +339,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gn
         A.w1[m][0] = A.w1[m][1] = A.w2[0][m] = A.w2[1][m] = A.w2s[m] = A.b1[m] = (v4f){0.f, 0.f, 0.f, 0.f};
     }
     A.b2[0] = A.b2[1] = A.b2s = 0.f;
+    BwdPending pend = {nullptr, 0};
 
     // ray tiles: workgroup `blk` owns tiles 4*blk .. 4*blk+3 (one per wave); XCD-contiguous like the forward kernels
     const int n_blocks = (P.n_tiles + kBwdWaves - 1) / kBwdWaves;
@@ -348,13 +378,13 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gn
         for (int k = lane; k < S; k += 64) L.t_e[k] = coarse_depth(P, ray, k);
         for (int k = lane; k < s_pad; k += 64) { L.v_e[k] = 0.f; L.dsig_e[k] = 0.f; L.q_e[k] = 0.f; }
         lds_wave_sync();
-        bwd_forward_tiles(P, L, R, 0, S, P.tiles_c, G, lane);
+        bwd_forward_tiles(P, L, R, 0, S, P.tiles_c, G, pend, lane);
         if (F > 0) {
             float w_sum, wt_sum;
             march(L.t_e, L.sig_e, L.w_s, S, lane, w_sum, wt_sum);
             lds_wave_sync();
             resample_fine(P, ray, L.t_e, L.w_s, L.s_sig, L.trans, L.t_e + fine_e0, nullptr, n_all, lane, [] { lds_wave_sync(); });
-            bwd_forward_tiles(P, L, R, fine_e0, F, P.tiles_f, G, lane);
+            bwd_forward_tiles(P, L, R, fine_e0, F, P.tiles_f, G, pend, lane);
             merge_by_depth(L.t_e, L.sig_e, L.rank_e, L.s_t, L.s_sig, S, F, fine_e0, lane);
         } else {
             for (int k = lane; k < S; k += 64) { L.rank_e[k] = k; L.s_t[k] = L.t_e[k]; L.s_sig[k] = L.sig_e[k]; }
@@ -434,8 +464,14 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gn
         lds_wave_sync();
 
         // ---- 3. decoder + lookup gradients
-        bwd_backward_tiles(P, L, R, grad_planes_item, 0, S, P.tiles_c, G, A, lane);
-        if (F > 0) bwd_backward_tiles(P, L, R, grad_planes_item, fine_e0, F, P.tiles_f, G, A, lane);
+        bwd_backward_tiles(P, L, R, grad_planes_item, 0, S, P.tiles_c, G, A, pend, lane);
+        if (F > 0) bwd_backward_tiles(P, L, R, grad_planes_item, fine_e0, F, P.tiles_f, G, A, pend, lane);
+    }
+    if (pend.live > 0) {                               // the last tile's scatter has no next lookup to hide in
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) bwd_scatter_chunk(L, pend, a, pl, lane);
     }
 
     // ---- decoder gradients: wave registers -> workgroup LDS -> global atomics

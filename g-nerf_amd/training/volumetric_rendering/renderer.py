@@ -8,10 +8,15 @@ kernel (csrc/render.hip through gnerf_hip.render_forward).  The random draws are
 torch, in the reference's order and shapes (rand_like([N,M,S,1]) then rand(N*M, F)), so a seeded
 run consumes the generator exactly like the reference and produces the same image.
 
+When autograd needs the gradient of the planes and/or the decoder (training), the same kernel runs
+inside an autograd.Function whose backward is the second kernel (gnerf_hip.render_backward): it
+recomputes the ray's forward pass and keeps nothing between the passes, where upstream autograd saves
+every intermediate of the op chain (~3 GB at the training shape).
+
 The PyTorch-op form below is what runs for CPU tensors (the reference's own behaviour: all of its
-renderer is PyTorch ops), when autograd needs a graph (the backward kernel is the next milestone),
-or when `decoder` is not the OSGDecoder 32->64->33 MLP.  A GPU call never silently degrades because
-the native library is absent: gnerf_hip raises.
+renderer is PyTorch ops), when the rays themselves need a gradient, or when `decoder` is not the
+OSGDecoder 32->64->33 MLP.  A GPU call never silently degrades because the native library is absent:
+gnerf_hip raises.
 """
 
 import math
@@ -83,6 +88,56 @@ def _osg_decoder_weights(decoder):
     return fc1, fc2
 
 
+class _FusedRender(torch.autograd.Function):
+    """render_forward / render_backward as one differentiable op.  Inputs with a gradient: planes [N,3,32,H,W] and the
+    decoder's effective weights; everything else is constant (importance depths are constants upstream as well,
+    renderer.py:198/211).  `cfg` is the dict of static keyword arguments of gnerf_hip.render_forward."""
+
+    @staticmethod
+    def forward(ctx, planes, w1, b1, w2, b2, ray_origins, ray_dirs, noise_c, noise_f, ray_start, ray_end, cfg):
+        N = planes.shape[0]
+        nhwc = gnerf_hip.planes_to_nhwc(planes.detach().float())
+        out = gnerf_hip.render_forward(nhwc, N, (w1, b1, w2, b2), ray_origins, ray_dirs, noise_c, noise_f,
+                                       ray_start=ray_start, ray_end=ray_end, **cfg)
+        tensors = [planes, w1, b1, w2, b2, ray_origins, ray_dirs, noise_c]
+        ctx.has_fine = noise_f is not None
+        ctx.limits_are_tensors = isinstance(ray_start, torch.Tensor)
+        if ctx.has_fine:
+            tensors.append(noise_f)
+        if ctx.limits_are_tensors:
+            tensors += [ray_start, ray_end]
+        else:
+            ctx.limits = (ray_start, ray_end)
+        ctx.save_for_backward(*tensors)       # the NHWC repack is redone in backward (30 us) rather than held (100 MB)
+        ctx.cfg = cfg
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_rgb, g_depth, g_wsum):
+        saved = list(ctx.saved_tensors)
+        planes, w1, b1, w2, b2, ray_origins, ray_dirs, noise_c = saved[:8]
+        rest = saved[8:]
+        noise_f = rest.pop(0) if ctx.has_fine else None
+        ray_start, ray_end = (rest[0], rest[1]) if ctx.limits_are_tensors else ctx.limits
+        need_planes = ctx.needs_input_grad[0]
+        need_decoder = any(ctx.needs_input_grad[1:5])
+        N = planes.shape[0]
+        nhwc = gnerf_hip.planes_to_nhwc(planes.detach().float())
+        g_planes, g_dec = gnerf_hip.render_backward(nhwc, N, (w1, b1, w2, b2), ray_origins, ray_dirs, noise_c, noise_f, g_rgb, g_depth, g_wsum,
+                                                    ray_start=ray_start, ray_end=ray_end, need_planes=need_planes, need_decoder=need_decoder,
+                                                    **ctx.cfg)
+        grads = [None] * 12
+        if need_planes:
+            H, W = planes.shape[3], planes.shape[4]
+            grads[0] = g_planes.view(N, 3, H, W, 32).permute(0, 1, 4, 2, 3).to(planes.dtype)      # a view: NCHW indexing over NHWC storage
+        if need_decoder:
+            for i, (g, t) in enumerate(zip(g_dec, (w1, b1, w2, b2))):
+                if ctx.needs_input_grad[1 + i]:
+                    grads[1 + i] = g.to(t.dtype)
+        return tuple(grads)
+
+
 class ImportanceRenderer(torch.nn.Module):
     def __init__(self):
         super().__init__()
@@ -98,12 +153,11 @@ class ImportanceRenderer(torch.nn.Module):
         self.plane_axes = self.plane_axes.to(ray_origins.device)
         if planes.device.type == 'cuda':
             fcs = _osg_decoder_weights(decoder)
-            needs_graph = torch.is_grad_enabled() and (
-                planes.requires_grad or ray_origins.requires_grad or ray_directions.requires_grad
-                or any(p.requires_grad for p in decoder.parameters()))
-            if fcs is not None and not needs_graph and planes.ndim == 5 and planes.shape[1] == 3 and planes.shape[2] == 32 \
+            rays_need_grad = torch.is_grad_enabled() and (ray_origins.requires_grad or ray_directions.requires_grad)
+            if fcs is not None and not rays_need_grad and planes.ndim == 5 and planes.shape[1] == 3 and planes.shape[2] == 32 \
                     and rendering_options.get('density_noise', 0) == 0:
-                return self._forward_hip(planes, fcs, ray_origins, ray_directions, rendering_options)
+                needs_graph = torch.is_grad_enabled() and (planes.requires_grad or any(p.requires_grad for p in decoder.parameters()))
+                return self._forward_hip(planes, fcs, ray_origins, ray_directions, rendering_options, differentiable=needs_graph)
             if fcs is None:
                 warnings.warn('ImportanceRenderer: decoder is not the OSGDecoder MLP; using PyTorch ops', RuntimeWarning)
         return self._forward_torch(planes, decoder, ray_origins, ray_directions, rendering_options)
@@ -136,7 +190,7 @@ class ImportanceRenderer(torch.nn.Module):
         self.__dict__['_gnerf_planes_cache'] = (weakref.ref(base), base._version, planes.data_ptr(), tuple(planes.shape), nhwc)
         return nhwc
 
-    def _forward_hip(self, planes, fcs, ray_origins, ray_directions, opts):
+    def _forward_hip(self, planes, fcs, ray_origins, ray_directions, opts, differentiable=False):
         N, M, _ = ray_origins.shape
         S = int(opts['depth_resolution'])
         F = int(opts['depth_resolution_importance'])
@@ -155,14 +209,19 @@ class ImportanceRenderer(torch.nn.Module):
         noise_c = torch.rand([N, M, S, 1], device=dev, dtype=torch.float32)
         noise_f = torch.rand(N * M, F, device=dev) if F > 0 else None
         side = math.isqrt(M)
-        rgb, depth, wsum = gnerf_hip.render_forward(
-            self._planes_nhwc(planes), N, self._decoder_cache(fcs), ray_origins.detach(), ray_directions.detach(), noise_c, noise_f,
-            depth_resolution=S, depth_resolution_importance=F, ray_start=ray_start, ray_end=ray_end, box_warp=opts['box_warp'],
-            white_back=bool(opts.get('white_back', False)), disparity_space_sampling=bool(opts.get('disparity_space_sampling', False)),
-            image_width=side if side * side == M else 0)
         if opts['clamp_mode'] != 'softplus':
             assert False, "MipRayMarcher only supports `clamp_mode`=`softplus`!"
-        return rgb, depth, wsum
+        cfg = dict(depth_resolution=S, depth_resolution_importance=F, box_warp=opts['box_warp'],
+                   white_back=bool(opts.get('white_back', False)), disparity_space_sampling=bool(opts.get('disparity_space_sampling', False)),
+                   image_width=side if side * side == M else 0)
+        if differentiable:
+            fc1, fc2 = fcs
+            eff = (fc1.weight.float() * fc1.weight_gain, fc1.bias.float() * fc1.bias_gain,          # networks_stylegan2.py:121-127
+                   fc2.weight.float() * fc2.weight_gain, fc2.bias.float() * fc2.bias_gain)
+            return _FusedRender.apply(planes, *eff, ray_origins.detach(), ray_directions.detach(), noise_c.reshape(N * M, S), noise_f,
+                                      ray_start, ray_end, cfg)
+        return gnerf_hip.render_forward(self._planes_nhwc(planes), N, self._decoder_cache(fcs), ray_origins.detach(), ray_directions.detach(),
+                                        noise_c, noise_f, ray_start=ray_start, ray_end=ray_end, **cfg)
 
     # ------------------------------------------------------------------ PyTorch-op path
 

@@ -352,6 +352,54 @@ def test_render_backward_vs_oracle(dev, cfg):
     assert _rel(gp2.reshape(N, 3, *cfg['hw'], 32).permute(0, 1, 4, 2, 3).cpu(), ref_planes2) < 2e-3
 
 
+def _oracle_free_planes_grad(results, g_rgb, ren, dec, g, o, d, opts, dev):
+    """planes gradient of sum(rgb * g_rgb) through the PyTorch-op path, same seed."""
+    planes = _t(g['planes'], dev).requires_grad_(True)
+    torch.manual_seed(321)
+    out = ren._forward_torch(planes, dec, o, d, opts)
+    (out[0] * g_rgb).sum().backward()
+    return planes.grad
+
+
+@pytest.mark.parametrize('case', ['render_s48.npz', 'render_misc.npz'])
+def test_importance_renderer_training_step_on_gpu(dev, golden, case):
+    """Drop-in class with gradients enabled: the fused forward + backward kernels give the same outputs and the same
+    plane / decoder-parameter gradients as autograd through the PyTorch-op path (the reference's behaviour), for the same seed."""
+    from training.volumetric_rendering.renderer import ImportanceRenderer
+    from test_host_cpu import Decoder, options_of
+    g = golden(case)
+    ren = ImportanceRenderer().to(dev)
+    dec = Decoder(g).to(dev).requires_grad_(True)
+    o, d = _t(g['ray_origins'], dev), _t(g['ray_dirs'], dev)
+    opts = options_of(g)
+    gen = torch.Generator().manual_seed(3)
+    N, M = o.shape[:2]
+    g_rgb, g_depth, g_w = [torch.randn(N, M, c, generator=gen).to(dev) for c in (32, 1, 1)]
+    results = []
+    for fused in (True, False):
+        planes = _t(g['planes'], dev).requires_grad_(True)
+        dec.zero_grad(set_to_none=True)
+        torch.manual_seed(321)
+        out = ren(planes, dec, o, d, opts) if fused else ren._forward_torch(planes, dec, o, d, opts)
+        assert (out[0].grad_fn is not None)
+        if fused:
+            assert type(out[0].grad_fn).__name__.startswith('_FusedRender')         # proves the fused op is in the graph
+        ((out[0] * g_rgb).sum() + (out[1] * g_depth).sum() + (out[2] * g_w).sum()).backward()
+        results.append((out, planes.grad.clone(), [p.grad.clone() for p in dec.parameters()]))
+    (out_f, gp_f, gd_f), (out_r, gp_r, gd_r) = results
+    assert float(((out_f[0] - out_r[0]).detach() ** 2).mean()) < 1e-8
+    assert _rel(gp_f, gp_r) < 2e-3, _rel(gp_f, gp_r)
+    for a, b in zip(gd_f, gd_r):
+        assert _rel(a, b) < 2e-3, _rel(a, b)
+    # planes only (frozen decoder): decoder gradients are not computed and not returned
+    dec.requires_grad_(False)
+    planes = _t(g['planes'], dev).requires_grad_(True)
+    torch.manual_seed(321)
+    out = ren(planes, dec, o, d, opts)
+    (out[0] * g_rgb).sum().backward()
+    assert _rel(planes.grad, _oracle_free_planes_grad(results, g_rgb, ren, dec, g, o, d, opts, dev)) < 2e-3
+
+
 # ---------------------------------------------------------------------------- ops
 
 

@@ -33,11 +33,12 @@ def test_library_exports_every_declared_symbol():
     assert b'gfx950' in lib.gnerf_build_info()
 
 
-def test_render_params_struct_matches_header():
-    """Field order of the ctypes mirror == field order of struct gnerf_render_params."""
+@pytest.mark.parametrize('struct,mirror', [('gnerf_render_params', 'RenderParams'), ('gnerf_render_grads', 'RenderGrads')])
+def test_render_structs_match_header(struct, mirror):
+    """Field order of each ctypes mirror == field order of the struct in the header."""
     import gnerf_hip
     text = open(os.path.join(ROOT, 'include', 'gnerf_hip.h')).read()
-    body = text[text.index('typedef struct gnerf_render_params {'):text.index('} gnerf_render_params;')]
+    body = text[text.index('typedef struct %s {' % struct):text.index('} %s;' % struct)]
     body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
     fields = []
     for stmt in body.split('{', 1)[1].split(';'):
@@ -46,7 +47,7 @@ def test_render_params_struct_matches_header():
             continue
         for part in stmt.split(','):
             fields.append(re.findall(r'[A-Za-z_0-9]+', part)[-1])
-    assert fields == [f[0] for f in gnerf_hip.RenderParams._fields_]
+    assert fields == [f[0] for f in getattr(gnerf_hip, mirror)._fields_]
 
 
 def test_gpu_ops_refuse_cpu_tensors():
