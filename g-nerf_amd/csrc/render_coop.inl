@@ -28,6 +28,18 @@ constexpr int kTapDwords = 24;      // per sample: 3 planes x (4 byte offsets + 
 //    instead of 64 x 32 cycles of v_mfma_f32_16x16x4_f32.
 //  * -DGNERF_MLP_F32: plain fp32 rows (exact fp32 products on the fp32-input MFMA), the round-1 baseline.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr float kLog2e = 1.44269504088896341f, kLn2 = 0.693147180559945309f;
+
+// hi/lo f16 split of two fp32 values: hi = (f16(a), f16(b)) packed, lo = (f16(a - hi.a), f16(b - hi.b)) packed.
+// Three instructions for the pair: v_fma_mix{lo,hi}_f16 take the f16 half and the fp32 value in one fused operation and
+// write one half of the destination (the compiler's own lowering of the same expression is eight).
+__device__ __forceinline__ void split_f16x2(float a, float b, unsigned& hi, unsigned& lo) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=&v"(lo) : "v"(hi), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
+}
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ h8 as_h8(u4v v) { return __builtin_bit_cast(h8, v); }
 constexpr int kW1HalfPitch = 40;    // halves per LDS row of W1 hi / lo (32 + pad: conflict-free ds_read_b128)
 #ifdef GNERF_MLP_F32
 constexpr int kWeightFloats = 64 * 36 + 33 * 68;
@@ -138,8 +150,14 @@ __device__ __forceinline__ void stage_decoder(CoopLds& L, float* base, const gne
     _Float16* w1h = reinterpret_cast<_Float16*>(base);                 // [hi|lo][64][kW1HalfPitch]
     _Float16* w2h = w1h + 2 * 64 * kW1HalfPitch;                       // [hi|lo][n=2][s=2][j=16][g=4][8]
     L.w2 = base + (2 * 64 * kW1HalfPitch + 2 * 2048) / 2;              // density row W2[0][:] in fp32
+    // The activations run on the hardware's base-2 exp/log, so their scale factors are folded into the weights:
+    //   layer 1 produces p' = log2(e) p                      (W1, b1 scaled by log2 e)
+    //   softplus becomes h' = log2(1 + 2^p') = h / ln 2       (no multiply on either side)
+    //   the density row carries the ln 2 back                 (W2[0] scaled by ln 2)
+    //   the colour rows produce o' = -log2(e) o = -(W2 h') - log2(e) b2, so sigmoid(o) = 1 / (1 + 2^o'):
+    //   W2[1..32] is only NEGATED (exact), b2[1..32] scaled by -log2 e.
     for (int i = tid; i < 64 * 32; i += nthreads) {
-        const float x = p.w1[i];
+        const float x = p.w1[i] * kLog2e;
         const _Float16 hi = (_Float16)x;
         w1h[(i >> 5) * kW1HalfPitch + (i & 31)] = hi;
         w1h[64 * kW1HalfPitch + (i >> 5) * kW1HalfPitch + (i & 31)] = (_Float16)(x - (float)hi);
@@ -148,17 +166,22 @@ __device__ __forceinline__ void stage_decoder(CoopLds& L, float* base, const gne
         // fragment order of layer 2's B operand: lane (out column j, k-group g) of k-step s holds, at position jj,
         // hidden unit 32 s + 16 (jj >> 2) + 4 g + (jj & 3) -- the unit whose activation that lane group carries there
         const int jj = i & 7, g = (i >> 3) & 3, j = (i >> 5) & 15, s = (i >> 9) & 1, n = i >> 10;
-        const float x = p.w2[(1 + 16 * n + j) * 64 + 32 * s + 16 * (jj >> 2) + 4 * g + (jj & 3)];
+        const float x = -p.w2[(1 + 16 * n + j) * 64 + 32 * s + 16 * (jj >> 2) + 4 * g + (jj & 3)];
         const _Float16 hi = (_Float16)x;
         w2h[i] = hi;
         w2h[2048 + i] = (_Float16)(x - (float)hi);
     }
-    for (int i = tid; i < 64; i += nthreads) L.w2[i] = p.w2[i];
+    for (int i = tid; i < 64; i += nthreads) L.w2[i] = p.w2[i] * kLn2;
 #endif
     L.b1 = base + kWeightFloats;
     L.b2 = L.b1 + 64;
+#ifdef GNERF_MLP_F32
     for (int i = tid; i < 64; i += nthreads) L.b1[i] = p.b1[i];
     for (int i = tid; i < 33; i += nthreads) L.b2[i] = p.b2[i];
+#else
+    for (int i = tid; i < 64; i += nthreads) L.b1[i] = p.b1[i] * kLog2e;
+    for (int i = tid; i < 33; i += nthreads) L.b2[i] = i == 0 ? p.b2[0] : p.b2[i] * -kLog2e;
+#endif
 }
 
 // v + (v from lane^16) + (v from lane^32) + (v from lane^48): sum over the four 16-lane rows, result in every lane.
@@ -358,9 +381,10 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     // A = this lane's 8 weights W1[16m + j][8g..8g+7], B = its 8 staged features (channels 8g..8g+7 of sample j).
     const _Float16* w1h = reinterpret_cast<const _Float16*>(L.w1);
     const _Float16* w2h = w1h + 2 * 64 * kW1HalfPitch;
-    h8 fh, fl;
+    unsigned fh_u[4], fl_u[4];
 #pragma unroll
-    for (int i = 0; i < 8; i++) { const _Float16 t = (_Float16)f[i]; fh[i] = t; fl[i] = (_Float16)(f[i] - (float)t); }
+    for (int i = 0; i < 4; i++) split_f16x2(f[2 * i], f[2 * i + 1], fh_u[i], fl_u[i]);
+    const h8 fh = as_h8((u4v){fh_u[0], fh_u[1], fh_u[2], fh_u[3]}), fl = as_h8((u4v){fl_u[0], fl_u[1], fl_u[2], fl_u[3]});
     v4f h[4];
     h8 a_hi[4], a_lo[4];
 #pragma unroll
@@ -396,13 +420,14 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     v4f hv[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) {
+        // h' = log2(1 + 2^p'); beyond p' = 126 the sum overflows and h' = p' takes over (it is exact from p' = 25 on)
         v4f e;
 #pragma unroll
-        for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(-fabsf(h[m][r]) * 1.44269504088896341f);
+        for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(fminf(h[m][r], 126.f));
 #pragma unroll
         for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_logf(1.0f + e[r]);
 #pragma unroll
-        for (int r = 0; r < 4; r++) hv[m][r] = act_softplus(fmaf(e[r], 0.693147180559945309f, fmaxf(h[m][r], 0.f)), h[m][r]);
+        for (int r = 0; r < 4; r++) hv[m][r] = act_softplus(fmaxf(e[r], h[m][r]), h[m][r]);
         const v4f ws = *reinterpret_cast<const v4f*>(L.w2 + 16 * m + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; r++) sig = fmaf(ws[r], hv[m][r], sig);
@@ -414,13 +439,11 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     h8 x_hi[2], x_lo[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
+        unsigned xh[4], xl[4];
 #pragma unroll
-        for (int jj = 0; jj < 8; jj++) {
-            const float x = hv[2 * s + (jj >> 2)][jj & 3];
-            const _Float16 t = (_Float16)x;
-            x_hi[s][jj] = t;
-            x_lo[s][jj] = (_Float16)(x - (float)t);
-        }
+        for (int q = 0; q < 4; q++) split_f16x2(hv[2 * s + (q >> 1)][2 * (q & 1)], hv[2 * s + (q >> 1)][2 * (q & 1) + 1], xh[q], xl[q]);
+        x_hi[s] = as_h8((u4v){xh[0], xh[1], xh[2], xh[3]});
+        x_lo[s] = as_h8((u4v){xl[0], xl[1], xl[2], xl[3]});
     }
 #pragma unroll
     for (int s = 0; s < 2; s++) {
@@ -444,8 +467,13 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
 #pragma unroll
     for (int n = 0; n < 2; n++) {
         v4f t;
+#ifdef GNERF_MLP_F32
 #pragma unroll
         for (int r = 0; r < 4; r++) t[r] = __builtin_amdgcn_exp2f(o[n][r] * -1.44269504088896341f);
+#else
+#pragma unroll
+        for (int r = 0; r < 4; r++) t[r] = __builtin_amdgcn_exp2f(o[n][r]);            // o already carries the -log2(e)
+#endif
 #pragma unroll
         for (int r = 0; r < 4; r++) t[r] = __builtin_amdgcn_rcpf(1.0f + t[r]);
 #pragma unroll
@@ -605,7 +633,7 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
             if (dbg) for (int k = tid; k < F; k += kCoopThreads) dbg[GNERF_DBG_SIGMA_FINE * n_all + k] = L.sig_e[fine_e0 + k];
 
             // ---- merge by depth (renderer.py:157-167) = stable rank of every element of cat([coarse, fine]).
-            // Coarse depths ascend by construction (lin_k + u*delta with u < 1), so a coarse sample's rank is
+            // Coarse depths ascend by construction (lin_k + u*delta with u < 1) up to rounding, so a coarse sample's rank is
             // k + #(fine before it) and a fine sample's is #(coarse <= it) [binary search] + #(fine before it).
             // Wave 0 ranks the fine samples, wave 1 the coarse ones; both count over the fine keys, read four at
             // a time as LDS broadcasts.  Ties: coarse before fine, lower index first (what a stable sort gives).
@@ -623,6 +651,11 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
                     }
                     int lo = 0, hi = S;                                  // number of coarse depths <= key
                     while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.t_e[mid] <= key) lo = mid + 1; else hi = mid; }
+                    // neighbouring coarse depths can be swapped by one ulp (see below), which can put the search off by
+                    // one: recount exactly in a window of four around its answer
+                    const int w0 = max(lo - 2, 0), w1 = min(lo + 2, S);
+                    lo = w0;
+                    for (int q = w0; q < w1; q++) lo += (L.t_e[q] <= key) ? 1 : 0;
                     const int rank = cnt + lo;
                     L.rank_e[fine_e0 + i] = rank;
                     L.s_t[rank] = key;
@@ -637,6 +670,10 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
 #pragma unroll
                         for (int c2 = 0; c2 < 4; c2++) cnt += (k4[c2] < key) ? 1 : 0;
                     }
+                    // t_k = lin_k + u delta can round one ulp past t_{k+1} when u is within ~1e-5 of 1; only neighbours can
+                    // swap (the grid step is ~1e5 ulps), so the coarse samples sorted before k number k, k+1 or k-1
+                    if (k + 1 < S && L.t_e[k + 1] < key) cnt += 1;
+                    if (k > 0 && L.t_e[k - 1] > key) cnt -= 1;
                     const int rank = k + cnt;
                     L.rank_e[k] = rank;
                     L.s_t[rank] = key;

@@ -238,6 +238,11 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
         }
         if (lane < S) {
             key_c = sl.t_e[lane];
+            // "ascend by construction" holds up to rounding: t_k = lin_k + u delta can round one ulp past t_{k+1} when
+            // u is within 1e-5 of 1.  Only neighbours can swap (the grid step is ~1e5 ulps), so the number of coarse
+            // samples sorted before k is k +- 1 from two compares.
+            if (lane + 1 < S && sl.t_e[lane + 1] < key_c) rank_c += 1;
+            if (lane > 0 && sl.t_e[lane - 1] > key_c) rank_c -= 1;
 #pragma unroll 4
             for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
                 const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + fine_e0 + o2);

@@ -174,6 +174,36 @@ def test_render_tied_fine_depths(dev, S, F):
     np.testing.assert_allclose(wsum.cpu().numpy(), ref_w.numpy(), atol=2e-4)
 
 
+@pytest.mark.parametrize('kernel', ['pipe', 'coop', 'generic'])
+def test_render_coarse_depths_swapped_by_rounding(dev, kernel, monkeypatch):
+    """Jitter u = 1 - 2^-24 makes lin_k + u*delta round one ulp past the next proposal (7 of the 47 neighbour pairs at
+    the default limits): the coarse depths are then NOT ascending, and the merge must still be the reference's stable
+    sort -- sorted depths non-decreasing, every slot written."""
+    import gnerf_hip
+    from oracle import render_ref as R
+    monkeypatch.setenv('GNERF_RENDER_KERNEL', kernel)
+    N, res, S, F = 1, 8, 48, 48
+    planes, dec, o, d, nc, nf = _random_scene(21, N, res, S, F, (32, 32))
+    nc = nc.clone()
+    nc[:, 0::2, 0::2] = 1.0 - 2.0 ** -24
+    nc[:, 1::2, 1::2] = 1.0 - 2.0 ** -24
+    nc[:, 1::2, 0::2] = 0.0
+    nc[:, 0::2, 1::2] = 0.0
+    opts = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, clamp_mode='softplus')
+    st = {}
+    ref_rgb, ref_depth, ref_w = R.render(planes, dec, o, d, opts, nc, nf, stages=st)
+    assert bool((st['depths_coarse'][:, 1:] < st['depths_coarse'][:, :-1]).any())          # the premise: swapped neighbours exist
+    nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
+    rgb, depth, wsum, dbg = gnerf_hip.render_forward(nhwc, N, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev),
+                                                     depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0,
+                                                     image_width=res, debug=True)
+    sorted_d = dbg[:, gnerf_hip.DBG_DEPTH_SORTED if hasattr(gnerf_hip, 'DBG_DEPTH_SORTED') else 5].cpu()
+    assert bool((sorted_d[:, 1:] >= sorted_d[:, :-1]).all())
+    np.testing.assert_allclose(sorted_d.numpy(), st['depths_all'].numpy(), atol=5e-7)
+    np.testing.assert_allclose(rgb.cpu().numpy(), ref_rgb.numpy(), atol=2e-4)
+    np.testing.assert_allclose(depth.cpu().numpy(), ref_depth.numpy(), atol=2e-4)
+
+
 def test_render_per_ray_limits_vs_oracle(dev):
     """'auto' ray limits: per-ray start/end tensors (renderer.py:93-98, math_utils.linspace)."""
     import gnerf_hip
