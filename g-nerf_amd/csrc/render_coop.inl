@@ -30,13 +30,27 @@ constexpr int kTapDwords = 24;      // per sample: 3 planes x (4 byte offsets + 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 constexpr float kLog2e = 1.44269504088896341f, kLn2 = 0.693147180559945309f;
 
-// hi/lo f16 split of two fp32 values: hi = (f16(a), f16(b)) packed, lo = (f16(a - hi.a), f16(b - hi.b)) packed.
-// Three instructions for the pair: v_fma_mix{lo,hi}_f16 take the f16 half and the fp32 value in one fused operation and
-// write one half of the destination (the compiler's own lowering of the same expression is eight).
-__device__ __forceinline__ void split_f16x2(float a, float b, unsigned& hi, unsigned& lo) {
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=&v"(lo) : "v"(hi), "v"(a));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
+// hi/lo f16 split of eight fp32 values into two MFMA operands: hi = f16(x), lo = f16(x - hi), packed in order.
+// Twelve instructions (v_cvt_pk_f16_f32 per pair; v_fma_mixlo/hi_f16 take the f16 half and the fp32 value in one fused
+// operation and write one half of the destination) where the compiler's lowering of the same expression is thirty-two.
+// ONE asm block, ending in s_nop 1: the consumers are MFMAs, which need two wait states after a VALU write of an operand,
+// and the compiler's hazard recogniser does not look inside inline asm.
+__device__ __forceinline__ void split_f16x8(const float (&x)[8], unsigned (&hi)[4], unsigned (&lo)[4]) {
+    asm("v_cvt_pk_f16_f32 %0, %8, %9\n\t"
+        "v_cvt_pk_f16_f32 %1, %10, %11\n\t"
+        "v_cvt_pk_f16_f32 %2, %12, %13\n\t"
+        "v_cvt_pk_f16_f32 %3, %14, %15\n\t"
+        "v_fma_mixlo_f16 %4, %0, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %5, %1, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %6, %2, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %7, %3, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %4, %0, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %5, %1, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %6, %2, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %7, %3, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 1"
+        : "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
 }
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ h8 as_h8(u4v v) { return __builtin_bit_cast(h8, v); }
@@ -272,10 +286,15 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
         tex[a][pl][3] = *reinterpret_cast<const v4f*>(R.planes_item + (off[a][pl].w + cq16));
 #endif
     };
+    // Per plane: the four taps as one sum of products, then added to the sample's accumulator (the first plane starts it).
+    // NOTE: the obvious cheaper form -- one fused multiply-add per tap chained through all 12 taps -- is NOT used: with
+    // hipcc 7.2's code for it (v_pk_fma_f32 chains) lanes 48-63 of ~3 % of the rays differed from run to run, while the same
+    // chain written with scalar v_fmac_f32 was bit-stable (tools/determinism.py; no wait state or s_waitcnt changed that).
     auto blend = [&](int a, int pl, v4f& acc) {
-        acc += tex[a][pl][0] * wgt[a][pl][0] + tex[a][pl][1] * wgt[a][pl][1] + tex[a][pl][2] * wgt[a][pl][2] + tex[a][pl][3] * wgt[a][pl][3];
+        const v4f sum = tex[a][pl][0] * wgt[a][pl][0] + tex[a][pl][1] * wgt[a][pl][1] + tex[a][pl][2] * wgt[a][pl][2] + tex[a][pl][3] * wgt[a][pl][3];
+        if (pl == 0) acc = sum; else acc += sum;
     };
-    v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    v4f acc0, acc1;
     read_records(0);
     issue(0, 0); issue(0, 1); issue(0, 2);
     read_records(1);
@@ -382,8 +401,7 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     const _Float16* w1h = reinterpret_cast<const _Float16*>(L.w1);
     const _Float16* w2h = w1h + 2 * 64 * kW1HalfPitch;
     unsigned fh_u[4], fl_u[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) split_f16x2(f[2 * i], f[2 * i + 1], fh_u[i], fl_u[i]);
+    split_f16x8(f, fh_u, fl_u);
     const h8 fh = as_h8((u4v){fh_u[0], fh_u[1], fh_u[2], fh_u[3]}), fl = as_h8((u4v){fl_u[0], fl_u[1], fl_u[2], fl_u[3]});
     v4f h[4];
     h8 a_hi[4], a_lo[4];
@@ -440,8 +458,8 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         unsigned xh[4], xl[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) split_f16x2(hv[2 * s + (q >> 1)][2 * (q & 1)], hv[2 * s + (q >> 1)][2 * (q & 1) + 1], xh[q], xl[q]);
+        const float xs[8] = {hv[2 * s][0], hv[2 * s][1], hv[2 * s][2], hv[2 * s][3], hv[2 * s + 1][0], hv[2 * s + 1][1], hv[2 * s + 1][2], hv[2 * s + 1][3]};
+        split_f16x8(xs, xh, xl);
         x_hi[s] = as_h8((u4v){xh[0], xh[1], xh[2], xh[3]});
         x_lo[s] = as_h8((u4v){xl[0], xl[1], xl[2], xl[3]});
     }

@@ -257,9 +257,10 @@ def test_render_full_size_properties(dev):
     kw = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0)
     nhwc = gnerf_hip.planes_to_nhwc(pl)
     a = gnerf_hip.render_forward(nhwc, N, de, od, dd, ncd, nfd, image_width=res, **kw)
-    b = gnerf_hip.render_forward(nhwc, N, de, od, dd, ncd, nfd, image_width=res, **kw)
-    for x, y in zip(a, b):
-        assert torch.equal(x, y)                         # deterministic (no float atomics on the data path)
+    for _ in range(6):                                       # bit-identical from run to run: no float atomics on the data path, and
+        b = gnerf_hip.render_forward(nhwc, N, de, od, dd, ncd, nfd, image_width=res, **kw)       # no timing-dependent hazards (a missed
+        for x, y in zip(a, b):                               # MFMA operand hazard once showed up here as 2 rays in 65536)
+            assert torch.equal(x, y)
     rgb, depth, wsum = a
     assert torch.isfinite(rgb).all() and torch.isfinite(depth).all() and torch.isfinite(wsum).all()
     assert float(rgb.min()) >= -1.0021 and float(rgb.max()) <= 1.0021       # sigmoid*1.002-0.001 composited with weights <= 1
