@@ -347,6 +347,8 @@ def _rel(a, b):
     dict(N=1, res=4, S=12, F=0, hw=(8, 8)),                 # no importance pass
     dict(N=1, res=4, S=96, F=96, hw=(16, 16), white_back=True),
     dict(N=3, res=4, S=4, F=5, hw=(4, 4)),
+    dict(N=1, res=3, S=130, F=100, hw=(8, 8)),              # beyond 96+96, ragged tiles, 9 rays: partial workgroup
+    dict(N=1, res=2, S=256, F=256, hw=(8, 8)),              # GNERF_MAX_SAMPLES on both passes (159 KB of LDS per workgroup)
 ])
 def test_render_backward_vs_oracle(dev, cfg):
     """gnerf_render_backward against autograd through the fp64 oracle: plane, weight and bias gradients of a random
