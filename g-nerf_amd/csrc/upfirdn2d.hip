@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void upfirdn_tile_kernel(UpArgs a, int tiles_x
 // ---------------------------------------------------------------------------------------------
 // Specialised kernel for what StyleGAN2 / G-NeRF actually issue: 4x4 filter, NCHW, same factor on both axes,
 // (up,down) in {(1,1) blur, (2,1) upsample, (1,2) downsample} (and their gradients, which are the same shapes).
-//   * a workgroup owns a 16-row x (16*OPL)-column output tile of one image; OPL = 16 bytes of outputs per lane
+//   * a workgroup owns a TH-row x TW-column output tile of one image (Fir4Shape below); a lane makes OPL = 16 bytes of outputs
 //   * the input window is staged into LDS as fp32 with ALIGNED 16-byte global loads (the window's rows start at
 //     arbitrary element offsets -- 513-wide images -- so lanes walk the flat tensor in aligned vectors and mask);
 //     out-of-image positions are staged as zeros, so the FIR loop has no bounds checks
@@ -157,9 +157,22 @@ __global__ __launch_bounds__(256) void upfirdn_tile_kernel(UpArgs a, int tiles_x
 //   * one 16-byte store per lane.
 template <class T> struct Vec16 { static constexpr int N = 16 / sizeof(T); };
 
+// Tile shape.  A lane produces OPL horizontally adjacent outputs and reads a run of window columns that starts
+// CS = OPL*DOWN/UP dwords after its left neighbour's.  With 16 lanes across, CS = 8 (fp16 blur: 2-way) or 16 (fp16
+// down-sampling: 4-way) puts lanes of one row on the same LDS banks -- PMC showed 5x more bank-conflict cycles than LDS
+// issue cycles for the fp16 blur, which ran at the same elements/s as fp32.  So the lanes across are limited to 64/CS
+// and the tile grows downwards instead; with an odd row pitch the 64 lanes of a wave then touch 64 distinct banks.
+template <class T, int UP, int DOWN> struct Fir4Shape {
+    static constexpr int OPL = Vec16<T>::N;
+    static constexpr int CS = (OPL * DOWN) / UP;
+    static constexpr int LXN = CS >= 16 ? 4 : (CS >= 8 ? 8 : 16);    // lanes across the tile
+    static constexpr int TW = LXN * OPL, TH = 256 / LXN;
+};
+
 template <class T, int UP, int DOWN, int PX, int PY>   // PY is implied by Y0 at run time; kept so launches are explicit about the phase
 __global__ __launch_bounds__(256) void upfirdn_fir4_kernel(UpArgs a, int tiles_x, int tiles_y) {
-    constexpr int OPL = Vec16<T>::N, TW = 16 * OPL, TH = 16, NT = 4 / UP;
+    typedef Fir4Shape<T, UP, DOWN> Shape;
+    constexpr int OPL = Shape::OPL, LXN = Shape::LXN, TW = Shape::TW, TH = Shape::TH, NT = 4 / UP;
     constexpr int WW = ((TW - 1) * DOWN + 3) / UP + 2, WH = ((TH - 1) * DOWN + 3) / UP + 2, PITCH = WW | 1;
     constexpr int SPAN = ((OPL - 1) * DOWN + (UP - 1)) / UP + NT;         // window columns one lane touches per row
     __shared__ float s_x[WH * PITCH];
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(256) void upfirdn_fir4_kernel(UpArgs a, int tiles_x
     }
     __syncthreads();
     // ---- FIR on registers
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int lx = threadIdx.x % LXN, ly = threadIdx.x / LXN;
     const int oy = oy0 + ly, oxb = ox0 + OPL * lx;
     // rows: Y0 = oy*DOWN - pady0 is the upsampled row of tap 0; the first tap on a real sample is k0y = (-Y0) mod UP
     const int Y0 = oy * DOWN - a.pady0;
@@ -249,9 +262,133 @@ __global__ __launch_bounds__(256) void upfirdn_fir4_kernel(UpArgs a, int tiles_x
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming kernel for the 4x4 filter WITHOUT resampling (up = down = 1): the blur after every transposed
+// convolution of the synthesis / superresolution blocks (conv2d_resample.py:114-131), the largest tensors of a forward
+// pass ([N,128,513,513] -> 512).  No LDS and no barriers: a lane owns OPL = 16 bytes of adjacent output columns and walks
+// down a strip of rows, holding the last four input rows (OPL + 3 values each) in registers; every step loads ONE new
+// input row straight from global memory -- two unaligned vector loads per lane (the hardware takes 2-byte-aligned
+// dwordx4 loads; rows of a 513-wide fp16 image start on odd elements), coalesced across the wave -- and makes one
+// output row with 16 FMAs per output.  The next row's load is issued before the current row's FMAs.
+// Compared with the tile kernel above (stage through LDS, ~38 VALU + 230 SALU instructions and 5.5 LDS reads per
+// output): ~20 VALU per output, input re-read factor (R+3)/R, so the kernel is HBM-bound instead of instruction-bound.
+template <class T>
+__global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpArgs a, int lx_shift, int strips_x, int strips_y, int rows_per_strip) {
+    constexpr int OPL = 16 / sizeof(T), NIN = OPL + 3;
+    constexpr int NLOAD = sizeof(T) == 2 ? 12 : 8;          // elements fetched per row: dwordx4 + dwordx2 (fp16) / dwordx4 x2 (fp32)
+    const T* x = static_cast<const T*>(a.x);
+    T* y = static_cast<T*>(a.y);
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const int lx = lane & ((1 << lx_shift) - 1), sub = lane >> lx_shift;
+    int64_t sid = (gw << (6 - lx_shift)) + sub;              // strip id: (image, strip row, strip column)
+    const int sx = int(sid % strips_x); sid /= strips_x;
+    const int sy = int(sid % strips_y); sid /= strips_y;
+    const int64_t img = sid;
+    const bool live = img < int64_t(a.n) * a.c;
+    const int ox0 = ((sx << lx_shift) + lx) * OPL, oy0 = sy * rows_per_strip;
+    const int ix0 = ox0 - a.padx0;
+    unsigned col_ok = 0;
+#pragma unroll
+    for (int e = 0; e < NIN; e++) col_ok |= (live && ix0 + e >= 0 && ix0 + e < a.in_w) ? (1u << e) : 0u;
+    // filter taps, flipped like a true convolution unless a.flip, gain folded in (wave-uniform: scalar registers)
+    float f[4][4];
+#pragma unroll
+    for (int ky = 0; ky < 4; ky++) {
+#pragma unroll
+        for (int kx = 0; kx < 4; kx++) f[ky][kx] = a.f[(a.flip ? ky : 3 - ky) * a.fs_h + (a.flip ? kx : 3 - kx) * a.fs_w] * a.gain;
+    }
+    const int64_t numel = int64_t(a.n) * a.c * a.in_h * a.in_w;
+    const int64_t img_base = img * int64_t(a.in_h) * a.in_w;
+
+    struct Raw { T v[NLOAD]; };
+    auto fetch = [&](int iy, Raw& raw) {                     // issue the loads of input row iy (zeros when the row is outside the image)
+#pragma unroll
+        for (int e = 0; e < NLOAD; e++) raw.v[e] = T(0.f);
+        if (col_ok == 0 || iy < 0 || iy >= a.in_h) return;
+        const int64_t idx = img_base + int64_t(iy) * a.in_w + ix0;
+        if (idx >= 0 && idx + NLOAD <= numel) {
+            if constexpr (sizeof(T) == 2) {
+                __builtin_memcpy(&raw.v[0], x + idx, 16);
+                __builtin_memcpy(&raw.v[8], x + idx + 8, 8);
+            } else {
+                __builtin_memcpy(&raw.v[0], x + idx, 16);
+                __builtin_memcpy(&raw.v[4], x + idx + 4, 16);
+            }
+        } else {                                             // first / last elements of the whole tensor: stay inside it
+#pragma unroll
+            for (int e = 0; e < NIN; e++) if (idx + e >= 0 && idx + e < numel) raw.v[e] = x[idx + e];
+        }
+    };
+    float rows[4][NIN];
+    auto unpack = [&](const Raw& raw, float (&dst)[NIN]) {
+#pragma unroll
+        for (int e = 0; e < NIN; e++) dst[e] = ((col_ok >> e) & 1u) ? float(load_as<T>(raw.v, e)) : 0.f;
+    };
+    auto emit = [&](int oy, const float (&r0)[NIN], const float (&r1)[NIN], const float (&r2)[NIN], const float (&r3)[NIN]) {
+        if (!live || oy < oy0 || oy >= a.out_h || oy >= oy0 + rows_per_strip || ox0 >= a.out_w) return;
+        float acc[OPL];
+#pragma unroll
+        for (int q = 0; q < OPL; q++) {
+            float s = 0.f;
+#pragma unroll
+            for (int kx = 0; kx < 4; kx++) s = fmaf(r0[q + kx], f[0][kx], s);
+#pragma unroll
+            for (int kx = 0; kx < 4; kx++) s = fmaf(r1[q + kx], f[1][kx], s);
+#pragma unroll
+            for (int kx = 0; kx < 4; kx++) s = fmaf(r2[q + kx], f[2][kx], s);
+#pragma unroll
+            for (int kx = 0; kx < 4; kx++) s = fmaf(r3[q + kx], f[3][kx], s);
+            acc[q] = s;
+        }
+        T* yp = y + img * int64_t(a.out_h) * a.out_w + int64_t(oy) * a.out_w + ox0;
+        if (ox0 + OPL <= a.out_w && ((reinterpret_cast<uintptr_t>(yp) & 15) == 0)) {
+            T outv[OPL];
+#pragma unroll
+            for (int q = 0; q < OPL; q++) store_as<T>(outv, q, acc[q]);
+            *reinterpret_cast<Pack16<T>*>(yp) = *reinterpret_cast<Pack16<T>*>(outv);
+        } else {
+#pragma unroll
+            for (int q = 0; q < OPL; q++)
+                if (ox0 + q < a.out_w) store_as<T>(yp, q, acc[q]);
+        }
+    };
+    // input row of step s: iy = oy0 - pady0 + s; step s completes output row oy0 + s - 3
+    const int iy_first = oy0 - a.pady0;
+    Raw raw;
+    fetch(iy_first, raw);
+    const int steps = min(rows_per_strip, a.out_h - oy0) + 3;
+    for (int s0 = 0; s0 < steps; s0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int s = s0 + u;
+            unpack(raw, rows[u]);
+            fetch(iy_first + s + 1, raw);                    // in flight during this step's FMAs
+            emit(oy0 + s - 3, rows[(u + 1) & 3], rows[(u + 2) & 3], rows[(u + 3) & 3], rows[u]);
+        }
+    }
+}
+
+template <class T>
+int launch_blur4(const UpArgs& a, hipStream_t stream) {
+    constexpr int OPL = 16 / sizeof(T);
+    const int lanes_needed = (a.out_w + OPL - 1) / OPL;
+    int lx_shift = 0;
+    while (lx_shift < 6 && (1 << lx_shift) < lanes_needed) lx_shift++;
+    const int strips_x = (lanes_needed + (1 << lx_shift) - 1) >> lx_shift;
+    const int rows_per_strip = a.out_h > 256 ? 32 : 16;      // measured flat between 8 and 64 rows: the kernel is issue-bound, not latency-bound
+    const int strips_y = (a.out_h + rows_per_strip - 1) / rows_per_strip;
+    const int64_t strips = int64_t(strips_x) * strips_y * a.n * a.c;
+    const int64_t waves = (strips + (64 >> lx_shift) - 1) / (64 >> lx_shift);
+    const int64_t blocks = (waves + 3) / 4;
+    if (blocks > INT32_MAX) return 1;
+    hipLaunchKernelGGL((upfirdn_blur4_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream, a, lx_shift, strips_x, strips_y, rows_per_strip);
+    return check_launch("upfirdn2d(blur4)") == GNERF_OK ? 0 : -1;
+}
+
 template <class T, int UP, int DOWN>
 int launch_fir4(const UpArgs& a, hipStream_t stream) {
-    constexpr int TW = 16 * Vec16<T>::N, TH = 16;
+    constexpr int TW = Fir4Shape<T, UP, DOWN>::TW, TH = Fir4Shape<T, UP, DOWN>::TH;
     const int tiles_x = (a.out_w + TW - 1) / TW, tiles_y = (a.out_h + TH - 1) / TH;
     const int64_t blocks = int64_t(tiles_x) * tiles_y * a.n * a.c;
     if (blocks > INT32_MAX) return 1;
@@ -275,7 +412,7 @@ int launch_up(const UpArgs& a, hipStream_t stream) {
                           (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
         if (fir4) {
             int rc = 1;
-            if (a.upx == 1 && a.downx == 1) rc = launch_fir4<T, 1, 1>(a, stream);
+            if (a.upx == 1 && a.downx == 1) rc = launch_blur4<T>(a, stream);
             else if (a.upx == 2 && a.downx == 1) rc = launch_fir4<T, 2, 1>(a, stream);
             else if (a.upx == 1 && a.downx == 2) rc = launch_fir4<T, 1, 2>(a, stream);
             if (rc == 0) return GNERF_OK;
