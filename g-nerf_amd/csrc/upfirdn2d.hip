@@ -269,13 +269,18 @@ __global__ __launch_bounds__(256) void upfirdn_fir4_kernel(UpArgs a, int tiles_x
 // down a strip of rows, holding the last four input rows (OPL + 3 values each) in registers; every step loads ONE new
 // input row straight from global memory -- two unaligned vector loads per lane (the hardware takes 2-byte-aligned
 // dwordx4 loads; rows of a 513-wide fp16 image start on odd elements), coalesced across the wave -- and makes one
-// output row with 16 FMAs per output.  The next row's load is issued before the current row's FMAs.
+// output row with 16 FMAs per output.
 // Compared with the tile kernel above (stage through LDS, ~38 VALU + 230 SALU instructions and 5.5 LDS reads per
 // output): ~20 VALU per output, input re-read factor (R+3)/R, so the kernel is HBM-bound instead of instruction-bound.
 template <class T>
 __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpArgs a, int lx_shift, int strips_x, int strips_y, int rows_per_strip) {
     constexpr int OPL = 16 / sizeof(T), NIN = OPL + 3;
     constexpr int NLOAD = sizeof(T) == 2 ? 12 : 8;          // elements fetched per row: dwordx4 + dwordx2 (fp16) / dwordx4 x2 (fp32)
+    constexpr int ND = NLOAD * sizeof(T) / 4;               // ... as dwords
+    // explicitly under-aligned vector types: ONE global_load_dwordx4 / dwordx2 each (a memcpy from a 2-byte-aligned
+    // address is split by the compiler into dwordx3 + dwordx2 + ushort pieces)
+    typedef unsigned u4u __attribute__((ext_vector_type(4), aligned(2)));
+    typedef unsigned u2u __attribute__((ext_vector_type(2), aligned(2)));
     const T* x = static_cast<const T*>(a.x);
     T* y = static_cast<T*>(a.y);
     const int lane = threadIdx.x & 63;
@@ -299,72 +304,113 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpArgs a, int lx_shi
         for (int kx = 0; kx < 4; kx++) f[ky][kx] = a.f[(a.flip ? ky : 3 - ky) * a.fs_h + (a.flip ? kx : 3 - kx) * a.fs_w] * a.gain;
     }
     const int64_t numel = int64_t(a.n) * a.c * a.in_h * a.in_w;
-    const int64_t img_base = img * int64_t(a.in_h) * a.in_w;
 
-    struct Raw { T v[NLOAD]; };
-    auto fetch = [&](int iy, Raw& raw) {                     // issue the loads of input row iy (zeros when the row is outside the image)
-#pragma unroll
-        for (int e = 0; e < NLOAD; e++) raw.v[e] = T(0.f);
-        if (col_ok == 0 || iy < 0 || iy >= a.in_h) return;
-        const int64_t idx = img_base + int64_t(iy) * a.in_w + ix0;
-        if (idx >= 0 && idx + NLOAD <= numel) {
-            if constexpr (sizeof(T) == 2) {
-                __builtin_memcpy(&raw.v[0], x + idx, 16);
-                __builtin_memcpy(&raw.v[8], x + idx + 8, 8);
-            } else {
-                __builtin_memcpy(&raw.v[0], x + idx, 16);
-                __builtin_memcpy(&raw.v[4], x + idx + 4, 16);
-            }
-        } else {                                             // first / last elements of the whole tensor: stay inside it
-#pragma unroll
-            for (int e = 0; e < NIN; e++) if (idx + e >= 0 && idx + e < numel) raw.v[e] = x[idx + e];
+    // Loads are issued unconditionally from an address clamped into the tensor -- a branch around them would make the
+    // compiler wait for the data at the end of the branch (observed: s_waitcnt right behind the load, no overlap with the
+    // previous row's arithmetic).  Rows outside the image and edge columns are zeroed when the row is unpacked; the few
+    // lanes whose true window leaves the tensor (its first / last elements) re-read it element-wise there.
+    const int64_t img_c = live ? img : 0;
+    const int64_t img_base_c = img_c * int64_t(a.in_h) * a.in_w;
+    auto row_index = [&](int iy) -> int64_t { return img_base_c + int64_t(min(max(iy, 0), a.in_h - 1)) * a.in_w + ix0; };
+    struct Raw { unsigned d[ND]; };
+    auto fetch = [&](int iy, Raw& raw) {
+        const int64_t idx = min(max(row_index(iy), int64_t(0)), numel - NLOAD);
+        const u4u lo = *reinterpret_cast<const u4u*>(x + idx);
+        raw.d[0] = lo[0]; raw.d[1] = lo[1]; raw.d[2] = lo[2]; raw.d[3] = lo[3];
+        if constexpr (sizeof(T) == 2) {
+            const u2u hi = *reinterpret_cast<const u2u*>(x + idx + 8);
+            raw.d[4] = hi[0]; raw.d[5] = hi[1];
+        } else {
+            const u4u hi = *reinterpret_cast<const u4u*>(x + idx + 4);
+            raw.d[4] = hi[0]; raw.d[5] = hi[1]; raw.d[6] = hi[2]; raw.d[7] = hi[3];
         }
     };
-    float rows[4][NIN];
-    auto unpack = [&](const Raw& raw, float (&dst)[NIN]) {
+    auto element = [&](const Raw& raw, int e) -> float {
+        if constexpr (sizeof(T) == 2) {
+            const unsigned d = raw.d[e >> 1];
+            return __half2float(__ushort_as_half((e & 1) ? (unsigned short)(d >> 16) : (unsigned short)(d & 0xffffu)));
+        } else {
+            return __uint_as_float(raw.d[e]);
+        }
+    };
+    float rows[7][NIN];
+    auto unpack = [&](int iy, const Raw& raw, float (&dst)[NIN]) {
+        const unsigned ok = (iy >= 0 && iy < a.in_h) ? col_ok : 0u;
 #pragma unroll
-        for (int e = 0; e < NIN; e++) dst[e] = ((col_ok >> e) & 1u) ? float(load_as<T>(raw.v, e)) : 0.f;
+        for (int e = 0; e < NIN; e++) dst[e] = ((ok >> e) & 1u) ? element(raw, e) : 0.f;
+        const int64_t idx = row_index(iy);
+        if (ok != 0 && (idx < 0 || idx + NLOAD > numel)) {
+#pragma unroll
+            for (int e = 0; e < NIN; e++)
+                if ((ok >> e) & 1u) dst[e] = (idx + e >= 0 && idx + e < numel) ? float(load_as<T>(x, idx + e)) : 0.f;
+        }
     };
     auto emit = [&](int oy, const float (&r0)[NIN], const float (&r1)[NIN], const float (&r2)[NIN], const float (&r3)[NIN]) {
-        if (!live || oy < oy0 || oy >= a.out_h || oy >= oy0 + rows_per_strip || ox0 >= a.out_w) return;
+        if (!live || oy >= a.out_h || oy >= oy0 + rows_per_strip || ox0 >= a.out_w) return;
         float acc[OPL];
 #pragma unroll
         for (int q = 0; q < OPL; q++) {
             float s = 0.f;
 #pragma unroll
             for (int kx = 0; kx < 4; kx++) s = fmaf(r0[q + kx], f[0][kx], s);
+#ifndef GNERF_ABLATE_BLURFMA
 #pragma unroll
             for (int kx = 0; kx < 4; kx++) s = fmaf(r1[q + kx], f[1][kx], s);
 #pragma unroll
             for (int kx = 0; kx < 4; kx++) s = fmaf(r2[q + kx], f[2][kx], s);
 #pragma unroll
             for (int kx = 0; kx < 4; kx++) s = fmaf(r3[q + kx], f[3][kx], s);
+#endif
             acc[q] = s;
         }
         T* yp = y + img * int64_t(a.out_h) * a.out_w + int64_t(oy) * a.out_w + ox0;
+#ifdef GNERF_ABLATE_BLURSTORE
+        if (acc[0] != 12345.f) return;
+#endif
         if (ox0 + OPL <= a.out_w && ((reinterpret_cast<uintptr_t>(yp) & 15) == 0)) {
-            T outv[OPL];
-#pragma unroll
-            for (int q = 0; q < OPL; q++) store_as<T>(outv, q, acc[q]);
-            *reinterpret_cast<Pack16<T>*>(yp) = *reinterpret_cast<Pack16<T>*>(outv);
+            uint4 w;                                         // ONE global_store_dwordx4
+            if constexpr (sizeof(T) == 2) {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                w.x = __builtin_bit_cast(unsigned, (h2){(_Float16)acc[0], (_Float16)acc[1]});
+                w.y = __builtin_bit_cast(unsigned, (h2){(_Float16)acc[2], (_Float16)acc[3]});
+                w.z = __builtin_bit_cast(unsigned, (h2){(_Float16)acc[4 % OPL], (_Float16)acc[5 % OPL]});
+                w.w = __builtin_bit_cast(unsigned, (h2){(_Float16)acc[6 % OPL], (_Float16)acc[7 % OPL]});
+            } else {
+                w = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3]));
+            }
+            *reinterpret_cast<uint4*>(yp) = w;
         } else {
 #pragma unroll
             for (int q = 0; q < OPL; q++)
                 if (ox0 + q < a.out_w) store_as<T>(yp, q, acc[q]);
         }
     };
-    // input row of step s: iy = oy0 - pady0 + s; step s completes output row oy0 + s - 3
+    // Rows are processed in BLOCKS OF FOUR.  On this hardware loads and stores share one counter (vmcnt), and with both
+    // kinds pending a wait for the loads also waits for every earlier store to be acknowledged; with one row per wait the
+    // kernel ran at 3 TB/s no matter how the arithmetic or the prefetch was arranged (removing the stores alone doubled
+    // its speed).  So: one wait per block -- it drains the previous block's four stores and this block's four row loads,
+    // which were both in flight during the previous block's arithmetic -- then the next block's loads are issued, then
+    // four output rows are made and stored.  rows[0..2] are the last three input rows of the previous block.
     const int iy_first = oy0 - a.pady0;
-    Raw raw;
-    fetch(iy_first, raw);
-    const int steps = min(rows_per_strip, a.out_h - oy0) + 3;
-    for (int s0 = 0; s0 < steps; s0 += 4) {
+    Raw raw[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int s = s0 + u;
-            unpack(raw, rows[u]);
-            fetch(iy_first + s + 1, raw);                    // in flight during this step's FMAs
-            emit(oy0 + s - 3, rows[(u + 1) & 3], rows[(u + 2) & 3], rows[(u + 3) & 3], rows[u]);
+    for (int u = 0; u < 3; u++) fetch(iy_first + u, raw[u]);
+#pragma unroll
+    for (int u = 0; u < 3; u++) unpack(iy_first + u, raw[u], rows[u]);
+#pragma unroll
+    for (int u = 0; u < 4; u++) fetch(iy_first + 3 + u, raw[u]);
+    const int rows_here = min(rows_per_strip, a.out_h - oy0);
+    for (int r0 = 0; r0 < rows_here; r0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) unpack(iy_first + 3 + r0 + u, raw[u], rows[3 + u]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) fetch(iy_first + 7 + r0 + u, raw[u]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) emit(oy0 + r0 + u, rows[u], rows[u + 1], rows[u + 2], rows[u + 3]);
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+#pragma unroll
+            for (int e = 0; e < NIN; e++) rows[u][e] = rows[4 + u][e];
         }
     }
 }
@@ -372,6 +418,7 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpArgs a, int lx_shi
 template <class T>
 int launch_blur4(const UpArgs& a, hipStream_t stream) {
     constexpr int OPL = 16 / sizeof(T);
+    if (int64_t(a.n) * a.c * a.in_h * a.in_w < 16) return 1;          // the clamped row loads need 12 elements to exist
     const int lanes_needed = (a.out_w + OPL - 1) / OPL;
     int lx_shift = 0;
     while (lx_shift < 6 && (1 << lx_shift) < lanes_needed) lx_shift++;
