@@ -4,9 +4,9 @@
 // semantics follow torch_utils/ops/bias_act.py:92-122 (forward) and the autograd wrappers :128-209.
 //
 // The op is a pure HBM stream (2-5 tensors in, 1 out), so the kernel is organised around 16-byte
-// per-lane accesses: every lane moves one 16-B vector per tensor per step (1 KiB per wave
-// instruction), a grid of <= 8 workgroups per CU strides over the tensor, and the bias index is
-// resolved once per vector whenever the bias stride allows it.
+// per-lane accesses (1 KiB per wave instruction), four vectors per tensor in flight per lane, a grid of
+// <= 8 workgroups per CU striding over the tensor, and the bias index resolved once per vector (or once per
+// workgroup) whenever the bias stride allows it.
 
 #include "common.h"
 
@@ -92,10 +92,52 @@ __device__ __forceinline__ A eval(A in, A bias, A xref, A yref, A dy2, int grad,
 
 template <class T, int VEC> struct alignas(sizeof(T) * VEC) Pack { T v[VEC]; };
 
+// Both kernels move kBatch vectors per lane per wait: all loads of a batch are issued, then the arithmetic, then all
+// stores.  Loads and stores share one completion counter (vmcnt) on this hardware, and with both kinds pending the compiler
+// must wait for everything -- a load -> store -> load -> store loop waits for each store's acknowledgement before the next
+// load's data can be used.  Out-of-range slots of the last batch load a valid address and skip the store.
+constexpr int kBatch = 4;
+
+template <class T, int ACT, int VEC>
+__device__ __forceinline__ void act_batch(const Args& a, const int64_t (&i0)[kBatch], const bool (&ok)[kBatch],
+                                          const typename Arith<T>::type (&bias)[kBatch], bool bias_per_elem) {
+    typedef typename Arith<T>::type A;
+    typedef Pack<T, VEC> P;
+    const A alpha = A(a.alpha), gain = A(a.gain), clamp = A(a.clamp);
+    const T* __restrict__ x = static_cast<const T*>(a.x);
+    const T* __restrict__ b = static_cast<const T*>(a.b);
+    const T* __restrict__ xref = static_cast<const T*>(a.xref);
+    const T* __restrict__ yref = static_cast<const T*>(a.yref);
+    const T* __restrict__ dy = static_cast<const T*>(a.dy);
+    T* __restrict__ y = static_cast<T*>(a.y);
+    P px[kBatch], pxr[kBatch], pyr[kBatch], pdy[kBatch], po[kBatch];
+#pragma unroll
+    for (int t = 0; t < kBatch; t++) {
+        px[t] = *reinterpret_cast<const P*>(x + i0[t]);
+        if (xref) pxr[t] = *reinterpret_cast<const P*>(xref + i0[t]);
+        if (yref) pyr[t] = *reinterpret_cast<const P*>(yref + i0[t]);
+        if (dy)   pdy[t] = *reinterpret_cast<const P*>(dy + i0[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < kBatch; t++) {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+            A bv = bias[t];
+            if (bias_per_elem) bv = load_as<T>(b, (unsigned(i0[t] + k) / a.step_b) % a.size_b);
+            const A r = eval<A, ACT>(load_as<T>(px[t].v, k), bv,
+                                     xref ? load_as<T>(pxr[t].v, k) : A(0), yref ? load_as<T>(pyr[t].v, k) : A(0),
+                                     dy ? load_as<T>(pdy[t].v, k) : A(1), a.grad, alpha, gain, clamp);
+            store_as<T>(po[t].v, k, r);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kBatch; t++)
+        if (ok[t]) *reinterpret_cast<P*>(y + i0[t]) = po[t];
+}
+
 template <class T, int ACT, int VEC>
 __global__ __launch_bounds__(kThreads) void bias_act_kernel(Args a) {
     typedef typename Arith<T>::type A;
-    typedef Pack<T, VEC> P;
     const A alpha = A(a.alpha), gain = A(a.gain), clamp = A(a.clamp);
     const T* x = static_cast<const T*>(a.x);
     const T* b = static_cast<const T*>(a.b);
@@ -105,24 +147,20 @@ __global__ __launch_bounds__(kThreads) void bias_act_kernel(Args a) {
     T* y = static_cast<T*>(a.y);
     const int64_t nvec = a.numel / VEC;
     const bool bias_per_vec = (b != nullptr) && (a.step_b % VEC == 0);
+    const bool bias_per_elem = (b != nullptr) && !bias_per_vec;
     const int64_t stride = int64_t(gridDim.x) * kThreads;
-    for (int64_t iv = int64_t(blockIdx.x) * kThreads + threadIdx.x; iv < nvec; iv += stride) {
-        const int64_t i0 = iv * VEC;
-        P px = *reinterpret_cast<const P*>(x + i0), pxr, pyr, pdy, po;
-        if (xref) pxr = *reinterpret_cast<const P*>(xref + i0);
-        if (yref) pyr = *reinterpret_cast<const P*>(yref + i0);
-        if (dy)   pdy = *reinterpret_cast<const P*>(dy + i0);
-        A bv = A(0);
-        if (bias_per_vec) bv = load_as<T>(b, (unsigned(i0) / a.step_b) % a.size_b);
+    for (int64_t iv = int64_t(blockIdx.x) * kThreads + threadIdx.x; iv < nvec; iv += stride * kBatch) {
+        int64_t i0[kBatch];
+        bool ok[kBatch];
+        A bias[kBatch];
 #pragma unroll
-        for (int k = 0; k < VEC; k++) {
-            if (b && !bias_per_vec) bv = load_as<T>(b, (unsigned(i0 + k) / a.step_b) % a.size_b);
-            const A r = eval<A, ACT>(load_as<T>(px.v, k), bv,
-                                     xref ? load_as<T>(pxr.v, k) : A(0), yref ? load_as<T>(pyr.v, k) : A(0),
-                                     dy ? load_as<T>(pdy.v, k) : A(1), a.grad, alpha, gain, clamp);
-            store_as<T>(po.v, k, r);
+        for (int t = 0; t < kBatch; t++) {
+            const int64_t v = iv + t * stride;
+            ok[t] = v < nvec;
+            i0[t] = (ok[t] ? v : iv) * VEC;
+            bias[t] = bias_per_vec ? load_as<T>(b, (unsigned(i0[t]) / a.step_b) % a.size_b) : A(0);
         }
-        *reinterpret_cast<P*>(y + i0) = po;
+        act_batch<T, ACT, VEC>(a, i0, ok, bias, bias_per_elem);
     }
     // ragged tail (fewer than VEC elements), one lane each
     const int64_t tail0 = nvec * VEC;
@@ -139,40 +177,28 @@ __global__ __launch_bounds__(kThreads) void bias_act_kernel(Args a) {
 // [rows = numel / step_b][step_b] and the bias is constant along a row, so blockIdx.y = row makes the bias index a
 // per-workgroup scalar -- no per-vector integer division, which otherwise costs as much as the activation itself
 // (measured on [4,128,512,512]: fp16 3.5 -> 4.8 TB/s, fp32 5.0 -> 5.7 TB/s).
-constexpr int kRowVecsPerLane = 4;
+constexpr int kRowVecsPerLane = kBatch;
 
 template <class T, int ACT, int VEC>
 __global__ __launch_bounds__(kThreads) void bias_act_rows_kernel(Args a) {
     typedef typename Arith<T>::type A;
-    typedef Pack<T, VEC> P;
-    const A alpha = A(a.alpha), gain = A(a.gain), clamp = A(a.clamp);
-    const T* x = static_cast<const T*>(a.x);
-    const T* xref = static_cast<const T*>(a.xref);
-    const T* yref = static_cast<const T*>(a.yref);
-    const T* dy = static_cast<const T*>(a.dy);
-    T* y = static_cast<T*>(a.y);
     const unsigned row = blockIdx.y;
     const A bv = load_as<T>(static_cast<const T*>(a.b), row % a.size_b);
     const int64_t row0 = int64_t(row) * a.step_b;
     const unsigned nvec_row = a.step_b / VEC;
+    const unsigned v0 = blockIdx.x * kRowVecsPerLane * kThreads + threadIdx.x;
+    if (v0 >= nvec_row) return;
+    int64_t i0[kBatch];
+    bool ok[kBatch];
+    A bias[kBatch];
 #pragma unroll
-    for (int it = 0; it < kRowVecsPerLane; it++) {
-        const unsigned v = (blockIdx.x * kRowVecsPerLane + it) * kThreads + threadIdx.x;
-        if (v >= nvec_row) break;
-        const int64_t i0 = row0 + int64_t(v) * VEC;
-        P px = *reinterpret_cast<const P*>(x + i0), pxr, pyr, pdy, po;
-        if (xref) pxr = *reinterpret_cast<const P*>(xref + i0);
-        if (yref) pyr = *reinterpret_cast<const P*>(yref + i0);
-        if (dy)   pdy = *reinterpret_cast<const P*>(dy + i0);
-#pragma unroll
-        for (int k = 0; k < VEC; k++) {
-            const A r = eval<A, ACT>(load_as<T>(px.v, k), bv,
-                                     xref ? load_as<T>(pxr.v, k) : A(0), yref ? load_as<T>(pyr.v, k) : A(0),
-                                     dy ? load_as<T>(pdy.v, k) : A(1), a.grad, alpha, gain, clamp);
-            store_as<T>(po.v, k, r);
-        }
-        *reinterpret_cast<P*>(y + i0) = po;
+    for (int t = 0; t < kBatch; t++) {
+        const unsigned v = v0 + t * kThreads;
+        ok[t] = v < nvec_row;
+        i0[t] = row0 + int64_t(ok[t] ? v : v0) * VEC;
+        bias[t] = bv;
     }
+    act_batch<T, ACT, VEC>(a, i0, ok, bias, false);
 }
 
 template <class T, int VEC>
