@@ -103,12 +103,38 @@ def _check(code, what):
         raise RuntimeError(f'{what} failed ({code}): {msg}')
 
 
+# The three helpers below sit on every call; written for low host overhead (the public ops are called ~45 times per
+# generator forward): raw stream handle without building a Stream object, plain ints for pointers (argtypes are
+# c_void_p), and no device context switch when the tensor already lives on the current device.
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(t.device).cuda_stream
 
 
 def _ptr(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()
+
+
+class _NoSwitch:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on_device(device):
+    """Context that makes `device` current for the launch; free when it already is."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(device)
 
 
 def _strides(t):
@@ -117,6 +143,8 @@ def _strides(t):
 
 def _is_dense(t):
     """Non-overlapping and dense in SOME dimension order (what ATen's is_non_overlapping_and_dense checks)."""
+    if t.is_contiguous():
+        return True
     expected = 1
     for stride, size in sorted((st, sz) for sz, st in zip(t.shape, t.stride()) if sz != 1):
         if stride != expected:
@@ -156,7 +184,7 @@ def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
             raise RuntimeError('bias_act: b has the wrong number of elements or dim is out of bounds')
         size_b, step_b = b.numel(), x.stride(dim)
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         code = load().gnerf_bias_act(_ptr(x), _ptr(b), _ptr(xref), _ptr(yref), _ptr(dy), _ptr(y), _DTYPE_CODE[x.dtype],
                                      x.numel(), size_b, step_b, int(grad), int(act), float(alpha), float(gain), float(clamp), _stream(x))
     _check(code, 'gnerf_bias_act')
@@ -181,7 +209,7 @@ def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
         raise RuntimeError('upfirdn2d: output must be at least 1x1')
     mf = torch.channels_last if (x.stride(1) == 1 and c > 1) else torch.contiguous_format
     y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device, memory_format=mf)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         code = load().gnerf_upfirdn2d(_ptr(x), _ptr(f), _ptr(y), _DTYPE_CODE[x.dtype], n, c, ih, iw, _strides(x),
                                       fh, fw, _strides(f), oh, ow, _strides(y), upx, upy, downx, downy, padx0, pady0,
                                       1 if flip else 0, float(gain), _stream(x))
@@ -211,7 +239,7 @@ def filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, write_signs):
         s_h = h
         so = torch.empty([n, c, s_h, s_w // 4], dtype=torch.uint8, device=x.device)
         s, mode, sx, sy = so, 1, 0, 0
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         code = load().gnerf_filtered_lrelu_act(_ptr(x), _ptr(s), _DTYPE_CODE[x.dtype], n, c, h, w, _strides(x), s_h, s_w, int(sx), int(sy),
                                                float(gain), float(slope), float(clamp), mode, _stream(x))
     _check(code, 'gnerf_filtered_lrelu_act')
@@ -226,7 +254,7 @@ def planes_to_nhwc(planes):
     p = planes.reshape(-1, *planes.shape[-3:]).contiguous()
     np_, c, h, w = p.shape
     out = torch.empty([np_, h, w, c], dtype=torch.float32, device=p.device)
-    with torch.cuda.device(p.device):
+    with _on_device(p.device):
         code = load().gnerf_planes_to_nhwc(_ptr(p), _ptr(out), np_, c, h, w, _stream(p))
     _check(code, 'gnerf_planes_to_nhwc')
     return out
@@ -241,7 +269,7 @@ def make_rays(cam2world, intrinsics, resolution):
         raise RuntimeError('make_rays: expected cam2world [N,4,4] and intrinsics [N,3,3]')
     o = torch.empty([n, resolution * resolution, 3], dtype=torch.float32, device=c2w.device)
     d = torch.empty_like(o)
-    with torch.cuda.device(c2w.device):
+    with _on_device(c2w.device):
         code = load().gnerf_make_rays(_ptr(c2w), _ptr(k), n, int(resolution), _ptr(o), _ptr(d), _stream(c2w))
     _check(code, 'gnerf_make_rays')
     return o, d
@@ -329,7 +357,7 @@ def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
     ws = _workspace(dev)
     p.out_rgb, p.out_depth, p.out_wsum = rgb.data_ptr(), depth.data_ptr(), wsum.data_ptr()
     p.workspace = ws.data_ptr(); p.debug = None if dbg is None else dbg.data_ptr()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         code = load().gnerf_render_forward(ctypes.byref(p), _stream(planes_nhwc))
     _check(code, 'gnerf_render_forward')
     del keep
@@ -365,7 +393,7 @@ def render_backward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_
                  torch.zeros([33, 64], dtype=torch.float32, device=dev), torch.zeros([33], dtype=torch.float32, device=dev))
         g.grad_w1, g.grad_b1, g.grad_w2, g.grad_b2 = [t.data_ptr() for t in g_dec]
     g.grad_planes_nhwc = None if g_planes is None else g_planes.data_ptr()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         code = load().gnerf_render_backward(ctypes.byref(p), ctypes.byref(g), _stream(planes_nhwc))
     _check(code, 'gnerf_render_backward')
     del keep, grads_in
@@ -382,7 +410,7 @@ def query_points(planes_nhwc, n_items, decoder, points, box_warp):
     n_pts = pts.shape[1]
     sigma = torch.empty([n_items, n_pts, 1], dtype=torch.float32, device=pts.device)
     rgb = torch.empty([n_items, n_pts, 32], dtype=torch.float32, device=pts.device)
-    with torch.cuda.device(pts.device):
+    with _on_device(pts.device):
         code = load().gnerf_query_points(_ptr(planes_nhwc), n_items, planes_nhwc.shape[1], planes_nhwc.shape[2], _ptr(pts), n_pts,
                                          float(box_warp), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(sigma), _ptr(rgb), _stream(pts))
     _check(code, 'gnerf_query_points')

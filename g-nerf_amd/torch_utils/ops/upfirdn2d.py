@@ -133,15 +133,24 @@ def _transposed(c, f, in_hw, out_hw):
                    not c.flip, c.gain)
 
 
+def _normalise_filter(x, f):
+    assert isinstance(x, torch.Tensor) and x.ndim == 4
+    if f is None:
+        f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+    if f.ndim == 1 and f.shape[0] == 1:
+        f = f.square().unsqueeze(0)             # a single separable tap is a 1x1 filter
+    assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
+    return f
+
+
+def _forward_only(x, f, cfg):
+    return _run(x, _normalise_filter(x, f), cfg)
+
+
 class _Resample(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, f, cfg):
-        assert isinstance(x, torch.Tensor) and x.ndim == 4
-        if f is None:
-            f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
-        if f.ndim == 1 and f.shape[0] == 1:
-            f = f.square().unsqueeze(0)             # a single separable tap is a 1x1 filter
-        assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
+        f = _normalise_filter(x, f)
         y = _run(x, f, cfg)
         ctx.save_for_backward(f)
         ctx.cfg_t = _transposed(cfg, f, x.shape[2:], y.shape[2:])
@@ -162,6 +171,9 @@ class _Bound:
         self.cfg = cfg
 
     def apply(self, x, f):
+        # inference fast path: no graph wanted, so skip the autograd.Function machinery
+        if not (torch.is_grad_enabled() and x.requires_grad):
+            return _forward_only(x, f, self.cfg)
         return _Resample.apply(x, f, self.cfg)
 
 
