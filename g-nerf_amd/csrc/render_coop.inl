@@ -258,8 +258,6 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     GNERF_STAMP(st, 1);         // tap setup
     // ---- lookup: 8 lanes per texel, 8 samples per step
     const int b = lane >> 3, cq16 = (lane & 7) * 16;
-    // all 24 texel loads of the tile (2 steps x 3 planes x 4 taps) are issued before the first blend, so one
-    // memory round trip covers both steps
     // The tile's 24 texel loads (2 steps x 3 planes x 4 taps) run as a ROLLING window of three 4-load units (48 VGPRs in
     // flight): as soon as a plane of step 0 has been blended, the same plane of step 1 is issued, so the second step's
     // round trip overlaps the first instead of following it.  Measured alternatives (tools/ablate.py, config 2): all 24
@@ -298,7 +296,6 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     read_records(0);
     issue(0, 0); issue(0, 1); issue(0, 2);
     read_records(1);
-#ifndef GNERF_GATHER_SEQUENTIAL
     __builtin_amdgcn_sched_barrier(0);
     blend(0, 0, acc0); issue(1, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -306,11 +303,6 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     __builtin_amdgcn_sched_barrier(0);
     blend(0, 2, acc0); issue(1, 2);
     __builtin_amdgcn_sched_barrier(0);
-#else
-    blend(0, 0, acc0); blend(0, 1, acc0); blend(0, 2, acc0);
-    __builtin_amdgcn_sched_barrier(0);
-    issue(1, 0); issue(1, 1); issue(1, 2);
-#endif
     *reinterpret_cast<v4f*>(stage + b * kStagePitch + (lane & 7) * 4) = acc0;
     blend(1, 0, acc1); blend(1, 1, acc1); blend(1, 2, acc1);
     *reinterpret_cast<v4f*>(stage + (8 + b) * kStagePitch + (lane & 7) * 4) = acc1;
