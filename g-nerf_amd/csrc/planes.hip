@@ -39,6 +39,32 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     }
 }
 
+// The inverse layout change, for the gradient of the planes: [plane, y, x, channel] -> [plane, channel, y, x].
+// Reads whole texels, writes rows along x.
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int c, int64_t hw, int tiles_p, int tiles_c) {
+    __shared__ float tile[PT][CT + 1];
+    int64_t t = blockIdx.x;
+    const int tp = int(t % tiles_p); t /= tiles_p;
+    const int tc = int(t % tiles_c); t /= tiles_c;
+    const int64_t plane = t;
+    const int64_t p0 = int64_t(tp) * PT;
+    const int c0 = tc * CT;
+    const float* s = src + plane * hw * c;
+    float* d = dst + plane * c * hw;
+    for (int e = threadIdx.x; e < CT * PT; e += 256) {
+        const int px = e / CT, ch = e % CT;
+        float v = 0.f;
+        if (c0 + ch < c && p0 + px < hw) v = s[(p0 + px) * c + c0 + ch];
+        tile[px][ch] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < CT * PT; e += 256) {
+        const int ch = e / PT, px = e % PT;
+        if (c0 + ch < c && p0 + px < hw) d[int64_t(c0 + ch) * hw + p0 + px] = tile[px][ch];
+    }
+}
+
 // One lane per ray.  Arithmetic order follows ray_sampler.py:43-59 (no fused multiply-adds, so that
 // the directions agree with the reference to the last bit or two).
 __global__ __launch_bounds__(256) void make_rays_kernel(const float* __restrict__ c2w, const float* __restrict__ intr,
@@ -94,6 +120,20 @@ extern "C" int gnerf_planes_to_nhwc(const float* planes_nchw, float* planes_nhwc
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
                        planes_nchw, planes_nhwc, c, hw, tiles_p, tiles_c);
     return check_launch("planes_to_nhwc");
+}
+
+extern "C" int gnerf_planes_from_nhwc(const float* planes_nhwc, float* planes_nchw, int np, int c, int h, int w,
+                                      gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!planes_nchw || !planes_nhwc) return fail(GNERF_E_ARG, "planes_from_nhwc: null pointer");
+    if (np < 1 || c < 1 || h < 1 || w < 1) return fail(GNERF_E_ARG, "planes_from_nhwc: empty tensor");
+    const int64_t hw = int64_t(h) * w;
+    const int tiles_p = int((hw + PT - 1) / PT), tiles_c = (c + CT - 1) / CT;
+    const int64_t blocks = int64_t(tiles_p) * tiles_c * np;
+    if (blocks > INT32_MAX) return fail(GNERF_E_ARG, "planes_from_nhwc: tensor too large");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                       planes_nhwc, planes_nchw, c, hw, tiles_p, tiles_c);
+    return check_launch("planes_from_nhwc");
 }
 
 extern "C" int gnerf_make_rays(const float* cam2world, const float* intrinsics, int n, int res,

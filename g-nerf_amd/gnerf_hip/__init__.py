@@ -66,6 +66,7 @@ SIGNATURES = {
     'gnerf_filtered_lrelu_act': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, ctypes.POINTER(_c_i64), _c_i, _c_i, _c_i, _c_i,
                                         _c_f, _c_f, _c_f, _c_i, _c_p]),
     'gnerf_planes_to_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
+    'gnerf_planes_from_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_make_rays': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_p, _c_p, _c_p]),
     'gnerf_render_workspace_bytes': (ctypes.c_size_t, []),
     'gnerf_render_forward': (_c_i, [ctypes.POINTER(RenderParams), _c_p]),
@@ -258,6 +259,19 @@ def planes_to_nhwc(planes):
         code = load().gnerf_planes_to_nhwc(_ptr(p), _ptr(out), np_, c, h, w, _stream(p))
     _check(code, 'gnerf_planes_to_nhwc')
     return out
+
+
+def planes_from_nhwc(planes_nhwc, n_items=None):
+    """[NP,H,W,C] float32 -> [NP,C,H,W] contiguous ([N,3,C,H,W] when n_items is given)."""
+    _require_cuda(planes_nhwc)
+    if planes_nhwc.dtype != torch.float32 or planes_nhwc.ndim != 4 or not planes_nhwc.is_contiguous():
+        raise RuntimeError('planes_from_nhwc: expected a contiguous float32 [NP,H,W,C] tensor')
+    np_, h, w, c = planes_nhwc.shape
+    out = torch.empty([np_, c, h, w], dtype=torch.float32, device=planes_nhwc.device)
+    with _on_device(planes_nhwc.device):
+        code = load().gnerf_planes_from_nhwc(_ptr(planes_nhwc), _ptr(out), np_, c, h, w, _stream(planes_nhwc))
+    _check(code, 'gnerf_planes_from_nhwc')
+    return out if n_items is None else out.view(n_items, np_ // n_items, c, h, w)
 
 
 def make_rays(cam2world, intrinsics, resolution):

@@ -129,8 +129,7 @@ class _FusedRender(torch.autograd.Function):
                                                     **ctx.cfg)
         grads = [None] * 12
         if need_planes:
-            H, W = planes.shape[3], planes.shape[4]
-            grads[0] = g_planes.view(N, 3, H, W, 32).permute(0, 1, 4, 2, 3).to(planes.dtype)      # a view: NCHW indexing over NHWC storage
+            grads[0] = gnerf_hip.planes_from_nhwc(g_planes, N).to(planes.dtype)     # contiguous NCHW, like the planes themselves
         if need_decoder:
             for i, (g, t) in enumerate(zip(g_dec, (w1, b1, w2, b2))):
                 if ctx.needs_input_grad[1 + i]:

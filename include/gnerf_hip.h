@@ -18,6 +18,8 @@
  *   gnerf_query_points      <- ImportanceRenderer.run_model        training/volumetric_rendering/renderer.py:142-148
  *   gnerf_make_rays         <- RaySampler.forward                  training/volumetric_rendering/ray_sampler.py:24-63
  *   gnerf_planes_to_nhwc    <- (layout change feeding the renderer; the reference keeps NCHW, triplane.py:74)
+ *   gnerf_planes_from_nhwc  <- (the same for the plane gradient on the way back)
+ *   gnerf_render_backward   <- autograd through renderer.py:88-140 (grid_sample_gradfix.py:62-77 for the planes)
  */
 #ifndef GNERF_HIP_H
 #define GNERF_HIP_H
@@ -90,6 +92,10 @@ int gnerf_filtered_lrelu_act(void* x, uint8_t* s, int dtype, int n, int c, int h
  * The renderer reads whole 128-byte texels (32 channels) from the NHWC copy. */
 int gnerf_planes_to_nhwc(const float* planes_nchw, float* planes_nhwc, int np, int c, int h, int w,
                          gnerf_stream_t stream);
+/* The inverse, NHWC [np, h, w, c] -> NCHW [np, c, h, w]: hands gnerf_render_backward's plane gradient back in the layout
+ * of the reference's planes (triplane.py:74). */
+int gnerf_planes_from_nhwc(const float* planes_nhwc, float* planes_nchw, int np, int c, int h, int w,
+                           gnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Ray generation (ray_sampler.py:24-63): cam2world [n,4,4], intrinsics [n,3,3] row-major ->

@@ -62,6 +62,16 @@ def test_planes_to_nhwc(dev):
         assert torch.equal(out, ref)
 
 
+def test_planes_from_nhwc_roundtrip(dev):
+    import gnerf_hip
+    for shape in [(2, 3, 32, 16, 16), (1, 3, 32, 20, 24), (1, 3, 32, 7, 5), (6, 40, 9, 13)]:
+        x = torch.randn(*shape, device=dev)
+        nhwc = gnerf_hip.planes_to_nhwc(x)
+        back = gnerf_hip.planes_from_nhwc(nhwc)
+        assert torch.equal(back, x.reshape(-1, *shape[-3:]))
+    assert gnerf_hip.planes_from_nhwc(gnerf_hip.planes_to_nhwc(torch.randn(2, 3, 32, 8, 8, device=dev)), 2).shape == (2, 3, 32, 8, 8)
+
+
 def test_make_rays(dev, golden):
     import gnerf_hip
     g = golden('camera.npz')
