@@ -764,3 +764,36 @@ extern "C" int gnerf_query_points(const float* planes_nhwc, int n_items, int pla
                        points, out_sigma, out_rgb);
     return check_launch("query_kernel");
 }
+
+extern "C" int gnerf_query_points_backward(const float* planes_nhwc, int n_items, int plane_h, int plane_w,
+                                           const float* points, int n_points, float box_warp,
+                                           const float* w1, const float* b1, const float* w2, const float* b2,
+                                           const float* grad_sigma, const float* grad_rgb,
+                                           float* grad_planes_nhwc, float* grad_w1, float* grad_b1, float* grad_w2, float* grad_b2,
+                                           gnerf_stream_t stream) {
+    using namespace gnerf;
+    Params P = {};
+    gnerf_render_params& p = P.p;
+    p.planes_nhwc = planes_nhwc; p.n_items = n_items; p.plane_h = plane_h; p.plane_w = plane_w;
+    p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.box_warp = box_warp;
+    if (int e = check_common(&p)) return e;
+    if (!points) return fail(GNERF_E_ARG, "query_points_backward: points is null");
+    if (n_points < 1) return fail(GNERF_E_ARG, "query_points_backward: n_points must be positive");
+    const int n_dec = (grad_w1 != nullptr) + (grad_b1 != nullptr) + (grad_w2 != nullptr) + (grad_b2 != nullptr);
+    if (n_dec != 0 && n_dec != 4) return fail(GNERF_E_ARG, "query_points_backward: the four decoder gradients are given together or not at all");
+    if ((!grad_planes_nhwc && n_dec == 0) || (!grad_sigma && !grad_rgb)) return GNERF_OK;
+    if (!(int64_t(plane_h) * plane_w * 3 * 128 < (int64_t(1) << 32))) return fail(GNERF_E_UNSUPPORTED, "query_points_backward: planes too large for 32-bit tap offsets");
+    P.box_scale = float(2.0 / double(box_warp));
+    QueryBwdArgs Q;
+    Q.points = points; Q.grad_sigma = grad_sigma; Q.grad_rgb = grad_rgb; Q.n_points = n_points;
+    Q.tiles_per_item = (n_points + 15) / 16;
+    const int64_t tiles = int64_t(n_items) * Q.tiles_per_item;
+    if (tiles > INT32_MAX) return fail(GNERF_E_ARG, "query_points_backward: too many points");
+    Q.n_tiles = int(tiles);
+    Q.grad_planes_nhwc = grad_planes_nhwc; Q.grad_w1 = grad_w1; Q.grad_b1 = grad_b1; Q.grad_w2 = grad_w2; Q.grad_b2 = grad_b2;
+    const size_t lds_bytes = (kBwdWeightFloats + kBwdWaves * bwd_wave_floats(0)) * sizeof(float);
+    int64_t blocks = (tiles + kBwdWaves - 1) / kBwdWaves;
+    if (blocks > int64_t(kNumCU) * 2) blocks = int64_t(kNumCU) * 2;
+    hipLaunchKernelGGL(query_bwd_kernel, dim3((unsigned)blocks), dim3(kBwdThreads), lds_bytes, as_stream(stream), P, Q);
+    return check_launch("query_bwd_kernel");
+}

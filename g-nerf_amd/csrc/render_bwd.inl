@@ -55,6 +55,17 @@ __device__ __forceinline__ float row_total(float v) {
 
 struct BwdRay { float ox, oy, oz, dx, dy, dz; const char* planes; };
 
+// sample j of tile `tile` of a ray: depth from t_list (clamped to the last real sample for tile padding)
+struct RayTilePos {
+    const BwdRay& R; const float* t_list; int count, tile; float box_scale;
+    __device__ __forceinline__ void operator()(int j, float& px, float& py, float& pz) const {
+        const float depth = t_list[min(16 * tile + j, count - 1)];
+        px = __fadd_rn(R.ox, __fmul_rn(depth, R.dx)) * box_scale;
+        py = __fadd_rn(R.oy, __fmul_rn(depth, R.dy)) * box_scale;
+        pz = __fadd_rn(R.oz, __fmul_rn(depth, R.dz)) * box_scale;
+    }
+};
+
 // A tile's plane-gradient scatter that has not been issued yet: dX[16][32] sits in tbuf, its tap records in taps.
 // It is issued from inside the NEXT tile's lookup, after that tile's texel loads: the wave then waits only for the
 // loads, and the atomics drain while the next tile's MLP runs.  (Issued right after dX is produced, the next lookup's
@@ -84,19 +95,16 @@ __device__ __forceinline__ void bwd_scatter_chunk(const BwdLds& L, const BwdPend
 // 8 lanes per texel, 8 samples per step, blended features staged as X[sample][channel].  The records travel through
 // hbuf (free between tiles) because `taps` may still hold the pending scatter's records; with KEEP_TAPS they are
 // written to `taps` once the pending scatter has been issued.
-template <bool KEEP_TAPS>
-__device__ __forceinline__ void bwd_gather_tile(const Params& P, const BwdLds& L, const BwdRay& R, const float* t_list, int count, int tile,
-                                                BwdPending& pend, int lane) {
+// `pos(j, px, py, pz)` yields the position of sample j of the tile, already scaled into the planes' [-1,1] frame.
+template <bool KEEP_TAPS, class PosFn>
+__device__ __forceinline__ void bwd_gather_tile(const Params& P, const BwdLds& L, const char* planes, PosFn pos, BwdPending& pend, int lane) {
     const int H = P.p.plane_h, W = P.p.plane_w;
     uint4 my_off = make_uint4(0, 0, 0, 0);
     v4f my_wgt = {0.f, 0.f, 0.f, 0.f};
     if (lane < 48) {
         const int j = lane & 15, pl = lane >> 4;
-        const int idx = min(16 * tile + j, count - 1);
-        const float depth = t_list[idx];
-        const float px = __fadd_rn(R.ox, __fmul_rn(depth, R.dx)) * P.box_scale;
-        const float py = __fadd_rn(R.oy, __fmul_rn(depth, R.dy)) * P.box_scale;
-        const float pz = __fadd_rn(R.oz, __fmul_rn(depth, R.dz)) * P.box_scale;
+        float px, py, pz;
+        pos(j, px, py, pz);
         const float u = pl == 2 ? pz : px;
         const float v = pl == 0 ? py : (pl == 1 ? pz : px);
         plane_taps(H, W, u, v, unsigned(pl) * unsigned(H) * unsigned(W) * 128u, my_off, my_wgt);
@@ -115,10 +123,10 @@ __device__ __forceinline__ void bwd_gather_tile(const Params& P, const BwdLds& L
             const float* rec = L.hbuf + js * kTapDwords + pl * 8;
             const uint4 off = *reinterpret_cast<const uint4*>(rec);
             const v4f wgt = *reinterpret_cast<const v4f*>(rec + 4);
-            const v4f t00 = *reinterpret_cast<const v4f*>(R.planes + off.x + cq16);
-            const v4f t01 = *reinterpret_cast<const v4f*>(R.planes + off.y + cq16);
-            const v4f t10 = *reinterpret_cast<const v4f*>(R.planes + off.z + cq16);
-            const v4f t11 = *reinterpret_cast<const v4f*>(R.planes + off.w + cq16);
+            const v4f t00 = *reinterpret_cast<const v4f*>(planes + off.x + cq16);
+            const v4f t01 = *reinterpret_cast<const v4f*>(planes + off.y + cq16);
+            const v4f t10 = *reinterpret_cast<const v4f*>(planes + off.z + cq16);
+            const v4f t11 = *reinterpret_cast<const v4f*>(planes + off.w + cq16);
             if (pend.live > 0) bwd_scatter_chunk(L, pend, a, pl, lane);
             acc += t00 * wgt[0] + t01 * wgt[1] + t10 * wgt[2] + t11 * wgt[3];
         }
@@ -182,7 +190,7 @@ __device__ __forceinline__ void bwd_forward_tiles(const Params& P, const BwdLds&
                                                   const float (&G)[2], BwdPending& pend, int lane) {
     const int j = lane & 15, g = lane >> 4;
     for (int t = 0; t < ntiles; t++) {
-        bwd_gather_tile<false>(P, L, R, L.t_e + e0, count, t, pend, lane);
+        bwd_gather_tile<false>(P, L, R.planes, RayTilePos{R, L.t_e + e0, count, t, P.box_scale}, pend, lane);
         v4f h[4], o[2];
         float sig;
         bwd_mlp_forward(L, lane, h, o, sig);
@@ -205,11 +213,83 @@ struct BwdAcc {
     float b2s;        // db2[0], partial
 };
 
+// The decoder's backward pass for one staged tile.  On entry: X in `stage`, dO[16][32] (colour pre-activation gradients)
+// in `tbuf`, h = the hidden activations (H^T layout), dsig = dL/dsigma of this lane's sample.  Accumulates the weight
+// gradients into A and leaves dX[16][32] in `tbuf`.
+__device__ __forceinline__ void bwd_tile_core(const BwdLds& L, v4f (&h)[4], float dsig, BwdAcc& A, int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    if (g == 0) A.b2s += dsig;
+    lds_wave_sync();
+    // ---- dH^T[hidden][sample] = sum_out W2[out][hidden] dO[sample][out]  (+ the density row on the vector ALU)
+    v4f dh[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const v4f ws = *reinterpret_cast<const v4f*>(L.w2 + 16 * m + 4 * g);
+        dh[m] = ws * dsig;
+        A.w2s[m] += h[m] * dsig;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const float bT = L.tbuf[j * kTPitch + 4 * s + g];
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+            dh[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(L.w2[(1 + 4 * s + g) * kW2Pitch + 16 * m + j], bT, dh[m], 0, 0, 0);
+    }
+    // ---- through softplus: d/dpre softplus(pre) = 1 - exp(-softplus(pre))
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) dh[m][r] *= 1.f - exp_hw(-h[m][r]);
+        A.b1[m] += dh[m];
+        *reinterpret_cast<v4f*>(L.hbuf + j * kHPitch + 16 * m + 4 * g) = h[m];
+    }
+    lds_wave_sync();
+    // ---- dW2[out][hidden] += sum_sample dO[sample][out] H[sample][hidden]
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float a0 = L.tbuf[(4 * g + r) * kTPitch + j], a1 = L.tbuf[(4 * g + r) * kTPitch + 16 + j];
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const float bh = L.hbuf[(4 * g + r) * kHPitch + 16 * n + j];
+            A.w2[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bh, A.w2[0][n], 0, 0, 0);
+            A.w2[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bh, A.w2[1][n], 0, 0, 0);
+        }
+    }
+    lds_wave_sync();
+    // ---- dX^T[channel][sample] = sum_hidden W1[hidden][channel] dPRE^T[hidden][sample]
+    v4f dx[2];
+    dx[0] = dx[1] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float* row = L.w1 + (16 * m + 4 * g + r) * kW1Pitch + j;
+            dx[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(row[0], dh[m][r], dx[0], 0, 0, 0);
+            dx[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(row[16], dh[m][r], dx[1], 0, 0, 0);
+        }
+        *reinterpret_cast<v4f*>(L.hbuf + j * kHPitch + 16 * m + 4 * g) = dh[m];             // dPRE[sample][hidden]
+    }
+    *reinterpret_cast<v4f*>(L.tbuf + j * kTPitch + 4 * g) = dx[0];                            // dX[sample][channel]
+    *reinterpret_cast<v4f*>(L.tbuf + j * kTPitch + 16 + 4 * g) = dx[1];
+    lds_wave_sync();
+    // ---- dW1[hidden][channel] += sum_sample dPRE[sample][hidden] X[sample][channel]
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float b0 = L.stage[(4 * g + r) * kStagePitch + j], b1 = L.stage[(4 * g + r) * kStagePitch + 16 + j];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const float ap = L.hbuf[(4 * g + r) * kHPitch + 16 * m + j];
+            A.w1[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap, b0, A.w1[m][0], 0, 0, 0);
+            A.w1[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap, b1, A.w1[m][1], 0, 0, 0);
+        }
+    }
+}
+
 __device__ __forceinline__ void bwd_backward_tiles(const Params& P, const BwdLds& L, const BwdRay& R, float* grad_planes_item,
                                                    int e0, int count, int ntiles, const float (&G)[2], BwdAcc& A, BwdPending& pend, int lane) {
     const int j = lane & 15, g = lane >> 4;
     for (int t = 0; t < ntiles; t++) {
-        bwd_gather_tile<true>(P, L, R, L.t_e + e0, count, t, pend, lane);
+        bwd_gather_tile<true>(P, L, R.planes, RayTilePos{R, L.t_e + e0, count, t, P.box_scale}, pend, lane);
 #ifdef GNERF_ABLATE_BWDMLP      // timing-only build: lookup + scatter without the decoder's backward pass (wrong results)
         for (int i = lane; i < 16 * kTPitch; i += 64) L.tbuf[i] = L.stage[i];
         if (grad_planes_item) { pend.base = grad_planes_item; pend.live = min(16, count - 16 * t); }
@@ -233,75 +313,56 @@ __device__ __forceinline__ void bwd_backward_tiles(const Params& P, const BwdLds
                 A.b2[n] += d;
             }
         }
-        if (g == 0) A.b2s += dsig;
-        lds_wave_sync();
-        // ---- dH^T[hidden][sample] = sum_out W2[out][hidden] dO[sample][out]  (+ the density row on the vector ALU)
-        v4f dh[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const v4f ws = *reinterpret_cast<const v4f*>(L.w2 + 16 * m + 4 * g);
-            dh[m] = ws * dsig;
-            A.w2s[m] += h[m] * dsig;
-        }
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-            const float bT = L.tbuf[j * kTPitch + 4 * s + g];
-#pragma unroll
-            for (int m = 0; m < 4; m++)
-                dh[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(L.w2[(1 + 4 * s + g) * kW2Pitch + 16 * m + j], bT, dh[m], 0, 0, 0);
-        }
-        // ---- through softplus: d/dpre softplus(pre) = 1 - exp(-softplus(pre))
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) dh[m][r] *= 1.f - exp_hw(-h[m][r]);
-            A.b1[m] += dh[m];
-            *reinterpret_cast<v4f*>(L.hbuf + j * kHPitch + 16 * m + 4 * g) = h[m];
-        }
-        lds_wave_sync();
-        // ---- dW2[out][hidden] += sum_sample dO[sample][out] H[sample][hidden]
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float a0 = L.tbuf[(4 * g + r) * kTPitch + j], a1 = L.tbuf[(4 * g + r) * kTPitch + 16 + j];
-#pragma unroll
-            for (int n = 0; n < 4; n++) {
-                const float bh = L.hbuf[(4 * g + r) * kHPitch + 16 * n + j];
-                A.w2[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bh, A.w2[0][n], 0, 0, 0);
-                A.w2[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bh, A.w2[1][n], 0, 0, 0);
-            }
-        }
-        lds_wave_sync();
-        // ---- dX^T[channel][sample] = sum_hidden W1[hidden][channel] dPRE^T[hidden][sample]
-        v4f dx[2];
-        dx[0] = dx[1] = (v4f){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float* row = L.w1 + (16 * m + 4 * g + r) * kW1Pitch + j;
-                dx[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(row[0], dh[m][r], dx[0], 0, 0, 0);
-                dx[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(row[16], dh[m][r], dx[1], 0, 0, 0);
-            }
-            *reinterpret_cast<v4f*>(L.hbuf + j * kHPitch + 16 * m + 4 * g) = dh[m];             // dPRE[sample][hidden]
-        }
-        *reinterpret_cast<v4f*>(L.tbuf + j * kTPitch + 4 * g) = dx[0];                            // dX[sample][channel]
-        *reinterpret_cast<v4f*>(L.tbuf + j * kTPitch + 16 + 4 * g) = dx[1];
-        lds_wave_sync();
-        // ---- dW1[hidden][channel] += sum_sample dPRE[sample][hidden] X[sample][channel]
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float b0 = L.stage[(4 * g + r) * kStagePitch + j], b1 = L.stage[(4 * g + r) * kStagePitch + 16 + j];
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const float ap = L.hbuf[(4 * g + r) * kHPitch + 16 * m + j];
-                A.w1[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap, b0, A.w1[m][0], 0, 0, 0);
-                A.w1[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap, b1, A.w1[m][1], 0, 0, 0);
-            }
-        }
+        bwd_tile_core(L, h, dsig, A, lane);
         // ---- dX goes to the plane gradient from inside the next lookup (see BwdPending)
         if (grad_planes_item) { pend.base = grad_planes_item; pend.live = min(16, count - 16 * t); }
         lds_wave_sync();
     }
+}
+
+// Decoder gradients: wave registers -> workgroup LDS (aliases the staged decoder) -> one global atomic per element.
+// Every thread of the workgroup must call (barriers inside).
+__device__ __forceinline__ void bwd_reduce_decoder_grads(const BwdAcc& A, float* smem, float* grad_w1, float* grad_b1, float* grad_w2, float* grad_b2,
+                                                         int tid, int lane, int j) {
+    if (!grad_w1) return;
+    __syncthreads();                                   // every wave is done with the LDS decoder
+    float* red = smem;
+    float* red_w1 = red, *red_b1 = red_w1 + 64 * 32, *red_w2 = red_b1 + 64, *red_b2 = red_w2 + 33 * 64;
+    for (int i = tid; i < kBwdGradFloats; i += kBwdThreads) red[i] = 0.f;
+    __syncthreads();
+    {
+        const int g = lane >> 4;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int hid = 16 * m + 4 * g + r;
+                atomicAdd(red_w1 + hid * 32 + j, A.w1[m][0][r]);
+                atomicAdd(red_w1 + hid * 32 + 16 + j, A.w1[m][1][r]);
+                const float s0 = row_total(A.w2s[m][r]), s1 = row_total(A.b1[m][r]);
+                if (j == 15) { atomicAdd(red_w2 + hid, s0); atomicAdd(red_b1 + hid, s1); }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) atomicAdd(red_w2 + (1 + 16 * o + 4 * g + r) * 64 + 16 * n + j, A.w2[o][n][r]);
+            }
+            float s = A.b2[o];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (g == 0) atomicAdd(red_b2 + 1 + 16 * o + j, s);
+        }
+        const float s = wave_sum(A.b2s);
+        if (lane == 0) atomicAdd(red_b2, s);
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * 32; i += kBwdThreads) unsafeAtomicAdd(grad_w1 + i, red_w1[i]);
+    for (int i = tid; i < 33 * 64; i += kBwdThreads) unsafeAtomicAdd(grad_w2 + i, red_w2[i]);
+    if (tid < 64) unsafeAtomicAdd(grad_b1 + tid, red_b1[tid]);
+    if (tid < 33) unsafeAtomicAdd(grad_b2 + tid, red_b2[tid]);
 }
 
 __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gnerf_render_grads Gr) {
@@ -474,44 +535,84 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gn
             for (int pl = 0; pl < 3; pl++) bwd_scatter_chunk(L, pend, a, pl, lane);
     }
 
-    // ---- decoder gradients: wave registers -> workgroup LDS -> global atomics
-    if (!Gr.grad_w1) return;
-    __syncthreads();                                   // every wave is done with the LDS decoder
-    float* red = smem;
-    float* red_w1 = red, *red_b1 = red_w1 + 64 * 32, *red_w2 = red_b1 + 64, *red_b2 = red_w2 + 33 * 64;
-    for (int i = tid; i < kBwdGradFloats; i += kBwdThreads) red[i] = 0.f;
+    bwd_reduce_decoder_grads(A, smem, Gr.grad_w1, Gr.grad_b1, Gr.grad_w2, Gr.grad_b2, tid, lane, j);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward of run_model for arbitrary points (renderer.py:142-148; TriPlaneGenerator.sample_mixed, which the density
+// regulariser of training differentiates): the gradient arrives per point -- dL/dsigma [n_items, n_points, 1] and
+// dL/drgb [n_items, n_points, 32] -- so there is no composite to undo; each wave takes 16-point tiles through the same
+// lookup + MLP forward + decoder backward + deferred plane scatter as the renderer's backward.
+struct QueryBwdArgs {
+    const float* points; const float* grad_sigma; const float* grad_rgb;      // any of the two gradients may be NULL
+    int n_points, tiles_per_item, n_tiles;
+    float* grad_planes_nhwc; float* grad_w1; float* grad_b1; float* grad_w2; float* grad_b2;
+};
+
+struct PointTilePos {
+    const float* pts; int n_points, tile; float box_scale;
+    __device__ __forceinline__ void operator()(int j, float& px, float& py, float& pz) const {
+        const int idx = min(16 * tile + j, n_points - 1);
+        px = pts[idx * 3 + 0] * box_scale; py = pts[idx * 3 + 1] * box_scale; pz = pts[idx * 3 + 2] * box_scale;
+    }
+};
+
+__global__ __launch_bounds__(kBwdThreads, 2) void query_bwd_kernel(Params P, QueryBwdArgs Q) {
+    extern __shared__ __align__(16) float smem[];
+    const gnerf_render_params& p = P.p;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* w1 = smem;
+    float* w2 = w1 + 64 * kW1Pitch;
+    float* b1 = w2 + 33 * kW2Pitch;
+    float* b2 = b1 + 64;
+    for (int i = tid; i < 64 * 32; i += kBwdThreads) w1[(i >> 5) * kW1Pitch + (i & 31)] = p.w1[i];
+    for (int i = tid; i < 33 * 64; i += kBwdThreads) w2[(i >> 6) * kW2Pitch + (i & 63)] = p.w2[i];
+    if (tid < 64) b1[tid] = p.b1[tid];
+    if (tid < 36) b2[tid] = tid < 33 ? p.b2[tid] : 0.f;
     __syncthreads();
-    {
-        const int g = lane >> 4;
+    BwdLds L = {};
+    L.w1 = w1; L.w2 = w2; L.b1 = b1; L.b2 = b2;
+    float* base = smem + kBwdWeightFloats + size_t(wv) * bwd_wave_floats(0);
+    L.stage = base; L.tbuf = L.stage + 16 * kStagePitch; L.hbuf = L.tbuf + 16 * kTPitch; L.taps = L.hbuf + 16 * kHPitch;
+    BwdAcc A;
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
+    for (int m = 0; m < 4; m++) A.w1[m][0] = A.w1[m][1] = A.w2[0][m] = A.w2[1][m] = A.w2s[m] = A.b1[m] = (v4f){0.f, 0.f, 0.f, 0.f};
+    A.b2[0] = A.b2[1] = A.b2s = 0.f;
+    BwdPending pend = {nullptr, 0};
+    const int j = lane & 15, g = lane >> 4;
+    const int64_t plane_floats = int64_t(3) * p.plane_h * p.plane_w * 32;
+    for (int tile = blockIdx.x * kBwdWaves + wv; tile < Q.n_tiles; tile += gridDim.x * kBwdWaves) {
+        const int item = tile / Q.tiles_per_item, t = tile % Q.tiles_per_item;
+        const char* planes = reinterpret_cast<const char*>(p.planes_nhwc + int64_t(item) * plane_floats);
+        const float* pts = Q.points + int64_t(item) * Q.n_points * 3;
+        bwd_gather_tile<true>(P, L, planes, PointTilePos{pts, Q.n_points, t, P.box_scale}, pend, lane);
+        v4f h[4], o[2];
+        float sig;
+        bwd_mlp_forward(L, lane, h, o, sig);
+        const int64_t pt0 = int64_t(item) * Q.n_points + 16 * t;
+        const float dsig = (Q.grad_sigma && 16 * t + j < Q.n_points) ? Q.grad_sigma[pt0 + j] : 0.f;
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int hid = 16 * m + 4 * g + r;
-                atomicAdd(red_w1 + hid * 32 + j, A.w1[m][0][r]);
-                atomicAdd(red_w1 + hid * 32 + 16 + j, A.w1[m][1][r]);
-                const float s0 = row_total(A.w2s[m][r]), s1 = row_total(A.b1[m][r]);
-                if (j == 15) { atomicAdd(red_w2 + hid, s0); atomicAdd(red_b1 + hid, s1); }
+                const int q = 4 * g + r;
+                const float gc = (Q.grad_rgb && 16 * t + q < Q.n_points) ? Q.grad_rgb[(pt0 + q) * 32 + 16 * n + j] : 0.f;
+                const float e = __builtin_amdgcn_exp2f(o[n][r] * -1.44269504088896341f);
+                const float s = __builtin_amdgcn_rcpf(1.0f + e);
+                const float d = gc * (1.002f * s * (1.f - s));                  // rgb = 1.002 sigmoid(o) - 0.001 (triplane.py:134)
+                L.tbuf[q * kTPitch + 16 * n + j] = d;
+                A.b2[n] += d;
             }
         }
-#pragma unroll
-        for (int o = 0; o < 2; o++) {
-#pragma unroll
-            for (int n = 0; n < 4; n++) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) atomicAdd(red_w2 + (1 + 16 * o + 4 * g + r) * 64 + 16 * n + j, A.w2[o][n][r]);
-            }
-            float s = A.b2[o];
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (g == 0) atomicAdd(red_b2 + 1 + 16 * o + j, s);
-        }
-        const float s = wave_sum(A.b2s);
-        if (lane == 0) atomicAdd(red_b2, s);
+        bwd_tile_core(L, h, dsig, A, lane);
+        if (Q.grad_planes_nhwc) { pend.base = Q.grad_planes_nhwc + int64_t(item) * plane_floats; pend.live = min(16, Q.n_points - 16 * t); }
+        lds_wave_sync();
     }
-    __syncthreads();
-    for (int i = tid; i < 64 * 32; i += kBwdThreads) unsafeAtomicAdd(Gr.grad_w1 + i, red_w1[i]);
-    for (int i = tid; i < 33 * 64; i += kBwdThreads) unsafeAtomicAdd(Gr.grad_w2 + i, red_w2[i]);
-    if (tid < 64) unsafeAtomicAdd(Gr.grad_b1 + tid, red_b1[tid]);
-    if (tid < 33) unsafeAtomicAdd(Gr.grad_b2 + tid, red_b2[tid]);
+    if (pend.live > 0) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) bwd_scatter_chunk(L, pend, a, pl, lane);
+    }
+    bwd_reduce_decoder_grads(A, smem, Q.grad_w1, Q.grad_b1, Q.grad_w2, Q.grad_b2, tid, lane, j);
 }

@@ -72,6 +72,8 @@ SIGNATURES = {
     'gnerf_render_forward': (_c_i, [ctypes.POINTER(RenderParams), _c_p]),
     'gnerf_render_backward': (_c_i, [ctypes.POINTER(RenderParams), ctypes.POINTER(RenderGrads), _c_p]),
     'gnerf_query_points': (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    'gnerf_query_points_backward': (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
+                                           _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
 }
 
 
@@ -429,3 +431,34 @@ def query_points(planes_nhwc, n_items, decoder, points, box_warp):
                                          float(box_warp), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(sigma), _ptr(rgb), _stream(pts))
     _check(code, 'gnerf_query_points')
     return sigma, rgb
+
+
+def query_points_backward(planes_nhwc, n_items, decoder, points, box_warp, grad_sigma, grad_rgb, need_planes=True, need_decoder=True):
+    """Gradient of query_points for the same arguments: grad_sigma [N,P,1] / grad_rgb [N,P,32] (either may be None).
+    Returns (grad_planes_nhwc or None, (grad_w1, grad_b1, grad_w2, grad_b2) or None), float32."""
+    w1, b1, w2, b2 = [t.to(torch.float32).contiguous() for t in decoder]
+    _require_cuda(planes_nhwc, points, w1, grad_sigma, grad_rgb)
+    if planes_nhwc.dtype != torch.float32 or not planes_nhwc.is_contiguous() or planes_nhwc.ndim != 4 or planes_nhwc.shape[3] != 32 \
+            or planes_nhwc.shape[0] != 3 * n_items:
+        raise RuntimeError('query_points_backward: planes_nhwc must be contiguous float32 [3N,H,W,32]')
+    pts = points.to(torch.float32).contiguous()
+    if pts.ndim != 3 or pts.shape[0] != n_items or pts.shape[2] != 3:
+        raise RuntimeError('query_points_backward: points must be [N,P,3]')
+    n_pts = pts.shape[1]
+    gs = None if grad_sigma is None else grad_sigma.to(torch.float32).contiguous()
+    gc = None if grad_rgb is None else grad_rgb.to(torch.float32).contiguous()
+    if (gs is not None and gs.numel() != n_items * n_pts) or (gc is not None and gc.numel() != n_items * n_pts * 32):
+        raise RuntimeError('query_points_backward: output gradients must match the forward outputs')
+    dev = pts.device
+    g_planes = torch.zeros_like(planes_nhwc) if need_planes else None
+    g_dec = None
+    if need_decoder:
+        g_dec = (torch.zeros([64, 32], dtype=torch.float32, device=dev), torch.zeros([64], dtype=torch.float32, device=dev),
+                 torch.zeros([33, 64], dtype=torch.float32, device=dev), torch.zeros([33], dtype=torch.float32, device=dev))
+    gd = g_dec if g_dec is not None else (None, None, None, None)
+    with _on_device(dev):
+        code = load().gnerf_query_points_backward(_ptr(planes_nhwc), n_items, planes_nhwc.shape[1], planes_nhwc.shape[2], _ptr(pts), n_pts,
+                                                  float(box_warp), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(gs), _ptr(gc),
+                                                  _ptr(g_planes), _ptr(gd[0]), _ptr(gd[1]), _ptr(gd[2]), _ptr(gd[3]), _stream(pts))
+    _check(code, 'gnerf_query_points_backward')
+    return g_planes, g_dec

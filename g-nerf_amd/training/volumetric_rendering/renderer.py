@@ -13,9 +13,12 @@ inside an autograd.Function whose backward is the second kernel (gnerf_hip.rende
 recomputes the ray's forward pass and keeps nothing between the passes, where upstream autograd saves
 every intermediate of the op chain (~3 GB at the training shape).
 
+`run_model` (arbitrary points: sample / sample_mixed, incl. the density regulariser of training) has the
+same pair of kernels (query_points / query_points_backward).
+
 The PyTorch-op form below is what runs for CPU tensors (the reference's own behaviour: all of its
-renderer is PyTorch ops), when the rays themselves need a gradient, or when `decoder` is not the
-OSGDecoder 32->64->33 MLP.  A GPU call never silently degrades because the native library is absent:
+renderer is PyTorch ops), when the rays or points themselves need a gradient, or when `decoder` is
+not the OSGDecoder 32->64->33 MLP.  A GPU call never silently degrades because the native library is absent:
 gnerf_hip raises.
 """
 
@@ -130,6 +133,38 @@ class _FusedRender(torch.autograd.Function):
         grads = [None] * 12
         if need_planes:
             grads[0] = gnerf_hip.planes_from_nhwc(g_planes, N).to(planes.dtype)     # contiguous NCHW, like the planes themselves
+        if need_decoder:
+            for i, (g, t) in enumerate(zip(g_dec, (w1, b1, w2, b2))):
+                if ctx.needs_input_grad[1 + i]:
+                    grads[1 + i] = g.to(t.dtype)
+        return tuple(grads)
+
+
+class _FusedQuery(torch.autograd.Function):
+    """query_points / query_points_backward as one differentiable op (run_model for arbitrary points): gradients for the
+    planes and the decoder's effective weights, none for the points."""
+
+    @staticmethod
+    def forward(ctx, planes, w1, b1, w2, b2, points, box_warp):
+        nhwc = gnerf_hip.planes_to_nhwc(planes.detach().float())
+        sigma, rgb = gnerf_hip.query_points(nhwc, planes.shape[0], (w1, b1, w2, b2), points, box_warp)
+        ctx.save_for_backward(planes, w1, b1, w2, b2, points)
+        ctx.box_warp = box_warp
+        return sigma, rgb
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_sigma, g_rgb):
+        planes, w1, b1, w2, b2, points = ctx.saved_tensors
+        need_planes = ctx.needs_input_grad[0]
+        need_decoder = any(ctx.needs_input_grad[1:5])
+        N = planes.shape[0]
+        nhwc = gnerf_hip.planes_to_nhwc(planes.detach().float())
+        g_planes, g_dec = gnerf_hip.query_points_backward(nhwc, N, (w1, b1, w2, b2), points, ctx.box_warp, g_sigma, g_rgb,
+                                                          need_planes=need_planes, need_decoder=need_decoder)
+        grads = [None] * 7
+        if need_planes:
+            grads[0] = gnerf_hip.planes_from_nhwc(g_planes, N).to(planes.dtype)
         if need_decoder:
             for i, (g, t) in enumerate(zip(g_dec, (w1, b1, w2, b2))):
                 if ctx.needs_input_grad[1 + i]:
@@ -264,14 +299,20 @@ class ImportanceRenderer(torch.nn.Module):
         density_noise = options.get('density_noise', 0)
         if planes.device.type == 'cuda' and planes.ndim == 5 and planes.shape[1] == 3 and planes.shape[2] == 32:
             fcs = _osg_decoder_weights(decoder)
-            needs_graph = torch.is_grad_enabled() and (planes.requires_grad or sample_coordinates.requires_grad
-                                                       or any(p.requires_grad for p in decoder.parameters()))
-            if fcs is not None and not needs_graph:
-                sigma, rgb = gnerf_hip.query_points(self._planes_nhwc(planes), planes.shape[0], self._decoder_cache(fcs),
-                                                    sample_coordinates.detach(), options['box_warp'])
+            points_need_grad = torch.is_grad_enabled() and sample_coordinates.requires_grad
+            if fcs is not None and not points_need_grad:
+                needs_graph = torch.is_grad_enabled() and (planes.requires_grad or any(p.requires_grad for p in decoder.parameters()))
+                if needs_graph:
+                    fc1, fc2 = fcs
+                    eff = (fc1.weight.float() * fc1.weight_gain, fc1.bias.float() * fc1.bias_gain,      # networks_stylegan2.py:121-127
+                           fc2.weight.float() * fc2.weight_gain, fc2.bias.float() * fc2.bias_gain)
+                    sigma, rgb = _FusedQuery.apply(planes, *eff, sample_coordinates.detach(), options['box_warp'])
+                else:
+                    sigma, rgb = gnerf_hip.query_points(self._planes_nhwc(planes), planes.shape[0], self._decoder_cache(fcs),
+                                                        sample_coordinates.detach(), options['box_warp'])
                 out = {'rgb': rgb, 'sigma': sigma}
                 if density_noise > 0:
-                    out['sigma'] += torch.randn_like(out['sigma']) * density_noise
+                    out['sigma'] = out['sigma'] + torch.randn_like(out['sigma']) * density_noise
                 return out
         feats = sample_from_planes(self.plane_axes, planes, sample_coordinates, padding_mode='zeros', box_warp=options['box_warp'])
         out = decoder(feats, sample_directions)

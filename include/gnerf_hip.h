@@ -189,6 +189,16 @@ int gnerf_query_points(const float* planes_nhwc, int n_items, int plane_h, int p
                        const float* w1, const float* b1, const float* w2, const float* b2,
                        float* out_sigma, float* out_rgb, gnerf_stream_t stream);
 
+/* Gradient of gnerf_query_points: grad_sigma [n_items, n_points, 1] and grad_rgb [n_items, n_points, 32] (either may be
+ * NULL) -> ACCUMULATED into grad_planes_nhwc and the four decoder gradients (same conventions as gnerf_render_backward).
+ * Points get no gradient.  Upstream: autograd through renderer.py:142-148 (sample_mixed in the density regulariser). */
+int gnerf_query_points_backward(const float* planes_nhwc, int n_items, int plane_h, int plane_w,
+                                const float* points, int n_points, float box_warp,
+                                const float* w1, const float* b1, const float* w2, const float* b2,
+                                const float* grad_sigma, const float* grad_rgb,
+                                float* grad_planes_nhwc, float* grad_w1, float* grad_b1, float* grad_w2, float* grad_b2,
+                                gnerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

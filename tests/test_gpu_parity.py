@@ -443,6 +443,61 @@ def test_importance_renderer_training_step_on_gpu(dev, golden, case):
     assert _rel(planes.grad, _oracle_free_planes_grad(results, g_rgb, ren, dec, g, o, d, opts, dev)) < 2e-3
 
 
+def test_query_points_backward_vs_oracle(dev):
+    """gnerf_query_points_backward against autograd through the fp64 oracle's query_points, and the drop-in run_model
+    under autograd against the PyTorch-op path (ragged point count: partial last tile)."""
+    import gnerf_hip
+    from oracle import render_ref as R
+    gen = torch.Generator().manual_seed(9)
+    N, P_, hw = 2, 70, (24, 20)
+    planes = torch.randn(N, 3, 32, *hw, generator=gen) * 1.5
+    dec = R.fold_decoder(torch.randn(64, 32, generator=gen), torch.randn(64, generator=gen) * 0.2,
+                         torch.randn(33, 64, generator=gen), torch.randn(33, generator=gen) * 0.2)
+    pts = (torch.rand(N, P_, 3, generator=gen) - 0.5) * 1.1          # some points outside the box: zero-padded taps
+    g_sigma = torch.randn(N, P_, 1, generator=gen)
+    g_rgb = torch.randn(N, P_, 32, generator=gen)
+    pl = planes.double().requires_grad_(True)
+    dc = [t.double().requires_grad_(True) for t in dec]
+    sig, rgb = R.query_points(pl, dc, pts.double(), 1.0)
+    ((sig * g_sigma.double()).sum() + (rgb * g_rgb.double()).sum()).backward()
+    nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
+    gp, gdec = gnerf_hip.query_points_backward(nhwc, N, [t.to(dev) for t in dec], pts.to(dev), 1.0, g_sigma.to(dev), g_rgb.to(dev))
+    assert _rel(gnerf_hip.planes_from_nhwc(gp, N).cpu(), pl.grad) < 2e-3
+    for a, b in zip(gdec, dc):
+        assert _rel(a.cpu(), b.grad) < 2e-3
+    # sigma-only gradient, planes only
+    gp2, none_dec = gnerf_hip.query_points_backward(nhwc, N, [t.to(dev) for t in dec], pts.to(dev), 1.0, g_sigma.to(dev), None, need_decoder=False)
+    assert none_dec is None
+    pl2 = planes.double().requires_grad_(True)
+    (R.query_points(pl2, [t.double() for t in dec], pts.double(), 1.0)[0] * g_sigma.double()).sum().backward()
+    assert _rel(gnerf_hip.planes_from_nhwc(gp2, N).cpu(), pl2.grad) < 2e-3
+
+
+def test_run_model_training_on_gpu(dev, golden):
+    from training.volumetric_rendering.renderer import ImportanceRenderer, sample_from_planes
+    from test_host_cpu import Decoder, options_of
+    g = golden('render_s12.npz')
+    ren = ImportanceRenderer().to(dev)
+    dec = Decoder(g).to(dev).requires_grad_(True)
+    opts = options_of(g)
+    pts = (torch.rand(g['planes'].shape[0], 50, 3, device=dev) - 0.5)
+    gs, gc = torch.randn(pts.shape[0], 50, 1, device=dev), torch.randn(pts.shape[0], 50, 32, device=dev)
+    res = []
+    for fused in (True, False):
+        planes = _t(g['planes'], dev).requires_grad_(True)
+        dec.zero_grad(set_to_none=True)
+        if fused:
+            out = ren.run_model(planes, dec, pts, torch.zeros_like(pts), opts)
+            assert type(out['sigma'].grad_fn).__name__.startswith('_FusedQuery')
+        else:
+            out = dec(sample_from_planes(ren.plane_axes.to(dev), planes, pts, padding_mode='zeros', box_warp=opts['box_warp']), None)
+        ((out['sigma'] * gs).sum() + (out['rgb'] * gc).sum()).backward()
+        res.append((planes.grad.clone(), [p.grad.clone() for p in dec.parameters()]))
+    assert _rel(res[0][0], res[1][0]) < 2e-3
+    for a, b in zip(res[0][1], res[1][1]):
+        assert _rel(a, b) < 2e-3
+
+
 # ---------------------------------------------------------------------------- ops
 
 
