@@ -618,6 +618,31 @@ def test_upfirdn2d_shapes_vs_oracle(dev, dtype):
     np.testing.assert_allclose(upfirdn2d.downsample2d(x, f).cpu().numpy(), O.upfirdn2d(x.cpu().numpy(), fn, down=2, padding=[1, 1, 1, 1]), atol=2e-6)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_upfirdn2d_blur_edge_shapes(dev, dtype):
+    """The streaming 4x4 kernel (up = down = 1) at the shapes that stress its edges: images narrower than a lane's 16
+    bytes, fewer rows than a block of four, widths that leave the last lane partial, many tiny images per wave (sub-strips),
+    asymmetric / negative / large padding, flipped filter, a non-symmetric filter, and the first/last elements of the tensor
+    (guarded path)."""
+    from torch_utils.ops import upfirdn2d
+    from oracle import ops_ref as O
+    torch.manual_seed(5)
+    tol = {torch.float32: 2e-5, torch.float16: 6e-3}[dtype]
+    f_sym = upfirdn2d.setup_filter([1, 3, 3, 1], device=dev)
+    f_any = torch.randn(4, 4, generator=torch.Generator().manual_seed(1)).to(dev)
+    cases = [((1, 1, 4, 4), [1, 1, 1, 1]), ((1, 1, 3, 3), [2, 1, 2, 1]), ((3, 5, 5, 9), [1, 1, 1, 1]), ((2, 7, 2, 37), [2, 1, 3, 2]),
+             ((1, 2, 9, 1), [3, 3, 1, 1]), ((40, 3, 6, 6), [1, 2, 2, 1]), ((1, 1, 70, 1030), [1, 1, 1, 1]), ((2, 2, 33, 257), [0, 3, 3, 0]),
+             ((1, 3, 12, 20), [-1, 2, 4, -2]), ((1, 1, 8, 8), [5, 5, 5, 5])]
+    for shape, pad in cases:
+        for f, flip in ((f_sym, False), (f_any, False), (f_any, True)):
+            x = torch.randn(*shape, dtype=torch.float64).to(dtype)
+            y = upfirdn2d.upfirdn2d(x.to(dev), f, padding=pad, flip_filter=flip, gain=1.7)
+            ref = O.upfirdn2d(x.double().numpy(), f.cpu().numpy(), padding=pad, flip_filter=flip, gain=1.7)
+            assert tuple(y.shape) == ref.shape, (shape, pad)
+            scale = max(1.0, float(np.abs(ref).max()))
+            np.testing.assert_allclose(y.double().cpu().numpy(), ref, rtol=tol, atol=tol * scale, err_msg=str((shape, pad, flip)))
+
+
 def test_upfirdn2d_linearity_at_full_size(dev):
     """[4,128,513,513] -> 512x512 blur (the largest call of a G-NeRF forward, fp16): too big for the numpy oracle;
     upfirdn is linear, so f(a*x + y) == a*f(x) + f(y), and a constant image maps to the filter's DC gain away from edges."""
