@@ -48,6 +48,7 @@ struct Params {
     int n_tiles;            // ray tiles in the grid
     int tiles_per_item, tiles_y;   // image tiling (0 when rays are not an image)
     int total_rays;
+    int split_shift;        // small launches: a 16-ray tile is shared by 1 << split_shift workgroups (coop / generic kernels)
 };
 
 // ---- order-preserving float <-> uint so that integer atomics give float min/max
@@ -396,9 +397,12 @@ __global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
 
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
     // contiguous run of ray tiles (its L2 then sees neighbouring rays).  Speed only.
-    const int per_xcd = (P.n_tiles + kNumXCD - 1) / kNumXCD;
-    const int tile = (blockIdx.x % kNumXCD) * per_xcd + blockIdx.x / kNumXCD;
-    if (tile >= P.n_tiles) return;
+    const int n_groups = P.n_tiles << P.split_shift;
+    const int per_xcd = (n_groups + kNumXCD - 1) / kNumXCD;
+    const int group = (blockIdx.x % kNumXCD) * per_xcd + blockIdx.x / kNumXCD;
+    if (group >= n_groups) return;
+    const int tile = group >> P.split_shift;
+    const int rr_count = kRaysPerWave >> P.split_shift, rr_first = (group & ((1 << P.split_shift) - 1)) * rr_count;
 
     Weights w;
     load_weights(w, p, lane);
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
     const int n_all = S + F;
     float blk_min = INFINITY, blk_max = -INFINITY;
 
-    for (int rr = 0; rr < kRaysPerWave; rr++) {
+    for (int rr = rr_first; rr < rr_first + rr_count; rr++) {
         // ---- which ray
         int64_t ray;
         if (P.tiles_per_item > 0) {             // 4x4 pixel tiles, walked down image columns
@@ -648,6 +652,7 @@ static int fill_params(const gnerf_render_params* p, Params& P) {
     P.tiles_c = (S + 15) / 16;
     P.tiles_f = (F + 15) / 16;
     P.total_rays = int(total);
+    P.split_shift = 0;
     const int iw = p->image_width;
     if (iw > 0 && iw % 4 == 0 && p->rays_per_item % iw == 0 && (p->rays_per_item / iw) % 4 == 0) {
         P.tiles_y = p->rays_per_item / iw / 4;
@@ -671,7 +676,12 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
     const int64_t total = P.total_rays;
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(init_range_kernel, dim3(1), dim3(1), 0, s, static_cast<unsigned*>(p->workspace));
-    const int per_xcd = (P.n_tiles + kNumXCD - 1) / kNumXCD;
+    // Small launches (one 64x64 frame of gen_videos.py is 256 ray tiles on 256 CUs): a workgroup walking its 16 rays one
+    // after the other leaves most of the chip idle and the launch takes 16 ray latencies.  Split each tile over up to four
+    // workgroups while that still fits the chip in one wave of workgroups.
+    P.split_shift = 0;
+    while (P.split_shift < 2 && (int64_t(P.n_tiles) << (P.split_shift + 1)) <= int64_t(kNumCU) * 4) P.split_shift++;
+    const int per_xcd = ((P.n_tiles << P.split_shift) + kNumXCD - 1) / kNumXCD;
     const dim3 grid(per_xcd * kNumXCD);
     // Kernel choice (GNERF_RENDER_KERNEL=pipe|coop|generic forces one, for A/B runs):
     //   pipe    3 shader waves + 1 scalar wave, three rays in flight: up to 48+48 samples with importance sampling
@@ -686,7 +696,9 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
     if (force && !strcmp(force, "pipe") && !pipe) return fail(GNERF_E_UNSUPPORTED, "render: pipelined kernel does not cover %d+%d samples", S, F);
     if (pipe) {
         const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : total;
-        int64_t g = (total_seq / 24 + kNumXCD - 1) / kNumXCD * kNumXCD;         // >= ~24 rays per workgroup amortise the pipeline fill
+        // one dealing unit (8 rays) per workgroup until the chip is full: a small launch is latency-bound, and the three
+        // half-steps of pipeline fill cost less than leaving compute units idle (64x64 rays: 167 -> 70 us)
+        int64_t g = (total_seq / kPipeUnit + kNumXCD - 1) / kNumXCD * kNumXCD;
         if (g < kNumXCD) g = kNumXCD;
         if (g > GNERF_PIPE_WAVES_PER_SIMD * kNumCU) g = GNERF_PIPE_WAVES_PER_SIMD * kNumCU;     // resident workgroups per CU
         hipLaunchKernelGGL(render_kernel_pipe, dim3((unsigned)g), dim3(kPipeThreads), pipe_lds_floats() * sizeof(float), s, P);

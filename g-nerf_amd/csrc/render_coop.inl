@@ -516,9 +516,12 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
     L.stage = L.taps + kCoopWaves * 16 * kTapDwords;
     L.part = L.stage + kCoopWaves * 16 * kStagePitch;
 
-    const int per_xcd = (P.n_tiles + kNumXCD - 1) / kNumXCD;
-    const int tile_id = (blockIdx.x % kNumXCD) * per_xcd + blockIdx.x / kNumXCD;
-    if (tile_id >= P.n_tiles) return;
+    const int n_groups = P.n_tiles << P.split_shift;
+    const int per_xcd = (n_groups + kNumXCD - 1) / kNumXCD;
+    const int group = (blockIdx.x % kNumXCD) * per_xcd + blockIdx.x / kNumXCD;
+    if (group >= n_groups) return;
+    const int tile_id = group >> P.split_shift;
+    const int rr_count = kRaysPerWave >> P.split_shift, rr_first = (group & ((1 << P.split_shift) - 1)) * rr_count;
 
     // decoder -> LDS (padded rows), once per workgroup
     stage_decoder(L, smem, p, tid, kCoopThreads);
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
     Stamps st;
     st.reset();
 
-    for (int rr = 0; rr < kRaysPerWave; rr++) {
+    for (int rr = rr_first; rr < rr_first + rr_count; rr++) {
         int64_t ray;
         if (P.tiles_per_item > 0) {
             const int item = tile_id / P.tiles_per_item, tt = tile_id % P.tiles_per_item;
