@@ -377,6 +377,19 @@ __device__ __forceinline__ void march(const float* t, const float* sig, float* w
     wt_sum = wave_sum(acc_wt);
 }
 
+// ---- the call-wide depth range (ray_marcher.py:49-50).
+// Workspace words: [0] ~ord_encode(min depth)  [1] ord_encode(max depth)  [3] clamp blocks finished.
+// ALL ZERO means idle ("min = +inf, max = -inf"): the caller provides a zeroed workspace once and every call leaves it
+// zeroed (clamp_depth_kernel's last block), so no launch is spent on initialising it.
+// (Also tried: letting the last render workgroup to finish apply the clamp itself for small launches, to save the second
+// launch -- the device-scope fences that needs at the end of every workgroup cost more than the launch: 86 -> 118 us per
+// 64x64-ray frame.)
+__device__ __forceinline__ void publish_depth_range(const Params& P, float blk_min, float blk_max) {
+    unsigned* ws = static_cast<unsigned*>(P.p.workspace);
+    atomicMax(ws + 0, ~ord_encode(blk_min));
+    atomicMax(ws + 1, ord_encode(blk_max));
+}
+
 __global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
     extern __shared__ __align__(16) float smem[];
     const gnerf_render_params& p = P.p;
@@ -400,9 +413,9 @@ __global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
     const int n_groups = P.n_tiles << P.split_shift;
     const int per_xcd = (n_groups + kNumXCD - 1) / kNumXCD;
     const int group = (blockIdx.x % kNumXCD) * per_xcd + blockIdx.x / kNumXCD;
-    if (group >= n_groups) return;
     const int tile = group >> P.split_shift;
-    const int rr_count = kRaysPerWave >> P.split_shift, rr_first = (group & ((1 << P.split_shift) - 1)) * rr_count;
+    const int rr_count = group < n_groups ? (kRaysPerWave >> P.split_shift) : 0;        // surplus workgroups of the rounded-up grid only report in
+    const int rr_first = (group & ((1 << P.split_shift) - 1)) * (kRaysPerWave >> P.split_shift);
 
     Weights w;
     load_weights(w, p, lane);
@@ -516,23 +529,20 @@ __global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
         }
         __syncthreads();
     }
-    if (lane == 0) {
-        unsigned* range = static_cast<unsigned*>(p.workspace);
-        atomicMin(range + 0, ord_encode(blk_min));
-        atomicMax(range + 1, ord_encode(blk_max));
+    if (lane == 0) publish_depth_range(P, blk_min, blk_max);
+}
+
+// The clamp.  The last block to finish puts the workspace back to idle.
+constexpr int kClampPerThread = 4;
+__global__ __launch_bounds__(256) void clamp_depth_kernel(float* depth, unsigned* ws, int64_t n) {
+    const float lo = ord_decode(~ws[0]), hi = ord_decode(ws[1]);
+#pragma unroll
+    for (int k = 0; k < kClampPerThread; k++) {
+        const int64_t i = (int64_t(blockIdx.x) * kClampPerThread + k) * 256 + threadIdx.x;
+        if (i < n) depth[i] = fminf(fmaxf(depth[i], lo), hi);   // torch.clamp(x, min, max)
     }
-}
-
-__global__ void init_range_kernel(unsigned* range) {
-    range[0] = 0xffffffffu;
-    range[1] = 0u;
-}
-
-__global__ __launch_bounds__(256) void clamp_depth_kernel(float* depth, const unsigned* range, int64_t n) {
-    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float lo = ord_decode(range[0]), hi = ord_decode(range[1]);
-    depth[i] = fminf(fmaxf(depth[i], lo), hi);       // torch.clamp(x, min, max)
+    __syncthreads();                                             // every thread of the block has read (and used) the range
+    if (threadIdx.x == 0 && atomicAdd(ws + 3, 1u) == gridDim.x - 1) { ws[0] = 0u; ws[1] = 0u; ws[3] = 0u; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -675,7 +685,6 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
     const int S = p->depth_resolution, F = p->depth_resolution_importance;
     const int64_t total = P.total_rays;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(init_range_kernel, dim3(1), dim3(1), 0, s, static_cast<unsigned*>(p->workspace));
     // Small launches (one 64x64 frame of gen_videos.py is 256 ray tiles on 256 CUs): a workgroup walking its 16 rays one
     // after the other leaves most of the chip idle and the launch takes 16 ray latencies.  Split each tile over up to four
     // workgroups while that still fits the chip in one wave of workgroups.
@@ -729,8 +738,8 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         hipLaunchKernelGGL(render_kernel_generic, grid, dim3(64), lds_bytes, s, P);
         if (int e = check_launch("render_kernel_generic")) return e;
     }
-    hipLaunchKernelGGL(clamp_depth_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       p->out_depth, static_cast<const unsigned*>(p->workspace), total);
+    hipLaunchKernelGGL(clamp_depth_kernel, dim3((unsigned)((total + 256 * kClampPerThread - 1) / (256 * kClampPerThread))), dim3(256), 0, s,
+                       p->out_depth, static_cast<unsigned*>(p->workspace), total);
     return check_launch("clamp_depth_kernel");
 }
 

@@ -519,9 +519,9 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
     const int n_groups = P.n_tiles << P.split_shift;
     const int per_xcd = (n_groups + kNumXCD - 1) / kNumXCD;
     const int group = (blockIdx.x % kNumXCD) * per_xcd + blockIdx.x / kNumXCD;
-    if (group >= n_groups) return;
     const int tile_id = group >> P.split_shift;
-    const int rr_count = kRaysPerWave >> P.split_shift, rr_first = (group & ((1 << P.split_shift) - 1)) * rr_count;
+    const int rr_count = group < n_groups ? (kRaysPerWave >> P.split_shift) : 0;        // surplus workgroups of the rounded-up grid only report in
+    const int rr_first = (group & ((1 << P.split_shift) - 1)) * (kRaysPerWave >> P.split_shift);
 
     // decoder -> LDS (padded rows), once per workgroup
     stage_decoder(L, smem, p, tid, kCoopThreads);
@@ -774,9 +774,5 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        unsigned* range = static_cast<unsigned*>(p.workspace);
-        atomicMin(range + 0, ord_encode(blk_min));
-        atomicMax(range + 1, ord_encode(blk_max));
-    }
+    if (tid == 0) publish_depth_range(P, blk_min, blk_max);
 }

@@ -390,9 +390,5 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
         out[15] = nr;
     }
 #endif
-    if (tid == 192) {
-        unsigned* range = static_cast<unsigned*>(p.workspace);
-        atomicMin(range + 0, ord_encode(blk_min));
-        atomicMax(range + 1, ord_encode(blk_max));
-    }
+    if (tid == 192) publish_depth_range(P, blk_min, blk_max);
 }

@@ -298,7 +298,7 @@ def _workspace(device):
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None:
-        ws = torch.empty([max(int(load().gnerf_render_workspace_bytes()), 16)], dtype=torch.uint8, device=device)
+        ws = torch.zeros([max(int(load().gnerf_render_workspace_bytes()), 16)], dtype=torch.uint8, device=device)     # zeroed once; calls leave it zeroed
         _workspaces[key] = ws
     return ws
 

@@ -140,7 +140,8 @@ typedef struct gnerf_render_params {
     float* out_depth;    /* [n_items, rays_per_item, 1] */
     float* out_wsum;     /* [n_items, rays_per_item, 1]   sum of the final weights */
     /* workspace of gnerf_render_workspace_bytes() bytes (holds the call-wide depth range used by the
-       global clamp of ray_marcher.py:49-50) */
+       global clamp of ray_marcher.py:49-50).  ZERO it once after allocation; every call leaves it zeroed.
+       One workspace per stream that renders concurrently. */
     void*  workspace;
     /* optional stage dump for debugging/parity: float32 [n*m, GNERF_DEBUG_SLOTS, S+F]; NULL in production */
     float* debug;
