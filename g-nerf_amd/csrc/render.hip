@@ -698,7 +698,8 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
     //   generic one wave per ray: everything else (up to 256+256)
     const char* force = getenv("GNERF_RENDER_KERNEL");
     const bool small_planes = int64_t(p->plane_h) * p->plane_w * 3 * 128 < (int64_t(1) << 32);
-    bool pipe = P.tiles_c <= 3 && P.tiles_f >= 1 && P.tiles_f <= 3 && small_planes;
+    bool pipe = P.tiles_c <= 6 && P.tiles_f >= 1 && P.tiles_f <= 6 && small_planes;
+    const int pipe_tp = (P.tiles_c <= 3 && P.tiles_f <= 3) ? 1 : 2;             // 16-sample tiles per shader wave and pass
     bool coop = P.tiles_c <= 2 * kCoopWaves && P.tiles_f <= 2 * kCoopWaves && small_planes;
     if (force && !strcmp(force, "generic")) pipe = coop = false;
     if (force && !strcmp(force, "coop")) { pipe = false; if (!coop) return fail(GNERF_E_UNSUPPORTED, "render: cooperative kernel does not cover %d+%d samples", S, F); }
@@ -709,8 +710,11 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         // half-steps of pipeline fill cost less than leaving compute units idle (64x64 rays: 167 -> 70 us)
         int64_t g = (total_seq / kPipeUnit + kNumXCD - 1) / kNumXCD * kNumXCD;
         if (g < kNumXCD) g = kNumXCD;
-        if (g > GNERF_PIPE_WAVES_PER_SIMD * kNumCU) g = GNERF_PIPE_WAVES_PER_SIMD * kNumCU;     // resident workgroups per CU
-        hipLaunchKernelGGL(render_kernel_pipe, dim3((unsigned)g), dim3(kPipeThreads), pipe_lds_floats() * sizeof(float), s, P);
+        const int per_cu = pipe_tp == 1 ? GNERF_PIPE_WAVES_PER_SIMD : 2;                         // resident workgroups per CU
+        if (g > per_cu * kNumCU) g = per_cu * kNumCU;
+        const size_t lds_bytes = pipe_lds_floats(pipe_tp) * sizeof(float);
+        if (pipe_tp == 1) hipLaunchKernelGGL(render_kernel_pipe<1>, dim3((unsigned)g), dim3(kPipeThreads), lds_bytes, s, P);
+        else              hipLaunchKernelGGL(render_kernel_pipe<2>, dim3((unsigned)g), dim3(kPipeThreads), lds_bytes, s, P);
         if (int e = check_launch("render_kernel_pipe")) return e;
     } else
     if (coop) {

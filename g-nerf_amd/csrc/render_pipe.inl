@@ -16,8 +16,9 @@
 // loads (noise, ray) at the start of a step and consumes them at the end, behind the march/cdf work.
 // Workgroups are persistent-style: each takes a contiguous run of the locality-ordered ray sequence, so the
 // 3-step pipeline fill/drain is paid once per ~85 rays, not once per 16.
-// Covers depth_resolution <= 48 and 1 <= depth_resolution_importance <= 48 (one 16-sample tile per shader wave
-// and pass) -- the reference's training/inference default (48+48); other shapes use the coop / generic kernels.
+// Instantiated for one 16-sample tile per shader wave and pass (depth_resolution <= 48, 1 <= importance <= 48: the
+// reference's training/inference default) and for two (up to 96+96: gen_videos.py's doubled counts, the ShapeNet config's
+// 64+64); other shapes use the coop / generic kernels.
 
 #ifdef GNERF_STAMPS
 #define GNERF_DBG_PTR(x) ((float*)nullptr)
@@ -31,28 +32,36 @@
 constexpr int kPipeUnit = GNERF_PIPE_UNIT;      // rays dealt to a workgroup at a time (see render_kernel_pipe)
 constexpr int kPipeThreads = 256;
 constexpr int kPipeSlots = 4;
-constexpr int kPipeMaxS = 48;
-constexpr int kPipeSPad = 96;
-constexpr int kSlotFloats = 8 * kPipeSPad + kPipeMaxS + 96 + 16;
+// TP = 16-sample tiles per shader wave and pass: 1 covers up to 48+48 samples (the reference's default), 2 up to 96+96
+// (gen_videos.py doubles the counts, gen_videos.py:127-128; the ShapeNet config uses 64+64).
+template <int TP> struct PipeDims {
+    static constexpr int kMaxS = 48 * TP;                  // samples per pass
+    static constexpr int kSPad = 2 * kMaxS;                // coarse [0, kMaxS) + fine [kMaxS, 2 kMaxS)
+    static constexpr int kRounds = (kMaxS + 63) / 64;      // lanes x rounds cover the samples of a pass
+    static constexpr int kSlotFloats = 8 * kSPad + kMaxS + 96 + 16;
+};
 
 struct PipeSlot {
     float* t_e; float* sig_e; float* v_e; int* rank_e; float* s_t; float* s_sig; float* w_s; float* cdf;
-    float* nf;      // [48] fine noise of this ray
+    float* nf;      // [kMaxS] fine noise of this ray
     float* part;    // [3][32] colour partial sums of the shader waves
     float* misc;    // [0..5] origin, direction  [6] item (int)  [7] ray (int)  [8] w_sum  [9] wt_sum
 };
 
+template <int TP>
 __device__ __forceinline__ PipeSlot pipe_slot(float* base, int slot) {
-    float* p = base + slot * kSlotFloats;
+    typedef PipeDims<TP> D;
+    float* p = base + slot * D::kSlotFloats;
     PipeSlot s;
-    s.t_e = p; s.sig_e = p + kPipeSPad; s.v_e = p + 2 * kPipeSPad; s.rank_e = reinterpret_cast<int*>(p + 3 * kPipeSPad);
-    s.s_t = p + 4 * kPipeSPad; s.s_sig = p + 5 * kPipeSPad; s.w_s = p + 6 * kPipeSPad; s.cdf = p + 7 * kPipeSPad;
-    s.nf = p + 8 * kPipeSPad; s.part = s.nf + kPipeMaxS; s.misc = s.part + 96;
+    s.t_e = p; s.sig_e = p + D::kSPad; s.v_e = p + 2 * D::kSPad; s.rank_e = reinterpret_cast<int*>(p + 3 * D::kSPad);
+    s.s_t = p + 4 * D::kSPad; s.s_sig = p + 5 * D::kSPad; s.w_s = p + 6 * D::kSPad; s.cdf = p + 7 * D::kSPad;
+    s.nf = p + 8 * D::kSPad; s.part = s.nf + D::kMaxS; s.misc = s.part + 96;
     return s;
 }
 
-__host__ __device__ inline size_t pipe_lds_floats() {
-    return size_t(kWeightFloats) + 64 + 36 + size_t(kPipeSlots) * kSlotFloats + 3 * 16 * kTapDwords + 3 * 16 * kStagePitch;
+__host__ __device__ inline size_t pipe_lds_floats(int tp) {
+    const size_t slot_floats = tp == 1 ? PipeDims<1>::kSlotFloats : PipeDims<2>::kSlotFloats;
+    return size_t(kWeightFloats) + 64 + 36 + size_t(kPipeSlots) * slot_floats + 3 * 16 * kTapDwords + 3 * 16 * kStagePitch;
 }
 
 // position `seq` of the locality-ordered ray sequence -> ray index (or -1 past the end)
@@ -73,7 +82,10 @@ __device__ __forceinline__ int pipe_seq_to_ray(const Params& P, int64_t seq) {
 #ifndef GNERF_PIPE_WAVES_PER_SIMD
 #define GNERF_PIPE_WAVES_PER_SIMD 3
 #endif
-__global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void render_kernel_pipe(Params P) {
+template <int TP>
+__global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD : 2) void render_kernel_pipe(Params P) {
+    typedef PipeDims<TP> D;
+    constexpr int kPipeMaxS = D::kMaxS, kPipeSPad = D::kSPad, kSlotFloats = D::kSlotFloats, RND = D::kRounds;
     extern __shared__ __align__(16) float smem[];
     const gnerf_render_params& p = P.p;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -110,27 +122,32 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
     Stamps st;
     // ------------------------------------------------------------------ scalar-wave pieces (lambdas, wave 3 only)
     float blk_min = INFINITY, blk_max = -INFINITY;
-    float pre_uc = 0.f, pre_uf = 0.f, pre_ray = 0.f, pre_rs = 0.f, pre_re = 0.f;       // prefetched by propose_issue
+    float pre_uc[RND] = {}, pre_uf[RND] = {}, pre_ray = 0.f, pre_rs = 0.f, pre_re = 0.f;       // prefetched by propose_issue
     int pre_ray_id = -1;
 
     auto propose_issue = [&](int r) {           // P(r), first half: start the global loads
         pre_ray_id = (r >= 0 && r < nr) ? local_to_ray(r) : -1;
         if (pre_ray_id < 0) return;
         const int64_t ray = pre_ray_id;
-        if (lane < S) pre_uc = p.noise_coarse[ray * S + lane];
-        if (lane < F) pre_uf = p.noise_fine[ray * F + lane];
+#pragma unroll
+        for (int q = 0; q < RND; q++) {
+            if (lane + 64 * q < S) pre_uc[q] = p.noise_coarse[ray * S + lane + 64 * q];
+            if (lane + 64 * q < F) pre_uf[q] = p.noise_fine[ray * F + lane + 64 * q];
+        }
         if (lane < 3) pre_ray = p.ray_origins[ray * 3 + lane];
         else if (lane < 6) pre_ray = p.ray_dirs[ray * 3 + lane - 3];
         if (p.ray_start_per_ray) { pre_rs = p.ray_start_per_ray[ray]; pre_re = p.ray_end_per_ray[ray]; }
     };
     auto propose_finish = [&](int r) {          // P(r), second half: depth proposals (renderer.py:169-192) into the slot
         if (r < 0 || r >= nr) return;
-        PipeSlot sl = pipe_slot(slots, r & (kPipeSlots - 1));
+        PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
         if (lane == 7) sl.misc[7] = __int_as_float(pre_ray_id);
         if (pre_ray_id < 0) return;
-        const int k = lane;
+#pragma unroll
+        for (int q = 0; q < RND; q++) {
+        const int k = lane + 64 * q;
         if (k < S) {
-            const float u = pre_uc;
+            const float u = pre_uc[q];
             float d;
             if (p.disparity_space_sampling) {
                 const float step = 1.0f / float(S - 1);
@@ -150,7 +167,10 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
             sl.t_e[k] = d;
             if (GNERF_DBG_PTR(p.debug)) p.debug[(int64_t(pre_ray_id) * GNERF_DEBUG_SLOTS + GNERF_DBG_DEPTH_COARSE) * n_all + k] = d;
         }
-        if (lane < F) sl.nf[lane] = pre_uf;
+        }
+#pragma unroll
+        for (int q = 0; q < RND; q++)
+            if (lane + 64 * q < F) sl.nf[lane + 64 * q] = pre_uf[q];
         if (lane < 6) sl.misc[lane] = pre_ray;
         if (lane == 6) sl.misc[6] = __int_as_float(pre_ray_id / p.rays_per_item);
         for (int e = lane; e < s_pad; e += 64) {
@@ -160,7 +180,7 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
     };
     auto importance = [&](int r) {              // B(r): coarse march (ray_marcher.py:26-42) + importance depths (renderer.py:194-253)
         if (r < 0 || r >= nr) return;
-        PipeSlot sl = pipe_slot(slots, r & (kPipeSlots - 1));
+        PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
         const int ray_id = __float_as_int(sl.misc[7]);
         if (ray_id < 0) return;
         float* dbg = GNERF_DBG_PTR(p.debug ? p.debug + int64_t(ray_id) * GNERF_DEBUG_SLOTS * n_all : nullptr);
@@ -168,46 +188,61 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
         march(sl.t_e, sl.sig_e, sl.w_s, S, lane, ws, wts);
         lds_wave_sync();
         const int n_w = S - 3;
-        float pw = 0.f;
-        if (lane < n_w) {
-            const float w0 = sl.w_s[lane], w1 = sl.w_s[lane + 1], w2 = sl.w_s[lane + 2];
-            pw = ((fmaxf(w0, w1) + fmaxf(w1, w2)) * 0.5f + 0.01f) + 1e-5f;
-        }
-        const float incl_pw = wave_scan_add(pw, lane);
-        const float inv_total = __builtin_amdgcn_rcpf(wave_last(incl_pw));
-        // cdf[i+1] = cumsum(pw * inv_total): scan the normalised terms like the reference does (pdf first, then cumsum)
-        const float incl = wave_scan_add(pw * inv_total, lane);
-        if (lane < n_w) sl.cdf[lane + 1] = incl;
-        if (lane == 0) sl.cdf[0] = 0.f;
-        if (n_w + 1 + lane < kPipeMaxS) sl.cdf[n_w + 1 + lane] = INFINITY;                  // lets the count below read 4 at a time
-        lds_wave_sync();
-        if (lane < F) {
-            const float u = sl.nf[lane];
-            int cnt = 0;                                                   // searchsorted(cdf, u, right=True) = #{cdf <= u}
-#pragma unroll 4                                       // 16 keys in flight per batch: enough to cover the LDS latency, few registers
-            for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {                    // cdf[n_w+1 ...] = +inf
-                const v4f c4 = *reinterpret_cast<const v4f*>(sl.cdf + o2);
+        float pw[RND], carry = 0.f;
 #pragma unroll
-                for (int c2 = 0; c2 < 4; c2++) cnt += (c4[c2] <= u) ? 1 : 0;
+        for (int q = 0; q < RND; q++) {
+            const int i = lane + 64 * q;
+            pw[q] = 0.f;
+            if (i < n_w) {
+                const float w0 = sl.w_s[i], w1 = sl.w_s[i + 1], w2 = sl.w_s[i + 2];
+                pw[q] = ((fmaxf(w0, w1) + fmaxf(w1, w2)) * 0.5f + 0.01f) + 1e-5f;
             }
-            const int below = max(cnt - 1, 0), above = min(cnt, n_w);
-            const float cb = sl.cdf[below], ca = sl.cdf[above];
-            const float bb = (sl.t_e[below] + sl.t_e[below + 1]) * 0.5f;
-            const float ba = (sl.t_e[above] + sl.t_e[above + 1]) * 0.5f;
-            float denom = ca - cb;
-            if (denom < 1e-5f) denom = 1.f;
-            const float d = bb + (u - cb) * __builtin_amdgcn_rcpf(denom) * (ba - bb);
-            sl.t_e[fine_e0 + lane] = d;
-            if (dbg) dbg[GNERF_DBG_DEPTH_FINE * n_all + lane] = d;
+            carry = wave_last(wave_scan_add(pw[q], lane) + carry);
+        }
+        const float inv_total = __builtin_amdgcn_rcpf(carry);
+        // cdf[i+1] = cumsum(pw * inv_total): scan the normalised terms like the reference does (pdf first, then cumsum)
+        carry = 0.f;
+#pragma unroll
+        for (int q = 0; q < RND; q++) {
+            const int i = lane + 64 * q;
+            const float incl = wave_scan_add(pw[q] * inv_total, lane) + carry;
+            if (i < n_w) sl.cdf[i + 1] = incl;
+            carry = wave_last(incl);
+        }
+        if (lane == 0) sl.cdf[0] = 0.f;
+        for (int e = n_w + 1 + lane; e < kPipeMaxS; e += 64) sl.cdf[e] = INFINITY;           // lets the count below read 4 at a time
+        lds_wave_sync();
+#pragma unroll
+        for (int q = 0; q < RND; q++) {
+            const int i = lane + 64 * q;
+            if (i < F) {
+                const float u = sl.nf[i];
+                int cnt = 0;                                               // searchsorted(cdf, u, right=True) = #{cdf <= u}
+#pragma unroll 4                                       // 16 keys in flight per batch: enough to cover the LDS latency, few registers
+                for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {                // cdf[n_w+1 ...] = +inf
+                    const v4f c4 = *reinterpret_cast<const v4f*>(sl.cdf + o2);
+#pragma unroll
+                    for (int c2 = 0; c2 < 4; c2++) cnt += (c4[c2] <= u) ? 1 : 0;
+                }
+                const int below = max(cnt - 1, 0), above = min(cnt, n_w);
+                const float cb = sl.cdf[below], ca = sl.cdf[above];
+                const float bb = (sl.t_e[below] + sl.t_e[below + 1]) * 0.5f;
+                const float ba = (sl.t_e[above] + sl.t_e[above + 1]) * 0.5f;
+                float denom = ca - cb;
+                if (denom < 1e-5f) denom = 1.f;
+                const float d = bb + (u - cb) * __builtin_amdgcn_rcpf(denom) * (ba - bb);
+                sl.t_e[fine_e0 + i] = d;
+                if (dbg) dbg[GNERF_DBG_DEPTH_FINE * n_all + i] = d;
+            }
         }
         if (dbg) {
-            if (lane < S) dbg[GNERF_DBG_SIGMA_COARSE * n_all + lane] = sl.sig_e[lane];
-            if (lane < S - 1) dbg[GNERF_DBG_WEIGHT_COARSE * n_all + lane] = sl.w_s[lane];
+            for (int k = lane; k < S; k += 64) dbg[GNERF_DBG_SIGMA_COARSE * n_all + k] = sl.sig_e[k];
+            for (int k = lane; k < S - 1; k += 64) dbg[GNERF_DBG_WEIGHT_COARSE * n_all + k] = sl.w_s[k];
         }
     };
     auto finalize = [&](int r) {                // D(r): merge by depth (renderer.py:157-167) + final march + per-sample colour weights
         if (r < 0 || r >= nr) return;
-        PipeSlot sl = pipe_slot(slots, r & (kPipeSlots - 1));
+        PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
         const int ray_id = __float_as_int(sl.misc[7]);
         if (ray_id < 0) return;
         float* dbg = GNERF_DBG_PTR(p.debug ? p.debug + int64_t(ray_id) * GNERF_DEBUG_SLOTS * n_all : nullptr);
@@ -217,52 +252,76 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
         // compare + add-with-carry scans over keys read four at a time as LDS broadcasts.  "#fine before i" is first taken
         // as #{fine < t_i}; two fine samples with bit-identical depth then collide on a rank, which is detected through
         // an owner table and repaired by a tie-broken recount (rare: needs two equal uniform draws or rounding collisions).
-        int rank_f = 0, rank_c = lane;
-        float key_f = 0.f, key_c = 0.f;
-        if (lane < F) {
-            key_f = sl.t_e[fine_e0 + lane];
-#pragma unroll 4
-            for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
-                const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + fine_e0 + o2);
+        int rank_f[RND], rank_c[RND];
+        float key_f[RND], key_c[RND];
 #pragma unroll
-                for (int c2 = 0; c2 < 4; c2++) rank_f += (k4[c2] < key_f) ? 1 : 0;
-            }
+        for (int q = 0; q < RND; q++) {
+            const int i = lane + 64 * q;
+            rank_f[q] = 0; key_f[q] = 0.f;
+            if (i < F) {
+                const float key = sl.t_e[fine_e0 + i];
+                int rk = 0;
 #pragma unroll 4
-            for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
-                const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + o2);
+                for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
+                    const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + fine_e0 + o2);
 #pragma unroll
-                for (int c2 = 0; c2 < 4; c2++) rank_f += (k4[c2] <= key_f) ? 1 : 0;
+                    for (int c2 = 0; c2 < 4; c2++) rk += (k4[c2] < key) ? 1 : 0;
+                }
+#pragma unroll 4
+                for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
+                    const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + o2);
+#pragma unroll
+                    for (int c2 = 0; c2 < 4; c2++) rk += (k4[c2] <= key) ? 1 : 0;
+                }
+                sl.rank_e[fine_e0 + i] = rk;
+                reinterpret_cast<int*>(sl.w_s)[rk] = i;             // owner table (w_s is free until the final march)
+                rank_f[q] = rk; key_f[q] = key;
             }
-            sl.rank_e[fine_e0 + lane] = rank_f;
-            reinterpret_cast<int*>(sl.w_s)[rank_f] = lane;          // owner table (w_s is free until the final march)
         }
-        if (lane < S) {
-            key_c = sl.t_e[lane];
-            // "ascend by construction" holds up to rounding: t_k = lin_k + u delta can round one ulp past t_{k+1} when
-            // u is within 1e-5 of 1.  Only neighbours can swap (the grid step is ~1e5 ulps), so the number of coarse
-            // samples sorted before k is k +- 1 from two compares.
-            if (lane + 1 < S && sl.t_e[lane + 1] < key_c) rank_c += 1;
-            if (lane > 0 && sl.t_e[lane - 1] > key_c) rank_c -= 1;
-#pragma unroll 4
-            for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
-                const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + fine_e0 + o2);
 #pragma unroll
-                for (int c2 = 0; c2 < 4; c2++) rank_c += (k4[c2] < key_c) ? 1 : 0;
+        for (int q = 0; q < RND; q++) {
+            const int k = lane + 64 * q;
+            rank_c[q] = k; key_c[q] = 0.f;
+            if (TP == 1 && k < S) {             // TP == 2: the shader waves did this a step earlier (coarse_ranks)
+                const float key = sl.t_e[k];
+                int rk = k;
+                // "ascend by construction" holds up to rounding: t_k = lin_k + u delta can round one ulp past t_{k+1} when
+                // u is within 1e-5 of 1.  Only neighbours can swap (the grid step is ~1e5 ulps), so the number of coarse
+                // samples sorted before k is k +- 1 from two compares.
+                if (k + 1 < S && sl.t_e[k + 1] < key) rk += 1;
+                if (k > 0 && sl.t_e[k - 1] > key) rk -= 1;
+#pragma unroll 4
+                for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
+                    const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + fine_e0 + o2);
+#pragma unroll
+                    for (int c2 = 0; c2 < 4; c2++) rk += (k4[c2] < key) ? 1 : 0;
+                }
+                sl.rank_e[k] = rk;
+                rank_c[q] = rk; key_c[q] = key;
             }
-            sl.rank_e[lane] = rank_c;
         }
         lds_wave_sync();
-        const bool clash = lane < F && reinterpret_cast<const int*>(sl.w_s)[rank_f] != lane;
+        bool clash = false;
+#pragma unroll
+        for (int q = 0; q < RND; q++) clash = clash || (lane + 64 * q < F && reinterpret_cast<const int*>(sl.w_s)[rank_f[q]] != lane + 64 * q);
         if (__any(clash)) {                                         // wave-uniform, rare
-            if (lane < F) {
-                int fix = 0;
-                for (int o2 = 0; o2 < F; o2++) fix += (sl.t_e[fine_e0 + o2] == key_f && o2 < lane) ? 1 : 0;
-                rank_f += fix;
-                sl.rank_e[fine_e0 + lane] = rank_f;
+#pragma unroll
+            for (int q = 0; q < RND; q++) {
+                const int i = lane + 64 * q;
+                if (i < F) {
+                    int fix = 0;
+                    for (int o2 = 0; o2 < F; o2++) fix += (sl.t_e[fine_e0 + o2] == key_f[q] && o2 < i) ? 1 : 0;
+                    rank_f[q] += fix;
+                    sl.rank_e[fine_e0 + i] = rank_f[q];
+                }
             }
         }
-        if (lane < F) { sl.s_t[rank_f] = key_f; sl.s_sig[rank_f] = sl.sig_e[fine_e0 + lane]; }
-        if (lane < S) { sl.s_t[rank_c] = key_c; sl.s_sig[rank_c] = sl.sig_e[lane]; }
+#pragma unroll
+        for (int q = 0; q < RND; q++) {
+            const int i = lane + 64 * q;
+            if (i < F) { sl.s_t[rank_f[q]] = key_f[q]; sl.s_sig[rank_f[q]] = sl.sig_e[fine_e0 + i]; }
+            if (TP == 1 && i < S) { sl.s_t[rank_c[q]] = key_c[q]; sl.s_sig[rank_c[q]] = sl.sig_e[i]; }
+        }
         lds_wave_sync();
         GNERF_STAMP(st, 13);    // merge ranks
         float ws, wts;
@@ -282,14 +341,14 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
             blk_max = fmaxf(blk_max, sl.s_t[n_all - 1]);
         }
         if (dbg) {
-            if (lane < F) dbg[GNERF_DBG_SIGMA_FINE * n_all + lane] = sl.sig_e[fine_e0 + lane];
+            for (int k = lane; k < F; k += 64) dbg[GNERF_DBG_SIGMA_FINE * n_all + k] = sl.sig_e[fine_e0 + k];
             for (int k = lane; k < n_all; k += 64) { dbg[GNERF_DBG_DEPTH_SORTED * n_all + k] = sl.s_t[k]; dbg[GNERF_DBG_SIGMA_SORTED * n_all + k] = sl.s_sig[k]; }
             for (int k = lane; k < n_all - 1; k += 64) dbg[GNERF_DBG_WEIGHT_FINAL * n_all + k] = sl.w_s[k];
         }
     };
     auto output = [&](int r) {                  // out(r): sum the shader waves' colour partials, write the three outputs
         if (r < 0 || r >= nr) return;
-        PipeSlot sl = pipe_slot(slots, r & (kPipeSlots - 1));
+        PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
         const int ray_id = __float_as_int(sl.misc[7]);
         if (ray_id < 0) return;
         const float ws = sl.misc[8], wts = sl.misc[9];
@@ -307,9 +366,9 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
     };
 
     // ------------------------------------------------------------------ shader-wave pieces (waves 0..2)
-    auto shade = [&](int r, bool fine, v4f (&col)[2]) {
+    auto shade = [&](int r, bool fine, v4f (&col)[TP][2]) {
         if (r < 0 || r >= nr) return;
-        PipeSlot sl = pipe_slot(slots, r & (kPipeSlots - 1));
+        PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
         const int ray_id = __builtin_amdgcn_readfirstlane(__float_as_int(sl.misc[7]));
         if (ray_id < 0) return;
         CoopRay R;
@@ -318,24 +377,59 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
         R.ox = sl.misc[0]; R.oy = sl.misc[1]; R.oz = sl.misc[2];
         R.dx = sl.misc[3]; R.dy = sl.misc[4]; R.dz = sl.misc[5];
         GNERF_STAMP(st, 0);     // ray parameters from the slot
-        if (!fine) coop_shade_tile<false>(P, L, R, sl.t_e, S, wv, wv < P.tiles_c, sl.sig_e, lane, wv, col, st);
-        else       coop_shade_tile<false>(P, L, R, sl.t_e + fine_e0, F, wv, wv < P.tiles_f, sl.sig_e + fine_e0, lane, wv, col, st);
+#pragma unroll
+        for (int i = 0; i < TP; i++) {
+            const int tile = wv + 3 * i;
+            if (TP > 1 && tile >= (fine ? P.tiles_f : P.tiles_c)) continue;       // wave-uniform: this wave has no such tile
+            if (!fine) coop_shade_tile<false>(P, L, R, sl.t_e, S, tile, tile < P.tiles_c, sl.sig_e, lane, wv, col[i], st);
+            else       coop_shade_tile<false>(P, L, R, sl.t_e + fine_e0, F, tile, tile < P.tiles_f, sl.sig_e + fine_e0, lane, wv, col[i], st);
+        }
     };
-    auto accumulate = [&](int r, const v4f (&cc)[2], const v4f (&cf)[2]) {
+    // TP == 2 only.  With 96+96 samples the merge is half of the scalar wave's time and the shader waves wait for it in the
+    // even half-step (stamps: 27 % of their cycles).  The coarse samples' ranks depend on depths only -- known as soon as
+    // the ray's fine depths are -- so the shader waves compute them, and place the coarse depths / densities in sorted
+    // order, at the end of the half-step BEFORE the scalar wave finalises that ray: a third of the merge moves into what
+    // was idle time.  Wave wv takes coarse samples [32 (2 - wv), 32 (2 - wv) + 32).
+    auto coarse_ranks = [&](int r) {
         if (r < 0 || r >= nr) return;
-        PipeSlot sl = pipe_slot(slots, r & (kPipeSlots - 1));
+        PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
+        if (__float_as_int(sl.misc[7]) < 0) return;
+        const int k = 32 * (2 - wv) + lane;         // wave 2 first: with 4 or 5 tiles per pass it is wave 0 that shades two
+        if (lane < 32 && k < S) {
+            const float key = sl.t_e[k];
+            int rk = k;
+            if (k + 1 < S && sl.t_e[k + 1] < key) rk += 1;          // neighbours swapped by rounding, see finalize
+            if (k > 0 && sl.t_e[k - 1] > key) rk -= 1;
+#pragma unroll 4
+            for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
+                const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + fine_e0 + o2);
+#pragma unroll
+                for (int c2 = 0; c2 < 4; c2++) rk += (k4[c2] < key) ? 1 : 0;
+            }
+            sl.rank_e[k] = rk;
+            sl.s_t[rk] = key;
+            sl.s_sig[rk] = sl.sig_e[k];
+        }
+    };
+    auto accumulate = [&](int r, const v4f (&cc)[TP][2], const v4f (&cf)[TP][2]) {
+        if (r < 0 || r >= nr) return;
+        PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
         if (__float_as_int(sl.misc[7]) < 0) return;
         const int j = lane & 15, g = lane >> 4;
         float acc[2] = {0.f, 0.f};
-        if (wv < P.tiles_c) {
-            const v4f v = *reinterpret_cast<const v4f*>(sl.v_e + 16 * wv + 4 * g);
 #pragma unroll
-            for (int n = 0; n < 2; n++) acc[n] += v[0] * cc[n][0] + v[1] * cc[n][1] + v[2] * cc[n][2] + v[3] * cc[n][3];
-        }
-        if (wv < P.tiles_f) {
-            const v4f v = *reinterpret_cast<const v4f*>(sl.v_e + fine_e0 + 16 * wv + 4 * g);
+        for (int i = 0; i < TP; i++) {
+            const int tile = wv + 3 * i;
+            if (tile < P.tiles_c) {
+                const v4f v = *reinterpret_cast<const v4f*>(sl.v_e + 16 * tile + 4 * g);
 #pragma unroll
-            for (int n = 0; n < 2; n++) acc[n] += v[0] * cf[n][0] + v[1] * cf[n][1] + v[2] * cf[n][2] + v[3] * cf[n][3];
+                for (int n = 0; n < 2; n++) acc[n] += v[0] * cc[i][n][0] + v[1] * cc[i][n][1] + v[2] * cc[i][n][2] + v[3] * cc[i][n][3];
+            }
+            if (tile < P.tiles_f) {
+                const v4f v = *reinterpret_cast<const v4f*>(sl.v_e + fine_e0 + 16 * tile + 4 * g);
+#pragma unroll
+                for (int n = 0; n < 2; n++) acc[n] += v[0] * cf[i][n][0] + v[1] * cf[i][n][1] + v[2] * cf[i][n][2] + v[3] * cf[i][n][3];
+            }
         }
 #pragma unroll
         for (int n = 0; n < 2; n++) acc[n] = row_sum4(acc[n]);
@@ -350,12 +444,13 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
     __syncthreads();                                            // weights are in LDS
     if (wv == 3) { propose_issue(0); propose_finish(0); }
     __syncthreads();
-    v4f cc0[2] = {}, cc1[2] = {}, cc2[2] = {}, cf[2] = {};      // coarse colours of rays k-1, k, k+1; fine colours of ray k-1
+    v4f cc0[TP][2] = {}, cc1[TP][2] = {}, cc2[TP][2] = {}, cf[TP][2] = {};      // coarse colours of rays k-1, k, k+1; fine colours of ray k-1
     st.reset();
     for (int k = -1; k <= nr + 1; k++) {
         // ---- step 2k+2
         if (wv < 3) {
             shade(k + 1, false, cc2);
+            if (TP == 2) coarse_ranks(k);       // ray k's fine depths exist since step 2k+1; the scalar wave finalises it in step 2k+4
         } else {
             finalize(k - 1);
             GNERF_STAMP(st, 8);     // merge + final march
@@ -371,7 +466,10 @@ __global__ __launch_bounds__(kPipeThreads, GNERF_PIPE_WAVES_PER_SIMD) void rende
             GNERF_STAMP(st, 10);    // colour accumulate
             shade(k, true, cf);
 #pragma unroll
-            for (int n = 0; n < 2; n++) { cc0[n] = cc1[n]; cc1[n] = cc2[n]; }
+            for (int i = 0; i < TP; i++) {
+#pragma unroll
+                for (int n = 0; n < 2; n++) { cc0[i][n] = cc1[i][n]; cc1[i][n] = cc2[i][n]; }
+            }
         } else {
             propose_issue(k + 2);
             importance(k + 1);

@@ -143,6 +143,9 @@ def _random_scene(seed, N, res, S, F, hw, scale=1.5):
     dict(N=1, res=4, S=130, F=100, hw=(8, 8)),              # beyond 96+96: one-wave-per-ray kernel, ragged tiles
     dict(N=1, res=2, S=256, F=256, hw=(8, 8)),              # GNERF_MAX_SAMPLES on both passes
     dict(N=2, res=8, S=64, F=64, hw=(16, 12)),              # ShapeNet config's sample counts (train.py:353-354)
+    dict(N=1, res=6, S=50, F=70, hw=(16, 16)),              # two-tiles-per-wave pipelined kernel, ragged on both passes
+    dict(N=2, res=4, S=96, F=5, hw=(8, 8)),                 # ... six coarse tiles, a sliver of a fine tile
+    dict(N=1, res=5, S=33, F=96, hw=(12, 8)),               # ... three coarse tiles (one nearly empty), six fine
 ])
 def test_render_vs_oracle(dev, cfg):
     import gnerf_hip
@@ -184,28 +187,29 @@ def test_render_tied_fine_depths(dev, S, F):
     np.testing.assert_allclose(wsum.cpu().numpy(), ref_w.numpy(), atol=2e-4)
 
 
-@pytest.mark.parametrize('kernel', ['pipe', 'coop', 'generic'])
-def test_render_coarse_depths_swapped_by_rounding(dev, kernel, monkeypatch):
+@pytest.mark.parametrize('kernel,S', [('pipe', 48), ('pipe', 96), ('coop', 48), ('generic', 48)])
+def test_render_coarse_depths_swapped_by_rounding(dev, kernel, S, monkeypatch):
     """Jitter u = 1 - 2^-24 makes lin_k + u*delta round one ulp past the next proposal (7 of the 47 neighbour pairs at
     the default limits): the coarse depths are then NOT ascending, and the merge must still be the reference's stable
     sort -- sorted depths non-decreasing, every slot written."""
     import gnerf_hip
     from oracle import render_ref as R
     monkeypatch.setenv('GNERF_RENDER_KERNEL', kernel)
-    N, res, S, F = 1, 8, 48, 48
+    N, res, F = 1, 8, S
     planes, dec, o, d, nc, nf = _random_scene(21, N, res, S, F, (32, 32))
     nc = nc.clone()
     nc[:, 0::2, 0::2] = 1.0 - 2.0 ** -24
     nc[:, 1::2, 1::2] = 1.0 - 2.0 ** -24
     nc[:, 1::2, 0::2] = 0.0
     nc[:, 0::2, 1::2] = 0.0
-    opts = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, clamp_mode='softplus')
+    rs, re = (2.25, 3.3) if S == 48 else (2.251, 3.3007)          # limits at which the rounding swaps neighbours for this S
+    opts = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=rs, ray_end=re, box_warp=1.0, clamp_mode='softplus')
     st = {}
     ref_rgb, ref_depth, ref_w = R.render(planes, dec, o, d, opts, nc, nf, stages=st)
     assert bool((st['depths_coarse'][:, 1:] < st['depths_coarse'][:, :-1]).any())          # the premise: swapped neighbours exist
     nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
     rgb, depth, wsum, dbg = gnerf_hip.render_forward(nhwc, N, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev),
-                                                     depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0,
+                                                     depth_resolution=S, depth_resolution_importance=F, ray_start=rs, ray_end=re, box_warp=1.0,
                                                      image_width=res, debug=True)
     sorted_d = dbg[:, gnerf_hip.DBG_DEPTH_SORTED if hasattr(gnerf_hip, 'DBG_DEPTH_SORTED') else 5].cpu()
     assert bool((sorted_d[:, 1:] >= sorted_d[:, :-1]).all())

@@ -11,6 +11,8 @@ import bench, gnerf_hip
 dev = torch.device('cuda', 0)
 planes, dec, c2w, intr = bench._scene(dev, 1000)
 N, RES, S, F = bench.N_ITEMS, bench.RES, bench.S_COARSE, bench.S_FINE
+if os.environ.get('STAMPS_SAMPLES'):
+    S = F = int(os.environ['STAMPS_SAMPLES'])
 o, d = gnerf_hip.make_rays(c2w, intr, RES)
 nhwc = gnerf_hip.planes_to_nhwc(planes)
 nc = torch.rand(N * RES * RES, S, device=dev); nf = torch.rand(N * RES * RES, F, device=dev)
@@ -19,7 +21,7 @@ for _ in range(3):
     out = gnerf_hip.render_forward(nhwc, N, dec, o, d, nc, nf, depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=RES, debug=True)
 torch.cuda.synchronize()
 dbg = out[3].cpu().numpy().view(np.uint64).reshape(-1)
-G = 768
+G = 768 if S <= 48 else 512
 st = dbg[:G * 4 * 16].reshape(G, 4, 16).astype(np.float64)
 names = {0: 'slot params', 1: 'tap setup', 2: 'lookups', 3: 'layer1', 4: 'act+layer2', 5: 'step tail', 6: 'barrier(even)', 7: 'barrier(odd)',
          8: 'colour weights (v_e)', 13: 'merge ranks', 14: 'final march', 9: 'outputs', 10: 'colour acc', 11: 'coarse march+importance', 12: 'depth proposals'}
