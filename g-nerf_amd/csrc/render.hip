@@ -7,7 +7,14 @@
 //   depth proposals -> tri-plane bilinear lookup -> 32->64->33 MLP -> coarse march -> importance
 //   resampling -> fine lookup + MLP -> depth merge -> final composite.
 //
-// Work decomposition: ONE WAVE (a 64-lane workgroup) owns a ray at a time and walks a small tile of rays
+// This file holds the pieces every kernel shares (depth proposals, importance resampling, the ray march, DPP scans),
+// the GENERIC kernel described below (any sample count up to 256+256), the entry points and the kernel choice.  The
+// kernels that run G-NeRF's actual configurations are in the .inl files included further down:
+//   render_pipe.inl  3 shader waves + 1 scalar wave per workgroup, three rays in flight: up to 48+48 and up to 96+96 samples
+//   render_coop.inl  3 waves per ray with barrier-separated phases (and the 16-sample shade tile all of them use)
+//   render_bwd.inl   the backward pass (plane + decoder gradients) of the renderer and of run_model
+//
+// Generic kernel: ONE WAVE (a 64-lane workgroup) owns a ray at a time and walks a small tile of rays
 // (4x4 pixels when the rays form an image).  Nothing but the three outputs is ever written to HBM.
 //
 //  * Lookup ("gather") layout: 8 adjacent lanes read one whole 128-byte texel (32 fp32 channels of the NHWC
