@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the fused renderer against the CPU oracle: random sample counts (all three kernels and both
+pipelined instantiations), ragged ray counts, plane sizes, white_back, disparity-space sampling and per-ray limits.
+usage: python tools/fuzz_render.py [n_cases] [seed]"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, 'g-nerf_amd'), os.path.join(ROOT, 'tests'), ROOT]
+import numpy as np
+import torch
+import gnerf_hip
+from oracle import render_ref as R
+from test_gpu_parity import _random_scene
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device('cuda', 0)
+worst = {'mse': 0.0, 'depth': 0.0, 'wsum': 0.0}
+fails = []
+for case in range(n_cases):
+    S = int(rng.choice([rng.integers(4, 49), rng.integers(49, 97), rng.integers(97, 140)], p=[0.4, 0.45, 0.15]))
+    F = int(rng.choice([0, rng.integers(1, 49), rng.integers(49, 97), rng.integers(97, 130)], p=[0.1, 0.4, 0.4, 0.1]))
+    N, res = int(rng.integers(1, 4)), int(rng.integers(2, 7))
+    hw = (int(rng.integers(4, 40)), int(rng.integers(4, 40)))
+    white_back, disparity = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) == 0)
+    per_ray = (not disparity) and bool(rng.integers(0, 4) == 0)
+    planes, dec, o, d, nc, nf = _random_scene(int(rng.integers(1 << 30)), N, res, S, F, hw)
+    rs, re = 2.25, 3.3
+    if per_ray:
+        g = torch.Generator().manual_seed(case)
+        rs = 2.0 + 0.5 * torch.rand(N, res * res, 1, generator=g)
+        re = rs + 0.6 + 0.6 * torch.rand(N, res * res, 1, generator=g)
+    opts = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=rs, ray_end=re, box_warp=1.0, clamp_mode='softplus',
+                white_back=white_back, disparity_space_sampling=disparity)
+    ref_rgb, ref_depth, ref_w = R.render(planes, dec, o, d, opts, nc, nf)
+    nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
+    to = lambda t: t.to(dev) if isinstance(t, torch.Tensor) else t
+    rgb, depth, wsum = gnerf_hip.render_forward(nhwc, N, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev) if F else None,
+                                                depth_resolution=S, depth_resolution_importance=F, ray_start=to(rs), ray_end=to(re), box_warp=1.0,
+                                                white_back=white_back, disparity_space_sampling=disparity, image_width=res)
+    mse = float(((rgb.cpu() - ref_rgb) ** 2).mean())
+    de = float((depth.cpu() - ref_depth).abs().max())
+    we = float((wsum.cpu() - ref_w).abs().max())
+    worst = {'mse': max(worst['mse'], mse), 'depth': max(worst['depth'], de), 'wsum': max(worst['wsum'], we)}
+    if not (mse < 1e-8 and de < 5e-4 and we < 5e-4):
+        fails.append(dict(case=case, S=S, F=F, N=N, res=res, hw=hw, white_back=white_back, disparity=disparity, per_ray=per_ray, mse=mse, depth=de, wsum=we))
+print(json.dumps({'cases': n_cases, 'worst': worst, 'failures': fails}))
+sys.exit(1 if fails else 0)
