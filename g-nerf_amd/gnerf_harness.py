@@ -76,7 +76,8 @@ def init_from_env():
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            use_gpu = torch.cuda.is_available()
+            # GNERF_DIST_BACKEND=gloo forces gloo although a GPU is visible (to exercise the multi-rank code on a one-GPU box)
+            use_gpu = torch.cuda.is_available() and os.environ.get('GNERF_DIST_BACKEND', 'nccl') == 'nccl'
             if use_gpu:
                 torch.cuda.set_device(local_rank)
                 dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
@@ -120,6 +121,8 @@ def max_over_ranks(value, device='cpu'):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
+    if dist.get_backend() != 'nccl':
+        device = 'cpu'
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
