@@ -180,7 +180,7 @@ def main():
                 'note': 'achieved = ALGORITHMIC MLP work (8320 FLOP/sample x 96 samples/ray) / render-kernel time, priced against the '
                         'fp32 matrix peak because the results are fp32-grade.  The kernel evaluates each product as an error-compensated '
                         'hi/lo split on v_mfma_f32_16x16x32_f16 (3 MFMAs per product, fp32 accumulate; pixel MSE vs the reference ~1e-13), '
-                        'which is why it can exceed what the fp32-input MFMA alone allows; rocprof PMC (profiles/r01_final3_pmc.json) shows the kernel '
+                        'which is why it can exceed what the fp32-input MFMA alone allows; rocprof PMC (profiles/r01_final4_pmc.json) shows the kernel '
                         'is VALU-issue bound (SQ_ACTIVE_INST_VALU ~65 % of SIMD cycles, MFMA pipe ~10 %), not HBM-bound (430 FLOP/B)',
                 'executed_f16_mfma_TFLOPs': 3 * samples * (2 * 32 * 64 + 2 * 64 * 32) / k_s / 1e12,
                 'executed_frac_of_f16_peak_2500': 3 * samples * (2 * 32 * 64 + 2 * 64 * 32) / k_s / 1e12 / 2500.0,
