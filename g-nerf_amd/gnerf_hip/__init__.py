@@ -65,6 +65,9 @@ SIGNATURES = {
                                _c_i, _c_i, ctypes.POINTER(_c_i64), _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_p]),
     'gnerf_filtered_lrelu_act': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, ctypes.POINTER(_c_i64), _c_i, _c_i, _c_i, _c_i,
                                         _c_f, _c_f, _c_f, _c_i, _c_p]),
+    'gnerf_filtered_lrelu': (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, ctypes.POINTER(_c_i64),
+                                    _c_i, _c_i, ctypes.POINTER(_c_i64), _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
+                                    _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_i, _c_p]),
     'gnerf_planes_to_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_planes_from_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_make_rays': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_p, _c_p, _c_p]),
@@ -247,6 +250,67 @@ def filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, write_signs):
                                                float(gain), float(slope), float(clamp), mode, _stream(x))
     _check(code, 'gnerf_filtered_lrelu_act')
     return so
+
+
+E_UNSUPPORTED = -3
+
+
+def filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, clamp, flip_filters, write_signs):
+    """Same contract as filtered_lrelu_plugin.filtered_lrelu (reference filtered_lrelu.cpp:20-213): returns
+    (y, so, rc); rc = -1 with empty tensors means "no fused kernel for this configuration" and the caller runs the
+    generic three-launch route (filtered_lrelu.py:225-231).  Anything else that goes wrong raises."""
+    _require_cuda(x)
+    if x.ndim != 4 or x.numel() == 0:
+        raise RuntimeError('filtered_lrelu: x must be a non-empty rank-4 tensor')
+    for f, name in ((fu, 'fu'), (fd, 'fd')):
+        _require_cuda(f)
+        if f.dtype != torch.float32 or f.ndim not in (1, 2) or f.numel() == 0:
+            raise RuntimeError(f'filtered_lrelu: {name} must be a non-empty float32 tensor of rank 1 or 2')
+    _require_cuda(b)
+    if b.dtype != x.dtype or b.ndim != 1 or b.shape[0] != x.shape[1]:
+        raise RuntimeError('filtered_lrelu: b must be a vector with one entry per channel of x, same dtype')
+    if up < 1 or down < 1:
+        raise RuntimeError('filtered_lrelu: up and down must be at least 1')
+    none = (torch.empty([0], device=x.device), torch.empty([0], device=x.device), -1)
+    if x.dtype not in (torch.float32, torch.float16):
+        return none
+    if (fu.ndim == 2 and tuple(fu.shape) != (1, 1)) or (fd.ndim == 2 and tuple(fd.shape) != (1, 1)):
+        return none                                            # non-separable filters: generic route
+    n, c, xh, xw = x.shape
+    fut, fdt = fu.shape[-1] - 1, fd.shape[-1] - 1
+    cw, chh = xw * up + (px0 + px1) - fut, xh * up + (py0 + py1) - fut
+    if not (cw > fdt and chh > fdt):
+        raise RuntimeError('filtered_lrelu: upsampled buffer must be at least the size of downsampling filter')
+    yw, yh = (cw - fdt + (down - 1)) // down, (chh - fdt + (down - 1)) // down
+    if yw < 1 or yh < 1:
+        raise RuntimeError('filtered_lrelu: output must be at least 1x1')
+    channels_last = x.stride(1) == 1 and c > 1
+    y = torch.empty([n, c, yh, yw], dtype=x.dtype, device=x.device,
+                    memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    read_signs = si is not None and si.numel() > 0
+    so = torch.empty([0], dtype=torch.uint8, device=x.device)
+    s, s_h, s_w, mode = None, 0, 0, 0
+    if write_signs:
+        s_h = yh * down - (down - 1) + fdt
+        s_w = (yw * down - (down - 1) + fdt + 15) & ~15
+        so = torch.empty([n, c, s_h, s_w >> 2], dtype=torch.uint8, device=x.device)
+        s, mode = so, 1
+    elif read_signs:
+        _require_cuda(si)
+        if si.dtype != torch.uint8 or si.ndim != 4 or not si.is_contiguous() or si.shape[0] != n or si.shape[1] != c:
+            raise RuntimeError('filtered_lrelu: signs must be a contiguous uint8 [n, c, h, w/4] tensor matching x')
+        s, s_h, s_w, mode = si, si.shape[2], si.shape[3] * 4, 2
+    fu_c, fd_c, b_c = fu.contiguous(), fd.contiguous(), b.contiguous()
+    with _on_device(x.device):
+        code = load().gnerf_filtered_lrelu(_ptr(x), _ptr(fu_c), _ptr(fd_c), _ptr(b_c), _ptr(s), _ptr(y), _DTYPE_CODE[x.dtype],
+                                           n, c, xh, xw, _strides(x), yh, yw, _strides(y),
+                                           fu.shape[-1], fu.ndim, fd.shape[-1], fd.ndim, int(up), int(down), int(px0), int(py0),
+                                           s_h, s_w, int(sx), int(sy), mode, float(gain), float(slope), float(clamp),
+                                           1 if flip_filters else 0, _stream(x))
+    if code == E_UNSUPPORTED:
+        return none
+    _check(code, 'gnerf_filtered_lrelu')
+    return y, so, 0
 
 
 def planes_to_nhwc(planes):

@@ -29,13 +29,10 @@ class _FilteredLReluPlugin:
     """filtered_lrelu_plugin (reference filtered_lrelu.cpp:298-302)."""
     filtered_lrelu_act_ = staticmethod(gnerf_hip.filtered_lrelu_act_)
 
-    @staticmethod
-    def filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, clamp, flip_filters, writeSigns):
-        # Return code -1 = "no specialised kernel for these parameters": the caller then runs the generic
-        # upfirdn2d -> filtered_lrelu_act_ -> upfirdn2d sequence, exactly as the reference does for
-        # unsupported configurations (filtered_lrelu.cpp:55-60, filtered_lrelu.py:225-231).
-        import torch
-        return torch.empty([0], device=x.device), torch.empty([0], device=x.device), -1
+    # Return code -1 = "no fused kernel for these parameters": the caller then runs the generic upfirdn2d ->
+    # filtered_lrelu_act_ -> upfirdn2d sequence, exactly as the reference does for configurations its fused
+    # kernel lacks (filtered_lrelu.cpp:55-60, filtered_lrelu.py:225-231).
+    filtered_lrelu = staticmethod(gnerf_hip.filtered_lrelu)
 
 
 _PLUGINS = {

@@ -88,6 +88,27 @@ int gnerf_filtered_lrelu_act(void* x, uint8_t* s, int dtype, int n, int c, int h
                              float gain, float slope, float clamp, int mode, gnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * filtered_lrelu, fused (filtered_lrelu.cpp:20-213): y = downfir(clamp(lrelu(upfir(x + b) * up^2 * gain))) in one
+ * launch.  x: [n, c, xh, xw] float16/float32 with element strides xs[4]; b: [c], same dtype, contiguous;
+ * fu, fd: float32 filters with fu_taps / fd_taps taps per axis, contiguous; *_rank 1 = separable (applied along
+ * both axes), 2 = a 1x1 rank-2 filter (applied once).  y: [n, c, yh, yw] (strides ys) allocated by the caller with
+ * yw = (xw*up + px0 + px1 - (fu_taps-1) - (fd_taps-1) + down-1) / down (only px0 / py0 are needed here).
+ * Signs: s is the bit-packed tensor of gnerf_filtered_lrelu_act ([n, c, s_h, s_w/4] bytes), sign_mode 0 none,
+ * 1 write (s_h = yh*down-(down-1)+fd_taps-1 rows, forward pass), 2 read (gradient pass: slope / zero factors come
+ * from s at offset (sx, sy), values outside s pass through with the gain only).
+ * Returns GNERF_E_UNSUPPORTED when no fused kernel covers the configuration (resampling factors other than
+ * 1/2/4, more than 8 taps per polyphase branch, non-separable filters, float64): the caller then composes
+ * gnerf_upfirdn2d + gnerf_filtered_lrelu_act + gnerf_upfirdn2d, which is what the reference does on return code -1
+ * (filtered_lrelu.cpp:55-60, filtered_lrelu.py:225-231). */
+int gnerf_filtered_lrelu(const void* x, const float* fu, const float* fd, const void* b, uint8_t* s, void* y,
+                         int dtype, int n, int c, int xh, int xw, const int64_t xs[4],
+                         int yh, int yw, const int64_t ys[4],
+                         int fu_taps, int fu_rank, int fd_taps, int fd_rank,
+                         int up, int down, int px0, int py0,
+                         int s_h, int s_w, int sx, int sy, int sign_mode,
+                         float gain, float slope, float clamp, int flip, gnerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Tri-plane layout change: NCHW float32 [np, c, h, w] -> NHWC [np, h, w, c] (np = 3*batch).
  * The renderer reads whole 128-byte texels (32 channels) from the NHWC copy. */
 int gnerf_planes_to_nhwc(const float* planes_nchw, float* planes_nhwc, int np, int c, int h, int w,

@@ -689,3 +689,132 @@ def test_filtered_lrelu_gpu(dev, golden):
         dxr, dbr = torch.autograd.grad(yr, (xr, br), gy.cpu())
     np.testing.assert_allclose(dx.cpu().numpy(), dxr.numpy(), rtol=1e-4, atol=5e-6)
     np.testing.assert_allclose(db.cpu().numpy(), dbr.numpy(), rtol=1e-4, atol=5e-5)
+
+
+# ---- fused filtered_lrelu kernel (csrc/filtered_lrelu_fused.hip) -----------------------------------------------------
+
+def _fl_filter(taps, seed):
+    rng = np.random.default_rng(seed)
+    f = rng.standard_normal(taps).astype(np.float32)
+    return f / np.abs(f).sum()
+
+
+_FL_CASES = [
+    # up, fu taps, down, fd taps, padding, flip, shape
+    (2, 12, 2, 12, [10, 10, 10, 10], False, (2, 3, 20, 24)),
+    (2, 12, 2, 12, [11, 9, 12, 8], True, (1, 2, 37, 41)),          # several tiles, odd phases
+    (4, 24, 2, 12, [20, 21, 19, 22], False, (1, 2, 18, 22)),
+    (2, 12, 4, 24, [15, 16, 17, 14], True, (1, 2, 40, 36)),
+    (4, 32, 4, 32, [31, 30, 29, 32], False, (1, 1, 24, 20)),
+    (2, 16, 2, 16, [12, 13, 14, 11], False, (1, 3, 19, 17)),
+    (2, 8, 1, 1, [4, 3, 5, 2], False, (2, 2, 15, 70)),            # no downsampling filter
+    (1, 1, 2, 8, [3, 4, 2, 5], True, (2, 2, 33, 31)),             # no upsampling filter
+    (1, 1, 1, 1, [0, 0, 0, 0], False, (2, 5, 9, 13)),             # bias + activation only
+    (2, 3, 2, 5, [3, 2, 3, 2], False, (1, 2, 16, 16)),            # short filters, zero-padded to the branch size
+    (4, 24, 4, 24, [22, 23, 21, 24], True, (1, 1, 70, 66)),
+]
+
+
+@pytest.mark.parametrize('case', _FL_CASES, ids=lambda c: f'up{c[0]}x{c[1]}_down{c[2]}x{c[3]}')
+@pytest.mark.parametrize('dtype', ['float32', 'float16'])
+def test_filtered_lrelu_fused_vs_oracle(dev, case, dtype):
+    """The single-launch kernel through the plugin entry point (return code 0 = it ran fused) against the numpy oracle."""
+    import gnerf_hip
+    from oracle import ops_ref as O
+    up, fut, down, fdt, pad, flip, shape = case
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(shape).astype(np.float32)
+    b = rng.standard_normal(shape[1]).astype(np.float32)
+    fu = _fl_filter(fut, 1) if fut > 1 else None
+    fd = _fl_filter(fdt, 2) if fdt > 1 else None
+    gain, slope, clamp = 1.7, 0.15, 0.6
+    td = getattr(torch, dtype)
+    xt, bt = _t(x, dev).to(td), _t(b, dev).to(td)
+    fut_t = _t(fu, dev) if fu is not None else torch.ones([1, 1], device=dev)
+    fdt_t = _t(fd, dev) if fd is not None else torch.ones([1, 1], device=dev)
+    y, so, rc = gnerf_hip.filtered_lrelu(xt, fut_t, fdt_t, bt, torch.empty([0]), up, down, *pad, 0, 0, gain, slope, clamp, flip, True)
+    assert rc == 0, 'configuration must be covered by the fused kernel'
+    ref = O.filtered_lrelu(xt.float().cpu().numpy(), fu, fd, bt.float().cpu().numpy(), up=up, down=down, padding=pad,
+                           gain=gain, slope=slope, clamp=clamp, flip_filter=flip)
+    assert tuple(y.shape) == ref.shape
+    if dtype == 'float32':
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=2e-4, atol=2e-5)
+    else:
+        np.testing.assert_allclose(y.float().cpu().numpy(), ref, rtol=4e-3, atol=2e-3)
+    # sign tensor: recompute the activated intermediate with the oracle and compare the two bits per pixel where the
+    # value is not within rounding of a decision boundary
+    if dtype == 'float32':
+        u = O.upfirdn2d(O.bias_act(xt.float().cpu().numpy(), bt.float().cpu().numpy()), fu, up=up, padding=pad, gain=up ** 2, flip_filter=flip) * gain
+        s_h, s_w = so.shape[2], so.shape[3] * 4
+        hh, ww = min(u.shape[2], s_h), min(u.shape[3], s_w)
+        sb = so.cpu().numpy()
+        bits = np.stack([(sb >> (2 * k)) & 3 for k in range(4)], axis=-1).reshape(*sb.shape[:3], -1)[:, :, :hh, :ww]
+        uu = u[:, :, :hh, :ww]
+        lr = np.where(uu < 0, uu * slope, uu)
+        want = np.where(np.abs(lr) > clamp, 2, (uu < 0).astype(np.int64))
+        safe = (np.abs(uu) > 1e-5) & (np.abs(np.abs(lr) - clamp) > 1e-5)
+        assert hh >= (y.shape[2] - 1) * down + 1 and safe.mean() > 0.25     # (zero padding leaves exact zeros: not 'safe')
+        assert np.array_equal(bits[safe], want[safe])
+
+
+@pytest.mark.parametrize('case', [_FL_CASES[1], _FL_CASES[2], _FL_CASES[3], _FL_CASES[6], _FL_CASES[7]],
+                         ids=lambda c: f'up{c[0]}x{c[1]}_down{c[2]}x{c[3]}')
+def test_filtered_lrelu_fused_gradient(dev, case):
+    """Backward = the fused kernel again with up/down swapped, reading the sign tensor (filtered_lrelu.py:254-265),
+    against autograd through the PyTorch-op form on the CPU."""
+    from torch_utils.ops import filtered_lrelu
+    import gnerf_hip
+    up, fut, down, fdt, pad, flip, shape = case
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(shape[1]).astype(np.float32))
+    fu = torch.from_numpy(_fl_filter(fut, 1)) if fut > 1 else None
+    fd = torch.from_numpy(_fl_filter(fdt, 2)) if fdt > 1 else None
+    kw = dict(up=up, down=down, padding=pad, gain=1.7, slope=0.15, clamp=0.6, flip_filter=flip)
+    calls = []
+    real = gnerf_hip.filtered_lrelu
+    plugin = filtered_lrelu.custom_ops.get_plugin('filtered_lrelu_plugin')
+
+    def spy(*a):
+        r = real(*a)
+        calls.append(r[2])
+        return r
+    plugin.filtered_lrelu = staticmethod(spy)
+    try:
+        xg, bg = x.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        y = filtered_lrelu.filtered_lrelu(xg, fu=None if fu is None else fu.to(dev), fd=None if fd is None else fd.to(dev), b=bg, **kw)
+        gy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+        dx, db = torch.autograd.grad(y, (xg, bg), gy.to(dev))
+    finally:
+        plugin.filtered_lrelu = staticmethod(real)
+    assert calls == [0, 0], f'forward and backward must both run fused, got return codes {calls}'
+    xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = filtered_lrelu.filtered_lrelu(xr, fu=fu, fd=fd, b=br, impl='ref', **kw)
+    dxr, dbr = torch.autograd.grad(yr, (xr, br), gy)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(dx.cpu().numpy(), dxr.numpy(), rtol=2e-4, atol=3e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), dbr.numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_filtered_lrelu_fused_declines_what_it_does_not_cover(dev):
+    import gnerf_hip
+    from oracle import ops_ref as O
+    x = torch.randn(1, 2, 16, 16, device=dev)
+    b = torch.zeros(2, device=dev)
+    one = torch.ones([1, 1], device=dev)
+    f2d = torch.ones([4, 4], device=dev) / 16
+    f3 = torch.ones([9], device=dev) / 9
+    big = torch.ones([40], device=dev) / 40
+    none = torch.empty([0])
+    assert gnerf_hip.filtered_lrelu(x, f2d, one, b, none, 2, 1, 2, 1, 2, 1, 0, 0, 1.0, 0.2, 1e9, False, False)[2] == -1     # non-separable
+    assert gnerf_hip.filtered_lrelu(x, f3, f3, b, none, 3, 3, 4, 4, 4, 4, 0, 0, 1.0, 0.2, 1e9, False, False)[2] == -1        # factor 3
+    assert gnerf_hip.filtered_lrelu(x, big, one, b, none, 2, 1, 20, 19, 20, 19, 0, 0, 1.0, 0.2, 1e9, False, False)[2] == -1  # 20 taps per branch
+    assert gnerf_hip.filtered_lrelu(x.double(), one, one, b.double(), none, 1, 1, 0, 0, 0, 0, 0, 0, 1.0, 0.2, 1e9, False, False)[2] == -1
+    # ... and the public op still answers through the three-launch route
+    from torch_utils.ops import filtered_lrelu
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        y = filtered_lrelu.filtered_lrelu(x, fu=f2d, up=2, padding=[2, 1, 2, 1])
+    ref = O.filtered_lrelu(x.cpu().numpy(), f2d.cpu().numpy(), None, None, up=2, padding=[2, 1, 2, 1])
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
