@@ -488,5 +488,5 @@ __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD :
         out[15] = nr;
     }
 #endif
-    if (tid == 192) publish_depth_range(P, blk_min, blk_max);
+    if (wv == 3 && lane == 0) publish_depth_range(P, blk_min, blk_max);
 }
