@@ -139,3 +139,128 @@ def render_orbit(render_frame, n_frames, rank=0, world=1, **orbit_kwargs):
     if not frames:
         return None, (lo, hi)
     return torch.cat(frames, 0), (lo, hi)
+
+
+# ---------------------------------------------------------------------------------------------
+# data-parallel training step (BASELINE config 5): the reference's collective call sites, re-done for xGMI
+
+
+def _dist_on():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def params_with_grad(*modules_or_tensors):
+    """Parameters that take part in the gradient exchange, in a fixed order (training_loop.py:380-386: numel > 0 and a
+    gradient present)."""
+    out = []
+    for m in modules_or_tensors:
+        ps = m.parameters() if isinstance(m, torch.nn.Module) else [m]
+        out += [p for p in ps if p.numel() > 0 and p.grad is not None]
+    return out
+
+
+def allreduce_flat_grads(params, bucket_bytes=None):
+    """Average the gradients of `params` over all ranks and scrub non-finite values, with the semantics of the
+    reference's manual exchange (training_loop.py:388-396, :427-436): flatten -> SUM all-reduce -> / world ->
+    nan_to_num(nan=0, posinf=1e5, neginf=-1e5) -> hand each parameter a view of the flat vector as its .grad.
+
+    What is different from the reference: the flat vector is exchanged in `bucket_bytes` pieces issued back to back as
+    asynchronous collectives (RCCL pipelines them over the 7 xGMI links; the reference issues one monolithic blocking
+    all-reduce of ~123 MB), and the division + scrub of a bucket runs while the next bucket is on the wire.
+    bucket_bytes=None -> one collective (the reference's pattern).  Returns the flat vector."""
+    import torch.distributed as dist
+    params = list(params)
+    if not params:
+        return None
+    flat = torch.cat([p.grad.flatten() for p in params])
+    if _dist_on():
+        world = dist.get_world_size()
+        if bucket_bytes is None or flat.numel() * flat.element_size() <= bucket_bytes:
+            dist.all_reduce(flat)
+            flat /= world
+            torch.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)
+        else:
+            per = max(1, bucket_bytes // flat.element_size())
+            pieces = list(flat.split(per))
+            works = [dist.all_reduce(pc, async_op=True) for pc in pieces]
+            for pc, w in zip(pieces, works):
+                w.wait()
+                pc /= world
+                torch.nan_to_num(pc, nan=0, posinf=1e5, neginf=-1e5, out=pc)
+    else:
+        torch.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)
+    for p, g in zip(params, flat.split([p.numel() for p in params])):
+        p.grad = g.reshape(p.shape)
+    return flat
+
+
+def broadcast_module(module, src=0):
+    """Make every parameter and buffer of `module` equal to rank `src`'s (training_loop.py:234-238).  The reference
+    broadcasts 195 tensors one by one; here tensors of one dtype travel as ONE flat buffer."""
+    import torch.distributed as dist
+    if not _dist_on():
+        return
+    tensors = [t for t in list(module.parameters()) + list(module.buffers()) if t.numel() > 0]
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dt, ts in by_dtype.items():
+        flat = torch.cat([t.detach().flatten() for t in ts])
+        dist.broadcast(flat, src=src)
+        for t, piece in zip(ts, flat.split([t.numel() for t in ts])):
+            t.detach().copy_(piece.reshape(t.shape))
+
+
+def check_ddp_consistency(module, src=0):
+    """Assert that every parameter / buffer equals rank `src`'s bit for bit (misc.py:202-213, run at snapshot time,
+    training_loop.py:520-521) -- one flat broadcast per dtype instead of one per tensor."""
+    import torch.distributed as dist
+    if not _dist_on():
+        return
+    named = [(n, t) for n, t in list(module.named_parameters()) + list(module.named_buffers()) if t.numel() > 0]
+    by_dtype = {}
+    for n, t in named:
+        by_dtype.setdefault(t.dtype, []).append((n, t))
+    for dt, nts in by_dtype.items():
+        mine = torch.cat([(torch.nan_to_num(t.detach()) if t.is_floating_point() else t.detach()).flatten() for _, t in nts])
+        other = mine.clone()
+        dist.broadcast(other, src=src)
+        if not torch.equal(mine, other):
+            ofs = 0
+            for n, t in nts:
+                if not torch.equal(mine[ofs:ofs + t.numel()], other[ofs:ofs + t.numel()]):
+                    raise AssertionError(f'{type(module).__name__}.{n} differs from rank {src}')
+                ofs += t.numel()
+
+
+class FullyConnected(torch.nn.Module):
+    """The layer OSGDecoder is made of (networks_stylegan2.py:101-134, 'linear' activation with bias): weight ~ N(0,1) /
+    lr_multiplier, runtime gains weight_gain = lr_multiplier / sqrt(in), bias_gain = lr_multiplier."""
+
+    def __init__(self, in_features, out_features, lr_multiplier=1.0):
+        super().__init__()
+        self.in_features, self.out_features, self.activation = in_features, out_features, 'linear'
+        self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
+        self.bias = torch.nn.Parameter(torch.zeros([out_features]))
+        self.weight_gain = lr_multiplier / (in_features ** 0.5)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        return torch.addmm((self.bias * self.bias_gain).unsqueeze(0), x, (self.weight * self.weight_gain).t())
+
+
+class TriPlaneDecoder(torch.nn.Module):
+    """OSGDecoder (triplane.py:113-136) for harnesses that must run where the reference tree is absent (the GPU box):
+    mean over the three planes -> FC(32,64) -> Softplus -> FC(64, 1+32); sigma = out[0], rgb = sigmoid(out[1:])*1.002-0.001."""
+
+    def __init__(self, n_features=32, decoder_lr_mul=1.0, decoder_output_dim=32):
+        super().__init__()
+        self.net = torch.nn.Sequential(FullyConnected(n_features, 64, decoder_lr_mul), torch.nn.Softplus(),
+                                       FullyConnected(64, 1 + decoder_output_dim, decoder_lr_mul))
+
+    def forward(self, sampled_features, ray_directions):
+        x = sampled_features.mean(1)
+        N, M, C = x.shape
+        x = self.net(x.view(N * M, C)).view(N, M, -1)
+        return {'rgb': torch.sigmoid(x[..., 1:]) * (1 + 2 * 0.001) - 0.001, 'sigma': x[..., 0:1]}

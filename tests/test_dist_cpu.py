@@ -87,3 +87,90 @@ def test_orbit_cameras_match_reference(golden):
     assert c.shape == (1, 25) and abs(float(c[0, 16]) - 4.2647) < 1e-6 and float(c[0, 24]) == 1.0
     img = torch.tensor([[[[-1.0, 0.0], [1.0, 2.0]]]])
     assert H.to_uint8(img).flatten().tolist() == [0, 128, 255, 255]        # (x*127.5+128).clamp(0,255) truncated
+
+
+# ---- data-parallel training step (BASELINE config 5): flat-gradient exchange, weight broadcast, consistency check ----
+
+def _train_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'g-nerf_amd'))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import gnerf_harness as H
+    import train_step_mi355x as T
+    H.init_from_env()
+    torch.manual_seed(10 + rank)                                      # deliberately DIFFERENT weights per rank ...
+    opts = dict(T.RENDERING, depth_resolution=6, depth_resolution_importance=6)
+    model = T.RendererTrainer(batch=1, plane_res=8, ballast_floats=100, rendering=opts)
+    w_before = model.decoder.net[0].weight.detach().clone()
+    H.broadcast_module(model)                                         # ... made equal to rank 0's
+    H.check_ddp_consistency(model)
+    w_rank0 = model.decoder.net[0].weight.detach().clone()
+    c, target, target_depth = T.synthetic_batch(1, 4, torch.device('cpu'), seed=100 + rank)
+    torch.manual_seed(1000 + rank)
+    # local gradients, then the exchange by hand-made reference: mean over ranks, NaN/inf scrubbed
+    img, depth = model(c, 4)
+    ((img - target).abs().mean() + (depth - target_depth).abs().mean() + 1e-3 * model.ballast.sum()).backward()
+    if rank == 1:
+        model.ballast.grad[3] = float('nan')
+        model.ballast.grad[4] = float('inf')
+    params = H.params_with_grad(model)
+    local = torch.cat([p.grad.flatten() for p in params]).clone()
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    want = torch.nan_to_num(torch.stack(gathered).sum(0) / world, nan=0, posinf=1e5, neginf=-1e5)
+    flat = H.allreduce_flat_grads(params, bucket_bytes=4096)      # several async buckets
+    ok_bucketed = bool(torch.allclose(flat, want, rtol=1e-6, atol=1e-9)) and all(p.grad.shape == p.shape for p in params)
+    for p, piece in zip(params, local.split([p.numel() for p in params])):
+        p.grad = piece.reshape(p.shape).clone()
+    flat1 = H.allreduce_flat_grads(params)                                                 # the reference's single collective
+    ok_single = bool(torch.allclose(flat1, want, rtol=1e-6, atol=1e-9))
+    ofs = 0
+    for p_ in params:
+        if p_ is model.ballast:
+            break
+        ofs += p_.numel()
+    scrubbed = (float(flat1[ofs + 3]), float(flat1[ofs + 4]))
+    # two full optimiser steps keep the replicas identical although the data differ per rank
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, betas=(0.0, 0.99), eps=1e-8)
+    for _ in range(2):
+        loss = T.train_step(model, opt, c, target, target_depth, 4, bucket_bytes=4096)
+    H.check_ddp_consistency(model)
+    moved = float((model.decoder.net[0].weight.detach() - w_rank0).abs().max())
+    # a diverged replica is caught
+    caught = False
+    if rank == 1:
+        with torch.no_grad():
+            model.decoder.net[2].bias[0] += 1.0
+    try:
+        H.check_ddp_consistency(model)
+    except AssertionError as e:
+        caught = 'bias' in str(e)
+    q.put((rank, ok_bucketed, ok_single, scrubbed, moved, caught, float((w_before - w_rank0).abs().max()), float(loss)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_step():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=300)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        ok_bucketed, ok_single, scrubbed, moved, caught, init_diff, loss = res[r]
+        assert ok_bucketed and ok_single
+        assert scrubbed[0] == 0.0                                                        # NaN + x -> NaN -> 0
+        assert scrubbed[1] == 1e5                                                        # inf -> 1e5
+        assert moved > 0 and np.isfinite(loss)
+    assert res[0][5] == 0.0 and res[1][5] > 0            # rank 1 started from different weights and now holds rank 0's
+    assert res[1][4] and not res[0][4]                   # the diverged replica (rank 1) is the one that notices
