@@ -3,8 +3,10 @@ interface (torch_utils/ops/filtered_lrelu.py: filtered_lrelu :58, _filtered_lrel
 _filtered_lrelu_cuda :161).
 
 G-NeRF never executes this op (only StyleGAN3's SynthesisLayer calls it and G-NeRF never builds one);
-it is kept API-complete.  On a GPU it runs as three hand-written gfx950 launches -- upfirdn2d,
-filtered_lrelu_act_ (which also records the 2-bit sign tensor), upfirdn2d -- i.e. the path the
+it is kept API-complete.  On a GPU it runs as ONE hand-written gfx950 launch (csrc/filtered_lrelu_fused.hip:
+separable filters, up/down in {1,2,4}, <= 8 taps per polyphase branch, fp16/fp32) with the upsampled
+intermediate held in LDS; configurations the fused kernel declines (return code -1) run as three launches
+-- upfirdn2d, filtered_lrelu_act_ (which also records the 2-bit sign tensor), upfirdn2d -- the path the
 reference itself takes whenever its fused kernel has no specialisation (filtered_lrelu.py:225-231).
 Only the packed sign tensor is kept for the backward pass, which is the same op with up and down
 swapped reading the signs back."""
@@ -114,8 +116,8 @@ class _FilteredLRelu(torch.autograd.Function):
         if any(lo < hi for lo, hi in zip(strides[:-1], strides[1:])):
             warnings.warn("low-performance memory layout detected in filtered_lrelu input", RuntimeWarning)
         pad = [c.px0, c.px1, c.py0, c.py1]
-        # A fused single-kernel variant would be tried first (return code < 0 = not available); this build always takes
-        # the three-launch route, which is also the reference's route for configurations its fused kernel lacks.
+        # The fused single-launch kernel first; return code < 0 = it does not cover this configuration, and the
+        # three-launch route below (the reference's route for configurations ITS fused kernel lacks) takes over.
         y, so, rc = _plugin.filtered_lrelu(x, fu, fd, b, si, c.up, c.down, *pad, sx, sy, c.gain, c.slope, c.clamp, c.flip, write_signs)
         if rc < 0:
             y = x.add(b.unsqueeze(-1).unsqueeze(-1))

@@ -114,7 +114,8 @@ def main():
 
     rank, world, local_rank = H.init_from_env()
     use_gpu = torch.cuda.is_available() if args.device is None else args.device.startswith('cuda')
-    dev = torch.device('cuda', local_rank) if use_gpu else torch.device('cpu')
+    # (modulo: a rehearsal of several ranks on a one-GPU box with GNERF_DIST_BACKEND=gloo shares the card)
+    dev = torch.device('cuda', local_rank % max(1, torch.cuda.device_count())) if use_gpu else torch.device('cpu')
     if use_gpu:
         torch.cuda.set_device(dev)
     torch.manual_seed(0)                                                    # same initial weights on every rank ...
