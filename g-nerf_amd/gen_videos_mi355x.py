@@ -46,10 +46,17 @@ def ffhq_generator_kwargs(depth_resolution=48, depth_resolution_importance=48):
 
 
 def build_random_generator(seed, device, **kw):
-    from training.triplane import TriPlaneGenerator          # the reference's class (its renderer/ops resolve to this repo)
+    """Seeded random-init FFHQ-config generator: the reference's TriPlaneGenerator when its tree is importable (its renderer
+    and ops then resolve to this repo through the overlay), else this repo's inference-only equivalent with the same layer
+    graph and parameter names (gnerf_generator.Generator; the GPU box has no reference tree)."""
     torch.manual_seed(seed)
-    G = TriPlaneGenerator(**ffhq_generator_kwargs(**kw)).eval().requires_grad_(False)
-    return G.to(device)
+    try:
+        from training.triplane import TriPlaneGenerator
+        G = TriPlaneGenerator(**ffhq_generator_kwargs(**kw))
+    except ImportError:
+        import gnerf_generator
+        G = gnerf_generator.Generator(rendering_kwargs=ffhq_generator_kwargs(**kw)['rendering_kwargs'])
+    return G.eval().requires_grad_(False).to(device)
 
 
 def load_generator(network_pkl, device):

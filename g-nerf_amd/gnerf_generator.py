@@ -1,0 +1,266 @@
+"""Inference-only tri-plane generator for benchmarks and harnesses that must run where the reference tree is absent
+(the GPU box): the CALLERS on either side of the hot path -- StyleGAN2 backbone -> tri-planes -> [renderer] ->
+super-resolution to 512x512 -- as plain PyTorch modules (convolutions go to MIOpen) around this repo's renderer and custom
+ops.  SURVEY.md section 8a rows 11 and C: these stay PyTorch; nothing here is a kernel.
+
+The layer graph and the parameter / buffer NAMES are those of the reference's FFHQ configuration, so a reference
+state_dict loads with strict=True and the two produce the same images (tests/test_generator_cpu.py does exactly that in
+the build container):
+    TriPlaneGenerator         g_nerf/training/triplane.py:19-108          -> Generator
+    OSGDecoder                g_nerf/training/triplane.py:113-136         -> gnerf_harness.TriPlaneDecoder
+    Generator/Mapping/Synthesis*  g_nerf/training/networks_stylegan2.py:41-557  -> Backbone, Mapping, Synthesis, Block, StyledConv, ToRGB
+    conv2d_resample (up=2)    g_nerf/torch_utils/ops/conv2d_resample.py:114-131 -> StyledConv.forward
+    SuperresolutionHybrid8XDC g_nerf/training/superresolution.py:266-303  -> SuperRes8XDC
+What is deliberately missing: training mode (un-fused modulated convolution, random noise, EMA updates, truncation),
+the 'orig'/'resnet' block architectures, the other seven super-resolution variants, pickling hooks.
+"""
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from torch_utils.ops import bias_act, upfirdn2d
+from training.volumetric_rendering.renderer import ImportanceRenderer
+from training.volumetric_rendering.ray_sampler import RaySampler
+
+import gnerf_harness as H
+
+LRELU_GAIN = math.sqrt(2)
+
+
+class Linear(nn.Module):
+    """FullyConnectedLayer (networks_stylegan2.py:101-134): runtime-scaled weight, optional activation through bias_act."""
+
+    def __init__(self, n_in, n_out, activation='linear', lr_multiplier=1.0, bias_init=0.0):
+        super().__init__()
+        self.activation = activation
+        self.weight = nn.Parameter(torch.randn(n_out, n_in) / lr_multiplier)
+        self.bias = nn.Parameter(torch.full([n_out], float(bias_init)))
+        self.weight_gain, self.bias_gain = lr_multiplier / math.sqrt(n_in), lr_multiplier
+
+    def forward(self, x):
+        w, b = self.weight.to(x.dtype) * self.weight_gain, self.bias.to(x.dtype) * self.bias_gain
+        if self.activation == 'linear':
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+
+
+def _second_moment_normalize(x, eps=1e-8):
+    return x * (x.square().mean(dim=1, keepdim=True) + eps).rsqrt()
+
+
+class Mapping(nn.Module):
+    """MappingNetwork (networks_stylegan2.py:200-272) without truncation / EMA: z, c -> ws [N, num_ws, w_dim]."""
+
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=2, lr_multiplier=0.01):
+        super().__init__()
+        self.num_ws, self.num_layers = num_ws, num_layers
+        self.embed = Linear(c_dim, w_dim)
+        feats = [z_dim + w_dim] + [w_dim] * num_layers
+        for i in range(num_layers):
+            setattr(self, f'fc{i}', Linear(feats[i], feats[i + 1], activation='lrelu', lr_multiplier=lr_multiplier))
+        self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    def forward(self, z, c):
+        x = torch.cat([_second_moment_normalize(z.float()), _second_moment_normalize(self.embed(c.float()))], dim=1)
+        for i in range(self.num_layers):
+            x = getattr(self, f'fc{i}')(x)
+        return x.unsqueeze(1).repeat(1, self.num_ws, 1)
+
+
+def _modulated_weights(weight, styles, demodulate, half):
+    """Per-sample convolution weights [N, O, I, k, k] (networks_stylegan2.py:61-75, the fused form used at inference)."""
+    if half and demodulate:             # pre-normalisation against fp16 overflow (:62-64)
+        weight = weight * (1 / math.sqrt(weight[0].numel()) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
+    w = weight.unsqueeze(0) * styles[:, None, :, None, None]
+    if demodulate:
+        w = w * (w.square().sum(dim=[2, 3, 4], keepdim=True) + 1e-8).rsqrt()
+    return w
+
+
+class StyledConv(nn.Module):
+    """SynthesisLayer (networks_stylegan2.py:280-345): modulated 3x3 convolution (optionally x2 upsampling = transposed
+    convolution + the 4x4 blur, conv2d_resample.py:114-131), constant noise, bias + leaky ReLU (+ clamp) in bias_act."""
+
+    def __init__(self, c_in, c_out, w_dim, resolution, up=1, conv_clamp=None):
+        super().__init__()
+        self.up, self.conv_clamp, self.resolution = up, conv_clamp, resolution
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter([1, 3, 3, 1]))
+        self.affine = Linear(w_dim, c_in, bias_init=1.0)
+        self.weight = nn.Parameter(torch.randn(c_out, c_in, 3, 3))
+        self.register_buffer('noise_const', torch.randn(resolution, resolution))
+        self.noise_strength = nn.Parameter(torch.zeros([]))
+        self.bias = nn.Parameter(torch.zeros(c_out))
+
+    def forward(self, x, w, noise_mode='const', gain=1.0):
+        n, c_in, h, wd = x.shape
+        wts = _modulated_weights(self.weight, self.affine(w), True, x.dtype == torch.float16).to(x.dtype)      # [N,O,I,3,3]
+        c_out = wts.shape[1]
+        x = x.reshape(1, n * c_in, h, wd)
+        if self.up == 1:
+            x = F.conv2d(x, wts.reshape(n * c_out, c_in, 3, 3), padding=1, groups=n)
+        else:
+            # stride-2 transposed convolution (kernel as is: the reference un-flips it twice), 2H+1 outputs per axis, then
+            # the low-pass filter with gain up^2 and one pixel of padding -> 2H
+            x = F.conv_transpose2d(x, wts.transpose(1, 2).reshape(n * c_in, c_out, 3, 3), stride=2, groups=n)
+            x = upfirdn2d.upfirdn2d(x, self.resample_filter, padding=[1, 1, 1, 1], gain=4)
+        x = x.reshape(n, c_out, *x.shape[2:])
+        if noise_mode == 'const':
+            x = x.add_((self.noise_const * self.noise_strength).to(x.dtype))
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        return bias_act.bias_act(x, self.bias.to(x.dtype), act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
+
+
+class ToRGB(nn.Module):
+    """ToRGBLayer (networks_stylegan2.py:349-367): modulated 1x1 convolution without demodulation, linear bias_act."""
+
+    def __init__(self, c_in, c_out, w_dim, conv_clamp=None):
+        super().__init__()
+        self.conv_clamp = conv_clamp
+        self.affine = Linear(w_dim, c_in, bias_init=1.0)
+        self.weight = nn.Parameter(torch.randn(c_out, c_in, 1, 1))
+        self.bias = nn.Parameter(torch.zeros(c_out))
+        self.weight_gain = 1 / math.sqrt(c_in)
+
+    def forward(self, x, w):
+        n, c_in, h, wd = x.shape
+        wts = _modulated_weights(self.weight, self.affine(w) * self.weight_gain, False, False).to(x.dtype)
+        x = F.conv2d(x.reshape(1, n * c_in, h, wd), wts.reshape(-1, c_in, 1, 1), groups=n).reshape(n, -1, h, wd)
+        return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
+
+
+class Block(nn.Module):
+    """SynthesisBlock, 'skip' architecture (networks_stylegan2.py:371-470): [const | conv0 (x up)] -> conv1 -> ToRGB added to
+    the (upsampled) running image."""
+
+    def __init__(self, c_in, c_out, w_dim, resolution, img_channels, is_last, use_fp16=False, conv_clamp=None, up=2):
+        super().__init__()
+        self.c_in, self.up, self.use_fp16, self.is_last = c_in, up, use_fp16, is_last
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter([1, 3, 3, 1]))
+        if c_in == 0:
+            self.const = nn.Parameter(torch.randn(c_out, resolution, resolution))
+        else:
+            self.conv0 = StyledConv(c_in, c_out, w_dim, resolution, up=up, conv_clamp=conv_clamp)
+        self.conv1 = StyledConv(c_out, c_out, w_dim, resolution, conv_clamp=conv_clamp)
+        self.torgb = ToRGB(c_out, img_channels, w_dim, conv_clamp=conv_clamp)
+        self.num_conv, self.num_torgb = (1 if c_in == 0 else 2), 1
+
+    def forward(self, x, img, ws, noise_mode='const'):
+        dtype = torch.float16 if self.use_fp16 and ws.is_cuda else torch.float32
+        ws = ws.unbind(dim=1)
+        if self.c_in == 0:
+            x = self.const.to(dtype).unsqueeze(0).repeat(ws[0].shape[0], 1, 1, 1)
+            x = self.conv1(x, ws[0], noise_mode)
+        else:
+            x = self.conv0(x.to(dtype), ws[0], noise_mode)
+            x = self.conv1(x, ws[1], noise_mode)
+        if img is not None and self.up == 2:
+            img = upfirdn2d.upsample2d(img, self.resample_filter)
+        y = self.torgb(x, ws[-1]).float()
+        return x, (img.add_(y) if img is not None else y)
+
+
+class Synthesis(nn.Module):
+    """SynthesisNetwork (networks_stylegan2.py:474-525): blocks b4 ... b<resolution>."""
+
+    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512):
+        super().__init__()
+        self.block_resolutions = [2 ** i for i in range(2, int(math.log2(img_resolution)) + 1)]
+        ch = {r: min(channel_base // r, channel_max) for r in self.block_resolutions}
+        self.num_ws = 0
+        for r in self.block_resolutions:
+            blk = Block(ch[r // 2] if r > 4 else 0, ch[r], w_dim, r, img_channels, is_last=(r == img_resolution))
+            self.num_ws += blk.num_conv + (blk.num_torgb if r == img_resolution else 0)
+            setattr(self, f'b{r}', blk)
+
+    def forward(self, ws, noise_mode='const'):
+        ws = ws.float()
+        x = img = None
+        i = 0
+        for r in self.block_resolutions:
+            blk = getattr(self, f'b{r}')
+            x, img = blk(x, img, ws.narrow(1, i, blk.num_conv + blk.num_torgb), noise_mode)
+            i += blk.num_conv
+        return img
+
+
+class Backbone(nn.Module):
+    """networks_stylegan2.Generator (:529-557): mapping + synthesis to the 96-channel 256x256 plane image."""
+
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, num_mapping_layers=2, **synthesis_kwargs):
+        super().__init__()
+        self.synthesis = Synthesis(w_dim, img_resolution, img_channels, **synthesis_kwargs)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = Mapping(z_dim, c_dim, w_dim, self.num_ws, num_layers=num_mapping_layers)
+
+
+class SuperRes8XDC(nn.Module):
+    """SuperresolutionHybrid8XDC (superresolution.py:266-303): 64^2 feature image -> block64 (no upsampling) -> antialiased
+    bilinear resize to 128^2 -> block0 (256^2, 256 ch) -> block1 (512^2, 128 ch); fp16 with clamp 256 on the GPU."""
+
+    def __init__(self, channels=32, w_dim=512, use_fp16=True, antialias=True):
+        super().__init__()
+        clamp = 256 if use_fp16 else None
+        self.antialias = antialias
+        self.block64 = Block(channels, channels, w_dim, 64, 3, is_last=True, use_fp16=use_fp16, conv_clamp=clamp, up=1)
+        self.block0 = Block(channels, 256, w_dim, 256, 3, is_last=False, use_fp16=use_fp16, conv_clamp=clamp)
+        self.block1 = Block(256, 128, w_dim, 512, 3, is_last=True, use_fp16=use_fp16, conv_clamp=clamp)
+
+    def forward(self, rgb, x, ws, noise_mode='none'):
+        ws = ws[:, -1:, :].repeat(1, 3, 1)
+        x_raw, image_raw = self.block64(x, rgb, ws, noise_mode)
+        if x.shape[-1] != 128:
+            x = F.interpolate(x_raw, size=(128, 128), mode='bilinear', align_corners=False, antialias=self.antialias)
+            rgb = F.interpolate(image_raw, size=(128, 128), mode='bilinear', align_corners=False, antialias=self.antialias)
+        x, rgb = self.block0(x, rgb, ws, noise_mode)
+        x, rgb = self.block1(x, rgb, ws, noise_mode)
+        return rgb, image_raw
+
+
+FFHQ_RENDERING = {
+    'depth_resolution': 48, 'depth_resolution_importance': 48, 'ray_start': 2.25, 'ray_end': 3.3, 'box_warp': 1,
+    'disparity_space_sampling': False, 'clamp_mode': 'softplus', 'avg_camera_radius': 2.7, 'avg_camera_pivot': [0, 0, 0.2],
+    'c_gen_conditioning_zero': False, 'c_scale': 1, 'superresolution_noise_mode': 'none', 'sr_antialias': True, 'decoder_lr_mul': 1,
+}
+
+
+class Generator(nn.Module):
+    """TriPlaneGenerator (triplane.py:19-108), FFHQ configuration (train.py:238-377), inference only."""
+
+    def __init__(self, z_dim=512, c_dim=25, w_dim=512, rendering_kwargs=None, sr_use_fp16=True):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
+        self.rendering_kwargs = dict(FFHQ_RENDERING if rendering_kwargs is None else rendering_kwargs)
+        self.renderer, self.ray_sampler = ImportanceRenderer(), RaySampler()
+        self.backbone = Backbone(z_dim, c_dim, w_dim, img_resolution=256, img_channels=96)
+        self.superresolution = SuperRes8XDC(32, w_dim, use_fp16=sr_use_fp16, antialias=self.rendering_kwargs.get('sr_antialias', True))
+        self.decoder = H.TriPlaneDecoder(32, self.rendering_kwargs.get('decoder_lr_mul', 1), 32)
+        self.neural_rendering_resolution = 64
+        self._last_planes = None
+
+    def mapping(self, z, c):
+        if self.rendering_kwargs.get('c_gen_conditioning_zero', False):
+            c = torch.zeros_like(c)
+        return self.backbone.mapping(z, c * self.rendering_kwargs.get('c_scale', 0))
+
+    def synthesis(self, ws, c, neural_rendering_resolution=None, cache_backbone=False, use_cached_backbone=False, noise_mode='const', **_ignored):
+        res = self.neural_rendering_resolution = neural_rendering_resolution or self.neural_rendering_resolution
+        o, d = self.ray_sampler(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), res)
+        if use_cached_backbone and self._last_planes is not None:
+            planes = self._last_planes
+        else:
+            planes = self.backbone.synthesis(ws, noise_mode=noise_mode)
+        if cache_backbone:
+            self._last_planes = planes
+        n = planes.shape[0]
+        feat, depth, _ = self.renderer(planes.view(n, 3, 32, *planes.shape[-2:]), self.decoder, o, d, self.rendering_kwargs)
+        feature_image = feat.permute(0, 2, 1).reshape(n, 32, res, res).contiguous()
+        depth_image = depth.permute(0, 2, 1).reshape(n, 1, res, res)
+        sr_image, raw = self.superresolution(feature_image[:, :3], feature_image, ws, noise_mode=self.rendering_kwargs.get('superresolution_noise_mode', 'none'))
+        return {'image': sr_image, 'image_raw': raw, 'image_depth': depth_image}
+
+    def forward(self, z, c, **kw):
+        return self.synthesis(self.mapping(z, c), c, **kw)

@@ -1,0 +1,58 @@
+"""gnerf_generator.Generator (the inference-only stand-in for the hot path's callers, used where the reference tree is
+absent) against the reference's own TriPlaneGenerator: same parameter / buffer names (strict state_dict load) and the same
+images for the same weights, latent, camera and seed.  Needs the reference tree: build container only, CPU, fp32."""
+
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference/g_nerf'
+
+SCRIPT = r'''
+import sys, types, numpy as np, torch
+sys.dont_write_bytecode = True
+for p in reversed(%(paths)r): sys.path.insert(0, p)
+tvr = types.ModuleType("torchvision.models.resnet"); tvr.ResNet = type("ResNet", (torch.nn.Module,), {}); tvr.Bottleneck = type("B", (torch.nn.Module,), {})
+sys.modules.update({"torchvision": types.ModuleType("torchvision"), "torchvision.models": types.ModuleType("torchvision.models"), "torchvision.models.resnet": tvr})
+import gen_videos_mi355x as gv, gnerf_generator, gnerf_harness as H
+import training.triplane
+assert "/root/reference" in training.triplane.__file__
+torch.set_num_threads(8)
+G_ref = gv.build_random_generator(0, torch.device("cpu"))
+assert type(G_ref).__name__ == "TriPlaneGenerator" and not isinstance(G_ref, gnerf_generator.Generator)
+# make the comparison bite: non-zero noise strengths and biases (both are zero at initialisation)
+g = torch.Generator().manual_seed(5)
+with torch.no_grad():
+    for n, p_ in G_ref.named_parameters():
+        if n.endswith("noise_strength") or n.endswith(".bias"):
+            p_.add_(torch.randn(p_.shape, generator=g) * 0.1)
+G = gnerf_generator.Generator(rendering_kwargs=G_ref.rendering_kwargs).eval().requires_grad_(False)
+missing = G.load_state_dict(G_ref.state_dict(), strict=True)
+z = torch.randn(2, 512, generator=g)
+c = torch.cat([H.camera_label(H.orbit_pose(i, 120)) for i in (3, 40)])
+with torch.no_grad():
+    ws_ref, ws = G_ref.mapping(z, c), G.mapping(z, c)
+    torch.manual_seed(11); a = G_ref.synthesis(ws_ref, c, noise_mode="const", neural_rendering_resolution=64)
+    torch.manual_seed(11); b = G.synthesis(ws, c, noise_mode="const", neural_rendering_resolution=64)
+    planes_ref = G_ref.backbone.synthesis(ws_ref, noise_mode="const"); planes = G.backbone.synthesis(ws, noise_mode="const")
+np.savez(%(out)r, ws=(ws_ref - ws).abs().max().numpy(), ws_shape=np.array(ws.shape), planes=(planes_ref - planes).abs().max().numpy(), planes_scale=planes_ref.abs().max().numpy(),
+         **{k + "_err": (a[k] - b[k]).abs().max().numpy() for k in a}, **{k + "_scale": a[k].abs().max().numpy() for k in a}, image_shape=np.array(b["image"].shape))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree only exists in the build container')
+def test_generator_matches_reference(tmp_path):
+    out = str(tmp_path / 'cmp.npz')
+    code = SCRIPT % dict(paths=[os.path.join(ROOT, 'g-nerf_amd'), REF], out=out)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'), cwd='/tmp', timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = np.load(out)
+    assert tuple(d['ws_shape']) == (2, 14, 512) and tuple(d['image_shape']) == (2, 3, 512, 512)
+    assert float(d['ws']) < 1e-5
+    assert float(d['planes']) < 1e-4 * max(1.0, float(d['planes_scale']))
+    for k in ('image', 'image_raw', 'image_depth'):
+        assert float(d[k + '_err']) < 2e-4 * max(1.0, float(d[k + '_scale'])), (k, float(d[k + '_err']), float(d[k + '_scale']))

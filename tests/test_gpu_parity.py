@@ -818,3 +818,39 @@ def test_filtered_lrelu_fused_declines_what_it_does_not_cover(dev):
         y = filtered_lrelu.filtered_lrelu(x, fu=f2d, up=2, padding=[2, 1, 2, 1])
     ref = O.filtered_lrelu(x.cpu().numpy(), f2d.cpu().numpy(), None, None, up=2, padding=[2, 1, 2, 1])
     np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+
+
+# ---- the whole generator around the hot path (callers in PyTorch/MIOpen, renderer + ops native) ----------------------
+
+def test_generator_forward_gpu_vs_cpu(dev):
+    """BASELINE config 3 at batch 1: gnerf_generator.Generator on the GPU (fused renderer, native bias_act / upfirdn2d, fp16
+    superresolution) against the same module on the CPU (PyTorch-op renderer and ops, fp32) with the same weights, latent,
+    camera and the same two uniform draws.  Tolerance = north_star's: pixel MSE < 1e-4 on images in [-1, 1]."""
+    import copy
+    import gnerf_generator
+    import gnerf_harness as H
+    from test_host_cpu import _Replay
+    torch.manual_seed(3)
+    G = gnerf_generator.Generator().eval().requires_grad_(False)
+    gen = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for n, p in G.named_parameters():
+            if n.endswith('noise_strength') or n.endswith('.bias'):
+                p.add_(torch.randn(p.shape, generator=gen) * 0.1)
+    z = torch.randn(1, 512, generator=gen)
+    c = H.camera_label(H.orbit_pose(17, 120))
+    res, S = 64, 48
+    draws = [torch.rand(1, res * res, S, 1, generator=gen), torch.rand(res * res, S, generator=gen)]
+    with torch.no_grad():
+        ws = G.mapping(z, c)
+        with _Replay([d.clone() for d in draws]):
+            ref = G.synthesis(ws, c, neural_rendering_resolution=res)
+        Gd = copy.deepcopy(G).to(dev)
+        with _Replay([d.to(dev) for d in draws]):
+            out = Gd.synthesis(Gd.mapping(z.to(dev), c.to(dev)), c.to(dev), neural_rendering_resolution=res)
+    assert out['image'].shape == (1, 3, 512, 512) and out['image'].dtype == torch.float32
+    scale = float(ref['image'].abs().max())
+    for k in ('image', 'image_raw'):
+        mse = float((((out[k].cpu() - ref[k]) / max(1.0, scale)) ** 2).mean())      # random-init images exceed [-1,1]: normalise
+        assert mse < 1e-4, (k, mse, scale)
+    assert float((out['image_depth'].cpu() - ref['image_depth']).abs().max()) < 2e-3
