@@ -79,8 +79,11 @@ def identity_latent(args, device, z_dim):
 
 
 @torch.no_grad()
-def render_orbit(G, z, n_frames, res, device, rank=0, world=1, double_depth=True, frame_seed=None):
-    """This rank's frames of the orbit: (uint8 [n_local,512,512,3], uint8 raw [n_local,res,res,3], (lo, hi))."""
+def render_orbit(G, z, n_frames, res, device, rank=0, world=1, double_depth=True, frame_seed=None, use_graph=False):
+    """This rank's frames of the orbit: (uint8 [n_local,512,512,3], uint8 raw [n_local,res,res,3], (lo, hi)).
+    use_graph (GPU only): the per-frame sequence -- rays, the two uniform draws, the fused render, superresolution, uint8
+    conversion, ~190 launches -- is captured once into a HIP graph and replayed per camera; no entry point of the native
+    library allocates or synchronises, and torch's graph-safe generator advances the draws from replay to replay."""
     if double_depth:                                                                        # gen_videos.py:127-128
         G.rendering_kwargs['depth_resolution'] = int(G.rendering_kwargs['depth_resolution'] * 2)
         G.rendering_kwargs['depth_resolution_importance'] = int(G.rendering_kwargs['depth_resolution_importance'] * 2)
@@ -88,17 +91,40 @@ def render_orbit(G, z, n_frames, res, device, rank=0, world=1, double_depth=True
     c0 = H.camera_label(H.lookat_pose(3.14 / 2, 3.14 / 2, radius, device))                # gen_videos.py:147-149
     ws = G.mapping(z=z, c=torch.zeros_like(c0).repeat(z.shape[0], 1))                       # gen_videos.py:150
     lo, hi = H.shard_range(n_frames, rank, world)
-    frames, raws = [], []
-    for k, i in enumerate(range(lo, hi)):
-        c = H.camera_label(H.orbit_pose(i, n_frames, radius, device=device)).repeat(z.shape[0], 1)
-        if frame_seed is not None:
-            torch.manual_seed(frame_seed + i)                                               # reproducible renderer draws per frame
-        out = G.synthesis(ws=ws, c=c, noise_mode='const', neural_rendering_resolution=res,
-                          cache_backbone=(k == 0), use_cached_backbone=(k > 0))
-        frames.append(H.to_uint8(out['image']))
-        raws.append(H.to_uint8(out['image_raw']))
-    if not frames:
+    if hi == lo:
         return None, None, (lo, hi)
+    cams = [H.camera_label(H.orbit_pose(i, n_frames, radius, device=device)).repeat(z.shape[0], 1) for i in range(lo, hi)]
+
+    def one_frame(c, cache=False, cached=True):
+        out = G.synthesis(ws=ws, c=c, noise_mode='const', neural_rendering_resolution=res, cache_backbone=cache, use_cached_backbone=cached)
+        return H.to_uint8(out['image']), H.to_uint8(out['image_raw'])
+
+    frames, raws = [], []
+    if use_graph and device.type == 'cuda':
+        assert frame_seed is None, 'per-frame reseeding and graph replay do not mix'
+        c_static = cams[0].clone()
+        one_frame(c_static, cache=True, cached=False)                                       # backbone once: ws is constant over the orbit
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                one_frame(c_static)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            f_static, r_static = one_frame(c_static)
+        for c in cams:
+            c_static.copy_(c)
+            graph.replay()
+            frames.append(f_static.clone())
+            raws.append(r_static.clone())
+    else:
+        for k, (i, c) in enumerate(zip(range(lo, hi), cams)):
+            if frame_seed is not None:
+                torch.manual_seed(frame_seed + i)                                           # reproducible renderer draws per frame
+            f, r = one_frame(c, cache=(k == 0), cached=(k > 0))
+            frames.append(f)
+            raws.append(r)
     return torch.cat(frames), torch.cat(raws), (lo, hi)
 
 
@@ -113,11 +139,15 @@ def main():
     ap.add_argument('--res', type=int, default=64)                      # neural rendering resolution, gen_videos.py:81
     ap.add_argument('--no-double-depth', action='store_true', help='keep the checkpoint depth resolutions (the reference CLI doubles them)')
     ap.add_argument('--device', default='cuda' if torch.cuda.is_available() else 'cpu')
+    ap.add_argument('--graph', action='store_true', help='replay the per-frame launch sequence from a captured HIP graph')
     ap.add_argument('--out', default=None, help='write frames to this .npy (rank 0)')
     args = ap.parse_args()
 
     rank, world, local_rank = H.init_from_env()
-    device = torch.device('cuda', local_rank) if args.device == 'cuda' else torch.device(args.device)
+    # (modulo: a rehearsal of several ranks on a one-GPU box with GNERF_DIST_BACKEND=gloo shares the card)
+    device = torch.device('cuda', local_rank % max(1, torch.cuda.device_count())) if args.device == 'cuda' else torch.device(args.device)
+    if device.type == 'cuda':
+        torch.cuda.set_device(device)
     if args.random_init:
         G = build_random_generator(args.seed, device)
     else:
@@ -125,16 +155,22 @@ def main():
         G = load_generator(args.network, device)
     z = identity_latent(args, device, G.z_dim)
 
+    # One untimed frame first: library load, MIOpen's per-shape kernel search (tens of seconds on a fresh machine) and the
+    # allocator's first touches are one-off costs of the process, not of the orbit.
+    render_orbit(G, z, args.frames, args.res, device, rank=0, world=args.frames, double_depth=False)
     if device.type == 'cuda':
         torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     t0 = time.perf_counter()
-    frames, raws, (lo, hi) = render_orbit(G, z, args.frames, args.res, device, rank, world, double_depth=not args.no_double_depth)
+    frames, raws, (lo, hi) = render_orbit(G, z, args.frames, args.res, device, rank, world, double_depth=not args.no_double_depth, use_graph=args.graph)
     full = H.gather_frames(frames, args.frames)
     if device.type == 'cuda':
         torch.cuda.synchronize()
     elapsed = H.max_over_ranks(time.perf_counter() - t0, device)
     if rank == 0:
-        print(f'{args.frames} frames on {world} rank(s): {elapsed:.3f} s = {args.frames / elapsed:.2f} frames/s '
+        print(f'{args.frames} frames on {world} rank(s){" (HIP graph replay)" if args.graph else ""}: {elapsed:.3f} s = {args.frames / elapsed:.2f} frames/s '
               f'(neural rendering {args.res}x{args.res}, {G.rendering_kwargs["depth_resolution"]}+{G.rendering_kwargs["depth_resolution_importance"]} samples)')
         if args.out:
             np.save(args.out, full.cpu().numpy())
