@@ -78,53 +78,73 @@ def identity_latent(args, device, z_dim):
     return torch.randn(1, z_dim, generator=torch.Generator().manual_seed(args.seed + 1)).to(device)
 
 
-@torch.no_grad()
-def render_orbit(G, z, n_frames, res, device, rank=0, world=1, double_depth=True, frame_seed=None, use_graph=False):
-    """This rank's frames of the orbit: (uint8 [n_local,512,512,3], uint8 raw [n_local,res,res,3], (lo, hi)).
-    use_graph (GPU only): the per-frame sequence -- rays, the two uniform draws, the fused render, superresolution, uint8
-    conversion, ~190 launches -- is captured once into a HIP graph and replayed per camera; no entry point of the native
-    library allocates or synchronises, and torch's graph-safe generator advances the draws from replay to replay."""
-    if double_depth:                                                                        # gen_videos.py:127-128
-        G.rendering_kwargs['depth_resolution'] = int(G.rendering_kwargs['depth_resolution'] * 2)
-        G.rendering_kwargs['depth_resolution_importance'] = int(G.rendering_kwargs['depth_resolution_importance'] * 2)
-    radius = G.rendering_kwargs['avg_camera_radius']
-    c0 = H.camera_label(H.lookat_pose(3.14 / 2, 3.14 / 2, radius, device))                # gen_videos.py:147-149
-    ws = G.mapping(z=z, c=torch.zeros_like(c0).repeat(z.shape[0], 1))                       # gen_videos.py:150
-    lo, hi = H.shard_range(n_frames, rank, world)
-    if hi == lo:
-        return None, None, (lo, hi)
-    cams = [H.camera_label(H.orbit_pose(i, n_frames, radius, device=device)).repeat(z.shape[0], 1) for i in range(lo, hi)]
+def orbit_latents(G, z, device):
+    """ws of the whole orbit: the mapping network runs once, on a zero camera label (gen_videos.py:147-150)."""
+    c0 = H.camera_label(H.lookat_pose(3.14 / 2, 3.14 / 2, G.rendering_kwargs['avg_camera_radius'], device))
+    return G.mapping(z=z, c=torch.zeros_like(c0).repeat(z.shape[0], 1))
 
-    def one_frame(c, cache=False, cached=True):
-        out = G.synthesis(ws=ws, c=c, noise_mode='const', neural_rendering_resolution=res, cache_backbone=cache, use_cached_backbone=cached)
-        return H.to_uint8(out['image']), H.to_uint8(out['image_raw'])
 
-    frames, raws = [], []
-    if use_graph and device.type == 'cuda':
-        assert frame_seed is None, 'per-frame reseeding and graph replay do not mix'
-        c_static = cams[0].clone()
-        one_frame(c_static, cache=True, cached=False)                                       # backbone once: ws is constant over the orbit
+class FrameProgram:
+    """One orbit frame -- rays, the two uniform draws, the fused render, superresolution, uint8 conversion, ~190 launches --
+    captured ONCE into a HIP graph and replayed per camera.  No entry point of the native library allocates or synchronises,
+    and torch's graph-safe generator advances the draws from replay to replay.  The backbone runs once, before the capture
+    (ws is constant over the orbit).  Reusable across orbits of the same generator, latent and resolution."""
+
+    @torch.no_grad()
+    def __init__(self, G, ws, res, device, batch=1):
+        self.G, self.ws, self.res = G, ws, res
+        self.c = H.camera_label(H.orbit_pose(0, 120, G.rendering_kwargs['avg_camera_radius'], device=device)).repeat(batch, 1)
+        self._frame(cache=True, cached=False)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
-                one_frame(c_static)
+                self._frame()
         torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            f_static, r_static = one_frame(c_static)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.frame, self.raw = self._frame()
+
+    def _frame(self, cache=False, cached=True):
+        out = self.G.synthesis(ws=self.ws, c=self.c, noise_mode='const', neural_rendering_resolution=self.res,
+                               cache_backbone=cache, use_cached_backbone=cached)
+        return H.to_uint8(out['image']), H.to_uint8(out['image_raw'])
+
+    def __call__(self, c):
+        self.c.copy_(c)
+        self.graph.replay()
+        return self.frame.clone(), self.raw.clone()
+
+
+@torch.no_grad()
+def render_orbit(G, z, n_frames, res, device, rank=0, world=1, double_depth=True, frame_seed=None, use_graph=False, program=None):
+    """This rank's frames of the orbit: (uint8 [n_local,512,512,3], uint8 raw [n_local,res,res,3], (lo, hi)).
+    use_graph (GPU only): frames come from a FrameProgram (`program`, or one captured here)."""
+    if double_depth:                                                                        # gen_videos.py:127-128
+        G.rendering_kwargs['depth_resolution'] = int(G.rendering_kwargs['depth_resolution'] * 2)
+        G.rendering_kwargs['depth_resolution_importance'] = int(G.rendering_kwargs['depth_resolution_importance'] * 2)
+    radius = G.rendering_kwargs['avg_camera_radius']
+    lo, hi = H.shard_range(n_frames, rank, world)
+    if hi == lo:
+        return None, None, (lo, hi)
+    cams = [H.camera_label(H.orbit_pose(i, n_frames, radius, device=device)).repeat(z.shape[0], 1) for i in range(lo, hi)]
+    frames, raws = [], []
+    if (use_graph or program is not None) and device.type == 'cuda':
+        assert frame_seed is None, 'per-frame reseeding and graph replay do not mix'
+        if program is None:
+            program = FrameProgram(G, orbit_latents(G, z, device), res, device, batch=z.shape[0])
         for c in cams:
-            c_static.copy_(c)
-            graph.replay()
-            frames.append(f_static.clone())
-            raws.append(r_static.clone())
+            f, r = program(c)
+            frames.append(f)
+            raws.append(r)
     else:
+        ws = orbit_latents(G, z, device)
         for k, (i, c) in enumerate(zip(range(lo, hi), cams)):
             if frame_seed is not None:
                 torch.manual_seed(frame_seed + i)                                           # reproducible renderer draws per frame
-            f, r = one_frame(c, cache=(k == 0), cached=(k > 0))
-            frames.append(f)
-            raws.append(r)
+            out = G.synthesis(ws=ws, c=c, noise_mode='const', neural_rendering_resolution=res, cache_backbone=(k == 0), use_cached_backbone=(k > 0))
+            frames.append(H.to_uint8(out['image']))
+            raws.append(H.to_uint8(out['image_raw']))
     return torch.cat(frames), torch.cat(raws), (lo, hi)
 
 
