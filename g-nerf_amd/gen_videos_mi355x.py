@@ -148,6 +148,50 @@ def render_orbit(G, z, n_frames, res, device, rank=0, world=1, double_depth=True
     return torch.cat(frames), torch.cat(raws), (lo, hi)
 
 
+def voxel_samples(lo, hi, n, cube_length, device):
+    """Points lo..hi-1 of gen_videos.py's create_samples(N=n, voxel_origin=[0,0,0], cube_length) (gen_videos.py:33-56), made on
+    the device chunk by chunk instead of as one [n^3, 3] host tensor (1.6 GB at n = 512).  The arithmetic is the reference's,
+    quirks included: the y and x indices come from FLOAT divisions of the linear index without a floor (a sheared lattice), in
+    fp32 (indices above 2^24 are rounded)."""
+    idx = torch.arange(lo, hi, dtype=torch.int64, device=device)
+    origin, size = -cube_length / 2, cube_length / (n - 1)
+    f = idx.float()
+    s2 = (idx % n).float()
+    s1 = (f / n) % n
+    s0 = ((f / n) / n) % n
+    return torch.stack([s0 * size + origin, s1 * size + origin, s2 * size + origin], dim=-1).unsqueeze(0)
+
+
+@torch.no_grad()
+def extract_density_grid(G, ws, resolution=512, max_batch=10000000, crop=True):
+    """The density volume gen_videos.py --shapes writes to .mrc (gen_videos.py:189-224): sigma at resolution^3 lattice points of
+    the box, flipped along the first axis, borders zeroed.  The reference calls G.sample_mixed per chunk of 10^7 points, which
+    re-runs the StyleGAN2 backbone for every chunk (14 passes at 512^3); here the planes are made once and every chunk goes
+    through ImportanceRenderer.run_model (the fused point-query kernel on a GPU).  Returns a float32 tensor [r, r, r] on ws' device."""
+    device = ws.device
+    planes = G.backbone.synthesis(ws, noise_mode='const')
+    planes = planes.view(len(planes), 3, 32, planes.shape[-2], planes.shape[-1])
+    total = resolution ** 3
+    sigmas = torch.empty(total, dtype=torch.float32, device=device)
+    for head in range(0, total, max_batch):
+        hi = min(total, head + max_batch)
+        pts = voxel_samples(head, hi, resolution, G.rendering_kwargs['box_warp'], device)
+        dirs = torch.zeros_like(pts)
+        dirs[..., -1] = -1
+        sigmas[head:hi] = G.renderer.run_model(planes, G.decoder, pts, dirs, G.rendering_kwargs)['sigma'].reshape(-1)
+    vol = sigmas.reshape(resolution, resolution, resolution).flip(0)
+    if crop:                                                                                # gen_videos.py:213-220
+        pad, pad_top = int(30 * resolution / 256), int(38 * resolution / 256)
+        vol = vol.clone()
+        vol[:pad] = 0
+        vol[-pad:] = 0
+        vol[:, :pad] = 0
+        vol[:, -pad_top:] = 0
+        vol[:, :, :pad] = 0
+        vol[:, :, -pad:] = 0
+    return vol
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument('--network', help='generator pickle (G_ema)')
@@ -161,6 +205,8 @@ def main():
     ap.add_argument('--device', default='cuda' if torch.cuda.is_available() else 'cpu')
     ap.add_argument('--graph', action='store_true', help='replay the per-frame launch sequence from a captured HIP graph')
     ap.add_argument('--out', default=None, help='write frames to this .npy (rank 0)')
+    ap.add_argument('--shapes', default=None, help='also extract the 512^3 density volume (gen_videos.py --shapes) and save it to this .npy (rank 0)')
+    ap.add_argument('--voxel-res', type=int, default=512)
     args = ap.parse_args()
 
     rank, world, local_rank = H.init_from_env()
@@ -194,6 +240,16 @@ def main():
               f'(neural rendering {args.res}x{args.res}, {G.rendering_kwargs["depth_resolution"]}+{G.rendering_kwargs["depth_resolution_importance"]} samples)')
         if args.out:
             np.save(args.out, full.cpu().numpy())
+        if args.shapes:
+            if device.type == 'cuda':
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            vol = extract_density_grid(G, orbit_latents(G, z, device), args.voxel_res)
+            if device.type == 'cuda':
+                torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(f'density volume {args.voxel_res}^3: {dt:.3f} s = {args.voxel_res ** 3 / dt / 1e9:.2f} G points/s')
+            np.save(args.shapes, vol.cpu().numpy())
 
 
 if __name__ == '__main__':

@@ -262,5 +262,13 @@ class Generator(nn.Module):
         sr_image, raw = self.superresolution(feature_image[:, :3], feature_image, ws, noise_mode=self.rendering_kwargs.get('superresolution_noise_mode', 'none'))
         return {'image': sr_image, 'image_raw': raw, 'image_depth': depth_image}
 
+    def sample_mixed(self, coordinates, directions, ws, noise_mode='const', **_ignored):
+        """Density / colour at arbitrary points for given latents (triplane.py:98-102; shape extraction, density regulariser)."""
+        planes = self.backbone.synthesis(ws, noise_mode=noise_mode)
+        return self.renderer.run_model(planes.view(len(planes), 3, 32, *planes.shape[-2:]), self.decoder, coordinates, directions, self.rendering_kwargs)
+
+    def sample(self, coordinates, directions, z, c, **kw):
+        return self.sample_mixed(coordinates, directions, self.mapping(z, c), **kw)
+
     def forward(self, z, c, **kw):
         return self.synthesis(self.mapping(z, c), c, **kw)

@@ -855,3 +855,22 @@ def test_generator_forward_gpu_vs_cpu(dev):
         mse = float((((out[k].cpu() - ref[k]) / max(1.0, scale)) ** 2).mean())      # random-init images exceed [-1,1]: normalise
         assert mse < 1e-4, (k, mse, scale)
     assert float((out['image_depth'].cpu() - ref['image_depth']).abs().max()) < 2e-3
+
+
+def test_density_volume_gpu_vs_cpu(dev):
+    """gen_videos.py --shapes counterpart: the density lattice through the fused point-query kernel (chunked, ragged last chunk)
+    against the same module's PyTorch-op path on the CPU."""
+    import copy
+    import gnerf_generator
+    import gen_videos_mi355x as gv
+    torch.manual_seed(5)
+    G = gnerf_generator.Generator().eval().requires_grad_(False)
+    with torch.no_grad():
+        ws = G.mapping(torch.randn(1, 512), torch.zeros(1, 25))
+        ref = gv.extract_density_grid(G, ws, resolution=40, max_batch=64000, crop=True)
+        Gd = copy.deepcopy(G).to(dev)
+        vol = gv.extract_density_grid(Gd, ws.to(dev), resolution=40, max_batch=7001, crop=True)
+    assert vol.shape == (40, 40, 40) and vol.is_cuda
+    scale = float(ref.abs().max())
+    assert scale > 0.1
+    assert float((vol.cpu() - ref).abs().max()) < 2e-4 * max(1.0, scale)
