@@ -225,6 +225,7 @@ __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD :
                     for (int c2 = 0; c2 < 4; c2++) cnt += (c4[c2] <= u) ? 1 : 0;
                 }
                 const int below = max(cnt - 1, 0), above = min(cnt, n_w);
+                sl.rank_e[fine_e0 + i] = below;                            // the sample's bin, for the merge (finalize)
                 const float cb = sl.cdf[below], ca = sl.cdf[above];
                 const float bb = (sl.t_e[below] + sl.t_e[below + 1]) * 0.5f;
                 const float ba = (sl.t_e[above] + sl.t_e[above + 1]) * 0.5f;
@@ -239,6 +240,9 @@ __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD :
             for (int k = lane; k < S; k += 64) dbg[GNERF_DBG_SIGMA_COARSE * n_all + k] = sl.sig_e[k];
             for (int k = lane; k < S - 1; k += 64) dbg[GNERF_DBG_WEIGHT_COARSE * n_all + k] = sl.w_s[k];
         }
+        // the cdf is dead from here until this slot's next ray: it becomes the merge's per-bin histogram (finalize), zeroed now
+        // (LDS operations of one wave execute in issue order, so these stores follow the reads above without a fence)
+        for (int e = lane; e < kPipeMaxS; e += 64) reinterpret_cast<int*>(sl.cdf)[e] = 0;
     };
     auto finalize = [&](int r) {                // D(r): merge by depth (renderer.py:157-167) + final march + per-sample colour weights
         if (r < 0 || r >= nr) return;
@@ -248,9 +252,17 @@ __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD :
         float* dbg = GNERF_DBG_PTR(p.debug ? p.debug + int64_t(ray_id) * GNERF_DEBUG_SLOTS * n_all : nullptr);
         // Stable rank in cat([coarse, fine]).  Coarse depths ascend by construction, so
         //   rank(coarse k) = k + #{fine < t_k}            rank(fine i) = #{coarse <= t_i} + #{fine before i}
-        // (ties: coarse first, then lower index -- what a stable sort of the concatenation gives).  All three counts are
-        // compare + add-with-carry scans over keys read four at a time as LDS broadcasts.  "#fine before i" is first taken
-        // as #{fine < t_i}; two fine samples with bit-identical depth then collide on a rank, which is detected through
+        // (ties: coarse first, then lower index -- what a stable sort of the concatenation gives).
+        // The two coarse-vs-fine counts need no scan.  A fine sample drawn from bin b of the inverse cdf lies between the
+        // midpoints mid[b] and mid[b+1] of the coarse depths (renderer.py:243-252; `below` of sample_pdf, kept by importance()),
+        // i.e. between coarse samples b and b+2 up to an ulp of rounding: coarse samples < b are before it and coarse samples
+        // > b+2 after it for certain (three consecutive coarse depths cannot be within rounding of each other: neighbours need
+        // a jitter of ~1 followed by a jitter of 0), and only b, b+1, b+2 are compared.  The coarse side is the mirror image:
+        // fine samples of bins <= k-3 are before coarse sample k, bins >= k+1 after it, and for the bins k-2, k-1, k the
+        // answer is the complement of the fine side's three comparisons, gathered per bin in a packed LDS histogram
+        // (count | #before coarse b | #before b+1 | #before b+2, 8 bits each) and prefix-summed over the bins.
+        // "#fine before i" is a compare + add-with-carry scan over the fine keys read four at a time as LDS broadcasts, first
+        // taken as #{fine < t_i}; two fine samples with bit-identical depth then collide on a rank, which is detected through
         // an owner table and repaired by a tie-broken recount (rare: needs two equal uniform draws or rounding collisions).
         int rank_f[RND], rank_c[RND];
         float key_f[RND], key_c[RND];
@@ -267,37 +279,46 @@ __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD :
 #pragma unroll
                     for (int c2 = 0; c2 < 4; c2++) rk += (k4[c2] < key) ? 1 : 0;
                 }
-#pragma unroll 4
-                for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
-                    const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + o2);
-#pragma unroll
-                    for (int c2 = 0; c2 < 4; c2++) rk += (k4[c2] <= key) ? 1 : 0;
+                {
+                    const int b = sl.rank_e[fine_e0 + i];
+                    const int c0 = sl.t_e[b] <= key ? 1 : 0, c1 = sl.t_e[b + 1] <= key ? 1 : 0, c2 = sl.t_e[b + 2] <= key ? 1 : 0;
+                    rk += b + c0 + c1 + c2;
+                    atomicAdd(reinterpret_cast<int*>(sl.cdf) + b, 1 | ((1 - c0) << 8) | ((1 - c1) << 16) | ((1 - c2) << 24));
                 }
                 sl.rank_e[fine_e0 + i] = rk;
                 reinterpret_cast<int*>(sl.w_s)[rk] = i;             // owner table (w_s is free until the final march)
                 rank_f[q] = rk; key_f[q] = key;
             }
         }
+        lds_wave_sync();                        // the histogram is complete
+        {
+            const int* hist = reinterpret_cast<const int*>(sl.cdf);
+            float carry = 0.f;
 #pragma unroll
-        for (int q = 0; q < RND; q++) {
-            const int k = lane + 64 * q;
-            rank_c[q] = k; key_c[q] = 0.f;
-            if (TP == 1 && k < S) {             // TP == 2: the shader waves did this a step earlier (coarse_ranks)
-                const float key = sl.t_e[k];
-                int rk = k;
-                // "ascend by construction" holds up to rounding: t_k = lin_k + u delta can round one ulp past t_{k+1} when
-                // u is within 1e-5 of 1.  Only neighbours can swap (the grid step is ~1e5 ulps), so the number of coarse
-                // samples sorted before k is k +- 1 from two compares.
-                if (k + 1 < S && sl.t_e[k + 1] < key) rk += 1;
-                if (k > 0 && sl.t_e[k - 1] > key) rk -= 1;
-#pragma unroll 4
-                for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
-                    const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + fine_e0 + o2);
+            for (int q = 0; q < RND; q++) {     // #fine in bins <= k, parked in v_e[k] (free until the end of this function, and rewritten there)
+                const int k = lane + 64 * q;
+                const float incl = wave_scan_add(float(hist[min(k, kPipeMaxS - 1)] & 255), lane) + carry;
+                carry = wave_last(incl);
+                if (k < S) sl.v_e[k] = incl;
+            }
+            lds_wave_sync();
 #pragma unroll
-                    for (int c2 = 0; c2 < 4; c2++) rk += (k4[c2] < key) ? 1 : 0;
+            for (int q = 0; q < RND; q++) {
+                const int k = lane + 64 * q;
+                rank_c[q] = k; key_c[q] = 0.f;
+                if (k < S) {
+                    const float key = sl.t_e[k];
+                    int rk = k;
+                    // "ascend by construction" holds up to rounding: t_k = lin_k + u delta can round one ulp past t_{k+1} when
+                    // u is within 1e-5 of 1.  Only neighbours can swap (the grid step is ~1e5 ulps), so the number of coarse
+                    // samples sorted before k is k +- 1 from two compares.
+                    if (k + 1 < S && sl.t_e[k + 1] < key) rk += 1;
+                    if (k > 0 && sl.t_e[k - 1] > key) rk -= 1;
+                    const int h0 = hist[k], h1 = hist[max(k - 1, 0)], h2 = hist[max(k - 2, 0)];       // bins >= S-2 do not exist: zero
+                    rk += (k >= 3 ? int(sl.v_e[k - 3]) : 0) + ((h0 >> 8) & 255) + (k >= 1 ? (h1 >> 16) & 255 : 0) + (k >= 2 ? (h2 >> 24) & 255 : 0);
+                    sl.rank_e[k] = rk;
+                    rank_c[q] = rk; key_c[q] = key;
                 }
-                sl.rank_e[k] = rk;
-                rank_c[q] = rk; key_c[q] = key;
             }
         }
         lds_wave_sync();
@@ -320,7 +341,7 @@ __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD :
         for (int q = 0; q < RND; q++) {
             const int i = lane + 64 * q;
             if (i < F) { sl.s_t[rank_f[q]] = key_f[q]; sl.s_sig[rank_f[q]] = sl.sig_e[fine_e0 + i]; }
-            if (TP == 1 && i < S) { sl.s_t[rank_c[q]] = key_c[q]; sl.s_sig[rank_c[q]] = sl.sig_e[i]; }
+            if (i < S) { sl.s_t[rank_c[q]] = key_c[q]; sl.s_sig[rank_c[q]] = sl.sig_e[i]; }
         }
         lds_wave_sync();
         GNERF_STAMP(st, 13);    // merge ranks
@@ -385,32 +406,6 @@ __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD :
             else       coop_shade_tile<false>(P, L, R, sl.t_e + fine_e0, F, tile, tile < P.tiles_f, sl.sig_e + fine_e0, lane, wv, col[i], st);
         }
     };
-    // TP == 2 only.  With 96+96 samples the merge is half of the scalar wave's time and the shader waves wait for it in the
-    // even half-step (stamps: 27 % of their cycles).  The coarse samples' ranks depend on depths only -- known as soon as
-    // the ray's fine depths are -- so the shader waves compute them, and place the coarse depths / densities in sorted
-    // order, at the end of the half-step BEFORE the scalar wave finalises that ray: a third of the merge moves into what
-    // was idle time.  Wave wv takes coarse samples [32 (2 - wv), 32 (2 - wv) + 32).
-    auto coarse_ranks = [&](int r) {
-        if (r < 0 || r >= nr) return;
-        PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
-        if (__float_as_int(sl.misc[7]) < 0) return;
-        const int k = 32 * (2 - wv) + lane;         // wave 2 first: with 4 or 5 tiles per pass it is wave 0 that shades two
-        if (lane < 32 && k < S) {
-            const float key = sl.t_e[k];
-            int rk = k;
-            if (k + 1 < S && sl.t_e[k + 1] < key) rk += 1;          // neighbours swapped by rounding, see finalize
-            if (k > 0 && sl.t_e[k - 1] > key) rk -= 1;
-#pragma unroll 4
-            for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {
-                const v4f k4 = *reinterpret_cast<const v4f*>(sl.t_e + fine_e0 + o2);
-#pragma unroll
-                for (int c2 = 0; c2 < 4; c2++) rk += (k4[c2] < key) ? 1 : 0;
-            }
-            sl.rank_e[k] = rk;
-            sl.s_t[rk] = key;
-            sl.s_sig[rk] = sl.sig_e[k];
-        }
-    };
     auto accumulate = [&](int r, const v4f (&cc)[TP][2], const v4f (&cf)[TP][2]) {
         if (r < 0 || r >= nr) return;
         PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
@@ -450,7 +445,6 @@ __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD :
         // ---- step 2k+2
         if (wv < 3) {
             shade(k + 1, false, cc2);
-            if (TP == 2) coarse_ranks(k);       // ray k's fine depths exist since step 2k+1; the scalar wave finalises it in step 2k+4
         } else {
             finalize(k - 1);
             GNERF_STAMP(st, 8);     // merge + final march
