@@ -874,3 +874,26 @@ def test_density_volume_gpu_vs_cpu(dev):
     scale = float(ref.abs().max())
     assert scale > 0.1
     assert float((vol.cpu() - ref).abs().max()) < 2e-4 * max(1.0, scale)
+
+
+def test_frame_program_replay_equals_eager(dev):
+    """gen_videos harness: an orbit frame replayed from the captured HIP graph (FrameProgram) is the frame plain launches give
+    for the same camera and the same generator state, bit for bit (uint8 images and the raw 64x64 image), replay after replay."""
+    import gnerf_generator
+    import gnerf_harness as H
+    import gen_videos_mi355x as gv
+    torch.manual_seed(2)
+    with torch.no_grad():
+        G = gnerf_generator.Generator().eval().requires_grad_(False).to(dev)
+        G.rendering_kwargs['depth_resolution'] = G.rendering_kwargs['depth_resolution_importance'] = 96      # the CLI's doubled sampling
+        z = torch.randn(1, 512, device=dev)
+        ws = gv.orbit_latents(G, z, dev)
+        prog = gv.FrameProgram(G, ws, 64, dev)
+        for i in (3, 77):
+            c = H.camera_label(H.orbit_pose(i, 240, device=dev))
+            torch.manual_seed(100 + i)
+            f_graph, r_graph = prog(c)
+            torch.manual_seed(100 + i)
+            out = G.synthesis(ws=ws, c=c, noise_mode='const', neural_rendering_resolution=64, use_cached_backbone=True)
+            assert torch.equal(f_graph, H.to_uint8(out['image'])) and torch.equal(r_graph, H.to_uint8(out['image_raw']))
+        assert f_graph.shape == (1, 512, 512, 3) and f_graph.dtype == torch.uint8 and float(f_graph.float().std()) > 1.0
