@@ -68,6 +68,8 @@ SIGNATURES = {
     'gnerf_filtered_lrelu': (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, ctypes.POINTER(_c_i64),
                                     _c_i, _c_i, ctypes.POINTER(_c_i64), _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                     _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_i, _c_p]),
+    'gnerf_grid_sample_2d': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, ctypes.POINTER(_c_i64), _c_i, _c_i, _c_p]),
+    'gnerf_grid_sample_2d_backward': (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, ctypes.POINTER(_c_i64), _c_i, _c_i, _c_p]),
     'gnerf_planes_to_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_planes_from_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_make_rays': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_p, _c_p, _c_p]),
@@ -311,6 +313,44 @@ def filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain,
         return none
     _check(code, 'gnerf_filtered_lrelu')
     return y, so, 0
+
+
+def grid_sample_supported(image, grid):
+    """True when the native sampler covers this call (GPU tensors, float16/float32 image, 4-D, positive strides)."""
+    return (image.is_cuda and grid.is_cuda and image.ndim == 4 and grid.ndim == 4 and grid.shape[-1] == 2 and grid.shape[0] == image.shape[0]
+            and image.dtype in (torch.float32, torch.float16) and image.numel() > 0 and grid.numel() > 0
+            and image.stride(2) > 0 and image.stride(3) > 0)
+
+
+def grid_sample_2d(image, grid):
+    """Bilinear, zero padding, align_corners=False (what grid_sample_gradfix.grid_sample evaluates, grid_sample_gradfix.py:45):
+    image [N,C,H,W], grid [N,Ho,Wo,2] -> [N,C,Ho,Wo] in image's dtype."""
+    _require_cuda(image, grid)
+    n, c, h, w = image.shape
+    ho, wo = grid.shape[1], grid.shape[2]
+    g = grid.float().contiguous()
+    out = torch.empty([n, c, ho, wo], dtype=image.dtype, device=image.device)
+    with _on_device(image.device):
+        code = load().gnerf_grid_sample_2d(_ptr(image), _ptr(g), _ptr(out), _DTYPE_CODE[image.dtype], n, c, h, w, _strides(image), ho, wo, _stream(image))
+    _check(code, 'gnerf_grid_sample_2d')
+    return out
+
+
+def grid_sample_2d_backward(grad_out, image, grid, need_image=True, need_grid=True):
+    """The adjoint (aten::grid_sampler_2d_backward upstream, grid_sample_gradfix.py:62-77): returns (grad_image, grad_grid), each
+    None when not requested; grad_image in image's dtype, grad_grid in grid's."""
+    _require_cuda(grad_out, image, grid)
+    n, c, h, w = image.shape
+    ho, wo = grid.shape[1], grid.shape[2]
+    g = grid.float().contiguous()
+    go = grad_out.to(image.dtype).contiguous()
+    gi = torch.zeros([n, c, h, w], dtype=torch.float32, device=image.device) if need_image else None
+    gg = torch.zeros([n, ho, wo, 2], dtype=torch.float32, device=image.device) if need_grid else None
+    with _on_device(image.device):
+        code = load().gnerf_grid_sample_2d_backward(_ptr(go), _ptr(image), _ptr(g), _ptr(gi), _ptr(gg), _DTYPE_CODE[image.dtype],
+                                                    n, c, h, w, _strides(image), ho, wo, _stream(image))
+    _check(code, 'gnerf_grid_sample_2d_backward')
+    return (None if gi is None else gi.to(image.dtype)), (None if gg is None else gg.to(grid.dtype))
 
 
 def planes_to_nhwc(planes):

@@ -3,7 +3,9 @@
 Interface of the reference's torch_utils/ops/grid_sample_gradfix.py (module flag `enabled` :24,
 `grid_sample(input, grid)` :28; fixed to mode='bilinear', padding_mode='zeros', align_corners=False).
 G-NeRF never calls it: its only user, the ADA augment pipe, is never constructed, and the renderer's lookups
-happen inside the fused render kernel on the GPU path.  Kept API-complete; the device work is ATen's sampler.
+happen inside the fused render kernel on the GPU path.  Kept API-complete.  With `enabled` set, GPU tensors go to the
+hand-written gfx950 sampler and its adjoint (csrc/grid_sample.hip through gnerf_hip.grid_sample_2d / _backward); CPU tensors,
+float64 and anything else the native kernels do not cover take ATen's sampler, as the reference does everywhere.
 
 Design: the sampler is linear in the image, so one autograd node suffices for every order -- its backward
 returns (another application of the adjoint sampler, the analytic grid gradient), and the adjoint's own
@@ -11,6 +13,8 @@ backward w.r.t. the incoming gradient is the forward sampler again.
 """
 
 import torch
+
+import gnerf_hip
 
 enabled = False     # when False, grid_sample() is exactly torch.nn.functional.grid_sample
 
@@ -27,8 +31,20 @@ def grid_sample(input, grid):
     return _Sample.apply(input, grid)
 
 
+def _native(image, grid):
+    return gnerf_hip.is_available() and gnerf_hip.grid_sample_supported(image, grid)
+
+
+def _forward(image, grid):
+    if _native(image, grid):
+        return gnerf_hip.grid_sample_2d(image, grid)
+    return torch.nn.functional.grid_sample(input=image, grid=grid, **_SAMPLER_ARGS)
+
+
 def _adjoint(grad_output, image, grid):
-    """(d loss / d image, d loss / d grid) of the sampler, straight from ATen (bilinear = 0, zeros = 0)."""
+    """(d loss / d image, d loss / d grid) of the sampler: the native adjoint on a GPU, else ATen's (bilinear = 0, zeros = 0)."""
+    if _native(image, grid):
+        return gnerf_hip.grid_sample_2d_backward(grad_output, image, grid)
     return torch.ops.aten.grid_sampler_2d_backward(grad_output, image, grid, 0, 0, False, [True, True])
 
 
@@ -40,7 +56,7 @@ class _Sample(torch.autograd.Function):
         if image.ndim != 4 or grid.ndim != 4:
             raise AssertionError('grid_sample_gradfix expects a 4-D image and a 4-D grid')
         ctx.save_for_backward(image, grid)
-        return torch.nn.functional.grid_sample(input=image, grid=grid, **_SAMPLER_ARGS)
+        return _forward(image, grid)
 
     @staticmethod
     def backward(ctx, grad_samples):

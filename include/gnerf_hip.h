@@ -13,6 +13,7 @@
  *   gnerf_upfirdn2d         <- upfirdn2d_plugin.upfirdn2d          torch_utils/ops/upfirdn2d.cpp:20
  *   gnerf_filtered_lrelu    <- filtered_lrelu_plugin.filtered_lrelu      torch_utils/ops/filtered_lrelu.cpp:20
  *   gnerf_filtered_lrelu_act<- filtered_lrelu_plugin.filtered_lrelu_act_ torch_utils/ops/filtered_lrelu.cpp:217
+ *   gnerf_grid_sample_2d(_backward) <- torch_utils/ops/grid_sample_gradfix.py:45, :62-77 (ATen's sampler upstream)
  *   gnerf_render_forward    <- ImportanceRenderer.forward          training/volumetric_rendering/renderer.py:88-140
  *                              (pure PyTorch in the reference; there is no native counterpart)
  *   gnerf_query_points      <- ImportanceRenderer.run_model        training/volumetric_rendering/renderer.py:142-148
@@ -107,6 +108,20 @@ int gnerf_filtered_lrelu(const void* x, const float* fu, const float* fd, const 
                          int up, int down, int px0, int py0,
                          int s_h, int s_w, int sx, int sy, int sign_mode,
                          float gain, float slope, float clamp, int flip, gnerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Bilinear 2-D grid sampling (mode bilinear, zero padding, align_corners = False): what grid_sample_gradfix.grid_sample
+ * evaluates upstream through torch.nn.functional.grid_sample (grid_sample_gradfix.py:45) and, in the backward,
+ * aten::grid_sampler_2d_backward (grid_sample_gradfix.py:62-77).
+ * image: [n, c, h, w] float16/float32 with element strides image_strides[4]; grid: [n, ho, wo, 2] float32 contiguous,
+ * (x, y) in [-1, 1]; out: [n, c, ho, wo] contiguous, image's dtype. */
+int gnerf_grid_sample_2d(const void* image, const float* grid, void* out, int dtype,
+                         int n, int c, int h, int w, const int64_t image_strides[4], int ho, int wo, gnerf_stream_t stream);
+/* The adjoint.  grad_out: [n, c, ho, wo] contiguous, image's dtype.  grad_image: float32 [n, c, h, w] contiguous or NULL;
+ * grad_grid: float32 [n, ho, wo, 2] or NULL (needs image).  Both are ACCUMULATED into (the caller zeroes them). */
+int gnerf_grid_sample_2d_backward(const void* grad_out, const void* image, const float* grid, float* grad_image, float* grad_grid,
+                                  int dtype, int n, int c, int h, int w, const int64_t image_strides[4], int ho, int wo,
+                                  gnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Tri-plane layout change: NCHW float32 [np, c, h, w] -> NHWC [np, h, w, c] (np = 3*batch).

@@ -244,3 +244,25 @@ def setup_filter(f, normalize=True, flip_filter=False, gain=1, separable=None):
         f = f[tuple(slice(None, None, -1) for _ in range(f.ndim))]
     f = f * (gain ** (f.ndim / 2))
     return np.ascontiguousarray(f, dtype=np.float32)
+
+
+def grid_sample_2d(image, grid):
+    """torch.nn.functional.grid_sample(image, grid, mode='bilinear', padding_mode='zeros', align_corners=False), the call
+    grid_sample_gradfix.grid_sample makes (grid_sample_gradfix.py:45).  image [N,C,H,W], grid [N,Ho,Wo,2] (x, y in [-1,1])
+    -> [N,C,Ho,Wo]; float64 arithmetic.  pixel = ((g + 1) * size - 1) / 2, taps outside the image contribute zero."""
+    image = np.asarray(image, dtype=np.float64)
+    grid = np.asarray(grid, dtype=np.float64)
+    N, C, H, W = image.shape
+    ix = ((grid[..., 0] + 1) * W - 1) / 2
+    iy = ((grid[..., 1] + 1) * H - 1) / 2
+    x0, y0 = np.floor(ix), np.floor(iy)
+    fx, fy = ix - x0, iy - y0
+    out = np.zeros((N, C) + grid.shape[1:3], dtype=np.float64)
+    n_idx = np.arange(N)[:, None, None]
+    for dy, wy in ((0, 1 - fy), (1, fy)):
+        for dx, wx in ((0, 1 - fx), (1, fx)):
+            xx, yy = (x0 + dx).astype(np.int64), (y0 + dy).astype(np.int64)
+            ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+            vals = image[n_idx, :, np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)]          # [N,Ho,Wo,C]
+            out += np.moveaxis(vals * (wx * wy * ok)[..., None], -1, 1)
+    return out

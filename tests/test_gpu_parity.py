@@ -897,3 +897,59 @@ def test_frame_program_replay_equals_eager(dev):
             out = G.synthesis(ws=ws, c=c, noise_mode='const', neural_rendering_resolution=64, use_cached_backbone=True)
             assert torch.equal(f_graph, H.to_uint8(out['image'])) and torch.equal(r_graph, H.to_uint8(out['image_raw']))
         assert f_graph.shape == (1, 512, 512, 3) and f_graph.dtype == torch.uint8 and float(f_graph.float().std()) > 1.0
+
+
+# ---- grid_sample_gradfix on the native sampler -----------------------------------------------------------------------
+
+@pytest.mark.parametrize('dtype', ['float32', 'float16'])
+@pytest.mark.parametrize('shape', [((2, 3, 7, 9), (5, 6)), ((1, 70, 33, 20), (64, 64)), ((3, 1, 4, 4), (1, 300))])
+def test_grid_sample_native_vs_oracle(dev, dtype, shape):
+    import gnerf_hip
+    from oracle import ops_ref as O
+    (N, C, H, W), (Ho, Wo) = shape
+    g = torch.Generator().manual_seed(1)
+    img = torch.randn(N, C, H, W, generator=g)
+    grid = torch.rand(N, Ho, Wo, 2, generator=g) * 2.8 - 1.4           # a good share of the points fall outside the image
+    grid[0, 0, 0] = torch.tensor([float('nan'), 0.0])
+    grid[0, 0, -1] = torch.tensor([1e30, -1e30])
+    td = getattr(torch, dtype)
+    x = img.to(dev).to(td)
+    assert gnerf_hip.grid_sample_supported(x, grid.to(dev))
+    out = gnerf_hip.grid_sample_2d(x, grid.to(dev))
+    ref = O.grid_sample_2d(x.float().cpu().numpy(), torch.nan_to_num(grid, nan=-9.0).clamp(-9, 9).numpy())      # NaN / huge = far outside = zeros
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == 'float32' else dict(rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, **tol)
+    # channels_last image: same values through the strided path
+    out_cl = gnerf_hip.grid_sample_2d(x.contiguous(memory_format=torch.channels_last), grid.to(dev))
+    assert torch.equal(out_cl, out)
+
+
+def test_grid_sample_gradfix_gpu_all_orders(dev):
+    """The drop-in op with `enabled`: forward, first-order gradients (image and grid) and the second-order gradient w.r.t. the
+    incoming gradient, on the native kernels, against autograd through torch's sampler on the CPU (the reference's path)."""
+    from torch_utils.ops import grid_sample_gradfix
+    g = torch.Generator().manual_seed(2)
+    img, grid = torch.randn(2, 5, 11, 8, generator=g), torch.rand(2, 9, 7, 2, generator=g) * 2.4 - 1.2
+    w1, w2 = torch.randn(2, 5, 9, 7, generator=g), torch.randn(2, 5, 11, 8, generator=g)
+
+    def run(image, grd, sample, second_order):
+        image, grd = image.clone().requires_grad_(True), grd.clone().requires_grad_(True)
+        out = sample(image, grd)
+        probe = w1.to(out.device).clone().requires_grad_(True)
+        g_img, g_grid = torch.autograd.grad(out, (image, grd), probe)
+        if second_order:                # (second order w.r.t. the grid is refused, upstream too: the grid is a constant in this pass)
+            image2 = image.detach().clone().requires_grad_(True)
+            (g_img2,) = torch.autograd.grad(sample(image2, grd.detach()), image2, probe, create_graph=True)
+            (gg,) = torch.autograd.grad((g_img2 * w2.to(out.device)).sum(), probe)     # d/d(grad_out) of the image gradient
+        else:       # torch's own sampler has no double backward (the reason the op exists); the image gradient is linear in the
+            gg = sample(w2, grd)        # incoming gradient with the sampler as its transpose, so the derivative is sample(w2, grid)
+        return [t.detach().cpu() for t in (out, g_img, g_grid, gg)]
+
+    ref = run(img, grid, lambda a, b: torch.nn.functional.grid_sample(a, b, mode='bilinear', padding_mode='zeros', align_corners=False), False)
+    grid_sample_gradfix.enabled = True
+    try:
+        got = run(img.to(dev), grid.to(dev), grid_sample_gradfix.grid_sample, True)
+    finally:
+        grid_sample_gradfix.enabled = False
+    for a, b, name in zip(got, ref, ('out', 'grad_image', 'grad_grid', 'grad_grad_out')):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-4, atol=2e-5, err_msg=name)

@@ -172,3 +172,14 @@ def test_filtered_lrelu(golden):
     y = O.filtered_lrelu(x, fu, fd, b, up=4, down=2, padding=[11, 10, 9, 12], flip_filter=True)
     np.testing.assert_allclose(y, g['fl_up4_down2'], rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(O.filtered_lrelu(x, b=b), g['fl_plain'], rtol=1e-5, atol=1e-6)
+
+
+def test_grid_sample_oracle_matches_torch():
+    """The numpy restatement of the sampler against the op the reference calls (torch's, on the CPU), incl. out-of-range points."""
+    import torch
+    from oracle import ops_ref as O
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(2, 3, 7, 9, generator=g)
+    grid = torch.rand(2, 5, 6, 2, generator=g) * 2.6 - 1.3
+    want = torch.nn.functional.grid_sample(img, grid, mode='bilinear', padding_mode='zeros', align_corners=False).numpy()
+    np.testing.assert_allclose(O.grid_sample_2d(img.numpy(), grid.numpy()), want, rtol=1e-5, atol=1e-6)
