@@ -605,6 +605,7 @@ __global__ __launch_bounds__(64) void query_kernel(gnerf_render_params p, float 
         sig += w.b2s;
         const int pt = 16 * t + j;
         if (g == 0 && pt < n_points) out_sigma[int64_t(item) * n_points + pt] = sig;
+        if (!out_rgb) continue;                 // densities only (shape extraction): the colour half of layer 2 is not evaluated
         v4f o[2];
 #pragma unroll
         for (int n = 0; n < 2; n++) o[n] = (v4f){w.b2c[n], w.b2c[n], w.b2c[n], w.b2c[n]};
@@ -787,7 +788,7 @@ extern "C" int gnerf_query_points(const float* planes_nhwc, int n_items, int pla
     p.planes_nhwc = planes_nhwc; p.n_items = n_items; p.plane_h = plane_h; p.plane_w = plane_w;
     p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.box_warp = box_warp;
     if (int e = check_common(&p)) return e;
-    if (!points || !out_sigma || !out_rgb) return fail(GNERF_E_ARG, "query_points: null pointer");
+    if (!points || !out_sigma) return fail(GNERF_E_ARG, "query_points: null pointer");
     if (n_points < 1) return fail(GNERF_E_ARG, "query_points: n_points must be positive");
     const int64_t tiles = int64_t(n_items) * ((n_points + 15) / 16);
     if (tiles > INT32_MAX) return fail(GNERF_E_ARG, "query_points: too many points");

@@ -176,9 +176,12 @@ def extract_density_grid(G, ws, resolution=512, max_batch=10000000, crop=True):
     for head in range(0, total, max_batch):
         hi = min(total, head + max_batch)
         pts = voxel_samples(head, hi, resolution, G.rendering_kwargs['box_warp'], device)
-        dirs = torch.zeros_like(pts)
-        dirs[..., -1] = -1
-        sigmas[head:hi] = G.renderer.run_model(planes, G.decoder, pts, dirs, G.rendering_kwargs)['sigma'].reshape(-1)
+        if hasattr(G.renderer, 'query_sigma'):                                              # this repo's renderer: densities only
+            sigmas[head:hi] = G.renderer.query_sigma(planes, G.decoder, pts, G.rendering_kwargs).reshape(-1)
+        else:
+            dirs = torch.zeros_like(pts)
+            dirs[..., -1] = -1
+            sigmas[head:hi] = G.renderer.run_model(planes, G.decoder, pts, dirs, G.rendering_kwargs)['sigma'].reshape(-1)
     vol = sigmas.reshape(resolution, resolution, resolution).flip(0)
     if crop:                                                                                # gen_videos.py:213-220
         pad, pad_top = int(30 * resolution / 256), int(38 * resolution / 256)

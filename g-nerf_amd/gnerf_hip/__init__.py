@@ -520,8 +520,8 @@ def render_backward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_
     return g_planes, g_dec
 
 
-def query_points(planes_nhwc, n_items, decoder, points, box_warp):
-    """run_model for arbitrary points [N,P,3] -> sigma [N,P,1], rgb [N,P,32]."""
+def query_points(planes_nhwc, n_items, decoder, points, box_warp, want_rgb=True):
+    """run_model for arbitrary points [N,P,3] -> sigma [N,P,1], rgb [N,P,32] (rgb None when want_rgb is False)."""
     w1, b1, w2, b2 = [t.to(torch.float32).contiguous() for t in decoder]
     _require_cuda(planes_nhwc, points, w1)
     pts = points.to(torch.float32).contiguous()
@@ -529,7 +529,7 @@ def query_points(planes_nhwc, n_items, decoder, points, box_warp):
         raise RuntimeError('query_points: points must be [N,P,3]')
     n_pts = pts.shape[1]
     sigma = torch.empty([n_items, n_pts, 1], dtype=torch.float32, device=pts.device)
-    rgb = torch.empty([n_items, n_pts, 32], dtype=torch.float32, device=pts.device)
+    rgb = torch.empty([n_items, n_pts, 32], dtype=torch.float32, device=pts.device) if want_rgb else None
     with _on_device(pts.device):
         code = load().gnerf_query_points(_ptr(planes_nhwc), n_items, planes_nhwc.shape[1], planes_nhwc.shape[2], _ptr(pts), n_pts,
                                          float(box_warp), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(sigma), _ptr(rgb), _stream(pts))

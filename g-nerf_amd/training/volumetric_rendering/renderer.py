@@ -320,6 +320,18 @@ class ImportanceRenderer(torch.nn.Module):
             out['sigma'] += torch.randn_like(out['sigma']) * density_noise
         return out
 
+    def query_sigma(self, planes, decoder, sample_coordinates, options):
+        """Densities [N,P,1] only -- run_model(...)['sigma'] without evaluating or writing the 32 colour channels (not part of the
+        reference's interface: used by this repo's shape-extraction harness, where rgb would be 17 GB of unread output at 512^3)."""
+        if planes.device.type == 'cuda' and planes.ndim == 5 and planes.shape[1] == 3 and planes.shape[2] == 32 and not torch.is_grad_enabled():
+            fcs = _osg_decoder_weights(decoder)
+            if fcs is not None and options.get('density_noise', 0) == 0:
+                return gnerf_hip.query_points(self._planes_nhwc(planes), planes.shape[0], self._decoder_cache(fcs),
+                                              sample_coordinates.detach(), options['box_warp'], want_rgb=False)[0]
+        dirs = torch.zeros_like(sample_coordinates)
+        dirs[..., -1] = -1
+        return self.run_model(planes, decoder, sample_coordinates, dirs, options)['sigma']
+
     def sort_samples(self, all_depths, all_colors, all_densities):
         _, order = torch.sort(all_depths, dim=-2)
         all_depths = torch.gather(all_depths, -2, order)

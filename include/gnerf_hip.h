@@ -220,7 +220,8 @@ int gnerf_render_backward(const gnerf_render_params* p, const gnerf_render_grads
 
 /* Density / colour of arbitrary points (run_model, renderer.py:142-148; used by
  * TriPlaneGenerator.sample / sample_mixed for shape extraction):
- * points [n_items, n_points, 3] -> sigma [n_items, n_points, 1], rgb [n_items, n_points, 32]. */
+ * points [n_items, n_points, 3] -> sigma [n_items, n_points, 1], rgb [n_items, n_points, 32].
+ * out_rgb may be NULL: densities only (the 512^3 shape extraction of gen_videos.py:189-224 reads nothing else). */
 int gnerf_query_points(const float* planes_nhwc, int n_items, int plane_h, int plane_w,
                        const float* points, int n_points, float box_warp,
                        const float* w1, const float* b1, const float* w2, const float* b2,
