@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of gnerf_render_backward against autograd through the fp64 CPU oracle.
-usage: python tools/fuzz_backward.py [n_cases] [seed]"""
+usage: python tests/parity_tools/fuzz_backward.py [n_cases] [seed]"""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, 'g-nerf_amd'), os.path.join(ROOT, 'tests'), ROOT]
 import numpy as np
 import torch

@@ -2,9 +2,9 @@
 """Randomised parity sweep of the fused filtered_lrelu kernel against the numpy oracle: random resampling factors, tap counts
 (zero-padded branches included), asymmetric paddings (also negative = cropping), shapes spanning several tiles, flips, clamp /
 no clamp, fp32 and fp16, with the gradient (second fused launch reading the signs) against autograd of the PyTorch-op form.
-usage: python tools/fuzz_filtered_lrelu.py [n_cases] [seed]"""
+usage: python tests/parity_tools/fuzz_filtered_lrelu.py [n_cases] [seed]"""
 import json, os, sys, warnings
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, 'g-nerf_amd'), ROOT]
 import numpy as np
 import torch

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the fused renderer against the CPU oracle: random sample counts (all three kernels and both
 pipelined instantiations), ragged ray counts, plane sizes, white_back, disparity-space sampling and per-ray limits.
-usage: python tools/fuzz_render.py [n_cases] [seed]"""
+usage: python tests/parity_tools/fuzz_render.py [n_cases] [seed]"""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, 'g-nerf_amd'), os.path.join(ROOT, 'tests'), ROOT]
 import numpy as np
 import torch

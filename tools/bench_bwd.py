@@ -14,11 +14,11 @@ dev = torch.device('cuda', 0)
 torch.manual_seed(0)
 planes = torch.randn(N, 3, 32, 256, 256, device=dev)
 dec = [torch.randn(64, 32, device=dev) * 0.18, torch.randn(64, device=dev) * 0.1, torch.randn(33, 64, device=dev) * 0.12, torch.randn(33, device=dev) * 0.1]
-from oracle import render_ref as R
 import numpy as np
-c2w = torch.cat([R.lookat_pose(3.14 / 2 + 0.3 * i, 3.14 / 2 - 0.05, 2.7) for i in range(N)])
+import gnerf_harness as H
+c2w = torch.cat([H.lookat_pose(3.14 / 2 + 0.3 * i, 3.14 / 2 - 0.05, 2.7) for i in range(N)])
 intr = torch.tensor([[4.2647, 0, 0.5], [0, 4.2647, 0.5], [0, 0, 1]]).repeat(N, 1, 1)
-o, d = [t.to(dev) for t in R.make_rays(c2w, intr, res)]
+o, d = gnerf_hip.make_rays(c2w.to(dev), intr.to(dev), res)
 M = res * res
 nc = torch.rand(N * M, S, device=dev); nf = torch.rand(N * M, F, device=dev)
 g_rgb = torch.randn(N, M, 32, device=dev); g_depth = torch.randn(N, M, 1, device=dev); g_w = torch.randn(N, M, 1, device=dev)
