@@ -59,3 +59,23 @@ with torch.no_grad():
     x = torch.randn(4, 128, 512, 512, device=dev, dtype=torch.float16)
     ms = timeit(lambda: torch.nn.functional.leaky_relu(x, 0.2))
     report('(torch leaky_relu, same bytes, for scale) f16', ms, 2 * x.numel() * 2)
+
+# grid_sample_gradfix's sampler (never executed by G-NeRF; for completeness): a smooth warp of a [8,64,256,256] image, as the ADA
+# pipe's geometric augmentations would issue it.  Algorithmic bytes: image + grid + output (forward); + the fp32 image gradient (adjoint).
+with torch.no_grad():
+    n, c, hw = 8, 64, 256
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, hw, device=dev), torch.linspace(-1, 1, hw, device=dev), indexing='ij')
+    base = torch.stack([xs, ys], -1)[None].repeat(n, 1, 1, 1)
+    grid = (base * 1.05 + 0.02 * torch.sin(7 * base.flip(-1))).contiguous()
+    for dt, nm in ((torch.float16, 'f16'), (torch.float32, 'f32')):
+        es = 2 if dt == torch.float16 else 4
+        img = torch.randn(n, c, hw, hw, device=dev, dtype=dt)
+        go = torch.randn(n, c, hw, hw, device=dev, dtype=dt)
+        ms = timeit(lambda: gnerf_hip.grid_sample_2d(img, grid))
+        report(f'grid_sample fwd [8,64,256,256] {nm}', ms, 2 * img.numel() * es + grid.numel() * 4)
+        ms_t = timeit(lambda: torch.nn.functional.grid_sample(img, grid.to(dt), mode='bilinear', padding_mode='zeros', align_corners=False))
+        report(f'(torch grid_sample fwd, same bytes, for scale) {nm}', ms_t, 2 * img.numel() * es + grid.numel() * 4)
+        ms = timeit(lambda: gnerf_hip.grid_sample_2d_backward(go, img, grid))
+        report(f'grid_sample adjoint (image + grid gradients) [8,64,256,256] {nm}', ms, 2 * img.numel() * es + img.numel() * 4 * 2 + 2 * grid.numel() * 4)
+        ms_t = timeit(lambda: torch.ops.aten.grid_sampler_2d_backward(go, img, grid.to(dt), 0, 0, False, [True, True]))
+        report(f'(aten grid_sampler_2d_backward, for scale) {nm}', ms_t, 2 * img.numel() * es + img.numel() * 4 * 2 + 2 * grid.numel() * 4)
