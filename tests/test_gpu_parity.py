@@ -953,3 +953,35 @@ def test_grid_sample_gradfix_gpu_all_orders(dev):
         grid_sample_gradfix.enabled = False
     for a, b, name in zip(got, ref, ('out', 'grad_image', 'grad_grid', 'grad_grad_out')):
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-4, atol=2e-5, err_msg=name)
+
+
+@pytest.mark.parametrize('S,F', [(48, 48), (96, 96), (20, 37)])
+def test_render_fine_samples_on_bin_edges(dev, S, F):
+    """The merge places a fine sample from the bin it was drawn in (three comparisons with the neighbouring coarse depths).  Draws
+    of exactly 0 and of 1 - 2^-24 put fine samples on the first midpoint and at the very end of the last bin, repeated draws put
+    many into one bin, and jitter of 0 / ~1 makes neighbouring coarse depths (nearly) coincide with the midpoints between them:
+    sorted depths must be non-decreasing, every slot written, and equal to the reference's sort."""
+    import gnerf_hip
+    from oracle import render_ref as R
+    planes, dec, o, d, nc, nf = _random_scene(31, N=1, res=8, S=S, F=F, hw=(24, 24))
+    nf, nc = nf.clone(), nc.clone()
+    nf[:, 0] = 0.0
+    nf[:, 1] = 1.0 - 2.0 ** -24
+    nf[:, 2:6] = nf[:, 6:7]                     # five samples from one draw
+    nf[5, :] = torch.linspace(0, 1 - 2.0 ** -24, F)
+    nf[6, :] = 0.0
+    nf[7, :] = 1.0 - 2.0 ** -24
+    nc[:, 8:16, 0::3] = 0.0
+    nc[:, 8:16, 1::3] = 1.0 - 2.0 ** -24
+    opts = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, clamp_mode='softplus')
+    st = {}
+    ref_rgb, ref_depth, ref_w = R.render(planes, dec, o, d, opts, nc, nf, stages=st)
+    nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
+    rgb, depth, wsum, dbg = gnerf_hip.render_forward(nhwc, 1, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev),
+                                                     depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0,
+                                                     image_width=8, debug=True)
+    sorted_d = dbg[:, 5].cpu()
+    assert bool((sorted_d[:, 1:] >= sorted_d[:, :-1]).all())
+    np.testing.assert_allclose(sorted_d.numpy(), st['depths_all'].numpy(), atol=5e-6)
+    assert float(((rgb.cpu() - ref_rgb) ** 2).mean()) < 1e-8
+    np.testing.assert_allclose(wsum.cpu().numpy(), ref_w.numpy(), atol=2e-4)
