@@ -147,6 +147,12 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the gen_videos frames/sec measurement')
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: libraries that chat on fd 1 (RCCL's version banner at communicator
+    # creation, gloo's connection notes, plugin status lines) are sent to stderr for the whole run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import gnerf_harness
     rank, world, local_rank = gnerf_harness.init_from_env()        # nccl (= RCCL) when WORLD_SIZE > 1
     if world > 1:
@@ -245,7 +251,8 @@ def main():
             line['cpu_baseline'] = cpu_baseline()
         else:
             line['cpu_baseline'] = None
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + '\n').encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

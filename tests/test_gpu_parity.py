@@ -985,3 +985,29 @@ def test_render_fine_samples_on_bin_edges(dev, S, F):
     np.testing.assert_allclose(sorted_d.numpy(), st['depths_all'].numpy(), atol=5e-6)
     assert float(((rgb.cpu() - ref_rgb) ** 2).mean()) < 1e-8
     np.testing.assert_allclose(wsum.cpu().numpy(), ref_w.numpy(), atol=2e-4)
+
+
+def test_bench_two_ranks_on_one_gpu(dev):
+    """The multi-rank path of bench.py end to end (rendezvous, per-rank scene, barriers, max-over-ranks timing, one JSON line from
+    rank 0), rehearsed with two processes sharing this box's one GPU over gloo (GNERF_DIST_BACKEND; the driver's 8-GPU run uses
+    RCCL).  Not a scaling number."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GNERF_DIST_BACKEND='gloo', OMP_NUM_THREADS='1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
+                        '--no-cpu-baseline', '--no-secondary'], capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                      # library chatter (gloo / RCCL banners) must not reach stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 5 and line['scaling'] == 'weak' and line['value'] > 1e6
+    assert line['roofline']['kernel_ms'] > 0 and line['cpu_baseline'] is None and line['secondary'] is None
