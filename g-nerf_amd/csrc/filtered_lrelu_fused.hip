@@ -8,8 +8,9 @@
 //
 // Design (not the reference's: no constant-memory filter staging, no per-specialisation tile tables):
 //   * one workgroup = one output tile of one (image, channel); all sizes are runtime values, only the resampling
-//     factors (1/2/4) and the taps per polyphase branch (1, 6 or 8) are compile-time, so the FIR inner loops are
-//     fully unrolled with their taps in SGPRs (uniform s_load straight from the filter tensors - the reference's
+//     factors (1/2/4), the taps per polyphase branch (1, 6 or 8) and the sign mode are compile-time, so the FIR inner loops
+//     are fully unrolled with their taps in SGPRs.  Every workgroup builds the polyphase tap tables itself, from the filter
+//     tensors into a few hundred bytes of LDS, and each pass reads its taps back with constant offsets (the reference's
 //     filter set-up kernel + memcpy-to-constant and its stream hazard, filtered_lrelu.py:217-218, do not exist);
 //   * four separable passes through two LDS buffers (fp32):  in -> (H up) -> (V up, activation, signs) -> (H down)
 //     -> (V down) -> y.  A lane owns a line perpendicular to the filter axis (rows for the horizontal passes with an

@@ -15,7 +15,9 @@ Run with this repo's g-nerf_amd/ in front of the reference's g_nerf/ on PYTHONPA
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 g-nerf_amd/gen_videos_mi355x.py --random-init --frames 240 ...
 
 `--random-init` builds the FFHQ-config TriPlaneGenerator with seeded random weights and a random z instead of loading
-pickles (there are no checkpoints or network access in the build environment).
+pickles (there are no checkpoints or network access in the build environment); where the reference tree is absent it is
+this repo's inference-only equivalent (gnerf_generator.Generator).  `--graph` replays the per-frame launch sequence from a
+HIP graph captured once (FrameProgram); `--shapes out.npy` also extracts the 512^3 density volume of gen_videos.py --shapes.
 """
 
 import argparse
