@@ -220,6 +220,21 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.isfile(tpath):
             traffic = json.load(open(tpath)).get('render_kernel_hbm_bytes_per_launch')
+        # what the kernel is actually short of: vector-instruction issue slots.  From the committed PMC pass of this same command
+        # (profiles/*_pmc.json, SQ_INSTS_VALU / SQ_INSTS_MFMA per launch): a wave64 VALU instruction holds its SIMD's issue port for
+        # 4 cycles and an MFMA for 8 (MI355X_MICROARCH.md, per-instruction constants), 1024 SIMDs at 2.4 GHz.
+        issue = None
+        try:
+            import re
+            pdir = os.path.join(ROOT, 'profiles')
+            named = [(re.fullmatch(r'r(\d+)_final(\d*)_pmc\.json', f), f) for f in os.listdir(pdir)]
+            latest = sorted((int(m.group(1)), int(m.group(2) or 0), f) for m, f in named if m)[-1][2]          # latest round, latest pass
+            c = json.load(open(os.path.join(pdir, latest)))['counters_mean_per_launch']
+            floor_ms = (c['SQ_INSTS_VALU'] * 4 + c['SQ_INSTS_MFMA'] * 8) / (1024 * 2.4e9) * 1e3
+            issue = {'source': 'profiles/' + latest, 'insts_valu_per_launch': c['SQ_INSTS_VALU'], 'insts_mfma_per_launch': c['SQ_INSTS_MFMA'],
+                     'issue_floor_ms': floor_ms, 'frac_of_issue_floor': floor_ms / kernel_ms}
+        except Exception:
+            issue = None
         line = {
             'metric': 'rays/sec at 128^2 neural render, 96 depth samples',
             'value': total_rays / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -232,7 +247,7 @@ def main():
                 'kernel': 'render_kernel_pipe', 'bound': 'mfma',
                 'achieved': flops / k_s / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': flops / k_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
-                'kernel_ms': kernel_ms,
+                'kernel_ms': kernel_ms, 'vector_issue': issue,
                 'note': 'achieved = ALGORITHMIC MLP work (8320 FLOP/sample x 96 samples/ray) / render-kernel time, priced against the '
                         'fp32 matrix peak because the results are fp32-grade.  The kernel evaluates each product as an error-compensated '
                         'hi/lo split on v_mfma_f32_16x16x32_f16 (3 MFMAs per product, fp32 accumulate; pixel MSE vs the reference ~1e-13), '
