@@ -21,8 +21,6 @@ HIP graph captured once (FrameProgram); `--shapes out.npy` also extracts the 512
 """
 
 import argparse
-import os
-import sys
 import time
 
 import numpy as np
