@@ -252,3 +252,18 @@ print("overlay ok")
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, cwd='/tmp')
     assert out.returncode == 0 and 'overlay ok' in out.stdout, out.stderr[-2000:]
+
+
+def test_bench_accounting_matches_survey():
+    """bench.py's algorithmic-work constants are SURVEY.md section 8d's: 136 331 908 compulsory HBM bytes per config-2 call,
+    8 320 MLP FLOP per sample, 1 536 gather bytes per sample; the scene builder gives config 2's shapes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.hbm_bytes_per_call(4, 4 * 128 * 128, 48, 48, 256) == 136331908
+    assert bench.FLOP_MLP_PER_SAMPLE == 8320 and bench.GATHER_BYTES_PER_SAMPLE == 1536
+    assert (bench.N_ITEMS, bench.RES, bench.S_COARSE, bench.S_FINE, bench.PLANE) == (4, 128, 48, 48, 256)
+    planes, dec, c2w, intr = bench._scene(torch.device('cpu'), 0, n_items=2, plane=8)
+    assert planes.shape == (2, 3, 32, 8, 8) and [tuple(t.shape) for t in dec] == [(64, 32), (64,), (33, 64), (33,)]
+    assert c2w.shape == (2, 4, 4) and abs(float(c2w[0, :3, 3].norm()) - 2.7) < 1e-5 and float(intr[0, 0, 0]) == pytest.approx(4.2647)
