@@ -42,7 +42,7 @@ _PLUGINS = {
 }
 
 
-def get_plugin(module_name, sources=None, headers=None, source_dir=None, **build_kwargs):
+def get_plugin(module_name, sources, headers=None, source_dir=None, **build_kwargs):
     assert verbosity in ['none', 'brief', 'full']
     if module_name in _cached_plugins:
         return _cached_plugins[module_name]

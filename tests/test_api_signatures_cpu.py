@@ -1,0 +1,90 @@
+"""Drop-in API check: every public callable of the overlay modules has the reference's signature (names, order, defaults), and
+every public name the reference modules define exists in the overlay.  Needs the reference tree (build container only)."""
+
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference/g_nerf'
+
+SCRIPT = r'''
+import sys, inspect, importlib, importlib.util, json
+sys.dont_write_bytecode = True
+MODS = ["torch_utils.ops.bias_act", "torch_utils.ops.upfirdn2d", "torch_utils.ops.filtered_lrelu", "torch_utils.ops.grid_sample_gradfix",
+        "torch_utils.custom_ops", "training.volumetric_rendering.renderer", "training.volumetric_rendering.ray_marcher",
+        "training.volumetric_rendering.ray_sampler", "training.volumetric_rendering.math_utils"]
+
+
+def load_from(root, name):
+    path = root + "/" + name.replace(".", "/") + ".py"
+    spec = importlib.util.spec_from_file_location("probe_" + name.replace(".", "_") + ("_ref" if "reference" in root else "_ours"), path,
+                                                  submodule_search_locations=None)
+    m = importlib.util.module_from_spec(spec)
+    m.__package__ = name.rsplit(".", 1)[0]
+    spec.loader.exec_module(m)
+    return m
+
+
+def public(m):
+    out = {}
+    for k, v in vars(m).items():
+        if k.startswith("_") or inspect.ismodule(v):
+            continue
+        if getattr(v, "__module__", None) not in (m.__name__, None) and not isinstance(v, (int, float, str, bool, dict)):
+            continue                                   # imported from elsewhere
+        out[k] = v
+    return out
+
+
+def sig(f):
+    try:
+        s = inspect.signature(f)
+    except (TypeError, ValueError):
+        return None
+    return [(p.name, str(p.kind), repr(p.default) if p.default is not inspect._empty else None) for p in s.parameters.values()]
+
+
+report = {"missing": [], "signature": []}
+sys.path.insert(0, %(ref)r)                            # the reference alone first ...
+ref_mods = {n: importlib.import_module(n) for n in MODS}
+ref_pub = {n: {k: (sig(v) if callable(v) else "value", {mn: sig(mv) for mn, mv in vars(v).items() if callable(mv) and not mn.startswith("_")} if inspect.isclass(v) else None)
+               for k, v in public(m).items()} for n, m in ref_mods.items()}
+for n in list(sys.modules):
+    if n.split(".")[0] in ("torch_utils", "training", "dnnlib"):
+        del sys.modules[n]
+sys.path.insert(0, %(ours)r)                           # ... then the overlay in front of it
+for n in MODS:
+    m = importlib.import_module(n)
+    assert %(ours)r in m.__file__, (n, m.__file__)
+    ours = public(m)
+    for k, (s_ref, methods_ref) in ref_pub[n].items():
+        if k not in vars(m):
+            report["missing"].append(n + "." + k)
+            continue
+        v = vars(m)[k]
+        if s_ref not in (None, "value") and callable(v) and not inspect.isclass(v):
+            if sig(v) != s_ref:
+                report["signature"].append([n + "." + k, sig(v), s_ref])
+        if methods_ref:
+            for mn, ms in methods_ref.items():
+                mv = getattr(v, mn, None)
+                if mv is None:
+                    report["missing"].append(n + "." + k + "." + mn)
+                elif ms is not None and sig(mv) != ms:
+                    report["signature"].append([n + "." + k + "." + mn, sig(mv), ms])
+print(json.dumps(report))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree only exists in the build container')
+def test_overlay_matches_reference_signatures():
+    import json
+    code = SCRIPT % dict(ref=REF, ours=os.path.join(ROOT, 'g-nerf_amd'))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'), cwd='/tmp', timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    report = json.loads(r.stdout.strip().splitlines()[-1])
+    assert report['missing'] == [], report['missing']
+    assert report['signature'] == [], report['signature']

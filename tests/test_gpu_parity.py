@@ -774,7 +774,7 @@ def test_filtered_lrelu_fused_gradient(dev, case):
     kw = dict(up=up, down=down, padding=pad, gain=1.7, slope=0.15, clamp=0.6, flip_filter=flip)
     calls = []
     real = gnerf_hip.filtered_lrelu
-    plugin = filtered_lrelu.custom_ops.get_plugin('filtered_lrelu_plugin')
+    plugin = filtered_lrelu.custom_ops.get_plugin('filtered_lrelu_plugin', sources=[])
 
     def spy(*a):
         r = real(*a)

@@ -220,11 +220,11 @@ def test_custom_ops_plugin_surface():
     custom_ops.verbosity = 'none'
     p = custom_ops.get_plugin('bias_act_plugin', sources=['x.cpp'], headers=['x.h'], source_dir='.', extra_cuda_cflags=['--use_fast_math'])
     assert callable(p.bias_act)
-    assert callable(custom_ops.get_plugin('upfirdn2d_plugin').upfirdn2d)
-    fl = custom_ops.get_plugin('filtered_lrelu_plugin')
+    assert callable(custom_ops.get_plugin('upfirdn2d_plugin', sources=[]).upfirdn2d)
+    fl = custom_ops.get_plugin('filtered_lrelu_plugin', sources=[])
     assert callable(fl.filtered_lrelu) and callable(fl.filtered_lrelu_act_)
     with pytest.raises(RuntimeError):
-        custom_ops.get_plugin('no_such_plugin')
+        custom_ops.get_plugin('no_such_plugin', sources=[])
 
 
 @pytest.mark.skipif(not os.path.isdir('/root/reference/g_nerf'), reason='reference tree only exists in the build container')
