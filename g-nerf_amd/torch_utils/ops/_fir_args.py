@@ -10,9 +10,10 @@ def as_xy(value, kinds=(int,)):
     """int -> (v, v); [x, y] -> (x, y).  Elements must be instances of `kinds`."""
     if isinstance(value, kinds) and not isinstance(value, bool):
         return value, value
-    assert isinstance(value, (list, tuple)) and len(value) == 2
+    assert isinstance(value, (list, tuple))
     assert all(isinstance(v, kinds) for v in value)
-    return value[0], value[1]
+    x, y = value                        # any other length: ValueError from the unpacking, as upstream (upfirdn2d.py:36-43)
+    return x, y
 
 
 def parse_scaling(scaling):
@@ -25,12 +26,13 @@ def parse_padding(padding, kinds=(int,)):
     """int | [x, y] | [x0, x1, y0, y1] -> (x0, x1, y0, y1)."""
     if isinstance(padding, kinds) and not isinstance(padding, bool):
         padding = [padding] * 4
-    assert isinstance(padding, (list, tuple)) and len(padding) in (2, 4)
+    assert isinstance(padding, (list, tuple))
     assert all(isinstance(v, kinds) for v in padding)
     values = [int(v) for v in padding]
     if len(values) == 2:
         values = [values[0], values[0], values[1], values[1]]
-    return tuple(values)
+    x0, x1, y0, y1 = values             # any other length: ValueError from the unpacking, as upstream (upfirdn2d.py:45-54)
+    return x0, x1, y0, y1
 
 
 def filter_size(f, strict=True):

@@ -88,3 +88,52 @@ def test_overlay_matches_reference_signatures():
     report = json.loads(r.stdout.strip().splitlines()[-1])
     assert report['missing'] == [], report['missing']
     assert report['signature'] == [], report['signature']
+
+
+ERR_SCRIPT = r'''
+import sys, json
+sys.dont_write_bytecode = True
+for p in reversed(%(paths)r): sys.path.insert(0, p)
+import torch, numpy as np
+from torch_utils.ops import bias_act, upfirdn2d, filtered_lrelu
+x = torch.randn(2, 3, 8, 8)
+f = upfirdn2d.setup_filter([1, 3, 3, 1])
+cases = {
+ 'ba_bad_impl': lambda: bias_act.bias_act(x, impl='foo'), 'ba_neg_clamp': lambda: bias_act.bias_act(x, clamp=-1),
+ 'ba_bad_b_shape': lambda: bias_act.bias_act(x, torch.zeros(4)), 'ba_bad_b_rank': lambda: bias_act.bias_act(x, torch.zeros(3, 1)),
+ 'ba_bad_dim': lambda: bias_act.bias_act(x, torch.zeros(3), dim=7), 'ba_bad_act': lambda: bias_act.bias_act(x, act='nope'),
+ 'up_bad_impl': lambda: upfirdn2d.upfirdn2d(x, f, impl='foo'), 'up_bad_rank': lambda: upfirdn2d.upfirdn2d(x[0], f),
+ 'up_bad_filter_dtype': lambda: upfirdn2d.upfirdn2d(x, f.double()), 'up_bad_filter_rank': lambda: upfirdn2d.upfirdn2d(x, f[None]),
+ 'up_bad_pad_len': lambda: upfirdn2d.upfirdn2d(x, f, padding=[1, 2, 3]), 'up_bad_pad_type': lambda: upfirdn2d.upfirdn2d(x, f, padding=[1.0, 2]),
+ 'up_bad_up': lambda: upfirdn2d.upfirdn2d(x, f, up=0), 'up_float_up': lambda: upfirdn2d.upfirdn2d(x, f, up=1.5), 'up_bad_up_len': lambda: upfirdn2d.upfirdn2d(x, f, up=[1, 2, 3]),
+ 'setup_filter_3d': lambda: upfirdn2d.setup_filter(np.ones((2, 2, 2))), 'setup_filter_empty': lambda: upfirdn2d.setup_filter([]),
+ 'setup_filter_none': lambda: tuple(upfirdn2d.setup_filter(None).shape), 'setup_filter_sep8': lambda: tuple(upfirdn2d.setup_filter(list(range(1, 9))).shape),
+ 'filter2d': lambda: tuple(upfirdn2d.filter2d(x, f).shape), 'upsample2d': lambda: tuple(upfirdn2d.upsample2d(x, f, up=2).shape),
+ 'downsample2d': lambda: tuple(upfirdn2d.downsample2d(x, f, down=2).shape), 'upsample2d_xy': lambda: tuple(upfirdn2d.upsample2d(x, f, up=[2, 1], padding=[1, 0]).shape),
+ 'fl_bad_impl': lambda: filtered_lrelu.filtered_lrelu(x, impl='foo'), 'fl_bad_up': lambda: filtered_lrelu.filtered_lrelu(x, up=0),
+ 'fl_bad_gain': lambda: filtered_lrelu.filtered_lrelu(x, gain=-1), 'fl_bad_b': lambda: filtered_lrelu.filtered_lrelu(x, b=torch.zeros(5)),
+ 'fl_bad_clamp': lambda: filtered_lrelu.filtered_lrelu(x, clamp=-2), 'fl_bad_pad_len': lambda: filtered_lrelu.filtered_lrelu(x, padding=[1, 2, 3]),
+ 'fl_plain': lambda: tuple(filtered_lrelu.filtered_lrelu(x).shape),
+}
+out = {}
+for k, fn in cases.items():
+    try:
+        out[k] = 'ok:' + str(fn())
+    except Exception as e:
+        out[k] = type(e).__name__
+print(json.dumps(out))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree only exists in the build container')
+def test_overlay_error_behaviour_matches_reference():
+    """The same misuse raises the same exception type in the overlay ops as in the reference's (and valid helper calls give the same
+    shapes): the error behaviour is part of the drop-in contract."""
+    import json
+    res = {}
+    for name, paths in (('ref', [REF]), ('ours', [os.path.join(ROOT, 'g-nerf_amd'), REF])):
+        r = subprocess.run([sys.executable, '-c', ERR_SCRIPT % dict(paths=paths)], capture_output=True, text=True,
+                           env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'), cwd='/tmp', timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res['ours'] == res['ref'], {k: (res['ref'][k], res['ours'][k]) for k in res['ref'] if res['ref'][k] != res['ours'][k]}
