@@ -137,3 +137,99 @@ def test_overlay_error_behaviour_matches_reference():
         assert r.returncode == 0, r.stderr[-3000:]
         res[name] = json.loads(r.stdout.strip().splitlines()[-1])
     assert res['ours'] == res['ref'], {k: (res['ref'][k], res['ours'][k]) for k in res['ref'] if res['ref'][k] != res['ours'][k]}
+
+
+RENDER_SCRIPT = r'''
+import sys, json
+sys.dont_write_bytecode = True
+for p in reversed(%(paths)r): sys.path.insert(0, p)
+import numpy as np, torch
+from training.volumetric_rendering.renderer import ImportanceRenderer, sample_from_3dgrid, generate_planes, project_onto_planes
+from training.volumetric_rendering.ray_sampler import RaySampler
+from training.volumetric_rendering.ray_marcher import MipRayMarcher2
+from training.volumetric_rendering import math_utils
+
+
+class FC(torch.nn.Module):
+    def __init__(self, i, o, g):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(o, i, generator=g)); self.bias = torch.nn.Parameter(torch.randn(o, generator=g) * 0.1)
+        self.activation = 'linear'; self.weight_gain = 1 / np.sqrt(i); self.bias_gain = 1
+    def forward(self, x):
+        return torch.addmm((self.bias * self.bias_gain).unsqueeze(0), x, (self.weight * self.weight_gain).t())
+
+
+class Dec(torch.nn.Module):
+    def __init__(self, g):
+        super().__init__()
+        self.net = torch.nn.Sequential(FC(32, 64, g), torch.nn.Softplus(), FC(64, 33, g))
+    def forward(self, feats, dirs):
+        x = feats.mean(1); N, M, C = x.shape
+        x = self.net(x.view(N * M, C)).view(N, M, -1)
+        return {'rgb': torch.sigmoid(x[..., 1:]) * 1.002 - 0.001, 'sigma': x[..., 0:1]}
+
+
+g = torch.Generator().manual_seed(0)
+planes = torch.randn(2, 3, 32, 12, 12, generator=g)
+dec = Dec(g)
+cams = torch.eye(4).repeat(2, 1, 1); cams[:, 2, 3] = 2.7; cams[1, 0, 3] = 0.3; cams[:, 2, 2] = -1; cams[:, 0, 0] = -1
+intr = torch.tensor([[4.2647, 0, 0.5], [0, 4.2647, 0.5], [0, 0, 1]]).repeat(2, 1, 1)
+o, d = RaySampler()(cams, intr, 6)
+base = dict(depth_resolution=10, depth_resolution_importance=9, ray_start=2.25, ray_end=3.3, box_warp=1, clamp_mode='softplus', disparity_space_sampling=False)
+out = {'rays_o': o.numpy().tolist(), 'rays_d': d.numpy().tolist()}
+variants = {'base': {}, 'white_back': {'white_back': True}, 'disparity': {'disparity_space_sampling': True}, 'auto': {'ray_start': 'auto', 'ray_end': 'auto'},
+            'no_importance': {'depth_resolution_importance': 0}, 'noise': {'density_noise': 0.3}, 'box2': {'box_warp': 2}}
+ren = ImportanceRenderer()
+for name, kw in variants.items():
+    torch.manual_seed(5)
+    with torch.no_grad():
+        r = ren(planes, dec, o, d, dict(base, **kw))
+    out[name] = [t.numpy().tolist() for t in r]
+torch.manual_seed(6)
+pts = torch.rand(2, 50, 3, generator=g) * 1.2 - 0.6
+with torch.no_grad():
+    rm = ren.run_model(planes, dec, pts, torch.zeros_like(pts), base)
+out['run_model'] = [rm['rgb'].numpy().tolist(), rm['sigma'].numpy().tolist()]
+out['grid3d'] = sample_from_3dgrid(torch.randn(1, 4, 5, 6, 7, generator=g), torch.rand(2, 9, 3, generator=g) * 2 - 1).numpy().tolist()
+out['project'] = project_onto_planes(generate_planes(), pts).numpy().tolist()
+v = torch.randn(4, 7, 3, generator=g)
+out['normalize'] = math_utils.normalize_vecs(v).numpy().tolist()
+out['dot'] = math_utils.torch_dot(v, v.flip(0)).numpy().tolist()
+lo, hi = math_utils.get_ray_limits_box(o, d, box_side_length=1)
+out['limits'] = [torch.nan_to_num(lo, posinf=9, neginf=-9).numpy().tolist(), torch.nan_to_num(hi, posinf=9, neginf=-9).numpy().tolist()]
+out['linspace'] = math_utils.linspace(torch.tensor([0.0, 1.0]), torch.tensor([2.0, 5.0]), 7).numpy().tolist()
+m = MipRayMarcher2()
+cols, dens, deps = torch.rand(2, 5, 8, 3, generator=g), torch.randn(2, 5, 8, 1, generator=g), torch.sort(torch.rand(2, 5, 8, 1, generator=g) + 2, dim=2)[0]
+out['marcher'] = [t.numpy().tolist() for t in m(cols, dens, deps, base)]
+try:
+    m(cols, dens, deps, dict(base, clamp_mode='relu')); out['marcher_bad_mode'] = 'ok'
+except Exception as e:
+    out['marcher_bad_mode'] = type(e).__name__
+print(json.dumps(out))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree only exists in the build container')
+def test_overlay_renderer_modules_match_reference_on_cpu():
+    """The four renderer modules of the overlay against the reference's on the CPU, same seeds (both consume torch's generator in the
+    same order): ImportanceRenderer.forward under every option the reference reads (white_back, disparity sampling, 'auto' ray limits,
+    no importance pass, density noise, box_warp), run_model, sample_from_3dgrid, project_onto_planes, the math_utils helpers and
+    MipRayMarcher2 incl. its refusal of other clamp modes."""
+    import json
+    import numpy as np
+    res = {}
+    for name, paths in (('ref', [REF]), ('ours', [os.path.join(ROOT, 'g-nerf_amd'), REF])):
+        r = subprocess.run([sys.executable, '-c', RENDER_SCRIPT % dict(paths=paths)], capture_output=True, text=True,
+                           env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'), cwd='/tmp', timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res['ours'].keys() == res['ref'].keys()
+    assert res['ours']['marcher_bad_mode'] == res['ref']['marcher_bad_mode']
+    for k in res['ref']:
+        if k == 'marcher_bad_mode':
+            continue
+        a, b = res['ref'][k], res['ours'][k]
+        if not isinstance(a[0], list) or not isinstance(a[0][0], list) or isinstance(a[0][0][0], float):
+            a, b = [a], [b]
+        for x, y in zip(a, b):
+            np.testing.assert_allclose(np.asarray(y, dtype=np.float64), np.asarray(x, dtype=np.float64), rtol=2e-4, atol=2e-5, err_msg=k)
