@@ -233,3 +233,98 @@ def test_overlay_renderer_modules_match_reference_on_cpu():
             a, b = [a], [b]
         for x, y in zip(a, b):
             np.testing.assert_allclose(np.asarray(y, dtype=np.float64), np.asarray(x, dtype=np.float64), rtol=2e-4, atol=2e-5, err_msg=k)
+
+
+OPS_SCRIPT = r'''
+import sys, json
+sys.dont_write_bytecode = True
+for p in reversed(%(paths)r): sys.path.insert(0, p)
+import numpy as np, torch
+from torch_utils.ops import bias_act, upfirdn2d, filtered_lrelu, grid_sample_gradfix
+rng = np.random.default_rng(3)
+out = {}
+ACTS = list(bias_act.activation_funcs.keys())
+out['acts'] = ACTS
+out['act_table'] = {k: [v.def_alpha, v.def_gain, v.cuda_idx, v.ref, v.has_2nd_grad] for k, v in bias_act.activation_funcs.items()}
+for i, act in enumerate(ACTS):
+    x = torch.from_numpy(rng.standard_normal((2, 5, 4, 3))).double().requires_grad_(True)
+    b = torch.from_numpy(rng.standard_normal(5)).double().requires_grad_(True)
+    kw = dict(dim=1, act=act, alpha=(None if i %% 2 else 0.3), gain=(None if i %% 3 else 1.7), clamp=(None if i %% 2 == 0 else 0.9))
+    y = bias_act.bias_act(x, b, **kw)
+    w = torch.from_numpy(rng.standard_normal(tuple(y.shape))).double()
+    gx, gb = torch.autograd.grad((y * w).sum(), (x, b), create_graph=True)
+    s2 = (gx * w).sum() + (gb ** 2).sum()
+    ggx = torch.autograd.grad(s2, x, allow_unused=True)[0] if s2.requires_grad else None
+    out['ba_' + act] = [y.detach().numpy().tolist(), gx.detach().numpy().tolist(), gb.detach().numpy().tolist(), (torch.zeros_like(x) if ggx is None else ggx).numpy().tolist()]
+for j, (up, down, pad, ftaps, flip, gain) in enumerate([(1, 1, [1, 1, 1, 1], [1, 3, 3, 1], False, 4.0), (2, 1, [2, 1, 2, 1], [1, 3, 3, 1], False, 4.0), (1, 2, [1, 1, 1, 1], [1, 3, 3, 1], True, 1.0),
+                                                      ([2, 1], [1, 3], [0, 1, 2, 0], list(range(1, 9)), False, 2.0), (3, 2, 2, [1, 2, 1], True, 1.5), (1, 1, [-1, 0, 0, -1], None, False, 1.0)]):
+    x = torch.from_numpy(rng.standard_normal((2, 3, 9, 11))).float().requires_grad_(True)
+    f = upfirdn2d.setup_filter(ftaps) if ftaps is not None else None
+    y = upfirdn2d.upfirdn2d(x, f, up=up, down=down, padding=pad, flip_filter=flip, gain=gain)
+    w = torch.from_numpy(rng.standard_normal(tuple(y.shape))).float()
+    gx, = torch.autograd.grad((y * w).sum(), x)
+    out['up_%%d' %% j] = [y.detach().numpy().tolist(), gx.numpy().tolist()]
+for j, kw in enumerate([dict(), dict(up=2, down=2, padding=[5, 5, 5, 5], gain=1.3, slope=0.1, clamp=0.8), dict(up=2, down=1, padding=[3, 2, 3, 2], flip_filter=True), dict(up=1, down=2, padding=3)]):
+    x = torch.from_numpy(rng.standard_normal((2, 3, 8, 8))).float().requires_grad_(True)
+    b = torch.from_numpy(rng.standard_normal(3)).float().requires_grad_(True)
+    fu = upfirdn2d.setup_filter([1, 4, 6, 4, 1, 0][: 6]) if kw.get('up', 1) > 1 else None
+    fd = upfirdn2d.setup_filter([1, 3, 3, 1, 2, 2]) if kw.get('down', 1) > 1 else None
+    y = filtered_lrelu.filtered_lrelu(x, fu=fu, fd=fd, b=b, **kw)
+    w = torch.from_numpy(rng.standard_normal(tuple(y.shape))).float()
+    gx, gb = torch.autograd.grad((y * w).sum(), (x, b))
+    out['fl_%%d' %% j] = [y.detach().numpy().tolist(), gx.numpy().tolist(), gb.numpy().tolist()]
+img = torch.from_numpy(rng.standard_normal((2, 3, 6, 7))).float().requires_grad_(True)
+grid = torch.from_numpy(rng.uniform(-1.2, 1.2, (2, 4, 5, 2))).float().requires_grad_(True)
+w = torch.from_numpy(rng.standard_normal((2, 3, 4, 5))).float()
+for flag in (False, True):
+    grid_sample_gradfix.enabled = flag
+    try:            # (with the flag on, the reference's own op fails under torch 2.x: torch._C._jit_get_operation returns a tuple there)
+        y = grid_sample_gradfix.grid_sample(img, grid)
+        gi, gg = torch.autograd.grad((y * w).sum(), (img, grid))
+        out['gs_%%d' %% flag] = [y.detach().numpy().tolist(), gi.numpy().tolist(), gg.numpy().tolist()]
+    except TypeError:
+        out['gs_%%d' %% flag] = None
+grid_sample_gradfix.enabled = False
+print(json.dumps(out))
+'''
+
+
+def _close(a, b, key, rtol=2e-5, atol=2e-6):
+    import numpy as np
+    if isinstance(a, list) and a and isinstance(a[0], list) and not _is_numeric(a):
+        assert len(a) == len(b), key
+        for x, y in zip(a, b):
+            _close(x, y, key, rtol, atol)
+    else:
+        np.testing.assert_allclose(np.asarray(b, dtype=np.float64), np.asarray(a, dtype=np.float64), rtol=rtol, atol=atol, err_msg=key)
+
+
+def _is_numeric(a):
+    import numpy as np
+    try:
+        return np.asarray(a, dtype=np.float64).dtype == np.float64
+    except (ValueError, TypeError):
+        return False
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree only exists in the build container')
+def test_overlay_ops_match_reference_on_cpu():
+    """The four op modules of the overlay against the reference's on the CPU (the reference's `_ref` forms; first- and second-order
+    gradients through autograd): every activation of bias_act incl. the activation table itself, upfirdn2d variants (per-axis factors,
+    crops, separable 8-tap filter, no filter), filtered_lrelu, grid_sample with the flag off and on."""
+    import json
+    res = {}
+    for name, paths in (('ref', [REF]), ('ours', [os.path.join(ROOT, 'g-nerf_amd'), REF])):
+        r = subprocess.run([sys.executable, '-c', OPS_SCRIPT % dict(paths=paths)], capture_output=True, text=True,
+                           env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'), cwd='/tmp', timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res['ours']['acts'] == res['ref']['acts'] and res['ours']['act_table'] == res['ref']['act_table']
+    assert res['ours']['gs_1'] is not None
+    if res['ref']['gs_1'] is None:                   # the reference's flag-on path is broken under this torch: the flag-off results are the same function
+        res['ref']['gs_1'] = res['ref']['gs_0']
+    for k in res['ref']:
+        if k in ('acts', 'act_table'):
+            continue
+        for x, y in zip(res['ref'][k], res['ours'][k]):
+            _close(x, y, k)
