@@ -32,7 +32,8 @@ def grid_sample(input, grid):
 
 
 def _native(image, grid):
-    return gnerf_hip.is_available() and gnerf_hip.grid_sample_supported(image, grid)
+    # no availability check: a GPU call with the library missing must raise (gnerf_hip.load), never fall back silently
+    return gnerf_hip.grid_sample_supported(image, grid)
 
 
 def _forward(image, grid):
