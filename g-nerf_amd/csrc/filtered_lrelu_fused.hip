@@ -16,7 +16,7 @@
 //     -> (V down) -> y.  A lane owns a line perpendicular to the filter axis (rows for the horizontal passes with an
 //     odd row pitch, columns for the vertical ones), so every LDS access of a wave is bank-conflict free, and it
 //     produces a block of outputs along the filter axis from one sliding register window: G*UP outputs from G+TU
-//     reads (up), R outputs from (R-1)*DOWN + FD reads (down);
+//     reads (up), R outputs from (R-1)*DOWN + FD reads (down), with G = R = 2;
 //   * the zero-insertion upsample is never materialised: output c of phase p reads input (c+k-pad)/up only for the
 //     taps k = phase - p (mod up);
 //   * signs: a lane's four neighbours in a row are the four pixels of one sign byte, combined with two DPP
@@ -24,6 +24,7 @@
 //     halos never write partial bytes.
 
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -47,8 +48,17 @@ struct FlArgs {
 };
 
 constexpr int kThreads = 256;
-constexpr int G = 4;   // polyphase groups per work item (up passes)
-constexpr int R = 4;   // outputs per work item (down passes)
+// Blocking along the filter axis, measured on the StyleGAN3-layer shapes (tools/bench_filtered_lrelu.py): 2 and 2 beat 1, 3, 4 and 8 --
+// wider blocks reuse more of the register window but leave fewer work items than the 256 lanes want (4 / 4: 0.35 ms, 2 / 2: 0.30 ms at
+// up 2 / down 2; 0.49 -> 0.40 ms at down 4).
+#ifndef GNERF_FL_G
+#define GNERF_FL_G 2
+#endif
+#ifndef GNERF_FL_R
+#define GNERF_FL_R 2
+#endif
+constexpr int G = GNERF_FL_G;   // polyphase groups per work item (up passes)
+constexpr int R = GNERF_FL_R;   // outputs per work item (down passes)
 
 __host__ __device__ constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
@@ -369,7 +379,19 @@ extern "C" int gnerf_filtered_lrelu(const void* x, const float* fu, const float*
     const size_t budget = 48 * 1024;
     size_t bytes = 0;
     bool found = false;
+    int forced[2] = {0, 0};
+    if (const char* e = getenv("GNERF_FL_TILE")) sscanf(e, "%d,%d", &forced[0], &forced[1]);        // A/B aid: force a tile (width*down must stay a multiple of 4)
+    if (forced[0] > 0 && forced[1] > 0 && (forced[0] * down) % 4 == 0) {
+        const FlGeom g = geometry(up, tu, down, td, forced[0], forced[1]);
+        if (g.bytes <= 64 * 1024) {
+            a.tow = forced[0]; a.toh = forced[1];
+            a.pitch_in = g.pitch_in; a.pitch_up = g.pitch_up; a.pitch_dn = g.pitch_dn; a.buf0_floats = g.buf0; a.buf1_floats = g.buf1;
+            bytes = g.bytes;
+            found = true;
+        }
+    }
     for (const auto& t : cand) {
+        if (found) break;
         const FlGeom g = geometry(up, tu, down, td, t[0], t[1]);
         if (g.bytes <= budget) {
             a.tow = t[0]; a.toh = t[1];
