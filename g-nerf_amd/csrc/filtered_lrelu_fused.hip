@@ -47,7 +47,7 @@ struct FlArgs {
     int buf0_floats, buf1_floats;
 };
 
-constexpr int kThreads = 256;
+constexpr int kMaxThreads = 512;        // the launcher picks 128, 256 or 512 lanes per workgroup (see gnerf_filtered_lrelu)
 // Blocking along the filter axis, measured on the StyleGAN3-layer shapes (tools/bench_filtered_lrelu.py): 2 and 2 beat 1, 3, 4 and 8 --
 // wider blocks reuse more of the register window but leave fewer work items than the 256 lanes want (4 / 4: 0.35 ms, 2 / 2: 0.30 ms at
 // up 2 / down 2; 0.49 -> 0.40 ms at down 4).
@@ -79,7 +79,7 @@ __device__ __forceinline__ float uniform(float v) { return __uint_as_float(__bui
 
 // SIGN: 0 none, 1 write, 2 read
 template <int UP, int TU, int DOWN, int TD, int SIGN>
-__global__ __launch_bounds__(kThreads) void filtered_lrelu_fused_kernel(FlArgs a) {
+__global__ __launch_bounds__(kMaxThreads) void filtered_lrelu_fused_kernel(FlArgs a) {
     extern __shared__ float lds[];
     constexpr int FD = TD * DOWN;
     constexpr int NFU = UP * (TU + 1);
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(kThreads) void filtered_lrelu_fused_kernel(FlArgs a
     const int ch = bid % a.c;
     const int img = bid / a.c;
     const int tid = threadIdx.x;
+    const int kThreads = blockDim.x;
 
     const int ox0 = tx * a.tow, oy0 = ty * a.toh;
     const int tow = min(a.tow, a.yw - ox0), toh = min(a.toh, a.yh - oy0);
@@ -106,18 +107,20 @@ __global__ __launch_bounds__(kThreads) void filtered_lrelu_fused_kernel(FlArgs a
 
     // ---- polyphase tables -> LDS (one tap per lane; the passes read them back with constant offsets).
     //      up:   F[p][t] = f'[phase - p + t*UP], t = 0..TU;   down: F[k] = f'[k]
-    if (tid < 2 * NFU) {
-        const int yy = tid >= NFU, e = tid - yy * NFU;
-        const int p = e / (TU + 1), t = e - p * (TU + 1);
-        const int k = (yy ? phy : phx) - p + t * UP;
-        float v = tap(a.fu, a.fuw, a.flip, k);
-        if (yy && a.fu_is2d) v = (k == 0) ? 1.f : 0.f;
-        taps[tid] = v;
-    } else if (tid < 2 * NFU + 2 * FD) {
-        const int e = tid - 2 * NFU, yy = e >= FD, k = e - yy * FD;
-        float v = tap(a.fd, a.fdw, a.flip, k);
-        if (yy && a.fd_is2d) v = (k == 0) ? 1.f : 0.f;
-        taps[tid] = v;
+    for (int e0 = tid; e0 < 2 * NFU + 2 * FD; e0 += kThreads) {
+        if (e0 < 2 * NFU) {
+            const int yy = e0 >= NFU, e = e0 - yy * NFU;
+            const int p = e / (TU + 1), t = e - p * (TU + 1);
+            const int k = (yy ? phy : phx) - p + t * UP;
+            float v = tap(a.fu, a.fuw, a.flip, k);
+            if (yy && a.fu_is2d) v = (k == 0) ? 1.f : 0.f;
+            taps[e0] = v;
+        } else {
+            const int e = e0 - 2 * NFU, yy = e >= FD, k = e - yy * FD;
+            float v = tap(a.fd, a.fdw, a.flip, k);
+            if (yy && a.fd_is2d) v = (k == 0) ? 1.f : 0.f;
+            taps[e0] = v;
+        }
     }
 
     // ---- S0: input tile + bias, zero outside the image.
@@ -406,6 +409,10 @@ extern "C" int gnerf_filtered_lrelu(const void* x, const float* fu, const float*
     a.tiles_y = (yh + a.toh - 1) / a.toh;
     const int64_t blocks = int64_t(a.tiles_x) * a.tiles_y * n * c;
     if (blocks > 0x7fffffffLL) return fail(GNERF_E_UNSUPPORTED, "filtered_lrelu: grid too large");
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), bytes, as_stream(stream), a);
+    // Lanes per workgroup, measured per resampling pair (tools/bench_filtered_lrelu.py): the passes of a tile offer between ~250 (no
+    // downsampling filter) and ~2 000 (down 4) work items each
+    int threads = down == 1 ? 128 : (down == 4 ? 512 : 256);
+    if (const char* e = getenv("GNERF_FL_THREADS")) { const int t = atoi(e); if (t == 128 || t == 256 || t == 512) threads = t; }       // A/B aid
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(threads), bytes, as_stream(stream), a);
     return check_launch("filtered_lrelu");
 }
