@@ -92,13 +92,16 @@ __device__ __forceinline__ A eval(A in, A bias, A xref, A yref, A dy2, int grad,
 
 template <class T, int VEC> struct alignas(sizeof(T) * VEC) Pack { T v[VEC]; };
 
-// Both kernels move kBatch vectors per lane per wait: all loads of a batch are issued, then the arithmetic, then all
+// Both kernels move a batch of vectors per lane per wait: all loads of a batch are issued, then the arithmetic, then all
 // stores.  Loads and stores share one completion counter (vmcnt) on this hardware, and with both kinds pending the compiler
 // must wait for everything -- a load -> store -> load -> store loop waits for each store's acknowledgement before the next
 // load's data can be used.  Out-of-range slots of the last batch load a valid address and skip the store.
-constexpr int kBatch = 4;
+// Batch size by element type, measured on [4,128,512,512], [4,256,256,256] and [1,128,512,512] (sweep 1, 2, 3, 4, 8): two 16-byte
+// vectors for fp16 (4.75 -> 5.0, 5.4 -> 5.7-6.0, 4.85 -> 5.3-5.4 TB/s against four), one for fp32 / fp64 (6.0 -> 6.3, 5.7 -> 6.2,
+// 6.6 -> 6.9 TB/s): enough workgroups are resident for the memory system without deeper per-lane batches, which only add registers.
+template <class T> __host__ __device__ constexpr int batch_of() { return sizeof(T) == 2 ? 2 : 1; }
 
-template <class T, int ACT, int VEC>
+template <class T, int ACT, int VEC, int kBatch>
 __device__ __forceinline__ void act_batch(const Args& a, const int64_t (&i0)[kBatch], const bool (&ok)[kBatch],
                                           const typename Arith<T>::type (&bias)[kBatch], bool bias_per_elem) {
     typedef typename Arith<T>::type A;
@@ -138,6 +141,7 @@ __device__ __forceinline__ void act_batch(const Args& a, const int64_t (&i0)[kBa
 template <class T, int ACT, int VEC>
 __global__ __launch_bounds__(kThreads) void bias_act_kernel(Args a) {
     typedef typename Arith<T>::type A;
+    constexpr int kBatch = batch_of<T>();
     const A alpha = A(a.alpha), gain = A(a.gain), clamp = A(a.clamp);
     const T* x = static_cast<const T*>(a.x);
     const T* b = static_cast<const T*>(a.b);
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(kThreads) void bias_act_kernel(Args a) {
             i0[t] = (ok[t] ? v : iv) * VEC;
             bias[t] = bias_per_vec ? load_as<T>(b, (unsigned(i0[t]) / a.step_b) % a.size_b) : A(0);
         }
-        act_batch<T, ACT, VEC>(a, i0, ok, bias, bias_per_elem);
+        act_batch<T, ACT, VEC, kBatch>(a, i0, ok, bias, bias_per_elem);
     }
     // ragged tail (fewer than VEC elements), one lane each
     const int64_t tail0 = nvec * VEC;
@@ -177,11 +181,10 @@ __global__ __launch_bounds__(kThreads) void bias_act_kernel(Args a) {
 // [rows = numel / step_b][step_b] and the bias is constant along a row, so blockIdx.y = row makes the bias index a
 // per-workgroup scalar -- no per-vector integer division, which otherwise costs as much as the activation itself
 // (measured on [4,128,512,512]: fp16 3.5 -> 4.8 TB/s, fp32 5.0 -> 5.7 TB/s).
-constexpr int kRowVecsPerLane = kBatch;
-
 template <class T, int ACT, int VEC>
 __global__ __launch_bounds__(kThreads) void bias_act_rows_kernel(Args a) {
     typedef typename Arith<T>::type A;
+    constexpr int kBatch = batch_of<T>(), kRowVecsPerLane = kBatch;
     const unsigned row = blockIdx.y;
     const A bv = load_as<T>(static_cast<const T*>(a.b), row % a.size_b);
     const int64_t row0 = int64_t(row) * a.step_b;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(kThreads) void bias_act_rows_kernel(Args a) {
         i0[t] = row0 + int64_t(ok[t] ? v : v0) * VEC;
         bias[t] = bv;
     }
-    act_batch<T, ACT, VEC>(a, i0, ok, bias, false);
+    act_batch<T, ACT, VEC, kBatch>(a, i0, ok, bias, false);
 }
 
 template <class T, int VEC>
@@ -211,6 +214,7 @@ int launch_act(const Args& a, int act, hipStream_t stream) {
     dim3 g((unsigned)blocks), t(kThreads);
     if (VEC > 1 && a.b && a.step_b >= 2048 && a.step_b % VEC == 0 && a.numel % a.step_b == 0 && a.numel / a.step_b <= 65535) {
         const unsigned nvec_row = a.step_b / VEC;
+        constexpr int kRowVecsPerLane = batch_of<T>();
         dim3 gr((nvec_row + kThreads * kRowVecsPerLane - 1) / (kThreads * kRowVecsPerLane), (unsigned)(a.numel / a.step_b));
         switch (act) {
 #define GNERF_CASE(A_) case A_: hipLaunchKernelGGL((bias_act_rows_kernel<T, A_, VEC>), gr, t, 0, stream, a); break;
