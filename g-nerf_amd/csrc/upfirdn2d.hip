@@ -274,6 +274,10 @@ __global__ __launch_bounds__(256) void upfirdn_fir4_kernel(UpArgs a, int tiles_x
 // output): ~20 VALU per output, input re-read factor (R+3)/R, so the kernel is HBM-bound instead of instruction-bound.
 template <class T>
 __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpArgs a, int lx_shift, int strips_x, int strips_y, int rows_per_strip) {
+#ifndef GNERF_BLUR_RB
+#define GNERF_BLUR_RB 4
+#endif
+    constexpr int RB = GNERF_BLUR_RB;                       // rows per wait (see below); 1, 2, 3, 6, 8 measured: 4 is best for fp32, 2-4 equal for fp16
     constexpr int OPL = 16 / sizeof(T), NIN = OPL + 3;
     constexpr int NLOAD = sizeof(T) == 2 ? 12 : 8;          // elements fetched per row: dwordx4 + dwordx2 (fp16) / dwordx4 x2 (fp32)
     constexpr int ND = NLOAD * sizeof(T) / 4;               // ... as dwords
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpArgs a, int lx_shi
             return __uint_as_float(raw.d[e]);
         }
     };
-    float rows[7][NIN];
+    float rows[3 + RB][NIN];
     auto unpack = [&](int iy, const Raw& raw, float (&dst)[NIN]) {
         const unsigned ok = (iy >= 0 && iy < a.in_h) ? col_ok : 0u;
 #pragma unroll
@@ -385,32 +389,32 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpArgs a, int lx_shi
                 if (ox0 + q < a.out_w) store_as<T>(yp, q, acc[q]);
         }
     };
-    // Rows are processed in BLOCKS OF FOUR.  On this hardware loads and stores share one counter (vmcnt), and with both
+    // Rows are processed in BLOCKS OF RB = FOUR.  On this hardware loads and stores share one counter (vmcnt), and with both
     // kinds pending a wait for the loads also waits for every earlier store to be acknowledged; with one row per wait the
     // kernel ran at 3 TB/s no matter how the arithmetic or the prefetch was arranged (removing the stores alone doubled
     // its speed).  So: one wait per block -- it drains the previous block's four stores and this block's four row loads,
     // which were both in flight during the previous block's arithmetic -- then the next block's loads are issued, then
     // four output rows are made and stored.  rows[0..2] are the last three input rows of the previous block.
     const int iy_first = oy0 - a.pady0;
-    Raw raw[4];
+    Raw raw[RB < 3 ? 3 : RB];
 #pragma unroll
     for (int u = 0; u < 3; u++) fetch(iy_first + u, raw[u]);
 #pragma unroll
     for (int u = 0; u < 3; u++) unpack(iy_first + u, raw[u], rows[u]);
 #pragma unroll
-    for (int u = 0; u < 4; u++) fetch(iy_first + 3 + u, raw[u]);
+    for (int u = 0; u < RB; u++) fetch(iy_first + 3 + u, raw[u]);
     const int rows_here = min(rows_per_strip, a.out_h - oy0);
-    for (int r0 = 0; r0 < rows_here; r0 += 4) {
+    for (int r0 = 0; r0 < rows_here; r0 += RB) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) unpack(iy_first + 3 + r0 + u, raw[u], rows[3 + u]);
+        for (int u = 0; u < RB; u++) unpack(iy_first + 3 + r0 + u, raw[u], rows[3 + u]);
 #pragma unroll
-        for (int u = 0; u < 4; u++) fetch(iy_first + 7 + r0 + u, raw[u]);
+        for (int u = 0; u < RB; u++) fetch(iy_first + 3 + RB + r0 + u, raw[u]);
 #pragma unroll
-        for (int u = 0; u < 4; u++) emit(oy0 + r0 + u, rows[u], rows[u + 1], rows[u + 2], rows[u + 3]);
+        for (int u = 0; u < RB; u++) emit(oy0 + r0 + u, rows[u], rows[u + 1], rows[u + 2], rows[u + 3]);
 #pragma unroll
         for (int u = 0; u < 3; u++) {
 #pragma unroll
-            for (int e = 0; e < NIN; e++) rows[u][e] = rows[4 + u][e];
+            for (int e = 0; e < NIN; e++) rows[u][e] = rows[RB + u][e];
         }
     }
 }
