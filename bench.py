@@ -33,11 +33,105 @@ import torch  # noqa: E402
 N_ITEMS, RES, S_COARSE, S_FINE, PLANE = 4, 128, 48, 48, 256
 RAY_START, RAY_END, BOX_WARP = 2.25, 3.3, 1.0
 
-# Algorithmic work per ray (DESIGN.md "Roofline accounting")
+# Algorithmic work per ray (DESIGN.md section 4 "Roofline accounting")
 FLOP_MLP_PER_SAMPLE = 2 * 32 * 64 + 2 * 64 * 33           # 8320, the MFMA-eligible contraction
 GATHER_BYTES_PER_SAMPLE = 12 * 32 * 4                     # 12 bilinear taps x 32 fp32 channels (cache-level traffic)
 PEAK_FP32_MFMA_TFLOPS = 157.3                             # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
+PEAK_F16_MFMA_TFLOPS = 2500.0                             # dense f16/bf16 matrix peak
 PEAK_HBM_GBS = 8000.0
+PEAK_L2_GBS = 34500.0                                     # aggregate L2 read bandwidth (MI355X_MICROARCH.md)
+N_SIMD, CLOCK_HZ = 1024, 2.4e9
+# vector-instruction ISSUE cost on one SIMD (MI355X_MICROARCH.md, cycle-constants table): plain VALU 4 cycles, transcendentals
+# (v_exp / v_log / v_rcp) 8, an MFMA holds the issue port for 8 of its 16
+CYC_VALU, CYC_TRANS, CYC_MFMA = 4, 8, 8
+
+
+def algorithmic_valu_per_ray(s=48, f=48):
+    """Vector instructions a PERFECT schedule of this algorithm needs per ray, as (plain lane-ops, transcendental lane-ops,
+    MFMA wave-instructions): every lane useful, no address/staging/LDS-handoff overhead, nothing recomputed.  This is the
+    numerator of roofline.frac (bound = VALU issue); DESIGN.md section 4 carries the same table."""
+    n = s + f
+    per_sample_plain = (
+        6                       # position o + t d (3 fma) and the box scale (3 mul)
+        + 3 * 32                # per plane: pixel coordinates 2, floor 2, fractions 4, four tap weights 4, zero-padding masks 8,
+                                #   integer coordinates + clamps 8, tap addresses 4
+        + 12 * 32               # the blend: 12 taps x 32 channels, one FMA each
+        + 48                    # hi/lo f16 split of the 32 features (1.5 instructions per value)
+        + 64 * 3                # softplus of the 64 hidden units: clamp, add, max around its exp2 / log2
+        + 64                    # density row: 64 FMAs (a 33rd MFMA column would cost a third more matrix instructions)
+        + 96                    # hi/lo split of the 64 activations
+        + 32 * 2                # sigmoid of the 32 colours: add, fma around its exp2 / rcp
+        + 32)                   # composite: one FMA per channel
+    per_sample_trans = 64 * 2 + 32 * 2
+    intervals = (s - 1) + (n - 1)                       # coarse march + final march (ray_marcher.py:26-42)
+    per_ray_plain = intervals * 30 + (f * 24 + 300) + (n * 12 + f * 10) + s * 4 + 64     # marches, importance, merge, proposals, outputs
+    per_ray_trans = intervals * 3                       # softplus (exp2, log2) and exp of every interval
+    mfma = 24 * ((s + 15) // 16 + (f + 15) // 16)       # 24 v_mfma_f32_16x16x32_f16 per 16-sample tile
+    return per_sample_plain * n + per_ray_plain, per_sample_trans * n + per_ray_trans, mfma
+
+
+def roofline(kernel_ms, rays, s, f, plane, n_items, pmc=None, pmc_source=None, traffic=None):
+    """The `roofline` object of the result line for the render kernel at `kernel_ms` per launch.  `pmc`: mean counters per
+    launch from a committed rocprofv3 pass of this same command (profiles/rNN_final*_pmc.json; tools/prof_forward.sh)."""
+    k_s = kernel_ms * 1e-3
+    samples = rays * (s + f)
+    flops = samples * FLOP_MLP_PER_SAMPLE
+    plain, trans, mfma = algorithmic_valu_per_ray(s, f)
+    alg_cycles_per_ray = plain / 64 * CYC_VALU + trans / 64 * CYC_TRANS + mfma * CYC_MFMA
+    alg_floor_ms = alg_cycles_per_ray * rays / (N_SIMD * CLOCK_HZ) * 1e3
+    out = {
+        'kernel': 'render_kernel_pipe<1, f16x3>', 'bound': 'valu_issue',
+        # achieved = algorithmic vector-issue cycles retired per second; peak = issue cycles the chip has per second
+        'achieved': alg_cycles_per_ray * rays / k_s / 1e9, 'peak': N_SIMD * CLOCK_HZ / 1e9, 'unit': 'G SIMD issue cycles/s',
+        'frac': alg_floor_ms / kernel_ms, 'traffic': traffic, 'kernel_ms': kernel_ms,
+        'algorithmic_valu_floor': {
+            'plain_lane_ops_per_ray': plain, 'transcendental_lane_ops_per_ray': trans, 'mfma_per_ray': mfma,
+            'issue_cycles_per_ray': alg_cycles_per_ray, 'floor_ms': alg_floor_ms, 'frac': alg_floor_ms / kernel_ms,
+            'pricing': f'{CYC_VALU} cycles per wave64 VALU instruction, {CYC_TRANS} per transcendental, {CYC_MFMA} of issue per MFMA; '
+                       f'{N_SIMD} SIMDs at {CLOCK_HZ / 1e9} GHz'},
+        'fp32_matrix_yardstick': {'TFLOPs': flops / k_s / 1e12, 'peak_TFLOPs': PEAK_FP32_MFMA_TFLOPS, 'frac': flops / k_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                  'note': 'algorithmic MLP FLOPs (8320 per sample) / kernel time against the fp32-input MFMA peak: a speed yardstick '
+                                          '(the results are fp32-grade), NOT utilisation of a pipe the kernel uses'},
+        'executed_f16_mfma': {'TFLOPs': 3 * samples * (2 * 32 * 64 + 2 * 64 * 32) / k_s / 1e12, 'peak_TFLOPs': PEAK_F16_MFMA_TFLOPS,
+                              'frac': 3 * samples * (2 * 32 * 64 + 2 * 64 * 32) / k_s / 1e12 / PEAK_F16_MFMA_TFLOPS},
+        'hbm': {'algorithmic_bytes_per_launch': hbm_bytes_per_call(n_items, rays, s, f, plane),
+                'algorithmic_GBs': hbm_bytes_per_call(n_items, rays, s, f, plane) / k_s / 1e9,
+                'frac_of_8TBs': hbm_bytes_per_call(n_items, rays, s, f, plane) / k_s / 1e9 / PEAK_HBM_GBS},
+        'l2_gather': {'algorithmic_bytes_per_launch': samples * GATHER_BYTES_PER_SAMPLE,
+                      'algorithmic_GBs': samples * GATHER_BYTES_PER_SAMPLE / k_s / 1e9,
+                      'algorithmic_frac_of_34_5TBs': samples * GATHER_BYTES_PER_SAMPLE / k_s / 1e9 / PEAK_L2_GBS},
+        'note': 'The kernel is bound by vector-instruction issue (PMC: VALU busy ~65 % of SIMD cycles, MFMA pipe ~10 %, L2 hit 98 %, HBM 2.5 % '
+                'of peak).  frac = issue time of the instructions a perfect schedule of the algorithm needs / measured kernel time; '
+                'measured_issue (below) prices the instructions the kernel actually executes the same way.',
+    }
+    if pmc:
+        valu, n_mfma = pmc.get('SQ_INSTS_VALU'), pmc.get('SQ_INSTS_MFMA')
+        trans_exec = trans / 64 * rays                     # the transcendentals are all algorithmic; the rest is counted plain
+        if valu and n_mfma:
+            cyc = (valu - trans_exec) * CYC_VALU + trans_exec * CYC_TRANS + n_mfma * CYC_MFMA
+            floor_ms = cyc / (N_SIMD * CLOCK_HZ) * 1e3
+            out['measured_issue'] = {'source': pmc_source, 'insts_valu_per_ray': valu / rays, 'insts_mfma_per_ray': n_mfma / rays,
+                                     'issue_floor_ms': floor_ms, 'frac_of_issue_floor': floor_ms / kernel_ms,
+                                     'algorithmic_over_executed_valu': (plain + trans) / 64 * rays / valu}
+        if pmc.get('TCP_TCC_READ_REQ_sum'):
+            b = pmc['TCP_TCC_READ_REQ_sum'] * 128
+            out['l2_gather'].update({'counter_bytes_per_launch': b, 'counter_GBs': b / k_s / 1e9, 'counter_frac_of_34_5TBs': b / k_s / 1e9 / PEAK_L2_GBS,
+                                     'source': pmc_source + ' TCP_TCC_READ_REQ x 128 B'})
+        if pmc.get('SQ_LDS_BANK_CONFLICT') and pmc.get('SQ_ACTIVE_INST_LDS'):
+            out['lds_conflict_over_active'] = pmc['SQ_LDS_BANK_CONFLICT'] / pmc['SQ_ACTIVE_INST_LDS']
+    return out
+
+
+def latest_pmc():
+    """(counters, 'profiles/<file>') of the latest committed PMC pass of this command, or (None, None)."""
+    import re
+    pdir = os.path.join(ROOT, 'profiles')
+    try:
+        named = [(re.fullmatch(r'r(\d+)_final(\d*)_pmc\.json', f), f) for f in os.listdir(pdir)]
+        latest = sorted((int(m.group(1)), int(m.group(2) or 0), f) for m, f in named if m)[-1][2]
+        return json.load(open(os.path.join(pdir, latest)))['counters_mean_per_launch'], 'profiles/' + latest
+    except Exception:
+        return None, None
 
 
 def hbm_bytes_per_call(n_items, rays, s, f, plane):
@@ -94,9 +188,11 @@ def cpu_baseline(seconds_budget=30.0):
         if time.time() - t_all > seconds_budget:
             break
     timed = sorted(times[1:] or times)
-    return {'value': rays / timed[len(timed) // 2], 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+    return {'value': rays / timed[len(timed) // 2], 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'host_cpu_count': os.cpu_count(),
+            'kind': 'port',
             'sample': f'config 2 whole batch ({rays} rays, 48+48 samples, 4x3x32x256x256 planes); median of {len(timed)} '
-                      f'pass(es) after 1 warm-up, torch {torch.__version__} CPU fp32, {torch.get_num_threads()} threads'}
+                      f'pass(es) after 1 warm-up, torch {torch.__version__} CPU fp32, {torch.get_num_threads()} threads used of '
+                      f'os.cpu_count() = {os.cpu_count()} (beyond ~32 threads the bandwidth-bound gather ops get slower)'}
 
 
 def gen_videos_secondary(rank, world, dev, n_frames=240):
@@ -143,6 +239,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--reps', type=int, default=5, help='repetitions of the timed K-step region (the median is reported)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the gen_videos frames/sec measurement')
     args = ap.parse_args()
@@ -169,16 +266,16 @@ def main():
     rays_per_call = N_ITEMS * RES * RES
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    def step(i=None):
+    def step(i=None, mlp='auto'):
         o, d = gnerf_hip.make_rays(c2w, intr, RES)
-        nhwc = gnerf_hip.planes_to_nhwc(planes)
+        nhwc, amax = gnerf_hip.planes_to_nhwc(planes, with_absmax=True)       # max |planes| rides on the repack: it picks the decoder arithmetic
         noise_c = torch.rand([N_ITEMS, RES * RES, S_COARSE, 1], device=dev)
         noise_f = torch.rand(N_ITEMS * RES * RES, S_FINE, device=dev)
         if i is not None:
             ev[i][0].record()
         out = gnerf_hip.render_forward(nhwc, N_ITEMS, dec, o, d, noise_c, noise_f, depth_resolution=S_COARSE,
                                        depth_resolution_importance=S_FINE, ray_start=RAY_START, ray_end=RAY_END,
-                                       box_warp=BOX_WARP, image_width=RES)
+                                       box_warp=BOX_WARP, image_width=RES, planes_absmax=amax, mlp=mlp)
         if i is not None:
             ev[i][1].record()
         return out
@@ -187,25 +284,41 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def timed_region(mlp='auto'):
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; (max-over-ranks seconds, mean render ms by HIP events)."""
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = step(i, mlp)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = gnerf_harness.max_over_ranks(time.perf_counter() - t0, dev)
+        assert torch.isfinite(out[0]).all()
+        return elapsed, sum(a.elapsed_time(b) for a, b in ev) / args.steps      # events sit on the launch stream around the render call
+
     for _ in range(args.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = gnerf_harness.max_over_ranks(elapsed, dev)
-    assert torch.isfinite(out[0]).all()
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps      # render_kernel (+2 one-block helpers), same stream
+        step()
+    regions = sorted(timed_region() for _ in range(max(1, args.reps)))          # by elapsed time
+    elapsed, kernel_ms = regions[len(regions) // 2]                              # the median repetition is the one reported
+    assert gnerf_hip.last_mlp_choice(dev) == 'f16x3', 'config 2 is inside the f16 hi/lo range: the device-side choice must pick it'
+    # render-call time of each shipped decoder arithmetic when forced (auto = select kernel + both launches, one of which returns at once)
+    kernel_ms_by_mlp = {'auto': kernel_ms}
+    for mlp in ('f16x3', 'f32'):
+        step(None, mlp)
+        kernel_ms_by_mlp[mlp] = sorted(timed_region(mlp)[1] for _ in range(3))[1]
+    per_rank_ms = [kernel_ms]
+    if world > 1:
+        t = torch.tensor([kernel_ms], device=dev)
+        allk = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allk, t)
+        per_rank_ms = [float(x) for x in allk]
 
     secondary = None
     if not args.no_secondary:
         try:
-            del planes, out
+            del planes
             torch.cuda.empty_cache()
             secondary = gen_videos_secondary(rank, world, dev)
         except Exception as e:                                           # never lose the headline line to the secondary metric
@@ -213,53 +326,30 @@ def main():
 
     if rank == 0:
         total_rays = rays_per_call * args.steps * world
-        samples = rays_per_call * (S_COARSE + S_FINE)
-        flops = samples * FLOP_MLP_PER_SAMPLE
-        k_s = kernel_ms * 1e-3
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.isfile(tpath):
             traffic = json.load(open(tpath)).get('render_kernel_hbm_bytes_per_launch')
-        # what the kernel is actually short of: vector-instruction issue slots.  From the committed PMC pass of this same command
-        # (profiles/*_pmc.json, SQ_INSTS_VALU / SQ_INSTS_MFMA per launch): a wave64 VALU instruction holds its SIMD's issue port for
-        # 4 cycles and an MFMA for 8 (MI355X_MICROARCH.md, per-instruction constants), 1024 SIMDs at 2.4 GHz.
-        issue = None
-        try:
-            import re
-            pdir = os.path.join(ROOT, 'profiles')
-            named = [(re.fullmatch(r'r(\d+)_final(\d*)_pmc\.json', f), f) for f in os.listdir(pdir)]
-            latest = sorted((int(m.group(1)), int(m.group(2) or 0), f) for m, f in named if m)[-1][2]          # latest round, latest pass
-            c = json.load(open(os.path.join(pdir, latest)))['counters_mean_per_launch']
-            floor_ms = (c['SQ_INSTS_VALU'] * 4 + c['SQ_INSTS_MFMA'] * 8) / (1024 * 2.4e9) * 1e3
-            issue = {'source': 'profiles/' + latest, 'insts_valu_per_launch': c['SQ_INSTS_VALU'], 'insts_mfma_per_launch': c['SQ_INSTS_MFMA'],
-                     'issue_floor_ms': floor_ms, 'frac_of_issue_floor': floor_ms / kernel_ms}
-        except Exception:
-            issue = None
+        pmc, pmc_source = latest_pmc()
+        roof = roofline(kernel_ms_by_mlp['f16x3'], rays_per_call, S_COARSE, S_FINE, PLANE, N_ITEMS, pmc, pmc_source, traffic)
+        roof['render_call_ms'] = kernel_ms_by_mlp
+        roof['render_call_ms_note'] = ('HIP events around the render call inside timed regions: auto = what the headline runs (device-side choice: '
+                                       'mlp_select + both precisions launched, the unchosen one returns at once; it picks f16x3 here), f16x3 / f32 = '
+                                       'that arithmetic forced; each includes the depth-clamp epilogue')
+        roof['render_call_ms_per_rank'] = per_rank_ms
         line = {
             'metric': 'rays/sec at 128^2 neural render, 96 depth samples',
             'value': total_rays / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (MLP products as compensated f16 hi/lo splits on MFMA, fp32 accumulate)', 'data': 'synthetic',
+            'dtype': 'f32 (MLP products as compensated f16 hi/lo splits on MFMA, fp32 accumulate; exact-fp32 MFMA when the device-side range '
+                     'check says so)', 'data': 'synthetic',
+            'repetitions': {'n': len(regions), 'reported': 'median', 'ms_per_step_all': [1e3 * e / args.steps for e, _ in regions],
+                            'value_min': total_rays / regions[-1][0], 'value_max': total_rays / regions[0][0],
+                            'spread_frac': (regions[-1][0] - regions[0][0]) / elapsed},
             'config': {'workload': 'config 2: renderer-only, 128x128 rays x (48+48) samples, 3x32x256x256 fp32 tri-planes, batch 4 per GPU; '
-                                   'step = make_rays + NCHW->NHWC planes + 2 torch.rand draws + fused render kernel',
+                                   'step = make_rays + NCHW->NHWC planes (+ max|planes|) + 2 torch.rand draws + decoder-arithmetic choice + fused render kernel',
                        'rays_per_step_per_gpu': rays_per_call, 'parallelism': f'rays sharded over {world} GPU(s), no data-path collective'},
-            'roofline': {
-                'kernel': 'render_kernel_pipe', 'bound': 'mfma',
-                'achieved': flops / k_s / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': flops / k_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
-                'kernel_ms': kernel_ms, 'vector_issue': issue,
-                'note': 'achieved = ALGORITHMIC MLP work (8320 FLOP/sample x 96 samples/ray) / render-kernel time, priced against the '
-                        'fp32 matrix peak because the results are fp32-grade.  The kernel evaluates each product as an error-compensated '
-                        'hi/lo split on v_mfma_f32_16x16x32_f16 (3 MFMAs per product, fp32 accumulate; pixel MSE vs the reference ~1e-13), '
-                        'which is why it can exceed what the fp32-input MFMA alone allows; rocprof PMC (profiles/r01_final4_pmc.json) shows the kernel '
-                        'is VALU-issue bound (SQ_ACTIVE_INST_VALU ~65 % of SIMD cycles, MFMA pipe ~10 %), not HBM-bound (430 FLOP/B)',
-                'executed_f16_mfma_TFLOPs': 3 * samples * (2 * 32 * 64 + 2 * 64 * 32) / k_s / 1e12,
-                'executed_frac_of_f16_peak_2500': 3 * samples * (2 * 32 * 64 + 2 * 64 * 32) / k_s / 1e12 / 2500.0,
-                'hbm_algorithmic_GBs': hbm_bytes_per_call(N_ITEMS, rays_per_call, S_COARSE, S_FINE, PLANE) / k_s / 1e9,
-                'hbm_frac_of_8TBs': hbm_bytes_per_call(N_ITEMS, rays_per_call, S_COARSE, S_FINE, PLANE) / k_s / 1e9 / PEAK_HBM_GBS,
-                'effective_gather_GBs': samples * GATHER_BYTES_PER_SAMPLE / k_s / 1e9,
-                'effective_gather_frac_of_8TBs': samples * GATHER_BYTES_PER_SAMPLE / k_s / 1e9 / PEAK_HBM_GBS,
-            },
+            'roofline': roof,
         }
         line['secondary'] = secondary
         if not args.no_cpu_baseline and world == 1:

@@ -8,6 +8,7 @@ out="$here/../gnerf_hip/libgnerf_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$root/include -I$here -Wall -Wno-unused-function ${GNERF_EXTRA_FLAGS:-}"
 objs=()
+pids=()
 for src in capi bias_act upfirdn2d filtered_lrelu filtered_lrelu_fused grid_sample planes render; do
     [ -f "$here/$src.hip" ] || continue
     obj="$here/$src.o"
@@ -18,10 +19,15 @@ for src in capi bias_act upfirdn2d filtered_lrelu filtered_lrelu_fused grid_samp
     done
     if [ "$stale" = 1 ]; then
         echo "[build] $src.hip"
+        rm -f "$obj"                     # a failed compile must not leave a stale object for the link
         $HIPCC $FLAGS -c "$here/$src.hip" -o "$obj" &
+        pids+=($!)
     fi
     objs+=("$obj")
 done
-wait
+# a bare `wait` returns 0 whatever the children did: wait for each compile and stop at the first failure
+for pid in "${pids[@]}"; do
+    wait "$pid" || { echo "[build] a compile failed" >&2; exit 1; }
+done
 $HIPCC -shared -fPIC --offload-arch=gfx950 "${objs[@]}" -o "$out"
 echo "[build] $out"

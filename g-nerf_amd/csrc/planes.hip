@@ -15,8 +15,18 @@ using namespace gnerf;
 
 constexpr int CT = 32, PT = 64;   // channel x pixel tile
 
+// max |x| as an unsigned compare of the sign-stripped bits: orders like the floats for finite values and +inf, and any
+// NaN compares above +inf, so a NaN in the input survives as a NaN in the result.
+__device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ void publish_absmax(unsigned m, unsigned* out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
+}
+
+template <bool STATS>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                           int c, int64_t hw, int tiles_p, int tiles_c) {
+                                                           int c, int64_t hw, int tiles_p, int tiles_c, unsigned* absmax) {
     __shared__ float tile[CT][PT + 1];
     int64_t t = blockIdx.x;
     const int tp = int(t % tiles_p); t /= tiles_p;
@@ -26,17 +36,32 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     const int c0 = tc * CT;
     const float* s = src + plane * c * hw;
     float* d = dst + plane * hw * c;
+    unsigned amax = 0u;
     for (int e = threadIdx.x; e < CT * PT; e += 256) {
         const int ch = e / PT, px = e % PT;
         float v = 0.f;
         if (c0 + ch < c && p0 + px < hw) v = s[int64_t(c0 + ch) * hw + p0 + px];
         tile[ch][px] = v;
+        if (STATS) amax = max(amax, abs_bits(v));
     }
     __syncthreads();
     for (int e = threadIdx.x; e < CT * PT; e += 256) {
         const int px = e / CT, ch = e % CT;
         if (c0 + ch < c && p0 + px < hw) d[(p0 + px) * c + c0 + ch] = tile[ch][px];
     }
+    if (STATS) publish_absmax(amax, absmax);
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t numel, unsigned* absmax) {
+    unsigned amax = 0u;
+    const int64_t n4 = numel >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n4; i += int64_t(gridDim.x) * 256) {
+        const float4 v = x4[i];
+        amax = max(max(amax, abs_bits(v.x)), max(max(abs_bits(v.y), abs_bits(v.z)), abs_bits(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (numel & 3)) amax = max(amax, abs_bits(x[(n4 << 2) + threadIdx.x]));
+    publish_absmax(amax, absmax);
 }
 
 // The inverse layout change, for the gradient of the planes: [plane, y, x, channel] -> [plane, channel, y, x].
@@ -108,18 +133,47 @@ __global__ __launch_bounds__(256) void make_rays_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" int gnerf_planes_to_nhwc(const float* planes_nchw, float* planes_nhwc, int np, int c, int h, int w,
-                                    gnerf_stream_t stream) {
+static int planes_to_nhwc_impl(const float* planes_nchw, float* planes_nhwc, int np, int c, int h, int w, float* absmax, bool stats,
+                               gnerf_stream_t stream) {
     using namespace gnerf;
-    if (!planes_nchw || !planes_nhwc) return fail(GNERF_E_ARG, "planes_to_nhwc: null pointer");
+    if (!planes_nchw || !planes_nhwc || (stats && !absmax)) return fail(GNERF_E_ARG, "planes_to_nhwc: null pointer");
     if (np < 1 || c < 1 || h < 1 || w < 1) return fail(GNERF_E_ARG, "planes_to_nhwc: empty tensor");
     const int64_t hw = int64_t(h) * w;
     const int tiles_p = int((hw + PT - 1) / PT), tiles_c = (c + CT - 1) / CT;
     const int64_t blocks = int64_t(tiles_p) * tiles_c * np;
     if (blocks > INT32_MAX) return fail(GNERF_E_ARG, "planes_to_nhwc: tensor too large");
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
-                       planes_nchw, planes_nhwc, c, hw, tiles_p, tiles_c);
+    if (stats) {
+        if (hipMemsetAsync(absmax, 0, sizeof(float), as_stream(stream)) != hipSuccess) return fail(GNERF_E_LAUNCH, "planes_to_nhwc: memset failed");
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                           planes_nchw, planes_nhwc, c, hw, tiles_p, tiles_c, reinterpret_cast<unsigned*>(absmax));
+    } else {
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                           planes_nchw, planes_nhwc, c, hw, tiles_p, tiles_c, static_cast<unsigned*>(nullptr));
+    }
     return check_launch("planes_to_nhwc");
+}
+
+extern "C" int gnerf_planes_to_nhwc(const float* planes_nchw, float* planes_nhwc, int np, int c, int h, int w,
+                                    gnerf_stream_t stream) {
+    return planes_to_nhwc_impl(planes_nchw, planes_nhwc, np, c, h, w, nullptr, false, stream);
+}
+
+extern "C" int gnerf_planes_to_nhwc_stats(const float* planes_nchw, float* planes_nhwc, int np, int c, int h, int w,
+                                          float* absmax, gnerf_stream_t stream) {
+    return planes_to_nhwc_impl(planes_nchw, planes_nhwc, np, c, h, w, absmax, true, stream);
+}
+
+extern "C" int gnerf_planes_absmax(const float* planes, int64_t numel, float* absmax, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!planes || !absmax) return fail(GNERF_E_ARG, "planes_absmax: null pointer");
+    if (numel < 1) return fail(GNERF_E_ARG, "planes_absmax: empty tensor");
+    if (reinterpret_cast<uintptr_t>(planes) & 15) return fail(GNERF_E_ARG, "planes_absmax: planes must be 16-byte aligned");
+    if (hipMemsetAsync(absmax, 0, sizeof(float), as_stream(stream)) != hipSuccess) return fail(GNERF_E_LAUNCH, "planes_absmax: memset failed");
+    int64_t blocks = (numel / 4 + 255) / 256;
+    if (blocks > kNumCU * 16) blocks = kNumCU * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), planes, numel, reinterpret_cast<unsigned*>(absmax));
+    return check_launch("planes_absmax");
 }
 
 extern "C" int gnerf_planes_from_nhwc(const float* planes_nhwc, float* planes_nchw, int np, int c, int h, int w,

@@ -56,6 +56,7 @@ struct Params {
     int tiles_per_item, tiles_y;   // image tiling (0 when rays are not an image)
     int total_rays;
     int split_shift;        // small launches: a 16-ray tile is shared by 1 << split_shift workgroups (coop / generic kernels)
+    const int* mlp_flag;    // GNERF_MLP_AUTO: device word holding the chosen decoder arithmetic (kMlpF16x3 / kMlpF32); NULL = run
 };
 
 // ---- order-preserving float <-> uint so that integer atomics give float min/max
@@ -632,6 +633,66 @@ __global__ __launch_bounds__(64) void query_kernel(gnerf_render_params p, float 
 #include "render_pipe.inl"
 #include "render_bwd.inl"
 
+// ---- GNERF_MLP_AUTO: which decoder arithmetic may this call use?  (one 64-lane workgroup, a few hundred loads)
+// The f16 hi/lo split (render_coop.inl) represents an operand v as hi + lo with |v - hi - lo| <= max(2^-22 |v|, 2^-25): fp32-grade
+// for operands well inside f16's range, but an ABSOLUTE 2^-25 per operand once the low half goes subnormal, and inf/NaN once the high
+// half overflows.  With A = max |planes| (the features are convex combinations of texels, so |x| <= A), W1' = log2(e) W1 and the
+// row norms R1 = max_r ||W1'[r,:]||_2, R2 = max_r ||W2[r,:]||_2 the decision is
+//   no overflow (hard bounds):  A, max |W1'|, max |W2|, and  max_r ||W1'[r,:]||_1 A + max |b1'| + 1  (>= every hidden activation) <= 30000
+//   accuracy (random-sign error model, the same one that gives the fp32 reference its ~2^-24 sqrt(n) behaviour):
+//     e_p = 2^-22 R1 A + 2^-25 (R1 + sqrt(32) A)                       error of a layer-1 pre-activation (base-2 scaled)
+//     h   = R1 A + max |b1'| + 1                                        scale of the hidden activations
+//     e_o = R2 e_p + 2^-22 R2 h + 2^-25 (R2 + 8 h)                      error of a layer-2 output
+//   f16x3 iff e_o <= 2^-12: |d rgb| <= 0.25 ln2 e_o = 4e-5 in the worst case (pixel MSE < 2e-9), typically 1e-3 of that.
+// Anything else -- including NaN/inf anywhere in the operands -- takes the exact-fp32 kernels.  BASELINE config 2 (randn planes,
+// default-init decoder) has e_o = 1.1e-5; planes scaled by ~20 or decoder weights by ~5 cross over to fp32.
+constexpr float kMlpRangeLimit = 30000.f;
+constexpr float kMlpErrLimit = 1.0f / 4096.f;
+__global__ __launch_bounds__(64) void mlp_select_kernel(gnerf_render_params p, const float* absmax, int* flag) {
+    const int lane = threadIdx.x;
+    // lane r < 64: row r of W1; lane r < 33: row r of W2
+    float l1 = 0.f, sq1 = 0.f, mx1 = 0.f;
+    for (int c = 0; c < 32; c++) { const float w = fabsf(p.w1[lane * 32 + c]) * kLog2e; l1 += w; sq1 += w * w; mx1 = fmaxf(mx1, w); }
+    float sq2 = 0.f, mx2 = 0.f;
+    if (lane < 33) for (int c = 0; c < 64; c++) { const float w = fabsf(p.w2[lane * 64 + c]); sq2 += w * w; mx2 = fmaxf(mx2, w); }
+    float mb1 = fabsf(p.b1[lane]) * kLog2e;
+    float mb2 = lane < 33 ? fabsf(p.b2[lane]) * kLog2e : 0.f;
+    // NaN-propagating maxima: fmaxf drops NaNs, so carry "anything not finite" separately
+    bool bad = !(l1 < INFINITY) || !(sq2 < INFINITY) || !(mb1 < INFINITY) || !(mb2 < INFINITY);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        l1 = fmaxf(l1, __shfl_xor(l1, o)); sq1 = fmaxf(sq1, __shfl_xor(sq1, o)); mx1 = fmaxf(mx1, __shfl_xor(mx1, o));
+        sq2 = fmaxf(sq2, __shfl_xor(sq2, o)); mx2 = fmaxf(mx2, __shfl_xor(mx2, o));
+        mb1 = fmaxf(mb1, __shfl_xor(mb1, o)); mb2 = fmaxf(mb2, __shfl_xor(mb2, o));
+    }
+    bad = __any(bad);
+    if (lane == 0) {
+        const float A = *absmax;
+        const float R1 = sqrtf(sq1), R2 = sqrtf(sq2);
+        const float h_hard = l1 * A + mb1 + 1.f;
+        const float e_p = 0x1p-22f * R1 * A + 0x1p-25f * (R1 + 5.657f * A);
+        const float h = R1 * A + mb1 + 1.f;
+        const float e_o = R2 * e_p + 0x1p-22f * R2 * h + 0x1p-25f * (R2 + 8.f * h);
+        const bool ok = !bad && A <= kMlpRangeLimit && mx1 <= kMlpRangeLimit && mx2 <= kMlpRangeLimit && h_hard <= kMlpRangeLimit
+                        && mb2 <= kMlpRangeLimit && e_o <= kMlpErrLimit;         // every comparison is false for NaN
+        *flag = ok ? kMlpF16x3 : kMlpF32;
+    }
+}
+
+// hipFuncSetAttribute is per device: remember which devices of this process have had a kernel's dynamic-LDS limit raised
+struct PerDeviceOnce {
+    bool done[64] = {};
+    template <class K> int raise_lds(K kernel, const char* what) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+        if (dev >= 0 && done[dev]) return GNERF_OK;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return fail(GNERF_E_LAUNCH, "%s: cannot raise the dynamic LDS limit", what);
+        if (dev >= 0) done[dev] = true;
+        return GNERF_OK;
+    }
+};
+
 int check_common(const gnerf_render_params* p) {
     if (!p) return fail(GNERF_E_ARG, "render: params is null");
     if (!p->planes_nhwc || !p->w1 || !p->b1 || !p->w2 || !p->b2) return fail(GNERF_E_ARG, "render: planes and decoder weights must not be null");
@@ -671,6 +732,7 @@ static int fill_params(const gnerf_render_params* p, Params& P) {
     P.tiles_f = (F + 15) / 16;
     P.total_rays = int(total);
     P.split_shift = 0;
+    P.mlp_flag = nullptr;
     const int iw = p->image_width;
     if (iw > 0 && iw % 4 == 0 && p->rays_per_item % iw == 0 && (p->rays_per_item / iw) % 4 == 0) {
         P.tiles_y = p->rays_per_item / iw / 4;
@@ -704,7 +766,10 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
     //   pipe    3 shader waves + 1 scalar wave, three rays in flight: up to 48+48 samples with importance sampling
     //   coop    3 waves per ray, phases separated by barriers: up to 96+96 samples
     //   generic one wave per ray: everything else (up to 256+256)
+    // A/B and test overrides, read per call (the parity tests switch kernels inside one process): two getenv walks of the
+    // environment, ~0.1 us against the ~10 us of a launch
     const char* force = getenv("GNERF_RENDER_KERNEL");
+    const char* force_mlp = getenv("GNERF_RENDER_MLP");                      // f16x3 | f32: overrides params.mlp_mode
     const bool small_planes = int64_t(p->plane_h) * p->plane_w * 3 * 128 < (int64_t(1) << 32);
     bool pipe = P.tiles_c <= 6 && P.tiles_f >= 1 && P.tiles_f <= 6 && small_planes;
     const int pipe_tp = (P.tiles_c <= 3 && P.tiles_f <= 3) ? 1 : 2;             // 16-sample tiles per shader wave and pass
@@ -712,6 +777,25 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
     if (force && !strcmp(force, "generic")) pipe = coop = false;
     if (force && !strcmp(force, "coop")) { pipe = false; if (!coop) return fail(GNERF_E_UNSUPPORTED, "render: cooperative kernel does not cover %d+%d samples", S, F); }
     if (force && !strcmp(force, "pipe") && !pipe) return fail(GNERF_E_UNSUPPORTED, "render: pipelined kernel does not cover %d+%d samples", S, F);
+    // Decoder arithmetic of the pipe / coop kernels (the generic kernel is fp32 throughout).
+    int mlp = p->mlp_mode;
+    if (force_mlp && !strcmp(force_mlp, "f16x3")) mlp = GNERF_MLP_F16X3;
+    if (force_mlp && !strcmp(force_mlp, "f32")) mlp = GNERF_MLP_F32;
+    if (mlp != GNERF_MLP_AUTO && mlp != GNERF_MLP_F16X3 && mlp != GNERF_MLP_F32) return fail(GNERF_E_ARG, "render: mlp_mode %d is not one of GNERF_MLP_*", mlp);
+    if ((pipe || coop) && mlp == GNERF_MLP_AUTO) {
+        // the choice is made on the device (no host round trip, graph-capturable): both precisions are launched and the
+        // one that was not chosen returns at once
+        int* ws_words = static_cast<int*>(p->workspace);
+        const float* absmax = p->planes_absmax;
+        if (!absmax) {
+            float* own = reinterpret_cast<float*>(ws_words + 5);
+            if (int e = gnerf_planes_absmax(p->planes_nhwc, int64_t(p->n_items) * 3 * p->plane_h * p->plane_w * 32, own, stream)) return e;
+            absmax = own;
+        }
+        hipLaunchKernelGGL(mlp_select_kernel, dim3(1), dim3(64), 0, s, *p, absmax, ws_words + 4);
+        if (int e = check_launch("mlp_select_kernel")) return e;
+        P.mlp_flag = ws_words + 4;
+    }
     if (pipe) {
         const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : total;
         // one dealing unit (8 rays) per workgroup until the chip is full: a small launch is latency-bound, and the three
@@ -720,33 +804,38 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         if (g < kNumXCD) g = kNumXCD;
         const int per_cu = pipe_tp == 1 ? GNERF_PIPE_WAVES_PER_SIMD : 2;                         // resident workgroups per CU
         if (g > per_cu * kNumCU) g = per_cu * kNumCU;
-        const size_t lds_bytes = pipe_lds_floats(pipe_tp) * sizeof(float);
-        if (pipe_tp == 1) hipLaunchKernelGGL(render_kernel_pipe<1>, dim3((unsigned)g), dim3(kPipeThreads), lds_bytes, s, P);
-        else              hipLaunchKernelGGL(render_kernel_pipe<2>, dim3((unsigned)g), dim3(kPipeThreads), lds_bytes, s, P);
-        if (int e = check_launch("render_kernel_pipe")) return e;
+        for (int m = kMlpF16x3; m <= kMlpF32; m++) {
+            if (mlp != GNERF_MLP_AUTO && mlp != m) continue;
+            const size_t lds_bytes = pipe_lds_floats(pipe_tp, m) * sizeof(float);
+            if (pipe_tp == 1 && m == kMlpF16x3) hipLaunchKernelGGL((render_kernel_pipe<1, kMlpF16x3>), dim3((unsigned)g), dim3(kPipeThreads), lds_bytes, s, P);
+            else if (pipe_tp == 1)              hipLaunchKernelGGL((render_kernel_pipe<1, kMlpF32>), dim3((unsigned)g), dim3(kPipeThreads), lds_bytes, s, P);
+            else if (m == kMlpF16x3)            hipLaunchKernelGGL((render_kernel_pipe<2, kMlpF16x3>), dim3((unsigned)g), dim3(kPipeThreads), lds_bytes, s, P);
+            else                                hipLaunchKernelGGL((render_kernel_pipe<2, kMlpF32>), dim3((unsigned)g), dim3(kPipeThreads), lds_bytes, s, P);
+            if (int e = check_launch("render_kernel_pipe")) return e;
+        }
     } else
     if (coop) {
         const int tc1 = (P.tiles_c + kCoopWaves - 1) / kCoopWaves, tf1 = (P.tiles_f + kCoopWaves - 1) / kCoopWaves;
-        const size_t lds_bytes = coop_lds_floats(16 * (P.tiles_c + P.tiles_f)) * sizeof(float);
         const dim3 block(kCoopThreads);
-#define GNERF_COOP(TC, TF) hipLaunchKernelGGL((render_kernel_coop<TC, TF>), grid, block, lds_bytes, s, P)
-        if (tc1 == 1 && tf1 == 0) GNERF_COOP(1, 0);
-        else if (tc1 == 1 && tf1 == 1) GNERF_COOP(1, 1);
-        else if (tc1 == 1 && tf1 == 2) GNERF_COOP(1, 2);
-        else if (tc1 == 2 && tf1 == 0) GNERF_COOP(2, 0);
-        else if (tc1 == 2 && tf1 == 1) GNERF_COOP(2, 1);
-        else GNERF_COOP(2, 2);
+        for (int m = kMlpF16x3; m <= kMlpF32; m++) {
+            if (mlp != GNERF_MLP_AUTO && mlp != m) continue;
+            const size_t lds_bytes = coop_lds_floats(16 * (P.tiles_c + P.tiles_f), m) * sizeof(float);
+#define GNERF_COOP(TC, TF) do { if (m == kMlpF16x3) hipLaunchKernelGGL((render_kernel_coop<TC, TF, kMlpF16x3>), grid, block, lds_bytes, s, P); \
+                                else hipLaunchKernelGGL((render_kernel_coop<TC, TF, kMlpF32>), grid, block, lds_bytes, s, P); } while (0)
+            if (tc1 == 1 && tf1 == 0) GNERF_COOP(1, 0);
+            else if (tc1 == 1 && tf1 == 1) GNERF_COOP(1, 1);
+            else if (tc1 == 1 && tf1 == 2) GNERF_COOP(1, 2);
+            else if (tc1 == 2 && tf1 == 0) GNERF_COOP(2, 0);
+            else if (tc1 == 2 && tf1 == 1) GNERF_COOP(2, 1);
+            else GNERF_COOP(2, 2);
 #undef GNERF_COOP
-        if (int e = check_launch("render_kernel_coop")) return e;
+            if (int e = check_launch("render_kernel_coop")) return e;
+        }
     } else {
         const size_t lds_bytes = scratch_floats(16 * (P.tiles_c + P.tiles_f), P.tiles_c + P.tiles_f) * sizeof(float);
         if (lds_bytes > 160 * 1024) return fail(GNERF_E_ARG, "render: %d+%d samples need %zu bytes of LDS (> 160 KiB)", S, F, lds_bytes);
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_kernel_generic), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return fail(GNERF_E_LAUNCH, "render: cannot raise the dynamic LDS limit");
-            attr_set = true;
-        }
+        static PerDeviceOnce once;
+        if (int e = once.raise_lds(render_kernel_generic, "render")) return e;
         hipLaunchKernelGGL(render_kernel_generic, grid, dim3(64), lds_bytes, s, P);
         if (int e = check_launch("render_kernel_generic")) return e;
     }
@@ -767,12 +856,8 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
     static_assert(kBwdRaysPerWave == kRaysPerWave, "ray tiles are shared with the forward launcher");
     const size_t lds_bytes = (kBwdWeightFloats + kBwdWaves * bwd_wave_floats(16 * (P.tiles_c + P.tiles_f))) * sizeof(float);
     if (lds_bytes > 160 * 1024) return fail(GNERF_E_ARG, "render_backward: %d+%d samples need %zu bytes of LDS (> 160 KiB)", p->depth_resolution, p->depth_resolution_importance, lds_bytes);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return fail(GNERF_E_LAUNCH, "render_backward: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (int e = once.raise_lds(render_bwd_kernel, "render_backward")) return e;
     const int n_blocks = (P.n_tiles + kBwdWaves - 1) / kBwdWaves;
     const int per_xcd = (n_blocks + kNumXCD - 1) / kNumXCD;
     hipLaunchKernelGGL(render_bwd_kernel, dim3(per_xcd * kNumXCD), dim3(kBwdThreads), lds_bytes, as_stream(stream), P, *g);

@@ -20,13 +20,17 @@ constexpr int kW1Pitch = 36;        // floats per LDS row of W1 [64 x 32]
 constexpr int kW2Pitch = 68;        // floats per LDS row of W2 [33 x 64]
 constexpr int kTapDwords = 24;      // per sample: 3 planes x (4 byte offsets + 4 weights)
 
-// Decoder weights in LDS.  Two formats:
-//  * default, "f16x3": every fp32 weight w is stored as two halves (hi = f16(w), lo = f16(w - hi)) in MFMA fragment
+// Decoder weights in LDS.  Two formats, BOTH shipped (template parameter MLP of the kernels; chosen per call, see
+// mlp_select_kernel in render.hip):
+//  * kMlpF16x3: every fp32 weight w is stored as two halves (hi = f16(w), lo = f16(w - hi)) in MFMA fragment
 //    order, and each product of the MLP is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with fp32
 //    accumulation (the dropped lo*lo term and the split's own rounding are ~2^-21 relative, i.e. fp32-grade: the
 //    renderer's pixel MSE against the reference stays ~1e-13).  24 matrix instructions x 16 cycles per 16-sample tile
-//    instead of 64 x 32 cycles of v_mfma_f32_16x16x4_f32.
-//  * -DGNERF_MLP_F32: plain fp32 rows (exact fp32 products on the fp32-input MFMA), the round-1 baseline.
+//    instead of 64 x 32 cycles of v_mfma_f32_16x16x4_f32.  Only valid while features, weights and hidden activations
+//    stay inside f16's range and the absolute error of the low halves (2^-25 per operand) stays negligible after the
+//    decoder's own amplification -- which is what mlp_select_kernel decides on the device, per call.
+//  * kMlpF32: plain fp32 rows (exact fp32 products on the fp32-input MFMA): any finite input.
+constexpr int kMlpF16x3 = 1, kMlpF32 = 2;          // = GNERF_MLP_F16X3 / GNERF_MLP_F32
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 constexpr float kLog2e = 1.44269504088896341f, kLn2 = 0.693147180559945309f;
 
@@ -55,11 +59,9 @@ __device__ __forceinline__ void split_f16x8(const float (&x)[8], unsigned (&hi)[
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ h8 as_h8(u4v v) { return __builtin_bit_cast(h8, v); }
 constexpr int kW1HalfPitch = 40;    // halves per LDS row of W1 hi / lo (32 + pad: conflict-free ds_read_b128)
-#ifdef GNERF_MLP_F32
-constexpr int kWeightFloats = 64 * 36 + 33 * 68;
-#else
-constexpr int kWeightFloats = (2 * 64 * kW1HalfPitch + 2 * 2048) / 2 + 64;     // W1 hi+lo, W2 hi+lo (fragment order), density row fp32
-#endif
+constexpr int kWeightFloatsF32 = 64 * 36 + 33 * 68;
+constexpr int kWeightFloatsF16 = (2 * 64 * kW1HalfPitch + 2 * 2048) / 2 + 64;  // W1 hi+lo, W2 hi+lo (fragment order), density row fp32
+__host__ __device__ constexpr int weight_floats(int mlp) { return mlp == kMlpF32 ? kWeightFloatsF32 : kWeightFloatsF16; }
 
 struct CoopLds {
     float* w1; float* w2; float* b1; float* b2;
@@ -69,8 +71,8 @@ struct CoopLds {
     float* part;     // [waves][32] colour partial sums, then [4] ray scalars
 };
 
-__host__ __device__ inline size_t coop_lds_floats(int s_pad) {
-    return size_t(kWeightFloats) + 64 + 36 + size_t(8) * s_pad +
+__host__ __device__ inline size_t coop_lds_floats(int s_pad, int mlp) {
+    return size_t(weight_floats(mlp)) + 64 + 36 + size_t(8) * s_pad +
            kCoopWaves * 16 * kTapDwords + kCoopWaves * 16 * kStagePitch + kCoopWaves * 32 + 4;
 }
 
@@ -154,13 +156,18 @@ struct Stamps { __device__ __forceinline__ void reset() {} };
 #endif
 
 // Copy the decoder into LDS (all threads of the workgroup; a barrier must follow).  base = start of the weight area.
+template <int MLP>
 __device__ __forceinline__ void stage_decoder(CoopLds& L, float* base, const gnerf_render_params& p, int tid, int nthreads) {
     L.w1 = base;
-#ifdef GNERF_MLP_F32
+    L.b1 = base + weight_floats(MLP);
+    L.b2 = L.b1 + 64;
+    if constexpr (MLP == kMlpF32) {
     L.w2 = L.w1 + 64 * kW1Pitch;
     for (int i = tid; i < 64 * 32; i += nthreads) L.w1[(i >> 5) * kW1Pitch + (i & 31)] = p.w1[i];
     for (int i = tid; i < 33 * 64; i += nthreads) L.w2[(i >> 6) * kW2Pitch + (i & 63)] = p.w2[i];
-#else
+    for (int i = tid; i < 64; i += nthreads) L.b1[i] = p.b1[i];
+    for (int i = tid; i < 33; i += nthreads) L.b2[i] = p.b2[i];
+    } else {
     _Float16* w1h = reinterpret_cast<_Float16*>(base);                 // [hi|lo][64][kW1HalfPitch]
     _Float16* w2h = w1h + 2 * 64 * kW1HalfPitch;                       // [hi|lo][n=2][s=2][j=16][g=4][8]
     L.w2 = base + (2 * 64 * kW1HalfPitch + 2 * 2048) / 2;              // density row W2[0][:] in fp32
@@ -186,16 +193,9 @@ __device__ __forceinline__ void stage_decoder(CoopLds& L, float* base, const gne
         w2h[2048 + i] = (_Float16)(x - (float)hi);
     }
     for (int i = tid; i < 64; i += nthreads) L.w2[i] = p.w2[i] * kLn2;
-#endif
-    L.b1 = base + kWeightFloats;
-    L.b2 = L.b1 + 64;
-#ifdef GNERF_MLP_F32
-    for (int i = tid; i < 64; i += nthreads) L.b1[i] = p.b1[i];
-    for (int i = tid; i < 33; i += nthreads) L.b2[i] = p.b2[i];
-#else
     for (int i = tid; i < 64; i += nthreads) L.b1[i] = p.b1[i] * kLog2e;
     for (int i = tid; i < 33; i += nthreads) L.b2[i] = i == 0 ? p.b2[0] : p.b2[i] * -kLog2e;
-#endif
+    }
 }
 
 // v + (v from lane^16) + (v from lane^32) + (v from lane^48): sum over the four 16-lane rows, result in every lane.
@@ -227,7 +227,7 @@ __device__ __forceinline__ void lds_wave_sync() {
     // load/store in flight (vmcnt(0)), serialising the scalar wave's prefetches and output stores.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
-template <bool BLOCK_SYNC>
+template <bool BLOCK_SYNC, int MLP>
 __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& L, const CoopRay& R, const float* t_list, int count,
                                                 int tile, bool active, float* sig_list, int lane, int wv, v4f (&col)[2], Stamps& st) {
 #ifdef GNERF_ABLATE_SHADE       // timing-only build: no lookups, no MLP
@@ -312,7 +312,9 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     const v4f f_lo = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g);
     const v4f f_hi = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g + 4);
     const float f[8] = {f_lo[0], f_lo[1], f_lo[2], f_lo[3], f_hi[0], f_hi[1], f_hi[2], f_hi[3]};
-#ifdef GNERF_MLP_F32
+    float sig = 0.f;
+    v4f o[2];
+    if constexpr (MLP == kMlpF32) {
     // ---- the MLP as one software-pipelined MFMA stream (64 matrix instructions back to back):
     //   L1(0) | L1(1)+SP(0) | L1(2)+SP(1) | L1(3)+SP(2) | L2(0)+SP(3) | L2(1) | L2(2) | L2(3) | sigmoid
     // L1(m): the 8 MFMAs of hidden block m (W1 rows 16m + j, columns 8g..8g+7; bias preloaded in the accumulator).
@@ -337,9 +339,8 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     load_w1(0);
     load_w1(1);
     const float bc0 = L.b2[1 + j], bc1 = L.b2[17 + j];
-    v4f o[2] = {(v4f){bc0, bc0, bc0, bc0}, (v4f){bc1, bc1, bc1, bc1}};
+    o[0] = (v4f){bc0, bc0, bc0, bc0}; o[1] = (v4f){bc1, bc1, bc1, bc1};
     v4f e, hv[4];
-    float sig = 0.f;
     auto sp_exp = [&](int m) {
 #pragma unroll
         for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(-fabsf(h[m][r]) * 1.44269504088896341f);
@@ -386,7 +387,7 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
         for (int r = 0; r < 4; r++) sig = fmaf(ws[m][r], hv[m][r], sig);
     }
 #undef GNERF_SCHED
-#else
+    } else {
     // ---- the MLP on v_mfma_f32_16x16x32_f16, every product as hi*hi + hi*lo + lo*hi with fp32 accumulation.
     // Layer 1: H^T block m [16 hidden x 16 samples] = W1 block [16 x 32] . X^T [32 x 16]: ONE k-step (K = 32 channels);
     // A = this lane's 8 weights W1[16m + j][8g..8g+7], B = its 8 staged features (channels 8g..8g+7 of sample j).
@@ -426,7 +427,6 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
 #endif
     GNERF_STAMP(st, 3);         // layer 1
     // softplus in 4-wide groups (four independent exp2/log2 chains), density row in fp32 on the VALU
-    float sig = 0.f;
     v4f hv[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) {
@@ -445,7 +445,7 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     // Layer 2: O [16 samples x 16 outs] = H [16 x 64] . W2^T: two k-steps of 32; this lane contributes, at k-step s,
     // its activations of blocks 2s and 2s+1 (weights were stored in the matching order by stage_decoder).
     const float bc0 = L.b2[1 + j], bc1 = L.b2[17 + j];
-    v4f o[2] = {(v4f){bc0, bc0, bc0, bc0}, (v4f){bc1, bc1, bc1, bc1}};
+    o[0] = (v4f){bc0, bc0, bc0, bc0}; o[1] = (v4f){bc1, bc1, bc1, bc1};
     h8 x_hi[2], x_lo[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
@@ -470,20 +470,20 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
 #pragma unroll
         for (int n = 0; n < 2; n++) o[n] = GNERF_MFMA16(x_lo[s], w_hi[n][s], o[n]);
     }
-#endif
+    }
     sig = row_sum4(sig) + L.b2[0];
     if (active && g == 0 && 16 * tile + j < count) sig_list[16 * tile + j] = sig;
     // rgb = sigmoid(o) * 1.002 - 0.001 (triplane.py:134), again in 4-wide groups
 #pragma unroll
     for (int n = 0; n < 2; n++) {
         v4f t;
-#ifdef GNERF_MLP_F32
+        if constexpr (MLP == kMlpF32) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) t[r] = __builtin_amdgcn_exp2f(o[n][r] * -1.44269504088896341f);
-#else
+            for (int r = 0; r < 4; r++) t[r] = __builtin_amdgcn_exp2f(o[n][r] * -1.44269504088896341f);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; r++) t[r] = __builtin_amdgcn_exp2f(o[n][r]);            // o already carries the -log2(e)
-#endif
+            for (int r = 0; r < 4; r++) t[r] = __builtin_amdgcn_exp2f(o[n][r]);        // o already carries the -log2(e)
+        }
 #pragma unroll
         for (int r = 0; r < 4; r++) t[r] = __builtin_amdgcn_rcpf(1.0f + t[r]);
 #pragma unroll
@@ -495,8 +495,9 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     GNERF_STAMP(st, 4);         // activations + layer 2
 }
 
-template <int TC1, int TF1>
+template <int TC1, int TF1, int MLP>
 __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) {
+    if (P.mlp_flag && *P.mlp_flag != MLP) return;       // auto mode: both precisions are launched, the device-side choice runs
     extern __shared__ __align__(16) float smem[];
     const gnerf_render_params& p = P.p;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
     const int S = p.depth_resolution, F = p.depth_resolution_importance;
     const int s_pad = 16 * (P.tiles_c + P.tiles_f);
     CoopLds L;
-    L.t_e = smem + kWeightFloats + 64 + 36;
+    L.t_e = smem + weight_floats(MLP) + 64 + 36;
     L.sig_e = L.t_e + s_pad;
     L.v_e = L.sig_e + s_pad;
     L.rank_e = reinterpret_cast<int*>(L.v_e + s_pad);
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
     const int rr_first = (group & ((1 << P.split_shift) - 1)) * (kRaysPerWave >> P.split_shift);
 
     // decoder -> LDS (padded rows), once per workgroup
-    stage_decoder(L, smem, p, tid, kCoopThreads);
+    stage_decoder<MLP>(L, smem, p, tid, kCoopThreads);
 
     const int fine_e0 = 16 * P.tiles_c;
     const int n_all = S + F;
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
 #pragma unroll
         for (int i = 0; i < TC1; i++) {
             const int t = wv + kCoopWaves * i;
-            coop_shade_tile<true>(P, L, R, L.t_e, S, t, t < P.tiles_c, L.sig_e, lane, wv, col_c[i], st);
+            coop_shade_tile<true, MLP>(P, L, R, L.t_e, S, t, t < P.tiles_c, L.sig_e, lane, wv, col_c[i], st);
         }
         __syncthreads();
         if (dbg) for (int k = tid; k < S; k += kCoopThreads) dbg[GNERF_DBG_SIGMA_COARSE * n_all + k] = L.sig_e[k];
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
 #pragma unroll
             for (int i = 0; i < TF1; i++) {
                 const int t = wv + kCoopWaves * i;
-                coop_shade_tile<true>(P, L, R, L.t_e + fine_e0, F, t, t < P.tiles_f, L.sig_e + fine_e0, lane, wv, col_f[i], st);
+                coop_shade_tile<true, MLP>(P, L, R, L.t_e + fine_e0, F, t, t < P.tiles_f, L.sig_e + fine_e0, lane, wv, col_f[i], st);
             }
             __syncthreads();
             if (dbg) for (int k = tid; k < F; k += kCoopThreads) dbg[GNERF_DBG_SIGMA_FINE * n_all + k] = L.sig_e[fine_e0 + k];

@@ -59,9 +59,9 @@ __device__ __forceinline__ PipeSlot pipe_slot(float* base, int slot) {
     return s;
 }
 
-__host__ __device__ inline size_t pipe_lds_floats(int tp) {
+__host__ __device__ inline size_t pipe_lds_floats(int tp, int mlp) {
     const size_t slot_floats = tp == 1 ? PipeDims<1>::kSlotFloats : PipeDims<2>::kSlotFloats;
-    return size_t(kWeightFloats) + 64 + 36 + size_t(kPipeSlots) * slot_floats + 3 * 16 * kTapDwords + 3 * 16 * kStagePitch;
+    return size_t(weight_floats(mlp)) + 64 + 36 + size_t(kPipeSlots) * slot_floats + 3 * 16 * kTapDwords + 3 * 16 * kStagePitch;
 }
 
 // position `seq` of the locality-ordered ray sequence -> ray index (or -1 past the end)
@@ -82,8 +82,9 @@ __device__ __forceinline__ int pipe_seq_to_ray(const Params& P, int64_t seq) {
 #ifndef GNERF_PIPE_WAVES_PER_SIMD
 #define GNERF_PIPE_WAVES_PER_SIMD 3
 #endif
-template <int TP>
+template <int TP, int MLP>
 __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD : 2) void render_kernel_pipe(Params P) {
+    if (P.mlp_flag && *P.mlp_flag != MLP) return;       // auto mode: both precisions are launched, the device-side choice runs
     typedef PipeDims<TP> D;
     constexpr int kPipeMaxS = D::kMaxS, kPipeSPad = D::kSPad, kSlotFloats = D::kSlotFloats, RND = D::kRounds;
     extern __shared__ __align__(16) float smem[];
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD :
     constexpr int fine_e0 = kPipeMaxS, s_pad = kPipeSPad;
     const int n_all = S + F;
     CoopLds L;
-    float* slots = smem + kWeightFloats + 64 + 36;
+    float* slots = smem + weight_floats(MLP) + 64 + 36;
     L.taps = slots + kPipeSlots * kSlotFloats;
     L.stage = L.taps + 3 * 16 * kTapDwords;
 
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD :
         return seq < x1 ? pipe_seq_to_ray(P, seq) : -1;
     };
 
-    stage_decoder(L, smem, p, tid, kPipeThreads);
+    stage_decoder<MLP>(L, smem, p, tid, kPipeThreads);
 
     Stamps st;
     // ------------------------------------------------------------------ scalar-wave pieces (lambdas, wave 3 only)
@@ -402,8 +403,8 @@ __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD :
         for (int i = 0; i < TP; i++) {
             const int tile = wv + 3 * i;
             if (TP > 1 && tile >= (fine ? P.tiles_f : P.tiles_c)) continue;       // wave-uniform: this wave has no such tile
-            if (!fine) coop_shade_tile<false>(P, L, R, sl.t_e, S, tile, tile < P.tiles_c, sl.sig_e, lane, wv, col[i], st);
-            else       coop_shade_tile<false>(P, L, R, sl.t_e + fine_e0, F, tile, tile < P.tiles_f, sl.sig_e + fine_e0, lane, wv, col[i], st);
+            if (!fine) coop_shade_tile<false, MLP>(P, L, R, sl.t_e, S, tile, tile < P.tiles_c, sl.sig_e, lane, wv, col[i], st);
+            else       coop_shade_tile<false, MLP>(P, L, R, sl.t_e + fine_e0, F, tile, tile < P.tiles_f, sl.sig_e + fine_e0, lane, wv, col[i], st);
         }
     };
     auto accumulate = [&](int r, const v4f (&cc)[TP][2], const v4f (&cf)[TP][2]) {

@@ -88,13 +88,23 @@ class FrameProgram:
     """One orbit frame -- rays, the two uniform draws, the fused render, superresolution, uint8 conversion, ~190 launches --
     captured ONCE into a HIP graph and replayed per camera.  No entry point of the native library allocates or synchronises,
     and torch's graph-safe generator advances the draws from replay to replay.  The backbone runs once, before the capture
-    (ws is constant over the orbit).  Reusable across orbits of the same generator, latent and resolution."""
+    (ws is constant over the orbit).  Reusable across orbits of the same generator, latent and resolution.
+
+    The graph bakes in the ADDRESSES of everything the captured frame read: the cached backbone planes, the renderer's NHWC
+    copy of them and its folded decoder weights.  The program therefore owns strong references to all three and puts them
+    back in place before every replay -- an eager frame with cache_backbone=True in between would otherwise replace (and
+    free) them and the replay would read recycled memory."""
 
     @torch.no_grad()
     def __init__(self, G, ws, res, device, batch=1):
         self.G, self.ws, self.res = G, ws, res
         self.c = H.camera_label(H.orbit_pose(0, 120, G.rendering_kwargs['avg_camera_radius'], device=device)).repeat(batch, 1)
         self._frame(cache=True, cached=False)
+        self.planes = G._last_planes
+        self._pin = None
+        if hasattr(G.renderer, 'pin_planes'):
+            p = self.planes
+            self._pin = G.renderer.pin_planes(p.view(len(p), 3, 32, p.shape[-2], p.shape[-1]))
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -104,6 +114,7 @@ class FrameProgram:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.frame, self.raw = self._frame()
+        self._decoder = G.renderer.__dict__.get('_gnerf_decoder_cache')
 
     def _frame(self, cache=False, cached=True):
         out = self.G.synthesis(ws=self.ws, c=self.c, noise_mode='const', neural_rendering_resolution=self.res,
@@ -112,6 +123,9 @@ class FrameProgram:
 
     def __call__(self, c):
         self.c.copy_(c)
+        self.G._last_planes = self.planes                         # what an eager use_cached_backbone frame after this one reads, too
+        if self._pin is not None:
+            self.G.renderer.repin(self._pin)
         self.graph.replay()
         return self.frame.clone(), self.raw.clone()
 

@@ -23,6 +23,9 @@ _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.float64: F64}
 
 MAX_SAMPLES = 256
 DEBUG_SLOTS = 8
+ABI_VERSION = 2
+# decoder arithmetic of the fused renderer (GNERF_MLP_* in include/gnerf_hip.h)
+MLP_MODES = {'auto': 0, 'f16x3': 1, 'f32': 2}
 
 _c_p = ctypes.c_void_p
 _c_i = ctypes.c_int
@@ -43,6 +46,7 @@ class RenderParams(ctypes.Structure):
         ('noise_coarse', _c_p), ('noise_fine', _c_p),
         ('out_rgb', _c_p), ('out_depth', _c_p), ('out_wsum', _c_p),
         ('workspace', _c_p), ('debug', _c_p),
+        ('planes_absmax', _c_p), ('mlp_mode', ctypes.c_int32),
     ]
 
 
@@ -71,6 +75,8 @@ SIGNATURES = {
     'gnerf_grid_sample_2d': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, ctypes.POINTER(_c_i64), _c_i, _c_i, _c_p]),
     'gnerf_grid_sample_2d_backward': (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, ctypes.POINTER(_c_i64), _c_i, _c_i, _c_p]),
     'gnerf_planes_to_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
+    'gnerf_planes_to_nhwc_stats': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
+    'gnerf_planes_absmax': (_c_i, [_c_p, _c_i64, _c_p, _c_p]),
     'gnerf_planes_from_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_make_rays': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_p, _c_p, _c_p]),
     'gnerf_render_workspace_bytes': (ctypes.c_size_t, []),
@@ -95,8 +101,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.gnerf_abi_version() != 1:
-        raise RuntimeError(f'libgnerf_hip.so ABI version {lib.gnerf_abi_version()} != 1')
+    if lib.gnerf_abi_version() != ABI_VERSION:
+        raise RuntimeError(f'libgnerf_hip.so ABI version {lib.gnerf_abi_version()} != {ABI_VERSION}: rebuild it (g-nerf_amd/csrc/build.sh)')
     _lib = lib
     return lib
 
@@ -161,6 +167,12 @@ def _is_dense(t):
     return True
 
 
+def _same_layout(a, b):
+    """has_same_layout of the reference's bias_act.cpp:18-29: strides are compared only where the size is >= 2 (a size-1
+    dimension's stride is arbitrary, e.g. after .contiguous() on [N,C,1,1])."""
+    return all(sa == sb for sz, sa, sb in zip(a.shape, a.stride(), b.stride()) if sz >= 2)
+
+
 def _require_cuda(*tensors):
     for t in tensors:
         if t is not None and t.device.type != 'cuda':
@@ -182,7 +194,7 @@ def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
     if not _is_dense(x):
         raise RuntimeError('bias_act: x must be non-overlapping and dense')
     for name, t in (('xref', xref), ('yref', yref), ('dy', dy)):
-        if t is not None and (t.shape != x.shape or t.dtype != x.dtype or t.stride() != x.stride()):
+        if t is not None and (t.shape != x.shape or t.dtype != x.dtype or not _same_layout(t, x)):
             raise RuntimeError(f'bias_act: {name} must have the same shape, dtype and layout as x')
     size_b, step_b = 0, 1
     if b is not None:
@@ -353,18 +365,37 @@ def grid_sample_2d_backward(grad_out, image, grid, need_image=True, need_grid=Tr
     return (None if gi is None else gi.to(image.dtype)), (None if gg is None else gg.to(grid.dtype))
 
 
-def planes_to_nhwc(planes):
-    """[N,3,C,H,W] (or [NP,C,H,W]) float32 NCHW -> [NP,H,W,C] contiguous."""
+def planes_to_nhwc(planes, with_absmax=False):
+    """[N,3,C,H,W] (or [NP,C,H,W]) float32 NCHW -> [NP,H,W,C] contiguous.  with_absmax: also return max |planes| as a
+    one-element device tensor, measured by the same pass (render_forward's planes_absmax)."""
     _require_cuda(planes)
     if planes.dtype != torch.float32:
         raise RuntimeError('planes_to_nhwc: planes must be float32')
     p = planes.reshape(-1, *planes.shape[-3:]).contiguous()
     np_, c, h, w = p.shape
     out = torch.empty([np_, h, w, c], dtype=torch.float32, device=p.device)
+    if with_absmax:
+        amax = torch.empty([1], dtype=torch.float32, device=p.device)
+        with _on_device(p.device):
+            code = load().gnerf_planes_to_nhwc_stats(_ptr(p), _ptr(out), np_, c, h, w, _ptr(amax), _stream(p))
+        _check(code, 'gnerf_planes_to_nhwc_stats')
+        return out, amax
     with _on_device(p.device):
         code = load().gnerf_planes_to_nhwc(_ptr(p), _ptr(out), np_, c, h, w, _stream(p))
     _check(code, 'gnerf_planes_to_nhwc')
     return out
+
+
+def planes_absmax(planes):
+    """max |x| of a contiguous float32 device tensor -> one-element device tensor (NaN if any element is NaN)."""
+    _require_cuda(planes)
+    if planes.dtype != torch.float32 or not planes.is_contiguous() or planes.numel() == 0:
+        raise RuntimeError('planes_absmax: expected a non-empty contiguous float32 tensor')
+    amax = torch.empty([1], dtype=torch.float32, device=planes.device)
+    with _on_device(planes.device):
+        code = load().gnerf_planes_absmax(_ptr(planes), planes.numel(), _ptr(amax), _stream(planes))
+    _check(code, 'gnerf_planes_absmax')
+    return amax
 
 
 def planes_from_nhwc(planes_nhwc, n_items=None):
@@ -407,9 +438,18 @@ def _workspace(device):
     return ws
 
 
+def last_mlp_choice(device):
+    """Decoder arithmetic the last mlp='auto' render call on `device`'s current stream picked: 'f16x3' or 'f32' (None if no such
+    call ran).  Reads the render workspace (synchronises); for tests and diagnostics."""
+    ws = _workspaces.get((device.index, torch.cuda.current_stream(device).cuda_stream))
+    if ws is None:
+        return None
+    return {1: 'f16x3', 2: 'f32'}.get(int(ws.view(torch.int32)[4].item()))
+
+
 def _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine,
                    depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
-                   white_back, disparity_space_sampling, image_width, what):
+                   white_back, disparity_space_sampling, image_width, what, planes_absmax=None, mlp='auto'):
     """Validate the arguments shared by render_forward / render_backward and fill a RenderParams.
     Returns (params, keepalive, rays_per_item); `keepalive` holds the converted tensors the pointers refer to."""
     w1, b1, w2, b2 = decoder
@@ -457,18 +497,28 @@ def _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
     p.ray_end_per_ray = None if re_t is None else re_t.data_ptr()
     p.box_warp = float(box_warp); p.white_back = int(bool(white_back)); p.disparity_space_sampling = int(bool(disparity_space_sampling))
     p.noise_coarse = nc.data_ptr(); p.noise_fine = None if nf is None else nf.data_ptr()
-    return p, (planes_nhwc, o, d, nc, nf, w1, b1, w2, b2, rs_t, re_t), m
+    if mlp not in MLP_MODES:
+        raise RuntimeError(f"{what}: mlp must be one of {sorted(MLP_MODES)}")
+    p.mlp_mode = MLP_MODES[mlp]
+    if planes_absmax is not None:
+        _require_cuda(planes_absmax)
+        if planes_absmax.dtype != torch.float32 or planes_absmax.numel() != 1:
+            raise RuntimeError(f'{what}: planes_absmax must be a one-element float32 device tensor')
+    p.planes_absmax = _ptr(planes_absmax)
+    return p, (planes_nhwc, o, d, nc, nf, w1, b1, w2, b2, rs_t, re_t, planes_absmax), m
 
 
 def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine, *,
                    depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
-                   white_back=False, disparity_space_sampling=False, image_width=0, debug=False):
+                   white_back=False, disparity_space_sampling=False, image_width=0, debug=False, planes_absmax=None, mlp='auto'):
     """planes_nhwc [3N,H,W,32]; decoder = (w1,b1,w2,b2) effective fp32 weights; rays [N,M,3];
     noise_coarse [N*M,S]; noise_fine [N*M,F] or None; ray_start/ray_end floats or [N*M] tensors.
+    mlp: decoder arithmetic, 'auto' (decided on the device from planes_absmax -- the one-element tensor planes_to_nhwc(...,
+    with_absmax=True) returns; measured by the call itself when None -- and the decoder's weights), 'f16x3' or 'f32'.
     Returns (rgb [N,M,32], depth [N,M,1], wsum [N,M,1][, debug [N*M,8,S+F]])."""
     p, keep, m = _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine,
                                 depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
-                                white_back, disparity_space_sampling, image_width, 'render_forward')
+                                white_back, disparity_space_sampling, image_width, 'render_forward', planes_absmax, mlp)
     dev = planes_nhwc.device
     rgb = torch.empty([n_items, m, 32], dtype=torch.float32, device=dev)
     depth = torch.empty([n_items, m, 1], dtype=torch.float32, device=dev)

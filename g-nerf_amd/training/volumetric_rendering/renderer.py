@@ -32,7 +32,11 @@ import torch.nn as nn
 from training.volumetric_rendering.ray_marcher import MipRayMarcher2
 from training.volumetric_rendering import math_utils
 
+import os
+
 import gnerf_hip
+
+_KEEP_NHWC = os.environ.get('GNERF_KEEP_NHWC', '1') != '0'
 
 
 def generate_planes():
@@ -99,10 +103,13 @@ class _FusedRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, planes, w1, b1, w2, b2, ray_origins, ray_dirs, noise_c, noise_f, ray_start, ray_end, cfg):
         N = planes.shape[0]
-        nhwc = gnerf_hip.planes_to_nhwc(planes.detach().float())
+        nhwc, amax = gnerf_hip.planes_to_nhwc(planes.detach().float(), with_absmax=True)
         out = gnerf_hip.render_forward(nhwc, N, (w1, b1, w2, b2), ray_origins, ray_dirs, noise_c, noise_f,
-                                       ray_start=ray_start, ray_end=ray_end, **cfg)
+                                       ray_start=ray_start, ray_end=ray_end, planes_absmax=amax, **cfg)
         tensors = [planes, w1, b1, w2, b2, ray_origins, ray_dirs, noise_c]
+        # The NHWC copy is kept for the backward pass (the planes' size again: 25 MB per item) unless GNERF_KEEP_NHWC=0, in
+        # which case the backward pass repacks the saved NCHW planes a second time (37 us per 100 MB).
+        ctx.nhwc = nhwc if _KEEP_NHWC else None
         ctx.has_fine = noise_f is not None
         ctx.limits_are_tensors = isinstance(ray_start, torch.Tensor)
         if ctx.has_fine:
@@ -111,7 +118,7 @@ class _FusedRender(torch.autograd.Function):
             tensors += [ray_start, ray_end]
         else:
             ctx.limits = (ray_start, ray_end)
-        ctx.save_for_backward(*tensors)       # the NHWC repack is redone in backward (30 us) rather than held (100 MB)
+        ctx.save_for_backward(*tensors)
         ctx.cfg = cfg
         return out
 
@@ -126,7 +133,7 @@ class _FusedRender(torch.autograd.Function):
         need_planes = ctx.needs_input_grad[0]
         need_decoder = any(ctx.needs_input_grad[1:5])
         N = planes.shape[0]
-        nhwc = gnerf_hip.planes_to_nhwc(planes.detach().float())
+        nhwc = ctx.nhwc if ctx.nhwc is not None else gnerf_hip.planes_to_nhwc(planes.detach().float())
         g_planes, g_dec = gnerf_hip.render_backward(nhwc, N, (w1, b1, w2, b2), ray_origins, ray_dirs, noise_c, noise_f, g_rgb, g_depth, g_wsum,
                                                     ray_start=ray_start, ray_end=ray_end, need_planes=need_planes, need_decoder=need_decoder,
                                                     **ctx.cfg)
@@ -201,10 +208,10 @@ class ImportanceRenderer(torch.nn.Module):
     def _decoder_cache(self, fcs):
         fc1, fc2 = fcs
         params = (fc1.weight, fc1.bias, fc2.weight, fc2.bias)
-        key = tuple((id(p), p._version, p.device) for p in params) + (float(fc1.weight_gain), float(fc1.bias_gain),
+        key = tuple((id(p), None if p.is_inference() else p._version, p.device) for p in params) + (float(fc1.weight_gain), float(fc1.bias_gain),
                                                                         float(fc2.weight_gain), float(fc2.bias_gain))
         cache = self.__dict__.get('_gnerf_decoder_cache')
-        if cache is None or cache[0] != key:
+        if cache is None or cache[0] != key or any(p.is_inference() for p in params):
             with torch.no_grad():
                 eff = (fc1.weight.float() * fc1.weight_gain, fc1.bias.float() * fc1.bias_gain,        # networks_stylegan2.py:121-127
                        fc2.weight.float() * fc2.weight_gain, fc2.bias.float() * fc2.bias_gain)
@@ -214,15 +221,37 @@ class ImportanceRenderer(torch.nn.Module):
         return cache[1]
 
     def _planes_nhwc(self, planes):
+        """(NHWC copy, max |planes|) of `planes`, cached on the tensor's identity and version: an orbit with cached backbone
+        planes (triplane.py:66-71) converts once.  Inference tensors carry no version counter: they are converted every call.
+        The cached copy is only handed to work on the stream that made it (another stream converts again, for itself)."""
+        if planes.is_inference():
+            return gnerf_hip.planes_to_nhwc(planes.float(), with_absmax=True)
         base = planes._base if planes._base is not None else planes
+        stream = torch.cuda.current_stream(planes.device).cuda_stream
         cache = self.__dict__.get('_gnerf_planes_cache')
         if cache is not None:
-            ref, version, ptr, shape, nhwc = cache
-            if ref() is base and version == base._version and ptr == planes.data_ptr() and shape == tuple(planes.shape):
-                return nhwc
-        nhwc = gnerf_hip.planes_to_nhwc(planes.detach().float())
-        self.__dict__['_gnerf_planes_cache'] = (weakref.ref(base), base._version, planes.data_ptr(), tuple(planes.shape), nhwc)
-        return nhwc
+            ref, version, ptr, shape, made_on, out = cache
+            if ref() is base and version == base._version and ptr == planes.data_ptr() and shape == tuple(planes.shape) \
+                    and (made_on is None or made_on == stream):
+                return out
+        out = gnerf_hip.planes_to_nhwc(planes.detach().float(), with_absmax=True)
+        self.__dict__['_gnerf_planes_cache'] = (weakref.ref(base), base._version, planes.data_ptr(), tuple(planes.shape), stream, out)
+        return out
+
+    def pin_planes(self, planes):
+        """Convert `planes` [N,3,32,H,W] now, wait for the device, and make the copy valid on EVERY stream (a HIP-graph
+        capture runs on its own stream).  Returns an opaque handle that keeps the converted tensors alive: a captured
+        graph bakes in their addresses, so whoever replays it must hold the handle and call `repin(handle)` before a replay
+        if other planes went through this renderer in between (gen_videos_mi355x.FrameProgram does)."""
+        base = planes._base if planes._base is not None else planes
+        out = gnerf_hip.planes_to_nhwc(planes.detach().float(), with_absmax=True)
+        torch.cuda.synchronize(planes.device)
+        handle = (weakref.ref(base), base._version, planes.data_ptr(), tuple(planes.shape), None, out)
+        self.__dict__['_gnerf_planes_cache'] = handle
+        return handle
+
+    def repin(self, handle):
+        self.__dict__['_gnerf_planes_cache'] = handle
 
     def _forward_hip(self, planes, fcs, ray_origins, ray_directions, opts, differentiable=False):
         N, M, _ = ray_origins.shape
@@ -254,8 +283,9 @@ class ImportanceRenderer(torch.nn.Module):
                    fc2.weight.float() * fc2.weight_gain, fc2.bias.float() * fc2.bias_gain)
             return _FusedRender.apply(planes, *eff, ray_origins.detach(), ray_directions.detach(), noise_c.reshape(N * M, S), noise_f,
                                       ray_start, ray_end, cfg)
-        return gnerf_hip.render_forward(self._planes_nhwc(planes), N, self._decoder_cache(fcs), ray_origins.detach(), ray_directions.detach(),
-                                        noise_c, noise_f, ray_start=ray_start, ray_end=ray_end, **cfg)
+        nhwc, amax = self._planes_nhwc(planes)
+        return gnerf_hip.render_forward(nhwc, N, self._decoder_cache(fcs), ray_origins.detach(), ray_directions.detach(),
+                                        noise_c, noise_f, ray_start=ray_start, ray_end=ray_end, planes_absmax=amax, **cfg)
 
     # ------------------------------------------------------------------ PyTorch-op path
 
@@ -308,7 +338,7 @@ class ImportanceRenderer(torch.nn.Module):
                            fc2.weight.float() * fc2.weight_gain, fc2.bias.float() * fc2.bias_gain)
                     sigma, rgb = _FusedQuery.apply(planes, *eff, sample_coordinates.detach(), options['box_warp'])
                 else:
-                    sigma, rgb = gnerf_hip.query_points(self._planes_nhwc(planes), planes.shape[0], self._decoder_cache(fcs),
+                    sigma, rgb = gnerf_hip.query_points(self._planes_nhwc(planes)[0], planes.shape[0], self._decoder_cache(fcs),
                                                         sample_coordinates.detach(), options['box_warp'])
                 out = {'rgb': rgb, 'sigma': sigma}
                 if density_noise > 0:
@@ -326,7 +356,7 @@ class ImportanceRenderer(torch.nn.Module):
         if planes.device.type == 'cuda' and planes.ndim == 5 and planes.shape[1] == 3 and planes.shape[2] == 32 and not torch.is_grad_enabled():
             fcs = _osg_decoder_weights(decoder)
             if fcs is not None and options.get('density_noise', 0) == 0:
-                return gnerf_hip.query_points(self._planes_nhwc(planes), planes.shape[0], self._decoder_cache(fcs),
+                return gnerf_hip.query_points(self._planes_nhwc(planes)[0], planes.shape[0], self._decoder_cache(fcs),
                                               sample_coordinates.detach(), options['box_warp'], want_rgb=False)[0]
         dirs = torch.zeros_like(sample_coordinates)
         dirs[..., -1] = -1

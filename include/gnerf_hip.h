@@ -19,6 +19,7 @@
  *   gnerf_query_points      <- ImportanceRenderer.run_model        training/volumetric_rendering/renderer.py:142-148
  *   gnerf_make_rays         <- RaySampler.forward                  training/volumetric_rendering/ray_sampler.py:24-63
  *   gnerf_planes_to_nhwc    <- (layout change feeding the renderer; the reference keeps NCHW, triplane.py:74)
+ *   gnerf_planes_to_nhwc_stats / gnerf_planes_absmax <- (the same + max |planes|, which picks the decoder arithmetic)
  *   gnerf_planes_from_nhwc  <- (the same for the plane gradient on the way back)
  *   gnerf_render_backward   <- autograd through renderer.py:88-140 (grid_sample_gradfix.py:62-77 for the planes)
  */
@@ -32,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GNERF_ABI_VERSION 1
+#define GNERF_ABI_VERSION 2
 
 /* error codes */
 #define GNERF_OK            0
@@ -128,6 +129,12 @@ int gnerf_grid_sample_2d_backward(const void* grad_out, const void* image, const
  * The renderer reads whole 128-byte texels (32 channels) from the NHWC copy. */
 int gnerf_planes_to_nhwc(const float* planes_nchw, float* planes_nhwc, int np, int c, int h, int w,
                          gnerf_stream_t stream);
+/* The same layout change, also measuring max |planes| on the way (the planes are read anyway): *absmax (one device
+ * float, overwritten) feeds gnerf_render_params.planes_absmax.  A NaN anywhere in the planes makes *absmax NaN. */
+int gnerf_planes_to_nhwc_stats(const float* planes_nchw, float* planes_nhwc, int np, int c, int h, int w,
+                               float* absmax, gnerf_stream_t stream);
+/* max |x| over `numel` floats (any layout) -> *absmax (one device float, overwritten). */
+int gnerf_planes_absmax(const float* planes, int64_t numel, float* absmax, gnerf_stream_t stream);
 /* The inverse, NHWC [np, h, w, c] -> NCHW [np, c, h, w]: hands gnerf_render_backward's plane gradient back in the layout
  * of the reference's planes (triplane.py:74). */
 int gnerf_planes_from_nhwc(const float* planes_nhwc, float* planes_nchw, int np, int c, int h, int w,
@@ -181,7 +188,22 @@ typedef struct gnerf_render_params {
     void*  workspace;
     /* optional stage dump for debugging/parity: float32 [n*m, GNERF_DEBUG_SLOTS, S+F]; NULL in production */
     float* debug;
+    /* Decoder arithmetic (the reference's decoder is fp32 addmm, triplane.py:124-136 / networks_stylegan2.py:121-134).
+       GNERF_MLP_F32: exact fp32 products on v_mfma_f32_16x16x4_f32, any finite input.
+       GNERF_MLP_F16X3: each product as an error-compensated f16 hi/lo split on v_mfma_f32_16x16x32_f16 (fp32-grade, 1.6x
+       faster) -- only valid while features, weights and hidden activations are inside f16's range.
+       GNERF_MLP_AUTO (0, default): decided ON THE DEVICE per call from max |planes| and the decoder's weights (bounds
+       in DESIGN.md section 2.1): out-of-range or ill-conditioned inputs take the fp32 path, so results never depend on
+       f16's range.  planes_absmax: one device float from gnerf_planes_to_nhwc_stats / gnerf_planes_absmax; NULL makes
+       the AUTO launcher measure it itself (one extra pass over the planes).  The kernels that always compute in fp32
+       (more than 96+96 samples, gnerf_query_points, both backward passes) ignore these two fields. */
+    const float* planes_absmax;
+    int32_t mlp_mode;
 } gnerf_render_params;
+
+#define GNERF_MLP_AUTO  0
+#define GNERF_MLP_F16X3 1
+#define GNERF_MLP_F32   2
 
 #define GNERF_MAX_SAMPLES   256
 #define GNERF_DEBUG_SLOTS   8

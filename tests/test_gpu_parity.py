@@ -292,6 +292,85 @@ def test_render_full_size_properties(dev):
     np.testing.assert_allclose(wsum.cpu()[:, idx].numpy(), ref_w.numpy(), atol=2e-4)
 
 
+def _scaled_scene(plane_scale, weight_scale, S, F, res=8):
+    planes, dec, o, d, nc, nf = _random_scene(31, N=2, res=res, S=S, F=F, hw=(24, 20), scale=1.0)
+    return planes * plane_scale, [t * weight_scale for t in dec], o, d, nc, nf
+
+
+@pytest.mark.parametrize('S,F', [(48, 48), (96, 96), (40, 0)])                   # pipe<1>, pipe<2>, coop
+@pytest.mark.parametrize('weight_scale', [1e-3, 1.0, 1e3])
+@pytest.mark.parametrize('plane_scale', [1e-5, 1e-3, 1.0, 1e3, 1e5])
+def test_render_decoder_arithmetic_is_range_safe(dev, plane_scale, weight_scale, S, F):
+    """The f16 hi/lo decoder arithmetic only holds inside f16's range (|x| < 65520 or hi = inf, lo = NaN; below 2^-14 the
+    compensation is lost).  The reference's decoder is fp32 (triplane.py:124-136, networks_stylegan2.py:121-134) and is
+    finite for all of these inputs, so the default (mlp='auto') must be too, at the usual tolerance: the device-side choice
+    sends out-of-range or ill-conditioned calls to the fp32-MFMA kernels."""
+    import gnerf_hip
+    from oracle import render_ref as R
+    planes, dec, o, d, nc, nf = _scaled_scene(plane_scale, weight_scale, S, F)
+    opts = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, clamp_mode='softplus')
+    ref_rgb, ref_depth, ref_w = R.render(planes, dec, o, d, opts, nc, nf)
+    assert torch.isfinite(ref_rgb).all() and torch.isfinite(ref_w).all()                    # the premise: fp32 is fine
+    nhwc, amax = gnerf_hip.planes_to_nhwc(planes.to(dev), with_absmax=True)
+    assert float(amax) == float(planes.abs().max())
+    args = (nhwc, 2, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev) if F else None)
+    kw = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=8)
+    for given in (amax, None):                                   # absmax handed over / measured by the call itself
+        rgb, depth, wsum = gnerf_hip.render_forward(*args, planes_absmax=given, **kw)
+        choice = gnerf_hip.last_mlp_choice(dev)
+        assert torch.isfinite(rgb).all() and torch.isfinite(wsum).all() and torch.isfinite(depth).all(), choice
+        mse = float(((rgb.cpu() - ref_rgb) ** 2).mean())
+        assert mse < 1e-8, (mse, choice)
+        np.testing.assert_allclose(wsum.cpu().numpy(), ref_w.numpy(), atol=2e-4)
+        fin = torch.isfinite(ref_depth)
+        np.testing.assert_allclose(depth.cpu()[fin].numpy(), ref_depth[fin].numpy(), atol=5e-4)
+    # where the choice is forced by the bounds
+    if plane_scale == 1.0 and weight_scale == 1.0:
+        assert choice == 'f16x3'
+    if plane_scale >= 1e5 or weight_scale >= 1e3:
+        assert choice == 'f32'
+
+
+@pytest.mark.parametrize('S,F', [(48, 48), (96, 96), (40, 0)])
+def test_render_decoder_arithmetic_forced(dev, S, F):
+    """Both shipped arithmetics agree with the oracle on an in-range scene when forced, and the forced f16 path shows the
+    hazard the default guards against (non-finite output at |planes| ~ 1e5)."""
+    import gnerf_hip
+    from oracle import render_ref as R
+    opts = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, clamp_mode='softplus')
+    kw = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=8)
+    planes, dec, o, d, nc, nf = _scaled_scene(1.0, 1.0, S, F)
+    ref_rgb, _, ref_w = R.render(planes, dec, o, d, opts, nc, nf)
+    args = (2, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev) if F else None)
+    nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
+    outs = {}
+    for mlp in ('f16x3', 'f32'):
+        rgb, depth, wsum = outs[mlp] = gnerf_hip.render_forward(nhwc, *args, mlp=mlp, **kw)
+        assert float(((rgb.cpu() - ref_rgb) ** 2).mean()) < 1e-8
+        np.testing.assert_allclose(wsum.cpu().numpy(), ref_w.numpy(), atol=2e-4)
+    assert float((outs['f16x3'][0] - outs['f32'][0]).abs().max()) < 1e-4
+    big = gnerf_hip.planes_to_nhwc((planes * 1e5).to(dev))
+    bad = gnerf_hip.render_forward(big, *args, mlp='f16x3', **kw)[0]
+    good = gnerf_hip.render_forward(big, *args, mlp='f32', **kw)[0]
+    assert torch.isfinite(good).all() and not torch.isfinite(bad).all()
+    with pytest.raises(RuntimeError):
+        gnerf_hip.render_forward(nhwc, *args, mlp='bf16', **kw)
+
+
+def test_planes_absmax(dev):
+    import gnerf_hip
+    for n in (1, 3, 4, 1000, 4097, 1 << 20):
+        x = torch.randn(n, device=dev) * 3
+        assert float(gnerf_hip.planes_absmax(x)) == float(x.abs().max())
+    x = torch.randn(2, 3, 32, 9, 7, device=dev)
+    x[1, 2, 5, 3, 3] = -77.5
+    assert float(gnerf_hip.planes_to_nhwc(x, with_absmax=True)[1]) == 77.5
+    x[0, 0, 0, 0, 0] = float('nan')
+    assert torch.isnan(gnerf_hip.planes_to_nhwc(x, with_absmax=True)[1]).all() and torch.isnan(gnerf_hip.planes_absmax(x)).all()
+    x[0, 0, 0, 0, 0] = float('inf')
+    assert float(gnerf_hip.planes_absmax(x)) == float('inf')
+
+
 def test_query_points_vs_oracle(dev):
     import gnerf_hip
     from oracle import render_ref as R
@@ -897,6 +976,23 @@ def test_frame_program_replay_equals_eager(dev):
             out = G.synthesis(ws=ws, c=c, noise_mode='const', neural_rendering_resolution=64, use_cached_backbone=True)
             assert torch.equal(f_graph, H.to_uint8(out['image'])) and torch.equal(r_graph, H.to_uint8(out['image_raw']))
         assert f_graph.shape == (1, 512, 512, 3) and f_graph.dtype == torch.uint8 and float(f_graph.float().std()) > 1.0
+        # The program owns what its graph reads: an eager frame of ANOTHER latent with cache_backbone=True replaces the
+        # generator's cached planes and the renderer's NHWC copy (and frees the old ones); the next replay must still render
+        # the program's own latent, not recycled memory.
+        c = H.camera_label(H.orbit_pose(5, 240, device=dev))
+        torch.manual_seed(7)
+        want, want_raw = prog(c)
+        ws2 = gv.orbit_latents(G, torch.randn(1, 512, device=dev), dev)
+        other = G.synthesis(ws=ws2, c=c, noise_mode='const', neural_rendering_resolution=64, cache_backbone=True)
+        junk = [torch.randn_like(G._last_planes) for _ in range(4)]          # recycle whatever the allocator got back
+        assert not torch.equal(H.to_uint8(other['image']), want)
+        torch.manual_seed(7)
+        again, again_raw = prog(c)
+        assert torch.equal(again, want) and torch.equal(again_raw, want_raw)
+        torch.manual_seed(7)                                                  # ... and eager frames after a replay see the program's planes
+        out = G.synthesis(ws=ws, c=c, noise_mode='const', neural_rendering_resolution=64, use_cached_backbone=True)
+        assert torch.equal(H.to_uint8(out['image']), want)
+        del junk
 
 
 # ---- grid_sample_gradfix on the native sampler -----------------------------------------------------------------------

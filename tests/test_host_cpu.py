@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f'{n} declared in gnerf_hip.h but not exported'
         assert n in gnerf_hip.SIGNATURES, f'{n} has no ctypes signature'
     assert sorted(gnerf_hip.SIGNATURES) == names
-    assert lib.gnerf_abi_version() == 1
+    assert lib.gnerf_abi_version() == gnerf_hip.ABI_VERSION
     assert b'gfx950' in lib.gnerf_build_info()
 
 
