@@ -1,4 +1,4 @@
-"""Inference-only tri-plane generator for benchmarks and harnesses that must run where the reference tree is absent
+"""Tri-plane generator and depth discriminator for benchmarks, tests and harnesses that must run where the reference tree is absent
 (the GPU box): the CALLERS on either side of the hot path -- StyleGAN2 backbone -> tri-planes -> [renderer] ->
 super-resolution to 512x512 -- as plain PyTorch modules (convolutions go to MIOpen) around this repo's renderer and custom
 ops.  SURVEY.md section 8a rows 11 and C: these stay PyTorch; nothing here is a kernel.
@@ -11,8 +11,13 @@ the build container):
     Generator/Mapping/Synthesis*  g_nerf/training/networks_stylegan2.py:41-557  -> Backbone, Mapping, Synthesis, Block, StyledConv, ToRGB
     conv2d_resample (up=2)    g_nerf/torch_utils/ops/conv2d_resample.py:114-131 -> StyledConv.forward
     SuperresolutionHybrid8XDC g_nerf/training/superresolution.py:266-303  -> SuperRes8XDC
-What is deliberately missing: training mode (un-fused modulated convolution, random noise, EMA updates, truncation),
-the 'orig'/'resnet' block architectures, the other seven super-resolution variants, pickling hooks.
+    Discriminator (+ blocks, epilogue, minibatch-std)  g_nerf/training/networks_stylegan2.py:561-799 -> Discriminator, DBlock, DEpilogue
+Both execution modes of the reference's layers exist: the fused form (per-sample modulated weights in one grouped
+convolution: inference, `fused_modconv=True`) and the un-fused form that training uses under the FFHQ configuration's
+`fused_modconv_default='inference_only'` (train.py:304, networks_stylegan2.py:76-86: activations scaled by the styles,
+ONE shared-weight convolution, demodulation and noise applied after it), with 'random' / 'const' / 'none' noise.
+What is deliberately missing: EMA updates and truncation of the mapping network, the 'orig' block architecture, the other
+seven super-resolution variants, Freeze-D, pickling hooks.
 """
 
 import math
@@ -70,20 +75,31 @@ class Mapping(nn.Module):
         return x.unsqueeze(1).repeat(1, self.num_ws, 1)
 
 
+def _prenormalize(weight, styles):
+    """Scaling of weights and styles against fp16 overflow, cancelled by the demodulation (networks_stylegan2.py:62-64)."""
+    weight = weight * (1 / math.sqrt(weight[0].numel()) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+    return weight, styles / styles.norm(float('inf'), dim=1, keepdim=True)
+
+
 def _modulated_weights(weight, styles, demodulate, half):
     """Per-sample convolution weights [N, O, I, k, k] (networks_stylegan2.py:61-75, the fused form used at inference)."""
-    if half and demodulate:             # pre-normalisation against fp16 overflow (:62-64)
-        weight = weight * (1 / math.sqrt(weight[0].numel()) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
-        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
+    if half and demodulate:
+        weight, styles = _prenormalize(weight, styles)
     w = weight.unsqueeze(0) * styles[:, None, :, None, None]
     if demodulate:
         w = w * (w.square().sum(dim=[2, 3, 4], keepdim=True) + 1e-8).rsqrt()
     return w
 
 
+def _demod_coefficients(weight, styles):
+    """[N, O] factors that normalise each output channel of the modulated weights (networks_stylegan2.py:71-72), without
+    materialising the [N, O, I, k, k] product: sum_ikk (w s)^2 = (w^2 summed over the taps) . s^2."""
+    return (weight.square().sum(dim=[2, 3]).matmul(styles.square().t()).t() + 1e-8).rsqrt()
+
+
 class StyledConv(nn.Module):
     """SynthesisLayer (networks_stylegan2.py:280-345): modulated 3x3 convolution (optionally x2 upsampling = transposed
-    convolution + the 4x4 blur, conv2d_resample.py:114-131), constant noise, bias + leaky ReLU (+ clamp) in bias_act."""
+    convolution + the 4x4 blur, conv2d_resample.py:114-131), noise, bias + leaky ReLU (+ clamp) in bias_act."""
 
     def __init__(self, c_in, c_out, w_dim, resolution, up=1, conv_clamp=None):
         super().__init__()
@@ -95,21 +111,40 @@ class StyledConv(nn.Module):
         self.noise_strength = nn.Parameter(torch.zeros([]))
         self.bias = nn.Parameter(torch.zeros(c_out))
 
-    def forward(self, x, w, noise_mode='const', gain=1.0):
-        n, c_in, h, wd = x.shape
-        wts = _modulated_weights(self.weight, self.affine(w), True, x.dtype == torch.float16).to(x.dtype)      # [N,O,I,3,3]
-        c_out = wts.shape[1]
-        x = x.reshape(1, n * c_in, h, wd)
+    def _resampled_conv(self, x, weight, groups):
+        """weight [groups*O, I, 3, 3] (correlation form).  up == 1: 3x3 convolution with padding 1.  up == 2: stride-2
+        transposed convolution (kernel as is: the reference un-flips it twice), 2H+1 outputs per axis, then the low-pass
+        filter with gain up^2 and one pixel of padding -> 2H."""
         if self.up == 1:
-            x = F.conv2d(x, wts.reshape(n * c_out, c_in, 3, 3), padding=1, groups=n)
+            return F.conv2d(x, weight, padding=1, groups=groups)
+        o, i = weight.shape[0] // groups, weight.shape[1]
+        wt = weight.reshape(groups, o, i, 3, 3).transpose(1, 2).reshape(groups * i, o, 3, 3)
+        x = F.conv_transpose2d(x, wt, stride=2, groups=groups)
+        return upfirdn2d.upfirdn2d(x, self.resample_filter, padding=[1, 1, 1, 1], gain=4)
+
+    def forward(self, x, w, noise_mode='random', gain=1.0, fused=True):
+        assert noise_mode in ('random', 'const', 'none')
+        n, c_in, h, wd = x.shape
+        styles = self.affine(w)
+        noise = None
+        if noise_mode == 'random':
+            noise = torch.randn([n, 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
+        elif noise_mode == 'const':
+            noise = self.noise_const * self.noise_strength
+        if fused:
+            wts = _modulated_weights(self.weight, styles, True, x.dtype == torch.float16).to(x.dtype)          # [N,O,I,3,3]
+            c_out = wts.shape[1]
+            x = self._resampled_conv(x.reshape(1, n * c_in, h, wd), wts.reshape(n * c_out, c_in, 3, 3), n)
+            x = x.reshape(n, c_out, *x.shape[2:])
+            if noise is not None:
+                x = x.add_(noise)
         else:
-            # stride-2 transposed convolution (kernel as is: the reference un-flips it twice), 2H+1 outputs per axis, then
-            # the low-pass filter with gain up^2 and one pixel of padding -> 2H
-            x = F.conv_transpose2d(x, wts.transpose(1, 2).reshape(n * c_in, c_out, 3, 3), stride=2, groups=n)
-            x = upfirdn2d.upfirdn2d(x, self.resample_filter, padding=[1, 1, 1, 1], gain=4)
-        x = x.reshape(n, c_out, *x.shape[2:])
-        if noise_mode == 'const':
-            x = x.add_((self.noise_const * self.noise_strength).to(x.dtype))
+            weight = self.weight
+            if x.dtype == torch.float16:
+                weight, styles = _prenormalize(weight, styles)
+            dcoefs = _demod_coefficients(weight, styles).to(x.dtype)[:, :, None, None]
+            x = self._resampled_conv(x * styles.to(x.dtype)[:, :, None, None], weight.to(x.dtype), 1)
+            x = torch.addcmul(noise.to(x.dtype), x, dcoefs) if noise is not None else x * dcoefs      # torch_utils/ops/fma.py
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return bias_act.bias_act(x, self.bias.to(x.dtype), act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
 
@@ -125,10 +160,14 @@ class ToRGB(nn.Module):
         self.bias = nn.Parameter(torch.zeros(c_out))
         self.weight_gain = 1 / math.sqrt(c_in)
 
-    def forward(self, x, w):
+    def forward(self, x, w, fused=True):
         n, c_in, h, wd = x.shape
-        wts = _modulated_weights(self.weight, self.affine(w) * self.weight_gain, False, False).to(x.dtype)
-        x = F.conv2d(x.reshape(1, n * c_in, h, wd), wts.reshape(-1, c_in, 1, 1), groups=n).reshape(n, -1, h, wd)
+        styles = self.affine(w) * self.weight_gain
+        if fused:
+            wts = _modulated_weights(self.weight, styles, False, False).to(x.dtype)
+            x = F.conv2d(x.reshape(1, n * c_in, h, wd), wts.reshape(-1, c_in, 1, 1), groups=n).reshape(n, -1, h, wd)
+        else:
+            x = F.conv2d(x * styles.to(x.dtype)[:, :, None, None], self.weight.to(x.dtype))
         return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
 
 
@@ -148,19 +187,27 @@ class Block(nn.Module):
         self.torgb = ToRGB(c_out, img_channels, w_dim, conv_clamp=conv_clamp)
         self.num_conv, self.num_torgb = (1 if c_in == 0 else 2), 1
 
-    def forward(self, x, img, ws, noise_mode='const'):
-        dtype = torch.float16 if self.use_fp16 and ws.is_cuda else torch.float32
+    def forward(self, x, img, ws, noise_mode='random', force_fp32=False, fused_modconv=None):
+        dtype = torch.float16 if self.use_fp16 and ws.is_cuda and not force_fp32 else torch.float32
+        fused = (not self.training) if fused_modconv in (None, 'inference_only') else bool(fused_modconv)      # networks_stylegan2.py:433-434
         ws = ws.unbind(dim=1)
         if self.c_in == 0:
             x = self.const.to(dtype).unsqueeze(0).repeat(ws[0].shape[0], 1, 1, 1)
-            x = self.conv1(x, ws[0], noise_mode)
+            x = self.conv1(x, ws[0], noise_mode, fused=fused)
         else:
-            x = self.conv0(x.to(dtype), ws[0], noise_mode)
-            x = self.conv1(x, ws[1], noise_mode)
+            x = self.conv0(x.to(dtype), ws[0], noise_mode, fused=fused)
+            x = self.conv1(x, ws[1], noise_mode, fused=fused)
         if img is not None and self.up == 2:
             img = upfirdn2d.upsample2d(img, self.resample_filter)
-        y = self.torgb(x, ws[-1]).float()
-        return x, (img.add_(y) if img is not None else y)
+        y = self.torgb(x, ws[-1], fused=fused).float()
+        if img is None:
+            return x, y
+        if torch.is_grad_enabled() and (img.requires_grad or y.requires_grad):
+            # Out of place under autograd: the super-resolution's first block receives `img` as a VIEW of the feature image it
+            # also convolves (triplane.py:86), and in fp32 the in-place form overwrites what that convolution saved for its
+            # backward pass (the reference's own block64 raises here when trained without fp16; with fp16 its cast makes a copy).
+            return x, img + y
+        return x, img.add_(y)
 
 
 class Synthesis(nn.Module):
@@ -176,13 +223,13 @@ class Synthesis(nn.Module):
             self.num_ws += blk.num_conv + (blk.num_torgb if r == img_resolution else 0)
             setattr(self, f'b{r}', blk)
 
-    def forward(self, ws, noise_mode='const'):
+    def forward(self, ws, noise_mode='random', **block_kwargs):
         ws = ws.float()
         x = img = None
         i = 0
         for r in self.block_resolutions:
             blk = getattr(self, f'b{r}')
-            x, img = blk(x, img, ws.narrow(1, i, blk.num_conv + blk.num_torgb), noise_mode)
+            x, img = blk(x, img, ws.narrow(1, i, blk.num_conv + blk.num_torgb), noise_mode, **block_kwargs)
             i += blk.num_conv
         return img
 
@@ -209,14 +256,14 @@ class SuperRes8XDC(nn.Module):
         self.block0 = Block(channels, 256, w_dim, 256, 3, is_last=False, use_fp16=use_fp16, conv_clamp=clamp)
         self.block1 = Block(256, 128, w_dim, 512, 3, is_last=True, use_fp16=use_fp16, conv_clamp=clamp)
 
-    def forward(self, rgb, x, ws, noise_mode='none'):
+    def forward(self, rgb, x, ws, noise_mode='none', **block_kwargs):
         ws = ws[:, -1:, :].repeat(1, 3, 1)
-        x_raw, image_raw = self.block64(x, rgb, ws, noise_mode)
+        x_raw, image_raw = self.block64(x, rgb, ws, noise_mode, **block_kwargs)
         if x.shape[-1] != 128:
             x = F.interpolate(x_raw, size=(128, 128), mode='bilinear', align_corners=False, antialias=self.antialias)
             rgb = F.interpolate(image_raw, size=(128, 128), mode='bilinear', align_corners=False, antialias=self.antialias)
-        x, rgb = self.block0(x, rgb, ws, noise_mode)
-        x, rgb = self.block1(x, rgb, ws, noise_mode)
+        x, rgb = self.block0(x, rgb, ws, noise_mode, **block_kwargs)
+        x, rgb = self.block1(x, rgb, ws, noise_mode, **block_kwargs)
         return rgb, image_raw
 
 
@@ -228,7 +275,7 @@ FFHQ_RENDERING = {
 
 
 class Generator(nn.Module):
-    """TriPlaneGenerator (triplane.py:19-108), FFHQ configuration (train.py:238-377), inference only."""
+    """TriPlaneGenerator (triplane.py:19-108), FFHQ configuration (train.py:238-377)."""
 
     def __init__(self, z_dim=512, c_dim=25, w_dim=512, rendering_kwargs=None, sr_use_fp16=True):
         super().__init__()
@@ -246,23 +293,30 @@ class Generator(nn.Module):
             c = torch.zeros_like(c)
         return self.backbone.mapping(z, c * self.rendering_kwargs.get('c_scale', 0))
 
-    def synthesis(self, ws, c, neural_rendering_resolution=None, cache_backbone=False, use_cached_backbone=False, noise_mode='const', **_ignored):
+    def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False, use_cached_backbone=False,
+                  only_depth=False, **synthesis_kwargs):
+        """triplane.py:53-89.  synthesis_kwargs (noise_mode, force_fp32, fused_modconv) go to the backbone as given and to the
+        superresolution without noise_mode, which the rendering options fix ('superresolution_noise_mode', triplane.py:87)."""
         res = self.neural_rendering_resolution = neural_rendering_resolution or self.neural_rendering_resolution
         o, d = self.ray_sampler(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), res)
         if use_cached_backbone and self._last_planes is not None:
             planes = self._last_planes
         else:
-            planes = self.backbone.synthesis(ws, noise_mode=noise_mode)
+            planes = self.backbone.synthesis(ws, **synthesis_kwargs)
         if cache_backbone:
             self._last_planes = planes
         n = planes.shape[0]
         feat, depth, _ = self.renderer(planes.view(n, 3, 32, *planes.shape[-2:]), self.decoder, o, d, self.rendering_kwargs)
         feature_image = feat.permute(0, 2, 1).reshape(n, 32, res, res).contiguous()
         depth_image = depth.permute(0, 2, 1).reshape(n, 1, res, res)
-        sr_image, raw = self.superresolution(feature_image[:, :3], feature_image, ws, noise_mode=self.rendering_kwargs.get('superresolution_noise_mode', 'none'))
+        if only_depth:                                                                          # triplane.py:83-84
+            return {'image': depth_image, 'image_raw': depth_image, 'image_depth': depth_image}
+        sr_kwargs = {k: v for k, v in synthesis_kwargs.items() if k != 'noise_mode'}
+        sr_image, raw = self.superresolution(feature_image[:, :3], feature_image, ws,
+                                             noise_mode=self.rendering_kwargs.get('superresolution_noise_mode', 'none'), **sr_kwargs)
         return {'image': sr_image, 'image_raw': raw, 'image_depth': depth_image}
 
-    def sample_mixed(self, coordinates, directions, ws, noise_mode='const', **_ignored):
+    def sample_mixed(self, coordinates, directions, ws, noise_mode='random', **_ignored):
         """Density / colour at arbitrary points for given latents (triplane.py:98-102; shape extraction, density regulariser)."""
         planes = self.backbone.synthesis(ws, noise_mode=noise_mode)
         return self.renderer.run_model(planes.view(len(planes), 3, 32, *planes.shape[-2:]), self.decoder, coordinates, directions, self.rendering_kwargs)
@@ -272,3 +326,134 @@ class Generator(nn.Module):
 
     def forward(self, z, c, **kw):
         return self.synthesis(self.mapping(z, c), c, **kw)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Discriminator on the 64x64 depth image (training_loop.py:183: Discriminator(c_dim=25, img_resolution=64, img_channels=1)).
+
+
+class Conv(nn.Module):
+    """Conv2dLayer (networks_stylegan2.py:140-197) for the cases the discriminator uses: 1x1 or 3x3, optional x2
+    downsampling (conv2d_resample.py:96-111: a 1x1 kernel decimates through the low-pass filter first and convolves after,
+    a 3x3 kernel blurs first and convolves with stride 2), bias + activation (+ clamp) in bias_act."""
+
+    def __init__(self, c_in, c_out, kernel_size, bias=True, activation='linear', down=1, conv_clamp=None):
+        super().__init__()
+        self.activation, self.down, self.conv_clamp, self.padding = activation, down, conv_clamp, kernel_size // 2
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter([1, 3, 3, 1]))
+        self.weight_gain = 1 / math.sqrt(c_in * kernel_size ** 2)
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        self.weight = nn.Parameter(torch.randn(c_out, c_in, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.zeros(c_out)) if bias else None
+
+    def forward(self, x, gain=1.0):
+        w = (self.weight * self.weight_gain).to(x.dtype)
+        if self.down == 1:
+            x = F.conv2d(x, w, padding=self.padding)
+        elif w.shape[-1] == 1:
+            x = F.conv2d(upfirdn2d.upfirdn2d(x, self.resample_filter, down=2, padding=[1, 1, 1, 1]), w)
+        else:
+            p = self.padding + 1
+            x = F.conv2d(upfirdn2d.upfirdn2d(x, self.resample_filter, padding=[p, p, p, p]), w, stride=2)
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        b = self.bias.to(x.dtype) if self.bias is not None else None
+        return bias_act.bias_act(x, b, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+
+
+class DBlock(nn.Module):
+    """DiscriminatorBlock, 'resnet' architecture (networks_stylegan2.py:561-651)."""
+
+    def __init__(self, c_in, c_tmp, c_out, resolution, img_channels, use_fp16=False, conv_clamp=None):
+        super().__init__()
+        self.c_in, self.resolution, self.use_fp16 = c_in, resolution, use_fp16
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter([1, 3, 3, 1]))
+        if c_in == 0:
+            self.fromrgb = Conv(img_channels, c_tmp, 1, activation='lrelu', conv_clamp=conv_clamp)
+        self.conv0 = Conv(c_tmp, c_tmp, 3, activation='lrelu', conv_clamp=conv_clamp)
+        self.conv1 = Conv(c_tmp, c_out, 3, activation='lrelu', down=2, conv_clamp=conv_clamp)
+        self.skip = Conv(c_tmp, c_out, 1, bias=False, down=2)
+
+    def forward(self, x, img, force_fp32=False):
+        dtype = torch.float16 if self.use_fp16 and img.is_cuda and not force_fp32 else torch.float32
+        if self.c_in == 0:
+            x = self.fromrgb(img.to(dtype))
+        else:
+            x = x.to(dtype)
+        y = self.skip(x, gain=math.sqrt(0.5))
+        x = self.conv1(self.conv0(x), gain=math.sqrt(0.5))
+        return y.add_(x)
+
+
+def minibatch_std(x, group_size, num_channels=1):
+    """MinibatchStdLayer (networks_stylegan2.py:655-683): one extra feature map per channel group holding the standard
+    deviation over groups of `group_size` items, averaged over channels and pixels.  The batch must be a multiple of the group
+    size (the reference's reshape fails otherwise -- train.py's default group of 3 with 4 items per GPU)."""
+    n, c, h, w = x.shape
+    g = min(group_size, n) if group_size is not None else n
+    y = x.reshape(g, -1, num_channels, c // num_channels, h, w)
+    y = (y - y.mean(dim=0)).square().mean(dim=0).add(1e-8).sqrt().mean(dim=[2, 3, 4])         # [n/g, F]
+    return torch.cat([x, y.reshape(-1, num_channels, 1, 1).repeat(g, 1, h, w)], dim=1)
+
+
+class DEpilogue(nn.Module):
+    """DiscriminatorEpilogue (networks_stylegan2.py:687-744), 'resnet' architecture, conditioned by projection."""
+
+    def __init__(self, c_in, cmap_dim, resolution, mbstd_group_size=4, mbstd_num_channels=1, conv_clamp=None):
+        super().__init__()
+        self.cmap_dim, self.mbstd_group_size, self.mbstd_num_channels = cmap_dim, mbstd_group_size, mbstd_num_channels
+        self.conv = Conv(c_in + mbstd_num_channels, c_in, 3, activation='lrelu', conv_clamp=conv_clamp)
+        self.fc = Linear(c_in * resolution ** 2, c_in, activation='lrelu')
+        self.out = Linear(c_in, 1 if cmap_dim == 0 else cmap_dim)
+
+    def forward(self, x, cmap):
+        x = x.float()
+        if self.mbstd_num_channels > 0:
+            x = minibatch_std(x, self.mbstd_group_size, self.mbstd_num_channels)
+        x = self.out(self.fc(self.conv(x).flatten(1)))
+        if self.cmap_dim > 0:
+            x = (x * cmap).sum(dim=1, keepdim=True) * (1 / math.sqrt(self.cmap_dim))
+        return x
+
+
+class LabelMapping(nn.Module):
+    """MappingNetwork with z_dim = 0 and no broadcast (networks_stylegan2.py:200-272 as the discriminator builds it, :786):
+    the camera label -> cmap_dim features through `embed` and eight lrelu layers."""
+
+    def __init__(self, c_dim, w_dim, num_layers=8, lr_multiplier=0.01):
+        super().__init__()
+        self.num_layers = num_layers
+        self.embed = Linear(c_dim, w_dim)
+        for i in range(num_layers):
+            setattr(self, f'fc{i}', Linear(w_dim, w_dim, activation='lrelu', lr_multiplier=lr_multiplier))
+
+    def forward(self, c):
+        x = _second_moment_normalize(self.embed(c.float()))
+        for i in range(self.num_layers):
+            x = getattr(self, f'fc{i}')(x)
+        return x
+
+
+class Discriminator(nn.Module):
+    """networks_stylegan2.Discriminator (:748-799), 'resnet' blocks from img_resolution down to 8, epilogue at 4."""
+
+    def __init__(self, c_dim=25, img_resolution=64, img_channels=1, channel_base=32768, channel_max=512, num_fp16_res=4,
+                 conv_clamp=256, mbstd_group_size=4):
+        super().__init__()
+        self.c_dim = c_dim
+        log2 = int(math.log2(img_resolution))
+        self.block_resolutions = [2 ** i for i in range(log2, 2, -1)]
+        ch = {r: min(channel_base // r, channel_max) for r in self.block_resolutions + [4]}
+        fp16_resolution = max(2 ** (log2 + 1 - num_fp16_res), 8)
+        cmap_dim = ch[4] if c_dim > 0 else 0
+        for r in self.block_resolutions:
+            setattr(self, f'b{r}', DBlock(ch[r] if r < img_resolution else 0, ch[r], ch[r // 2], r, img_channels,
+                                          use_fp16=(r >= fp16_resolution), conv_clamp=conv_clamp))
+        if c_dim > 0:
+            self.mapping = LabelMapping(c_dim, cmap_dim)
+        self.b4 = DEpilogue(ch[4], cmap_dim, 4, mbstd_group_size=mbstd_group_size, conv_clamp=conv_clamp)
+
+    def forward(self, img, c, update_emas=False, force_fp32=False):
+        x = None
+        for r in self.block_resolutions:
+            x = getattr(self, f'b{r}')(x, img, force_fp32=force_fp32)
+        return self.b4(x, self.mapping(c) if self.c_dim > 0 else None)

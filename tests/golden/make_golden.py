@@ -284,8 +284,100 @@ def make_ops_cases():
     print('ops.npz', len(out), 'arrays')
 
 
+def _ffhq_g_kwargs():
+    """G_kwargs as train.py:238-377 assembles them from its option defaults (FFHQ configuration)."""
+    rendering = {
+        'image_resolution': 512, 'disparity_space_sampling': False, 'clamp_mode': 'softplus',
+        'superresolution_module': 'training.superresolution.SuperresolutionHybrid8XDC',
+        'c_gen_conditioning_zero': False, 'gpc_reg_prob': 0.5, 'c_scale': 1, 'superresolution_noise_mode': 'none',
+        'density_reg': 0.25, 'density_reg_p_dist': 0.004, 'reg_type': 'l1', 'decoder_lr_mul': 1, 'sr_antialias': True,
+        'depth_resolution': 48, 'depth_resolution_importance': 48,
+        'ray_start': 2.25, 'ray_end': 3.3, 'box_warp': 1, 'avg_camera_radius': 2.7, 'avg_camera_pivot': [0, 0, 0.2],
+    }
+    return dict(z_dim=512, w_dim=512, c_dim=25, img_resolution=512, img_channels=3,
+                mapping_kwargs=dict(num_layers=2), channel_base=32768, channel_max=512, fused_modconv_default='inference_only',
+                rendering_kwargs=rendering, num_fp16_res=0, conv_clamp=None, sr_num_fp16_res=4,
+                sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default='inference_only', w_dim=512))
+
+
+def make_generator_cases():
+    """BASELINE configs 3 and 5 from the reference's own classes on the CPU (fp32; the reference forces fp32 for CPU tensors):
+    generator_n4.npz  TriPlaneGenerator.synthesis at N=4, render resolution 64, noise_mode='const' (config 3);
+    train_step.npz    one G + D step of training_loop.py:314-437 (SSIM / VGG terms dropped) on the same
+                      generator in training mode and Discriminator(c_dim=25, img_resolution=64, img_channels=1,
+                      mbstd_group_size=4): loss terms and the norm of every parameter's gradient.
+    Weights, noise and the batch are functions of names / call indices (det_init.py), so only outputs are stored."""
+    import det_init as DI
+    from training.triplane import TriPlaneGenerator
+    from training.networks_stylegan2 import Discriminator
+    torch.set_num_threads(os.cpu_count() or 1)
+    torch.manual_seed(0)
+    G = DI.det_init_(TriPlaneGenerator(**_ffhq_g_kwargs()), 'G/').eval().requires_grad_(False)
+    batch = DI.synthetic_batch(4)
+    with torch.no_grad(), DI.DetNoise('config3'):
+        ws = G.mapping(batch['z'], batch['c'])
+        out = G.synthesis(ws, batch['c'], noise_mode='const', neural_rendering_resolution=64)
+        planes_absmax = float(G.backbone.synthesis(ws, noise_mode='const').abs().max())
+    img = out['image']
+    np.savez_compressed(os.path.join(HERE, 'generator_n4.npz'),
+                        ws_first=np_(ws[:, 0, :8]), image_raw=np_(out['image_raw']), image_depth=np_(out['image_depth']),
+                        image_sub=np_(img[:, :, 4::8, 4::8]), image_mean=np_(img.mean((1, 2, 3))), image_std=np_(img.std((1, 2, 3))),
+                        image_absmax=np.float32(img.abs().max()), planes_absmax=np.float32(planes_absmax))
+    print('generator_n4: image std', float(img.std()), 'absmax', float(img.abs().max()), 'raw absmax', float(out['image_raw'].abs().max()))
+
+    # ---- one training step (training_loop.py:314-437)
+    import torch.nn.functional as F
+    D = DI.det_init_(Discriminator(c_dim=25, img_resolution=64, img_channels=1, channel_base=32768, channel_max=512, num_fp16_res=4,
+                                   conv_clamp=256, block_kwargs={}, mapping_kwargs={}, epilogue_kwargs=dict(mbstd_group_size=4)), 'D/')
+    D.train().requires_grad_(False)
+    G.train().requires_grad_(True)
+    res, r1_gamma = 64, 1.0
+    # The reference's block64 adds its ToRGB output IN PLACE into a view of the feature image that its first convolution
+    # saved (superresolution.py:295 with triplane.py:86, networks_stylegan2.py:460): fine with fp16 blocks (the cast copies),
+    # an autograd error in fp32.  allow_mutation_on_saved_tensors gives the gradient of the values that were actually used.
+    with DI.DetNoise('config5'), torch.autograd.graph.allow_mutation_on_saved_tensors():
+        ws = G.mapping(batch['z'], batch['c'], update_emas=False)                                                   # :333
+        gen = G.synthesis(ws, batch['c'], neural_rendering_resolution=res, update_emas=False)                       # :335
+        real = batch['loss_image']
+        real_raw = F.interpolate(real, size=(res, res), mode='bilinear', align_corners=False, antialias=True)       # ssim_resize :180,:337
+        l1 = (real - gen['image']).abs().mean((1, 2, 3))                                                            # :349
+        l1_raw = (real_raw - gen['image_raw']).abs().mean((1, 2, 3))                                                # :343
+        factor = batch['factor']
+        gen_logits = D(gen['image_depth'], batch['c'])                                                              # :371
+        loss_gan = F.softplus(-gen_logits).mean()
+        loss = ((l1 + l1_raw) * factor).sum() / (factor.sum() + 1e-6) + 1.2 * loss_gan                              # :374
+        loss.backward()
+    g_names = [n for n, p_ in G.named_parameters() if p_.grad is not None]
+    g_norms = np.array([float(p_.grad.double().norm()) for n, p_ in G.named_parameters() if p_.grad is not None])
+    G.requires_grad_(False)
+    D.requires_grad_(True)                                                                                          # :402-423
+    d_gen_logits = D(gen['image_depth'].detach(), batch['c'])
+    loss_dgen = F.softplus(d_gen_logits)
+    loss_dgen.mean().backward()
+    real_depth = batch['depth_image'].detach().requires_grad_(True)
+    real_logits = D(real_depth, batch['condition_c'])
+    loss_dreal = F.softplus(-real_logits)
+    r1, = torch.autograd.grad(outputs=[real_logits.sum()], inputs=[real_depth], create_graph=True, only_inputs=True)
+    loss_r1 = r1.square().sum([1, 2, 3]) * (r1_gamma / 2)
+    (loss_dreal + loss_r1).mean().backward()
+    d_names = [n for n, p_ in D.named_parameters()]
+    d_norms = np.array([float(p_.grad.double().norm()) for n, p_ in D.named_parameters()])
+    np.savez_compressed(os.path.join(HERE, 'train_step.npz'),
+                        loss=np_(loss), l1=np_(l1), l1_raw=np_(l1_raw), loss_gan=np_(loss_gan), gen_logits=np_(gen_logits),
+                        d_gen_logits=np_(d_gen_logits), real_logits=np_(real_logits), loss_dgen=np_(loss_dgen.mean()),
+                        loss_dreal=np_(loss_dreal.mean()), loss_r1=np_(loss_r1), r1_gamma=np.float32(r1_gamma),
+                        image_raw=np_(gen['image_raw']), image_depth=np_(gen['image_depth']), image_sub=np_(gen['image'][:, :, 4::8, 4::8]),
+                        g_names=np.array(g_names), g_grad_norms=g_norms, d_names=np.array(d_names), d_grad_norms=d_norms,
+                        g_grad_decoder_w1=np_(G.decoder.net[0].weight.grad), d_grad_out_w=np_(D.b4.out.weight.grad[:4, :64]))
+    print('train_step: loss', float(loss), 'gan', float(loss_gan), 'r1', float(loss_r1.mean()), '|dG|', float(np.sqrt((g_norms ** 2).sum())),
+          '|dD|', float(np.sqrt((d_norms ** 2).sum())))
+
+
 def main():
     _import_reference()
+    sys.path.insert(0, HERE)
+    if len(sys.argv) > 1 and sys.argv[1] == 'generator':          # the two slow ones alone
+        return make_generator_cases()
     make_render_case('render_s12.npz', seed=1, N=2, res=8, S=12, F=12, plane_hw=(16, 16), plane_scale=2.0)
     make_render_case('render_s48.npz', seed=2, N=1, res=4, S=48, F=48, plane_hw=(20, 24), plane_scale=1.0)
     make_render_case('render_misc.npz', seed=3, N=1, res=4, S=8, F=8, plane_hw=(8, 8), plane_scale=3.0,
@@ -294,6 +386,7 @@ def main():
     make_stage_cases()
     make_camera_cases()
     make_ops_cases()
+    make_generator_cases()
 
 
 if __name__ == '__main__':
