@@ -950,10 +950,10 @@ def test_generator_forward_gpu_vs_cpu(dev):
     with torch.no_grad():
         ws = G.mapping(z, c)
         with _Replay([d.clone() for d in draws]):
-            ref = G.synthesis(ws, c, neural_rendering_resolution=res)
+            ref = G.synthesis(ws, c, neural_rendering_resolution=res, noise_mode='const')
         Gd = copy.deepcopy(G).to(dev)
         with _Replay([d.to(dev) for d in draws]):
-            out = Gd.synthesis(Gd.mapping(z.to(dev), c.to(dev)), c.to(dev), neural_rendering_resolution=res)
+            out = Gd.synthesis(Gd.mapping(z.to(dev), c.to(dev)), c.to(dev), neural_rendering_resolution=res, noise_mode='const')
     assert out['image'].shape == (1, 3, 512, 512) and out['image'].dtype == torch.float32
     scale = float(ref['image'].abs().max())
     assert 0.5 < scale < 3.0, scale

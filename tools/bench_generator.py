@@ -57,14 +57,14 @@ with torch.no_grad():
     z = torch.randn(N, 512, device=dev)
     c = torch.cat([H.camera_label(H.orbit_pose(7 * i, 240)) for i in range(N)]).to(dev)
     ws = G.mapping(z, c)
-    t, out = timed(lambda: G.synthesis(ws, c, neural_rendering_resolution=64), 10)
+    t, out = timed(lambda: G.synthesis(ws, c, neural_rendering_resolution=64, noise_mode='const'), 10)
     assert out['image'].shape == (N, 3, 512, 512) and torch.isfinite(out['image']).all()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     o, d = G.ray_sampler(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), 64)
     split = [0.0, 0.0, 0.0]
     for _ in range(5):
         ev[0].record()
-        planes = G.backbone.synthesis(ws)
+        planes = G.backbone.synthesis(ws, noise_mode='const')
         ev[1].record()
         feat, depth, _ = G.renderer(planes.view(N, 3, 32, 256, 256), G.decoder, o, d, G.rendering_kwargs)
         fi = feat.permute(0, 2, 1).reshape(N, 32, 64, 64).contiguous()
@@ -85,7 +85,7 @@ with torch.no_grad():
     for S in ((96, 48) if args.only != 3 else ()):
         G.rendering_kwargs['depth_resolution'] = G.rendering_kwargs['depth_resolution_importance'] = S
         cams = torch.cat([H.camera_label(H.orbit_pose(i, 240)) for i in range(args.frames)]).to(dev)
-        G.synthesis(ws1, cams[:1], neural_rendering_resolution=64, cache_backbone=True)
+        G.synthesis(ws1, cams[:1], neural_rendering_resolution=64, cache_backbone=True, noise_mode='const')
 
         def orbit():
             frames = []
