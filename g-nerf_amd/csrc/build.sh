@@ -31,3 +31,24 @@ for pid in "${pids[@]}"; do
 done
 $HIPCC -shared -fPIC --offload-arch=gfx950 "${objs[@]}" -o "$out"
 echo "[build] $out"
+
+# ---- the thin PyTorch-ROCm C++ extension over the same C ABI (host code only: g++, no device code)
+ext="$here/../gnerf_hip/gnerf_torch_ext.so"
+PY="${PYTHON:-python3}"
+stale=0
+[ -f "$ext" ] || stale=1
+for dep in "$here/torch_binding.cpp" "$root/include/gnerf_hip.h" "$here/build.sh"; do
+    [ "$stale" = 1 ] || { [ "$dep" -nt "$ext" ] && stale=1; } || true
+done
+if [ "$stale" = 1 ]; then
+    echo "[build] torch_binding.cpp"
+    read -r TORCH_DIR PY_INC CXX11 < <($PY -c "import os, sysconfig, torch; print(os.path.dirname(torch.__file__), sysconfig.get_paths()['include'], int(torch._C._GLIBCXX_USE_CXX11_ABI))")
+    rm -f "$ext"
+    g++ -O2 -std=c++17 -fPIC -shared -w -D__HIP_PLATFORM_AMD__=1 -DUSE_ROCM=1 -DTORCH_EXTENSION_NAME=gnerf_torch_ext \
+        -DTORCH_API_INCLUDE_EXTENSION_H -D_GLIBCXX_USE_CXX11_ABI=$CXX11 \
+        -I"$root/include" -I"$TORCH_DIR/include" -I"$TORCH_DIR/include/torch/csrc/api/include" -I/opt/rocm/include -I"$PY_INC" \
+        "$here/torch_binding.cpp" -o "$ext" \
+        -L"$TORCH_DIR/lib" -lc10 -lc10_hip -ltorch -ltorch_cpu -ltorch_hip -ltorch_python \
+        -L"$here/../gnerf_hip" -lgnerf_hip -Wl,-rpath,'$ORIGIN' -Wl,-rpath,"$TORCH_DIR/lib"
+    echo "[build] $ext"
+fi

@@ -111,6 +111,38 @@ def is_available():
     return os.path.isfile(LIB_PATH)
 
 
+# The thin PyTorch-ROCm C++ extension over the same C ABI (csrc/torch_binding.cpp -> gnerf_torch_ext.so): pybind entry points
+# with the reference plugins' exact signatures (bias_act.cpp:36, upfirdn2d.cpp:20, filtered_lrelu.cpp:20,217) plus
+# render_forward.  It is the default binding of the public ops (custom_ops.get_plugin) because a call costs ~3 us of host
+# time instead of ~11 through ctypes; GNERF_HIP_BINDING=ctypes forces the ctypes route, which stays complete and is what
+# everything falls back to when the extension has not been built.  Either way the kernels are libgnerf_hip.so's.
+EXT_PATH = os.path.join(_HERE, 'gnerf_torch_ext.so')
+_ext = None
+
+
+def ext():
+    """The extension module, or None (not built, or GNERF_HIP_BINDING=ctypes).  GNERF_HIP_BINDING=ext makes absence an error."""
+    global _ext
+    if _ext is None:
+        want = os.environ.get('GNERF_HIP_BINDING', '')
+        if want == 'ctypes' or os.environ.get('GNERF_HIP_LIB'):          # variant builds of the library are ctypes-only
+            _ext = False
+        elif not os.path.isfile(EXT_PATH):
+            if want == 'ext':
+                raise RuntimeError(f'{EXT_PATH} is missing: build it with g-nerf_amd/csrc/build.sh')
+            _ext = False
+        else:
+            load()
+            import importlib.util
+            spec = importlib.util.spec_from_file_location('gnerf_torch_ext', EXT_PATH)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            if mod.abi_version() != ABI_VERSION:
+                raise RuntimeError(f'gnerf_torch_ext.so was built against ABI {mod.abi_version()} != {ABI_VERSION}: rebuild (csrc/build.sh)')
+            _ext = mod
+    return _ext or None
+
+
 def _check(code, what):
     if code != 0:
         msg = load().gnerf_last_error().decode('utf-8', 'replace')
@@ -427,6 +459,7 @@ def make_rays(cam2world, intrinsics, resolution):
 
 
 _workspaces = {}
+_EMPTY = torch.empty([0])          # "absent tensor" for the C++ binding, as the reference's _null_tensor (bias_act.py:38)
 
 
 def _workspace(device):
@@ -516,6 +549,30 @@ def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
     mlp: decoder arithmetic, 'auto' (decided on the device from planes_absmax -- the one-element tensor planes_to_nhwc(...,
     with_absmax=True) returns; measured by the call itself when None -- and the decoder's weights), 'f16x3' or 'f32'.
     Returns (rgb [N,M,32], depth [N,M,1], wsum [N,M,1][, debug [N*M,8,S+F]])."""
+    e = ext()
+    if e is not None and not debug and planes_nhwc.dtype == torch.float32 and planes_nhwc.is_contiguous():
+        # the C++ binding: same validation and the same C ABI call, without ctypes marshalling
+        def f32c(t):
+            return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+        if mlp not in MLP_MODES:
+            raise RuntimeError(f"render_forward: mlp must be one of {sorted(MLP_MODES)}")
+        per_ray = isinstance(ray_start, torch.Tensor) or isinstance(ray_end, torch.Tensor)
+        dev = planes_nhwc.device
+        n, m_ = ray_origins.shape[0], ray_origins.shape[1]
+        if per_ray:
+            rs_t = f32c(ray_start if isinstance(ray_start, torch.Tensor) else torch.as_tensor(ray_start, device=dev).expand(n, m_, 1)).reshape(-1)
+            re_t = f32c(ray_end if isinstance(ray_end, torch.Tensor) else torch.as_tensor(ray_end, device=dev).expand(n, m_, 1)).reshape(-1)
+            rs, re = 0.0, 0.0
+        else:
+            rs_t = re_t = _EMPTY
+            rs, re = float(ray_start), float(ray_end)
+        w1, b1, w2, b2 = decoder
+        with _on_device(dev):
+            return e.render_forward(planes_nhwc, n_items, f32c(w1), f32c(b1), f32c(w2), f32c(b2), f32c(ray_origins), f32c(ray_dirs),
+                                    f32c(noise_coarse), _EMPTY if noise_fine is None else f32c(noise_fine),
+                                    int(depth_resolution), int(depth_resolution_importance), rs, re, rs_t, re_t, float(box_warp),
+                                    bool(white_back), bool(disparity_space_sampling), int(image_width),
+                                    _EMPTY if planes_absmax is None else planes_absmax, MLP_MODES[mlp], _workspace(dev))
     p, keep, m = _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine,
                                 depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
                                 white_back, disparity_space_sampling, image_width, 'render_forward', planes_absmax, mlp)

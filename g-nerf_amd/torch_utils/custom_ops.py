@@ -4,9 +4,11 @@ plugin's entry points; `verbosity` controls the status line.
 
 The reference JIT-compiles CUDA sources with nvcc at first use.  Here the three plugins are views of
 ONE ahead-of-time-built library, libgnerf_hip.so (hand-written gfx950 kernels, C ABI in
-include/gnerf_hip.h), bound through ctypes in gnerf_hip/__init__.py.  `sources`, `headers`,
-`source_dir` and the build keywords are accepted and ignored.  A missing library is an error: there is
-no silent fallback for GPU tensors."""
+include/gnerf_hip.h), reached through the thin PyTorch C++ extension gnerf_torch_ext.so
+(csrc/torch_binding.cpp: pybind entry points with the reference plugins' exact signatures), or through
+the ctypes binding in gnerf_hip/__init__.py when the extension is not built / GNERF_HIP_BINDING=ctypes.
+`sources`, `headers`, `source_dir` and the build keywords are accepted and ignored.  A missing library
+is an error: there is no silent fallback for GPU tensors."""
 
 import gnerf_hip
 
@@ -61,5 +63,9 @@ def get_plugin(module_name, sources, headers=None, source_dir=None, **build_kwar
     elif verbosity == 'brief':
         print('Done.')
     plugin = _PLUGINS[module_name]
+    ext = gnerf_hip.ext()
+    if ext is not None:                 # same entry points, C++ binding (lower host cost per call)
+        plugin = type(plugin.__name__ + 'Ext', (), {name: staticmethod(getattr(ext, name))
+                                                    for name in vars(plugin) if not name.startswith('_')})
     _cached_plugins[module_name] = plugin
     return plugin

@@ -924,6 +924,50 @@ def test_filtered_lrelu_fused_declines_what_it_does_not_cover(dev):
     np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
 
 
+def test_cpp_extension_and_ctypes_bindings_agree(dev):
+    """The two bindings of the C ABI -- gnerf_torch_ext (pybind, the default of the public ops) and ctypes -- reach the same
+    kernels: bit-identical results for bias_act (forward and both gradient orders), upfirdn2d (three variants, NCHW and
+    channels_last), filtered_lrelu (+ signs, + the -1 return code) and the fused renderer."""
+    import gnerf_hip
+    e = gnerf_hip.ext()
+    assert e is not None, 'gnerf_torch_ext.so missing on the GPU box'
+    null = torch.empty([0])
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 6, 9, 11, generator=gen).to(dev)
+    b = torch.randn(6, generator=gen).to(dev)
+    dy = torch.randn(2, 6, 9, 11, generator=gen).to(dev)
+    for dt in (torch.float32, torch.float16):
+        xx, bb, dd = x.to(dt), b.to(dt), dy.to(dt)
+        y1, y2 = e.bias_act(xx, bb, null, null, null, 0, 1, 3, 0.2, 1.41, 0.5), gnerf_hip.bias_act(xx, bb, None, None, None, 0, 1, 3, 0.2, 1.41, 0.5)
+        assert torch.equal(y1, y2)
+        g1, g2 = e.bias_act(dd, bb, null, y1, null, 1, 1, 3, 0.2, 1.41, 0.5), gnerf_hip.bias_act(dd, bb, None, y2, None, 1, 1, 3, 0.2, 1.41, 0.5)
+        assert torch.equal(g1, g2)
+        cl = xx.contiguous(memory_format=torch.channels_last)
+        assert torch.equal(e.bias_act(cl, bb, null, null, null, 0, 1, 5, 0.0, 1.0, -1.0), gnerf_hip.bias_act(cl, bb, None, None, None, 0, 1, 5, 0.0, 1.0, -1.0))
+        f = torch.tensor([[1., 3, 3, 1]], device=dev).t() @ torch.tensor([[1., 3, 3, 1]], device=dev) / 64
+        for args in ((1, 1, 1, 1, 1, 1, 1, 1, False, 4.0), (2, 2, 1, 1, 2, 1, 2, 1, False, 4.0), (1, 1, 2, 2, 1, 1, 1, 1, True, 1.0)):
+            for t in (xx, cl):
+                u1, u2 = e.upfirdn2d(t, f, *args), gnerf_hip.upfirdn2d(t, f, *args)
+                assert u1.stride() == u2.stride() and torch.equal(u1, u2)
+    f1 = torch.tensor([1., 3, 3, 1], device=dev) / 8
+    for write in (False, True):
+        a = e.filtered_lrelu(x, f1, f1, b, null, 2, 2, 3, 2, 3, 2, 0, 0, 1.41, 0.2, 0.8, False, write)
+        c = gnerf_hip.filtered_lrelu(x, f1, f1, b, None, 2, 2, 3, 2, 3, 2, 0, 0, 1.41, 0.2, 0.8, False, write)
+        assert a[2] == c[2] == 0 and torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    assert e.filtered_lrelu(x, f1, f1, b, null, 3, 3, 3, 2, 3, 2, 0, 0, 1.0, 0.2, -1.0, False, False)[2] == -1
+    xa, xb = x.clone(), x.clone()
+    assert torch.equal(e.filtered_lrelu_act_(xa, null, 0, 0, 1.41, 0.2, 0.5, True), gnerf_hip.filtered_lrelu_act_(xb, None, 0, 0, 1.41, 0.2, 0.5, True)) and torch.equal(xa, xb)
+    # renderer: the default route (extension) against the ctypes route forced through the debug flag's code path
+    planes, dec, o, d, nc, nf = _random_scene(3, N=2, res=8, S=48, F=48, hw=(16, 16))
+    nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
+    args = (nhwc, 2, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev))
+    kw = dict(depth_resolution=48, depth_resolution_importance=48, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=8)
+    via_ext = gnerf_hip.render_forward(*args, **kw)
+    via_ctypes = gnerf_hip.render_forward(*args, debug=True, **kw)[:3]
+    for p_, q_ in zip(via_ext, via_ctypes):
+        assert torch.equal(p_, q_)
+
+
 # ---- the whole generator around the hot path (callers in PyTorch/MIOpen, renderer + ops native) ----------------------
 
 def test_generator_forward_gpu_vs_cpu(dev):

@@ -50,6 +50,42 @@ def test_render_structs_match_header(struct, mirror):
     assert fields == [f[0] for f in getattr(gnerf_hip, mirror)._fields_]
 
 
+def test_torch_extension_binding_exports_the_reference_plugin_entry_points():
+    """gnerf_torch_ext.so (csrc/torch_binding.cpp) loads next to libgnerf_hip.so and exports pybind functions with the argument
+    lists of the reference's plugins (bias_act.cpp:36, upfirdn2d.cpp:20, filtered_lrelu.cpp:20, :217); get_plugin hands them out.
+    No compute here (no GPU): CPU tensors are refused by every entry point."""
+    import gnerf_hip
+    from torch_utils import custom_ops
+    e = gnerf_hip.ext()
+    assert e is not None, 'gnerf_torch_ext.so is not built (g-nerf_amd/csrc/build.sh)'
+    assert e.abi_version() == gnerf_hip.ABI_VERSION
+    want = {
+        'bias_act': '(arg0: torch.Tensor, arg1: torch.Tensor, arg2: torch.Tensor, arg3: torch.Tensor, arg4: torch.Tensor, arg5: typing.SupportsInt, '
+                    'arg6: typing.SupportsInt, arg7: typing.SupportsInt, arg8: typing.SupportsFloat, arg9: typing.SupportsFloat, arg10: typing.SupportsFloat) -> torch.Tensor',
+        'upfirdn2d': 12, 'filtered_lrelu': 18, 'filtered_lrelu_act_': 8,
+    }
+    for name, sig in want.items():
+        doc = getattr(e, name).__doc__
+        n_args = doc.split(' -> ')[0].count('arg')
+        assert n_args == (sig if isinstance(sig, int) else 11), (name, doc)
+    assert 'SupportsInt' in e.bias_act.__doc__ or 'int' in e.bias_act.__doc__
+    custom_ops._cached_plugins.clear()
+    old = custom_ops.verbosity
+    custom_ops.verbosity = 'none'
+    try:
+        assert custom_ops.get_plugin('bias_act_plugin', sources=[]).bias_act is e.bias_act
+        assert custom_ops.get_plugin('upfirdn2d_plugin', sources=[]).upfirdn2d is e.upfirdn2d
+        fl = custom_ops.get_plugin('filtered_lrelu_plugin', sources=[])
+        assert fl.filtered_lrelu is e.filtered_lrelu and fl.filtered_lrelu_act_ is e.filtered_lrelu_act_
+    finally:
+        custom_ops.verbosity = old
+    x, null = torch.zeros(2, 3, 4, 4), torch.empty([0])
+    with pytest.raises(RuntimeError, match='CUDA device'):
+        e.bias_act(x, null, null, null, null, 0, 1, 1, 0.0, 1.0, -1.0)
+    with pytest.raises(RuntimeError, match='CUDA device'):
+        e.upfirdn2d(x, torch.ones(2, 2), 1, 1, 1, 1, 0, 0, 0, 0, False, 1.0)
+
+
 def test_gpu_ops_refuse_cpu_tensors():
     """The native entry points never compute on the host."""
     import gnerf_hip
