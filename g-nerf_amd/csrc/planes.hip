@@ -18,10 +18,19 @@ constexpr int CT = 32, PT = 64;   // channel x pixel tile
 // max |x| as an unsigned compare of the sign-stripped bits: orders like the floats for finite values and +inf, and any
 // NaN compares above +inf, so a NaN in the input survives as a NaN in the result.
 __device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+// One atomic per WORKGROUP at most, and only when it would raise the published value: thousands of same-address atomics
+// serialise at the memory side (49 152 of them -- one per wave -- made the 37 us repack take 0.5 ms).  The pre-check reads the
+// word with a device-scope atomic load; a stale or racing read only costs a redundant atomicMax, never a wrong result.
 __device__ __forceinline__ void publish_absmax(unsigned m, unsigned* out) {
+    __shared__ unsigned wave_max[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned b = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+        if (b > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, b);
+    }
 }
 
 template <bool STATS>
