@@ -73,6 +73,72 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     publish_absmax(amax, absmax);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The tri-plane PRODUCER's last step, fused and writing the renderer's layout directly.
+// The backbone's final block ends with  img = upsample2d(img) + torgb(x)  (networks_stylegan2.py:456-463: the 4x4 low-pass
+// filter after x2 zero insertion, gain 4, then an add), and triplane.py:74 views the result as three 32-channel planes.
+// This kernel computes that sum and stores it CHANNELS-LAST: [n, 2h, 2w, c] memory = the interleaved plane layout the render
+// kernels address directly (gnerf_render_params.planes_interleaved), plus max |planes| for the decoder-arithmetic choice --
+// in place of an NCHW upsample, an NCHW add, and a 100 MB layout change.
+// Workgroup = 4 x 32 output pixels x 32 channels.  Phase A (lanes along x: coalesced NCHW reads of y, input window of img in
+// LDS) makes the sums into an LDS tile; phase B (lanes along channels) writes whole 128-byte channel groups.
+struct Up2Taps { float k[4][4]; };      // effective taps: gain * (f flipped unless flip)
+
+constexpr int kUpCh = 32, kUpRows = 4, kUpCols = 32, kUpInPitch = 4 * 18 + 1, kUpOutPitch = kUpCh + 1;
+
+__global__ __launch_bounds__(256) void upsample2x_add_nhwc_kernel(const float* __restrict__ img, const float* __restrict__ y, Up2Taps K,
+                                                                  float* __restrict__ out, int c, int h, int w, unsigned* absmax) {
+    __shared__ float in[kUpCh * kUpInPitch];
+    __shared__ float ot[kUpRows * kUpCols * kUpOutPitch];
+    const int OH = 2 * h, OW = 2 * w;
+    const int tiles_x = OW / kUpCols, tiles_y = OH / kUpRows, groups = c / kUpCh;
+    int b = blockIdx.x;
+    const int tx0 = b % tiles_x; b /= tiles_x;
+    const int ty0 = b % tiles_y; b /= tiles_y;
+    const int cg0 = b % groups;  b /= groups;
+    const int n = b;
+    const int ox0 = tx0 * kUpCols, oy0 = ty0 * kUpRows, c0 = cg0 * kUpCh;
+    const int ix0 = ox0 / 2 - 1, iy0 = oy0 / 2 - 1;
+    const float* img_n = img + (int64_t(n) * c + c0) * h * w;
+    for (int e = threadIdx.x; e < kUpCh * 4 * 18; e += 256) {
+        const int ch = e / 72, r = (e % 72) / 18, cc = e % 18;
+        const int iy = iy0 + r, ix = ix0 + cc;
+        float v = 0.f;
+        if (iy >= 0 && iy < h && ix >= 0 && ix < w) v = img_n[(int64_t(ch) * h + iy) * w + ix];
+        in[ch * kUpInPitch + r * 18 + cc] = v;
+    }
+    __syncthreads();
+    {
+        const int tx = threadIdx.x & 31, ty = (threadIdx.x >> 5) & 3, cg = threadIdx.x >> 7;
+        const int ry = ty & 1, rx = tx & 1;
+        const float k00 = K.k[ry][rx], k01 = K.k[ry][rx + 2], k10 = K.k[ry + 2][rx], k11 = K.k[ry + 2][rx + 2];
+        const int r = (ty >> 1) + ry, cc = (tx >> 1) + rx;
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        const float* y_px = y ? y + ((int64_t(n) * c + c0) * OH + oy) * OW + ox : nullptr;
+#pragma unroll 4
+        for (int q = 0; q < 16; q++) {
+            const int ch = cg * 16 + q;
+            const float* win = in + ch * kUpInPitch + r * 18 + cc;
+            float v = k00 * win[0] + k01 * win[1] + k10 * win[18] + k11 * win[19];
+            if (y_px) v += y_px[int64_t(ch) * OH * OW];
+            ot[(ty * kUpCols + tx) * kUpOutPitch + ch] = v;
+        }
+    }
+    __syncthreads();
+    unsigned amax = 0u;
+    {
+        const int ch = threadIdx.x & 31, p0 = threadIdx.x >> 5;
+#pragma unroll 4
+        for (int q = 0; q < 16; q++) {
+            const int px = p0 + 8 * q;                          // pixel of the tile: row px / 32, column px % 32
+            const float v = ot[px * kUpOutPitch + ch];
+            out[((int64_t(n) * OH + oy0 + (px >> 5)) * OW + ox0 + (px & 31)) * c + c0 + ch] = v;
+            amax = max(amax, abs_bits(v));
+        }
+    }
+    if (absmax) publish_absmax(amax, absmax);
+}
+
 // The inverse layout change, for the gradient of the planes: [plane, y, x, channel] -> [plane, channel, y, x].
 // Reads whole texels, writes rows along x.
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
@@ -170,6 +236,23 @@ extern "C" int gnerf_planes_to_nhwc(const float* planes_nchw, float* planes_nhwc
 extern "C" int gnerf_planes_to_nhwc_stats(const float* planes_nchw, float* planes_nhwc, int np, int c, int h, int w,
                                           float* absmax, gnerf_stream_t stream) {
     return planes_to_nhwc_impl(planes_nchw, planes_nhwc, np, c, h, w, absmax, true, stream);
+}
+
+extern "C" int gnerf_upsample2x_add_nhwc(const float* img, const float* y, const float* f_host, int flip, float gain, float* out,
+                                         int n, int c, int h, int w, float* absmax, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!img || !f_host || !out) return fail(GNERF_E_ARG, "upsample2x_add_nhwc: null pointer");
+    if (n < 1 || c < 1 || h < 1 || w < 1) return fail(GNERF_E_ARG, "upsample2x_add_nhwc: empty tensor");
+    if (c % kUpCh != 0 || (2 * w) % kUpCols != 0 || (2 * h) % kUpRows != 0) return fail(GNERF_E_UNSUPPORTED, "upsample2x_add_nhwc: needs channels %% 32 == 0, width %% 16 == 0, height %% 2 == 0");
+    const int64_t blocks = int64_t(n) * (c / kUpCh) * (2 * h / kUpRows) * (2 * w / kUpCols);
+    if (blocks > INT32_MAX || int64_t(n) * c * 4 * h * w > INT32_MAX * int64_t(2)) return fail(GNERF_E_ARG, "upsample2x_add_nhwc: tensor too large");
+    Up2Taps K;
+    for (int ky = 0; ky < 4; ky++)
+        for (int kx = 0; kx < 4; kx++) K.k[ky][kx] = gain * (flip ? f_host[ky * 4 + kx] : f_host[(3 - ky) * 4 + (3 - kx)]);
+    if (absmax && hipMemsetAsync(absmax, 0, sizeof(float), as_stream(stream)) != hipSuccess) return fail(GNERF_E_LAUNCH, "upsample2x_add_nhwc: memset failed");
+    hipLaunchKernelGGL(upsample2x_add_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), img, y, K, out, c, h, w,
+                       reinterpret_cast<unsigned*>(absmax));
+    return check_launch("upsample2x_add_nhwc");
 }
 
 extern "C" int gnerf_planes_absmax(const float* planes, int64_t numel, float* absmax, gnerf_stream_t stream) {

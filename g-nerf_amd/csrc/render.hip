@@ -56,6 +56,7 @@ struct Params {
     int tiles_per_item, tiles_y;   // image tiling (0 when rays are not an image)
     int total_rays;
     int split_shift;        // small launches: a 16-ray tile is shared by 1 << split_shift workgroups (coop / generic kernels)
+    unsigned tex_pitch, row_pitch, plane_pitch;     // byte addressing of a texel, see plane_taps (render_coop.inl)
     const int* mlp_flag;    // GNERF_MLP_AUTO: device word holding the chosen decoder arithmetic (kMlpF16x3 / kMlpF32); NULL = run
 };
 
@@ -172,7 +173,8 @@ __device__ __forceinline__ void load_weights(Weights& w, const gnerf_render_para
 
 // Bilinear lookup of one plane for this lane's sample; adds (weight * 4 channels) into acc.
 // u indexes W, v indexes H (grid_sample, align_corners=False, zero padding; renderer.py:64).
-__device__ __forceinline__ void lookup_plane(v4f& acc, const float* __restrict__ plane, int H, int W, float u, float v, int cq) {
+__device__ __forceinline__ void lookup_plane(v4f& acc, const float* __restrict__ plane, int H, int W, unsigned tex_q, unsigned row_q, float u, float v, int cq) {
+    // tex_q / row_q: texel and row pitch in 16-byte units
     float ix = ((u + 1.f) * float(W) - 1.f) * 0.5f;
     float iy = ((v + 1.f) * float(H) - 1.f) * 0.5f;
     ix = fminf(fmaxf(ix, -1.5f), float(W) + 0.5f);     // keeps "everything out of range" out of range, and int conversion safe
@@ -188,10 +190,10 @@ __device__ __forceinline__ void lookup_plane(v4f& acc, const float* __restrict__
     const float w10 = (vx0 && vy1) ? (1.f - fx) * fy : 0.f;
     const float w11 = (vx1 && vy1) ? fx * fy : 0.f;
     const v4f* base = reinterpret_cast<const v4f*>(plane) + cq;
-    const v4f t00 = base[(cy0 * W + cx0) * 8];
-    const v4f t01 = base[(cy0 * W + cx1) * 8];
-    const v4f t10 = base[(cy1 * W + cx0) * 8];
-    const v4f t11 = base[(cy1 * W + cx1) * 8];
+    const v4f t00 = base[cy0 * row_q + cx0 * tex_q];
+    const v4f t01 = base[cy0 * row_q + cx1 * tex_q];
+    const v4f t10 = base[cy1 * row_q + cx0 * tex_q];
+    const v4f t11 = base[cy1 * row_q + cx1 * tex_q];
     acc += t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11;
 }
 
@@ -201,7 +203,8 @@ __device__ __forceinline__ void shade(const Params& P, const Weights& w, const S
                                       float ox, float oy, float oz, float dx, float dy, float dz,
                                       int e0, int count, int ntiles, int tile0, int lane) {
     const int H = P.p.plane_h, W = P.p.plane_w;
-    const int64_t plane_stride = int64_t(H) * W * 32;
+    const int64_t plane_stride = P.plane_pitch / 4;
+    const unsigned tex_q = P.tex_pitch / 16, row_q = P.row_pitch / 16;
     const int b = lane >> 3, cq = lane & 7;     // lookup layout: sample-in-step, channel quad
     const int j = lane & 15, g = lane >> 4;     // MFMA layout: sample-in-tile, k group
     for (int t = 0; t < ntiles; t++) {
@@ -215,9 +218,9 @@ __device__ __forceinline__ void shade(const Params& P, const Weights& w, const S
             const float py = __fadd_rn(oy, __fmul_rn(depth, dy)) * P.box_scale;
             const float pz = __fadd_rn(oz, __fmul_rn(depth, dz)) * P.box_scale;
             v4f acc = {0.f, 0.f, 0.f, 0.f};
-            lookup_plane(acc, planes_item, H, W, px, py, cq);                          // plane 0: (x, y)
-            lookup_plane(acc, planes_item + plane_stride, H, W, px, pz, cq);           // plane 1: (x, z)
-            lookup_plane(acc, planes_item + 2 * plane_stride, H, W, pz, px, cq);       // plane 2: (z, x)
+            lookup_plane(acc, planes_item, H, W, tex_q, row_q, px, py, cq);                          // plane 0: (x, y)
+            lookup_plane(acc, planes_item + plane_stride, H, W, tex_q, row_q, px, pz, cq);           // plane 1: (x, z)
+            lookup_plane(acc, planes_item + 2 * plane_stride, H, W, tex_q, row_q, pz, px, cq);       // plane 2: (z, x)
             acc *= (1.f / 3.f);                                                         // mean over planes, triplane.py:126
             *reinterpret_cast<v4f*>(lds.stage + js * kStagePitch + 4 * cq) = acc;
         }
@@ -561,14 +564,16 @@ __global__ __launch_bounds__(64) void query_kernel(gnerf_render_params p, float 
     __shared__ __align__(16) float stage[16 * kStagePitch];
     const int lane = threadIdx.x;
     const int H = p.plane_h, W = p.plane_w;
-    const int64_t plane_stride = int64_t(H) * W * 32;
+    const int64_t item_stride = int64_t(3) * H * W * 32;
+    const int64_t plane_stride = p.planes_interleaved ? 32 : int64_t(H) * W * 32;
+    const unsigned tex_q = p.planes_interleaved ? 24 : 8, row_q = tex_q * unsigned(W);
     const int b = lane >> 3, cq = lane & 7, j = lane & 15, g = lane >> 4;
     Weights w;
     load_weights(w, p, lane);
     const int tiles_per_item = (n_points + 15) / 16;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int item = tile / tiles_per_item, t = tile % tiles_per_item;
-        const float* planes_item = p.planes_nhwc + int64_t(item) * 3 * plane_stride;
+        const float* planes_item = p.planes_nhwc + int64_t(item) * item_stride;
         const float* pts = points + int64_t(item) * n_points * 3;
 #pragma unroll
         for (int a = 0; a < 2; a++) {
@@ -576,9 +581,9 @@ __global__ __launch_bounds__(64) void query_kernel(gnerf_render_params p, float 
             const int idx = min(16 * t + js, n_points - 1);
             const float px = pts[idx * 3 + 0] * box_scale, py = pts[idx * 3 + 1] * box_scale, pz = pts[idx * 3 + 2] * box_scale;
             v4f acc = {0.f, 0.f, 0.f, 0.f};
-            lookup_plane(acc, planes_item, H, W, px, py, cq);
-            lookup_plane(acc, planes_item + plane_stride, H, W, px, pz, cq);
-            lookup_plane(acc, planes_item + 2 * plane_stride, H, W, pz, px, cq);
+            lookup_plane(acc, planes_item, H, W, tex_q, row_q, px, py, cq);
+            lookup_plane(acc, planes_item + plane_stride, H, W, tex_q, row_q, px, pz, cq);
+            lookup_plane(acc, planes_item + 2 * plane_stride, H, W, tex_q, row_q, pz, px, cq);
             acc *= (1.f / 3.f);
             *reinterpret_cast<v4f*>(stage + js * kStagePitch + 4 * cq) = acc;
         }
@@ -700,7 +705,15 @@ int check_common(const gnerf_render_params* p) {
     if (int64_t(p->n_items) * 3 * p->plane_h * p->plane_w * 32 > INT32_MAX * int64_t(4))
         return fail(GNERF_E_ARG, "render: planes too large");
     if (!(p->box_warp > 0.f)) return fail(GNERF_E_ARG, "render: box_warp must be positive");
+    if (p->planes_interleaved != 0 && p->planes_interleaved != 1) return fail(GNERF_E_ARG, "render: planes_interleaved must be 0 or 1");
     return GNERF_OK;
+}
+
+void fill_pitches(Params& P) {
+    const unsigned W = unsigned(P.p.plane_w), H = unsigned(P.p.plane_h);
+    P.tex_pitch = P.p.planes_interleaved ? 384u : 128u;
+    P.row_pitch = P.tex_pitch * W;
+    P.plane_pitch = P.p.planes_interleaved ? 128u : H * W * 128u;
 }
 
 }  // namespace
@@ -723,6 +736,8 @@ static int fill_params(const gnerf_render_params* p, Params& P) {
     if (total * (S + F) > INT32_MAX * int64_t(8)) return fail(GNERF_E_ARG, "render: too many samples in one call");
 
     P.p = *p;
+    fill_pitches(P);
+    if (P.row_pitch >= (1u << 24)) return fail(GNERF_E_UNSUPPORTED, "render: plane rows wider than 2^24 bytes");
     P.box_scale = float(2.0 / double(p->box_warp));
     P.delta = float((double(p->ray_end) - double(p->ray_start)) / double(S - 1));
     P.inv_start = float(1.0 / double(p->ray_start));
@@ -867,9 +882,10 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
 extern "C" int gnerf_query_points(const float* planes_nhwc, int n_items, int plane_h, int plane_w,
                                   const float* points, int n_points, float box_warp,
                                   const float* w1, const float* b1, const float* w2, const float* b2,
-                                  float* out_sigma, float* out_rgb, gnerf_stream_t stream) {
+                                  float* out_sigma, float* out_rgb, int planes_interleaved, gnerf_stream_t stream) {
     using namespace gnerf;
     gnerf_render_params p = {};
+    p.planes_interleaved = planes_interleaved;
     p.planes_nhwc = planes_nhwc; p.n_items = n_items; p.plane_h = plane_h; p.plane_w = plane_w;
     p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.box_warp = box_warp;
     if (int e = check_common(&p)) return e;
@@ -888,10 +904,11 @@ extern "C" int gnerf_query_points_backward(const float* planes_nhwc, int n_items
                                            const float* w1, const float* b1, const float* w2, const float* b2,
                                            const float* grad_sigma, const float* grad_rgb,
                                            float* grad_planes_nhwc, float* grad_w1, float* grad_b1, float* grad_w2, float* grad_b2,
-                                           gnerf_stream_t stream) {
+                                           int planes_interleaved, gnerf_stream_t stream) {
     using namespace gnerf;
     Params P = {};
     gnerf_render_params& p = P.p;
+    p.planes_interleaved = planes_interleaved;
     p.planes_nhwc = planes_nhwc; p.n_items = n_items; p.plane_h = plane_h; p.plane_w = plane_w;
     p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.box_warp = box_warp;
     if (int e = check_common(&p)) return e;
@@ -902,6 +919,7 @@ extern "C" int gnerf_query_points_backward(const float* planes_nhwc, int n_items
     if ((!grad_planes_nhwc && n_dec == 0) || (!grad_sigma && !grad_rgb)) return GNERF_OK;
     if (!(int64_t(plane_h) * plane_w * 3 * 128 < (int64_t(1) << 32))) return fail(GNERF_E_UNSUPPORTED, "query_points_backward: planes too large for 32-bit tap offsets");
     P.box_scale = float(2.0 / double(box_warp));
+    fill_pitches(P);
     QueryBwdArgs Q;
     Q.points = points; Q.grad_sigma = grad_sigma; Q.grad_rgb = grad_rgb; Q.n_points = n_points;
     Q.tiles_per_item = (n_points + 15) / 16;

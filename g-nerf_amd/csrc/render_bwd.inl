@@ -107,7 +107,7 @@ __device__ __forceinline__ void bwd_gather_tile(const Params& P, const BwdLds& L
         pos(j, px, py, pz);
         const float u = pl == 2 ? pz : px;
         const float v = pl == 0 ? py : (pl == 1 ? pz : px);
-        plane_taps(H, W, u, v, unsigned(pl) * unsigned(H) * unsigned(W) * 128u, my_off, my_wgt);
+        plane_taps(H, W, u, v, P.tex_pitch, P.row_pitch, unsigned(pl) * P.plane_pitch, my_off, my_wgt);
         float* rec = L.hbuf + j * kTapDwords + pl * 8;
         *reinterpret_cast<uint4*>(rec) = my_off;
         *reinterpret_cast<v4f*>(rec + 4) = my_wgt;

@@ -116,7 +116,10 @@ __device__ __forceinline__ float sigmoid_rgb_hw(float x) {      // sigmoid(x) * 
 
 // Taps of one plane for one sample: 4 byte offsets into the plane (clamped, always safe to load) and the
 // 4 bilinear weights (zero where the tap is outside the image; the 1/3 of the plane mean folded in).
-__device__ __forceinline__ void plane_taps(int H, int W, float u, float v, unsigned plane_bytes_off, uint4& off, v4f& wgt) {
+// Byte addressing of a texel: y * row_pitch + x * tex_pitch + plane offset (Params::tex_pitch / row_pitch / plane_pitch):
+// [3N,H,W,32] planes have tex_pitch 128, plane offset pl * H * W * 128; the interleaved [N,H,W,96] form (channels_last of the
+// backbone's [N,96,H,W] output) has tex_pitch 384, plane offset pl * 128.  Pitches and coordinates are < 2^24: 24-bit multiplies.
+__device__ __forceinline__ void plane_taps(int H, int W, float u, float v, unsigned tex_pitch, unsigned row_pitch, unsigned plane_bytes_off, uint4& off, v4f& wgt) {
     float ix = ((u + 1.f) * float(W) - 1.f) * 0.5f;
     float iy = ((v + 1.f) * float(H) - 1.f) * 0.5f;
     ix = fminf(fmaxf(ix, -1.5f), float(W) + 0.5f);
@@ -126,9 +129,9 @@ __device__ __forceinline__ void plane_taps(int H, int W, float u, float v, unsig
     const int x0 = int(x0f), y0 = int(y0f), x1 = x0 + 1, y1 = y0 + 1;
     const float wx0 = (x0 >= 0 && x0 < W) ? 1.f - fx : 0.f, wx1 = (x1 >= 0 && x1 < W) ? fx : 0.f;
     const float wy0 = (y0 >= 0 && y0 < H) ? (1.f - fy) * (1.f / 3.f) : 0.f, wy1 = (y1 >= 0 && y1 < H) ? fy * (1.f / 3.f) : 0.f;
-    const unsigned cx0 = unsigned(min(max(x0, 0), W - 1)) * 128u, cx1 = unsigned(min(max(x1, 0), W - 1)) * 128u;
-    const unsigned cy0 = unsigned(min(max(y0, 0), H - 1)) * unsigned(W) * 128u + plane_bytes_off;
-    const unsigned cy1 = unsigned(min(max(y1, 0), H - 1)) * unsigned(W) * 128u + plane_bytes_off;
+    const unsigned cx0 = __umul24(unsigned(min(max(x0, 0), W - 1)), tex_pitch), cx1 = __umul24(unsigned(min(max(x1, 0), W - 1)), tex_pitch);
+    const unsigned cy0 = __umul24(unsigned(min(max(y0, 0), H - 1)), row_pitch) + plane_bytes_off;
+    const unsigned cy1 = __umul24(unsigned(min(max(y1, 0), H - 1)), row_pitch) + plane_bytes_off;
     off = make_uint4(cy0 + cx0, cy0 + cx1, cy1 + cx0, cy1 + cx1);
     wgt = (v4f){wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
 }
@@ -249,7 +252,7 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
         const float u = pl == 2 ? pz : px;                               // plane 0 (x,y), 1 (x,z), 2 (z,x)
         const float v = pl == 0 ? py : (pl == 1 ? pz : px);
         uint4 off; v4f wgt;
-        plane_taps(H, W, u, v, unsigned(pl) * unsigned(H) * unsigned(W) * 128u, off, wgt);
+        plane_taps(H, W, u, v, P.tex_pitch, P.row_pitch, unsigned(pl) * P.plane_pitch, off, wgt);
         float* rec = taps + j * kTapDwords + pl * 8;
         *reinterpret_cast<uint4*>(rec) = off;
         *reinterpret_cast<v4f*>(rec + 4) = wgt;

@@ -209,7 +209,7 @@ Tensor filtered_lrelu_act_(Tensor x, Tensor si, int sx, int sy, float gain, floa
 
 // ------------------------------------------------------------------------------------------------ the fused renderer
 
-// planes_nhwc [3N,H,W,32] f32 contiguous; w1,b1,w2,b2 effective f32 weights; rays [N,M,3]; noise_coarse [N*M*S]; noise_fine [N*M*F] or
+// planes_nhwc [3N,H,W,32] (or interleaved [N,H,W,96]) f32 contiguous; w1,b1,w2,b2 effective f32 weights; rays [N,M,3]; noise_coarse [N*M*S]; noise_fine [N*M*F] or
 // empty; ray_start_t / ray_end_t per-ray limits or empty (then the scalars are used); planes_absmax one float or empty; workspace uint8
 // (zeroed once by the caller).  Returns (rgb [N,M,32], depth [N,M,1], wsum [N,M,1]).
 std::tuple<Tensor, Tensor, Tensor> render_forward(Tensor planes_nhwc, int64_t n_items, Tensor w1, Tensor b1, Tensor w2, Tensor b2,
@@ -222,7 +222,9 @@ std::tuple<Tensor, Tensor, Tensor> render_forward(Tensor planes_nhwc, int64_t n_
     };
     f32c(planes_nhwc, "planes_nhwc"); f32c(w1, "w1"); f32c(b1, "b1"); f32c(w2, "w2"); f32c(b2, "b2");
     f32c(ray_origins, "ray_origins"); f32c(ray_dirs, "ray_dirs"); f32c(noise_coarse, "noise_coarse");
-    TORCH_CHECK(planes_nhwc.dim() == 4 && planes_nhwc.size(3) == 32 && planes_nhwc.size(0) == 3 * n_items, "render_forward: planes_nhwc must be [3N,H,W,32]");
+    const bool separate = planes_nhwc.dim() == 4 && planes_nhwc.size(3) == 32 && planes_nhwc.size(0) == 3 * n_items;
+    const bool interleaved = planes_nhwc.dim() == 4 && planes_nhwc.size(3) == 96 && planes_nhwc.size(0) == n_items;
+    TORCH_CHECK(separate || interleaved, "render_forward: planes_nhwc must be [3N,H,W,32] or [N,H,W,96]");
     TORCH_CHECK(w1.numel() == 64 * 32 && b1.numel() == 64 && w2.numel() == 33 * 64 && b2.numel() == 33, "render_forward: decoder must be the 32->64->33 MLP");
     TORCH_CHECK(ray_origins.dim() == 3 && ray_origins.size(0) == n_items && ray_origins.size(2) == 3 && ray_dirs.sizes() == ray_origins.sizes(), "render_forward: rays must be [N,M,3]");
     const int64_t m = ray_origins.size(1), S = depth_resolution, F = depth_resolution_importance;
@@ -252,6 +254,7 @@ std::tuple<Tensor, Tensor, Tensor> render_forward(Tensor planes_nhwc, int64_t n_
     p.workspace = workspace.data_ptr(); p.debug = nullptr;
     p.planes_absmax = present(planes_absmax) ? planes_absmax.data_ptr<float>() : nullptr;
     p.mlp_mode = int32_t(mlp_mode);
+    p.planes_interleaved = interleaved ? 1 : 0;
     check_rc(gnerf_render_forward(&p, current_stream()), "gnerf_render_forward");
     return std::make_tuple(rgb, depth, wsum);
 }

@@ -175,9 +175,12 @@ class Block(nn.Module):
     """SynthesisBlock, 'skip' architecture (networks_stylegan2.py:371-470): [const | conv0 (x up)] -> conv1 -> ToRGB added to
     the (upsampled) running image."""
 
-    def __init__(self, c_in, c_out, w_dim, resolution, img_channels, is_last, use_fp16=False, conv_clamp=None, up=2):
+    def __init__(self, c_in, c_out, w_dim, resolution, img_channels, is_last, use_fp16=False, conv_clamp=None, up=2, emit_channels_last=False):
         super().__init__()
         self.c_in, self.up, self.use_fp16, self.is_last = c_in, up, use_fp16, is_last
+        # The backbone's final block: its `upsample2d(img) + torgb(x)` IS the tri-plane image.  One fused kernel writes it
+        # channels_last (memory [N,H,W,96]), the layout the fused renderer reads in place (SURVEY section 8f.2).
+        self.emit_channels_last = emit_channels_last
         self.register_buffer('resample_filter', upfirdn2d.setup_filter([1, 3, 3, 1]))
         if c_in == 0:
             self.const = nn.Parameter(torch.randn(c_out, resolution, resolution))
@@ -197,9 +200,11 @@ class Block(nn.Module):
         else:
             x = self.conv0(x.to(dtype), ws[0], noise_mode, fused=fused)
             x = self.conv1(x, ws[1], noise_mode, fused=fused)
+        y = self.torgb(x, ws[-1], fused=fused).float()
+        if img is not None and self.up == 2 and self.emit_channels_last and img.is_cuda:
+            return x, upfirdn2d.upsample2d_add_channels_last(img, y, self.resample_filter)
         if img is not None and self.up == 2:
             img = upfirdn2d.upsample2d(img, self.resample_filter)
-        y = self.torgb(x, ws[-1], fused=fused).float()
         if img is None:
             return x, y
         if torch.is_grad_enabled() and (img.requires_grad or y.requires_grad):
@@ -213,13 +218,14 @@ class Block(nn.Module):
 class Synthesis(nn.Module):
     """SynthesisNetwork (networks_stylegan2.py:474-525): blocks b4 ... b<resolution>."""
 
-    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512):
+    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, emit_channels_last=False):
         super().__init__()
         self.block_resolutions = [2 ** i for i in range(2, int(math.log2(img_resolution)) + 1)]
         ch = {r: min(channel_base // r, channel_max) for r in self.block_resolutions}
         self.num_ws = 0
         for r in self.block_resolutions:
-            blk = Block(ch[r // 2] if r > 4 else 0, ch[r], w_dim, r, img_channels, is_last=(r == img_resolution))
+            blk = Block(ch[r // 2] if r > 4 else 0, ch[r], w_dim, r, img_channels, is_last=(r == img_resolution),
+                        emit_channels_last=(r == img_resolution and emit_channels_last))
             self.num_ws += blk.num_conv + (blk.num_torgb if r == img_resolution else 0)
             setattr(self, f'b{r}', blk)
 
@@ -277,12 +283,12 @@ FFHQ_RENDERING = {
 class Generator(nn.Module):
     """TriPlaneGenerator (triplane.py:19-108), FFHQ configuration (train.py:238-377)."""
 
-    def __init__(self, z_dim=512, c_dim=25, w_dim=512, rendering_kwargs=None, sr_use_fp16=True):
+    def __init__(self, z_dim=512, c_dim=25, w_dim=512, rendering_kwargs=None, sr_use_fp16=True, planes_channels_last=True):
         super().__init__()
         self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
         self.rendering_kwargs = dict(FFHQ_RENDERING if rendering_kwargs is None else rendering_kwargs)
         self.renderer, self.ray_sampler = ImportanceRenderer(), RaySampler()
-        self.backbone = Backbone(z_dim, c_dim, w_dim, img_resolution=256, img_channels=96)
+        self.backbone = Backbone(z_dim, c_dim, w_dim, img_resolution=256, img_channels=96, emit_channels_last=planes_channels_last)
         self.superresolution = SuperRes8XDC(32, w_dim, use_fp16=sr_use_fp16, antialias=self.rendering_kwargs.get('sr_antialias', True))
         self.decoder = H.TriPlaneDecoder(32, self.rendering_kwargs.get('decoder_lr_mul', 1), 32)
         self.neural_rendering_resolution = 64

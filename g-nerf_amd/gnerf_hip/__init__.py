@@ -23,7 +23,7 @@ _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.float64: F64}
 
 MAX_SAMPLES = 256
 DEBUG_SLOTS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 # decoder arithmetic of the fused renderer (GNERF_MLP_* in include/gnerf_hip.h)
 MLP_MODES = {'auto': 0, 'f16x3': 1, 'f32': 2}
 
@@ -46,7 +46,7 @@ class RenderParams(ctypes.Structure):
         ('noise_coarse', _c_p), ('noise_fine', _c_p),
         ('out_rgb', _c_p), ('out_depth', _c_p), ('out_wsum', _c_p),
         ('workspace', _c_p), ('debug', _c_p),
-        ('planes_absmax', _c_p), ('mlp_mode', ctypes.c_int32),
+        ('planes_absmax', _c_p), ('mlp_mode', ctypes.c_int32), ('planes_interleaved', ctypes.c_int32),
     ]
 
 
@@ -82,9 +82,10 @@ SIGNATURES = {
     'gnerf_render_workspace_bytes': (ctypes.c_size_t, []),
     'gnerf_render_forward': (_c_i, [ctypes.POINTER(RenderParams), _c_p]),
     'gnerf_render_backward': (_c_i, [ctypes.POINTER(RenderParams), ctypes.POINTER(RenderGrads), _c_p]),
-    'gnerf_query_points': (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    'gnerf_query_points': (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_p]),
     'gnerf_query_points_backward': (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
-                                           _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
+                                           _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_p]),
+    'gnerf_upsample2x_add_nhwc': (_c_i, [_c_p, _c_p, ctypes.POINTER(_c_f), _c_i, _c_f, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
 }
 
 
@@ -471,6 +472,55 @@ def _workspace(device):
     return ws
 
 
+def planes_layout(planes_nhwc, n_items, what):
+    """0 for [3N,H,W,32] (one NHWC image per plane), 1 for [N,H,W,96] (planes interleaved per texel: channels_last memory of the
+    backbone's [N,96,H,W] output).  Anything else raises."""
+    if planes_nhwc.dtype != torch.float32 or not planes_nhwc.is_contiguous() or planes_nhwc.ndim != 4:
+        raise RuntimeError(f'{what}: planes must be a contiguous float32 4-D tensor')
+    if planes_nhwc.shape[3] == 32 and planes_nhwc.shape[0] == 3 * n_items:
+        return 0
+    if planes_nhwc.shape[3] == 96 and planes_nhwc.shape[0] == n_items:
+        return 1
+    raise RuntimeError(f'{what}: planes_nhwc must be [3N,H,W,32] or [N,H,W,96] (3 planes of 32 channels per item)')
+
+
+def upsample2x_add_nhwc(img, y, f, flip=False, gain=4.0, with_absmax=False):
+    """upfirdn2d(img, f, up=2, padding=[2,1,2,1], gain) + y written channels_last in one launch (the tri-plane producer's last
+    step, networks_stylegan2.py:456-463).  img [N,C,h,w], y [N,C,2h,2w] or None, both float32 NCHW-contiguous; f the 4x4 filter.
+    Returns a [N,C,2h,2w] tensor with channels_last strides (its memory is [N,2h,2w,C]) and, with_absmax, max |out| [1].
+    Returns None when the kernel does not cover the shape (C % 32, w % 16, h % 2) -- the caller composes the ops instead."""
+    _require_cuda(img, y)
+    if img.dtype != torch.float32 or img.ndim != 4 or not img.is_contiguous() or tuple(f.shape) != (4, 4):
+        return None
+    n, c, h, w = img.shape
+    if c % 32 or w % 16 or h % 2:
+        return None
+    if y is not None and (y.dtype != torch.float32 or tuple(y.shape) != (n, c, 2 * h, 2 * w) or not y.is_contiguous()):
+        return None
+    taps = _filter_taps(f)
+    out = torch.empty([n, c, 2 * h, 2 * w], dtype=torch.float32, device=img.device, memory_format=torch.channels_last)
+    amax = torch.empty([1], dtype=torch.float32, device=img.device) if with_absmax else None
+    with _on_device(img.device):
+        code = load().gnerf_upsample2x_add_nhwc(_ptr(img), _ptr(y), taps, 1 if flip else 0, float(gain), _ptr(out), n, c, h, w, _ptr(amax), _stream(img))
+    _check(code, 'gnerf_upsample2x_add_nhwc')
+    return (out, amax) if with_absmax else out
+
+
+_filter_tap_cache = {}
+
+
+def _filter_taps(f):
+    """The 16 taps of a 4x4 filter as a host float array (one device read per filter tensor and version, then cached)."""
+    key = (f.data_ptr(), f._version if not f.is_inference() else None, f.device)
+    taps = _filter_tap_cache.get(key)
+    if taps is None:
+        if len(_filter_tap_cache) > 64:
+            _filter_tap_cache.clear()
+        taps = (ctypes.c_float * 16)(*f.detach().float().cpu().reshape(-1).tolist())
+        _filter_tap_cache[key] = taps
+    return taps
+
+
 def last_mlp_choice(device):
     """Decoder arithmetic the last mlp='auto' render call on `device`'s current stream picked: 'f16x3' or 'f32' (None if no such
     call ran).  Reads the render workspace (synchronises); for tests and diagnostics."""
@@ -491,10 +541,7 @@ def _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
 
     def f32c(t):
         return t.to(torch.float32).contiguous()
-    if planes_nhwc.dtype != torch.float32 or not planes_nhwc.is_contiguous() or planes_nhwc.ndim != 4 or planes_nhwc.shape[3] != 32:
-        raise RuntimeError(f'{what}: planes_nhwc must be contiguous float32 [3N,H,W,32]')
-    if planes_nhwc.shape[0] != 3 * n_items:
-        raise RuntimeError(f'{what}: planes_nhwc must hold 3 planes per item')
+    interleaved = planes_layout(planes_nhwc, n_items, what)
     if tuple(w1.shape) != (64, 32) or tuple(b1.shape) != (64,) or tuple(w2.shape) != (33, 64) or tuple(b2.shape) != (33,):
         raise RuntimeError(f'{what}: decoder must be the 32->64->33 OSGDecoder MLP')
     o, d = f32c(ray_origins), f32c(ray_dirs)
@@ -538,6 +585,7 @@ def _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
         if planes_absmax.dtype != torch.float32 or planes_absmax.numel() != 1:
             raise RuntimeError(f'{what}: planes_absmax must be a one-element float32 device tensor')
     p.planes_absmax = _ptr(planes_absmax)
+    p.planes_interleaved = interleaved
     return p, (planes_nhwc, o, d, nc, nf, w1, b1, w2, b2, rs_t, re_t, planes_absmax), m
 
 
@@ -635,11 +683,12 @@ def query_points(planes_nhwc, n_items, decoder, points, box_warp, want_rgb=True)
     if pts.ndim != 3 or pts.shape[0] != n_items or pts.shape[2] != 3:
         raise RuntimeError('query_points: points must be [N,P,3]')
     n_pts = pts.shape[1]
+    interleaved = planes_layout(planes_nhwc, n_items, 'query_points')
     sigma = torch.empty([n_items, n_pts, 1], dtype=torch.float32, device=pts.device)
     rgb = torch.empty([n_items, n_pts, 32], dtype=torch.float32, device=pts.device) if want_rgb else None
     with _on_device(pts.device):
         code = load().gnerf_query_points(_ptr(planes_nhwc), n_items, planes_nhwc.shape[1], planes_nhwc.shape[2], _ptr(pts), n_pts,
-                                         float(box_warp), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(sigma), _ptr(rgb), _stream(pts))
+                                         float(box_warp), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(sigma), _ptr(rgb), interleaved, _stream(pts))
     _check(code, 'gnerf_query_points')
     return sigma, rgb
 
@@ -649,9 +698,7 @@ def query_points_backward(planes_nhwc, n_items, decoder, points, box_warp, grad_
     Returns (grad_planes_nhwc or None, (grad_w1, grad_b1, grad_w2, grad_b2) or None), float32."""
     w1, b1, w2, b2 = [t.to(torch.float32).contiguous() for t in decoder]
     _require_cuda(planes_nhwc, points, w1, grad_sigma, grad_rgb)
-    if planes_nhwc.dtype != torch.float32 or not planes_nhwc.is_contiguous() or planes_nhwc.ndim != 4 or planes_nhwc.shape[3] != 32 \
-            or planes_nhwc.shape[0] != 3 * n_items:
-        raise RuntimeError('query_points_backward: planes_nhwc must be contiguous float32 [3N,H,W,32]')
+    interleaved = planes_layout(planes_nhwc, n_items, 'query_points_backward')
     pts = points.to(torch.float32).contiguous()
     if pts.ndim != 3 or pts.shape[0] != n_items or pts.shape[2] != 3:
         raise RuntimeError('query_points_backward: points must be [N,P,3]')
@@ -670,6 +717,6 @@ def query_points_backward(planes_nhwc, n_items, decoder, points, box_warp, grad_
     with _on_device(dev):
         code = load().gnerf_query_points_backward(_ptr(planes_nhwc), n_items, planes_nhwc.shape[1], planes_nhwc.shape[2], _ptr(pts), n_pts,
                                                   float(box_warp), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(gs), _ptr(gc),
-                                                  _ptr(g_planes), _ptr(gd[0]), _ptr(gd[1]), _ptr(gd[2]), _ptr(gd[3]), _stream(pts))
+                                                  _ptr(g_planes), _ptr(gd[0]), _ptr(gd[1]), _ptr(gd[2]), _ptr(gd[3]), interleaved, _stream(pts))
     _check(code, 'gnerf_query_points_backward')
     return g_planes, g_dec

@@ -206,6 +206,60 @@ def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1, impl='cuda'):
     return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * upx * upy, impl=impl)
 
 
+# ---------------------------------------------------------------------------------------------
+# Producing the tri-planes in the renderer's layout.  NOT part of the reference's interface.
+
+# Output shapes (C, H, W) for which upsample2d(up=2, 4x4 filter, float32 NCHW input on a GPU) returns a channels_last tensor:
+# same values, same shape, different strides.  ImportanceRenderer fills it in with the shape of the planes it is handed when
+# GNERF_NHWC_PLANES=1 (opt-in: in the reference's SynthesisBlock the next op is `img.add_(y)` with an NCHW `y`, a strided
+# add), so that the backbone's last skip-image upsample writes the planes' memory as [N, H, W, 96] and the renderer reads it
+# without a layout change.  This repo's own generator does not need the hint: it calls upsample2d_add_channels_last.
+channels_last_output_shapes = set()
+
+
+class _UpsampleAddChannelsLast(torch.autograd.Function):
+    """upsample2d(img, f) + y in one launch, written channels_last (gnerf_hip.upsample2x_add_nhwc)."""
+
+    @staticmethod
+    def forward(ctx, img, y, f, flip_filter, gain):
+        import gnerf_hip
+        out, amax = gnerf_hip.upsample2x_add_nhwc(img, y, f, flip=flip_filter, gain=gain, with_absmax=True)
+        out._gnerf_absmax = (out._version, amax)              # max |out|, for the renderer's decoder-arithmetic choice
+        ctx.save_for_backward(f)
+        ctx.has_y = y is not None
+        ctx.cfg_t = _transposed(_Config(2, 2, 1, 1, 2, 1, 2, 1, flip_filter, gain), f, img.shape[2:], out.shape[2:])
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (f,) = ctx.saved_tensors
+        d_img = d_y = None
+        if ctx.needs_input_grad[0]:             # the adjoint of the x2 upsample: the transposed configuration, as in _Resample
+            d_img = _Resample.apply(d_out.contiguous(), f, ctx.cfg_t)
+        if ctx.has_y and ctx.needs_input_grad[1]:
+            d_y = d_out
+        return d_img, d_y, None, None, None
+
+
+def upsample2d_add_channels_last(img, y, f, flip_filter=False, gain=1):
+    """upsample2d(img, f, up=2, gain=gain) + y (y may be None), as a [N,C,2H,2W] tensor whose MEMORY is channels_last
+    ([N,2H,2W,C]) -- for C = 96 exactly the interleaved tri-plane layout the fused renderer reads in place.  One kernel on a
+    GPU for float32 NCHW inputs with C % 32 == 0; anything else composes upsample2d and the add (NCHW result)."""
+    if img.device.type == 'cuda' and img.dtype == torch.float32 and isinstance(f, torch.Tensor) and tuple(f.shape) == (4, 4) \
+            and img.is_contiguous() and img.shape[1] % 32 == 0 and img.shape[3] % 16 == 0 and img.shape[2] % 2 == 0 \
+            and (y is None or (y.dtype == torch.float32 and y.is_contiguous() and y.shape[1:] == (img.shape[1], 2 * img.shape[2], 2 * img.shape[3]))) and _init():
+        if torch.is_grad_enabled() and (img.requires_grad or (y is not None and y.requires_grad)):
+            return _UpsampleAddChannelsLast.apply(img, y, f, flip_filter, gain * 4)
+        return _UpsampleAddChannelsLast.forward(_NoCtx(), img, y, f, flip_filter, gain * 4)
+    out = upsample2d(img, f, flip_filter=flip_filter, gain=gain)
+    return out if y is None else out.add_(y) if not (torch.is_grad_enabled() and (out.requires_grad or y.requires_grad)) else out + y
+
+
+class _NoCtx:
+    def save_for_backward(self, *a):
+        pass
+
+
 def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1, impl='cuda'):
     """Downsample by `down`; by default the output is exactly 1/down of the input size."""
     downx, downy = _parse_scaling(down)

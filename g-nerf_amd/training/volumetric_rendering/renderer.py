@@ -37,6 +37,7 @@ import os
 import gnerf_hip
 
 _KEEP_NHWC = os.environ.get('GNERF_KEEP_NHWC', '1') != '0'
+_NHWC_HINT = os.environ.get('GNERF_NHWC_PLANES', '0') == '1'
 
 
 def generate_planes():
@@ -77,6 +78,24 @@ def sample_from_3dgrid(grid, coordinates):
     return out.permute(0, 4, 3, 2, 1).reshape(N, H * W * D, C)
 
 
+def _interleaved_view(planes):
+    """If `planes` [N,3,32,H,W] is a view of a channels_last [N,96,H,W] tensor -- memory [N,H,W,96], what a producer that writes
+    channels_last hands over (torch_utils.ops.upfirdn2d.upsample2d_add_channels_last; triplane.py:74's view keeps the strides) --
+    return that memory as a contiguous [N,H,W,96] view; else None.  The render kernels address this layout in place."""
+    if planes.ndim != 5 or planes.dtype != torch.float32:
+        return None
+    N, P, C, H, W = planes.shape
+    if planes.stride() != (P * C * H * W, C, 1, P * C * W, P * C) or N * P * C * H * W == 0:
+        return None
+    return planes.permute(0, 3, 4, 1, 2).reshape(N, H, W, P * C)
+
+
+def _planes_from_interleaved(g, like):
+    """[N,H,W,96] gradient in the interleaved layout -> a [N,3,32,H,W] view of it (the strides of `like`)."""
+    N, P, C, H, W = like.shape
+    return g.view(N, H, W, P, C).permute(0, 3, 4, 1, 2)
+
+
 def _osg_decoder_weights(decoder):
     """Return the effective (w1,b1,w2,b2) of an OSGDecoder-shaped module (triplane.py:113-122:
     FullyConnectedLayer(32,64) -> Softplus -> FullyConnectedLayer(64,33), both 'linear' with bias),
@@ -103,13 +122,18 @@ class _FusedRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, planes, w1, b1, w2, b2, ray_origins, ray_dirs, noise_c, noise_f, ray_start, ray_end, cfg):
         N = planes.shape[0]
-        nhwc, amax = gnerf_hip.planes_to_nhwc(planes.detach().float(), with_absmax=True)
+        nhwc = _interleaved_view(planes.detach())
+        ctx.interleaved = nhwc is not None
+        if ctx.interleaved:
+            amax = _producer_absmax(planes)                 # None: the launcher measures it
+        else:
+            nhwc, amax = gnerf_hip.planes_to_nhwc(planes.detach().float(), with_absmax=True)
         out = gnerf_hip.render_forward(nhwc, N, (w1, b1, w2, b2), ray_origins, ray_dirs, noise_c, noise_f,
                                        ray_start=ray_start, ray_end=ray_end, planes_absmax=amax, **cfg)
         tensors = [planes, w1, b1, w2, b2, ray_origins, ray_dirs, noise_c]
         # The NHWC copy is kept for the backward pass (the planes' size again: 25 MB per item) unless GNERF_KEEP_NHWC=0, in
         # which case the backward pass repacks the saved NCHW planes a second time (37 us per 100 MB).
-        ctx.nhwc = nhwc if _KEEP_NHWC else None
+        ctx.nhwc = nhwc if (_KEEP_NHWC and not ctx.interleaved) else None
         ctx.has_fine = noise_f is not None
         ctx.limits_are_tensors = isinstance(ray_start, torch.Tensor)
         if ctx.has_fine:
@@ -133,18 +157,33 @@ class _FusedRender(torch.autograd.Function):
         need_planes = ctx.needs_input_grad[0]
         need_decoder = any(ctx.needs_input_grad[1:5])
         N = planes.shape[0]
-        nhwc = ctx.nhwc if ctx.nhwc is not None else gnerf_hip.planes_to_nhwc(planes.detach().float())
+        if ctx.interleaved:
+            nhwc = _interleaved_view(planes.detach())
+        else:
+            nhwc = ctx.nhwc if ctx.nhwc is not None else gnerf_hip.planes_to_nhwc(planes.detach().float())
         g_planes, g_dec = gnerf_hip.render_backward(nhwc, N, (w1, b1, w2, b2), ray_origins, ray_dirs, noise_c, noise_f, g_rgb, g_depth, g_wsum,
                                                     ray_start=ray_start, ray_end=ray_end, need_planes=need_planes, need_decoder=need_decoder,
                                                     **ctx.cfg)
         grads = [None] * 12
         if need_planes:
-            grads[0] = gnerf_hip.planes_from_nhwc(g_planes, N).to(planes.dtype)     # contiguous NCHW, like the planes themselves
+            if ctx.interleaved:
+                grads[0] = _planes_from_interleaved(g_planes, planes)                # laid out like the planes themselves: no repack
+            else:
+                grads[0] = gnerf_hip.planes_from_nhwc(g_planes, N).to(planes.dtype)     # contiguous NCHW, like the planes themselves
         if need_decoder:
             for i, (g, t) in enumerate(zip(g_dec, (w1, b1, w2, b2))):
                 if ctx.needs_input_grad[1 + i]:
                     grads[1 + i] = g.to(t.dtype)
         return tuple(grads)
+
+
+def _producer_absmax(planes):
+    """max |planes| left on the producer's output by upsample2d_add_channels_last (valid while that tensor is unmodified)."""
+    base = planes._base if planes._base is not None else planes
+    tag = getattr(base, '_gnerf_absmax', None)
+    if tag is not None and not base.is_inference() and tag[0] == base._version:
+        return tag[1]
+    return None
 
 
 class _FusedQuery(torch.autograd.Function):
@@ -153,7 +192,9 @@ class _FusedQuery(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, planes, w1, b1, w2, b2, points, box_warp):
-        nhwc = gnerf_hip.planes_to_nhwc(planes.detach().float())
+        nhwc = _interleaved_view(planes.detach())
+        if nhwc is None:
+            nhwc = gnerf_hip.planes_to_nhwc(planes.detach().float())
         sigma, rgb = gnerf_hip.query_points(nhwc, planes.shape[0], (w1, b1, w2, b2), points, box_warp)
         ctx.save_for_backward(planes, w1, b1, w2, b2, points)
         ctx.box_warp = box_warp
@@ -166,12 +207,15 @@ class _FusedQuery(torch.autograd.Function):
         need_planes = ctx.needs_input_grad[0]
         need_decoder = any(ctx.needs_input_grad[1:5])
         N = planes.shape[0]
-        nhwc = gnerf_hip.planes_to_nhwc(planes.detach().float())
+        nhwc = _interleaved_view(planes.detach())
+        interleaved = nhwc is not None
+        if not interleaved:
+            nhwc = gnerf_hip.planes_to_nhwc(planes.detach().float())
         g_planes, g_dec = gnerf_hip.query_points_backward(nhwc, N, (w1, b1, w2, b2), points, ctx.box_warp, g_sigma, g_rgb,
                                                           need_planes=need_planes, need_decoder=need_decoder)
         grads = [None] * 7
         if need_planes:
-            grads[0] = gnerf_hip.planes_from_nhwc(g_planes, N).to(planes.dtype)
+            grads[0] = _planes_from_interleaved(g_planes, planes) if interleaved else gnerf_hip.planes_from_nhwc(g_planes, N).to(planes.dtype)
         if need_decoder:
             for i, (g, t) in enumerate(zip(g_dec, (w1, b1, w2, b2))):
                 if ctx.needs_input_grad[1 + i]:
@@ -224,6 +268,14 @@ class ImportanceRenderer(torch.nn.Module):
         """(NHWC copy, max |planes|) of `planes`, cached on the tensor's identity and version: an orbit with cached backbone
         planes (triplane.py:66-71) converts once.  Inference tensors carry no version counter: they are converted every call.
         The cached copy is only handed to work on the stream that made it (another stream converts again, for itself)."""
+        inter = _interleaved_view(planes.detach() if not planes.is_inference() else planes)
+        if inter is not None:                               # already the renderer's layout (a channels_last producer): no copy
+            amax = _producer_absmax(planes)
+            if amax is not None or planes.is_inference():
+                return inter, amax                          # (None: the launcher measures max |planes| itself)
+        elif _NHWC_HINT and planes.ndim == 5 and planes.shape[1] == 3:
+            from torch_utils.ops import upfirdn2d           # opt-in: ask the producer for channels_last planes from now on
+            upfirdn2d.channels_last_output_shapes.add((planes.shape[1] * planes.shape[2], planes.shape[3], planes.shape[4]))
         if planes.is_inference():
             return gnerf_hip.planes_to_nhwc(planes.float(), with_absmax=True)
         base = planes._base if planes._base is not None else planes
@@ -234,7 +286,10 @@ class ImportanceRenderer(torch.nn.Module):
             if ref() is base and version == base._version and ptr == planes.data_ptr() and shape == tuple(planes.shape) \
                     and (made_on is None or made_on == stream):
                 return out
-        out = gnerf_hip.planes_to_nhwc(planes.detach().float(), with_absmax=True)
+        if inter is not None:
+            out = (inter, gnerf_hip.planes_absmax(inter))   # measured once per planes tensor and version, like the repack
+        else:
+            out = gnerf_hip.planes_to_nhwc(planes.detach().float(), with_absmax=True)
         self.__dict__['_gnerf_planes_cache'] = (weakref.ref(base), base._version, planes.data_ptr(), tuple(planes.shape), stream, out)
         return out
 
@@ -244,7 +299,12 @@ class ImportanceRenderer(torch.nn.Module):
         graph bakes in their addresses, so whoever replays it must hold the handle and call `repin(handle)` before a replay
         if other planes went through this renderer in between (gen_videos_mi355x.FrameProgram does)."""
         base = planes._base if planes._base is not None else planes
-        out = gnerf_hip.planes_to_nhwc(planes.detach().float(), with_absmax=True)
+        inter = _interleaved_view(planes.detach())
+        if inter is not None:
+            amax = _producer_absmax(planes)
+            out = (inter, gnerf_hip.planes_absmax(inter) if amax is None else amax)
+        else:
+            out = gnerf_hip.planes_to_nhwc(planes.detach().float(), with_absmax=True)
         torch.cuda.synchronize(planes.device)
         handle = (weakref.ref(base), base._version, planes.data_ptr(), tuple(planes.shape), None, out)
         self.__dict__['_gnerf_planes_cache'] = handle

@@ -20,6 +20,7 @@
  *   gnerf_make_rays         <- RaySampler.forward                  training/volumetric_rendering/ray_sampler.py:24-63
  *   gnerf_planes_to_nhwc    <- (layout change feeding the renderer; the reference keeps NCHW, triplane.py:74)
  *   gnerf_planes_to_nhwc_stats / gnerf_planes_absmax <- (the same + max |planes|, which picks the decoder arithmetic)
+ *   gnerf_upsample2x_add_nhwc <- the backbone's last `upsample2d(img) + torgb(x)` (networks_stylegan2.py:456-463), channels_last
  *   gnerf_planes_from_nhwc  <- (the same for the plane gradient on the way back)
  *   gnerf_render_backward   <- autograd through renderer.py:88-140 (grid_sample_gradfix.py:62-77 for the planes)
  */
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GNERF_ABI_VERSION 2
+#define GNERF_ABI_VERSION 3
 
 /* error codes */
 #define GNERF_OK            0
@@ -135,6 +136,15 @@ int gnerf_planes_to_nhwc_stats(const float* planes_nchw, float* planes_nhwc, int
                                float* absmax, gnerf_stream_t stream);
 /* max |x| over `numel` floats (any layout) -> *absmax (one device float, overwritten). */
 int gnerf_planes_absmax(const float* planes, int64_t numel, float* absmax, gnerf_stream_t stream);
+/* The tri-plane producer's last step, writing the renderer's layout directly (no layout change afterwards):
+ *   out = upfirdn2d(img, f, up=2, padding=[2,1,2,1], gain) + y          (networks_stylegan2.py:456-463, upfirdn2d.py:315-350)
+ * img [n, c, h, w] float32 NCHW contiguous; y [n, c, 2h, 2w] float32 NCHW contiguous or NULL; f_host: the 4x4 filter, 16 floats
+ * in HOST memory (row-major; flipped inside unless `flip`, like gnerf_upfirdn2d); out: [n, 2h, 2w, c] = channels_last memory of
+ * [n, c, 2h, 2w], i.e. for c = 96 the interleaved plane layout (gnerf_render_params.planes_interleaved = 1).
+ * absmax: optional device float receiving max |out| (gnerf_render_params.planes_absmax).
+ * Returns GNERF_E_UNSUPPORTED unless c % 32 == 0, w % 16 == 0 and h % 2 == 0. */
+int gnerf_upsample2x_add_nhwc(const float* img, const float* y, const float* f_host, int flip, float gain, float* out,
+                              int n, int c, int h, int w, float* absmax, gnerf_stream_t stream);
 /* The inverse, NHWC [np, h, w, c] -> NCHW [np, c, h, w]: hands gnerf_render_backward's plane gradient back in the layout
  * of the reference's planes (triplane.py:74). */
 int gnerf_planes_from_nhwc(const float* planes_nhwc, float* planes_nchw, int np, int c, int h, int w,
@@ -199,6 +209,12 @@ typedef struct gnerf_render_params {
        (more than 96+96 samples, gnerf_query_points, both backward passes) ignore these two fields. */
     const float* planes_absmax;
     int32_t mlp_mode;
+    /* Layout of `planes_nhwc` (and of gnerf_render_grads.grad_planes_nhwc, which always mirrors it):
+       0: [n_items*3, plane_h, plane_w, 32]  one NHWC image per plane (what gnerf_planes_to_nhwc makes);
+       1: [n_items, plane_h, plane_w, 96]    the three planes of an item interleaved per texel = the channels_last memory of the
+          backbone's own [n_items, 96, plane_h, plane_w] output (triplane.py:69-74), plane p = channels 32p..32p+31.  A
+          producer that writes channels_last (gnerf_upsample2x_add_nhwc) feeds the renderer with no layout change at all. */
+    int32_t planes_interleaved;
 } gnerf_render_params;
 
 #define GNERF_MLP_AUTO  0
@@ -243,11 +259,12 @@ int gnerf_render_backward(const gnerf_render_params* p, const gnerf_render_grads
 /* Density / colour of arbitrary points (run_model, renderer.py:142-148; used by
  * TriPlaneGenerator.sample / sample_mixed for shape extraction):
  * points [n_items, n_points, 3] -> sigma [n_items, n_points, 1], rgb [n_items, n_points, 32].
- * out_rgb may be NULL: densities only (the 512^3 shape extraction of gen_videos.py:189-224 reads nothing else). */
+ * out_rgb may be NULL: densities only (the 512^3 shape extraction of gen_videos.py:189-224 reads nothing else).
+ * planes_interleaved: layout of planes_nhwc, as gnerf_render_params.planes_interleaved. */
 int gnerf_query_points(const float* planes_nhwc, int n_items, int plane_h, int plane_w,
                        const float* points, int n_points, float box_warp,
                        const float* w1, const float* b1, const float* w2, const float* b2,
-                       float* out_sigma, float* out_rgb, gnerf_stream_t stream);
+                       float* out_sigma, float* out_rgb, int planes_interleaved, gnerf_stream_t stream);
 
 /* Gradient of gnerf_query_points: grad_sigma [n_items, n_points, 1] and grad_rgb [n_items, n_points, 32] (either may be
  * NULL) -> ACCUMULATED into grad_planes_nhwc and the four decoder gradients (same conventions as gnerf_render_backward).
@@ -257,7 +274,7 @@ int gnerf_query_points_backward(const float* planes_nhwc, int n_items, int plane
                                 const float* w1, const float* b1, const float* w2, const float* b2,
                                 const float* grad_sigma, const float* grad_rgb,
                                 float* grad_planes_nhwc, float* grad_w1, float* grad_b1, float* grad_w2, float* grad_b2,
-                                gnerf_stream_t stream);
+                                int planes_interleaved, gnerf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -380,6 +380,123 @@ def test_planes_absmax(dev):
     assert float(gnerf_hip.planes_absmax(x)) == float('inf')
 
 
+def test_render_interleaved_plane_layout(dev):
+    """The renderer reads the producer's channels_last planes in place: planes as [N,H,W,96] (the three planes of an item
+    interleaved per texel = channels_last memory of the backbone's [N,96,H,W] output) give bit-identical forward results to the
+    [3N,H,W,32] layout on every forward kernel, the same point queries, and the same gradients (laid out like the planes)."""
+    import gnerf_hip
+    for S, F in ((48, 48), (96, 96), (40, 0), (130, 100)):                       # pipe<1>, pipe<2>, coop, generic
+        planes, dec, o, d, nc, nf = _random_scene(17, N=2, res=8, S=S, F=F, hw=(24, 20))
+        N = 2
+        sep = gnerf_hip.planes_to_nhwc(planes.to(dev))                                           # [6,24,20,32]
+        inter = planes.to(dev).reshape(N, 96, 24, 20).permute(0, 2, 3, 1).contiguous()           # [2,24,20,96]
+        args = (N, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev) if F else None)
+        kw = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=8)
+        a = gnerf_hip.render_forward(sep, *args, **kw)
+        b = gnerf_hip.render_forward(inter, *args, **kw)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), (S, F)
+        gen = torch.Generator().manual_seed(1)
+        g = [torch.randn(N, 64, k, generator=gen).to(dev) for k in (32, 1, 1)]
+        gp_s, gd_s = gnerf_hip.render_backward(sep, *args, *g, **kw)
+        gp_i, gd_i = gnerf_hip.render_backward(inter, *args, *g, **kw)
+        assert gp_i.shape == inter.shape
+        back = gp_i.reshape(N, 24, 20, 3, 32).permute(0, 3, 1, 2, 4).reshape(6, 24, 20, 32)
+        assert float((back - gp_s).abs().max()) <= 1e-5 * float(gp_s.abs().max())
+        for x, y in zip(gd_s, gd_i):
+            assert _rel(x, y) < 1e-5
+    pts = (torch.rand(2, 77, 3, generator=gen) - 0.5).to(dev) * 1.3
+    qa, qb = gnerf_hip.query_points(sep, 2, args[1], pts, 1.0), gnerf_hip.query_points(inter, 2, args[1], pts, 1.0)
+    assert torch.equal(qa[0], qb[0]) and torch.equal(qa[1], qb[1])
+    gs, gc = torch.randn(2, 77, 1, device=dev), torch.randn(2, 77, 32, device=dev)
+    ba, bb = gnerf_hip.query_points_backward(sep, 2, args[1], pts, 1.0, gs, gc), gnerf_hip.query_points_backward(inter, 2, args[1], pts, 1.0, gs, gc)
+    back = bb[0].reshape(2, 24, 20, 3, 32).permute(0, 3, 1, 2, 4).reshape(6, 24, 20, 32)
+    assert float((back - ba[0]).abs().max()) <= 1e-5 * float(ba[0].abs().max())
+    with pytest.raises(RuntimeError):
+        gnerf_hip.render_forward(inter[:, :, :, :64].contiguous(), *args, **kw)
+
+
+def test_upsample2x_add_channels_last_producer(dev):
+    """The tri-plane producer's last step as one kernel: upsample2d(img, [1,3,3,1]) + y written channels_last, with max |out|;
+    against the numpy oracle of upfirdn2d, in both filter orientations, with and without y; its gradient against autograd
+    through the composed ops; shapes it does not cover fall back to the composed ops."""
+    import gnerf_hip
+    from oracle import ops_ref as O
+    from torch_utils.ops import upfirdn2d
+    gen = torch.Generator().manual_seed(0)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device=dev)
+    f_odd = (f + torch.arange(16, device=dev).reshape(4, 4) * 0.01)                  # asymmetric: orientation matters
+    for (n, c, h, w), filt, flip, with_y in [((2, 96, 8, 16), f, False, True), ((1, 32, 6, 32), f_odd, False, True),
+                                             ((1, 64, 2, 16), f_odd, True, False), ((4, 96, 128, 128), f, False, True)]:
+        img = torch.randn(n, c, h, w, generator=gen).to(dev)
+        y = torch.randn(n, c, 2 * h, 2 * w, generator=gen).to(dev) if with_y else None
+        out, amax = gnerf_hip.upsample2x_add_nhwc(img, y, filt, flip=flip, gain=4.0, with_absmax=True)
+        assert out.shape == (n, c, 2 * h, 2 * w) and out.is_contiguous(memory_format=torch.channels_last)
+        ref = O.upfirdn2d(img.cpu().numpy().astype(np.float64), filt.cpu().numpy(), up=2, padding=[2, 1, 2, 1], flip_filter=flip, gain=4.0)
+        if with_y:
+            ref = ref + y.cpu().numpy()
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+        assert float(amax) == float(out.abs().max())
+    assert gnerf_hip.upsample2x_add_nhwc(torch.randn(1, 3, 8, 16, device=dev), None, f) is None
+    # the public entry: gradients of both inputs equal those of the composed ops; uncovered shapes compose
+    img = torch.randn(2, 32, 8, 16, generator=gen).to(dev).requires_grad_(True)
+    y = torch.randn(2, 32, 16, 32, generator=gen).to(dev).requires_grad_(True)
+    w8 = torch.randn(2, 32, 16, 32, generator=gen).to(dev)
+    fused = upfirdn2d.upsample2d_add_channels_last(img, y, f)
+    assert fused.is_contiguous(memory_format=torch.channels_last)
+    gi, gy = torch.autograd.grad((fused * w8).sum(), [img, y])
+    plain = upfirdn2d.upsample2d(img, f) + y
+    gi2, gy2 = torch.autograd.grad((plain * w8).sum(), [img, y])
+    np.testing.assert_allclose(fused.detach().cpu().numpy(), plain.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gi.cpu().numpy(), gi2.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gy.cpu().numpy(), gy2.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    small = upfirdn2d.upsample2d_add_channels_last(torch.randn(1, 3, 8, 16, device=dev), None, f)
+    assert small.shape == (1, 3, 16, 32)
+
+
+def test_importance_renderer_reads_channels_last_planes_in_place(dev, monkeypatch):
+    """Drop-in class: planes that arrive as triplane.py:74's view of a channels_last [N,96,H,W] tensor are rendered without the
+    NCHW->NHWC layout change (gnerf_hip.planes_to_nhwc is never called), with the image an NCHW copy of the same planes gives;
+    gradients come back laid out like the planes."""
+    import gnerf_hip
+    import gnerf_harness as H
+    from training.volumetric_rendering.renderer import ImportanceRenderer
+    from training.volumetric_rendering.ray_sampler import RaySampler
+    torch.manual_seed(0)
+    dec = H.TriPlaneDecoder().to(dev)
+    opts = dict(depth_resolution=48, depth_resolution_importance=48, ray_start=2.25, ray_end=3.3, box_warp=1, clamp_mode='softplus',
+                disparity_space_sampling=False)
+    img = torch.randn(2, 96, 32, 32, device=dev)
+    planes_nchw = img.view(2, 3, 32, 32, 32)
+    planes_cl = img.contiguous(memory_format=torch.channels_last).view(2, 3, 32, 32, 32)
+    assert not planes_cl.is_contiguous()
+    c = torch.cat([H.camera_label(H.orbit_pose(i, 120)) for i in (3, 40)]).to(dev)
+    o, d = RaySampler()(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), 16)
+    r = ImportanceRenderer()
+    with torch.no_grad():
+        torch.manual_seed(5)
+        want = r(planes_nchw, dec, o, d, opts)
+        calls = []
+        real = gnerf_hip.planes_to_nhwc
+        monkeypatch.setattr(gnerf_hip, 'planes_to_nhwc', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        torch.manual_seed(5)
+        got = r(planes_cl, dec, o, d, opts)
+        assert not calls
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+    # training: gradient of the channels_last planes, laid out like them, equals the NCHW route's
+    grads = []
+    for pl in (planes_nchw, planes_cl):
+        pl = pl.detach().requires_grad_(True)
+        torch.manual_seed(6)
+        rgb, depth, _ = r(pl, dec, o, d, opts)
+        g, = torch.autograd.grad(rgb.square().sum() + depth.sum(), [pl])
+        grads.append(g)
+    assert not calls
+    assert grads[1].stride() == planes_cl.stride()
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * float(grads[0].abs().max())
+
+
 def test_query_points_vs_oracle(dev):
     import gnerf_hip
     from oracle import render_ref as R
