@@ -9,7 +9,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$root/include -I$here -Wall -Wno-unused-function ${GNERF_EXTRA_FLAGS:-}"
 objs=()
 pids=()
-for src in capi bias_act upfirdn2d filtered_lrelu filtered_lrelu_fused grid_sample planes render; do
+for src in capi bias_act upfirdn2d filtered_lrelu filtered_lrelu_fused grid_sample planes modconv render; do
     [ -f "$here/$src.hip" ] || continue
     obj="$here/$src.o"
     stale=0

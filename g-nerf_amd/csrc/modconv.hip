@@ -1,0 +1,206 @@
+// The surroundings of the modulated convolutions: everything StyleGAN2's SynthesisLayer / ToRGBLayer do
+// around the MIOpen convolution itself (networks_stylegan2.py:41-98 modulated_conv2d, :315-334 SynthesisLayer.forward), which
+// upstream is a chain of ~10 ATen elementwise / reduction launches per layer:
+//
+//   gnerf_modulate_weights   per-sample weights w[n,o,i,k] = weight[o,i,k] * styles[n,i] * dcoef[n,o]  (fused form, :61-75) and /
+//                            or the demodulation coefficients dcoef[n,o] = rsqrt(sum_ik (weight styles)^2 + 1e-8) alone (un-fused
+//                            form, :71-72), with the fp16 pre-normalisation of :62-64 -- one launch instead of 7.
+//   gnerf_scale_channels     x[n,c,:,:] * styles[n,c]  (the un-fused form's input scaling, :77).
+//   gnerf_modconv_epilogue   what follows the convolution: demodulation (un-fused, :79-80) + noise (:79-83 / :96-97) + bias +
+//                            activation + gain + clamp (bias_act, :331-333) in ONE pass over the activations instead of three.
+// Every intermediate the composed ops would have materialised in the activations' dtype is rounded to that dtype here too, so the
+// results equal the composed ops' bit for bit (tests/test_gpu_parity.py::test_modconv_*).
+
+#include "common.h"
+
+namespace {
+
+using namespace gnerf;
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float w = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, w) : v + w;
+    }
+    __syncthreads();                                   // `red` may still be read from a previous reduction
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float a = red[0], b = red[1], c = red[2], d = red[3];
+    return is_max ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : (a + b) + (c + d);
+}
+
+// One workgroup per (n, o).  ik = I * K * K elements of weight[o] against styles[n, i = e / kk].
+template <class T>
+__global__ __launch_bounds__(kThreads) void modulate_weights_kernel(const float* __restrict__ weight, const float* __restrict__ styles,
+                                                                    T* __restrict__ out, float* __restrict__ dcoefs,
+                                                                    int n_out, int n_in, int kk, int demodulate, int prenorm) {
+    __shared__ float red[4];
+    const int o = blockIdx.x % n_out, n = blockIdx.x / n_out;
+    const int ik = n_in * kk;
+    const float* w = weight + int64_t(o) * ik;
+    const float* s = styles + int64_t(n) * n_in;
+    float w_scale = 1.f, s_scale = 1.f;
+    if (prenorm) {                                     // networks_stylegan2.py:62-64: weight / (sqrt(fan_in) max|weight[o]|), styles / max|styles[n]|
+        float wm = 0.f, sm = 0.f;
+        for (int e = threadIdx.x; e < ik; e += kThreads) wm = fmaxf(wm, fabsf(w[e]));
+        for (int i = threadIdx.x; i < n_in; i += kThreads) sm = fmaxf(sm, fabsf(s[i]));
+        wm = block_reduce(wm, true, red);
+        sm = block_reduce(sm, true, red);
+        w_scale = (1.0f / sqrtf(float(ik))) / wm;
+        s_scale = 1.0f / sm;
+    }
+    float d = 1.f;
+    if (demodulate) {
+        float acc = 0.f;
+        for (int e = threadIdx.x; e < ik; e += kThreads) {
+            const float v = (w[e] * w_scale) * (s[e / kk] * s_scale);
+            acc = fmaf(v, v, acc);
+        }
+        d = rsqrtf(block_reduce(acc, false, red) + 1e-8f);
+        if (dcoefs && threadIdx.x == 0) dcoefs[int64_t(n) * n_out + o] = d;
+    }
+    if (out) {
+        T* dst = out + (int64_t(n) * n_out + o) * ik;
+        for (int e = threadIdx.x; e < ik; e += kThreads) store_as<T>(dst, e, ((w[e] * w_scale) * (s[e / kk] * s_scale)) * d);
+    }
+}
+
+// fp16 pre-normalised styles alone (the un-fused form multiplies the activations by them): styles[n,:] / max|styles[n,:]|
+__global__ __launch_bounds__(kThreads) void normalise_styles_kernel(const float* __restrict__ styles, float* __restrict__ out, int n_in) {
+    __shared__ float red[4];
+    const float* s = styles + int64_t(blockIdx.x) * n_in;
+    float sm = 0.f;
+    for (int i = threadIdx.x; i < n_in; i += kThreads) sm = fmaxf(sm, fabsf(s[i]));
+    sm = block_reduce(sm, true, red);
+    for (int i = threadIdx.x; i < n_in; i += kThreads) out[int64_t(blockIdx.x) * n_in + i] = s[i] / sm;
+}
+
+template <class T, int VEC> struct alignas(sizeof(T) * VEC) Pk { T v[VEC]; };
+
+template <class T> __device__ __forceinline__ float round_to(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<__half>(float v) { return __half2float(__float2half(v)); }
+
+struct EpiArgs {
+    const void* x; void* y;
+    const float* scale;      // [rows] or NULL
+    const float* noise;      // [row_len] (or [rows / channels][row_len] when noise_per_item) or NULL
+    const void* bias;        // [channels], activations' dtype, or NULL
+    unsigned row_len, channels;
+    int noise_per_item, round_noise, act;
+    float alpha, gain, clamp;
+};
+
+// y[row, :] = clamp(act(round_T(x[row, :] * T(scale[row]) + noise[:]) + bias[row % channels]) * gain); rows = blockIdx.y
+template <class T, int VEC, int ACT>
+__global__ __launch_bounds__(kThreads) void modconv_epilogue_kernel(EpiArgs a) {
+    typedef Pk<T, VEC> P;
+    const unsigned row = blockIdx.y;
+    const unsigned v = blockIdx.x * kThreads + threadIdx.x;
+    if (v * VEC >= a.row_len) return;
+    const T* x = static_cast<const T*>(a.x) + int64_t(row) * a.row_len;
+    T* y = static_cast<T*>(a.y) + int64_t(row) * a.row_len;
+    const float sc = a.scale ? round_to<T>(a.scale[row]) : 1.f;
+    const float bv = a.bias ? float(load_as<T>(static_cast<const T*>(a.bias), row % a.channels)) : 0.f;
+    const float* nz = a.noise ? a.noise + (a.noise_per_item ? int64_t(row / a.channels) * a.row_len : 0) : nullptr;
+    const P in = *reinterpret_cast<const P*>(x + v * VEC);
+    float nv[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) nv[k] = nz ? nz[v * VEC + k] : 0.f;
+    P out;
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+        float t = float(load_as<T>(in.v, k));
+        if (a.scale || nz) t = round_to<T>(fmaf(t, sc, a.round_noise ? round_to<T>(nv[k]) : nv[k]));
+        t += bv;
+        float r = t;
+        if (ACT == 3) r = t > 0.f ? t : t * a.alpha;          // lrelu
+        r *= a.gain;
+        if (a.clamp >= 0.f) r = r > a.clamp ? a.clamp : (r < -a.clamp ? -a.clamp : r);
+        store_as<T>(out.v, k, r);
+    }
+    *reinterpret_cast<P*>(y + v * VEC) = out;
+}
+
+template <class T, int VEC>
+__global__ __launch_bounds__(kThreads) void scale_channels_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ y, unsigned row_len) {
+    typedef Pk<T, VEC> P;
+    const unsigned row = blockIdx.y;
+    const unsigned v = blockIdx.x * kThreads + threadIdx.x;
+    if (v * VEC >= row_len) return;
+    const float sc = round_to<T>(s[row]);
+    const P in = *reinterpret_cast<const P*>(x + int64_t(row) * row_len + v * VEC);
+    P out;
+#pragma unroll
+    for (int k = 0; k < VEC; k++) store_as<T>(out.v, k, float(load_as<T>(in.v, k)) * sc);
+    *reinterpret_cast<P*>(y + int64_t(row) * row_len + v * VEC) = out;
+}
+
+}  // namespace
+
+extern "C" int gnerf_modulate_weights(const float* weight, const float* styles, void* out, int out_dtype, float* dcoefs,
+                                      int n, int n_out, int n_in, int kk, int demodulate, int prenorm, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!weight || !styles) return fail(GNERF_E_ARG, "modulate_weights: null pointer");
+    if (n < 1 || n_out < 1 || n_in < 1 || kk < 1) return fail(GNERF_E_ARG, "modulate_weights: empty shape");
+    if (!out && !dcoefs) return GNERF_OK;
+    if (dcoefs && !demodulate) return fail(GNERF_E_ARG, "modulate_weights: dcoefs requested without demodulation");
+    const dim3 g((unsigned)(n * n_out)), b(kThreads);
+    if (!out || out_dtype == GNERF_F32)
+        hipLaunchKernelGGL(modulate_weights_kernel<float>, g, b, 0, as_stream(stream), weight, styles, static_cast<float*>(out), dcoefs, n_out, n_in, kk, demodulate, prenorm);
+    else if (out_dtype == GNERF_F16)
+        hipLaunchKernelGGL(modulate_weights_kernel<__half>, g, b, 0, as_stream(stream), weight, styles, static_cast<__half*>(out), dcoefs, n_out, n_in, kk, demodulate, prenorm);
+    else
+        return fail(GNERF_E_ARG, "modulate_weights: output dtype must be float32 or float16");
+    return check_launch("modulate_weights");
+}
+
+extern "C" int gnerf_normalise_styles(const float* styles, float* out, int n, int n_in, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!styles || !out || n < 1 || n_in < 1) return fail(GNERF_E_ARG, "normalise_styles: bad argument");
+    hipLaunchKernelGGL(normalise_styles_kernel, dim3((unsigned)n), dim3(kThreads), 0, as_stream(stream), styles, out, n_in);
+    return check_launch("normalise_styles");
+}
+
+extern "C" int gnerf_scale_channels(const void* x, const float* scale, void* y, int dtype, int rows, int row_len, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!x || !scale || !y) return fail(GNERF_E_ARG, "scale_channels: null pointer");
+    if (rows < 1 || row_len < 1 || rows > 65535) return fail(GNERF_E_ARG, "scale_channels: rows must be in 1..65535");
+    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    if (dtype == GNERF_F16) {
+        if (al && row_len % 8 == 0) hipLaunchKernelGGL((scale_channels_kernel<__half, 8>), dim3((row_len / 8 + kThreads - 1) / kThreads, rows), dim3(kThreads), 0, as_stream(stream),
+                                                       static_cast<const __half*>(x), scale, static_cast<__half*>(y), unsigned(row_len));
+        else hipLaunchKernelGGL((scale_channels_kernel<__half, 1>), dim3((row_len + kThreads - 1) / kThreads, rows), dim3(kThreads), 0, as_stream(stream),
+                                static_cast<const __half*>(x), scale, static_cast<__half*>(y), unsigned(row_len));
+    } else if (dtype == GNERF_F32) {
+        if (al && row_len % 4 == 0) hipLaunchKernelGGL((scale_channels_kernel<float, 4>), dim3((row_len / 4 + kThreads - 1) / kThreads, rows), dim3(kThreads), 0, as_stream(stream),
+                                                       static_cast<const float*>(x), scale, static_cast<float*>(y), unsigned(row_len));
+        else hipLaunchKernelGGL((scale_channels_kernel<float, 1>), dim3((row_len + kThreads - 1) / kThreads, rows), dim3(kThreads), 0, as_stream(stream),
+                                static_cast<const float*>(x), scale, static_cast<float*>(y), unsigned(row_len));
+    } else {
+        return fail(GNERF_E_ARG, "scale_channels: dtype must be float32 or float16");
+    }
+    return check_launch("scale_channels");
+}
+
+extern "C" int gnerf_modconv_epilogue(const void* x, void* y, int dtype, int rows, int row_len, int channels,
+                                      const float* scale, const float* noise, int noise_per_item, int round_noise, const void* bias,
+                                      int act, float alpha, float gain, float clamp, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!x || !y) return fail(GNERF_E_ARG, "modconv_epilogue: null pointer");
+    if (rows < 1 || row_len < 1 || channels < 1 || rows % channels != 0 || rows > 65535) return fail(GNERF_E_ARG, "modconv_epilogue: bad shape (rows %d, channels %d)", rows, channels);
+    if (act != 1 && act != 3) return fail(GNERF_E_UNSUPPORTED, "modconv_epilogue: only linear and lrelu");
+    EpiArgs a{x, y, scale, noise, bias, unsigned(row_len), unsigned(channels), noise_per_item, round_noise, act, alpha, gain, clamp};
+    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    hipStream_t s = as_stream(stream);
+#define GNERF_EPI(T_, V_) do { const dim3 g((row_len / V_ + kThreads - 1) / kThreads, rows); \
+        if (act == 3) hipLaunchKernelGGL((modconv_epilogue_kernel<T_, V_, 3>), g, dim3(kThreads), 0, s, a); \
+        else          hipLaunchKernelGGL((modconv_epilogue_kernel<T_, V_, 1>), g, dim3(kThreads), 0, s, a); } while (0)
+    if (dtype == GNERF_F16) { if (al && row_len % 8 == 0) GNERF_EPI(__half, 8); else GNERF_EPI(__half, 1); }
+    else if (dtype == GNERF_F32) { if (al && row_len % 4 == 0) GNERF_EPI(float, 4); else GNERF_EPI(float, 1); }
+    else return fail(GNERF_E_ARG, "modconv_epilogue: dtype must be float32 or float16");
+#undef GNERF_EPI
+    return check_launch("modconv_epilogue");
+}

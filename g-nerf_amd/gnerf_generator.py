@@ -21,6 +21,7 @@ seven super-resolution variants, Freeze-D, pickling hooks.
 """
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -33,6 +34,28 @@ from training.volumetric_rendering.ray_sampler import RaySampler
 import gnerf_harness as H
 
 LRELU_GAIN = math.sqrt(2)
+# Inference on a GPU: the ATen elementwise chains around each convolution (weight modulation / demodulation, noise, bias,
+# activation, clamp: ~10 launches per layer) run as this repo's modconv kernels (csrc/modconv.hip), and a
+# batch of fp16 layers uses the shared-weight form of the convolution (one batched MIOpen convolution instead of a grouped one
+# with per-sample weights: 2.2x faster at batch 4, tools/bench_upconv.py).  GNERF_MODCONV_FAST=0 keeps the plain PyTorch forms.
+_MODCONV_FAST = os.environ.get('GNERF_MODCONV_FAST', '1') != '0'
+
+
+def _fast_path(x, *params):
+    return (_MODCONV_FAST and x.is_cuda and x.is_contiguous() and x.dtype in (torch.float16, torch.float32)
+            and not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))))
+
+
+def _prenormalised_weight(module, dtype):
+    """weight / (sqrt(fan_in) max|weight[o]|) in `dtype` (networks_stylegan2.py:63), cached per weight version: a constant at inference."""
+    w = module.weight
+    key = (w.data_ptr(), w._version if not w.is_inference() else None, dtype)
+    cache = module.__dict__.get('_gnerf_prenorm')
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            cache = (key, (w * (1 / math.sqrt(w[0].numel()) / w.norm(float('inf'), dim=[1, 2, 3], keepdim=True))).to(dtype).contiguous())
+        module.__dict__['_gnerf_prenorm'] = cache
+    return cache[1]
 
 
 class Linear(nn.Module):
@@ -131,6 +154,19 @@ class StyledConv(nn.Module):
             noise = torch.randn([n, 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
         elif noise_mode == 'const':
             noise = self.noise_const * self.noise_strength
+        if _fast_path(x, self.weight, self.bias, self.noise_strength, styles):
+            import gnerf_hip
+            half = x.dtype == torch.float16
+            c_out = self.weight.shape[0]
+            clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+            if half and n > 1:          # shared-weight form: activations scaled by the styles, demodulation in the epilogue
+                _, dco = gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=x.dtype, want_weights=False, want_dcoefs=True)
+                x = self._resampled_conv(gnerf_hip.scale_channels(x, gnerf_hip.normalise_styles(styles)), _prenormalised_weight(self, x.dtype), 1)
+                return gnerf_hip.modconv_epilogue(x, self.bias, scale=dco, noise=noise, round_noise=True, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
+            wts, _ = gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=x.dtype)                  # [N,O,I,3,3], one launch
+            x = self._resampled_conv(x.reshape(1, n * c_in, h, wd), wts.reshape(n * c_out, c_in, 3, 3), n)
+            x = x.reshape(n, c_out, *x.shape[2:])
+            return gnerf_hip.modconv_epilogue(x, self.bias, noise=noise, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
         if fused:
             wts = _modulated_weights(self.weight, styles, True, x.dtype == torch.float16).to(x.dtype)          # [N,O,I,3,3]
             c_out = wts.shape[1]
@@ -163,6 +199,14 @@ class ToRGB(nn.Module):
     def forward(self, x, w, fused=True):
         n, c_in, h, wd = x.shape
         styles = self.affine(w) * self.weight_gain
+        if _fast_path(x, self.weight, self.bias, styles):
+            import gnerf_hip
+            if x.dtype == torch.float16 and n > 1:
+                x = F.conv2d(gnerf_hip.scale_channels(x, styles), self.weight.to(x.dtype))
+            else:
+                wts, _ = gnerf_hip.modulate_weights(self.weight, styles, False, out_dtype=x.dtype)
+                x = F.conv2d(x.reshape(1, n * c_in, h, wd), wts.reshape(-1, c_in, 1, 1), groups=n).reshape(n, -1, h, wd)
+            return gnerf_hip.modconv_epilogue(x, self.bias, act='linear', gain=1.0, clamp=self.conv_clamp)
         if fused:
             wts = _modulated_weights(self.weight, styles, False, False).to(x.dtype)
             x = F.conv2d(x.reshape(1, n * c_in, h, wd), wts.reshape(-1, c_in, 1, 1), groups=n).reshape(n, -1, h, wd)

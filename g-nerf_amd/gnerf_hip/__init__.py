@@ -85,6 +85,10 @@ SIGNATURES = {
     'gnerf_query_points': (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_p]),
     'gnerf_query_points_backward': (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                            _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_p]),
+    'gnerf_modulate_weights': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),
+    'gnerf_normalise_styles': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_p]),
+    'gnerf_scale_channels': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
+    'gnerf_modconv_epilogue': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p, _c_i, _c_f, _c_f, _c_f, _c_p]),
     'gnerf_upsample2x_add_nhwc': (_c_i, [_c_p, _c_p, ctypes.POINTER(_c_f), _c_i, _c_f, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
 }
 
@@ -470,6 +474,86 @@ def _workspace(device):
         ws = torch.zeros([max(int(load().gnerf_render_workspace_bytes()), 16)], dtype=torch.uint8, device=device)     # zeroed once; calls leave it zeroed
         _workspaces[key] = ws
     return ws
+
+
+# ---------------------------------------------------------------------------- surroundings of the modulated convolution
+
+
+def modulate_weights(weight, styles, demodulate=True, out_dtype=torch.float32, want_weights=True, want_dcoefs=False):
+    """Per-sample modulated (+ demodulated) convolution weights in one launch (networks_stylegan2.py:61-75), with the fp16
+    pre-normalisation of :62-64 when out_dtype is float16 and demodulate.  weight [O,I,k,k], styles [N,I] float32.
+    Returns (w [N,O,I,k,k] in out_dtype or None, dcoefs [N,O] float32 or None)."""
+    _require_cuda(weight, styles)
+    w32, s32 = weight.detach().to(torch.float32).contiguous(), styles.detach().to(torch.float32).contiguous()
+    o, i, kh, kw = w32.shape
+    n = s32.shape[0]
+    if s32.shape != (n, i) or out_dtype not in (torch.float32, torch.float16):
+        raise RuntimeError('modulate_weights: styles must be [N, I] and out_dtype float32 or float16')
+    out = torch.empty([n, o, i, kh, kw], dtype=out_dtype, device=w32.device) if want_weights else None
+    dco = torch.empty([n, o], dtype=torch.float32, device=w32.device) if (want_dcoefs and demodulate) else None
+    prenorm = 1 if (out_dtype == torch.float16 and demodulate) else 0
+    with _on_device(w32.device):
+        code = load().gnerf_modulate_weights(_ptr(w32), _ptr(s32), _ptr(out), _DTYPE_CODE[out_dtype], _ptr(dco), n, o, i, kh * kw,
+                                             1 if demodulate else 0, prenorm, _stream(w32))
+    _check(code, 'gnerf_modulate_weights')
+    return out, dco
+
+
+def normalise_styles(styles):
+    """styles [N,I] / max|styles[n]| per row (networks_stylegan2.py:64)."""
+    _require_cuda(styles)
+    s32 = styles.detach().to(torch.float32).contiguous()
+    out = torch.empty_like(s32)
+    with _on_device(s32.device):
+        code = load().gnerf_normalise_styles(_ptr(s32), _ptr(out), s32.shape[0], s32.shape[1], _stream(s32))
+    _check(code, 'gnerf_normalise_styles')
+    return out
+
+
+def scale_channels(x, scale):
+    """x [N,C,H,W] (NCHW contiguous, float16/32) * scale [N,C] float32, the product formed in x's dtype (networks_stylegan2.py:77)."""
+    _require_cuda(x, scale)
+    if x.ndim != 4 or not x.is_contiguous() or x.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError('scale_channels: x must be a contiguous float16/float32 NCHW tensor')
+    n, c, h, w = x.shape
+    s32 = scale.detach().to(torch.float32).contiguous()
+    if s32.numel() != n * c:
+        raise RuntimeError('scale_channels: scale must have N*C elements')
+    y = torch.empty_like(x)
+    with _on_device(x.device):
+        code = load().gnerf_scale_channels(_ptr(x), _ptr(s32), _ptr(y), _DTYPE_CODE[x.dtype], n * c, h * w, _stream(x))
+    _check(code, 'gnerf_scale_channels')
+    return y
+
+
+def modconv_epilogue(x, bias=None, scale=None, noise=None, round_noise=False, act='lrelu', alpha=0.2, gain=1.0, clamp=None):
+    """Everything after the modulated convolution in one pass (networks_stylegan2.py:79-83 / :96-97 then :331-333):
+    t = x * scale[n,c] + noise (rounded to x's dtype; skipped when both are None), y = clamp(act(t + bias[c]) * gain).
+    x [N,C,H,W] NCHW contiguous float16/32; scale [N,C] float32; noise float32 [H,W] or [N,1,H,W]; bias [C] (any float dtype)."""
+    _require_cuda(x, bias, scale, noise)
+    if x.ndim != 4 or not x.is_contiguous() or x.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError('modconv_epilogue: x must be a contiguous float16/float32 NCHW tensor')
+    if act not in ('linear', 'lrelu'):
+        raise RuntimeError('modconv_epilogue: act must be linear or lrelu')
+    n, c, h, w = x.shape
+    s32 = None if scale is None else scale.detach().to(torch.float32).contiguous()
+    nz = None if noise is None else noise.detach().to(torch.float32).contiguous()
+    per_item = 0
+    if nz is not None:
+        if nz.numel() == n * h * w and n > 1:
+            per_item = 1
+        elif nz.numel() != h * w:
+            raise RuntimeError('modconv_epilogue: noise must have H*W or N*H*W elements')
+    b = None if bias is None else bias.detach().to(x.dtype).contiguous()
+    if (s32 is not None and s32.numel() != n * c) or (b is not None and b.numel() != c):
+        raise RuntimeError('modconv_epilogue: scale must have N*C and bias C elements')
+    y = torch.empty_like(x)
+    with _on_device(x.device):
+        code = load().gnerf_modconv_epilogue(_ptr(x), _ptr(y), _DTYPE_CODE[x.dtype], n * c, h * w, c, _ptr(s32), _ptr(nz), per_item,
+                                             1 if round_noise else 0, _ptr(b), 3 if act == 'lrelu' else 1, float(alpha), float(gain),
+                                             float(-1 if clamp is None else clamp), _stream(x))
+    _check(code, 'gnerf_modconv_epilogue')
+    return y
 
 
 def planes_layout(planes_nhwc, n_items, what):

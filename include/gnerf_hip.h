@@ -14,6 +14,8 @@
  *   gnerf_filtered_lrelu    <- filtered_lrelu_plugin.filtered_lrelu      torch_utils/ops/filtered_lrelu.cpp:20
  *   gnerf_filtered_lrelu_act<- filtered_lrelu_plugin.filtered_lrelu_act_ torch_utils/ops/filtered_lrelu.cpp:217
  *   gnerf_grid_sample_2d(_backward) <- torch_utils/ops/grid_sample_gradfix.py:45, :62-77 (ATen's sampler upstream)
+ *   gnerf_modulate_weights / gnerf_scale_channels / gnerf_modconv_epilogue <- the ATen elementwise chains of modulated_conv2d
+ *                              and SynthesisLayer.forward                training/networks_stylegan2.py:41-98, :315-334
  *   gnerf_render_forward    <- ImportanceRenderer.forward          training/volumetric_rendering/renderer.py:88-140
  *                              (pure PyTorch in the reference; there is no native counterpart)
  *   gnerf_query_points      <- ImportanceRenderer.run_model        training/volumetric_rendering/renderer.py:142-148
@@ -65,6 +67,32 @@ const char* gnerf_build_info(void);          /* e.g. "gfx950 hipcc ..." , host p
 int gnerf_bias_act(const void* x, const void* b, const void* xref, const void* yref, const void* dy,
                    void* y, int dtype, int64_t numel, int size_b, int64_t step_b,
                    int grad, int act, float alpha, float gain, float clamp, gnerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The surroundings of StyleGAN2's modulated convolution (networks_stylegan2.py:41-98 modulated_conv2d, :315-334
+ * SynthesisLayer.forward; the convolution itself stays MIOpen's).  SURVEY.md section 8f.3.
+ *
+ * gnerf_modulate_weights: out[n,o,i,k] = weight[o,i,k] * styles[n,i] * dcoef[n,o] with dcoef = rsqrt(sum_ik (weight styles)^2 + 1e-8)
+ * when `demodulate` (:66-75), after the fp16 pre-normalisation of :62-64 when `prenorm` (weight[o] / (sqrt(n_in*kk) max|weight[o]|),
+ * styles[n] / max|styles[n]|).  weight [n_out, n_in, kk] and styles [n, n_in] float32; out [n, n_out, n_in, kk] in out_dtype
+ * (GNERF_F32 / GNERF_F16) or NULL; dcoefs [n, n_out] float32 or NULL (the un-fused form needs only these, :71-72). */
+int gnerf_modulate_weights(const float* weight, const float* styles, void* out, int out_dtype, float* dcoefs,
+                           int n, int n_out, int n_in, int kk, int demodulate, int prenorm, gnerf_stream_t stream);
+/* styles[n,:] / max|styles[n,:]| (the pre-normalised styles the un-fused form scales the activations with, :64 and :77). */
+int gnerf_normalise_styles(const float* styles, float* out, int n, int n_in, gnerf_stream_t stream);
+/* y[r, :] = x[r, :] * scale[r] for r < rows (rows = batch * channels of an NCHW tensor, row_len = H*W); the product is formed in
+ * the activations' dtype like `x * styles.to(x.dtype)` (:77). */
+int gnerf_scale_channels(const void* x, const float* scale, void* y, int dtype, int rows, int row_len, gnerf_stream_t stream);
+/* One pass for everything after the convolution:
+ *   t = x * scale[row] + noise            (un-fused demodulation + noise, fma.fma at :79-80; or `x.add_(noise)` at :96-97; rounded to
+ *                                          the activations' dtype as the materialised tensor would be; skipped when both are NULL)
+ *   y = clamp(act(t + bias[row % channels]) * gain)                                          (bias_act, :331-333)
+ * x, y: [rows, row_len] NCHW activations (rows = batch * channels <= 65535); scale: float32 [rows] or NULL; noise: float32
+ * [row_len] (or [batch, row_len] when noise_per_item: 'random' mode) or NULL, rounded to the activations' dtype first when
+ * round_noise; bias: [channels] in the activations' dtype or NULL; act: 1 linear or 3 lrelu (GNERF_E_UNSUPPORTED otherwise). */
+int gnerf_modconv_epilogue(const void* x, void* y, int dtype, int rows, int row_len, int channels,
+                           const float* scale, const float* noise, int noise_per_item, int round_noise, const void* bias,
+                           int act, float alpha, float gain, float clamp, gnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * upfirdn2d.  Zero-insert upsample, pad/crop, 2-D FIR, decimate (upfirdn2d.cpp:20-102).

@@ -487,12 +487,13 @@ def test_importance_renderer_reads_channels_last_planes_in_place(dev, monkeypatc
     # training: gradient of the channels_last planes, laid out like them, equals the NCHW route's
     grads = []
     for pl in (planes_nchw, planes_cl):
+        del calls[:]
         pl = pl.detach().requires_grad_(True)
         torch.manual_seed(6)
         rgb, depth, _ = r(pl, dec, o, d, opts)
         g, = torch.autograd.grad(rgb.square().sum() + depth.sum(), [pl])
         grads.append(g)
-    assert not calls
+    assert not calls                                        # (the channels_last pass, last in the loop)
     assert grads[1].stride() == planes_cl.stride()
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * float(grads[0].abs().max())
 
@@ -1086,6 +1087,81 @@ def test_cpp_extension_and_ctypes_bindings_agree(dev):
     via_ctypes = gnerf_hip.render_forward(*args, debug=True, **kw)[:3]
     for p_, q_ in zip(via_ext, via_ctypes):
         assert torch.equal(p_, q_)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_modconv_kernels_vs_composed_ops(dev, dtype):
+    """csrc/modconv.hip against the PyTorch-op chains of modulated_conv2d / SynthesisLayer.forward they replace
+    (networks_stylegan2.py:61-86, :315-334): modulated + demodulated weights with the fp16 pre-normalisation, the demodulation
+    coefficients alone, the input scaling, and the fused demodulation + noise + bias + lrelu + gain + clamp epilogue in both
+    the fused-convolution (x.add_(noise)) and un-fused (fma) orders."""
+    import gnerf_hip
+    import gnerf_generator as GG
+    from torch_utils.ops import bias_act
+    gen = torch.Generator().manual_seed(0)
+    half = dtype == torch.float16
+    for (n, o, i, k) in [(4, 64, 32, 3), (1, 96, 256, 1), (3, 8, 5, 3)]:
+        weight = torch.randn(o, i, k, k, generator=gen).to(dev)
+        styles = (torch.randn(n, i, generator=gen) + 1).to(dev)
+        for demod in (True, False):
+            ref = GG._modulated_weights(weight, styles, demod, half).to(dtype)
+            got, dco = gnerf_hip.modulate_weights(weight, styles, demod, out_dtype=dtype, want_dcoefs=True)
+            assert got.shape == (n, o, i, k, k) and got.dtype == dtype
+            np.testing.assert_allclose(got.float().cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-3 if half else 3e-6, atol=1e-7)
+            if demod:
+                w_, s_ = GG._prenormalize(weight, styles) if half else (weight, styles)
+                np.testing.assert_allclose(dco.cpu().numpy(), GG._demod_coefficients(w_, s_).cpu().numpy(), rtol=3e-6)
+                if half:
+                    np.testing.assert_allclose(gnerf_hip.normalise_styles(styles).cpu().numpy(), s_.cpu().numpy(), rtol=1e-6)
+            else:
+                assert dco is None
+    x = (torch.randn(3, 8, 12, 16, generator=gen) * 3).to(dev).to(dtype)
+    sc = (torch.randn(3, 8, generator=gen) + 1).to(dev)
+    assert torch.equal(gnerf_hip.scale_channels(x, sc), x * sc.to(dtype)[:, :, None, None])
+    b = torch.randn(8, generator=gen).to(dev)
+    tol = dict(rtol=2e-3, atol=2e-3) if half else dict(rtol=2e-6, atol=2e-6)
+    for noise in (None, torch.randn(12, 16, generator=gen).to(dev), torch.randn(3, 1, 12, 16, generator=gen).to(dev)):
+        for clamp in (None, 1.5):
+            # fused-convolution order: x.add_(noise) in x's dtype, then bias_act
+            want = bias_act.bias_act(x.clone().add_(noise) if noise is not None else x, b.to(dtype), act='lrelu', gain=1.3, clamp=clamp)
+            got = gnerf_hip.modconv_epilogue(x, b, noise=noise, act='lrelu', gain=1.3, clamp=clamp)
+            np.testing.assert_allclose(got.float().cpu().numpy(), want.float().cpu().numpy(), **tol)
+            # un-fused order: fma(x, dcoefs, noise) in x's dtype, then bias_act
+            d4 = sc.to(dtype)[:, :, None, None]
+            want = bias_act.bias_act(torch.addcmul(noise.to(dtype), x, d4) if noise is not None else x * d4, b.to(dtype), act='lrelu', gain=1.3, clamp=clamp)
+            got = gnerf_hip.modconv_epilogue(x, b, scale=sc, noise=noise, round_noise=True, act='lrelu', gain=1.3, clamp=clamp)
+            np.testing.assert_allclose(got.float().cpu().numpy(), want.float().cpu().numpy(), **tol)
+    want = bias_act.bias_act(x, b.to(dtype), clamp=2.0)
+    assert torch.equal(gnerf_hip.modconv_epilogue(x, b, act='linear', clamp=2.0), want)
+    with pytest.raises(RuntimeError):
+        gnerf_hip.modconv_epilogue(x, b, act='relu')
+
+
+def test_generator_fast_modconv_path_equals_plain_path(dev, monkeypatch):
+    """The generator with csrc/modconv.hip around its convolutions (and the shared-weight convolution form for fp16 batches)
+    against the same generator on the plain PyTorch-op chains: batch 1 (grouped form) and batch 3 (shared-weight form)."""
+    import gnerf_generator as GG
+    import gnerf_harness as H
+    torch.manual_seed(1)
+    G = GG.Generator().eval().requires_grad_(False).to(dev)
+    with torch.no_grad():
+        for n_, p_ in G.named_parameters():
+            if n_.endswith('noise_strength') or n_.endswith('.bias'):
+                p_.add_(torch.randn_like(p_) * 0.1)
+            if n_.endswith('torgb.weight') and 'superresolution' in n_:
+                p_.mul_(0.08)
+        for nb in (1, 3):
+            z = torch.randn(nb, 512, device=dev)
+            c = torch.cat([H.camera_label(H.orbit_pose(5 + 9 * i, 120)) for i in range(nb)]).to(dev)
+            ws = G.mapping(z, c)
+            outs = []
+            for fast in (True, False):
+                monkeypatch.setattr(GG, '_MODCONV_FAST', fast)
+                torch.manual_seed(3)
+                outs.append(G.synthesis(ws, c, noise_mode='const', neural_rendering_resolution=64))
+            for k in ('image', 'image_raw', 'image_depth'):
+                mse = float(((outs[0][k] - outs[1][k]) ** 2).mean())
+                assert mse < (1e-5 if k != 'image_depth' else 1e-6), (nb, k, mse)
 
 
 # ---- the whole generator around the hot path (callers in PyTorch/MIOpen, renderer + ops native) ----------------------
