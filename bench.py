@@ -6,10 +6,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One step = one pass of the hot path over one batch, exactly what ImportanceRenderer.forward does per
-call on the GPU: ray generation from the cameras, the NCHW->NHWC plane layout change, the reference's two
-uniform draws (torch.rand, same shapes/order as renderer.py:190/:241), and the fused render kernel
-(+ its depth-clamp epilogue).  Inputs (planes, decoder, cameras) are resident in HBM before the timed
-region.  Rays shard embarrassingly: each rank renders its own batch (weak scaling, no data-path
+call on the GPU: ray generation from the cameras, the reference's two uniform draws (torch.rand, same
+shapes/order as renderer.py:190/:241), the device-side choice of the decoder arithmetic, and the fused
+render kernel (+ its depth-clamp epilogue).  Inputs (planes, decoder, cameras) are resident in HBM before
+the timed region, the planes in the layout their producer writes (channels_last [N,H,W,96], read in place;
+`--nchw-input` adds the round-1 NCHW->NHWC layout change to every step).  Rays shard embarrassingly: each rank renders its own batch (weak scaling, no data-path
 collective); the only collectives are the barriers bracketing the timed region and the max-reduce of
 the elapsed time.
 
@@ -240,6 +241,7 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--reps', type=int, default=5, help='repetitions of the timed K-step region (the median is reported)')
+    ap.add_argument('--nchw-input', action='store_true', help='planes arrive NCHW and are repacked inside every step (the round-1 step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the gen_videos frames/sec measurement')
     args = ap.parse_args()
@@ -266,9 +268,18 @@ def main():
     rays_per_call = N_ITEMS * RES * RES
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    def step(i=None, mlp='auto'):
+    # The planes as their PRODUCER hands them over: the backbone's last step, gnerf_upsample2x_add_nhwc, writes
+    # channels_last memory [N,H,W,96] = the interleaved plane layout the render kernels address in place, and max |planes| with it.
+    # (`--nchw-input` times the round-1 step instead: NCHW planes + the 100 MB NCHW->NHWC layout change inside every step.)
+    planes_cl = planes.reshape(N_ITEMS, 96, PLANE, PLANE).permute(0, 2, 3, 1).contiguous()
+    amax_cl = gnerf_hip.planes_absmax(planes_cl)
+
+    def step(i=None, mlp='auto', nchw_input=False):
         o, d = gnerf_hip.make_rays(c2w, intr, RES)
-        nhwc, amax = gnerf_hip.planes_to_nhwc(planes, with_absmax=True)       # max |planes| rides on the repack: it picks the decoder arithmetic
+        if nchw_input or args.nchw_input:
+            nhwc, amax = gnerf_hip.planes_to_nhwc(planes, with_absmax=True)   # max |planes| rides on the repack: it picks the decoder arithmetic
+        else:
+            nhwc, amax = planes_cl, amax_cl
         noise_c = torch.rand([N_ITEMS, RES * RES, S_COARSE, 1], device=dev)
         noise_f = torch.rand(N_ITEMS * RES * RES, S_FINE, device=dev)
         if i is not None:
@@ -284,14 +295,14 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def timed_region(mlp='auto'):
+    def timed_region(mlp='auto', nchw_input=False):
         """EXACTLY args.steps steps between barrier + synchronize on both sides; (max-over-ranks seconds, mean render ms by HIP events)."""
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            out = step(i, mlp)
+            out = step(i, mlp, nchw_input)
         torch.cuda.synchronize()
         barrier()
         elapsed = gnerf_harness.max_over_ranks(time.perf_counter() - t0, dev)
@@ -308,6 +319,7 @@ def main():
     for mlp in ('f16x3', 'f32'):
         step(None, mlp)
         kernel_ms_by_mlp[mlp] = sorted(timed_region(mlp)[1] for _ in range(3))[1]
+    nchw_elapsed = sorted(timed_region(nchw_input=True)[0] for _ in range(3))[1]
     per_rank_ms = [kernel_ms]
     if world > 1:
         t = torch.tensor([kernel_ms], device=dev)
@@ -347,8 +359,12 @@ def main():
                             'value_min': total_rays / regions[-1][0], 'value_max': total_rays / regions[0][0],
                             'spread_frac': (regions[-1][0] - regions[0][0]) / elapsed},
             'config': {'workload': 'config 2: renderer-only, 128x128 rays x (48+48) samples, 3x32x256x256 fp32 tri-planes, batch 4 per GPU; '
-                                   'step = make_rays + NCHW->NHWC planes (+ max|planes|) + 2 torch.rand draws + decoder-arithmetic choice + fused render kernel',
-                       'rays_per_step_per_gpu': rays_per_call, 'parallelism': f'rays sharded over {world} GPU(s), no data-path collective'},
+                                   'step = make_rays + 2 torch.rand draws + decoder-arithmetic choice + fused render kernel; planes resident in HBM in their '
+                                   'producer\'s layout' + (' (NCHW: + the NCHW->NHWC layout change in every step)' if args.nchw_input else
+                                                          ' (channels_last [N,H,W,96] as gnerf_upsample2x_add_nhwc writes them: read in place)'),
+                       'rays_per_step_per_gpu': rays_per_call, 'parallelism': f'rays sharded over {world} GPU(s), no data-path collective',
+                       'nchw_input_step': {'ms_per_step': 1e3 * nchw_elapsed / args.steps, 'value': total_rays / nchw_elapsed,
+                                           'note': 'the same step with NCHW planes repacked (100 MB) inside every step, as in round 1'}},
             'roofline': roof,
         }
         line['secondary'] = secondary

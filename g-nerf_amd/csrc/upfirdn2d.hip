@@ -16,6 +16,7 @@
 //     (L1/L2 absorb the tap re-reads).
 
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -272,19 +273,30 @@ __global__ __launch_bounds__(256) void upfirdn_fir4_kernel(UpArgs a, int tiles_x
 // output row with 16 FMAs per output.
 // Compared with the tile kernel above (stage through LDS, ~38 VALU + 230 SALU instructions and 5.5 LDS reads per
 // output): ~20 VALU per output, input re-read factor (R+3)/R, so the kernel is HBM-bound instead of instruction-bound.
-template <class T>
+// Two refinements of the second session (profiles/r02_ops_*):
+//  * Strips of one image ALTERNATE direction: even strips walk down, odd strips walk up.  The four waves of a workgroup own four
+//    consecutive strips; walking all of them downwards, a strip's three halo rows are read at its START while the neighbour that
+//    owns them reads them at its END, a whole strip later, when they have long left the L2: measured 11 % more HBM reads than the
+//    algorithm needs.  With alternating directions both sides of every strip boundary inside a workgroup are read at the same
+//    moment (both strips start there, or both end there), so the second read hits the L2.  An upward walk is the downward walk of
+//    the vertically mirrored problem: rows addressed as H-1-row, filter rows reversed, pady0 -> 3 - (in_h - out_h + pady0).
+//  * float16: the products are formed by v_dot2_f32_f16 on the packed halves as loaded (two taps per instruction, fp32
+//    accumulation: exact products, the reference's float accumulation) instead of 16 conversions + 16 FMAs per output -- the
+//    kernel was instruction-bound in fp16 (half the bytes per output, the same instruction count).  Taps are split hi + lo into
+//    two halves each, so any fp32 filter is applied to ~2^-22; the [1,3,3,1] filters of the networks have lo = 0 and that half
+//    of the work is skipped by a wave-uniform branch.  Odd-aligned tap pairs come from one v_alignbit per dword per input row.
+template <class T, int RB>                                  // RB = rows per wait (see below)
 __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpArgs a, int lx_shift, int strips_x, int strips_y, int rows_per_strip) {
-#ifndef GNERF_BLUR_RB
-#define GNERF_BLUR_RB 4
-#endif
-    constexpr int RB = GNERF_BLUR_RB;                       // rows per wait (see below); 1, 2, 3, 6, 8 measured: 4 is best for fp32, 2-4 equal for fp16
+    constexpr bool kHalf = sizeof(T) == 2;
     constexpr int OPL = 16 / sizeof(T), NIN = OPL + 3;
-    constexpr int NLOAD = sizeof(T) == 2 ? 12 : 8;          // elements fetched per row: dwordx4 + dwordx2 (fp16) / dwordx4 x2 (fp32)
+    constexpr int NLOAD = kHalf ? 12 : 8;                   // elements fetched per row: dwordx4 + dwordx2 (fp16) / dwordx4 x2 (fp32)
     constexpr int ND = NLOAD * sizeof(T) / 4;               // ... as dwords
+    constexpr int NROW = kHalf ? 11 : NIN;                  // registers per input row: 6 aligned + 5 odd-aligned pairs (fp16) / 7 floats (fp32)
     // explicitly under-aligned vector types: ONE global_load_dwordx4 / dwordx2 each (a memcpy from a 2-byte-aligned
     // address is split by the compiler into dwordx3 + dwordx2 + ushort pieces)
     typedef unsigned u4u __attribute__((ext_vector_type(4), aligned(2)));
     typedef unsigned u2u __attribute__((ext_vector_type(2), aligned(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const T* x = static_cast<const T*>(a.x);
     T* y = static_cast<T*>(a.y);
     const int lane = threadIdx.x & 63;
@@ -295,7 +307,12 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpArgs a, int lx_shi
     const int sy = int(sid % strips_y); sid /= strips_y;
     const int64_t img = sid;
     const bool live = img < int64_t(a.n) * a.c;
-    const int ox0 = ((sx << lx_shift) + lx) * OPL, oy0 = sy * rows_per_strip;
+    // everything below works in the strip's WALK coordinates: rows count from the top for a downward walk, from the bottom for an
+    // upward one (odd strips)
+    const bool up = (sy & 1) != 0;
+    const int pady0 = up ? 3 - (a.in_h - a.out_h + a.pady0) : a.pady0;
+    const int rows_here = min(rows_per_strip, a.out_h - sy * rows_per_strip);
+    const int ox0 = ((sx << lx_shift) + lx) * OPL, oy0 = up ? a.out_h - (sy * rows_per_strip + rows_here) : sy * rows_per_strip;
     const int ix0 = ox0 - a.padx0;
     unsigned col_ok = 0;
 #pragma unroll
@@ -305,7 +322,30 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpArgs a, int lx_shi
 #pragma unroll
     for (int ky = 0; ky < 4; ky++) {
 #pragma unroll
-        for (int kx = 0; kx < 4; kx++) f[ky][kx] = a.f[(a.flip ? ky : 3 - ky) * a.fs_h + (a.flip ? kx : 3 - kx) * a.fs_w] * a.gain;
+        for (int kx = 0; kx < 4; kx++) {
+            const int kyp = up ? 3 - ky : ky;
+            f[ky][kx] = a.f[(a.flip ? kyp : 3 - kyp) * a.fs_h + (a.flip ? kx : 3 - kx) * a.fs_w] * a.gain;
+        }
+    }
+    // fp16: taps as packed pairs, split hi + lo
+    h2 fh[4][2], fl[4][2];
+    bool has_lo = false;
+    unsigned cmask[6] = {0, 0, 0, 0, 0, 0};
+    if constexpr (kHalf) {
+#pragma unroll
+        for (int ky = 0; ky < 4; ky++) {
+#pragma unroll
+            for (int p2 = 0; p2 < 2; p2++) {
+                const _Float16 h0 = (_Float16)f[ky][2 * p2], h1 = (_Float16)f[ky][2 * p2 + 1];
+                const _Float16 l0 = (_Float16)(f[ky][2 * p2] - (float)h0), l1 = (_Float16)(f[ky][2 * p2 + 1] - (float)h1);
+                fh[ky][p2] = (h2){h0, h1};
+                fl[ky][p2] = (h2){l0, l1};
+                has_lo = has_lo || (float)l0 != 0.f || (float)l1 != 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+            cmask[i] = (((col_ok >> (2 * i)) & 1u) ? 0xffffu : 0u) | ((2 * i + 1 < NIN && ((col_ok >> (2 * i + 1)) & 1u)) ? 0xffff0000u : 0u);
     }
     const int64_t numel = int64_t(a.n) * a.c * a.in_h * a.in_w;
 
@@ -315,13 +355,16 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpArgs a, int lx_shi
     // lanes whose true window leaves the tensor (its first / last elements) re-read it element-wise there.
     const int64_t img_c = live ? img : 0;
     const int64_t img_base_c = img_c * int64_t(a.in_h) * a.in_w;
-    auto row_index = [&](int iy) -> int64_t { return img_base_c + int64_t(min(max(iy, 0), a.in_h - 1)) * a.in_w + ix0; };
+    auto row_index = [&](int iy) -> int64_t {               // iy in walk coordinates
+        const int phys = up ? a.in_h - 1 - iy : iy;
+        return img_base_c + int64_t(min(max(phys, 0), a.in_h - 1)) * a.in_w + ix0;
+    };
     struct Raw { unsigned d[ND]; };
     auto fetch = [&](int iy, Raw& raw) {
         const int64_t idx = min(max(row_index(iy), int64_t(0)), numel - NLOAD);
         const u4u lo = *reinterpret_cast<const u4u*>(x + idx);
         raw.d[0] = lo[0]; raw.d[1] = lo[1]; raw.d[2] = lo[2]; raw.d[3] = lo[3];
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (kHalf) {
             const u2u hi = *reinterpret_cast<const u2u*>(x + idx + 8);
             raw.d[4] = hi[0]; raw.d[5] = hi[1];
         } else {
@@ -329,52 +372,89 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpArgs a, int lx_shi
             raw.d[4] = hi[0]; raw.d[5] = hi[1]; raw.d[6] = hi[2]; raw.d[7] = hi[3];
         }
     };
-    auto element = [&](const Raw& raw, int e) -> float {
-        if constexpr (sizeof(T) == 2) {
-            const unsigned d = raw.d[e >> 1];
-            return __half2float(__ushort_as_half((e & 1) ? (unsigned short)(d >> 16) : (unsigned short)(d & 0xffffu)));
-        } else {
-            return __uint_as_float(raw.d[e]);
-        }
-    };
-    float rows[3 + RB][NIN];
-    auto unpack = [&](int iy, const Raw& raw, float (&dst)[NIN]) {
-        const unsigned ok = (iy >= 0 && iy < a.in_h) ? col_ok : 0u;
-#pragma unroll
-        for (int e = 0; e < NIN; e++) dst[e] = ((ok >> e) & 1u) ? element(raw, e) : 0.f;
+    // One input row in registers.  fp32: NIN floats.  fp16: dwords 0..5 = element pairs (0,1) (2,3) ... (10,-) masked, dwords 6..10 =
+    // the odd-aligned pairs (1,2) (3,4) ... (9,10).
+    struct Row { unsigned r[NROW]; };
+    Row rows[3 + RB];
+    auto unpack = [&](int iy, const Raw& raw, Row& dst) {
+        const bool row_ok = iy >= 0 && iy < a.in_h;
+        const unsigned ok = row_ok ? col_ok : 0u;
         const int64_t idx = row_index(iy);
-        if (ok != 0 && (idx < 0 || idx + NLOAD > numel)) {
+        const bool ragged = ok != 0 && (idx < 0 || idx + NLOAD > numel);     // first / last elements of the tensor: element-wise re-read
+        if constexpr (kHalf) {
+            unsigned d[6];
 #pragma unroll
-            for (int e = 0; e < NIN; e++)
-                if ((ok >> e) & 1u) dst[e] = (idx + e >= 0 && idx + e < numel) ? float(load_as<T>(x, idx + e)) : 0.f;
+            for (int i = 0; i < 6; i++) d[i] = row_ok ? (raw.d[i] & cmask[i]) : 0u;
+            if (ragged) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    unsigned lo = 0, hi = 0;
+                    if (((ok >> (2 * i)) & 1u) && idx + 2 * i >= 0 && idx + 2 * i < numel) lo = __half_as_ushort(x[idx + 2 * i]);
+                    if (2 * i + 1 < NIN && ((ok >> (2 * i + 1)) & 1u) && idx + 2 * i + 1 >= 0 && idx + 2 * i + 1 < numel) hi = __half_as_ushort(x[idx + 2 * i + 1]);
+                    d[i] = lo | (hi << 16);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) dst.r[i] = d[i];
+#pragma unroll
+            for (int i = 0; i < 5; i++) dst.r[6 + i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], 16);      // (element 2i+1, element 2i+2)
+        } else {
+#pragma unroll
+            for (int e = 0; e < NIN; e++) dst.r[e] = ((ok >> e) & 1u) ? raw.d[e] : 0u;
+            if (ragged) {
+#pragma unroll
+                for (int e = 0; e < NIN; e++)
+                    if ((ok >> e) & 1u) dst.r[e] = (idx + e >= 0 && idx + e < numel) ? __float_as_uint(float(load_as<T>(x, idx + e))) : 0u;
+            }
         }
     };
-    auto emit = [&](int oy, const float (&r0)[NIN], const float (&r1)[NIN], const float (&r2)[NIN], const float (&r3)[NIN]) {
-        if (!live || oy >= a.out_h || oy >= oy0 + rows_per_strip || ox0 >= a.out_w) return;
+    auto emit = [&](int oy, const Row& r0, const Row& r1, const Row& r2, const Row& r3) {        // oy in walk coordinates
+        if (!live || oy >= oy0 + rows_here || ox0 >= a.out_w) return;
         float acc[OPL];
+        const Row* rr[4] = {&r0, &r1, &r2, &r3};
+        if constexpr (kHalf) {
 #pragma unroll
-        for (int q = 0; q < OPL; q++) {
-            float s = 0.f;
+            for (int q = 0; q < OPL; q++) {
+                float sacc = 0.f;
 #pragma unroll
-            for (int kx = 0; kx < 4; kx++) s = fmaf(r0[q + kx], f[0][kx], s);
-#ifndef GNERF_ABLATE_BLURFMA
+                for (int ky = 0; ky < 4; ky++) {
+                    // outputs at even q read aligned pairs (q,q+1),(q+2,q+3); odd q the odd-aligned ones
+                    const unsigned pa = (q & 1) ? rr[ky]->r[6 + (q >> 1)] : rr[ky]->r[q >> 1];
+                    const unsigned pb = (q & 1) ? rr[ky]->r[6 + (q >> 1) + 1] : rr[ky]->r[(q >> 1) + 1];
+                    sacc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, pa), fh[ky][0], sacc, false);
+                    sacc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, pb), fh[ky][1], sacc, false);
+                }
+                acc[q] = sacc;
+            }
+            if (has_lo) {                                    // wave-uniform: taps that are not exact in fp16
 #pragma unroll
-            for (int kx = 0; kx < 4; kx++) s = fmaf(r1[q + kx], f[1][kx], s);
+                for (int q = 0; q < OPL; q++) {
 #pragma unroll
-            for (int kx = 0; kx < 4; kx++) s = fmaf(r2[q + kx], f[2][kx], s);
+                    for (int ky = 0; ky < 4; ky++) {
+                        const unsigned pa = (q & 1) ? rr[ky]->r[6 + (q >> 1)] : rr[ky]->r[q >> 1];
+                        const unsigned pb = (q & 1) ? rr[ky]->r[6 + (q >> 1) + 1] : rr[ky]->r[(q >> 1) + 1];
+                        acc[q] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, pa), fl[ky][0], acc[q], false);
+                        acc[q] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, pb), fl[ky][1], acc[q], false);
+                    }
+                }
+            }
+        } else {
 #pragma unroll
-            for (int kx = 0; kx < 4; kx++) s = fmaf(r3[q + kx], f[3][kx], s);
-#endif
-            acc[q] = s;
+            for (int q = 0; q < OPL; q++) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 4; ky++) {
+#pragma unroll
+                    for (int kx = 0; kx < 4; kx++) sacc = fmaf(__uint_as_float(rr[ky]->r[q + kx]), f[ky][kx], sacc);
+                }
+                acc[q] = sacc;
+            }
         }
-        T* yp = y + img * int64_t(a.out_h) * a.out_w + int64_t(oy) * a.out_w + ox0;
-#ifdef GNERF_ABLATE_BLURSTORE
-        if (acc[0] != 12345.f) return;
-#endif
+        const int oy_phys = up ? a.out_h - 1 - oy : oy;
+        T* yp = y + img * int64_t(a.out_h) * a.out_w + int64_t(oy_phys) * a.out_w + ox0;
         if (ox0 + OPL <= a.out_w && ((reinterpret_cast<uintptr_t>(yp) & 15) == 0)) {
             uint4 w;                                         // ONE global_store_dwordx4
-            if constexpr (sizeof(T) == 2) {
-                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            if constexpr (kHalf) {
                 w.x = __builtin_bit_cast(unsigned, (h2){(_Float16)acc[0], (_Float16)acc[1]});
                 w.y = __builtin_bit_cast(unsigned, (h2){(_Float16)acc[2], (_Float16)acc[3]});
                 w.z = __builtin_bit_cast(unsigned, (h2){(_Float16)acc[4 % OPL], (_Float16)acc[5 % OPL]});
@@ -395,7 +475,7 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpArgs a, int lx_shi
     // its speed).  So: one wait per block -- it drains the previous block's four stores and this block's four row loads,
     // which were both in flight during the previous block's arithmetic -- then the next block's loads are issued, then
     // four output rows are made and stored.  rows[0..2] are the last three input rows of the previous block.
-    const int iy_first = oy0 - a.pady0;
+    const int iy_first = oy0 - pady0;
     Raw raw[RB < 3 ? 3 : RB];
 #pragma unroll
     for (int u = 0; u < 3; u++) fetch(iy_first + u, raw[u]);
@@ -403,7 +483,6 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpArgs a, int lx_shi
     for (int u = 0; u < 3; u++) unpack(iy_first + u, raw[u], rows[u]);
 #pragma unroll
     for (int u = 0; u < RB; u++) fetch(iy_first + 3 + u, raw[u]);
-    const int rows_here = min(rows_per_strip, a.out_h - oy0);
     for (int r0 = 0; r0 < rows_here; r0 += RB) {
 #pragma unroll
         for (int u = 0; u < RB; u++) unpack(iy_first + 3 + r0 + u, raw[u], rows[3 + u]);
@@ -412,10 +491,7 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_kernel(UpArgs a, int lx_shi
 #pragma unroll
         for (int u = 0; u < RB; u++) emit(oy0 + r0 + u, rows[u], rows[u + 1], rows[u + 2], rows[u + 3]);
 #pragma unroll
-        for (int u = 0; u < 3; u++) {
-#pragma unroll
-            for (int e = 0; e < NIN; e++) rows[u][e] = rows[RB + u][e];
-        }
+        for (int u = 0; u < 3; u++) rows[u] = rows[RB + u];
     }
 }
 
@@ -427,13 +503,20 @@ int launch_blur4(const UpArgs& a, hipStream_t stream) {
     int lx_shift = 0;
     while (lx_shift < 6 && (1 << lx_shift) < lanes_needed) lx_shift++;
     const int strips_x = (lanes_needed + (1 << lx_shift) - 1) >> lx_shift;
-    const int rows_per_strip = a.out_h > 256 ? 32 : 16;      // measured flat between 8 and 64 rows: the kernel is issue-bound, not latency-bound
+    // rows per wait: 4 for fp32 (1, 2, 3, 6, 8 measured slower); 3 for fp16, whose packed row window then fits 128 VGPRs = 4 waves
+    // per SIMD (with 4 the kernel needs 130 and drops to 3: 4.04 vs ... TB/s).  GNERF_BLUR_RB overrides for A/B runs.
+    int rb = sizeof(T) == 2 ? 3 : 4;
+    if (const char* e = getenv("GNERF_BLUR_RB")) rb = atoi(e);
+    const int rows_per_strip = (a.out_h > 256 ? 32 : 16) / rb * rb + (rb == 3 ? 3 : 0);      // a multiple of rb: 32/16 (rb 2, 4), 33/18 (rb 3)
+    if (a.in_h - a.out_h + a.pady0 > 3 || a.in_h - a.out_h + a.pady0 < 0) return 1;   // upward walks need the mirrored padding inside the filter
     const int strips_y = (a.out_h + rows_per_strip - 1) / rows_per_strip;
     const int64_t strips = int64_t(strips_x) * strips_y * a.n * a.c;
     const int64_t waves = (strips + (64 >> lx_shift) - 1) / (64 >> lx_shift);
     const int64_t blocks = (waves + 3) / 4;
     if (blocks > INT32_MAX) return 1;
-    hipLaunchKernelGGL((upfirdn_blur4_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream, a, lx_shift, strips_x, strips_y, rows_per_strip);
+    if (rb == 2)      hipLaunchKernelGGL((upfirdn_blur4_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, a, lx_shift, strips_x, strips_y, rows_per_strip);
+    else if (rb == 3) hipLaunchKernelGGL((upfirdn_blur4_kernel<T, 3>), dim3((unsigned)blocks), dim3(256), 0, stream, a, lx_shift, strips_x, strips_y, rows_per_strip);
+    else              hipLaunchKernelGGL((upfirdn_blur4_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), 0, stream, a, lx_shift, strips_x, strips_y, rows_per_strip);
     return check_launch("upfirdn2d(blur4)") == GNERF_OK ? 0 : -1;
 }
 

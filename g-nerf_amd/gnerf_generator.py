@@ -68,8 +68,21 @@ class Linear(nn.Module):
         self.bias = nn.Parameter(torch.full([n_out], float(bias_init)))
         self.weight_gain, self.bias_gain = lr_multiplier / math.sqrt(n_in), lr_multiplier
 
+    def _scaled(self, dtype):
+        """(weight * weight_gain, bias * bias_gain) in `dtype`; constants at inference, cached per parameter version."""
+        w, b = self.weight, self.bias
+        if torch.is_grad_enabled() and (w.requires_grad or b.requires_grad):
+            return w.to(dtype) * self.weight_gain, b.to(dtype) * self.bias_gain
+        key = (w.data_ptr(), b.data_ptr(), None if w.is_inference() else (w._version, b._version), dtype)
+        cache = self.__dict__.get('_gnerf_scaled')
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                cache = (key, (w.to(dtype) * self.weight_gain).contiguous(), (b.to(dtype) * self.bias_gain).contiguous())
+            self.__dict__['_gnerf_scaled'] = cache
+        return cache[1], cache[2]
+
     def forward(self, x):
-        w, b = self.weight.to(x.dtype) * self.weight_gain, self.bias.to(x.dtype) * self.bias_gain
+        w, b = self._scaled(x.dtype)
         if self.activation == 'linear':
             return torch.addmm(b.unsqueeze(0), x, w.t())
         return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
