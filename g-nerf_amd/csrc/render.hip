@@ -57,7 +57,7 @@ struct Params {
     int total_rays;
     int split_shift;        // small launches: a 16-ray tile is shared by 1 << split_shift workgroups (coop / generic kernels)
     unsigned tex_pitch, row_pitch, plane_pitch;     // byte addressing of a texel, see plane_taps (render_coop.inl)
-    const int* mlp_flag;    // GNERF_MLP_AUTO: device word holding the chosen decoder arithmetic (kMlpF16x3 / kMlpF32); NULL = run
+    const float* absmax;    // GNERF_MLP_AUTO: max |planes| (one device float) for choose_mlp
 };
 
 // ---- order-preserving float <-> uint so that integer atomics give float min/max
@@ -634,11 +634,8 @@ __global__ __launch_bounds__(64) void query_kernel(gnerf_render_params p, float 
     }
 }
 
-#include "render_coop.inl"
-#include "render_pipe.inl"
-#include "render_bwd.inl"
-
-// ---- GNERF_MLP_AUTO: which decoder arithmetic may this call use?  (one 64-lane workgroup, a few hundred loads)
+// ---- GNERF_MLP_AUTO: which decoder arithmetic may this call use?  Evaluated by every workgroup of the pipe / coop kernels before
+// it stages the decoder (one wave, a few hundred loads from L2, ~0.1 % of a workgroup's work): no separate launch.
 // The f16 hi/lo split (render_coop.inl) represents an operand v as hi + lo with |v - hi - lo| <= max(2^-22 |v|, 2^-25): fp32-grade
 // for operands well inside f16's range, but an ABSOLUTE 2^-25 per operand once the low half goes subnormal, and inf/NaN once the high
 // half overflows.  With A = max |planes| (the features are convex combinations of texels, so |x| <= A), W1' = log2(e) W1 and the
@@ -649,40 +646,67 @@ __global__ __launch_bounds__(64) void query_kernel(gnerf_render_params p, float 
 //     h   = R1 A + max |b1'| + 1                                        scale of the hidden activations
 //     e_o = R2 e_p + 2^-22 R2 h + 2^-25 (R2 + 8 h)                      error of a layer-2 output
 //   f16x3 iff e_o <= 2^-12: |d rgb| <= 0.25 ln2 e_o = 4e-5 in the worst case (pixel MSE < 2e-9), typically 1e-3 of that.
-// Anything else -- including NaN/inf anywhere in the operands -- takes the exact-fp32 kernels.  BASELINE config 2 (randn planes,
+// Anything else -- including NaN/inf anywhere in the operands -- takes the exact-fp32 arithmetic.  BASELINE config 2 (randn planes,
 // default-init decoder) has e_o = 1.1e-5; planes scaled by ~20 or decoder weights by ~5 cross over to fp32.
 constexpr float kMlpRangeLimit = 30000.f;
 constexpr float kMlpErrLimit = 1.0f / 4096.f;
-__global__ __launch_bounds__(64) void mlp_select_kernel(gnerf_render_params p, const float* absmax, int* flag) {
-    const int lane = threadIdx.x;
-    // lane r < 64: row r of W1; lane r < 33: row r of W2
-    float l1 = 0.f, sq1 = 0.f, mx1 = 0.f;
-    for (int c = 0; c < 32; c++) { const float w = fabsf(p.w1[lane * 32 + c]) * kLog2e; l1 += w; sq1 += w * w; mx1 = fmaxf(mx1, w); }
-    float sq2 = 0.f, mx2 = 0.f;
-    if (lane < 33) for (int c = 0; c < 64; c++) { const float w = fabsf(p.w2[lane * 64 + c]); sq2 += w * w; mx2 = fmaxf(mx2, w); }
-    float mb1 = fabsf(p.b1[lane]) * kLog2e;
-    float mb2 = lane < 33 ? fabsf(p.b2[lane]) * kLog2e : 0.f;
-    // NaN-propagating maxima: fmaxf drops NaNs, so carry "anything not finite" separately
-    bool bad = !(l1 < INFINITY) || !(sq2 < INFINITY) || !(mb1 < INFINITY) || !(mb2 < INFINITY);
+__device__ __forceinline__ int choose_mlp(const Params& P, float* smem) {
+    const gnerf_render_params& p = P.p;
+    constexpr float kL2e = 1.44269504088896341f;
+    // the decoder into LDS with coalesced loads (rows padded to an odd pitch: the row sums below are conflict-free); a first
+    // version read the rows straight from global memory, one row per lane -- 96 uncoalesced load instructions in front of every
+    // workgroup's first ray cost 40 us per launch
+    constexpr int kP1 = 33, kP2 = 65;
+    float* s1 = smem + 4;
+    float* s2 = s1 + 64 * kP1;
+    for (int i = threadIdx.x; i < 64 * 32; i += blockDim.x) s1[(i >> 5) * kP1 + (i & 31)] = p.w1[i];
+    for (int i = threadIdx.x; i < 33 * 64; i += blockDim.x) s2[(i >> 6) * kP2 + (i & 63)] = p.w2[i];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        // lane r < 64: row r of W1; lane r < 33: row r of W2
+        float l1 = 0.f, sq1 = 0.f, mx1 = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < 32; c++) { const float w = fabsf(s1[lane * kP1 + c]) * kL2e; l1 += w; sq1 = fmaf(w, w, sq1); mx1 = fmaxf(mx1, w); }
+        float sq2 = 0.f, mx2 = 0.f;
+        if (lane < 33) {
+#pragma unroll 8
+            for (int c = 0; c < 64; c++) { const float w = fabsf(s2[lane * kP2 + c]); sq2 = fmaf(w, w, sq2); mx2 = fmaxf(mx2, w); }
+        }
+        float mb1 = fabsf(p.b1[lane]) * kL2e;
+        float mb2 = lane < 33 ? fabsf(p.b2[lane]) * kL2e : 0.f;
+        // NaN-propagating maxima: fmaxf drops NaNs, so carry "anything not finite" separately
+        bool bad = !(l1 < INFINITY) || !(sq2 < INFINITY) || !(mb1 < INFINITY) || !(mb2 < INFINITY);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        l1 = fmaxf(l1, __shfl_xor(l1, o)); sq1 = fmaxf(sq1, __shfl_xor(sq1, o)); mx1 = fmaxf(mx1, __shfl_xor(mx1, o));
-        sq2 = fmaxf(sq2, __shfl_xor(sq2, o)); mx2 = fmaxf(mx2, __shfl_xor(mx2, o));
-        mb1 = fmaxf(mb1, __shfl_xor(mb1, o)); mb2 = fmaxf(mb2, __shfl_xor(mb2, o));
+        for (int o = 32; o > 0; o >>= 1) {
+            l1 = fmaxf(l1, __shfl_xor(l1, o)); sq1 = fmaxf(sq1, __shfl_xor(sq1, o)); mx1 = fmaxf(mx1, __shfl_xor(mx1, o));
+            sq2 = fmaxf(sq2, __shfl_xor(sq2, o)); mx2 = fmaxf(mx2, __shfl_xor(mx2, o));
+            mb1 = fmaxf(mb1, __shfl_xor(mb1, o)); mb2 = fmaxf(mb2, __shfl_xor(mb2, o));
+        }
+        bad = __any(bad);
+        if (lane == 0) {
+            const float A = *P.absmax;
+            const float R1 = sqrtf(sq1), R2 = sqrtf(sq2);
+            const float h_hard = l1 * A + mb1 + 1.f;
+            const float e_p = 0x1p-22f * R1 * A + 0x1p-25f * (R1 + 5.657f * A);
+            const float h = R1 * A + mb1 + 1.f;
+            const float e_o = R2 * e_p + 0x1p-22f * R2 * h + 0x1p-25f * (R2 + 8.f * h);
+            const bool ok = !bad && A <= kMlpRangeLimit && mx1 <= kMlpRangeLimit && mx2 <= kMlpRangeLimit && h_hard <= kMlpRangeLimit
+                            && mb2 <= kMlpRangeLimit && e_o <= kMlpErrLimit;         // every comparison is false for NaN
+            const int choice = ok ? 1 : 2;                                           // kMlpF16x3 : kMlpF32
+            reinterpret_cast<int*>(smem)[0] = choice;
+            if (blockIdx.x == 0) static_cast<int*>(p.workspace)[4] = choice;         // diagnostics (gnerf_hip.last_mlp_choice)
+        }
     }
-    bad = __any(bad);
-    if (lane == 0) {
-        const float A = *absmax;
-        const float R1 = sqrtf(sq1), R2 = sqrtf(sq2);
-        const float h_hard = l1 * A + mb1 + 1.f;
-        const float e_p = 0x1p-22f * R1 * A + 0x1p-25f * (R1 + 5.657f * A);
-        const float h = R1 * A + mb1 + 1.f;
-        const float e_o = R2 * e_p + 0x1p-22f * R2 * h + 0x1p-25f * (R2 + 8.f * h);
-        const bool ok = !bad && A <= kMlpRangeLimit && mx1 <= kMlpRangeLimit && mx2 <= kMlpRangeLimit && h_hard <= kMlpRangeLimit
-                        && mb2 <= kMlpRangeLimit && e_o <= kMlpErrLimit;         // every comparison is false for NaN
-        *flag = ok ? kMlpF16x3 : kMlpF32;
-    }
+    __syncthreads();
+    const int choice = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(smem)[0]);
+    __syncthreads();                                     // smem is the body's from here on
+    return choice;
 }
+
+#include "render_coop.inl"
+#include "render_pipe.inl"
+#include "render_bwd.inl"
 
 // hipFuncSetAttribute is per device: remember which devices of this process have had a kernel's dynamic-LDS limit raised
 struct PerDeviceOnce {
@@ -747,7 +771,7 @@ static int fill_params(const gnerf_render_params* p, Params& P) {
     P.tiles_f = (F + 15) / 16;
     P.total_rays = int(total);
     P.split_shift = 0;
-    P.mlp_flag = nullptr;
+    P.absmax = nullptr;
     const int iw = p->image_width;
     if (iw > 0 && iw % 4 == 0 && p->rays_per_item % iw == 0 && (p->rays_per_item / iw) % 4 == 0) {
         P.tiles_y = p->rays_per_item / iw / 4;
@@ -798,18 +822,13 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
     if (force_mlp && !strcmp(force_mlp, "f32")) mlp = GNERF_MLP_F32;
     if (mlp != GNERF_MLP_AUTO && mlp != GNERF_MLP_F16X3 && mlp != GNERF_MLP_F32) return fail(GNERF_E_ARG, "render: mlp_mode %d is not one of GNERF_MLP_*", mlp);
     if ((pipe || coop) && mlp == GNERF_MLP_AUTO) {
-        // the choice is made on the device (no host round trip, graph-capturable): both precisions are launched and the
-        // one that was not chosen returns at once
-        int* ws_words = static_cast<int*>(p->workspace);
-        const float* absmax = p->planes_absmax;
-        if (!absmax) {
-            float* own = reinterpret_cast<float*>(ws_words + 5);
+        // the choice is made on the device, by every workgroup for itself (no host round trip, graph-capturable): see choose_mlp
+        P.absmax = p->planes_absmax;
+        if (!P.absmax) {
+            float* own = reinterpret_cast<float*>(static_cast<int*>(p->workspace) + 5);
             if (int e = gnerf_planes_absmax(p->planes_nhwc, int64_t(p->n_items) * 3 * p->plane_h * p->plane_w * 32, own, stream)) return e;
-            absmax = own;
+            P.absmax = own;
         }
-        hipLaunchKernelGGL(mlp_select_kernel, dim3(1), dim3(64), 0, s, *p, absmax, ws_words + 4);
-        if (int e = check_launch("mlp_select_kernel")) return e;
-        P.mlp_flag = ws_words + 4;
     }
     if (pipe) {
         const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : total;
@@ -819,33 +838,30 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         if (g < kNumXCD) g = kNumXCD;
         const int per_cu = pipe_tp == 1 ? GNERF_PIPE_WAVES_PER_SIMD : 2;                         // resident workgroups per CU
         if (g > per_cu * kNumCU) g = per_cu * kNumCU;
-        for (int m = kMlpF16x3; m <= kMlpF32; m++) {
-            if (mlp != GNERF_MLP_AUTO && mlp != m) continue;
-            const size_t lds_bytes = pipe_lds_floats(pipe_tp, m) * sizeof(float);
-            if (pipe_tp == 1 && m == kMlpF16x3) hipLaunchKernelGGL((render_kernel_pipe<1, kMlpF16x3>), dim3((unsigned)g), dim3(kPipeThreads), lds_bytes, s, P);
-            else if (pipe_tp == 1)              hipLaunchKernelGGL((render_kernel_pipe<1, kMlpF32>), dim3((unsigned)g), dim3(kPipeThreads), lds_bytes, s, P);
-            else if (m == kMlpF16x3)            hipLaunchKernelGGL((render_kernel_pipe<2, kMlpF16x3>), dim3((unsigned)g), dim3(kPipeThreads), lds_bytes, s, P);
-            else                                hipLaunchKernelGGL((render_kernel_pipe<2, kMlpF32>), dim3((unsigned)g), dim3(kPipeThreads), lds_bytes, s, P);
-            if (int e = check_launch("render_kernel_pipe")) return e;
-        }
+        const size_t lds_bytes = pipe_lds_floats(pipe_tp, mlp) * sizeof(float);
+        const dim3 gd((unsigned)g), bd(kPipeThreads);
+#define GNERF_PIPE(TP) do { if (mlp == kMlpAuto) hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpAuto>), gd, bd, lds_bytes, s, P); \
+                            else if (mlp == kMlpF16x3) hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpF16x3>), gd, bd, lds_bytes, s, P); \
+                            else hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpF32>), gd, bd, lds_bytes, s, P); } while (0)
+        if (pipe_tp == 1) GNERF_PIPE(1); else GNERF_PIPE(2);
+#undef GNERF_PIPE
+        if (int e = check_launch("render_kernel_pipe")) return e;
     } else
     if (coop) {
         const int tc1 = (P.tiles_c + kCoopWaves - 1) / kCoopWaves, tf1 = (P.tiles_f + kCoopWaves - 1) / kCoopWaves;
         const dim3 block(kCoopThreads);
-        for (int m = kMlpF16x3; m <= kMlpF32; m++) {
-            if (mlp != GNERF_MLP_AUTO && mlp != m) continue;
-            const size_t lds_bytes = coop_lds_floats(16 * (P.tiles_c + P.tiles_f), m) * sizeof(float);
-#define GNERF_COOP(TC, TF) do { if (m == kMlpF16x3) hipLaunchKernelGGL((render_kernel_coop<TC, TF, kMlpF16x3>), grid, block, lds_bytes, s, P); \
+        const size_t lds_bytes = coop_lds_floats(16 * (P.tiles_c + P.tiles_f), mlp) * sizeof(float);
+#define GNERF_COOP(TC, TF) do { if (mlp == kMlpAuto) hipLaunchKernelGGL((render_kernel_coop<TC, TF, kMlpAuto>), grid, block, lds_bytes, s, P); \
+                                else if (mlp == kMlpF16x3) hipLaunchKernelGGL((render_kernel_coop<TC, TF, kMlpF16x3>), grid, block, lds_bytes, s, P); \
                                 else hipLaunchKernelGGL((render_kernel_coop<TC, TF, kMlpF32>), grid, block, lds_bytes, s, P); } while (0)
-            if (tc1 == 1 && tf1 == 0) GNERF_COOP(1, 0);
-            else if (tc1 == 1 && tf1 == 1) GNERF_COOP(1, 1);
-            else if (tc1 == 1 && tf1 == 2) GNERF_COOP(1, 2);
-            else if (tc1 == 2 && tf1 == 0) GNERF_COOP(2, 0);
-            else if (tc1 == 2 && tf1 == 1) GNERF_COOP(2, 1);
-            else GNERF_COOP(2, 2);
+        if (tc1 == 1 && tf1 == 0) GNERF_COOP(1, 0);
+        else if (tc1 == 1 && tf1 == 1) GNERF_COOP(1, 1);
+        else if (tc1 == 1 && tf1 == 2) GNERF_COOP(1, 2);
+        else if (tc1 == 2 && tf1 == 0) GNERF_COOP(2, 0);
+        else if (tc1 == 2 && tf1 == 1) GNERF_COOP(2, 1);
+        else GNERF_COOP(2, 2);
 #undef GNERF_COOP
-            if (int e = check_launch("render_kernel_coop")) return e;
-        }
+        if (int e = check_launch("render_kernel_coop")) return e;
     } else {
         const size_t lds_bytes = scratch_floats(16 * (P.tiles_c + P.tiles_f), P.tiles_c + P.tiles_f) * sizeof(float);
         if (lds_bytes > 160 * 1024) return fail(GNERF_E_ARG, "render: %d+%d samples need %zu bytes of LDS (> 160 KiB)", S, F, lds_bytes);

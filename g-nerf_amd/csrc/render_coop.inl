@@ -21,16 +21,16 @@ constexpr int kW2Pitch = 68;        // floats per LDS row of W2 [33 x 64]
 constexpr int kTapDwords = 24;      // per sample: 3 planes x (4 byte offsets + 4 weights)
 
 // Decoder weights in LDS.  Two formats, BOTH shipped (template parameter MLP of the kernels; chosen per call, see
-// mlp_select_kernel in render.hip):
+// choose_mlp in render.hip):
 //  * kMlpF16x3: every fp32 weight w is stored as two halves (hi = f16(w), lo = f16(w - hi)) in MFMA fragment
 //    order, and each product of the MLP is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with fp32
 //    accumulation (the dropped lo*lo term and the split's own rounding are ~2^-21 relative, i.e. fp32-grade: the
 //    renderer's pixel MSE against the reference stays ~1e-13).  24 matrix instructions x 16 cycles per 16-sample tile
 //    instead of 64 x 32 cycles of v_mfma_f32_16x16x4_f32.  Only valid while features, weights and hidden activations
 //    stay inside f16's range and the absolute error of the low halves (2^-25 per operand) stays negligible after the
-//    decoder's own amplification -- which is what mlp_select_kernel decides on the device, per call.
+//    decoder's own amplification -- which is what choose_mlp (render.hip) decides on the device, per call.
 //  * kMlpF32: plain fp32 rows (exact fp32 products on the fp32-input MFMA): any finite input.
-constexpr int kMlpF16x3 = 1, kMlpF32 = 2;          // = GNERF_MLP_F16X3 / GNERF_MLP_F32
+constexpr int kMlpAuto = 0, kMlpF16x3 = 1, kMlpF32 = 2;          // = GNERF_MLP_AUTO / GNERF_MLP_F16X3 / GNERF_MLP_F32
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 constexpr float kLog2e = 1.44269504088896341f, kLn2 = 0.693147180559945309f;
 
@@ -61,7 +61,9 @@ __device__ __forceinline__ h8 as_h8(u4v v) { return __builtin_bit_cast(h8, v); }
 constexpr int kW1HalfPitch = 40;    // halves per LDS row of W1 hi / lo (32 + pad: conflict-free ds_read_b128)
 constexpr int kWeightFloatsF32 = 64 * 36 + 33 * 68;
 constexpr int kWeightFloatsF16 = (2 * 64 * kW1HalfPitch + 2 * 2048) / 2 + 64;  // W1 hi+lo, W2 hi+lo (fragment order), density row fp32
-__host__ __device__ constexpr int weight_floats(int mlp) { return mlp == kMlpF32 ? kWeightFloatsF32 : kWeightFloatsF16; }
+__host__ __device__ constexpr int weight_floats(int mlp) {
+    return mlp == kMlpF32 ? kWeightFloatsF32 : (mlp == kMlpF16x3 ? kWeightFloatsF16 : (kWeightFloatsF32 > kWeightFloatsF16 ? kWeightFloatsF32 : kWeightFloatsF16));
+}
 
 struct CoopLds {
     float* w1; float* w2; float* b1; float* b2;
@@ -499,9 +501,7 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
 }
 
 template <int TC1, int TF1, int MLP>
-__global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) {
-    if (P.mlp_flag && *P.mlp_flag != MLP) return;       // auto mode: both precisions are launched, the device-side choice runs
-    extern __shared__ __align__(16) float smem[];
+__device__ __forceinline__ void render_coop_body(const Params& P, float* smem) {
     const gnerf_render_params& p = P.p;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -779,4 +779,17 @@ __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) 
         __syncthreads();
     }
     if (tid == 0) publish_depth_range(P, blk_min, blk_max);
+}
+
+// GNERF_MLP_AUTO: every workgroup evaluates the (cheap, deterministic) range bounds itself -- choose_mlp in render.hip -- and runs
+// the body of the arithmetic they allow: one launch, no select kernel, no second grid that returns at once.
+template <int TC1, int TF1, int MLP>
+__global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) {
+    extern __shared__ __align__(16) float smem[];
+    if constexpr (MLP == kMlpAuto) {
+        if (choose_mlp(P, smem) == kMlpF32) render_coop_body<TC1, TF1, kMlpF32>(P, smem);
+        else                               render_coop_body<TC1, TF1, kMlpF16x3>(P, smem);
+    } else {
+        render_coop_body<TC1, TF1, MLP>(P, smem);
+    }
 }

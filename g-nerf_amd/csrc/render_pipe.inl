@@ -83,11 +83,9 @@ __device__ __forceinline__ int pipe_seq_to_ray(const Params& P, int64_t seq) {
 #define GNERF_PIPE_WAVES_PER_SIMD 3
 #endif
 template <int TP, int MLP>
-__global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD : 2) void render_kernel_pipe(Params P) {
-    if (P.mlp_flag && *P.mlp_flag != MLP) return;       // auto mode: both precisions are launched, the device-side choice runs
+__device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
     typedef PipeDims<TP> D;
     constexpr int kPipeMaxS = D::kMaxS, kPipeSPad = D::kSPad, kSlotFloats = D::kSlotFloats, RND = D::kRounds;
-    extern __shared__ __align__(16) float smem[];
     const gnerf_render_params& p = P.p;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -484,4 +482,15 @@ __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD :
     }
 #endif
     if (wv == 3 && lane == 0) publish_depth_range(P, blk_min, blk_max);
+}
+
+template <int TP, int MLP>
+__global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD : 2) void render_kernel_pipe(Params P) {
+    extern __shared__ __align__(16) float smem[];
+    if constexpr (MLP == kMlpAuto) {            // see render_kernel_coop
+        if (choose_mlp(P, smem) == kMlpF32) render_pipe_body<TP, kMlpF32>(P, smem);
+        else                               render_pipe_body<TP, kMlpF16x3>(P, smem);
+    } else {
+        render_pipe_body<TP, MLP>(P, smem);
+    }
 }
