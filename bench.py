@@ -229,10 +229,13 @@ def gen_videos_secondary(rank, world, dev, n_frames=240):
             out[name] = n_frames / H.max_over_ranks(time.perf_counter() - t0, dev)
             if rank == 0:
                 assert full.shape == (n_frames, 512, 512, 3) and full.dtype == torch.uint8
-    return {'metric': 'frames/sec gen_videos', 'value': out['hip_graph'], 'unit': 'frames/s', 'eager_value': out['eager'], 'n_gpus': world,
+    best = max(out, key=out.get)
+    return {'metric': 'frames/sec gen_videos', 'value': out[best], 'unit': 'frames/s', 'value_is': best, 'eager_value': out['eager'],
+            'hip_graph_value': out['hip_graph'], 'n_gpus': world,
             'workload': f'config 4: {n_frames}-frame orbit sharded over {world} GPU(s), 64x64 rays x (96+96) samples, cached backbone, SR to '
-                        '512x512 fp16, uint8 frames, one all-gather; random-init FFHQ-config generator; value = HIP-graph replay of the '
-                        'per-frame sequence (captured once, before the timed orbit), eager_value = plain launches (backbone pass included)'}
+                        '512x512 fp16, uint8 frames, one all-gather; random-init FFHQ-config generator; hip_graph_value = HIP-graph replay of the '
+                        'per-frame sequence (captured once, before the timed orbit), eager_value = plain launches (backbone pass included); '
+                        'value = the faster of the two'}
 
 
 def main():

@@ -55,6 +55,31 @@ with torch.no_grad():
     planes = torch.randn(4, 3, 32, 256, 256, device=dev)
     ms = timeit(lambda: gnerf_hip.planes_to_nhwc(planes))
     report('planes NCHW->NHWC [12,32,256,256] f32', ms, 2 * planes.numel() * 4)
+    # round 2: the producer's fused last step (upsample2d + add, channels_last out, max|planes|), the modconv kernels
+    img = torch.randn(4, 96, 128, 128, device=dev)
+    yy = torch.randn(4, 96, 256, 256, device=dev)
+    ms = timeit(lambda: gnerf_hip.upsample2x_add_nhwc(img, yy, f, with_absmax=True))
+    report('upsample2d + add -> channels_last (+absmax) [4,96,128,128]->256 f32', ms, (img.numel() + 2 * yy.numel()) * 4)
+    ms = timeit(lambda: upfirdn2d.upsample2d(img, f).add_(yy))
+    report('(the same as two launches: upsample2d, add_, NCHW; the NCHW->NHWC repack would follow) f32', ms, (img.numel() + 2 * yy.numel()) * 4)
+    ms = timeit(lambda: gnerf_hip.planes_absmax(yy))
+    report('planes_absmax [4,96,256,256] f32', ms, yy.numel() * 4)
+    for dt, nm in ((torch.float16, 'f16'), (torch.float32, 'f32')):
+        es = 2 if dt == torch.float16 else 4
+        x = torch.randn(4, 128, 512, 512, device=dev, dtype=dt)
+        b = torch.randn(128, device=dev, dtype=dt)
+        sc = torch.rand(4, 128, device=dev) + 0.5
+        nz = torch.randn(512, 512, device=dev)
+        ms = timeit(lambda: gnerf_hip.modconv_epilogue(x, b, scale=sc, noise=nz, round_noise=True, act='lrelu', gain=1.41, clamp=256))
+        report(f'modconv_epilogue (demod + noise + bias + lrelu + clamp) [4,128,512,512] {nm}', ms, 2 * x.numel() * es + nz.numel() * 4)
+        ms = timeit(lambda: gnerf_hip.scale_channels(x, sc))
+        report(f'scale_channels [4,128,512,512] {nm}', ms, 2 * x.numel() * es)
+    wgt, sty = torch.randn(512, 512, 3, 3, device=dev), torch.randn(4, 512, device=dev)
+    ms = timeit(lambda: gnerf_hip.modulate_weights(wgt, sty, True, out_dtype=torch.float32))
+    report('modulate_weights [512,512,3,3] x 4 styles -> f32', ms, wgt.numel() * 4 + 4 * wgt.numel() * 4)
+    import gnerf_generator as GG
+    ms = timeit(lambda: GG._modulated_weights(wgt, sty, True, False))
+    report('(the PyTorch-op chain it replaces: 7 launches) f32', ms, wgt.numel() * 4 + 4 * wgt.numel() * 4)
     # torch's own elementwise path for scale: same bytes as bias_act
     x = torch.randn(4, 128, 512, 512, device=dev, dtype=torch.float16)
     ms = timeit(lambda: torch.nn.functional.leaky_relu(x, 0.2))

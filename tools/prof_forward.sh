@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
-CMD="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary"
+CMD="python3 $R/bench.py --steps 20 --warmup 3 --reps 3 --no-cpu-baseline --no-secondary"
 timeout 180 rocprofv3 --kernel-trace --stats -d $out/stats -o run -- $CMD > $out/stats.log 2>&1
 pass() { name=$1; shift; timeout 180 rocprofv3 --pmc "$@" -d $out/$name -o run -- $CMD > $out/$name.log 2>&1; }
 pass sq1 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES
