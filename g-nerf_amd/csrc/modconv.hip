@@ -9,7 +9,7 @@
 //   gnerf_modconv_epilogue   what follows the convolution: demodulation (un-fused, :79-80) + noise (:79-83 / :96-97) + bias +
 //                            activation + gain + clamp (bias_act, :331-333) in ONE pass over the activations instead of three.
 // Every intermediate the composed ops would have materialised in the activations' dtype is rounded to that dtype here too, so the
-// results equal the composed ops' bit for bit (tests/test_gpu_parity.py::test_modconv_*).
+// results equal the composed ops' up to a last-place rounding (tests/test_gpu_parity.py::test_modconv_*).
 
 #include "common.h"
 
@@ -94,7 +94,12 @@ struct EpiArgs {
 };
 
 // y[row, :] = clamp(act(round_T(x[row, :] * T(scale[row]) + noise[:]) + bias[row % channels]) * gain); rows = blockIdx.y
-template <class T, int VEC, int ACT>
+// SCALE / NOISE are compile-time so that the superresolution's layers (no noise) and the fused-convolution form (no scale) carry
+// none of the other's instructions: the fp16 kernel is instruction-bound (first version, everything at run time: 2.2 TB/s on
+// [4,128,512,512] against bias_act's 5.5).  The fp16 demodulation + noise step is ONE packed half FMA per pair of elements:
+// x, scale and noise are halves there, so v_pk_fma_f16 rounds the exact x * scale + noise once -- the value torch.addcmul / the
+// half multiply of the composed ops store.
+template <class T, int VEC, int ACT, bool SCALE, bool NOISE>
 __global__ __launch_bounds__(kThreads) void modconv_epilogue_kernel(EpiArgs a) {
     typedef Pk<T, VEC> P;
     const unsigned row = blockIdx.y;
@@ -102,21 +107,52 @@ __global__ __launch_bounds__(kThreads) void modconv_epilogue_kernel(EpiArgs a) {
     if (v * VEC >= a.row_len) return;
     const T* x = static_cast<const T*>(a.x) + int64_t(row) * a.row_len;
     T* y = static_cast<T*>(a.y) + int64_t(row) * a.row_len;
-    const float sc = a.scale ? round_to<T>(a.scale[row]) : 1.f;
     const float bv = a.bias ? float(load_as<T>(static_cast<const T*>(a.bias), row % a.channels)) : 0.f;
-    const float* nz = a.noise ? a.noise + (a.noise_per_item ? int64_t(row / a.channels) * a.row_len : 0) : nullptr;
-    const P in = *reinterpret_cast<const P*>(x + v * VEC);
+    const float* nz = NOISE ? a.noise + (a.noise_per_item ? int64_t(row / a.channels) * a.row_len : 0) : nullptr;
+    P in = *reinterpret_cast<const P*>(x + v * VEC);
     float nv[VEC];
+    if constexpr (NOISE) {
 #pragma unroll
-    for (int k = 0; k < VEC; k++) nv[k] = nz ? nz[v * VEC + k] : 0.f;
+        for (int k = 0; k < VEC; k++) nv[k] = nz[v * VEC + k];
+    }
+    float t[VEC];
+    if constexpr (sizeof(T) == 2 && VEC % 2 == 0 && (SCALE || NOISE)) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const _Float16 sh = SCALE ? (_Float16)a.scale[row] : (_Float16)1.0f;
+        const h2 s2 = {sh, sh};
+#pragma unroll
+        for (int k = 0; k < VEC; k += 2) {
+            h2 xv = {__builtin_bit_cast(_Float16, in.v[k]), __builtin_bit_cast(_Float16, in.v[k + 1])};
+            h2 r;
+            if constexpr (NOISE) {
+                // fused-convolution order adds the fp32 noise to the half activation (one rounding); the un-fused order rounds the noise first
+                if (a.round_noise || SCALE) {
+                    const h2 n2 = {(_Float16)nv[k], (_Float16)nv[k + 1]};
+                    r = __builtin_elementwise_fma(xv, s2, n2);
+                } else {
+                    r = (h2){(_Float16)((float)xv[0] + nv[k]), (_Float16)((float)xv[1] + nv[k + 1])};
+                }
+            } else {
+                r = xv * s2;
+            }
+            t[k] = (float)r[0];
+            t[k + 1] = (float)r[1];
+        }
+    } else {
+        const float sc = SCALE ? round_to<T>(a.scale[row]) : 1.f;
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+            float u = float(load_as<T>(in.v, k));
+            if constexpr (SCALE || NOISE) u = round_to<T>(fmaf(u, sc, NOISE ? (a.round_noise ? round_to<T>(nv[k]) : nv[k]) : 0.f));
+            t[k] = u;
+        }
+    }
     P out;
 #pragma unroll
     for (int k = 0; k < VEC; k++) {
-        float t = float(load_as<T>(in.v, k));
-        if (a.scale || nz) t = round_to<T>(fmaf(t, sc, a.round_noise ? round_to<T>(nv[k]) : nv[k]));
-        t += bv;
-        float r = t;
-        if (ACT == 3) r = t > 0.f ? t : t * a.alpha;          // lrelu
+        const float u = t[k] + bv;
+        float r = u;
+        if (ACT == 3) r = u > 0.f ? u : u * a.alpha;          // lrelu
         r *= a.gain;
         if (a.clamp >= 0.f) r = r > a.clamp ? a.clamp : (r < -a.clamp ? -a.clamp : r);
         store_as<T>(out.v, k, r);
@@ -195,12 +231,17 @@ extern "C" int gnerf_modconv_epilogue(const void* x, void* y, int dtype, int row
     EpiArgs a{x, y, scale, noise, bias, unsigned(row_len), unsigned(channels), noise_per_item, round_noise, act, alpha, gain, clamp};
     const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
     hipStream_t s = as_stream(stream);
+#define GNERF_EPI3(T_, V_, A_) do { \
+        if (scale && noise)  hipLaunchKernelGGL((modconv_epilogue_kernel<T_, V_, A_, true, true>), g, dim3(kThreads), 0, s, a); \
+        else if (scale)      hipLaunchKernelGGL((modconv_epilogue_kernel<T_, V_, A_, true, false>), g, dim3(kThreads), 0, s, a); \
+        else if (noise)      hipLaunchKernelGGL((modconv_epilogue_kernel<T_, V_, A_, false, true>), g, dim3(kThreads), 0, s, a); \
+        else                 hipLaunchKernelGGL((modconv_epilogue_kernel<T_, V_, A_, false, false>), g, dim3(kThreads), 0, s, a); } while (0)
 #define GNERF_EPI(T_, V_) do { const dim3 g((row_len / V_ + kThreads - 1) / kThreads, rows); \
-        if (act == 3) hipLaunchKernelGGL((modconv_epilogue_kernel<T_, V_, 3>), g, dim3(kThreads), 0, s, a); \
-        else          hipLaunchKernelGGL((modconv_epilogue_kernel<T_, V_, 1>), g, dim3(kThreads), 0, s, a); } while (0)
+        if (act == 3) GNERF_EPI3(T_, V_, 3); else GNERF_EPI3(T_, V_, 1); } while (0)
     if (dtype == GNERF_F16) { if (al && row_len % 8 == 0) GNERF_EPI(__half, 8); else GNERF_EPI(__half, 1); }
     else if (dtype == GNERF_F32) { if (al && row_len % 4 == 0) GNERF_EPI(float, 4); else GNERF_EPI(float, 1); }
     else return fail(GNERF_E_ARG, "modconv_epilogue: dtype must be float32 or float16");
 #undef GNERF_EPI
+#undef GNERF_EPI3
     return check_launch("modconv_epilogue");
 }

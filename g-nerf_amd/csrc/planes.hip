@@ -65,7 +65,17 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     unsigned amax = 0u;
     const int64_t n4 = numel >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
-    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n4; i += int64_t(gridDim.x) * 256) {
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {          // four independent 16-byte loads in flight per lane
+        const float4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
+        const unsigned m0 = max(max(abs_bits(v0.x), abs_bits(v0.y)), max(abs_bits(v0.z), abs_bits(v0.w)));
+        const unsigned m1 = max(max(abs_bits(v1.x), abs_bits(v1.y)), max(abs_bits(v1.z), abs_bits(v1.w)));
+        const unsigned m2 = max(max(abs_bits(v2.x), abs_bits(v2.y)), max(abs_bits(v2.z), abs_bits(v2.w)));
+        const unsigned m3 = max(max(abs_bits(v3.x), abs_bits(v3.y)), max(abs_bits(v3.z), abs_bits(v3.w)));
+        amax = max(amax, max(max(m0, m1), max(m2, m3)));
+    }
+    for (; i < n4; i += stride) {
         const float4 v = x4[i];
         amax = max(max(amax, abs_bits(v.x)), max(max(abs_bits(v.y), abs_bits(v.z)), abs_bits(v.w)));
     }
