@@ -124,8 +124,8 @@ __device__ __forceinline__ float sigmoid_rgb_hw(float x) {      // sigmoid(x) * 
 __device__ __forceinline__ void plane_taps(int H, int W, float u, float v, unsigned tex_pitch, unsigned row_pitch, unsigned plane_bytes_off, uint4& off, v4f& wgt) {
     float ix = ((u + 1.f) * float(W) - 1.f) * 0.5f;
     float iy = ((v + 1.f) * float(H) - 1.f) * 0.5f;
-    ix = fminf(fmaxf(ix, -1.5f), float(W) + 0.5f);
-    iy = fminf(fmaxf(iy, -1.5f), float(H) + 0.5f);
+    ix = clamp_nn(ix, -1.5f, float(W) + 0.5f);           // (a NaN coordinate comes out as one of the bounds: all taps get weight 0 or
+    iy = clamp_nn(iy, -1.5f, float(H) + 0.5f);           //  NaN weights, as before -- the fp32 oracle's NaN propagates either way)
     const float x0f = floorf(ix), y0f = floorf(iy);
     const float fx = ix - x0f, fy = iy - y0f;
     const int x0 = int(x0f), y0 = int(y0f), x1 = x0 + 1, y1 = y0 + 1;
@@ -438,11 +438,11 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
         // h' = log2(1 + 2^p'); beyond p' = 126 the sum overflows and h' = p' takes over (it is exact from p' = 25 on)
         v4f e;
 #pragma unroll
-        for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(fminf(h[m][r], 126.f));
+        for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(min_nn(h[m][r], 126.f));
 #pragma unroll
         for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_logf(1.0f + e[r]);
 #pragma unroll
-        for (int r = 0; r < 4; r++) hv[m][r] = act_softplus(fmaxf(e[r], h[m][r]), h[m][r]);
+        for (int r = 0; r < 4; r++) hv[m][r] = act_softplus(max_nn(e[r], h[m][r]), h[m][r]);
         const v4f ws = *reinterpret_cast<const v4f*>(L.w2 + 16 * m + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; r++) sig = fmaf(ws[r], hv[m][r], sig);

@@ -194,7 +194,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
             pw[q] = 0.f;
             if (i < n_w) {
                 const float w0 = sl.w_s[i], w1 = sl.w_s[i + 1], w2 = sl.w_s[i + 2];
-                pw[q] = ((fmaxf(w0, w1) + fmaxf(w1, w2)) * 0.5f + 0.01f) + 1e-5f;
+                pw[q] = ((max_nn(w0, w1) + max_nn(w1, w2)) * 0.5f + 0.01f) + 1e-5f;
             }
             carry = wave_last(wave_scan_add(pw[q], lane) + carry);
         }
