@@ -358,9 +358,9 @@ def main():
         pmc, pmc_source = latest_pmc()
         roof = roofline(kernel_ms_by_mlp['f16x3'], rays_per_call, S_COARSE, S_FINE, PLANE, N_ITEMS, pmc, pmc_source, traffic)
         roof['render_call_ms'] = kernel_ms_by_mlp
-        roof['render_call_ms_note'] = ('HIP events around the render call inside timed regions: auto = what the headline runs (device-side choice: '
-                                       'mlp_select + both precisions launched, the unchosen one returns at once; it picks f16x3 here), f16x3 / f32 = '
-                                       'that arithmetic forced; each includes the depth-clamp epilogue')
+        roof['render_call_ms_note'] = ('HIP events around the render call inside timed regions: auto = what the headline runs (every workgroup '
+                                       'evaluates the range bounds itself and runs the f16x3 body here), f16x3 / f32 = that arithmetic forced; each '
+                                       'includes the depth-clamp epilogue')
         roof['render_call_ms_per_rank'] = per_rank_ms
         line = {
             'metric': 'rays/sec at 128^2 neural render, 96 depth samples',

@@ -11,6 +11,6 @@ for v in "$@"; do
   defs=""
   IFS='+' read -ra parts <<< "$v"
   for p in "${parts[@]}"; do if [ "$p" = STAMPS ]; then defs="$defs -DGNERF_STAMPS"; elif [ "${p#D:}" != "$p" ]; then defs="$defs -D${p#D:}"; elif [ "$p" != base ]; then defs="$defs -DGNERF_ABLATE_$p"; fi; done
-  ( /opt/rocm/bin/hipcc $FLAGS $defs -shared "$src"/capi.hip "$src"/planes.hip "$src"/render.hip "$src"/bias_act.hip "$src"/upfirdn2d.hip "$src"/filtered_lrelu.hip "$src"/filtered_lrelu_fused.hip "$src"/grid_sample.hip -o "$out/libgnerf_$v.so" && echo "[variant] $v" ) &
+  ( /opt/rocm/bin/hipcc $FLAGS $defs -shared "$src"/capi.hip "$src"/planes.hip "$src"/modconv.hip "$src"/render.hip "$src"/bias_act.hip "$src"/upfirdn2d.hip "$src"/filtered_lrelu.hip "$src"/filtered_lrelu_fused.hip "$src"/grid_sample.hip -o "$out/libgnerf_$v.so" && echo "[variant] $v" ) &
 done
 wait
