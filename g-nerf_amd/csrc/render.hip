@@ -898,8 +898,29 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
     if (int e = once.raise_lds(render_bwd_kernel, "render_backward")) return e;
     const int n_blocks = (P.n_tiles + kBwdWaves - 1) / kBwdWaves;
     const int per_xcd = (n_blocks + kNumXCD - 1) / kNumXCD;
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(per_xcd * kNumXCD), dim3(kBwdThreads), lds_bytes, as_stream(stream), P, *g);
-    return check_launch("render_bwd_kernel");
+    // Staged scatter (see plane_scatter_kernel): needs the caller's staging buffer, a plane gradient to make, and ray tiles that do
+    // not straddle items.  GNERF_BWD_SCATTER=direct|staged forces one route (A/B runs and tests).
+    const char* route = getenv("GNERF_BWD_SCATTER");
+    const bool tiles_ok = P.tiles_per_item > 0 || p->n_items == 1 || p->rays_per_item % kBwdRaysPerWave == 0;
+    bool staged = g->scatter_stage != nullptr && g->grad_planes_nhwc != nullptr && tiles_ok;
+    if (route && !strcmp(route, "direct")) staged = false;
+    if (route && !strcmp(route, "staged") && !staged) return fail(GNERF_E_ARG, "render_backward: the staged scatter needs scatter_stage, a plane gradient and whole tiles per item");
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(per_xcd * kNumXCD), dim3(kBwdThreads), lds_bytes, as_stream(stream), P, *g, staged ? g->scatter_stage : static_cast<float*>(nullptr));
+    if (int e = check_launch("render_bwd_kernel")) return e;
+    if (staged) {
+        static PerDeviceOnce once_scatter;
+        if (int e = once_scatter.raise_lds(plane_scatter_kernel, "render_backward")) return e;
+        hipLaunchKernelGGL(plane_scatter_kernel, dim3(P.n_tiles), dim3(kScatterThreads), scatter_lds_floats() * sizeof(float), as_stream(stream),
+                           P, static_cast<const float*>(g->scatter_stage), g->grad_planes_nhwc);
+        return check_launch("plane_scatter_kernel");
+    }
+    return GNERF_OK;
+}
+
+extern "C" size_t gnerf_render_backward_stage_bytes(const gnerf_render_params* p) {
+    if (!p || p->n_items < 1 || p->rays_per_item < 1) return 0;
+    const size_t n_all = size_t(p->depth_resolution) + size_t(p->depth_resolution_importance);
+    return size_t(p->n_items) * size_t(p->rays_per_item) * n_all * 33 * sizeof(float);
 }
 
 extern "C" int gnerf_query_points(const float* planes_nhwc, int n_items, int plane_h, int plane_w,

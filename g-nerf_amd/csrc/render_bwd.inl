@@ -285,7 +285,9 @@ __device__ __forceinline__ void bwd_tile_core(const BwdLds& L, v4f (&h)[4], floa
     }
 }
 
-__device__ __forceinline__ void bwd_backward_tiles(const Params& P, const BwdLds& L, const BwdRay& R, float* grad_planes_item,
+// `stage_ray`: when not NULL the plane gradient is NOT scattered from here: each sample's dX row (32 floats) is written to
+// stage_ray[rank * 32 ...], rank = the sample's position in the ray's merged depth order, for plane_scatter_kernel below.
+__device__ __forceinline__ void bwd_backward_tiles(const Params& P, const BwdLds& L, const BwdRay& R, float* grad_planes_item, float* stage_ray,
                                                    int e0, int count, int ntiles, const float (&G)[2], BwdAcc& A, BwdPending& pend, int lane) {
     const int j = lane & 15, g = lane >> 4;
     for (int t = 0; t < ntiles; t++) {
@@ -314,8 +316,19 @@ __device__ __forceinline__ void bwd_backward_tiles(const Params& P, const BwdLds
             }
         }
         bwd_tile_core(L, h, dsig, A, lane);
-        // ---- dX goes to the plane gradient from inside the next lookup (see BwdPending)
-        if (grad_planes_item) { pend.base = grad_planes_item; pend.live = min(16, count - 16 * t); }
+        if (stage_ray) {
+            // ---- dX rows to the staging buffer in depth order: two 128-byte rows per store instruction
+            const int half = lane >> 5, ch = lane & 31;
+            const int live = min(16, count - 16 * t);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int smp = 2 * q + half;
+                if (smp < live) stage_ray[L.rank_e[e0 + 16 * t + smp] * 32 + ch] = L.tbuf[smp * kTPitch + ch];
+            }
+        } else if (grad_planes_item) {
+            // ---- dX goes to the plane gradient from inside the next lookup (see BwdPending)
+            pend.base = grad_planes_item; pend.live = min(16, count - 16 * t);
+        }
         lds_wave_sync();
     }
 }
@@ -365,7 +378,7 @@ __device__ __forceinline__ void bwd_reduce_decoder_grads(const BwdAcc& A, float*
     if (tid < 33) unsafeAtomicAdd(grad_b2 + tid, red_b2[tid]);
 }
 
-__global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gnerf_render_grads Gr) {
+__global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gnerf_render_grads Gr, float* stage) {
     extern __shared__ __align__(16) float smem[];
     const gnerf_render_params& p = P.p;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -525,8 +538,13 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gn
         lds_wave_sync();
 
         // ---- 3. decoder + lookup gradients
-        bwd_backward_tiles(P, L, R, grad_planes_item, 0, S, P.tiles_c, G, A, pend, lane);
-        if (F > 0) bwd_backward_tiles(P, L, R, grad_planes_item, fine_e0, F, P.tiles_f, G, A, pend, lane);
+        float* stage_ray = nullptr;
+        if (stage && grad_planes_item) {                // staged scatter: per ray n_all depths, then n_all rows of 32 floats
+            stage_ray = stage + ray * int64_t(n_all) * 33 + n_all;
+            for (int k = lane; k < n_all; k += 64) stage[ray * int64_t(n_all) * 33 + k] = L.s_t[k];
+        }
+        bwd_backward_tiles(P, L, R, grad_planes_item, stage_ray, 0, S, P.tiles_c, G, A, pend, lane);
+        if (F > 0) bwd_backward_tiles(P, L, R, grad_planes_item, stage_ray, fine_e0, F, P.tiles_f, G, A, pend, lane);
     }
     if (pend.live > 0) {                               // the last tile's scatter has no next lookup to hide in
 #pragma unroll
@@ -536,6 +554,158 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gn
     }
 
     bwd_reduce_decoder_grads(A, smem, Gr.grad_w1, Gr.grad_b1, Gr.grad_w2, Gr.grad_b2, tid, lane, j);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Staged plane-gradient scatter, second pass (round 2).  render_bwd_kernel above is bound by the device's float-atomic rate: every
+// (sample, tap) costs two 64-byte atomic requests that are resolved at the memory side, 149 M per launch at BASELINE config 2.  A
+// 4x4-pixel ray tile touches each texel ~4-5 times, mostly from samples at similar depth on neighbouring rays, but the first
+// pass has neither LDS (2 x 79 KB per CU) nor registers (256) left to aggregate them.  So, when the caller provides a staging
+// buffer, the first pass writes each sample's dX row in its ray's merged DEPTH ORDER and this kernel does the scatter: one
+// workgroup per 16-ray tile walks the tile's samples in chunks of kScatterRanks depth ranks (all 16 rays at once) and SORTS the
+// chunk's 2 304 tap contributions by texel with a counting sort in LDS -- texel -> table slot by compare-and-swap on integer tags
+// (open addressing at a load of ~0.3), a counter per slot that also hands each contribution its place in the slot's bucket, a prefix
+// sum, a scatter of (sample, weight) pairs -- after which every half-wave sums whole buckets from the chunk's dX rows in LDS and
+// sends ONE global atomic per texel and channel.  (A first version accumulated into an LDS table with float LDS atomics: those
+// run at ~0.4 lanes per cycle here and made this pass 14 ms; the sort needs integer atomics only, 2 304 per chunk.)
+// A contribution that finds no free slot goes straight to global memory, so correctness never depends on the table.
+constexpr int kScatterThreads = 1024, kScatterSlots = 2048, kScatterRanks = 16, kScatterProbes = 16;
+constexpr unsigned kScatterEmpty = 0xffffffffu;
+constexpr int kScatterSamples = 16 * kScatterRanks;             // samples of one chunk
+constexpr int kScatterEntries = kScatterSamples * 12;           // tap contributions of one chunk
+static_assert(kScatterSamples * 3 <= kScatterThreads && kScatterSlots == 2 * kScatterThreads, "one thread per (sample, plane), two slots per thread in the scan");
+__host__ __device__ inline size_t scatter_lds_floats() {
+    return 16 * 8 + size_t(kScatterSamples) * 32 + 2 * size_t(kScatterSlots) + 2 + 2 * size_t(kScatterEntries) + 32;
+}
+
+__global__ __launch_bounds__(kScatterThreads, 2) void plane_scatter_kernel(Params P, const float* __restrict__ stage, float* __restrict__ grad_planes) {
+    extern __shared__ __align__(16) float smem[];
+    const gnerf_render_params& p = P.p;
+    float* rays = smem;                                                        // [16][o, d, ray id, -]
+    float* dx = rays + 16 * 8;                                                 // [samples][32]
+    unsigned* tag = reinterpret_cast<unsigned*>(dx + kScatterSamples * 32);    // [slots] texel key, or empty
+    int* cnt = reinterpret_cast<int*>(tag + kScatterSlots);                    // [slots + 1] bucket sizes, then (in place) bucket starts
+    float2* entry = reinterpret_cast<float2*>(cnt + kScatterSlots + 2);        // [entries] (sample of the chunk, bilinear weight)
+    int* wave_tot = reinterpret_cast<int*>(entry + kScatterEntries);           // [16]
+    const int tid = threadIdx.x, lane = tid & 63, ch = lane & 31, wv = tid >> 6;
+    const int hw = tid >> 5;                                                   // half-wave index
+    const int n_all = p.depth_resolution + p.depth_resolution_importance;
+    const int tile = blockIdx.x;
+    const int H = p.plane_h, W = p.plane_w;
+    if (tid < 16) {                                                            // the tile's 16 rays (the first pass's tile order)
+        int64_t ray = -1;
+        if (P.tiles_per_item > 0) {
+            const int item = tile / P.tiles_per_item, tt = tile % P.tiles_per_item;
+            const int tx = tt / P.tiles_y, ty = tt % P.tiles_y;
+            ray = int64_t(item) * p.rays_per_item + int64_t(ty * 4 + (tid >> 2)) * p.image_width + tx * 4 + (tid & 3);
+        } else {
+            ray = int64_t(tile) * 16 + tid;
+            if (ray >= P.total_rays) ray = -1;
+        }
+        float* r = rays + tid * 8;
+        if (ray >= 0) {
+            r[0] = p.ray_origins[ray * 3 + 0]; r[1] = p.ray_origins[ray * 3 + 1]; r[2] = p.ray_origins[ray * 3 + 2];
+            r[3] = p.ray_dirs[ray * 3 + 0];    r[4] = p.ray_dirs[ray * 3 + 1];    r[5] = p.ray_dirs[ray * 3 + 2];
+        }
+        reinterpret_cast<int*>(r)[6] = int(ray);
+    }
+    for (int i = tid; i < kScatterSlots; i += kScatterThreads) { tag[i] = kScatterEmpty; cnt[i] = 0; }
+    __syncthreads();
+    const int first_ray = reinterpret_cast<const int*>(rays)[6];
+    if (first_ray < 0) return;                                                 // (uniform: tiles are filled from ray 0 of the tile)
+    const int item = first_ray / p.rays_per_item;                             // a tile never straddles items (checked by the launcher)
+    float* grad_item = grad_planes + int64_t(item) * 3 * H * W * 32;
+
+    for (int k0 = 0; k0 < n_all; k0 += kScatterRanks) {
+        const int nk = min(kScatterRanks, n_all - k0);
+        const int n_smp = 16 * nk;
+        // ---- the chunk's dX rows into LDS (sample sr = ray-in-tile * nk + rank-in-chunk)
+        for (int sr = hw; sr < n_smp; sr += kScatterThreads / 32) {
+            const int ray = reinterpret_cast<const int*>(rays + (sr / nk) * 8)[6];
+            dx[sr * 32 + ch] = ray >= 0 ? stage[int64_t(ray) * n_all * 33 + n_all + int64_t(k0 + sr % nk) * 32 + ch] : 0.f;
+        }
+        // ---- one thread per (sample, plane): its four taps, a table slot and a place in the slot's bucket for each
+        int slot[4] = {-1, -1, -1, -1}, pos[4] = {0, 0, 0, 0};
+        unsigned keys[4] = {0, 0, 0, 0};
+        v4f wgt = {0.f, 0.f, 0.f, 0.f};
+        const int my_sr = tid / 3, my_pl = tid % 3;
+        const bool mine = my_sr < n_smp;
+        if (mine) {
+            const float* r = rays + (my_sr / nk) * 8;
+            const int ray = reinterpret_cast<const int*>(r)[6];
+            if (ray >= 0) {
+                const float depth = stage[int64_t(ray) * n_all * 33 + k0 + my_sr % nk];
+                const float px = __fadd_rn(r[0], __fmul_rn(depth, r[3])) * P.box_scale;
+                const float py = __fadd_rn(r[1], __fmul_rn(depth, r[4])) * P.box_scale;
+                const float pz = __fadd_rn(r[2], __fmul_rn(depth, r[5])) * P.box_scale;
+                const float u = my_pl == 2 ? pz : px;
+                const float v = my_pl == 0 ? py : (my_pl == 1 ? pz : px);
+                uint4 off;
+                plane_taps(H, W, u, v, P.tex_pitch, P.row_pitch, unsigned(my_pl) * P.plane_pitch, off, wgt);
+                keys[0] = off.x; keys[1] = off.y; keys[2] = off.z; keys[3] = off.w;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (wgt[t] != 0.f) {
+                        const unsigned h = ((keys[t] >> 7) * 2654435761u) >> 21;               // 11 bits
+                        for (int pr = 0; pr < kScatterProbes; pr++) {
+                            const unsigned s2 = (h + pr) & (kScatterSlots - 1);
+                            const unsigned old = atomicCAS(tag + s2, kScatterEmpty, keys[t]);
+                            if (old == kScatterEmpty || old == keys[t]) { slot[t] = int(s2); break; }
+                        }
+                        if (slot[t] >= 0) pos[t] = atomicAdd(cnt + slot[t], 1);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- exclusive prefix sum of the bucket sizes (two adjacent slots per thread)
+        {
+            const int c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
+            int incl = c0 + c1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+            if (lane == 63) wave_tot[wv] = incl;
+            __syncthreads();
+            int base = 0;
+            for (int w2 = 0; w2 < wv; w2++) base += wave_tot[w2];
+            cnt[2 * tid] = base + incl - c0 - c1;                              // (every size was read before the barrier above)
+            cnt[2 * tid + 1] = base + incl - c1;
+            if (tid == kScatterThreads - 1) cnt[kScatterSlots] = base + incl;
+        }
+        __syncthreads();
+        // ---- contributions to their buckets; the rare ones without a slot go straight to memory (32 channels from one lane)
+        if (mine) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (wgt[t] != 0.f) {
+                    if (slot[t] >= 0) {
+                        entry[cnt[slot[t]] + pos[t]] = make_float2(__int_as_float(my_sr * 32), wgt[t]);
+                    } else {
+                        for (int c2 = 0; c2 < 32; c2++) {
+                            const float c = dx[my_sr * 32 + c2] * wgt[t];
+                            if (c != 0.f) unsafeAtomicAdd(grad_item + (keys[t] >> 2) + c2, c);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- every half-wave sums whole buckets (lane = channel): one global atomic per texel and channel
+        for (int s2 = hw; s2 < kScatterSlots; s2 += kScatterThreads / 32) {
+            const int st = cnt[s2], en = cnt[s2 + 1];
+            if (en > st) {                                                     // (uniform within the half-wave)
+                float sum = 0.f;
+                for (int i = st; i < en; i++) {
+                    const float2 e = entry[i];
+                    sum = fmaf(e.y, dx[__float_as_int(e.x) + ch], sum);
+                }
+                if (sum != 0.f) unsafeAtomicAdd(grad_item + (tag[s2] >> 2) + ch, sum);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < kScatterSlots; i += kScatterThreads) { tag[i] = kScatterEmpty; cnt[i] = 0; }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.float64: F64}
 
 MAX_SAMPLES = 256
 DEBUG_SLOTS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 # decoder arithmetic of the fused renderer (GNERF_MLP_* in include/gnerf_hip.h)
 MLP_MODES = {'auto': 0, 'f16x3': 1, 'f32': 2}
 
@@ -56,6 +56,7 @@ class RenderGrads(ctypes.Structure):
         ('grad_rgb', _c_p), ('grad_depth', _c_p), ('grad_wsum', _c_p),
         ('grad_planes_nhwc', _c_p),
         ('grad_w1', _c_p), ('grad_b1', _c_p), ('grad_w2', _c_p), ('grad_b2', _c_p),
+        ('scatter_stage', _c_p),
     ]
 
 
@@ -82,6 +83,7 @@ SIGNATURES = {
     'gnerf_render_workspace_bytes': (ctypes.c_size_t, []),
     'gnerf_render_forward': (_c_i, [ctypes.POINTER(RenderParams), _c_p]),
     'gnerf_render_backward': (_c_i, [ctypes.POINTER(RenderParams), ctypes.POINTER(RenderGrads), _c_p]),
+    'gnerf_render_backward_stage_bytes': (ctypes.c_size_t, [ctypes.POINTER(RenderParams)]),
     'gnerf_query_points': (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_p]),
     'gnerf_query_points_backward': (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                            _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_p]),
@@ -464,6 +466,7 @@ def make_rays(cam2world, intrinsics, resolution):
 
 
 _workspaces = {}
+_stages = {}
 _EMPTY = torch.empty([0])          # "absent tensor" for the C++ binding, as the reference's _null_tensor (bias_act.py:38)
 
 
@@ -727,9 +730,12 @@ def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
 
 def render_backward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine, grad_rgb, grad_depth, grad_wsum, *,
                     depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
-                    white_back=False, disparity_space_sampling=False, image_width=0, need_planes=True, need_decoder=True):
+                    white_back=False, disparity_space_sampling=False, image_width=0, need_planes=True, need_decoder=True,
+                    staged_scatter=True):
     """Gradient of render_forward for the same arguments (the forward pass is recomputed inside the kernel).
     grad_rgb [N,M,32], grad_depth [N,M,1], grad_wsum [N,M,1]; any of them may be None (zeros).
+    staged_scatter: make the plane gradient in two passes through a staging buffer (per-texel aggregation in LDS before the
+    atomics; see include/gnerf_hip.h) -- the default; False = the single-pass form.
     Returns (grad_planes_nhwc [3N,H,W,32] or None, (grad_w1, grad_b1, grad_w2, grad_b2) or None), all float32."""
     p, keep, m = _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine,
                                 depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
@@ -752,10 +758,22 @@ def render_backward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_
                  torch.zeros([33, 64], dtype=torch.float32, device=dev), torch.zeros([33], dtype=torch.float32, device=dev))
         g.grad_w1, g.grad_b1, g.grad_w2, g.grad_b2 = [t.data_ptr() for t in g_dec]
     g.grad_planes_nhwc = None if g_planes is None else g_planes.data_ptr()
+    stage = None
+    if g_planes is not None and staged_scatter:
+        # staging buffer of the two-pass scatter: S+F rows of 33 floats per ray (830 MB at BASELINE config 2), kept per (device, stream)
+        nbytes = int(load().gnerf_render_backward_stage_bytes(ctypes.byref(p)))
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        stage = _stages.get(key)
+        if stage is None or stage.numel() < nbytes:
+            stage = None
+            _stages.pop(key, None)
+            stage = torch.empty([nbytes], dtype=torch.uint8, device=dev)
+            _stages[key] = stage
+        g.scatter_stage = stage.data_ptr()
     with _on_device(dev):
         code = load().gnerf_render_backward(ctypes.byref(p), ctypes.byref(g), _stream(planes_nhwc))
     _check(code, 'gnerf_render_backward')
-    del keep, grads_in
+    del keep, grads_in, stage
     return g_planes, g_dec
 
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GNERF_ABI_VERSION 3
+#define GNERF_ABI_VERSION 4
 
 /* error codes */
 #define GNERF_OK            0
@@ -279,7 +279,14 @@ typedef struct gnerf_render_grads {
     float* grad_b1;             /* [64] */
     float* grad_w2;             /* [33,64] */
     float* grad_b2;             /* [33] */
+    /* Optional workspace of gnerf_render_backward_stage_bytes(p) bytes (contents irrelevant before and after the call).  With it
+       the plane gradient is made in two passes: the backward kernel writes every sample's feature gradient in its ray's depth
+       order, and a second kernel aggregates each 4x4-ray tile's contributions per texel in LDS before they reach memory --
+       3-4x fewer float atomics, which is what bounds the single-pass form.  NULL: single pass (one atomic per tap and channel). */
+    float* scatter_stage;
 } gnerf_render_grads;
+
+size_t gnerf_render_backward_stage_bytes(const gnerf_render_params* p);
 
 /* p: the forward call's params (outputs, workspace and debug are ignored). */
 int gnerf_render_backward(const gnerf_render_params* p, const gnerf_render_grads* g, gnerf_stream_t stream);

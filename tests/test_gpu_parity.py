@@ -600,17 +600,18 @@ def test_render_backward_vs_oracle(dev, cfg):
                 white_back=white_back)
     ref_planes, ref_dec = _oracle_grads(planes, dec, o, d, nc, nf, opts, g_rgb, g_depth, g_wsum)
     nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
-    gp, gdec = gnerf_hip.render_backward(nhwc, N, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev) if F else None,
-                                         g_rgb.to(dev), g_depth.to(dev), g_wsum.to(dev),
-                                         depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0,
-                                         white_back=white_back, image_width=cfg['res'])
-    gp_nchw = gp.reshape(N, 3, *cfg['hw'], 32).permute(0, 1, 4, 2, 3).cpu()
-    assert _rel(gp_nchw, ref_planes) < 2e-3, _rel(gp_nchw, ref_planes)
-    assert _rel_l2(gp_nchw, ref_planes) < 1e-3, _rel_l2(gp_nchw, ref_planes)
-    assert _entrywise_ok(gp_nchw, ref_planes)
-    for name, a, b in zip(['w1', 'b1', 'w2', 'b2'], gdec, ref_dec):
-        assert _rel(a.cpu(), b) < 2e-3, (name, _rel(a.cpu(), b))
-        assert _rel_l2(a.cpu(), b) < 1e-3, (name, _rel_l2(a.cpu(), b))
+    for staged in (True, False):                 # two-pass scatter with per-texel aggregation in LDS (the default) / single pass
+        gp, gdec = gnerf_hip.render_backward(nhwc, N, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev) if F else None,
+                                             g_rgb.to(dev), g_depth.to(dev), g_wsum.to(dev),
+                                             depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0,
+                                             white_back=white_back, image_width=cfg['res'], staged_scatter=staged)
+        gp_nchw = gp.reshape(N, 3, *cfg['hw'], 32).permute(0, 1, 4, 2, 3).cpu()
+        assert _rel(gp_nchw, ref_planes) < 2e-3, (staged, _rel(gp_nchw, ref_planes))
+        assert _rel_l2(gp_nchw, ref_planes) < 1e-3, (staged, _rel_l2(gp_nchw, ref_planes))
+        assert _entrywise_ok(gp_nchw, ref_planes), staged
+        for name, a, b in zip(['w1', 'b1', 'w2', 'b2'], gdec, ref_dec):
+            assert _rel(a.cpu(), b) < 2e-3, (name, _rel(a.cpu(), b))
+            assert _rel_l2(a.cpu(), b) < 1e-3, (name, _rel_l2(a.cpu(), b))
     # each input gradient alone (NULL pointers for the others) and planes-only / decoder-only requests
     gp2, none_dec = gnerf_hip.render_backward(nhwc, N, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev) if F else None,
                                               g_rgb.to(dev), None, None, depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3,

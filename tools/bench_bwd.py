@@ -34,8 +34,18 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n
 
 out = {'N': N, 'res': res, 'S': S, 'F': F}
+if os.environ.get('BWD_ONLY'):         # profiling aid: only the staged (two-pass) or only the single-pass form, 5 calls
+    staged = os.environ['BWD_ONLY'] == 'staged'
+    out['only'] = os.environ['BWD_ONLY']
+    out['bwd_ms'] = timeit(lambda: gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, g_rgb, g_depth, g_w, staged_scatter=staged, **kw), 4)
+    print(json.dumps(out))
+    sys.exit(0)
 out['fwd_ms'] = timeit(lambda: gnerf_hip.render_forward(nhwc, N, dec, o, d, nc, nf, **kw))
 out['bwd_ms'] = timeit(lambda: gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, g_rgb, g_depth, g_w, **kw))
+out['bwd_single_pass_ms'] = timeit(lambda: gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, g_rgb, g_depth, g_w, staged_scatter=False, **kw))
+a = gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, g_rgb, g_depth, g_w, **kw)[0]
+b = gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, g_rgb, g_depth, g_w, staged_scatter=False, **kw)[0]
+out['staged_vs_single_pass_max_rel'] = float((a - b).abs().max() / b.abs().max())
 out['bwd_planes_only_ms'] = timeit(lambda: gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, g_rgb, g_depth, g_w, need_decoder=False, **kw))
 out['bwd_decoder_only_ms'] = timeit(lambda: gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, g_rgb, g_depth, g_w, need_planes=False, **kw))
 out['memset_ms'] = timeit(lambda: torch.zeros_like(nhwc))

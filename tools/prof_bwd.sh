@@ -1,9 +1,43 @@
 #!/bin/bash
-# rocprofv3 passes over the backward benchmark (run on the GPU box through gpurun).  One counter group per pass, each
-# pass under its own timeout: a counter set the hardware cannot collect aborts rocprofv3 and then hangs in finalisation.
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-export BWD_TORCH=0
-timeout 120 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/bwd_stats -o run -- python3 $R/tools/bench_bwd.py 4 128 > $R/gpurun_out/bwd_stats.log 2>&1
-timeout 120 rocprofv3 --pmc TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum TCC_BUSY_sum TCC_REQ_sum -d $R/gpurun_out/bwd_pmc_a -o run -- python3 $R/tools/bench_bwd.py 4 128 > $R/gpurun_out/bwd_pmc_a.log 2>&1
-timeout 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $R/gpurun_out/bwd_pmc_b -o run -- python3 $R/tools/bench_bwd.py 4 128 > $R/gpurun_out/bwd_pmc_b.log 2>&1
+# Backward kernels at BASELINE config 2 under rocprofv3 (run on the GPU box through gpurun): kernel stats, then the atomic
+# request counters in their own --pmc passes, for the staged (two-pass) and the single-pass forms.
+#   -> gpurun_out/r02_backward_profile.json
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd /tmp && export TMPDIR=/tmp BWD_TORCH=0
+out=$R/gpurun_out/prof_bwd
+rm -rf $out; mkdir -p $out
+for form in staged single; do
+  export BWD_ONLY=$form
+  timeout 200 rocprofv3 --kernel-trace --stats -d $out/${form}_stats -o run -- python3 $R/tools/bench_bwd.py 4 128 > $out/${form}_stats.log 2>&1
+  timeout 200 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum -d $out/${form}_atomic -o run -- python3 $R/tools/bench_bwd.py 4 128 > $out/${form}_atomic.log 2>&1
+  timeout 200 rocprofv3 --pmc FETCH_SIZE -d $out/${form}_fetch -o run -- python3 $R/tools/bench_bwd.py 4 128 > $out/${form}_fetch.log 2>&1
+  timeout 200 rocprofv3 --pmc WRITE_SIZE -d $out/${form}_write -o run -- python3 $R/tools/bench_bwd.py 4 128 > $out/${form}_write.log 2>&1
+done
+cd $R && python3 - "$out" <<'PY'
+import collections, glob, json, os, sqlite3, sys
+d = sys.argv[1]
+res = {}
+for form in ('staged', 'single'):
+    r = collections.defaultdict(dict)
+    f = glob.glob(os.path.join(d, form + '_stats', '**', '*.db'), recursive=True)
+    if f:
+        for name, calls, avg in sqlite3.connect(f[0]).execute('select name, total_calls, average from top_kernels'):
+            if 'render_bwd_kernel' in name or 'plane_scatter_kernel' in name:
+                r[name.split('(anonymous namespace)::')[1].split('(')[0]].update(calls=calls, avg_ms=round(avg / 1000.0, 2))      # top_kernels.average is in microseconds
+    for grp in ('atomic', 'fetch', 'write'):
+        f = glob.glob(os.path.join(d, f'{form}_{grp}', '**', '*.db'), recursive=True)
+        if not f:
+            r['_missing'][grp] = open(os.path.join(d, f'{form}_{grp}.log')).read()[-300:]
+            continue
+        per = collections.defaultdict(lambda: collections.defaultdict(list))
+        for kname, disp, ctr, val in sqlite3.connect(f[0]).execute('select kernel_name, dispatch_id, counter_name, sum(value) from counters_collection group by dispatch_id, counter_name'):
+            if 'render_bwd_kernel' in kname or 'plane_scatter_kernel' in kname:
+                per[kname.split('(anonymous namespace)::')[1].split('(')[0]][ctr].append(val)
+        for k, ctrs in per.items():
+            for ctr, vals in ctrs.items():
+                r[k][ctr] = round(sum(vals) / len(vals), 1)
+    res[form] = r
+json.dump(res, open('gpurun_out/r02_backward_profile.json', 'w'), indent=1)
+print(json.dumps(res, indent=1))
+PY
+rm -rf $out
