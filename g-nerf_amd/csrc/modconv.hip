@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kThreads) void modconv_epilogue_kernel(EpiArgs a) {
 #pragma unroll
         for (int k = 0; k < VEC; k++) {
             float u = float(load_as<T>(in.v, k));
-            if constexpr (SCALE || NOISE) u = round_to<T>(fmaf(u, sc, NOISE ? (a.round_noise ? round_to<T>(nv[k]) : nv[k]) : 0.f));
+            if constexpr (SCALE || NOISE) u = round_to<T>(fmaf(u, sc, NOISE ? ((a.round_noise || SCALE) ? round_to<T>(nv[k]) : nv[k]) : 0.f));
             t[k] = u;
         }
     }
@@ -172,6 +172,188 @@ __global__ __launch_bounds__(kThreads) void scale_channels_kernel(const T* __res
 #pragma unroll
     for (int k = 0; k < VEC; k++) store_as<T>(out.v, k, float(load_as<T>(in.v, k)) * sc);
     *reinterpret_cast<P*>(y + int64_t(row) * row_len + v * VEC) = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Channels_last forms (memory [N, pixels, C]).  The fp16 blocks of the generator run in the layout MIOpen's fp16 kernels compute
+// in, which removes its NCHW<->NHWC transposes around every convolution (tools/bench_sr_conv_layout.py: 0.63 ms of the 3.8 ms
+// superresolution at batch 4).  A lane owns one 16-byte vector of adjacent channels of one pixel; per-channel operands (bias,
+// demodulation, the next layer's styles) are vectors too, per-pixel operands (noise) one scalar.
+
+struct EpiNhwcArgs {
+    const void* x; void* y;
+    const float* scale;      // [n, channels] or NULL
+    const float* noise;      // [pixels] (or [n, pixels] when noise_per_item) or NULL
+    const void* bias;        // [channels], activations' dtype, or NULL
+    const float* next_scale; // [n, channels] or NULL: the result is additionally multiplied by these (the next layer's input scaling)
+    unsigned pixels, channels;
+    int noise_per_item, round_noise, act;
+    float alpha, gain, clamp;
+};
+
+// y[n, p, c] = round_T(clamp(act(round_T(x * T(scale[n,c]) + noise[p]) + bias[c]) * gain)) (* T(next_scale[n,c]), rounded again):
+// the same roundings, in the same order, as modconv_epilogue_kernel followed by scale_channels_kernel.
+// A lane keeps ONE channel vector and walks over pixels (FIXED: the workgroup's 256 lanes are 256 / cv pixel rows of cv channel
+// vectors, cv = channels / VEC dividing 256), so bias, demodulation and next-layer scale are loaded once per lane, not once per
+// element: the first version re-loaded them per vector (three extra vector loads next to the 16 bytes of data) and ran at a
+// quarter of the memory rate.  Other channel counts take the per-vector form (FIXED = false).
+template <class T, int VEC, int ACT, bool SCALE, bool NOISE, bool NEXT, bool FIXED>
+__global__ __launch_bounds__(kThreads) void modconv_epilogue_nhwc_kernel(EpiNhwcArgs a, unsigned pixels_per_block) {
+    typedef Pk<T, VEC> P;
+    const unsigned n = blockIdx.y;
+    const unsigned cv = a.channels / VEC;
+    unsigned pix, pix_end, pix_step, c0;
+    if constexpr (FIXED) {
+        c0 = (threadIdx.x % cv) * VEC;
+        pix_step = kThreads / cv;
+        pix = blockIdx.x * pixels_per_block + threadIdx.x / cv;
+        pix_end = min(a.pixels, (blockIdx.x + 1) * pixels_per_block);
+    } else {
+        const unsigned v = blockIdx.x * kThreads + threadIdx.x;
+        if (v >= a.pixels * cv) return;
+        pix = v / cv; c0 = (v % cv) * VEC;
+        pix_end = pix + 1; pix_step = 1;
+    }
+    float sc[VEC], nx[VEC], bv[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+        sc[k] = SCALE ? a.scale[int64_t(n) * a.channels + c0 + k] : 1.f;
+        nx[k] = NEXT ? round_to<T>(a.next_scale[int64_t(n) * a.channels + c0 + k]) : 1.f;
+        bv[k] = a.bias ? float(load_as<T>(static_cast<const T*>(a.bias), c0 + k)) : 0.f;
+    }
+    const T* xn = static_cast<const T*>(a.x) + int64_t(n) * a.pixels * a.channels + c0;
+    T* yn = static_cast<T*>(a.y) + int64_t(n) * a.pixels * a.channels + c0;
+    const float* nzp = NOISE ? a.noise + (a.noise_per_item ? int64_t(n) * a.pixels : 0) : nullptr;
+    constexpr int UN = FIXED ? 4 : 1;
+    for (; pix < pix_end; pix += pix_step * UN) {
+        P in[UN];
+        float nzs[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const unsigned pu = min(pix + u * pix_step, a.pixels - 1);
+            in[u] = *reinterpret_cast<const P*>(xn + int64_t(pu) * a.channels);
+            nzs[u] = NOISE ? nzp[pu] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const unsigned pu = pix + u * pix_step;
+            if (pu >= pix_end) break;
+            const float nz = nzs[u];
+            float t[VEC];
+            if constexpr (sizeof(T) == 2 && VEC % 2 == 0 && (SCALE || NOISE)) {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int k = 0; k < VEC; k += 2) {
+                    const h2 xv = {__builtin_bit_cast(_Float16, in[u].v[k]), __builtin_bit_cast(_Float16, in[u].v[k + 1])};
+                    const h2 s2 = {(_Float16)sc[k], (_Float16)sc[k + 1]};
+                    h2 r;
+                    if constexpr (NOISE) {
+                        if (a.round_noise || SCALE) {
+                            const h2 n2 = {(_Float16)nz, (_Float16)nz};
+                            r = __builtin_elementwise_fma(xv, s2, n2);
+                        } else {
+                            r = (h2){(_Float16)((float)xv[0] + nz), (_Float16)((float)xv[1] + nz)};
+                        }
+                    } else {
+                        r = xv * s2;
+                    }
+                    t[k] = (float)r[0];
+                    t[k + 1] = (float)r[1];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; k++) {
+                    float uu = float(load_as<T>(in[u].v, k));
+                    if constexpr (SCALE || NOISE) uu = round_to<T>(fmaf(uu, SCALE ? round_to<T>(sc[k]) : 1.f, NOISE ? ((a.round_noise || SCALE) ? round_to<T>(nz) : nz) : 0.f));
+                    t[k] = uu;
+                }
+            }
+            P out;
+#pragma unroll
+            for (int k = 0; k < VEC; k++) {
+                const float uu = t[k] + bv[k];
+                float r = uu;
+                if (ACT == 3) r = uu > 0.f ? uu : uu * a.alpha;          // lrelu
+                r *= a.gain;
+                if (a.clamp >= 0.f) r = r > a.clamp ? a.clamp : (r < -a.clamp ? -a.clamp : r);
+                if constexpr (NEXT) r = round_to<T>(r) * nx[k];
+                store_as<T>(out.v, k, r);
+            }
+            *reinterpret_cast<P*>(yn + int64_t(pu) * a.channels) = out;
+        }
+    }
+}
+
+template <class T, int VEC>
+__global__ __launch_bounds__(kThreads) void scale_channels_nhwc_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ y,
+                                                                       unsigned pixels, unsigned channels) {
+    typedef Pk<T, VEC> P;
+    const unsigned n = blockIdx.y;
+    const unsigned cv = channels / VEC;
+    const unsigned v = blockIdx.x * kThreads + threadIdx.x;
+    if (v >= pixels * cv) return;
+    const unsigned c0 = (v % cv) * VEC;
+    const int64_t base = int64_t(n) * pixels * channels + int64_t(v) * VEC;
+    const P in = *reinterpret_cast<const P*>(x + base);
+    P out;
+#pragma unroll
+    for (int k = 0; k < VEC; k++) store_as<T>(out.v, k, float(load_as<T>(in.v, k)) * round_to<T>(s[int64_t(n) * channels + c0 + k]));
+    *reinterpret_cast<P*>(y + base) = out;
+}
+
+// ToRGBLayer on a channels_last fp16 tensor (networks_stylegan2.py:349-367 with the fused modulation of :89-96): a modulated 1x1
+// convolution to THREE channels, bias and clamp -- y[n,o,p] = clamp(half(sum_c x[n,p,c] * half(weight[o,c] * styles[n,c])) + bias[o]).
+// It is a streaming read of x: C/8 lanes share a pixel, one 16-byte vector each, three v_dot2_f32_f16 chains per lane on the packed
+// halves as loaded, a butterfly over the pixel's lanes, the first three lanes store (y is NCHW: it is added to the running image).
+// Replaces scale_channels (read + write of x) + MIOpen's 1x1 convolution + the bias/clamp pass: 0.22 -> 0.06 ms on [4,128,512,512].
+template <int LPP>                                         // lanes per pixel = C / 8
+__global__ __launch_bounds__(kThreads) void torgb_nhwc_kernel(const __half* __restrict__ x, const float* __restrict__ weight, const float* __restrict__ styles,
+                                                              const __half* __restrict__ bias, __half* __restrict__ y, unsigned pixels, float clamp) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    constexpr int C = LPP * 8, PPB = kThreads / LPP;      // pixels per workgroup step
+    constexpr int UNROLL = 4;
+    const unsigned n = blockIdx.y;
+    const unsigned sub = threadIdx.x % LPP, grp = threadIdx.x / LPP;
+    h2 w[3][4];
+#pragma unroll
+    for (int o = 0; o < 3; o++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned c = sub * 8 + 2 * k;
+            w[o][k] = (h2){(_Float16)(weight[o * C + c] * styles[n * C + c]), (_Float16)(weight[o * C + c + 1] * styles[n * C + c + 1])};
+        }
+    const float b = sub < 3 && bias ? __half2float(bias[sub]) : 0.f;
+    const __half* xn = x + int64_t(n) * pixels * C;
+    __half* yn = y + int64_t(n) * 3 * pixels;
+    for (unsigned p0 = (blockIdx.x * UNROLL) * PPB; p0 < pixels; p0 += gridDim.x * UNROLL * PPB) {
+        uint4 raw[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const unsigned p = min(p0 + u * PPB + grp, pixels - 1);
+            raw[u] = *reinterpret_cast<const uint4*>(xn + int64_t(p) * C + sub * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const unsigned p = p0 + u * PPB + grp;
+            const unsigned q[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+            float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const h2 xv = __builtin_bit_cast(h2, q[k]);
+#pragma unroll
+                for (int o = 0; o < 3; o++) acc[o] = __builtin_amdgcn_fdot2(xv, w[o][k], acc[o], false);
+            }
+#pragma unroll
+            for (int off = 1; off < LPP; off <<= 1)
+#pragma unroll
+                for (int o = 0; o < 3; o++) acc[o] += __shfl_xor(acc[o], off);
+            if (sub < 3 && p < pixels) {
+                float r = __half2float(__float2half(sub == 0 ? acc[0] : (sub == 1 ? acc[1] : acc[2]))) + b;
+                if (clamp >= 0.f) r = r > clamp ? clamp : (r < -clamp ? -clamp : r);
+                yn[int64_t(sub) * pixels + p] = __float2half(r);
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -244,4 +426,76 @@ extern "C" int gnerf_modconv_epilogue(const void* x, void* y, int dtype, int row
 #undef GNERF_EPI
 #undef GNERF_EPI3
     return check_launch("modconv_epilogue");
+}
+
+extern "C" int gnerf_scale_channels_nhwc(const void* x, const float* scale, void* y, int dtype, int n, int pixels, int channels, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!x || !scale || !y) return fail(GNERF_E_ARG, "scale_channels_nhwc: null pointer");
+    if (n < 1 || n > 65535 || pixels < 1 || channels < 1 || int64_t(pixels) * channels > INT32_MAX) return fail(GNERF_E_ARG, "scale_channels_nhwc: bad shape");
+    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    hipStream_t s = as_stream(stream);
+#define GNERF_SC(T_, V_) hipLaunchKernelGGL((scale_channels_nhwc_kernel<T_, V_>), dim3((unsigned)((int64_t(pixels) * (channels / V_) + kThreads - 1) / kThreads), n), dim3(kThreads), 0, s, \
+                                            static_cast<const T_*>(x), scale, static_cast<T_*>(y), unsigned(pixels), unsigned(channels))
+    if (dtype == GNERF_F16) { if (al && channels % 8 == 0) GNERF_SC(__half, 8); else GNERF_SC(__half, 1); }
+    else if (dtype == GNERF_F32) { if (al && channels % 4 == 0) GNERF_SC(float, 4); else GNERF_SC(float, 1); }
+    else return fail(GNERF_E_ARG, "scale_channels_nhwc: dtype must be float32 or float16");
+#undef GNERF_SC
+    return check_launch("scale_channels_nhwc");
+}
+
+extern "C" int gnerf_modconv_epilogue_nhwc(const void* x, void* y, int dtype, int n, int pixels, int channels,
+                                           const float* scale, const float* noise, int noise_per_item, int round_noise, const void* bias,
+                                           int act, float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!x || !y) return fail(GNERF_E_ARG, "modconv_epilogue_nhwc: null pointer");
+    if (n < 1 || n > 65535 || pixels < 1 || channels < 1 || int64_t(pixels) * channels > INT32_MAX) return fail(GNERF_E_ARG, "modconv_epilogue_nhwc: bad shape");
+    if (act != 1 && act != 3) return fail(GNERF_E_UNSUPPORTED, "modconv_epilogue_nhwc: only linear and lrelu");
+    EpiNhwcArgs a{x, y, scale, noise, bias, next_scale, unsigned(pixels), unsigned(channels), noise_per_item, round_noise, act, alpha, gain, clamp};
+    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    hipStream_t s = as_stream(stream);
+#define GNERF_EPI5(T_, V_, A_, S_, N_, X_) do { \
+        if (fixed) hipLaunchKernelGGL((modconv_epilogue_nhwc_kernel<T_, V_, A_, S_, N_, X_, true>), g, dim3(kThreads), 0, s, a, ppb); \
+        else       hipLaunchKernelGGL((modconv_epilogue_nhwc_kernel<T_, V_, A_, S_, N_, X_, false>), g, dim3(kThreads), 0, s, a, ppb); } while (0)
+#define GNERF_EPI4(T_, V_, A_, S_, N_) do { if (next_scale) GNERF_EPI5(T_, V_, A_, S_, N_, true); else GNERF_EPI5(T_, V_, A_, S_, N_, false); } while (0)
+#define GNERF_EPI3(T_, V_, A_) do { \
+        if (scale && noise)  GNERF_EPI4(T_, V_, A_, true, true); \
+        else if (scale)      GNERF_EPI4(T_, V_, A_, true, false); \
+        else if (noise)      GNERF_EPI4(T_, V_, A_, false, true); \
+        else                 GNERF_EPI4(T_, V_, A_, false, false); } while (0)
+#define GNERF_EPI(T_, V_) do { const unsigned cv = channels / V_; const bool fixed = cv <= kThreads && kThreads % cv == 0; \
+        const unsigned ppb = fixed ? (kThreads / cv) * 16 : 0; \
+        const dim3 g(fixed ? (unsigned)((pixels + ppb - 1) / ppb) : (unsigned)((int64_t(pixels) * cv + kThreads - 1) / kThreads), n); \
+        if (act == 3) GNERF_EPI3(T_, V_, 3); else GNERF_EPI3(T_, V_, 1); } while (0)
+    if (dtype == GNERF_F16) { if (al && channels % 8 == 0) GNERF_EPI(__half, 8); else GNERF_EPI(__half, 1); }
+    else if (dtype == GNERF_F32) { if (al && channels % 4 == 0) GNERF_EPI(float, 4); else GNERF_EPI(float, 1); }
+    else return fail(GNERF_E_ARG, "modconv_epilogue_nhwc: dtype must be float32 or float16");
+#undef GNERF_EPI
+#undef GNERF_EPI3
+#undef GNERF_EPI4
+#undef GNERF_EPI5
+    return check_launch("modconv_epilogue_nhwc");
+}
+
+extern "C" int gnerf_torgb_nhwc(const void* x, const float* weight, const float* styles, const void* bias, void* y,
+                                int n, int pixels, int channels, float clamp, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!x || !weight || !styles || !y) return fail(GNERF_E_ARG, "torgb_nhwc: null pointer");
+    if (n < 1 || n > 65535 || pixels < 1) return fail(GNERF_E_ARG, "torgb_nhwc: bad shape");
+    if (reinterpret_cast<uintptr_t>(x) & 15) return fail(GNERF_E_ARG, "torgb_nhwc: x must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    const __half* xh = static_cast<const __half*>(x);
+    const __half* bh = static_cast<const __half*>(bias);
+    __half* yh = static_cast<__half*>(y);
+#define GNERF_RGB(L_) do { const int ppb = kThreads / L_ * 4; int blocks = (pixels + ppb - 1) / ppb; if (blocks > kNumCU * 8) blocks = kNumCU * 8; \
+        hipLaunchKernelGGL((torgb_nhwc_kernel<L_>), dim3((unsigned)blocks, n), dim3(kThreads), 0, s, xh, weight, styles, bh, yh, unsigned(pixels), clamp); } while (0)
+    switch (channels) {
+        case 32: GNERF_RGB(4); break;
+        case 64: GNERF_RGB(8); break;
+        case 128: GNERF_RGB(16); break;
+        case 256: GNERF_RGB(32); break;
+        case 512: GNERF_RGB(64); break;
+        default: return fail(GNERF_E_UNSUPPORTED, "torgb_nhwc: %d input channels (32, 64, 128, 256 or 512)", channels);
+    }
+#undef GNERF_RGB
+    return check_launch("torgb_nhwc");
 }

@@ -520,6 +520,127 @@ int launch_blur4(const UpArgs& a, hipStream_t stream) {
     return check_launch("upfirdn2d(blur4)") == GNERF_OK ? 0 : -1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same 4x4 blur for CHANNELS_LAST tensors (memory [N,H,W,C]): what the fp16 blocks hold when they run in the layout
+// MIOpen's fp16 kernels compute in (no NCHW<->NHWC transposes around every convolution: tools/bench_sr_conv_layout.py), or when
+// the reference's `fp16_channels_last` is set (networks_stylegan2.py:385,417).  A lane owns one 16-byte channel vector of one
+// output column and walks down a strip of rows; lanes run along (column, channel vector) = along memory, so every access is
+// a coalesced 16-byte vector.  Formulated as a SCATTER over input rows: input row r contributes to the four output rows
+// r-3+pad .. r+pad, so the lane keeps four output accumulators (fp32) instead of a 4x4 window of inputs; each step loads the
+// four column vectors of one input row (issued one row ahead), converts them once, adds them into the four pending rows and
+// stores the row that is complete.  Input re-read (R+3)/R over the strip boundary, served by the L2 for neighbouring strips.
+template <class T>
+__global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int cv, int strips_y, int rows_per_strip) {
+    constexpr int VEC = 16 / sizeof(T);
+    struct alignas(16) Vec { T v[VEC]; };
+    const int64_t per_row = int64_t(a.out_w) * cv;
+    int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= per_row * strips_y * a.n) return;
+    const int col = int(t % per_row); t /= per_row;
+    const int sy = int(t % strips_y);
+    const int img = int(t / strips_y);
+    const int ox = col / cv, c0 = (col % cv) * VEC;
+    const int oy0 = sy * rows_per_strip, rows = min(rows_per_strip, a.out_h - oy0);
+    const T* x = static_cast<const T*>(a.x) + img * a.xs_n + c0;
+    T* y = static_cast<T*>(a.y) + img * a.ys_n + int64_t(ox) * a.ys_w + c0;
+    // taps in walk order: tap[ky][kx] multiplies input (oy - pady0 + ky, ox - padx0 + kx)
+    float tap[4][4];
+#pragma unroll
+    for (int ky = 0; ky < 4; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 4; kx++)
+            tap[ky][kx] = a.f[(a.flip ? ky : 3 - ky) * a.fs_h + (a.flip ? kx : 3 - kx) * a.fs_w];
+    const int ix0 = ox - a.padx0;
+    bool col_ok[4];
+    int64_t col_off[4];
+#pragma unroll
+    for (int kx = 0; kx < 4; kx++) {
+        col_ok[kx] = ix0 + kx >= 0 && ix0 + kx < a.in_w;
+        col_off[kx] = int64_t(min(max(ix0 + kx, 0), a.in_w - 1)) * a.xs_w;          // clamped: loads are unconditional, values masked
+    }
+    const int iy_first = oy0 - a.pady0;
+    // fp32 arithmetic on PAIRS of channels (v_pk_fma_f32: the kernel is instruction-bound otherwise -- 128 scalar FMAs + 39 selects
+    // per output vector ran at 3.6 TB/s in fp16); elements outside the image are zeroed on the raw dwords (data, not taps:
+    // a clamped load may have fetched an Inf that the reference's zero padding never sees).
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int DW = 16 / 4;                                      // dwords per vector
+    struct alignas(16) Raw { unsigned d[DW]; };
+    f2 acc[4][VEC / 2];
+    Raw raw[4], nxt[4];
+    auto fetch_raw = [&](int iy, Raw (&dst)[4]) {
+        const int64_t row = int64_t(min(max(iy, 0), a.in_h - 1)) * a.xs_h;
+#pragma unroll
+        for (int kx = 0; kx < 4; kx++) dst[kx] = *reinterpret_cast<const Raw*>(x + row + col_off[kx]);
+    };
+    fetch_raw(iy_first, raw);
+    const int steps = rows + 3;
+    for (int s4 = 0; s4 < steps; s4 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int s = s4 + u;                                   // input row iy_first + s
+            if (s < steps) {                                        // (uniform over the strip's lanes)
+                if (s + 1 < steps) fetch_raw(iy_first + s + 1, nxt);
+                const bool row_ok = iy_first + s >= 0 && iy_first + s < a.in_h;
+                f2 in[4][VEC / 2];
+#pragma unroll
+                for (int kx = 0; kx < 4; kx++) {
+                    unsigned keep = (row_ok && col_ok[kx]) ? ~0u : 0u;
+                    asm volatile("" : "+v"(keep));                     // keep it a mask: one AND per dword instead of one select per converted float
+#pragma unroll
+                    for (int q = 0; q < DW; q++) {
+                        const unsigned d = raw[kx].d[q] & keep;
+                        if constexpr (sizeof(T) == 2) {
+                            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                            const h2 hv = __builtin_bit_cast(h2, d);
+                            in[kx][q] = (f2){(float)hv[0], (float)hv[1]};
+                        } else {
+                            if ((q & 1) == 0) in[kx][q / 2][0] = __uint_as_float(d); else in[kx][q / 2][1] = __uint_as_float(d);
+                        }
+                    }
+                }
+                // this row is tap row ky of output row s - ky; accumulator (s - ky) & 3 = (u - ky) & 3
+#pragma unroll
+                for (int ky = 0; ky < 4; ky++) {
+                    f2 (&ac)[VEC / 2] = acc[(u - ky) & 3];
+#pragma unroll
+                    for (int k = 0; k < VEC / 2; k++) {
+                        f2 v = ky == 0 ? (f2){0.f, 0.f} : ac[k];
+#pragma unroll
+                        for (int kx = 0; kx < 4; kx++) v = __builtin_elementwise_fma(in[kx][k], (f2){tap[ky][kx], tap[ky][kx]}, v);
+                        ac[k] = v;
+                    }
+                }
+                const int done = s - 3;                             // output row oy0 + done is complete
+                if (done >= 0) {
+                    Vec out;
+#pragma unroll
+                    for (int k = 0; k < VEC / 2; k++) {
+                        const f2 r = acc[(u - 3) & 3][k] * (f2){a.gain, a.gain};
+                        store_as<T>(out.v, 2 * k, r[0]);
+                        store_as<T>(out.v, 2 * k + 1, r[1]);
+                    }
+                    *reinterpret_cast<Vec*>(y + int64_t(oy0 + done) * a.ys_h) = out;
+                }
+#pragma unroll
+                for (int kx = 0; kx < 4; kx++) raw[kx] = nxt[kx];
+            }
+        }
+    }
+}
+
+template <class T>
+int launch_blur4_nhwc(const UpArgs& a, hipStream_t stream) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int cv = a.c / VEC;
+    const int rows_per_strip = a.out_h > 256 ? 64 : (a.out_h > 64 ? 32 : 16);
+    const int strips_y = (a.out_h + rows_per_strip - 1) / rows_per_strip;
+    const int64_t threads = int64_t(a.out_w) * cv * strips_y * a.n;
+    const int64_t blocks = (threads + 255) / 256;
+    if (blocks > INT32_MAX) return 1;
+    hipLaunchKernelGGL((upfirdn_blur4_nhwc_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream, a, cv, strips_y, rows_per_strip);
+    return check_launch("upfirdn2d(blur4, channels_last)") == GNERF_OK ? 0 : -1;
+}
+
 template <class T, int UP, int DOWN>
 int launch_fir4(const UpArgs& a, hipStream_t stream) {
     constexpr int TW = Fir4Shape<T, UP, DOWN>::TW, TH = Fir4Shape<T, UP, DOWN>::TH;
@@ -549,6 +670,17 @@ int launch_up(const UpArgs& a, hipStream_t stream) {
             if (a.upx == 1 && a.downx == 1) rc = launch_blur4<T>(a, stream);
             else if (a.upx == 2 && a.downx == 1) rc = launch_fir4<T, 2, 1>(a, stream);
             else if (a.upx == 1 && a.downx == 2) rc = launch_fir4<T, 1, 2>(a, stream);
+            if (rc == 0) return GNERF_OK;
+            if (rc < 0) return GNERF_E_LAUNCH;
+        }
+    }
+    if constexpr (sizeof(typename Arith<T>::type) == 4) {
+        constexpr int VEC = 16 / sizeof(T);
+        const bool nhwc = a.c > 1 && a.xs_c == 1 && a.xs_w == a.c && a.xs_h == int64_t(a.in_w) * a.c && a.xs_n == a.xs_h * a.in_h &&
+                          a.ys_c == 1 && a.ys_w == a.c && a.ys_h == int64_t(a.out_w) * a.c && a.ys_n == a.ys_h * a.out_h;
+        if (nhwc && a.fh == 4 && a.fw == 4 && a.upx == 1 && a.upy == 1 && a.downx == 1 && a.downy == 1 && a.c % VEC == 0 &&
+            (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0) {
+            const int rc = launch_blur4_nhwc<T>(a, stream);
             if (rc == 0) return GNERF_OK;
             if (rc < 0) return GNERF_E_LAUNCH;
         }

@@ -41,21 +41,36 @@ LRELU_GAIN = math.sqrt(2)
 _MODCONV_FAST = os.environ.get('GNERF_MODCONV_FAST', '1') != '0'
 
 
+# The fp16 blocks run channels_last on the fast path (memory [N,H,W,C]): MIOpen's fp16 convolutions compute in that layout and
+# otherwise transpose in and out around every call (tools/bench_sr_conv_layout.py: 0.63 ms of the superresolution at batch 4), and
+# the surrounding kernels (blur, epilogue, ToRGB) have channels_last forms.  GNERF_FP16_CHANNELS_LAST=0 keeps NCHW.
+_FP16_CHANNELS_LAST = os.environ.get('GNERF_FP16_CHANNELS_LAST', '1') != '0'
+
+
+def _is_channels_last(x):
+    return x.ndim == 4 and x.shape[1] > 1 and x.stride(1) == 1 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+
+
 def _fast_path(x, *params):
-    return (_MODCONV_FAST and x.is_cuda and x.is_contiguous() and x.dtype in (torch.float16, torch.float32)
+    return (_MODCONV_FAST and x.is_cuda and (x.is_contiguous() or _is_channels_last(x)) and x.dtype in (torch.float16, torch.float32)
             and not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))))
 
 
-def _prenormalised_weight(module, dtype):
-    """weight / (sqrt(fan_in) max|weight[o]|) in `dtype` (networks_stylegan2.py:63), cached per weight version: a constant at inference."""
+def _prenormalised_weight(module, dtype, channels_last=False, transposed=False):
+    """weight / (sqrt(fan_in) max|weight[o]|) in `dtype` (networks_stylegan2.py:63), cached per weight version: a constant at inference.
+    channels_last: in that memory format (for channels_last activations); transposed: as [I,O,k,k] for conv_transpose2d."""
     w = module.weight
-    key = (w.data_ptr(), w._version if not w.is_inference() else None, dtype)
-    cache = module.__dict__.get('_gnerf_prenorm')
-    if cache is None or cache[0] != key:
+    key = (w.data_ptr(), w._version if not w.is_inference() else None, dtype, channels_last, transposed)
+    cache = module.__dict__.setdefault('_gnerf_prenorm', {})
+    hit = cache.get(key[2:])
+    if hit is None or hit[0] != key:
         with torch.no_grad():
-            cache = (key, (w * (1 / math.sqrt(w[0].numel()) / w.norm(float('inf'), dim=[1, 2, 3], keepdim=True))).to(dtype).contiguous())
-        module.__dict__['_gnerf_prenorm'] = cache
-    return cache[1]
+            v = (w * (1 / math.sqrt(w[0].numel()) / w.norm(float('inf'), dim=[1, 2, 3], keepdim=True))).to(dtype)
+            if transposed:
+                v = v.transpose(0, 1)
+            hit = (key, v.contiguous(memory_format=torch.channels_last if channels_last else torch.contiguous_format))
+        cache[key[2:]] = hit
+    return hit[1]
 
 
 class Linear(nn.Module):
@@ -147,18 +162,25 @@ class StyledConv(nn.Module):
         self.noise_strength = nn.Parameter(torch.zeros([]))
         self.bias = nn.Parameter(torch.zeros(c_out))
 
-    def _resampled_conv(self, x, weight, groups):
+    def _resampled_conv(self, x, weight, groups, weight_t=None):
         """weight [groups*O, I, 3, 3] (correlation form).  up == 1: 3x3 convolution with padding 1.  up == 2: stride-2
         transposed convolution (kernel as is: the reference un-flips it twice), 2H+1 outputs per axis, then the low-pass
-        filter with gain up^2 and one pixel of padding -> 2H."""
+        filter with gain up^2 and one pixel of padding -> 2H.  weight_t: the [groups*I, O, 3, 3] form, when the caller has it."""
+        fmt = torch.channels_last if _is_channels_last(x) else torch.contiguous_format
         if self.up == 1:
-            return F.conv2d(x, weight, padding=1, groups=groups)
-        o, i = weight.shape[0] // groups, weight.shape[1]
-        wt = weight.reshape(groups, o, i, 3, 3).transpose(1, 2).reshape(groups * i, o, 3, 3)
-        x = F.conv_transpose2d(x, wt, stride=2, groups=groups)
+            return F.conv2d(x, weight if fmt == torch.contiguous_format else weight.contiguous(memory_format=fmt), padding=1, groups=groups)
+        if weight_t is None:
+            o, i = weight.shape[0] // groups, weight.shape[1]
+            weight_t = weight.reshape(groups, o, i, 3, 3).transpose(1, 2).reshape(groups * i, o, 3, 3)
+            if fmt == torch.channels_last:
+                weight_t = weight_t.contiguous(memory_format=fmt)
+        x = F.conv_transpose2d(x, weight_t, stride=2, groups=groups)
         return upfirdn2d.upfirdn2d(x, self.resample_filter, padding=[1, 1, 1, 1], gain=4)
 
-    def forward(self, x, w, noise_mode='random', gain=1.0, fused=True):
+    def forward(self, x, w, noise_mode='random', gain=1.0, fused=True, prescaled=False, next_layer=None, next_w=None):
+        """prescaled: x already carries this layer's input scaling (see next_layer).  next_layer / next_w: the StyledConv that
+        consumes the result and its w; where the shared-weight channels_last form applies, that layer's `x * styles` is folded
+        into this layer's epilogue, and the call returns (x, folded) instead of x."""
         assert noise_mode in ('random', 'const', 'none')
         n, c_in, h, wd = x.shape
         styles = self.affine(w)
@@ -167,19 +189,32 @@ class StyledConv(nn.Module):
             noise = torch.randn([n, 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
         elif noise_mode == 'const':
             noise = self.noise_const * self.noise_strength
+        folded = False
+        assert not prescaled or (_fast_path(x, self.weight, self.bias, self.noise_strength, styles) and x.dtype == torch.float16 and n > 1)
         if _fast_path(x, self.weight, self.bias, self.noise_strength, styles):
             import gnerf_hip
             half = x.dtype == torch.float16
+            cl = _is_channels_last(x)
             c_out = self.weight.shape[0]
             clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
             if half and n > 1:          # shared-weight form: activations scaled by the styles, demodulation in the epilogue
                 _, dco = gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=x.dtype, want_weights=False, want_dcoefs=True)
-                x = self._resampled_conv(gnerf_hip.scale_channels(x, gnerf_hip.normalise_styles(styles)), _prenormalised_weight(self, x.dtype), 1)
-                return gnerf_hip.modconv_epilogue(x, self.bias, scale=dco, noise=noise, round_noise=True, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
+                if not prescaled:
+                    x = gnerf_hip.scale_channels(x, gnerf_hip.normalise_styles(styles))
+                x = self._resampled_conv(x, _prenormalised_weight(self, x.dtype, cl), 1,
+                                         weight_t=_prenormalised_weight(self, x.dtype, cl, transposed=True) if self.up == 2 else None)
+                nxt = None
+                if next_layer is not None and _is_channels_last(x) and _fast_path(x, next_layer.weight, next_layer.bias, next_layer.noise_strength):
+                    nxt = gnerf_hip.normalise_styles(next_layer.affine(next_w))
+                    folded = True
+                x = gnerf_hip.modconv_epilogue(x, self.bias, scale=dco, noise=noise, round_noise=True, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp,
+                                               next_scale=nxt)
+                return (x, folded) if next_layer is not None else x
             wts, _ = gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=x.dtype)                  # [N,O,I,3,3], one launch
-            x = self._resampled_conv(x.reshape(1, n * c_in, h, wd), wts.reshape(n * c_out, c_in, 3, 3), n)
-            x = x.reshape(n, c_out, *x.shape[2:])
-            return gnerf_hip.modconv_epilogue(x, self.bias, noise=noise, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
+            x = self._resampled_conv(x.reshape(1, n * c_in, h, wd) if n > 1 else x, wts.reshape(n * c_out, c_in, 3, 3), n)
+            x = x.reshape(n, c_out, *x.shape[2:]) if n > 1 else x
+            x = gnerf_hip.modconv_epilogue(x, self.bias, noise=noise, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
+            return (x, folded) if next_layer is not None else x
         if fused:
             wts = _modulated_weights(self.weight, styles, True, x.dtype == torch.float16).to(x.dtype)          # [N,O,I,3,3]
             c_out = wts.shape[1]
@@ -195,7 +230,8 @@ class StyledConv(nn.Module):
             x = self._resampled_conv(x * styles.to(x.dtype)[:, :, None, None], weight.to(x.dtype), 1)
             x = torch.addcmul(noise.to(x.dtype), x, dcoefs) if noise is not None else x * dcoefs      # torch_utils/ops/fma.py
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
-        return bias_act.bias_act(x, self.bias.to(x.dtype), act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
+        x = bias_act.bias_act(x, self.bias.to(x.dtype), act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
+        return (x, folded) if next_layer is not None else x
 
 
 class ToRGB(nn.Module):
@@ -214,6 +250,8 @@ class ToRGB(nn.Module):
         styles = self.affine(w) * self.weight_gain
         if _fast_path(x, self.weight, self.bias, styles):
             import gnerf_hip
+            if x.dtype == torch.float16 and _is_channels_last(x) and self.weight.shape[0] == 3 and c_in in gnerf_hip.TORGB_CHANNELS:
+                return gnerf_hip.torgb_channels_last(x, self.weight, styles, self.bias, clamp=self.conv_clamp)      # one streaming read of x
             if x.dtype == torch.float16 and n > 1:
                 x = F.conv2d(gnerf_hip.scale_channels(x, styles), self.weight.to(x.dtype))
             else:
@@ -255,8 +293,11 @@ class Block(nn.Module):
             x = self.const.to(dtype).unsqueeze(0).repeat(ws[0].shape[0], 1, 1, 1)
             x = self.conv1(x, ws[0], noise_mode, fused=fused)
         else:
-            x = self.conv0(x.to(dtype), ws[0], noise_mode, fused=fused)
-            x = self.conv1(x, ws[1], noise_mode, fused=fused)
+            x = x.to(dtype)
+            if dtype == torch.float16 and _FP16_CHANNELS_LAST and x.shape[1] % 8 == 0 and (x.is_contiguous() or _is_channels_last(x)) and _fast_path(x, ws[0], self.conv0.weight, self.conv1.weight, self.torgb.weight):
+                x = x.contiguous(memory_format=torch.channels_last)
+            x, folded = self.conv0(x, ws[0], noise_mode, fused=fused, next_layer=self.conv1, next_w=ws[1])
+            x = self.conv1(x, ws[1], noise_mode, fused=fused, prescaled=folded)
         y = self.torgb(x, ws[-1], fused=fused).float()
         if img is not None and self.up == 2 and self.emit_channels_last and img.is_cuda:
             return x, upfirdn2d.upsample2d_add_channels_last(img, y, self.resample_filter)

@@ -23,7 +23,7 @@ _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.float64: F64}
 
 MAX_SAMPLES = 256
 DEBUG_SLOTS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 # decoder arithmetic of the fused renderer (GNERF_MLP_* in include/gnerf_hip.h)
 MLP_MODES = {'auto': 0, 'f16x3': 1, 'f32': 2}
 
@@ -92,6 +92,9 @@ SIGNATURES = {
     'gnerf_scale_channels': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_modconv_epilogue': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p, _c_i, _c_f, _c_f, _c_f, _c_p]),
     'gnerf_upsample2x_add_nhwc': (_c_i, [_c_p, _c_p, ctypes.POINTER(_c_f), _c_i, _c_f, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
+    'gnerf_scale_channels_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
+    'gnerf_modconv_epilogue_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p, _c_i, _c_f, _c_f, _c_f, _c_p, _c_p]),
+    'gnerf_torgb_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_p]),
 }
 
 
@@ -513,29 +516,49 @@ def normalise_styles(styles):
     return out
 
 
+def is_channels_last(x):
+    """True for a 4-D tensor whose MEMORY is [N,H,W,C] with C > 1 (and not also NCHW-contiguous)."""
+    return x.ndim == 4 and x.shape[1] > 1 and x.stride(1) == 1 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+
+
+def _activation_layout(x, what):
+    """'nchw' or 'nhwc' for a dense float16/float32 4-D activation tensor; anything else raises."""
+    if x.ndim != 4 or x.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError(f'{what}: x must be a 4-D float16/float32 tensor')
+    if x.is_contiguous():
+        return 'nchw'
+    if is_channels_last(x):
+        return 'nhwc'
+    raise RuntimeError(f'{what}: x must be contiguous (NCHW) or channels_last')
+
+
 def scale_channels(x, scale):
-    """x [N,C,H,W] (NCHW contiguous, float16/32) * scale [N,C] float32, the product formed in x's dtype (networks_stylegan2.py:77)."""
+    """x [N,C,H,W] (NCHW contiguous or channels_last, float16/32) * scale [N,C] float32, the product formed in x's dtype
+    (networks_stylegan2.py:77).  The result has x's memory format."""
     _require_cuda(x, scale)
-    if x.ndim != 4 or not x.is_contiguous() or x.dtype not in (torch.float32, torch.float16):
-        raise RuntimeError('scale_channels: x must be a contiguous float16/float32 NCHW tensor')
+    layout = _activation_layout(x, 'scale_channels')
     n, c, h, w = x.shape
     s32 = scale.detach().to(torch.float32).contiguous()
     if s32.numel() != n * c:
         raise RuntimeError('scale_channels: scale must have N*C elements')
     y = torch.empty_like(x)
     with _on_device(x.device):
-        code = load().gnerf_scale_channels(_ptr(x), _ptr(s32), _ptr(y), _DTYPE_CODE[x.dtype], n * c, h * w, _stream(x))
+        if layout == 'nhwc':
+            code = load().gnerf_scale_channels_nhwc(_ptr(x), _ptr(s32), _ptr(y), _DTYPE_CODE[x.dtype], n, h * w, c, _stream(x))
+        else:
+            code = load().gnerf_scale_channels(_ptr(x), _ptr(s32), _ptr(y), _DTYPE_CODE[x.dtype], n * c, h * w, _stream(x))
     _check(code, 'gnerf_scale_channels')
     return y
 
 
-def modconv_epilogue(x, bias=None, scale=None, noise=None, round_noise=False, act='lrelu', alpha=0.2, gain=1.0, clamp=None):
+def modconv_epilogue(x, bias=None, scale=None, noise=None, round_noise=False, act='lrelu', alpha=0.2, gain=1.0, clamp=None, next_scale=None):
     """Everything after the modulated convolution in one pass (networks_stylegan2.py:79-83 / :96-97 then :331-333):
     t = x * scale[n,c] + noise (rounded to x's dtype; skipped when both are None), y = clamp(act(t + bias[c]) * gain).
-    x [N,C,H,W] NCHW contiguous float16/32; scale [N,C] float32; noise float32 [H,W] or [N,1,H,W]; bias [C] (any float dtype)."""
-    _require_cuda(x, bias, scale, noise)
-    if x.ndim != 4 or not x.is_contiguous() or x.dtype not in (torch.float32, torch.float16):
-        raise RuntimeError('modconv_epilogue: x must be a contiguous float16/float32 NCHW tensor')
+    x [N,C,H,W] NCHW contiguous or channels_last, float16/32; scale [N,C] float32; noise float32 [H,W] or [N,1,H,W]; bias [C] (any
+    float dtype).  next_scale [N,C] (channels_last only): y is additionally multiplied by it in x's dtype -- the next layer's
+    `x * styles` folded into this pass.  The result has x's memory format."""
+    _require_cuda(x, bias, scale, noise, next_scale)
+    layout = _activation_layout(x, 'modconv_epilogue')
     if act not in ('linear', 'lrelu'):
         raise RuntimeError('modconv_epilogue: act must be linear or lrelu')
     n, c, h, w = x.shape
@@ -550,12 +573,42 @@ def modconv_epilogue(x, bias=None, scale=None, noise=None, round_noise=False, ac
     b = None if bias is None else bias.detach().to(x.dtype).contiguous()
     if (s32 is not None and s32.numel() != n * c) or (b is not None and b.numel() != c):
         raise RuntimeError('modconv_epilogue: scale must have N*C and bias C elements')
+    nx = None if next_scale is None else next_scale.detach().to(torch.float32).contiguous()
+    if nx is not None and (layout != 'nhwc' or nx.numel() != n * c):
+        raise RuntimeError('modconv_epilogue: next_scale needs a channels_last x and N*C elements')
     y = torch.empty_like(x)
     with _on_device(x.device):
-        code = load().gnerf_modconv_epilogue(_ptr(x), _ptr(y), _DTYPE_CODE[x.dtype], n * c, h * w, c, _ptr(s32), _ptr(nz), per_item,
-                                             1 if round_noise else 0, _ptr(b), 3 if act == 'lrelu' else 1, float(alpha), float(gain),
-                                             float(-1 if clamp is None else clamp), _stream(x))
+        if layout == 'nhwc':
+            code = load().gnerf_modconv_epilogue_nhwc(_ptr(x), _ptr(y), _DTYPE_CODE[x.dtype], n, h * w, c, _ptr(s32), _ptr(nz), per_item,
+                                                      1 if round_noise else 0, _ptr(b), 3 if act == 'lrelu' else 1, float(alpha), float(gain),
+                                                      float(-1 if clamp is None else clamp), _ptr(nx), _stream(x))
+        else:
+            code = load().gnerf_modconv_epilogue(_ptr(x), _ptr(y), _DTYPE_CODE[x.dtype], n * c, h * w, c, _ptr(s32), _ptr(nz), per_item,
+                                                 1 if round_noise else 0, _ptr(b), 3 if act == 'lrelu' else 1, float(alpha), float(gain),
+                                                 float(-1 if clamp is None else clamp), _stream(x))
     _check(code, 'gnerf_modconv_epilogue')
+    return y
+
+
+TORGB_CHANNELS = (32, 64, 128, 256, 512)
+
+
+def torgb_channels_last(x, weight, styles, bias=None, clamp=None):
+    """ToRGBLayer to three channels on a channels_last float16 x [N,C,H,W] (networks_stylegan2.py:349-367): weight [3,C,1,1] or [3,C]
+    float32, styles [N,C] float32 (weight_gain applied), bias [3].  Returns float16 [N,3,H,W], NCHW.  See include/gnerf_hip.h."""
+    _require_cuda(x, weight, styles, bias)
+    if x.dtype != torch.float16 or not is_channels_last(x) or x.shape[1] not in TORGB_CHANNELS:
+        raise RuntimeError('torgb_channels_last: x must be a channels_last float16 tensor with 32, 64, 128, 256 or 512 channels')
+    n, c, h, w = x.shape
+    w32 = weight.detach().to(torch.float32).reshape(-1).contiguous()
+    s32 = styles.detach().to(torch.float32).contiguous()
+    if w32.numel() != 3 * c or s32.numel() != n * c:
+        raise RuntimeError('torgb_channels_last: weight must be [3,C] and styles [N,C]')
+    b = None if bias is None else bias.detach().to(torch.float16).contiguous()
+    y = torch.empty([n, 3, h, w], dtype=torch.float16, device=x.device)
+    with _on_device(x.device):
+        code = load().gnerf_torgb_nhwc(_ptr(x), _ptr(w32), _ptr(s32), _ptr(b), _ptr(y), n, h * w, c, float(-1 if clamp is None else clamp), _stream(x))
+    _check(code, 'gnerf_torgb_nhwc')
     return y
 
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GNERF_ABI_VERSION 4
+#define GNERF_ABI_VERSION 5
 
 /* error codes */
 #define GNERF_OK            0
@@ -89,10 +89,26 @@ int gnerf_scale_channels(const void* x, const float* scale, void* y, int dtype, 
  *   y = clamp(act(t + bias[row % channels]) * gain)                                          (bias_act, :331-333)
  * x, y: [rows, row_len] NCHW activations (rows = batch * channels <= 65535); scale: float32 [rows] or NULL; noise: float32
  * [row_len] (or [batch, row_len] when noise_per_item: 'random' mode) or NULL, rounded to the activations' dtype first when
- * round_noise; bias: [channels] in the activations' dtype or NULL; act: 1 linear or 3 lrelu (GNERF_E_UNSUPPORTED otherwise). */
+ * round_noise or when scale is given (the un-fused form's fma takes a noise tensor of the activations' dtype, :79-80); bias: [channels] in the activations' dtype or NULL; act: 1 linear or 3 lrelu (GNERF_E_UNSUPPORTED otherwise). */
 int gnerf_modconv_epilogue(const void* x, void* y, int dtype, int rows, int row_len, int channels,
                            const float* scale, const float* noise, int noise_per_item, int round_noise, const void* bias,
                            int act, float alpha, float gain, float clamp, gnerf_stream_t stream);
+/* The same three steps for CHANNELS_LAST activations (memory [n, pixels, channels]; the layout the fp16 blocks run in so that
+ * MIOpen's fp16 convolutions need no transposes, and what the reference's `fp16_channels_last` produces, networks_stylegan2.py:385).
+ * scale / next_scale: float32 [n, channels] or NULL; noise: float32 [pixels] (or [n, pixels] when noise_per_item) or NULL.
+ * next_scale: the result, rounded to the activations' dtype, is additionally multiplied by next_scale[n, c] -- the NEXT layer's
+ * `x * styles` (:77) folded into this pass (bit-identical to gnerf_modconv_epilogue_nhwc followed by gnerf_scale_channels_nhwc). */
+int gnerf_scale_channels_nhwc(const void* x, const float* scale, void* y, int dtype, int n, int pixels, int channels, gnerf_stream_t stream);
+int gnerf_modconv_epilogue_nhwc(const void* x, void* y, int dtype, int n, int pixels, int channels,
+                                const float* scale, const float* noise, int noise_per_item, int round_noise, const void* bias,
+                                int act, float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream);
+/* ToRGBLayer with three output channels on a channels_last float16 tensor (networks_stylegan2.py:349-367, modulation as in the
+ * fused form :89-96): y[n, o, p] = clamp(half(sum_c x[n, p, c] * half(weight[o, c] * styles[n, c])) + bias[o]), products exact, fp32
+ * accumulation.  x: float16 [n, pixels, channels] (channels 32, 64, 128, 256 or 512, 16-byte aligned); weight float32 [3, channels];
+ * styles float32 [n, channels] (weight_gain already applied, :364); bias float16 [3] or NULL; y: float16 [n, 3, pixels] (NCHW: it is
+ * added to the running image); clamp < 0 = none.  One streaming read of x instead of scale pass + 1x1 convolution + bias pass. */
+int gnerf_torgb_nhwc(const void* x, const float* weight, const float* styles, const void* bias, void* y,
+                     int n, int pixels, int channels, float clamp, gnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * upfirdn2d.  Zero-insert upsample, pad/crop, 2-D FIR, decimate (upfirdn2d.cpp:20-102).

@@ -5,6 +5,8 @@ size-independent properties at BASELINE.json's full sizes.
 Tolerances (fp32 arithmetic on both sides, different summation orders and hardware exp2/log2 in the MLP
 activations): rgb pixel MSE < 1e-8 against the oracle here -- north_star's bound is 1e-4."""
 
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -1493,3 +1495,72 @@ def test_bench_two_ranks_on_one_gpu(dev):
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['steps'] == 5 and line['scaling'] == 'weak' and line['value'] > 1e6
     assert line['roofline']['kernel_ms'] > 0 and line['cpu_baseline'] is None and line['secondary'] is None
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+def test_channels_last_forms_equal_nchw_forms(dev, dtype):
+    """The channels_last kernels (csrc/modconv.hip *_nhwc, the channels_last 4x4 blur of csrc/upfirdn2d.hip) against the NCHW
+    kernels on the same values: scale_channels and the epilogue are bit-identical (same roundings), the epilogue with next_scale
+    equals epilogue followed by scale_channels, the blur agrees with the PyTorch-op form to the storage type's rounding; every
+    result keeps the input's memory format."""
+    import gnerf_hip
+    from torch_utils.ops import upfirdn2d
+    gen = torch.Generator().manual_seed(3)
+    half = dtype == torch.float16
+    for (n, c, h, w) in [(3, 16, 12, 20), (1, 64, 33, 17), (2, 8, 5, 7)]:
+        x = (torch.randn(n, c, h, w, generator=gen) * 3).to(dev).to(dtype)
+        xc = x.contiguous(memory_format=torch.channels_last)
+        assert gnerf_hip.is_channels_last(xc)
+        sc = (torch.randn(n, c, generator=gen) + 1).to(dev)
+        nx = (torch.randn(n, c, generator=gen) + 1).to(dev)
+        b = torch.randn(c, generator=gen).to(dev)
+        got = gnerf_hip.scale_channels(xc, sc)
+        assert gnerf_hip.is_channels_last(got) and torch.equal(got, gnerf_hip.scale_channels(x, sc))
+        for noise in (None, torch.randn(h, w, generator=gen).to(dev), torch.randn(n, 1, h, w, generator=gen).to(dev)):
+            for scale in (None, sc):
+                for rn in (False, True):
+                    kw = dict(scale=scale, noise=noise, round_noise=rn, act='lrelu', gain=1.3, clamp=2.5)
+                    want = gnerf_hip.modconv_epilogue(x, b, **kw)
+                    got = gnerf_hip.modconv_epilogue(xc, b, **kw)
+                    assert gnerf_hip.is_channels_last(got) and torch.equal(got, want), (n, c, noise is None, scale is None, rn)
+                    both = gnerf_hip.modconv_epilogue(xc, b, next_scale=nx, **kw)
+                    assert torch.equal(both, gnerf_hip.scale_channels(got, nx))
+        assert torch.equal(gnerf_hip.modconv_epilogue(xc, b, act='linear', clamp=2.0), gnerf_hip.modconv_epilogue(x, b, act='linear', clamp=2.0))
+        with pytest.raises(RuntimeError):
+            gnerf_hip.modconv_epilogue(x, b, next_scale=nx)                      # folding needs the channels_last form
+        # the blur after a transposed convolution: [.., 2h+1, 2w+1] -> [.., 2h, 2w] with gain 4, and a plain filter2d
+        f = upfirdn2d.setup_filter([1, 3, 3, 1], device=dev)
+        for pad, gain, flip in (([1, 1, 1, 1], 4.0, False), ([2, 1, 2, 1], 1.0, True), ([0, 0, 0, 0], 1.0, False), ([3, 3, 3, 3], 2.0, False)):
+            if h + pad[2] + pad[3] < 4 or w + pad[0] + pad[1] < 4:
+                continue
+            got = upfirdn2d.upfirdn2d(xc, f, padding=pad, gain=gain, flip_filter=flip)
+            want = upfirdn2d.upfirdn2d(x.float(), f, padding=pad, gain=gain, flip_filter=flip, impl='ref')
+            assert got.dtype == dtype and gnerf_hip.is_channels_last(got) and got.shape == want.shape
+            tol = dict(rtol=2e-3, atol=2e-3 * float(want.abs().max())) if half else dict(rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+            np.testing.assert_allclose(got.float().cpu().numpy(), want.cpu().numpy(), **tol)
+        g = torch.randn(4, 4, generator=gen).to(dev)                             # a non-symmetric filter: flip and orientation matter
+        got = upfirdn2d.upfirdn2d(xc, g, padding=[1, 2, 2, 1])
+        want = upfirdn2d.upfirdn2d(x.float(), g, padding=[1, 2, 2, 1], impl='ref')
+        np.testing.assert_allclose(got.float().cpu().numpy(), want.cpu().numpy(), rtol=2e-3 if half else 1e-5, atol=(4e-3 if half else 1e-5) * float(want.abs().max()))
+
+
+def test_torgb_channels_last_vs_composed_ops(dev):
+    """gnerf_torgb_nhwc against ToRGBLayer's op chain (networks_stylegan2.py:349-367, fused modulation :89-96): fp16 modulated
+    weights, fp32 accumulation, bias, clamp.  The kernel rounds once where the chain rounds the convolution's output and the bias
+    sum separately, so the comparison allows two fp16 roundings."""
+    import gnerf_hip
+    gen = torch.Generator().manual_seed(5)
+    for (n, c, h, w) in [(4, 128, 24, 40), (1, 256, 16, 16), (2, 32, 9, 13), (1, 512, 4, 4), (3, 64, 7, 5)]:
+        x = (torch.randn(n, c, h, w, generator=gen) * 2).to(dev).half().contiguous(memory_format=torch.channels_last)
+        weight = torch.randn(3, c, 1, 1, generator=gen).to(dev)
+        styles = ((torch.randn(n, c, generator=gen) + 1) / math.sqrt(c)).to(dev)
+        bias = torch.randn(3, generator=gen).to(dev)
+        for clamp in (None, 0.75):
+            got = gnerf_hip.torgb_channels_last(x, weight, styles, bias, clamp=clamp)
+            assert got.shape == (n, 3, h, w) and got.dtype == torch.float16 and got.is_contiguous()
+            wmod = (weight.reshape(1, 3, c) * styles[:, None, :]).half().float()                     # [n,3,c]
+            acc = torch.einsum('nchw,noc->nohw', x.float(), wmod).half().float() + bias.half().float()[None, :, None, None]
+            want = acc if clamp is None else acc.clamp(-clamp, clamp)
+            np.testing.assert_allclose(got.float().cpu().numpy(), want.half().float().cpu().numpy(), rtol=2e-3, atol=2e-3 * float(want.abs().max()))
+    with pytest.raises(RuntimeError):
+        gnerf_hip.torgb_channels_last(x.contiguous(), weight, styles, bias)

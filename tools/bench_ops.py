@@ -74,6 +74,24 @@ with torch.no_grad():
         report(f'modconv_epilogue (demod + noise + bias + lrelu + clamp) [4,128,512,512] {nm}', ms, 2 * x.numel() * es + nz.numel() * 4)
         ms = timeit(lambda: gnerf_hip.scale_channels(x, sc))
         report(f'scale_channels [4,128,512,512] {nm}', ms, 2 * x.numel() * es)
+    # channels_last forms (the fp16 blocks' layout on the fast path)
+    for dt, nm in ((torch.float16, 'f16'),):
+        es = 2
+        x = torch.randn(4, 128, 512, 512, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(128, device=dev, dtype=dt)
+        sc = torch.rand(4, 128, device=dev) + 0.5
+        ms = timeit(lambda: gnerf_hip.modconv_epilogue(x, b, scale=sc, act='lrelu', gain=1.41, clamp=256))
+        report(f'channels_last modconv_epilogue (demod + bias + lrelu + clamp) [4,128,512,512] {nm}', ms, 2 * x.numel() * es)
+        ms = timeit(lambda: gnerf_hip.modconv_epilogue(x, b, scale=sc, act='lrelu', gain=1.41, clamp=256, next_scale=sc))
+        report(f'channels_last modconv_epilogue + next layer input scale [4,128,512,512] {nm}', ms, 2 * x.numel() * es)
+        ms = timeit(lambda: gnerf_hip.scale_channels(x, sc))
+        report(f'channels_last scale_channels [4,128,512,512] {nm}', ms, 2 * x.numel() * es)
+        xb = torch.randn(4, 128, 513, 513, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
+        ms = timeit(lambda: upfirdn2d.upfirdn2d(xb, f, padding=[1, 1, 1, 1], gain=4))
+        report(f'channels_last upfirdn2d blur 4x4 [4,128,513,513]->512 {nm}', ms, (xb.numel() + 4 * 128 * 512 * 512) * es)
+        wrgb, srgb, brgb = torch.randn(3, 128, 1, 1, device=dev), torch.randn(4, 128, device=dev) / 11, torch.randn(3, device=dev)
+        ms = timeit(lambda: gnerf_hip.torgb_channels_last(x, wrgb, srgb, brgb, clamp=256))
+        report(f'channels_last ToRGB (modulated 1x1 conv to 3 ch + bias + clamp) [4,128,512,512] {nm}', ms, x.numel() * es + 4 * 3 * 512 * 512 * es)
     wgt, sty = torch.randn(512, 512, 3, 3, device=dev), torch.randn(4, 512, device=dev)
     ms = timeit(lambda: gnerf_hip.modulate_weights(wgt, sty, True, out_dtype=torch.float32))
     report('modulate_weights [512,512,3,3] x 4 styles -> f32', ms, wgt.numel() * 4 + 4 * wgt.numel() * 4)
