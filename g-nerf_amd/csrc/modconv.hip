@@ -36,7 +36,7 @@ __device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) 
 template <class T>
 __global__ __launch_bounds__(kThreads) void modulate_weights_kernel(const float* __restrict__ weight, const float* __restrict__ styles,
                                                                     T* __restrict__ out, float* __restrict__ dcoefs,
-                                                                    int n_out, int n_in, int kk, int demodulate, int prenorm) {
+                                                                    int n_out, int n_in, int kk, int demodulate, int prenorm, int layout) {
     __shared__ float red[4];
     const int o = blockIdx.x % n_out, n = blockIdx.x / n_out;
     const int ik = n_in * kk;
@@ -63,8 +63,16 @@ __global__ __launch_bounds__(kThreads) void modulate_weights_kernel(const float*
         if (dcoefs && threadIdx.x == 0) dcoefs[int64_t(n) * n_out + o] = d;
     }
     if (out) {
-        T* dst = out + (int64_t(n) * n_out + o) * ik;
-        for (int e = threadIdx.x; e < ik; e += kThreads) store_as<T>(dst, e, ((w[e] * w_scale) * (s[e / kk] * s_scale)) * d);
+        // element (o, i, k) of sample n at o * so + i * si + k * sk: [O,I,K] (conv2d), [I,O,K] (conv_transpose2d), and the
+        // channels_last memory of either, [O,K,I] / [I,K,O]
+        const int64_t so = layout == 0 ? ik : (layout == 1 ? kk : (layout == 2 ? ik : 1));
+        const int64_t si = layout == 0 ? kk : (layout == 1 ? int64_t(n_out) * kk : (layout == 2 ? 1 : int64_t(n_out) * kk));
+        const int64_t sk = layout == 0 || layout == 1 ? 1 : (layout == 2 ? n_in : n_out);
+        T* dst = out + int64_t(n) * n_out * ik + o * so;
+        for (int e = threadIdx.x; e < ik; e += kThreads) {
+            const int i = e / kk, k = e - i * kk;
+            store_as<T>(dst, i * si + k * sk, ((w[e] * w_scale) * (s[i] * s_scale)) * d);
+        }
     }
 }
 
@@ -359,17 +367,18 @@ __global__ __launch_bounds__(kThreads) void torgb_nhwc_kernel(const __half* __re
 }  // namespace
 
 extern "C" int gnerf_modulate_weights(const float* weight, const float* styles, void* out, int out_dtype, float* dcoefs,
-                                      int n, int n_out, int n_in, int kk, int demodulate, int prenorm, gnerf_stream_t stream) {
+                                      int n, int n_out, int n_in, int kk, int demodulate, int prenorm, int out_layout, gnerf_stream_t stream) {
     using namespace gnerf;
     if (!weight || !styles) return fail(GNERF_E_ARG, "modulate_weights: null pointer");
     if (n < 1 || n_out < 1 || n_in < 1 || kk < 1) return fail(GNERF_E_ARG, "modulate_weights: empty shape");
     if (!out && !dcoefs) return GNERF_OK;
     if (dcoefs && !demodulate) return fail(GNERF_E_ARG, "modulate_weights: dcoefs requested without demodulation");
+    if (out_layout < 0 || out_layout > 3) return fail(GNERF_E_ARG, "modulate_weights: out_layout must be GNERF_W_OIK .. GNERF_W_IKO");
     const dim3 g((unsigned)(n * n_out)), b(kThreads);
     if (!out || out_dtype == GNERF_F32)
-        hipLaunchKernelGGL(modulate_weights_kernel<float>, g, b, 0, as_stream(stream), weight, styles, static_cast<float*>(out), dcoefs, n_out, n_in, kk, demodulate, prenorm);
+        hipLaunchKernelGGL(modulate_weights_kernel<float>, g, b, 0, as_stream(stream), weight, styles, static_cast<float*>(out), dcoefs, n_out, n_in, kk, demodulate, prenorm, out_layout);
     else if (out_dtype == GNERF_F16)
-        hipLaunchKernelGGL(modulate_weights_kernel<__half>, g, b, 0, as_stream(stream), weight, styles, static_cast<__half*>(out), dcoefs, n_out, n_in, kk, demodulate, prenorm);
+        hipLaunchKernelGGL(modulate_weights_kernel<__half>, g, b, 0, as_stream(stream), weight, styles, static_cast<__half*>(out), dcoefs, n_out, n_in, kk, demodulate, prenorm, out_layout);
     else
         return fail(GNERF_E_ARG, "modulate_weights: output dtype must be float32 or float16");
     return check_launch("modulate_weights");

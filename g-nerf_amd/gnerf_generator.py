@@ -43,7 +43,8 @@ _MODCONV_FAST = os.environ.get('GNERF_MODCONV_FAST', '1') != '0'
 
 # The fp16 blocks run channels_last on the fast path (memory [N,H,W,C]): MIOpen's fp16 convolutions compute in that layout and
 # otherwise transpose in and out around every call (tools/bench_sr_conv_layout.py: 0.63 ms of the superresolution at batch 4), and
-# the surrounding kernels (blur, epilogue, ToRGB) have channels_last forms.  GNERF_FP16_CHANNELS_LAST=0 keeps NCHW.
+# the surrounding kernels (blur, epilogue, ToRGB) have channels_last forms.  GNERF_FP16_CHANNELS_LAST=0 keeps NCHW.  Inference fast path
+# only: under autograd (un-fused forms) the same switch measured G forward 12.7 -> 13.4 ms, G backward 26.6 -> 25.8 ms: no gain.
 _FP16_CHANNELS_LAST = os.environ.get('GNERF_FP16_CHANNELS_LAST', '1') != '0'
 
 
@@ -210,8 +211,12 @@ class StyledConv(nn.Module):
                 x = gnerf_hip.modconv_epilogue(x, self.bias, scale=dco, noise=noise, round_noise=True, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp,
                                                next_scale=nxt)
                 return (x, folded) if next_layer is not None else x
-            wts, _ = gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=x.dtype)                  # [N,O,I,3,3], one launch
-            x = self._resampled_conv(x.reshape(1, n * c_in, h, wd) if n > 1 else x, wts.reshape(n * c_out, c_in, 3, 3), n)
+            # per-sample weights in one launch, already in the order and memory format the convolution takes them
+            # ([N,O,I,3,3] for conv2d, [N,I,O,3,3] for conv_transpose2d: re-ordering 38 MB of fp32 weights per up-layer was a
+            # strided copy per call)
+            wts, _ = gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=x.dtype, transposed=self.up == 2, channels_last=cl)
+            wts = wts.reshape(-1, *wts.shape[2:]) if n > 1 else wts[0]
+            x = self._resampled_conv(x.reshape(1, n * c_in, h, wd) if n > 1 else x, None if self.up == 2 else wts, n, weight_t=wts if self.up == 2 else None)
             x = x.reshape(n, c_out, *x.shape[2:]) if n > 1 else x
             x = gnerf_hip.modconv_epilogue(x, self.bias, noise=noise, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
             return (x, folded) if next_layer is not None else x
@@ -294,7 +299,7 @@ class Block(nn.Module):
             x = self.conv1(x, ws[0], noise_mode, fused=fused)
         else:
             x = x.to(dtype)
-            if dtype == torch.float16 and _FP16_CHANNELS_LAST and x.shape[1] % 8 == 0 and (x.is_contiguous() or _is_channels_last(x)) and _fast_path(x, ws[0], self.conv0.weight, self.conv1.weight, self.torgb.weight):
+            if dtype == torch.float16 and _FP16_CHANNELS_LAST and x.is_cuda and x.shape[1] % 8 == 0 and _fast_path(x, ws[0], self.conv0.weight, self.conv1.weight, self.torgb.weight):
                 x = x.contiguous(memory_format=torch.channels_last)
             x, folded = self.conv0(x, ws[0], noise_mode, fused=fused, next_layer=self.conv1, next_w=ws[1])
             x = self.conv1(x, ws[1], noise_mode, fused=fused, prescaled=folded)

@@ -87,7 +87,7 @@ SIGNATURES = {
     'gnerf_query_points': (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_p]),
     'gnerf_query_points_backward': (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                            _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_p]),
-    'gnerf_modulate_weights': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),
+    'gnerf_modulate_weights': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_normalise_styles': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_p]),
     'gnerf_scale_channels': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_modconv_epilogue': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p, _c_i, _c_f, _c_f, _c_f, _c_p]),
@@ -485,24 +485,34 @@ def _workspace(device):
 # ---------------------------------------------------------------------------- surroundings of the modulated convolution
 
 
-def modulate_weights(weight, styles, demodulate=True, out_dtype=torch.float32, want_weights=True, want_dcoefs=False):
+def modulate_weights(weight, styles, demodulate=True, out_dtype=torch.float32, want_weights=True, want_dcoefs=False, transposed=False,
+                     channels_last=False):
     """Per-sample modulated (+ demodulated) convolution weights in one launch (networks_stylegan2.py:61-75), with the fp16
     pre-normalisation of :62-64 when out_dtype is float16 and demodulate.  weight [O,I,k,k], styles [N,I] float32.
-    Returns (w [N,O,I,k,k] in out_dtype or None, dcoefs [N,O] float32 or None)."""
+    Returns (w, dcoefs): w [N,O,I,k,k] in out_dtype (or None), or -- transposed -- [N,I,O,k,k], the form conv_transpose2d takes;
+    with channels_last the memory of every sample's 4-D weight is channels_last ([O,k,k,I] / [I,k,k,O]; the returned tensor is
+    a strided view with the logical shape above).  dcoefs [N,O] float32 or None."""
     _require_cuda(weight, styles)
     w32, s32 = weight.detach().to(torch.float32).contiguous(), styles.detach().to(torch.float32).contiguous()
     o, i, kh, kw = w32.shape
     n = s32.shape[0]
     if s32.shape != (n, i) or out_dtype not in (torch.float32, torch.float16):
         raise RuntimeError('modulate_weights: styles must be [N, I] and out_dtype float32 or float16')
-    out = torch.empty([n, o, i, kh, kw], dtype=out_dtype, device=w32.device) if want_weights else None
+    out = view = None
+    if want_weights:
+        a, b = (i, o) if transposed else (o, i)
+        if channels_last:
+            out = torch.empty([n, a, kh, kw, b], dtype=out_dtype, device=w32.device)
+            view = out.permute(0, 1, 4, 2, 3)
+        else:
+            out = view = torch.empty([n, a, b, kh, kw], dtype=out_dtype, device=w32.device)
     dco = torch.empty([n, o], dtype=torch.float32, device=w32.device) if (want_dcoefs and demodulate) else None
     prenorm = 1 if (out_dtype == torch.float16 and demodulate) else 0
     with _on_device(w32.device):
         code = load().gnerf_modulate_weights(_ptr(w32), _ptr(s32), _ptr(out), _DTYPE_CODE[out_dtype], _ptr(dco), n, o, i, kh * kw,
-                                             1 if demodulate else 0, prenorm, _stream(w32))
+                                             1 if demodulate else 0, prenorm, (1 if transposed else 0) + (2 if channels_last else 0), _stream(w32))
     _check(code, 'gnerf_modulate_weights')
-    return out, dco
+    return view, dco
 
 
 def normalise_styles(styles):

@@ -75,9 +75,16 @@ int gnerf_bias_act(const void* x, const void* b, const void* xref, const void* y
  * gnerf_modulate_weights: out[n,o,i,k] = weight[o,i,k] * styles[n,i] * dcoef[n,o] with dcoef = rsqrt(sum_ik (weight styles)^2 + 1e-8)
  * when `demodulate` (:66-75), after the fp16 pre-normalisation of :62-64 when `prenorm` (weight[o] / (sqrt(n_in*kk) max|weight[o]|),
  * styles[n] / max|styles[n]|).  weight [n_out, n_in, kk] and styles [n, n_in] float32; out [n, n_out, n_in, kk] in out_dtype
- * (GNERF_F32 / GNERF_F16) or NULL; dcoefs [n, n_out] float32 or NULL (the un-fused form needs only these, :71-72). */
+ * (GNERF_F32 / GNERF_F16) or NULL; dcoefs [n, n_out] float32 or NULL (the un-fused form needs only these, :71-72).
+ * out_layout: memory order of each sample's weights -- GNERF_W_OIK [n_out, n_in, kk] (conv2d), GNERF_W_IOK [n_in, n_out, kk]
+ * (what conv_transpose2d takes: the x2-upsampling layers, conv2d_resample.py:114-123, otherwise a strided copy of all weights
+ * per call), GNERF_W_OKI / GNERF_W_IKO: the channels_last memory of those two ([O,k,k,I] / [I,k,k,O]). */
+#define GNERF_W_OIK 0
+#define GNERF_W_IOK 1
+#define GNERF_W_OKI 2
+#define GNERF_W_IKO 3
 int gnerf_modulate_weights(const float* weight, const float* styles, void* out, int out_dtype, float* dcoefs,
-                           int n, int n_out, int n_in, int kk, int demodulate, int prenorm, gnerf_stream_t stream);
+                           int n, int n_out, int n_in, int kk, int demodulate, int prenorm, int out_layout, gnerf_stream_t stream);
 /* styles[n,:] / max|styles[n,:]| (the pre-normalised styles the un-fused form scales the activations with, :64 and :77). */
 int gnerf_normalise_styles(const float* styles, float* out, int n, int n_in, gnerf_stream_t stream);
 /* y[r, :] = x[r, :] * scale[r] for r < rows (rows = batch * channels of an NCHW tensor, row_len = H*W); the product is formed in

@@ -1110,6 +1110,12 @@ def test_modconv_kernels_vs_composed_ops(dev, dtype):
             ref = GG._modulated_weights(weight, styles, demod, half).to(dtype)
             got, dco = gnerf_hip.modulate_weights(weight, styles, demod, out_dtype=dtype, want_dcoefs=True)
             assert got.shape == (n, o, i, k, k) and got.dtype == dtype
+            # the other memory orders hold the same values: [N,I,O,k,k] for conv_transpose2d, channels_last memory of either
+            for tr in (False, True):
+                for cl in (False, True):
+                    alt, _ = gnerf_hip.modulate_weights(weight, styles, demod, out_dtype=dtype, transposed=tr, channels_last=cl)
+                    assert torch.equal(alt, got.transpose(1, 2) if tr else got)
+                    assert alt[0].is_contiguous(memory_format=torch.channels_last) if cl else alt.is_contiguous()
             np.testing.assert_allclose(got.float().cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-3 if half else 3e-6, atol=1e-7)
             if demod:
                 w_, s_ = GG._prenormalize(weight, styles) if half else (weight, styles)
