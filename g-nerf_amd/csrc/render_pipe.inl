@@ -438,41 +438,56 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
     __syncthreads();                                            // weights are in LDS
     if (wv == 3) { propose_issue(0); propose_finish(0); }
     __syncthreads();
-    v4f cc0[TP][2] = {}, cc1[TP][2] = {}, cc2[TP][2] = {}, cf[TP][2] = {};      // coarse colours of rays k-1, k, k+1; fine colours of ray k-1
     st.reset();
-    for (int k = -1; k <= nr + 1; k++) {
-        // ---- step 2k+2
-        if (wv < 3) {
+    // Two loops with the same barrier count, one per role.  The roles never change, and with ONE loop and `if (wv < 3)` inside
+    // every step the compiler must assume that a wave can enter the scalar branch with the shader branch's registers live (the
+    // 32 colour registers) and the other way round: splitting the loops took pipe<2> from 242 to 174 VGPRs and pipe<1> from
+    // 0.618-0.635 to 0.60 ms at config 2.
+    // (Measured on top of this and dropped: issuing a tile's tap records and its first twelve texel loads BEFORE the barrier that
+    // precedes it, with depth proposals one ray earlier and five ray slots, so that the L2 round trip runs under the barrier
+    // wait -- 0.617 ms: the two other waves of the SIMD already cover that latency, and the loads' registers are then live across
+    // the barrier; its first version spilled two of the loaded vectors, i.e. waited for them on the spot: 0.71 ms.)
+    if (wv < 3) {
+        v4f cc0[TP][2] = {}, cc1[TP][2] = {}, cc2[TP][2] = {}, cf[TP][2] = {};      // coarse colours of rays k-1, k, k+1; fine colours of ray k-1
+        for (int k = -1; k <= nr + 1; k++) {
+            // ---- step 2k+2
             shade(k + 1, false, cc2);
-        } else {
-            finalize(k - 1);
-            GNERF_STAMP(st, 8);     // merge + final march
-            output(k - 2);
-            GNERF_STAMP(st, 9);     // outputs
-        }
-        GNERF_STAMP(st, 5);         // (shader: nothing) / scalar: rounding
-        __syncthreads();
-        GNERF_STAMP(st, 6);         // barrier wait, even step
-        // ---- step 2k+3
-        if (wv < 3) {
+            GNERF_STAMP(st, 5);
+            __syncthreads();
+            GNERF_STAMP(st, 6);         // barrier wait, even step
+            // ---- step 2k+3
             accumulate(k - 1, cc0, cf);
-            GNERF_STAMP(st, 10);    // colour accumulate
+            GNERF_STAMP(st, 10);        // colour accumulate
             shade(k, true, cf);
 #pragma unroll
             for (int i = 0; i < TP; i++) {
 #pragma unroll
                 for (int n = 0; n < 2; n++) { cc0[i][n] = cc1[i][n]; cc1[i][n] = cc2[i][n]; }
             }
-        } else {
+            GNERF_STAMP(st, 5);
+            __syncthreads();
+            GNERF_STAMP(st, 7);         // barrier wait, odd step
+        }
+    } else {
+        for (int k = -1; k <= nr + 1; k++) {
+            // ---- step 2k+2
+            finalize(k - 1);
+            GNERF_STAMP(st, 8);         // merge + final march
+            output(k - 2);
+            GNERF_STAMP(st, 9);         // outputs
+            GNERF_STAMP(st, 5);         // rounding
+            __syncthreads();
+            GNERF_STAMP(st, 6);         // barrier wait, even step
+            // ---- step 2k+3
             propose_issue(k + 2);
             importance(k + 1);
-            GNERF_STAMP(st, 11);    // coarse march + importance
+            GNERF_STAMP(st, 11);        // coarse march + importance
             propose_finish(k + 2);
-            GNERF_STAMP(st, 12);    // depth proposals
+            GNERF_STAMP(st, 12);        // depth proposals
+            GNERF_STAMP(st, 5);
+            __syncthreads();
+            GNERF_STAMP(st, 7);         // barrier wait, odd step
         }
-        GNERF_STAMP(st, 5);
-        __syncthreads();
-        GNERF_STAMP(st, 7);         // barrier wait, odd step
     }
 #ifdef GNERF_STAMPS
     if (lane == 0 && p.debug) {
