@@ -843,7 +843,7 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         // half-steps of pipeline fill cost less than leaving compute units idle (64x64 rays: 167 -> 70 us)
         int64_t g = (total_seq / kPipeUnit + kNumXCD - 1) / kNumXCD * kNumXCD;
         if (g < kNumXCD) g = kNumXCD;
-        const int per_cu = pipe_tp == 1 ? GNERF_PIPE_WAVES_PER_SIMD : 2;                         // resident workgroups per CU
+        const int per_cu = pipe_tp == 1 ? GNERF_PIPE_WAVES_PER_SIMD : GNERF_PIPE2_WAVES_PER_SIMD;                         // resident workgroups per CU
         if (g > per_cu * kNumCU) g = per_cu * kNumCU;
         const size_t lds_bytes = pipe_lds_floats(pipe_tp, mlp) * sizeof(float);
         const dim3 gd((unsigned)g), bd(kPipeThreads);

@@ -68,8 +68,9 @@ __host__ __device__ constexpr int weight_floats(int mlp) {
 struct CoopLds {
     float* w1; float* w2; float* b1; float* b2;
     float* t_e; float* sig_e; float* v_e; int* rank_e; float* s_t; float* s_sig; float* w_s; float* cdf;
-    float* taps;     // [waves][16][24]
-    float* stage;    // [waves][16][kStagePitch]
+    float* taps;     // [waves][16][24]           wave w's records at taps + w * wave_pitch_taps
+    float* stage;    // [waves][16][kStagePitch]  wave w's rows at stage + w * wave_pitch_stage
+    int wave_pitch_taps, wave_pitch_stage;     // (the pipelined kernel lays the two over each other: see render_pipe_body)
     float* part;     // [waves][32] colour partial sums, then [4] ray scalars
 };
 
@@ -241,8 +242,8 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     return;
 #endif
     const int H = P.p.plane_h, W = P.p.plane_w;
-    float* taps = L.taps + wv * 16 * kTapDwords;
-    float* stage = L.stage + wv * 16 * kStagePitch;
+    float* taps = L.taps + wv * L.wave_pitch_taps;
+    float* stage = L.stage + wv * L.wave_pitch_stage;
     // ---- tap setup: lane (sample j, plane pl) for lanes 0..47
     if (lane < 48) {
         const int j = lane & 15, pl = lane >> 4;
@@ -518,6 +519,7 @@ __device__ __forceinline__ void render_coop_body(const Params& P, float* smem) {
     L.cdf = L.w_s + s_pad;
     L.taps = L.cdf + s_pad;
     L.stage = L.taps + kCoopWaves * 16 * kTapDwords;
+    L.wave_pitch_taps = 16 * kTapDwords; L.wave_pitch_stage = 16 * kStagePitch;
     L.part = L.stage + kCoopWaves * 16 * kStagePitch;
 
     const int n_groups = P.n_tiles << P.split_shift;

@@ -38,7 +38,7 @@ template <int TP> struct PipeDims {
     static constexpr int kMaxS = 48 * TP;                  // samples per pass
     static constexpr int kSPad = 2 * kMaxS;                // coarse [0, kMaxS) + fine [kMaxS, 2 kMaxS)
     static constexpr int kRounds = (kMaxS + 63) / 64;      // lanes x rounds cover the samples of a pass
-    static constexpr int kSlotFloats = 8 * kSPad + kMaxS + 96 + 16;
+    static constexpr int kSlotFloats = 7 * kSPad + 2 * kMaxS + 96 + 16;        // seven per-sample arrays, cdf + fine noise (per pass), partials, ray
 };
 
 struct PipeSlot {
@@ -55,13 +55,13 @@ __device__ __forceinline__ PipeSlot pipe_slot(float* base, int slot) {
     PipeSlot s;
     s.t_e = p; s.sig_e = p + D::kSPad; s.v_e = p + 2 * D::kSPad; s.rank_e = reinterpret_cast<int*>(p + 3 * D::kSPad);
     s.s_t = p + 4 * D::kSPad; s.s_sig = p + 5 * D::kSPad; s.w_s = p + 6 * D::kSPad; s.cdf = p + 7 * D::kSPad;
-    s.nf = p + 8 * D::kSPad; s.part = s.nf + D::kMaxS; s.misc = s.part + 96;
+    s.nf = s.cdf + D::kMaxS; s.part = s.nf + D::kMaxS; s.misc = s.part + 96;       // cdf: kMaxS entries (n_w + 1 <= S - 2 used, the rest +inf / histogram)
     return s;
 }
 
 __host__ __device__ inline size_t pipe_lds_floats(int tp, int mlp) {
     const size_t slot_floats = tp == 1 ? PipeDims<1>::kSlotFloats : PipeDims<2>::kSlotFloats;
-    return size_t(weight_floats(mlp)) + 64 + 36 + size_t(kPipeSlots) * slot_floats + 3 * 16 * kTapDwords + 3 * 16 * kStagePitch;
+    return size_t(weight_floats(mlp)) + 64 + 36 + size_t(kPipeSlots) * slot_floats + 3 * 16 * kStagePitch;       // (tap records live in the staging rows)
 }
 
 // position `seq` of the locality-ordered ray sequence -> ray index (or -1 past the end)
@@ -79,8 +79,11 @@ __device__ __forceinline__ int pipe_seq_to_ray(const Params& P, int64_t seq) {
 #ifndef GNERF_SCALAR_PRIO
 #define GNERF_SCALAR_PRIO 3
 #endif
+#ifndef GNERF_PIPE2_WAVES_PER_SIMD
+#define GNERF_PIPE2_WAVES_PER_SIMD 3
+#endif
 #ifndef GNERF_PIPE_WAVES_PER_SIMD
-#define GNERF_PIPE_WAVES_PER_SIMD 3
+#define GNERF_PIPE_WAVES_PER_SIMD 4
 #endif
 template <int TP, int MLP>
 __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
@@ -96,8 +99,13 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
     const int n_all = S + F;
     CoopLds L;
     float* slots = smem + weight_floats(MLP) + 64 + 36;
+    // A wave's tap records (16 x 24 floats) and its staging rows (16 x 36) share one area: coop_shade_tile has every record in
+    // registers before it writes the first staging row, and has read the rows back before the next tile's records are written
+    // (LDS operations of a wave execute in order).  Those 4.6 KB are what lets FOUR workgroups share a CU's 160 KB.
+    static_assert(kStagePitch >= kTapDwords, "tap records must fit in the staging rows");
     L.taps = slots + kPipeSlots * kSlotFloats;
-    L.stage = L.taps + 3 * 16 * kTapDwords;
+    L.stage = L.taps;
+    L.wave_pitch_taps = L.wave_pitch_stage = 16 * kStagePitch;
 
     // This workgroup's share of the locality-ordered ray sequence.  Workgroups b, b+8, ... share an XCD (round-robin
     // dispatch), and each XCD owns a contiguous eighth of the sequence.  Inside an XCD the sequence is dealt to its W
@@ -500,7 +508,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
 }
 
 template <int TP, int MLP>
-__global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD : 2) void render_kernel_pipe(Params P) {
+__global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD : GNERF_PIPE2_WAVES_PER_SIMD) void render_kernel_pipe(Params P) {
     extern __shared__ __align__(16) float smem[];
     if constexpr (MLP == kMlpAuto) {            // see render_kernel_coop
         if (choose_mlp(P, smem) == kMlpF32) render_pipe_body<TP, kMlpF32>(P, smem);
