@@ -101,7 +101,7 @@ def roofline(kernel_ms, rays, s, f, plane, n_items, pmc=None, pmc_source=None, t
         'l2_gather': {'algorithmic_bytes_per_launch': samples * GATHER_BYTES_PER_SAMPLE,
                       'algorithmic_GBs': samples * GATHER_BYTES_PER_SAMPLE / k_s / 1e9,
                       'algorithmic_frac_of_34_5TBs': samples * GATHER_BYTES_PER_SAMPLE / k_s / 1e9 / PEAK_L2_GBS},
-        'note': 'The kernel is bound by vector-instruction issue (PMC: VALU busy ~65 % of SIMD cycles, MFMA pipe ~10 %, L2 hit 98 %, HBM 2.5 % '
+        'note': 'The kernel is bound by vector-instruction issue (PMC: VALU busy ~74 % of SIMD cycles, MFMA pipe ~11 %, L2 hit 98 %, HBM 3 % '
                 'of peak).  frac = issue time of the instructions a perfect schedule of the algorithm needs / measured kernel time; '
                 'measured_issue (below) prices the instructions the kernel actually executes the same way.',
     }
