@@ -94,6 +94,28 @@ def test_gpu_ops_refuse_cpu_tensors():
         gnerf_hip.bias_act(x, None, None, None, None, 0, 1, 1, 0.0, 1.0, -1.0)
     with pytest.raises(RuntimeError):
         gnerf_hip.planes_to_nhwc(torch.zeros(3, 32, 4, 4))
+    with pytest.raises(RuntimeError):
+        gnerf_hip.modconv_epilogue(torch.zeros(1, 8, 4, 4), torch.zeros(8))
+    with pytest.raises(RuntimeError):
+        gnerf_hip.torgb_channels_last(torch.zeros(1, 32, 4, 4, dtype=torch.float16).contiguous(memory_format=torch.channels_last),
+                                      torch.zeros(3, 32), torch.zeros(1, 32))
+
+
+def test_activation_layout_detection():
+    """Host logic that routes activations to the NCHW or the channels_last kernels (gnerf_hip._activation_layout)."""
+    import gnerf_hip
+    x = torch.zeros(2, 8, 4, 6)
+    assert gnerf_hip._activation_layout(x, 't') == 'nchw' and not gnerf_hip.is_channels_last(x)
+    xc = x.contiguous(memory_format=torch.channels_last)
+    assert gnerf_hip._activation_layout(xc, 't') == 'nhwc' and gnerf_hip.is_channels_last(xc)
+    one = torch.zeros(2, 1, 4, 6).contiguous(memory_format=torch.channels_last)          # C == 1: both formats describe the same memory
+    assert gnerf_hip._activation_layout(one, 't') == 'nchw' and not gnerf_hip.is_channels_last(one)
+    with pytest.raises(RuntimeError):
+        gnerf_hip._activation_layout(x[:, :, :, ::2], 't')                                # neither dense format
+    with pytest.raises(RuntimeError):
+        gnerf_hip._activation_layout(torch.zeros(2, 8, 4), 't')
+    with pytest.raises(RuntimeError):
+        gnerf_hip._activation_layout(torch.zeros(2, 8, 4, 6, dtype=torch.float64), 't')
 
 
 # ---------------------------------------------------------------------------- drop-in modules on CPU
