@@ -809,7 +809,7 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
     const int per_xcd = ((P.n_tiles << P.split_shift) + kNumXCD - 1) / kNumXCD;
     const dim3 grid(per_xcd * kNumXCD);
     // Kernel choice (GNERF_RENDER_KERNEL=pipe|coop|generic forces one, for A/B runs):
-    //   pipe    3 shader waves + 1 scalar wave, three rays in flight: up to 48+48 samples with importance sampling
+    //   pipe    3 shader waves + 1 scalar wave, three rays in flight: up to 144+144 samples with importance sampling (1, 2 or 3 tiles per wave)
     //   coop    3 waves per ray, phases separated by barriers: up to 96+96 samples
     //   generic one wave per ray: everything else (up to 256+256)
     // A/B and test overrides, read per call (the parity tests switch kernels inside one process): two getenv walks of the
@@ -817,8 +817,8 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
     const char* force = getenv("GNERF_RENDER_KERNEL");
     const char* force_mlp = getenv("GNERF_RENDER_MLP");                      // f16x3 | f32: overrides params.mlp_mode
     const bool small_planes = int64_t(p->plane_h) * p->plane_w * 3 * 128 < (int64_t(1) << 32);
-    bool pipe = P.tiles_c <= 6 && P.tiles_f >= 1 && P.tiles_f <= 6 && small_planes;
-    const int pipe_tp = (P.tiles_c <= 3 && P.tiles_f <= 3) ? 1 : 2;             // 16-sample tiles per shader wave and pass
+    bool pipe = P.tiles_c <= 9 && P.tiles_f >= 1 && P.tiles_f <= 9 && small_planes;
+    const int pipe_tp = (P.tiles_c <= 3 && P.tiles_f <= 3) ? 1 : ((P.tiles_c <= 6 && P.tiles_f <= 6) ? 2 : 3);   // 16-sample tiles per shader wave and pass
     bool coop = P.tiles_c <= 2 * kCoopWaves && P.tiles_f <= 2 * kCoopWaves && small_planes;
     if (force && !strcmp(force, "generic")) pipe = coop = false;
     if (force && !strcmp(force, "coop")) { pipe = false; if (!coop) return fail(GNERF_E_UNSUPPORTED, "render: cooperative kernel does not cover %d+%d samples", S, F); }
@@ -843,14 +843,22 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         // half-steps of pipeline fill cost less than leaving compute units idle (64x64 rays: 167 -> 70 us)
         int64_t g = (total_seq / kPipeUnit + kNumXCD - 1) / kNumXCD * kNumXCD;
         if (g < kNumXCD) g = kNumXCD;
-        const int per_cu = pipe_tp == 1 ? GNERF_PIPE_WAVES_PER_SIMD : GNERF_PIPE2_WAVES_PER_SIMD;                         // resident workgroups per CU
+        const int per_cu = pipe_tp == 1 ? GNERF_PIPE_WAVES_PER_SIMD : (pipe_tp == 2 ? GNERF_PIPE2_WAVES_PER_SIMD : 2);                         // resident workgroups per CU
         if (g > per_cu * kNumCU) g = per_cu * kNumCU;
         const size_t lds_bytes = pipe_lds_floats(pipe_tp, mlp) * sizeof(float);
         const dim3 gd((unsigned)g), bd(kPipeThreads);
 #define GNERF_PIPE(TP) do { if (mlp == kMlpAuto) hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpAuto>), gd, bd, lds_bytes, s, P); \
                             else if (mlp == kMlpF16x3) hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpF16x3>), gd, bd, lds_bytes, s, P); \
                             else hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpF32>), gd, bd, lds_bytes, s, P); } while (0)
-        if (pipe_tp == 1) GNERF_PIPE(1); else GNERF_PIPE(2);
+        if (pipe_tp == 1) GNERF_PIPE(1);
+        else if (pipe_tp == 2) GNERF_PIPE(2);
+        else {                                              // 65 KB of LDS: above the default dynamic limit
+            static PerDeviceOnce once3[3];
+            if (mlp == kMlpAuto) { if (int e = once3[0].raise_lds(render_kernel_pipe<3, kMlpAuto>, "render")) return e; }
+            else if (mlp == kMlpF16x3) { if (int e = once3[1].raise_lds(render_kernel_pipe<3, kMlpF16x3>, "render")) return e; }
+            else { if (int e = once3[2].raise_lds(render_kernel_pipe<3, kMlpF32>, "render")) return e; }
+            GNERF_PIPE(3);
+        }
 #undef GNERF_PIPE
         if (int e = check_launch("render_kernel_pipe")) return e;
     } else

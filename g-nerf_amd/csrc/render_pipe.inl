@@ -32,7 +32,8 @@
 constexpr int kPipeUnit = GNERF_PIPE_UNIT;      // rays dealt to a workgroup at a time (see render_kernel_pipe)
 constexpr int kPipeThreads = 256;
 constexpr int kPipeSlots = 4;
-// TP = 16-sample tiles per shader wave and pass: 1 covers up to 48+48 samples (the reference's default), 2 up to 96+96
+// TP = 16-sample tiles per shader wave and pass: 1 covers up to 48+48 samples (the reference's default), 2 up to 96+96, 3 up to 144+144
+// (gen_videos.py doubles the ShapeNet configuration's 64+64 to 128+128)
 // (gen_videos.py doubles the counts, gen_videos.py:127-128; the ShapeNet config uses 64+64).
 template <int TP> struct PipeDims {
     static constexpr int kMaxS = 48 * TP;                  // samples per pass
@@ -60,7 +61,7 @@ __device__ __forceinline__ PipeSlot pipe_slot(float* base, int slot) {
 }
 
 __host__ __device__ inline size_t pipe_lds_floats(int tp, int mlp) {
-    const size_t slot_floats = tp == 1 ? PipeDims<1>::kSlotFloats : PipeDims<2>::kSlotFloats;
+    const size_t slot_floats = tp == 1 ? PipeDims<1>::kSlotFloats : (tp == 2 ? PipeDims<2>::kSlotFloats : PipeDims<3>::kSlotFloats);
     return size_t(weight_floats(mlp)) + 64 + 36 + size_t(kPipeSlots) * slot_floats + 3 * 16 * kStagePitch;       // (tap records live in the staging rows)
 }
 
@@ -508,7 +509,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
 }
 
 template <int TP, int MLP>
-__global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD : GNERF_PIPE2_WAVES_PER_SIMD) void render_kernel_pipe(Params P) {
+__global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD : (TP == 2 ? GNERF_PIPE2_WAVES_PER_SIMD : 2)) void render_kernel_pipe(Params P) {
     extern __shared__ __align__(16) float smem[];
     if constexpr (MLP == kMlpAuto) {            // see render_kernel_coop
         if (choose_mlp(P, smem) == kMlpF32) render_pipe_body<TP, kMlpF32>(P, smem);

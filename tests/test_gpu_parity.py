@@ -142,7 +142,11 @@ def _random_scene(seed, N, res, S, F, hw, scale=1.5):
     dict(N=3, res=4, S=64, F=3, hw=(16, 16)),
     dict(N=1, res=4, S=4, F=5, hw=(4, 4)),                  # smallest importance-sampled case (S-3 = 1 pdf bin)
     dict(N=1, res=4, S=2, F=0, hw=(4, 4)),                  # smallest case at all
-    dict(N=1, res=4, S=130, F=100, hw=(8, 8)),              # beyond 96+96: one-wave-per-ray kernel, ragged tiles
+    dict(N=1, res=4, S=130, F=100, hw=(8, 8)),              # beyond 96+96: three-tiles-per-wave pipelined kernel, ragged tiles
+    dict(N=1, res=8, S=128, F=128, hw=(16, 16)),            # gen_videos.py's doubling of the ShapeNet config's 64+64
+    dict(N=1, res=4, S=144, F=144, hw=(8, 8)),              # ... its limit
+    dict(N=1, res=4, S=97, F=1, hw=(8, 8)),                 # ... seven coarse tiles, one fine sample
+    dict(N=1, res=4, S=145, F=20, hw=(8, 8)),               # one sample past it: one-wave-per-ray kernel
     dict(N=1, res=2, S=256, F=256, hw=(8, 8)),              # GNERF_MAX_SAMPLES on both passes
     dict(N=2, res=8, S=64, F=64, hw=(16, 12)),              # ShapeNet config's sample counts (train.py:353-354)
     dict(N=1, res=6, S=50, F=70, hw=(16, 16)),              # two-tiles-per-wave pipelined kernel, ragged on both passes
@@ -167,7 +171,7 @@ def test_render_vs_oracle(dev, cfg):
     np.testing.assert_allclose(wsum.cpu().numpy(), ref_w.numpy(), atol=2e-4)
 
 
-@pytest.mark.parametrize('S,F', [(48, 48), (24, 40), (96, 96)])
+@pytest.mark.parametrize('S,F', [(48, 48), (24, 40), (96, 96), (128, 128)])
 def test_render_tied_fine_depths(dev, S, F):
     """Equal uniform draws give bit-identical fine depths: the merge must still produce a permutation (stable order,
     like torch.sort on the concatenation).  Exercises the tie-repair path of the merge in every kernel."""
@@ -342,7 +346,7 @@ def test_render_decoder_arithmetic_is_range_safe(dev, plane_scale, weight_scale,
         assert choice == 'f32'
 
 
-@pytest.mark.parametrize('S,F', [(48, 48), (96, 96), (40, 0)])
+@pytest.mark.parametrize('S,F', [(48, 48), (96, 96), (128, 128), (40, 0)])
 def test_render_decoder_arithmetic_forced(dev, S, F):
     """Both shipped arithmetics agree with the oracle on an in-range scene when forced, and the forced f16 path shows the
     hazard the default guards against (non-finite output at |planes| ~ 1e5)."""
@@ -1445,7 +1449,7 @@ def test_grid_sample_gradfix_gpu_all_orders(dev):
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-4, atol=2e-5, err_msg=name)
 
 
-@pytest.mark.parametrize('S,F', [(48, 48), (96, 96), (20, 37)])
+@pytest.mark.parametrize('S,F', [(48, 48), (96, 96), (20, 37), (128, 128)])
 def test_render_fine_samples_on_bin_edges(dev, S, F):
     """The merge places a fine sample from the bin it was drawn in (three comparisons with the neighbouring coarse depths).  Draws
     of exactly 0 and of 1 - 2^-24 put fine samples on the first midpoint and at the very end of the last bin, repeated draws put
