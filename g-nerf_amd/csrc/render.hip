@@ -904,7 +904,9 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
     if (lds_bytes > 160 * 1024) return fail(GNERF_E_ARG, "render_backward: %d+%d samples need %zu bytes of LDS (> 160 KiB)", p->depth_resolution, p->depth_resolution_importance, lds_bytes);
     static PerDeviceOnce once;
     if (int e = once.raise_lds(render_bwd_kernel, "render_backward")) return e;
-    const int n_blocks = (P.n_tiles + kBwdWaves - 1) / kBwdWaves;
+    P.split_shift = 0;                                       // up to two workgroups of four waves per CU: share tiles until the chip is full
+    while (P.split_shift < 2 && (int64_t(P.n_tiles) << (P.split_shift + 1)) <= int64_t(kNumCU) * 2 * kBwdWaves) P.split_shift++;
+    const int n_blocks = ((P.n_tiles << P.split_shift) + kBwdWaves - 1) / kBwdWaves;
     const int per_xcd = (n_blocks + kNumXCD - 1) / kNumXCD;
     // Staged scatter (see plane_scatter_kernel): needs the caller's staging buffer, a plane gradient to make, and ray tiles that do
     // not straddle items.  GNERF_BWD_SCATTER=direct|staged forces one route (A/B runs and tests).

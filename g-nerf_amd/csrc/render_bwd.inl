@@ -416,15 +416,20 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gn
     BwdPending pend = {nullptr, 0};
 
     // ray tiles: workgroup `blk` owns tiles 4*blk .. 4*blk+3 (one per wave); XCD-contiguous like the forward kernels
-    const int n_blocks = (P.n_tiles + kBwdWaves - 1) / kBwdWaves;
+    // Small launches (the training shape is 1 024 tiles = one wave per SIMD): a tile's 16 rays are shared by 1 << split_shift waves
+    const int n_groups = P.n_tiles << P.split_shift;
+    const int n_blocks = (n_groups + kBwdWaves - 1) / kBwdWaves;
     const int per_xcd = (n_blocks + kNumXCD - 1) / kNumXCD;
     const int blk = (blockIdx.x % kNumXCD) * per_xcd + blockIdx.x / kNumXCD;
-    const int tile = blk * kBwdWaves + wv;
-    const bool have_tile = blk < n_blocks && tile < P.n_tiles;
+    const int group = blk * kBwdWaves + wv;
+    const int tile = group >> P.split_shift;
+    const bool have_tile = blk < n_blocks && group < n_groups;
+    const int rr_count = kBwdRaysPerWave >> P.split_shift;
+    const int rr_first = (group & ((1 << P.split_shift) - 1)) * rr_count;
     const int64_t plane_floats = int64_t(3) * p.plane_h * p.plane_w * 32;
     const int j = lane & 15;
 
-    for (int rr = 0; have_tile && rr < kBwdRaysPerWave; rr++) {
+    for (int rr = rr_first; have_tile && rr < rr_first + rr_count; rr++) {
         int64_t ray;
         if (P.tiles_per_item > 0) {
             const int item = tile / P.tiles_per_item, tt = tile % P.tiles_per_item;
