@@ -55,7 +55,8 @@ struct Params {
     int n_tiles;            // ray tiles in the grid
     int tiles_per_item, tiles_y;   // image tiling (0 when rays are not an image)
     int total_rays;
-    int split_shift;        // small launches: a 16-ray tile is shared by 1 << split_shift workgroups (coop / generic kernels)
+    int split_shift;        // small launches: a 16-ray tile is shared by 1 << split_shift workgroups (coop / generic / backward kernels)
+    int pipe_unit;          // pipelined kernel: rays dealt to a workgroup at a time (kPipeUnit; fewer for launches that do not fill the chip)
     unsigned tex_pitch, row_pitch, plane_pitch;     // byte addressing of a texel, see plane_taps (render_coop.inl)
     const float* absmax;    // GNERF_MLP_AUTO: max |planes| (one device float) for choose_mlp
 };
@@ -778,6 +779,7 @@ static int fill_params(const gnerf_render_params* p, Params& P) {
     P.tiles_f = (F + 15) / 16;
     P.total_rays = int(total);
     P.split_shift = 0;
+    P.pipe_unit = 8;
     P.absmax = nullptr;
     const int iw = p->image_width;
     if (iw > 0 && iw % 4 == 0 && p->rays_per_item % iw == 0 && (p->rays_per_item / iw) % 4 == 0) {
@@ -839,12 +841,16 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
     }
     if (pipe) {
         const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : total;
-        // one dealing unit (8 rays) per workgroup until the chip is full: a small launch is latency-bound, and the three
-        // half-steps of pipeline fill cost less than leaving compute units idle (64x64 rays: 167 -> 70 us)
-        int64_t g = (total_seq / kPipeUnit + kNumXCD - 1) / kNumXCD * kNumXCD;
-        if (g < kNumXCD) g = kNumXCD;
         const int per_cu = pipe_tp == 1 ? GNERF_PIPE_WAVES_PER_SIMD : (pipe_tp == 2 ? GNERF_PIPE2_WAVES_PER_SIMD : 2);                         // resident workgroups per CU
-        if (g > per_cu * kNumCU) g = per_cu * kNumCU;
+        // one dealing unit per workgroup until the chip is full: a small launch is latency-bound, and the three half-steps of
+        // pipeline fill cost less than leaving compute units idle (64x64 rays: 167 -> 70 us); the unit shrinks from 8 rays down
+        // to what spreads the launch over every resident workgroup slot (a 64x64 frame: 4 rays each on pipe<1>, 6 on pipe<2>)
+        const int64_t capacity = int64_t(per_cu) * kNumCU;
+        P.pipe_unit = kPipeUnit;
+        if (total_seq < capacity * kPipeUnit) P.pipe_unit = int((total_seq + capacity - 1) / capacity);       // >= 1: total_seq >= 1
+        int64_t g = ((total_seq + P.pipe_unit - 1) / P.pipe_unit + kNumXCD - 1) / kNumXCD * kNumXCD;
+        if (g < kNumXCD) g = kNumXCD;
+        if (g > capacity) g = capacity;
         const size_t lds_bytes = pipe_lds_floats(pipe_tp, mlp) * sizeof(float);
         const dim3 gd((unsigned)g), bd(kPipeThreads);
 #define GNERF_PIPE(TP) do { if (mlp == kMlpAuto) hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpAuto>), gd, bd, lds_bytes, s, P); \

@@ -117,11 +117,12 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
     const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : int64_t(P.total_rays);
     const int W = gridDim.x / kNumXCD, xcd = blockIdx.x % kNumXCD, wg = blockIdx.x / kNumXCD;
     const int64_t x0 = total_seq * xcd / kNumXCD, x1 = total_seq * (xcd + 1) / kNumXCD;
-    const int n_units = int((x1 - x0 + kPipeUnit - 1) / kPipeUnit);
+    const int unit = P.pipe_unit;
+    const int n_units = int((x1 - x0 + unit - 1) / unit);
     const int my_units = n_units > wg ? (n_units - wg + W - 1) / W : 0;
-    const int nr = my_units * kPipeUnit;
+    const int nr = my_units * unit;
     auto local_to_ray = [&](int r) -> int {
-        const int64_t seq = x0 + (int64_t(wg) + int64_t(r / kPipeUnit) * W) * kPipeUnit + r % kPipeUnit;
+        const int64_t seq = x0 + (int64_t(wg) + int64_t(r / unit) * W) * unit + r % unit;
         return seq < x1 ? pipe_seq_to_ray(P, seq) : -1;
     };
 
