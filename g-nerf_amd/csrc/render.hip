@@ -909,7 +909,9 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
     const size_t lds_bytes = (kBwdWeightFloats + kBwdWaves * bwd_wave_floats(16 * (P.tiles_c + P.tiles_f))) * sizeof(float);
     if (lds_bytes > 160 * 1024) return fail(GNERF_E_ARG, "render_backward: %d+%d samples need %zu bytes of LDS (> 160 KiB)", p->depth_resolution, p->depth_resolution_importance, lds_bytes);
     static PerDeviceOnce once;
-    if (int e = once.raise_lds(render_bwd_kernel, "render_backward")) return e;
+    static PerDeviceOnce once_staged;
+    if (int e = once.raise_lds(render_bwd_kernel<false>, "render_backward")) return e;
+    if (int e = once_staged.raise_lds(render_bwd_kernel<true>, "render_backward")) return e;
     P.split_shift = 0;                                       // up to two workgroups of four waves per CU: share tiles until the chip is full
     while (P.split_shift < 2 && (int64_t(P.n_tiles) << (P.split_shift + 1)) <= int64_t(kNumCU) * 2 * kBwdWaves) P.split_shift++;
     const int n_blocks = ((P.n_tiles << P.split_shift) + kBwdWaves - 1) / kBwdWaves;
@@ -921,7 +923,8 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
     bool staged = g->scatter_stage != nullptr && g->grad_planes_nhwc != nullptr && tiles_ok;
     if (route && !strcmp(route, "direct")) staged = false;
     if (route && !strcmp(route, "staged") && !staged) return fail(GNERF_E_ARG, "render_backward: the staged scatter needs scatter_stage, a plane gradient and whole tiles per item");
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(per_xcd * kNumXCD), dim3(kBwdThreads), lds_bytes, as_stream(stream), P, *g, staged ? g->scatter_stage : static_cast<float*>(nullptr));
+    if (staged) hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(per_xcd * kNumXCD), dim3(kBwdThreads), lds_bytes, as_stream(stream), P, *g, g->scatter_stage);
+    else        hipLaunchKernelGGL(render_bwd_kernel<false>, dim3(per_xcd * kNumXCD), dim3(kBwdThreads), lds_bytes, as_stream(stream), P, *g, static_cast<float*>(nullptr));
     if (int e = check_launch("render_bwd_kernel")) return e;
     if (staged) {
         static PerDeviceOnce once_scatter;

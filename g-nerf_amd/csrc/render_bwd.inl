@@ -96,7 +96,7 @@ __device__ __forceinline__ void bwd_scatter_chunk(const BwdLds& L, const BwdPend
 // hbuf (free between tiles) because `taps` may still hold the pending scatter's records; with KEEP_TAPS they are
 // written to `taps` once the pending scatter has been issued.
 // `pos(j, px, py, pz)` yields the position of sample j of the tile, already scaled into the planes' [-1,1] frame.
-template <bool KEEP_TAPS, class PosFn>
+template <bool KEEP_TAPS, class PosFn, bool SCATTER = true>
 __device__ __forceinline__ void bwd_gather_tile(const Params& P, const BwdLds& L, const char* planes, PosFn pos, BwdPending& pend, int lane) {
     const int H = P.p.plane_h, W = P.p.plane_w;
     uint4 my_off = make_uint4(0, 0, 0, 0);
@@ -127,7 +127,7 @@ __device__ __forceinline__ void bwd_gather_tile(const Params& P, const BwdLds& L
             const v4f t01 = *reinterpret_cast<const v4f*>(planes + off.y + cq16);
             const v4f t10 = *reinterpret_cast<const v4f*>(planes + off.z + cq16);
             const v4f t11 = *reinterpret_cast<const v4f*>(planes + off.w + cq16);
-            if (pend.live > 0) bwd_scatter_chunk(L, pend, a, pl, lane);
+            if constexpr (SCATTER) { if (pend.live > 0) bwd_scatter_chunk(L, pend, a, pl, lane); }
             acc += t00 * wgt[0] + t01 * wgt[1] + t10 * wgt[2] + t11 * wgt[3];
         }
         *reinterpret_cast<v4f*>(L.stage + js * kStagePitch + (cq16 >> 2)) = acc;
@@ -186,11 +186,12 @@ __device__ __forceinline__ void bwd_mlp_forward(const BwdLds& L, int lane, v4f (
 
 // Forward-only walk of `ntiles` tiles: densities -> sig_e[e0...], q -> q_e[e0...].
 // G[n] = dL/d(colour sum) of channel 16n + (lane & 15), i.e. 2 * grad_rgb.
+template <bool STAGED>
 __device__ __forceinline__ void bwd_forward_tiles(const Params& P, const BwdLds& L, const BwdRay& R, int e0, int count, int ntiles,
                                                   const float (&G)[2], BwdPending& pend, int lane) {
     const int j = lane & 15, g = lane >> 4;
     for (int t = 0; t < ntiles; t++) {
-        bwd_gather_tile<false>(P, L, R.planes, RayTilePos{R, L.t_e + e0, count, t, P.box_scale}, pend, lane);
+        bwd_gather_tile<false, RayTilePos, !STAGED>(P, L, R.planes, RayTilePos{R, L.t_e + e0, count, t, P.box_scale}, pend, lane);
         v4f h[4], o[2];
         float sig;
         bwd_mlp_forward(L, lane, h, o, sig);
@@ -287,11 +288,12 @@ __device__ __forceinline__ void bwd_tile_core(const BwdLds& L, v4f (&h)[4], floa
 
 // `stage_ray`: when not NULL the plane gradient is NOT scattered from here: each sample's dX row (32 floats) is written to
 // stage_ray[rank * 32 ...], rank = the sample's position in the ray's merged depth order, for plane_scatter_kernel below.
+template <bool STAGED>
 __device__ __forceinline__ void bwd_backward_tiles(const Params& P, const BwdLds& L, const BwdRay& R, float* grad_planes_item, float* stage_ray,
                                                    int e0, int count, int ntiles, const float (&G)[2], BwdAcc& A, BwdPending& pend, int lane) {
     const int j = lane & 15, g = lane >> 4;
     for (int t = 0; t < ntiles; t++) {
-        bwd_gather_tile<true>(P, L, R.planes, RayTilePos{R, L.t_e + e0, count, t, P.box_scale}, pend, lane);
+        bwd_gather_tile<!STAGED, RayTilePos, !STAGED>(P, L, R.planes, RayTilePos{R, L.t_e + e0, count, t, P.box_scale}, pend, lane);
 #ifdef GNERF_ABLATE_BWDMLP      // timing-only build: lookup + scatter without the decoder's backward pass (wrong results)
         for (int i = lane; i < 16 * kTPitch; i += 64) L.tbuf[i] = L.stage[i];
         if (grad_planes_item) { pend.base = grad_planes_item; pend.live = min(16, count - 16 * t); }
@@ -316,7 +318,7 @@ __device__ __forceinline__ void bwd_backward_tiles(const Params& P, const BwdLds
             }
         }
         bwd_tile_core(L, h, dsig, A, lane);
-        if (stage_ray) {
+        if constexpr (STAGED) {
             // ---- dX rows to the staging buffer in depth order: two 128-byte rows per store instruction
             const int half = lane >> 5, ch = lane & 31;
             const int live = min(16, count - 16 * t);
@@ -378,6 +380,9 @@ __device__ __forceinline__ void bwd_reduce_decoder_grads(const BwdAcc& A, float*
     if (tid < 33) unsafeAtomicAdd(grad_b2 + tid, red_b2[tid]);
 }
 
+// STAGED: the plane gradient leaves through the staging buffer (`stage` != NULL, a plane gradient is requested): no tap records are
+// kept and no scatter code is compiled in.
+template <bool STAGED>
 __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gnerf_render_grads Gr, float* stage) {
     extern __shared__ __align__(16) float smem[];
     const gnerf_render_params& p = P.p;
@@ -457,13 +462,13 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gn
         for (int k = lane; k < S; k += 64) L.t_e[k] = coarse_depth(P, ray, k);
         for (int k = lane; k < s_pad; k += 64) { L.v_e[k] = 0.f; L.dsig_e[k] = 0.f; L.q_e[k] = 0.f; }
         lds_wave_sync();
-        bwd_forward_tiles(P, L, R, 0, S, P.tiles_c, G, pend, lane);
+        bwd_forward_tiles<STAGED>(P, L, R, 0, S, P.tiles_c, G, pend, lane);
         if (F > 0) {
             float w_sum, wt_sum;
             march(L.t_e, L.sig_e, L.w_s, S, lane, w_sum, wt_sum);
             lds_wave_sync();
             resample_fine(P, ray, L.t_e, L.w_s, L.s_sig, L.trans, L.t_e + fine_e0, nullptr, n_all, lane, [] { lds_wave_sync(); });
-            bwd_forward_tiles(P, L, R, fine_e0, F, P.tiles_f, G, pend, lane);
+            bwd_forward_tiles<STAGED>(P, L, R, fine_e0, F, P.tiles_f, G, pend, lane);
             merge_by_depth(L.t_e, L.sig_e, L.rank_e, L.s_t, L.s_sig, S, F, fine_e0, lane);
         } else {
             for (int k = lane; k < S; k += 64) { L.rank_e[k] = k; L.s_t[k] = L.t_e[k]; L.s_sig[k] = L.sig_e[k]; }
@@ -544,18 +549,20 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gn
 
         // ---- 3. decoder + lookup gradients
         float* stage_ray = nullptr;
-        if (stage && grad_planes_item) {                // staged scatter: per ray n_all depths, then n_all rows of 32 floats
+        if constexpr (STAGED) {                         // staged scatter: per ray n_all depths, then n_all rows of 32 floats
             stage_ray = stage + ray * int64_t(n_all) * 33 + n_all;
             for (int k = lane; k < n_all; k += 64) stage[ray * int64_t(n_all) * 33 + k] = L.s_t[k];
         }
-        bwd_backward_tiles(P, L, R, grad_planes_item, stage_ray, 0, S, P.tiles_c, G, A, pend, lane);
-        if (F > 0) bwd_backward_tiles(P, L, R, grad_planes_item, stage_ray, fine_e0, F, P.tiles_f, G, A, pend, lane);
+        bwd_backward_tiles<STAGED>(P, L, R, grad_planes_item, stage_ray, 0, S, P.tiles_c, G, A, pend, lane);
+        if (F > 0) bwd_backward_tiles<STAGED>(P, L, R, grad_planes_item, stage_ray, fine_e0, F, P.tiles_f, G, A, pend, lane);
     }
-    if (pend.live > 0) {                               // the last tile's scatter has no next lookup to hide in
+    if constexpr (!STAGED) {
+        if (pend.live > 0) {                           // the last tile's scatter has no next lookup to hide in
 #pragma unroll
-        for (int a = 0; a < 2; a++)
+            for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) bwd_scatter_chunk(L, pend, a, pl, lane);
+                for (int pl = 0; pl < 3; pl++) bwd_scatter_chunk(L, pend, a, pl, lane);
+        }
     }
 
     bwd_reduce_decoder_grads(A, smem, Gr.grad_w1, Gr.grad_b1, Gr.grad_w2, Gr.grad_b2, tid, lane, j);
