@@ -70,14 +70,13 @@ __device__ __forceinline__ float ord_decode(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
-// min / max / clamp of values that are known not to be NaN as ONE v_med3_f32.  fminf / fmaxf cost a second instruction per
-// operand of unknown origin here: kernels run in IEEE mode, where the compiler must quieten a possible signalling NaN with a
-// canonicalising v_max x, x, x before the compare -- 16 extra instructions per 16-sample tile in the softplus alone.
-// (min / max are written as the instruction itself: the compiler folds fmed3(a, b, +-inf) back into fmaxf / fminf and re-inserts the
-// canonicalisation -- the ISA of the first version still had its 16 `v_max x, x, x` per tile.  384 -> 368 vector instructions per
-// tile; the kernel time did not move, 0.54 ms either way.)
-__device__ __forceinline__ float max_nn(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float min_nn(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// min / max / clamp of values that are known not to be NaN.  Kernels run in IEEE mode, where fminf / fmaxf on an operand of unknown
+// origin cost a canonicalising `v_max x, x, x` next to the compare (16 per 16-sample tile in the softplus).  clamp_nn is one
+// v_med3_f32.  For min / max two ways around the canonicalisation were tried and measured: fmed3(a, b, +-inf) -- the compiler folds it
+// straight back into fmaxf / fminf -- and the bare instruction as inline assembly -- 16 instructions fewer per tile (384 -> 368) and
+// no change in kernel time (0.54 ms either way, inside the run-to-run spread).  So these are plain fminf / fmaxf.
+__device__ __forceinline__ float max_nn(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float min_nn(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ float clamp_nn(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
 __device__ __forceinline__ float softplus_f(float x) {          // torch softplus, beta 1, threshold 20

@@ -21,7 +21,7 @@ for _ in range(3):
     out = gnerf_hip.render_forward(nhwc, N, dec, o, d, nc, nf, depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=RES, debug=True)
 torch.cuda.synchronize()
 dbg = out[3].cpu().numpy().view(np.uint64).reshape(-1)
-G = 768 if S <= 48 else 512
+G = 1024 if S <= 48 else (768 if S <= 96 else 512)          # resident workgroups of pipe<1> / pipe<2> / pipe<3> (4, 3, 2 per CU)
 st = dbg[:G * 4 * 16].reshape(G, 4, 16).astype(np.float64)
 names = {0: 'slot params', 1: 'tap setup', 2: 'lookups', 3: 'layer1', 4: 'act+layer2', 5: 'step tail', 6: 'barrier(even)', 7: 'barrier(odd)',
          8: 'colour weights (v_e)', 13: 'merge ranks', 14: 'final march', 9: 'outputs', 10: 'colour acc', 11: 'coarse march+importance', 12: 'depth proposals'}
