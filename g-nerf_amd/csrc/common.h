@@ -45,4 +45,59 @@ template <> __device__ __forceinline__ void store_as<__half>(__half* p, int64_t 
 constexpr int kNumCU = 256;   // MI355X
 constexpr int kNumXCD = 8;
 
+// ---- the modulated convolution's epilogue on one vector of adjacent channels (shared by csrc/modconv.hip and the fused
+// blur + epilogue of csrc/upfirdn2d.hip):
+//   t = round_T(x * T(sc) + noise)        (SCALE / NOISE; the fp16 form is one packed half FMA / multiply per pair, see modconv.hip)
+//   y = clamp(act(t + bias) * gain)       (ACT 1 linear, 3 lrelu)
+//   NEXT: round_T(y) * nx                 (nx already rounded to T: the next layer's input scaling folded in)
+template <class T, int VEC> struct alignas(sizeof(T) * VEC) Pk { T v[VEC]; };
+template <class T> __device__ __forceinline__ float round_to(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<__half>(float v) { return __half2float(__float2half(v)); }
+
+template <class T, int VEC, int ACT, bool SCALE, bool NOISE, bool NEXT>
+__device__ __forceinline__ Pk<T, VEC> modconv_epilogue_vec(const Pk<T, VEC>& in, const float (&sc)[VEC], float nz, bool round_noise, const float (&bv)[VEC],
+                                                          const float (&nx)[VEC], float alpha, float gain, float clamp) {
+    float t[VEC];
+    if constexpr (sizeof(T) == 2 && VEC % 2 == 0 && (SCALE || NOISE)) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int k = 0; k < VEC; k += 2) {
+            const h2 xv = {__builtin_bit_cast(_Float16, in.v[k]), __builtin_bit_cast(_Float16, in.v[k + 1])};
+            const h2 s2 = {(_Float16)sc[k], (_Float16)sc[k + 1]};
+            h2 r;
+            if constexpr (NOISE) {
+                if (round_noise || SCALE) {
+                    const h2 n2 = {(_Float16)nz, (_Float16)nz};
+                    r = __builtin_elementwise_fma(xv, s2, n2);
+                } else {
+                    r = (h2){(_Float16)((float)xv[0] + nz), (_Float16)((float)xv[1] + nz)};
+                }
+            } else {
+                r = xv * s2;
+            }
+            t[k] = (float)r[0];
+            t[k + 1] = (float)r[1];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+            float uu = float(load_as<T>(in.v, k));
+            if constexpr (SCALE || NOISE) uu = round_to<T>(fmaf(uu, SCALE ? round_to<T>(sc[k]) : 1.f, NOISE ? ((round_noise || SCALE) ? round_to<T>(nz) : nz) : 0.f));
+            t[k] = uu;
+        }
+    }
+    Pk<T, VEC> out;
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+        const float uu = t[k] + bv[k];
+        float r = uu;
+        if (ACT == 3) r = uu > 0.f ? uu : uu * alpha;          // lrelu
+        r *= gain;
+        if (clamp >= 0.f) r = r > clamp ? clamp : (r < -clamp ? -clamp : r);
+        if constexpr (NEXT) r = round_to<T>(r) * nx[k];
+        store_as<T>(out.v, k, r);
+    }
+    return out;
+}
+
 }  // namespace gnerf

@@ -86,10 +86,6 @@ __global__ __launch_bounds__(kThreads) void normalise_styles_kernel(const float*
     for (int i = threadIdx.x; i < n_in; i += kThreads) out[int64_t(blockIdx.x) * n_in + i] = s[i] / sm;
 }
 
-template <class T, int VEC> struct alignas(sizeof(T) * VEC) Pk { T v[VEC]; };
-
-template <class T> __device__ __forceinline__ float round_to(float v) { return v; }
-template <> __device__ __forceinline__ float round_to<__half>(float v) { return __half2float(__float2half(v)); }
 
 struct EpiArgs {
     const void* x; void* y;
@@ -246,47 +242,7 @@ __global__ __launch_bounds__(kThreads) void modconv_epilogue_nhwc_kernel(EpiNhwc
         for (int u = 0; u < UN; u++) {
             const unsigned pu = pix + u * pix_step;
             if (pu >= pix_end) break;
-            const float nz = nzs[u];
-            float t[VEC];
-            if constexpr (sizeof(T) == 2 && VEC % 2 == 0 && (SCALE || NOISE)) {
-                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                for (int k = 0; k < VEC; k += 2) {
-                    const h2 xv = {__builtin_bit_cast(_Float16, in[u].v[k]), __builtin_bit_cast(_Float16, in[u].v[k + 1])};
-                    const h2 s2 = {(_Float16)sc[k], (_Float16)sc[k + 1]};
-                    h2 r;
-                    if constexpr (NOISE) {
-                        if (a.round_noise || SCALE) {
-                            const h2 n2 = {(_Float16)nz, (_Float16)nz};
-                            r = __builtin_elementwise_fma(xv, s2, n2);
-                        } else {
-                            r = (h2){(_Float16)((float)xv[0] + nz), (_Float16)((float)xv[1] + nz)};
-                        }
-                    } else {
-                        r = xv * s2;
-                    }
-                    t[k] = (float)r[0];
-                    t[k + 1] = (float)r[1];
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < VEC; k++) {
-                    float uu = float(load_as<T>(in[u].v, k));
-                    if constexpr (SCALE || NOISE) uu = round_to<T>(fmaf(uu, SCALE ? round_to<T>(sc[k]) : 1.f, NOISE ? ((a.round_noise || SCALE) ? round_to<T>(nz) : nz) : 0.f));
-                    t[k] = uu;
-                }
-            }
-            P out;
-#pragma unroll
-            for (int k = 0; k < VEC; k++) {
-                const float uu = t[k] + bv[k];
-                float r = uu;
-                if (ACT == 3) r = uu > 0.f ? uu : uu * a.alpha;          // lrelu
-                r *= a.gain;
-                if (a.clamp >= 0.f) r = r > a.clamp ? a.clamp : (r < -a.clamp ? -a.clamp : r);
-                if constexpr (NEXT) r = round_to<T>(r) * nx[k];
-                store_as<T>(out.v, k, r);
-            }
+            const P out = modconv_epilogue_vec<T, VEC, ACT, SCALE, NOISE, NEXT>(in[u], sc, nzs[u], a.round_noise != 0, bv, nx, a.alpha, a.gain, a.clamp);
             *reinterpret_cast<P*>(yn + int64_t(pu) * a.channels) = out;
         }
     }

@@ -529,10 +529,20 @@ int launch_blur4(const UpArgs& a, hipStream_t stream) {
 // r-3+pad .. r+pad, so the lane keeps four output accumulators (fp32) instead of a 4x4 window of inputs; each step loads the
 // four column vectors of one input row (issued one row ahead), converts them once, adds them into the four pending rows and
 // stores the row that is complete.  Input re-read (R+3)/R over the strip boundary, served by the L2 for neighbouring strips.
-template <class T>
-__global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int cv, int strips_y, int rows_per_strip) {
+// EPI: the modulated convolution's epilogue runs on the blurred value before it is stored (the x2-upsampling layers: transposed
+// convolution -> this blur -> demodulation + bias + lrelu + clamp [+ the next layer's input scale]; one pass over the activations
+// instead of two).  The blurred value is rounded to T first, as the separate blur would have stored it, so the result is bit-identical
+// to blur followed by gnerf_modconv_epilogue_nhwc.
+struct BlurEpi {
+    const float* scale;        // [n, c] demodulation coefficients or NULL
+    const void* bias;          // [c] in T or NULL
+    const float* next_scale;   // [n, c] or NULL
+    float alpha, gain, clamp;
+};
+
+template <class T, int EPI>                                 // EPI: 0 none, 1 linear, 3 lrelu
+__global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int cv, int strips_y, int rows_per_strip, BlurEpi ep) {
     constexpr int VEC = 16 / sizeof(T);
-    struct alignas(16) Vec { T v[VEC]; };
     const int64_t per_row = int64_t(a.out_w) * cv;
     int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (t >= per_row * strips_y * a.n) return;
@@ -557,6 +567,13 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int c
     for (int kx = 0; kx < 4; kx++) {
         col_ok[kx] = ix0 + kx >= 0 && ix0 + kx < a.in_w;
         col_off[kx] = int64_t(min(max(ix0 + kx, 0), a.in_w - 1)) * a.xs_w;          // clamped: loads are unconditional, values masked
+    }
+    float e_sc[VEC], e_bv[VEC], e_nx[VEC];                       // this lane's channel vector of the epilogue operands
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+        e_sc[k] = (EPI != 0 && ep.scale) ? ep.scale[int64_t(img) * a.c + c0 + k] : 1.f;
+        e_nx[k] = (EPI != 0 && ep.next_scale) ? round_to<T>(ep.next_scale[int64_t(img) * a.c + c0 + k]) : 1.f;
+        e_bv[k] = (EPI != 0 && ep.bias) ? float(load_as<T>(static_cast<const T*>(ep.bias), c0 + k)) : 0.f;
     }
     const int iy_first = oy0 - a.pady0;
     // fp32 arithmetic on PAIRS of channels (v_pk_fma_f32: the kernel is instruction-bound otherwise -- 128 scalar FMAs + 39 selects
@@ -612,14 +629,20 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int c
                 }
                 const int done = s - 3;                             // output row oy0 + done is complete
                 if (done >= 0) {
-                    Vec out;
+                    Pk<T, VEC> out;
 #pragma unroll
                     for (int k = 0; k < VEC / 2; k++) {
                         const f2 r = acc[(u - 3) & 3][k] * (f2){a.gain, a.gain};
                         store_as<T>(out.v, 2 * k, r[0]);
                         store_as<T>(out.v, 2 * k + 1, r[1]);
                     }
-                    *reinterpret_cast<Vec*>(y + int64_t(oy0 + done) * a.ys_h) = out;
+                    if constexpr (EPI != 0) {
+                        if (ep.scale && ep.next_scale) out = modconv_epilogue_vec<T, VEC, EPI, true, false, true>(out, e_sc, 0.f, false, e_bv, e_nx, ep.alpha, ep.gain, ep.clamp);
+                        else if (ep.scale)             out = modconv_epilogue_vec<T, VEC, EPI, true, false, false>(out, e_sc, 0.f, false, e_bv, e_nx, ep.alpha, ep.gain, ep.clamp);
+                        else if (ep.next_scale)        out = modconv_epilogue_vec<T, VEC, EPI, false, false, true>(out, e_sc, 0.f, false, e_bv, e_nx, ep.alpha, ep.gain, ep.clamp);
+                        else                           out = modconv_epilogue_vec<T, VEC, EPI, false, false, false>(out, e_sc, 0.f, false, e_bv, e_nx, ep.alpha, ep.gain, ep.clamp);
+                    }
+                    *reinterpret_cast<Pk<T, VEC>*>(y + int64_t(oy0 + done) * a.ys_h) = out;
                 }
 #pragma unroll
                 for (int kx = 0; kx < 4; kx++) raw[kx] = nxt[kx];
@@ -629,7 +652,7 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int c
 }
 
 template <class T>
-int launch_blur4_nhwc(const UpArgs& a, hipStream_t stream) {
+int launch_blur4_nhwc(const UpArgs& a, hipStream_t stream, const BlurEpi* ep = nullptr, int act = 0) {
     constexpr int VEC = 16 / sizeof(T);
     const int cv = a.c / VEC;
     const int rows_per_strip = a.out_h > 256 ? 64 : (a.out_h > 64 ? 32 : 16);
@@ -637,7 +660,11 @@ int launch_blur4_nhwc(const UpArgs& a, hipStream_t stream) {
     const int64_t threads = int64_t(a.out_w) * cv * strips_y * a.n;
     const int64_t blocks = (threads + 255) / 256;
     if (blocks > INT32_MAX) return 1;
-    hipLaunchKernelGGL((upfirdn_blur4_nhwc_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream, a, cv, strips_y, rows_per_strip);
+    const dim3 g((unsigned)blocks), b(256);
+    const BlurEpi none = {nullptr, nullptr, nullptr, 0.f, 1.f, -1.f};
+    if (!ep)           hipLaunchKernelGGL((upfirdn_blur4_nhwc_kernel<T, 0>), g, b, 0, stream, a, cv, strips_y, rows_per_strip, none);
+    else if (act == 3) hipLaunchKernelGGL((upfirdn_blur4_nhwc_kernel<T, 3>), g, b, 0, stream, a, cv, strips_y, rows_per_strip, *ep);
+    else               hipLaunchKernelGGL((upfirdn_blur4_nhwc_kernel<T, 1>), g, b, 0, stream, a, cv, strips_y, rows_per_strip, *ep);
     return check_launch("upfirdn2d(blur4, channels_last)") == GNERF_OK ? 0 : -1;
 }
 
@@ -727,4 +754,24 @@ extern "C" int gnerf_upfirdn2d(const void* x, const float* f, void* y, int dtype
         case GNERF_F64: return launch_up<double>(a, s);
         default: return fail(GNERF_E_ARG, "upfirdn2d: unsupported dtype code %d", dtype);
     }
+}
+
+extern "C" int gnerf_blur4_epilogue_nhwc(const void* x, const float* f, void* y, int dtype, int n, int c, int in_h, int in_w, int out_h, int out_w,
+                                         int padx0, int pady0, int flip, float blur_gain,
+                                         const float* scale, const void* bias, int act, float alpha, float gain, float clamp, const float* next_scale,
+                                         gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!x || !f || !y) return fail(GNERF_E_ARG, "blur4_epilogue_nhwc: null pointer argument");
+    if (n < 1 || c < 1 || in_h < 1 || in_w < 1 || out_h < 1 || out_w < 1) return fail(GNERF_E_ARG, "blur4_epilogue_nhwc: empty shape");
+    if (act != 1 && act != 3) return fail(GNERF_E_UNSUPPORTED, "blur4_epilogue_nhwc: only linear and lrelu");
+    if (int64_t(n) * c * out_h * out_w > INT32_MAX || int64_t(n) * c * in_h * in_w > INT32_MAX) return fail(GNERF_E_ARG, "blur4_epilogue_nhwc: tensor is too large");
+    const int es = dtype == GNERF_F16 ? 2 : (dtype == GNERF_F32 ? 4 : 0);
+    if (!es) return fail(GNERF_E_ARG, "blur4_epilogue_nhwc: dtype must be float32 or float16");
+    if (c % (16 / es) != 0 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15))
+        return fail(GNERF_E_UNSUPPORTED, "blur4_epilogue_nhwc: channels must fill 16-byte vectors and the tensors be 16-byte aligned");
+    UpArgs a{x, f, y, n, c, in_h, in_w, int64_t(in_h) * in_w * c, 1, int64_t(in_w) * c, c, 4, 4, 4, 1, out_h, out_w,
+             int64_t(out_h) * out_w * c, 1, int64_t(out_w) * c, c, 1, 1, 1, 1, padx0, pady0, flip ? 1 : 0, blur_gain};
+    const BlurEpi ep{scale, bias, next_scale, alpha, gain, clamp};
+    const int rc = dtype == GNERF_F16 ? launch_blur4_nhwc<__half>(a, as_stream(stream), &ep, act) : launch_blur4_nhwc<float>(a, as_stream(stream), &ep, act);
+    return rc == 0 ? GNERF_OK : (rc < 0 ? GNERF_E_LAUNCH : fail(GNERF_E_ARG, "blur4_epilogue_nhwc: grid too large"));
 }

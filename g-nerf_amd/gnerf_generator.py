@@ -163,20 +163,27 @@ class StyledConv(nn.Module):
         self.noise_strength = nn.Parameter(torch.zeros([]))
         self.bias = nn.Parameter(torch.zeros(c_out))
 
-    def _resampled_conv(self, x, weight, groups, weight_t=None):
+    def _resampled_conv(self, x, weight, groups, weight_t=None, epilogue=None):
         """weight [groups*O, I, 3, 3] (correlation form).  up == 1: 3x3 convolution with padding 1.  up == 2: stride-2
         transposed convolution (kernel as is: the reference un-flips it twice), 2H+1 outputs per axis, then the low-pass
-        filter with gain up^2 and one pixel of padding -> 2H.  weight_t: the [groups*I, O, 3, 3] form, when the caller has it."""
+        filter with gain up^2 and one pixel of padding -> 2H.  weight_t: the [groups*I, O, 3, 3] form, when the caller has it.
+        epilogue: keyword arguments of gnerf_hip.modconv_epilogue (no noise); the call then returns (x, done) and, where the fused
+        blur + epilogue kernel applies (x2 layers on channels_last activations), x already carries the epilogue (done = True)."""
         fmt = torch.channels_last if _is_channels_last(x) else torch.contiguous_format
         if self.up == 1:
-            return F.conv2d(x, weight if fmt == torch.contiguous_format else weight.contiguous(memory_format=fmt), padding=1, groups=groups)
+            x = F.conv2d(x, weight if fmt == torch.contiguous_format else weight.contiguous(memory_format=fmt), padding=1, groups=groups)
+            return (x, False) if epilogue is not None else x
         if weight_t is None:
             o, i = weight.shape[0] // groups, weight.shape[1]
             weight_t = weight.reshape(groups, o, i, 3, 3).transpose(1, 2).reshape(groups * i, o, 3, 3)
             if fmt == torch.channels_last:
                 weight_t = weight_t.contiguous(memory_format=fmt)
         x = F.conv_transpose2d(x, weight_t, stride=2, groups=groups)
-        return upfirdn2d.upfirdn2d(x, self.resample_filter, padding=[1, 1, 1, 1], gain=4)
+        if epilogue is not None and groups == 1 and _is_channels_last(x) and x.shape[1] % 8 == 0:
+            import gnerf_hip                                # blur + epilogue in one pass over the activations (csrc/upfirdn2d.hip)
+            return gnerf_hip.blur_epilogue_channels_last(x, self.resample_filter, [1, 1, 1, 1], blur_gain=4, **epilogue), True
+        x = upfirdn2d.upfirdn2d(x, self.resample_filter, padding=[1, 1, 1, 1], gain=4)
+        return (x, False) if epilogue is not None else x
 
     def forward(self, x, w, noise_mode='random', gain=1.0, fused=True, prescaled=False, next_layer=None, next_w=None):
         """prescaled: x already carries this layer's input scaling (see next_layer).  next_layer / next_w: the StyledConv that
@@ -202,23 +209,34 @@ class StyledConv(nn.Module):
                 _, dco = gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=x.dtype, want_weights=False, want_dcoefs=True)
                 if not prescaled:
                     x = gnerf_hip.scale_channels(x, gnerf_hip.normalise_styles(styles))
-                x = self._resampled_conv(x, _prenormalised_weight(self, x.dtype, cl), 1,
-                                         weight_t=_prenormalised_weight(self, x.dtype, cl, transposed=True) if self.up == 2 else None)
                 nxt = None
-                if next_layer is not None and _is_channels_last(x) and _fast_path(x, next_layer.weight, next_layer.bias, next_layer.noise_strength):
+                if next_layer is not None and cl and _fast_path(x, next_layer.weight, next_layer.bias, next_layer.noise_strength):
                     nxt = gnerf_hip.normalise_styles(next_layer.affine(next_w))
                     folded = True
-                x = gnerf_hip.modconv_epilogue(x, self.bias, scale=dco, noise=noise, round_noise=True, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp,
-                                               next_scale=nxt)
+                epi = dict(bias=self.bias, scale=dco, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp, next_scale=nxt) if noise is None else None
+                out = self._resampled_conv(x, _prenormalised_weight(self, x.dtype, cl), 1,
+                                           weight_t=_prenormalised_weight(self, x.dtype, cl, transposed=True) if self.up == 2 else None, epilogue=epi)
+                x, done = out if epi is not None else (out, False)
+                if not done:
+                    if nxt is not None and not _is_channels_last(x):          # (the convolution gave back another layout: scale separately)
+                        x = gnerf_hip.modconv_epilogue(x, self.bias, scale=dco, noise=noise, round_noise=True, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
+                        x = gnerf_hip.scale_channels(x, nxt)
+                    else:
+                        x = gnerf_hip.modconv_epilogue(x, self.bias, scale=dco, noise=noise, round_noise=True, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp,
+                                                       next_scale=nxt)
                 return (x, folded) if next_layer is not None else x
             # per-sample weights in one launch, already in the order and memory format the convolution takes them
             # ([N,O,I,3,3] for conv2d, [N,I,O,3,3] for conv_transpose2d: re-ordering 38 MB of fp32 weights per up-layer was a
             # strided copy per call)
             wts, _ = gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=x.dtype, transposed=self.up == 2, channels_last=cl)
             wts = wts.reshape(-1, *wts.shape[2:]) if n > 1 else wts[0]
-            x = self._resampled_conv(x.reshape(1, n * c_in, h, wd) if n > 1 else x, None if self.up == 2 else wts, n, weight_t=wts if self.up == 2 else None)
+            epi = dict(bias=self.bias, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp) if (noise is None and n == 1) else None
+            x = self._resampled_conv(x.reshape(1, n * c_in, h, wd) if n > 1 else x, None if self.up == 2 else wts, n, weight_t=wts if self.up == 2 else None,
+                                     epilogue=epi)
+            x, done = x if epi is not None else (x, False)
             x = x.reshape(n, c_out, *x.shape[2:]) if n > 1 else x
-            x = gnerf_hip.modconv_epilogue(x, self.bias, noise=noise, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
+            if not done:
+                x = gnerf_hip.modconv_epilogue(x, self.bias, noise=noise, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
             return (x, folded) if next_layer is not None else x
         if fused:
             wts = _modulated_weights(self.weight, styles, True, x.dtype == torch.float16).to(x.dtype)          # [N,O,I,3,3]

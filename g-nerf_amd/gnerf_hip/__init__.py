@@ -95,6 +95,7 @@ SIGNATURES = {
     'gnerf_scale_channels_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_modconv_epilogue_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p, _c_i, _c_f, _c_f, _c_f, _c_p, _c_p]),
     'gnerf_torgb_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_p]),
+    'gnerf_blur4_epilogue_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_p, _c_p, _c_i, _c_f, _c_f, _c_f, _c_p, _c_p]),
 }
 
 
@@ -597,6 +598,38 @@ def modconv_epilogue(x, bias=None, scale=None, noise=None, round_noise=False, ac
                                                  1 if round_noise else 0, _ptr(b), 3 if act == 'lrelu' else 1, float(alpha), float(gain),
                                                  float(-1 if clamp is None else clamp), _stream(x))
     _check(code, 'gnerf_modconv_epilogue')
+    return y
+
+
+def blur_epilogue_channels_last(x, f, padding, blur_gain=1.0, bias=None, scale=None, act='lrelu', alpha=0.2, gain=1.0, clamp=None, next_scale=None,
+                                flip_filter=False):
+    """upfirdn2d(x, f, padding=padding, gain=blur_gain) with a 4x4 filter, then modconv_epilogue (no noise), in one pass over a
+    channels_last x [N,C,H,W] (float16 / float32, C filling 16-byte vectors).  padding = [x0, x1, y0, y1].  Bit-identical to the
+    two calls.  Returns a channels_last tensor."""
+    _require_cuda(x, f, bias, scale, next_scale)
+    if not is_channels_last(x) or x.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError('blur_epilogue_channels_last: x must be a channels_last float16/float32 tensor')
+    if act not in ('linear', 'lrelu'):
+        raise RuntimeError('blur_epilogue_channels_last: act must be linear or lrelu')
+    n, c, h, w = x.shape
+    f32 = f.detach().to(torch.float32).contiguous()
+    if f32.shape != (4, 4) or c % (16 // x.element_size()) != 0:
+        raise RuntimeError('blur_epilogue_channels_last: a 4x4 filter and whole 16-byte channel vectors are required')
+    px0, px1, py0, py1 = [int(v) for v in padding]
+    oh, ow = h + py0 + py1 - 3, w + px0 + px1 - 3
+    if oh < 1 or ow < 1:
+        raise RuntimeError('blur_epilogue_channels_last: output must be at least 1x1')
+    s32 = None if scale is None else scale.detach().to(torch.float32).contiguous()
+    nx = None if next_scale is None else next_scale.detach().to(torch.float32).contiguous()
+    b = None if bias is None else bias.detach().to(x.dtype).contiguous()
+    if (s32 is not None and s32.numel() != n * c) or (nx is not None and nx.numel() != n * c) or (b is not None and b.numel() != c):
+        raise RuntimeError('blur_epilogue_channels_last: scale / next_scale must have N*C and bias C elements')
+    y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    with _on_device(x.device):
+        code = load().gnerf_blur4_epilogue_nhwc(_ptr(x), _ptr(f32), _ptr(y), _DTYPE_CODE[x.dtype], n, c, h, w, oh, ow, px0, py0, 1 if flip_filter else 0,
+                                                float(blur_gain), _ptr(s32), _ptr(b), 3 if act == 'lrelu' else 1, float(alpha), float(gain),
+                                                float(-1 if clamp is None else clamp), _ptr(nx), _stream(x))
+    _check(code, 'gnerf_blur4_epilogue_nhwc')
     return y
 
 

@@ -109,6 +109,15 @@ int gnerf_scale_channels_nhwc(const void* x, const float* scale, void* y, int dt
 int gnerf_modconv_epilogue_nhwc(const void* x, void* y, int dtype, int n, int pixels, int channels,
                                 const float* scale, const float* noise, int noise_per_item, int round_noise, const void* bias,
                                 int act, float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream);
+/* The 4x4 blur that follows a x2-upsampling transposed convolution (conv2d_resample.py:114-131) and the epilogue above in ONE pass over
+ * channels_last activations: y = epilogue(round_T(blur(x) * blur_gain)), bit-identical to gnerf_upfirdn2d followed by
+ * gnerf_modconv_epilogue_nhwc (no noise term: the layers that add noise run in NCHW float32 here).  x: [n, in_h, in_w, c] dense,
+ * y: [n, out_h, out_w, c] dense, both 16-byte aligned with c filling whole 16-byte vectors; f: float32 [4,4] dense; padx0 / pady0 / flip
+ * as in gnerf_upfirdn2d (up = down = 1); scale / next_scale: float32 [n, c] or NULL; bias: [c] in the activations' dtype or NULL. */
+int gnerf_blur4_epilogue_nhwc(const void* x, const float* f, void* y, int dtype, int n, int c, int in_h, int in_w, int out_h, int out_w,
+                              int padx0, int pady0, int flip, float blur_gain,
+                              const float* scale, const void* bias, int act, float alpha, float gain, float clamp, const float* next_scale,
+                              gnerf_stream_t stream);
 /* ToRGBLayer with three output channels on a channels_last float16 tensor (networks_stylegan2.py:349-367, modulation as in the
  * fused form :89-96): y[n, o, p] = clamp(half(sum_c x[n, p, c] * half(weight[o, c] * styles[n, c])) + bias[o]), products exact, fp32
  * accumulation.  x: float16 [n, pixels, channels] (channels 32, 64, 128, 256 or 512, 16-byte aligned); weight float32 [3, channels];

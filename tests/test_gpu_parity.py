@@ -1554,6 +1554,36 @@ def test_channels_last_forms_equal_nchw_forms(dev, dtype):
         np.testing.assert_allclose(got.float().cpu().numpy(), want.cpu().numpy(), rtol=2e-3 if half else 1e-5, atol=(4e-3 if half else 1e-5) * float(want.abs().max()))
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+def test_blur_epilogue_fused_equals_two_passes(dev, dtype):
+    """gnerf_blur4_epilogue_nhwc against gnerf_upfirdn2d followed by gnerf_modconv_epilogue_nhwc on channels_last activations: bit for
+    bit (the blurred value is rounded to the storage type in between, as the materialised tensor would be)."""
+    import gnerf_hip
+    from torch_utils.ops import upfirdn2d
+    gen = torch.Generator().manual_seed(9)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device=dev)
+    g = torch.randn(4, 4, generator=gen).to(dev)
+    for (n, c, h, w) in [(3, 16, 13, 21), (1, 64, 33, 17), (2, 8, 5, 7), (1, 128, 65, 65)]:
+        x = (torch.randn(n, c, h, w, generator=gen) * 3).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+        sc = (torch.randn(n, c, generator=gen) + 1).to(dev)
+        nx = (torch.randn(n, c, generator=gen) + 1).to(dev)
+        b = torch.randn(c, generator=gen).to(dev)
+        for filt, pad, bg, flip in ((f, [1, 1, 1, 1], 4.0, False), (g, [2, 1, 1, 2], 1.0, True), (f, [0, 0, 0, 0], 1.0, False)):
+            if h + pad[2] + pad[3] < 4 or w + pad[0] + pad[1] < 4:
+                continue
+            blurred = upfirdn2d.upfirdn2d(x, filt, padding=pad, gain=bg, flip_filter=flip)
+            for scale in (None, sc):
+                for nxt in (None, nx):
+                    for act, clamp in (('lrelu', 2.5), ('linear', None)):
+                        kw = dict(bias=b, scale=scale, act=act, gain=1.3, clamp=clamp, next_scale=nxt)
+                        want = gnerf_hip.modconv_epilogue(blurred, **kw)
+                        got = gnerf_hip.blur_epilogue_channels_last(x, filt, pad, blur_gain=bg, flip_filter=flip, **kw)
+                        assert gnerf_hip.is_channels_last(got) and got.shape == want.shape
+                        assert torch.equal(got, want), (n, c, pad, scale is None, nxt is None, act)
+    with pytest.raises(RuntimeError):
+        gnerf_hip.blur_epilogue_channels_last(x.contiguous(), f, [1, 1, 1, 1])
+
+
 def test_torgb_channels_last_vs_composed_ops(dev):
     """gnerf_torgb_nhwc against ToRGBLayer's op chain (networks_stylegan2.py:349-367, fused modulation :89-96): fp16 modulated
     weights, fp32 accumulation, bias, clamp.  The kernel rounds once where the chain rounds the convolution's output and the bias

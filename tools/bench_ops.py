@@ -89,6 +89,10 @@ with torch.no_grad():
         xb = torch.randn(4, 128, 513, 513, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
         ms = timeit(lambda: upfirdn2d.upfirdn2d(xb, f, padding=[1, 1, 1, 1], gain=4))
         report(f'channels_last upfirdn2d blur 4x4 [4,128,513,513]->512 {nm}', ms, (xb.numel() + 4 * 128 * 512 * 512) * es)
+        ms = timeit(lambda: gnerf_hip.blur_epilogue_channels_last(xb, f, [1, 1, 1, 1], blur_gain=4, bias=b, scale=sc, act='lrelu', gain=1.41, clamp=256, next_scale=sc))
+        report(f'channels_last blur 4x4 + epilogue (+ next scale) in one pass [4,128,513,513]->512 {nm}', ms, (xb.numel() + 4 * 128 * 512 * 512) * es)
+        ms = timeit(lambda: gnerf_hip.modconv_epilogue(upfirdn2d.upfirdn2d(xb, f, padding=[1, 1, 1, 1], gain=4), b, scale=sc, act='lrelu', gain=1.41, clamp=256, next_scale=sc))
+        report(f'(the same as two passes) {nm}', ms, (xb.numel() + 3 * 4 * 128 * 512 * 512) * es)
         wrgb, srgb, brgb = torch.randn(3, 128, 1, 1, device=dev), torch.randn(4, 128, device=dev) / 11, torch.randn(3, device=dev)
         ms = timeit(lambda: gnerf_hip.torgb_channels_last(x, wrgb, srgb, brgb, clamp=256))
         report(f'channels_last ToRGB (modulated 1x1 conv to 3 ch + bias + clamp) [4,128,512,512] {nm}', ms, x.numel() * es + 4 * 3 * 512 * 512 * es)
