@@ -483,6 +483,12 @@ def _workspace(device):
     return ws
 
 
+def release_workspaces():
+    """Drop the cached staging buffers of render_backward's two-pass scatter (up to rays x (S+F) x 132 bytes per device and stream:
+    830 MB at BASELINE config 2); the next call allocates afresh.  The small per-stream render workspaces stay."""
+    _stages.clear()
+
+
 # ---------------------------------------------------------------------------- surroundings of the modulated convolution
 
 
