@@ -58,9 +58,14 @@ __device__ __forceinline__ void split_f16x8(const float (&x)[8], unsigned (&hi)[
 }
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ h8 as_h8(u4v v) { return __builtin_bit_cast(h8, v); }
-constexpr int kW1HalfPitch = 40;    // halves per LDS row of W1 hi / lo (32 + pad: conflict-free ds_read_b128)
+// LDS layouts that a lane (j = lane & 15, g = lane >> 4) reads 16 bytes of are kept in FRAGMENT ORDER: the chunk of lane i at
+// 16 i bytes.  Measured with tools/probes/lds_probe.hip: a wave's ds_read_b128 takes 4 LDS cycles only when consecutive lanes read
+// consecutive 16-byte chunks (or all read the same one); every row-per-j layout -- whatever its pitch: 16, 20, 24, 34, 36, 40, 68
+// dwords were tried -- takes 8, and SQ_LDS_BANK_CONFLICT counts the other 4.  The decoder's fragments are stored that way (16 of the 22
+// conflicted reads of a tile); time-neutral at config 2 (A/B on one box: 0.5845 vs 0.5852 ms per step), the LDS unit was ~44 % busy.
+constexpr int kW1FragHalves = 4 * 64 * 8;   // halves of W1 hi (or lo): [m = 4 hidden blocks][lane][8 channels]
 constexpr int kWeightFloatsF32 = 64 * 36 + 33 * 68;
-constexpr int kWeightFloatsF16 = (2 * 64 * kW1HalfPitch + 2 * 2048) / 2 + 64;  // W1 hi+lo, W2 hi+lo (fragment order), density row fp32
+constexpr int kWeightFloatsF16 = (2 * kW1FragHalves + 2 * 2048) / 2 + 64;     // W1 hi+lo, W2 hi+lo (fragment order), density row fp32
 __host__ __device__ constexpr int weight_floats(int mlp) {
     return mlp == kMlpF32 ? kWeightFloatsF32 : (mlp == kMlpF16x3 ? kWeightFloatsF16 : (kWeightFloatsF32 > kWeightFloatsF16 ? kWeightFloatsF32 : kWeightFloatsF16));
 }
@@ -174,9 +179,9 @@ __device__ __forceinline__ void stage_decoder(CoopLds& L, float* base, const gne
     for (int i = tid; i < 64; i += nthreads) L.b1[i] = p.b1[i];
     for (int i = tid; i < 33; i += nthreads) L.b2[i] = p.b2[i];
     } else {
-    _Float16* w1h = reinterpret_cast<_Float16*>(base);                 // [hi|lo][64][kW1HalfPitch]
-    _Float16* w2h = w1h + 2 * 64 * kW1HalfPitch;                       // [hi|lo][n=2][s=2][j=16][g=4][8]
-    L.w2 = base + (2 * 64 * kW1HalfPitch + 2 * 2048) / 2;              // density row W2[0][:] in fp32
+    _Float16* w1h = reinterpret_cast<_Float16*>(base);                 // [hi|lo][m=4][lane = 16 g + j][8]: W1[16 m + j][8 g ..]
+    _Float16* w2h = w1h + 2 * kW1FragHalves;                           // [hi|lo][n=2][s=2][lane = 16 g + j][8]
+    L.w2 = base + (2 * kW1FragHalves + 2 * 2048) / 2;                  // density row W2[0][:] in fp32
     // The activations run on the hardware's base-2 exp/log, so their scale factors are folded into the weights:
     //   layer 1 produces p' = log2(e) p                      (W1, b1 scaled by log2 e)
     //   softplus becomes h' = log2(1 + 2^p') = h / ln 2       (no multiply on either side)
@@ -186,8 +191,10 @@ __device__ __forceinline__ void stage_decoder(CoopLds& L, float* base, const gne
     for (int i = tid; i < 64 * 32; i += nthreads) {
         const float x = p.w1[i] * kLog2e;
         const _Float16 hi = (_Float16)x;
-        w1h[(i >> 5) * kW1HalfPitch + (i & 31)] = hi;
-        w1h[64 * kW1HalfPitch + (i >> 5) * kW1HalfPitch + (i & 31)] = (_Float16)(x - (float)hi);
+        const int r = i >> 5, c = i & 31;
+        const int dst = (((r >> 4) * 4 + (c >> 3)) * 16 + (r & 15)) * 8 + (c & 7);          // block m, lane 16 g + j, element
+        w1h[dst] = hi;
+        w1h[kW1FragHalves + dst] = (_Float16)(x - (float)hi);
     }
     for (int i = tid; i < 2048; i += nthreads) {
         // fragment order of layer 2's B operand: lane (out column j, k-group g) of k-step s holds, at position jj,
@@ -195,8 +202,9 @@ __device__ __forceinline__ void stage_decoder(CoopLds& L, float* base, const gne
         const int jj = i & 7, g = (i >> 3) & 3, j = (i >> 5) & 15, s = (i >> 9) & 1, n = i >> 10;
         const float x = -p.w2[(1 + 16 * n + j) * 64 + 32 * s + 16 * (jj >> 2) + 4 * g + (jj & 3)];
         const _Float16 hi = (_Float16)x;
-        w2h[i] = hi;
-        w2h[2048 + i] = (_Float16)(x - (float)hi);
+        const int dst = (((n * 2 + s) * 4 + g) * 16 + j) * 8 + jj;                           // lane 16 g + j of fragment (n, s)
+        w2h[dst] = hi;
+        w2h[2048 + dst] = (_Float16)(x - (float)hi);
     }
     for (int i = tid; i < 64; i += nthreads) L.w2[i] = p.w2[i] * kLn2;
     for (int i = tid; i < 64; i += nthreads) L.b1[i] = p.b1[i] * kLog2e;
@@ -309,6 +317,8 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     __builtin_amdgcn_sched_barrier(0);
     blend(0, 2, acc0); issue(1, 2);
     __builtin_amdgcn_sched_barrier(0);
+    // (the staging rows stay [sample][kStagePitch]: 2-way conflicts on the writes and on the reads; fragment order for the reads makes
+    //  the writes 8-way -- 8 lanes of a sample land on one bank group -- and was 3 % slower overall)
     *reinterpret_cast<v4f*>(stage + b * kStagePitch + (lane & 7) * 4) = acc0;
     blend(1, 0, acc1); blend(1, 1, acc1); blend(1, 2, acc1);
     *reinterpret_cast<v4f*>(stage + (8 + b) * kStagePitch + (lane & 7) * 4) = acc1;
@@ -398,7 +408,7 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     // Layer 1: H^T block m [16 hidden x 16 samples] = W1 block [16 x 32] . X^T [32 x 16]: ONE k-step (K = 32 channels);
     // A = this lane's 8 weights W1[16m + j][8g..8g+7], B = its 8 staged features (channels 8g..8g+7 of sample j).
     const _Float16* w1h = reinterpret_cast<const _Float16*>(L.w1);
-    const _Float16* w2h = w1h + 2 * 64 * kW1HalfPitch;
+    const _Float16* w2h = w1h + 2 * kW1FragHalves;
     unsigned fh_u[4], fl_u[4];
     split_f16x8(f, fh_u, fl_u);
     const h8 fh = as_h8((u4v){fh_u[0], fh_u[1], fh_u[2], fh_u[3]}), fl = as_h8((u4v){fl_u[0], fl_u[1], fl_u[2], fl_u[3]});
@@ -407,8 +417,8 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         h[m] = *reinterpret_cast<const v4f*>(L.b1 + 16 * m + 4 * g);
-        a_hi[m] = *reinterpret_cast<const h8*>(w1h + (16 * m + j) * kW1HalfPitch + 8 * g);
-        a_lo[m] = *reinterpret_cast<const h8*>(w1h + 64 * kW1HalfPitch + (16 * m + j) * kW1HalfPitch + 8 * g);
+        a_hi[m] = *reinterpret_cast<const h8*>(w1h + (m * 64 + lane) * 8);
+        a_lo[m] = *reinterpret_cast<const h8*>(w1h + kW1FragHalves + (m * 64 + lane) * 8);
     }
 #pragma unroll
     for (int m = 0; m < 4; m++) h[m] = GNERF_MFMA16(a_hi[m], fh, h[m]);
@@ -424,8 +434,8 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     for (int n = 0; n < 2; n++) {
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-            w_hi[n][s] = *reinterpret_cast<const h8*>(w2h + (((n * 2 + s) * 16 + j) * 4 + g) * 8);
-            w_lo[n][s] = *reinterpret_cast<const h8*>(w2h + 2048 + (((n * 2 + s) * 16 + j) * 4 + g) * 8);
+            w_hi[n][s] = *reinterpret_cast<const h8*>(w2h + ((n * 2 + s) * 64 + lane) * 8);
+            w_lo[n][s] = *reinterpret_cast<const h8*>(w2h + 2048 + ((n * 2 + s) * 64 + lane) * 8);
         }
     }
 #ifdef GNERF_STAMPS
