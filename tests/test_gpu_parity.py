@@ -391,7 +391,7 @@ def test_render_interleaved_plane_layout(dev):
     interleaved per texel = channels_last memory of the backbone's [N,96,H,W] output) give bit-identical forward results to the
     [3N,H,W,32] layout on every forward kernel, the same point queries, and the same gradients (laid out like the planes)."""
     import gnerf_hip
-    for S, F in ((48, 48), (96, 96), (40, 0), (130, 100)):                       # pipe<1>, pipe<2>, coop, generic
+    for S, F in ((48, 48), (96, 96), (40, 0), (130, 100), (150, 20)):            # pipe<1>, pipe<2>, coop, pipe<3>, generic
         planes, dec, o, d, nc, nf = _random_scene(17, N=2, res=8, S=S, F=F, hw=(24, 20))
         N = 2
         sep = gnerf_hip.planes_to_nhwc(planes.to(dev))                                           # [6,24,20,32]
