@@ -855,19 +855,24 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         if (g > capacity) g = capacity;
         const size_t lds_bytes = pipe_lds_floats(pipe_tp, mlp) * sizeof(float);
         const dim3 gd((unsigned)g), bd(kPipeThreads);
-#define GNERF_PIPE(TP) do { if (mlp == kMlpAuto) hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpAuto>), gd, bd, lds_bytes, s, P); \
-                            else if (mlp == kMlpF16x3) hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpF16x3>), gd, bd, lds_bytes, s, P); \
-                            else hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpF32>), gd, bd, lds_bytes, s, P); } while (0)
+        // the instantiation with compile-time sample counts (render_pipe_body<.., FULL>) where the call fills the slots exactly
+        bool full = S == 48 * pipe_tp && F == 48 * pipe_tp && !p->disparity_space_sampling && !p->ray_start_per_ray && !p->debug;
+        if (const char* f = getenv("GNERF_PIPE_FULL")) full = full && strcmp(f, "0") != 0;       // A/B runs and the tests' cross-check
+#define GNERF_PIPE2(TP, FULL) do { if (mlp == kMlpAuto) hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpAuto, FULL>), gd, bd, lds_bytes, s, P); \
+                            else if (mlp == kMlpF16x3) hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpF16x3, FULL>), gd, bd, lds_bytes, s, P); \
+                            else hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpF32, FULL>), gd, bd, lds_bytes, s, P); } while (0)
+#define GNERF_PIPE(TP) do { if (full) GNERF_PIPE2(TP, true); else GNERF_PIPE2(TP, false); } while (0)
         if (pipe_tp == 1) GNERF_PIPE(1);
         else if (pipe_tp == 2) GNERF_PIPE(2);
         else {                                              // 65 KB of LDS: above the default dynamic limit
-            static PerDeviceOnce once3[3];
-            if (mlp == kMlpAuto) { if (int e = once3[0].raise_lds(render_kernel_pipe<3, kMlpAuto>, "render")) return e; }
-            else if (mlp == kMlpF16x3) { if (int e = once3[1].raise_lds(render_kernel_pipe<3, kMlpF16x3>, "render")) return e; }
-            else { if (int e = once3[2].raise_lds(render_kernel_pipe<3, kMlpF32>, "render")) return e; }
+            static PerDeviceOnce once3[6];
+            if (mlp == kMlpAuto) { if (int e = full ? once3[0].raise_lds(render_kernel_pipe<3, kMlpAuto, true>, "render") : once3[3].raise_lds(render_kernel_pipe<3, kMlpAuto, false>, "render")) return e; }
+            else if (mlp == kMlpF16x3) { if (int e = full ? once3[1].raise_lds(render_kernel_pipe<3, kMlpF16x3, true>, "render") : once3[4].raise_lds(render_kernel_pipe<3, kMlpF16x3, false>, "render")) return e; }
+            else { if (int e = full ? once3[2].raise_lds(render_kernel_pipe<3, kMlpF32, true>, "render") : once3[5].raise_lds(render_kernel_pipe<3, kMlpF32, false>, "render")) return e; }
             GNERF_PIPE(3);
         }
 #undef GNERF_PIPE
+#undef GNERF_PIPE2
         if (int e = check_launch("render_kernel_pipe")) return e;
     } else
     if (coop) {

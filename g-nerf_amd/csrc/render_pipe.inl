@@ -86,14 +86,22 @@ __device__ __forceinline__ int pipe_seq_to_ray(const Params& P, int64_t seq) {
 #ifndef GNERF_PIPE_WAVES_PER_SIMD
 #define GNERF_PIPE_WAVES_PER_SIMD 4
 #endif
-template <int TP, int MLP>
+// FULL: the call fills the kernel's sample slots exactly (depth_resolution = depth_resolution_importance = 48 TP: the reference's 48+48
+// default, gen_videos.py's doubled 96+96) with plain stratified sampling (no disparity spacing, no per-ray limits) and no stage dump.
+// Sample counts, tile counts and every `k < S` predicate are then compile-time constants; the cold options are not compiled in at
+// all.  Same arithmetic, same results (the tests run both instantiations on the same inputs); what it buys is the scalar wave's
+// instruction count and the scalar-register pressure: the general instantiation spills 227 SGPRs to VGPR lanes and reloads them
+// with v_readlane_b32 all over the scalar wave's loop.
+template <int TP, int MLP, bool FULL>
 __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
     typedef PipeDims<TP> D;
     constexpr int kPipeMaxS = D::kMaxS, kPipeSPad = D::kSPad, kSlotFloats = D::kSlotFloats, RND = D::kRounds;
     const gnerf_render_params& p = P.p;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int S = p.depth_resolution, F = p.depth_resolution_importance;
+    const int S = FULL ? kPipeMaxS : p.depth_resolution, F = FULL ? kPipeMaxS : p.depth_resolution_importance;
+    const int tiles_c = FULL ? 3 * TP : P.tiles_c, tiles_f = FULL ? 3 * TP : P.tiles_f;
+    float* const debug = FULL ? nullptr : GNERF_DBG_PTR(p.debug);
     // fixed slot layout: coarse samples at [0,48), fine samples at [48,96); unused entries hold +inf depths so that the
     // fully unrolled 4-wide key scans below need no bounds checks
     constexpr int fine_e0 = kPipeMaxS, s_pad = kPipeSPad;
@@ -145,7 +153,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
         }
         if (lane < 3) pre_ray = p.ray_origins[ray * 3 + lane];
         else if (lane < 6) pre_ray = p.ray_dirs[ray * 3 + lane - 3];
-        if (p.ray_start_per_ray) { pre_rs = p.ray_start_per_ray[ray]; pre_re = p.ray_end_per_ray[ray]; }
+        if (!FULL && p.ray_start_per_ray) { pre_rs = p.ray_start_per_ray[ray]; pre_re = p.ray_end_per_ray[ray]; }
     };
     auto propose_finish = [&](int r) {          // P(r), second half: depth proposals (renderer.py:169-192) into the slot
         if (r < 0 || r >= nr) return;
@@ -158,12 +166,12 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
         if (k < S) {
             const float u = pre_uc[q];
             float d;
-            if (p.disparity_space_sampling) {
+            if (!FULL && p.disparity_space_sampling) {
                 const float step = 1.0f / float(S - 1);
                 const float lin = (k < S / 2) ? __fmul_rn(step, float(k)) : __fsub_rn(1.0f, __fmul_rn(step, float(S - 1 - k)));
                 const float q = __fadd_rn(lin, __fmul_rn(u, P.disp_delta));
                 d = __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(P.inv_start, __fsub_rn(1.0f, q)), __fmul_rn(P.inv_end, q)));
-            } else if (p.ray_start_per_ray) {
+            } else if (!FULL && p.ray_start_per_ray) {
                 const float span = __fsub_rn(pre_re, pre_rs);
                 const float lin = __fadd_rn(pre_rs, __fmul_rn(__fdiv_rn(float(k), float(S - 1)), span));
                 d = __fadd_rn(lin, __fmul_rn(u, __fdiv_rn(span, float(S - 1))));
@@ -174,7 +182,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
                 d = __fadd_rn(lin, __fmul_rn(u, P.delta));
             }
             sl.t_e[k] = d;
-            if (GNERF_DBG_PTR(p.debug)) p.debug[(int64_t(pre_ray_id) * GNERF_DEBUG_SLOTS + GNERF_DBG_DEPTH_COARSE) * n_all + k] = d;
+            if (debug) debug[(int64_t(pre_ray_id) * GNERF_DEBUG_SLOTS + GNERF_DBG_DEPTH_COARSE) * n_all + k] = d;
         }
         }
 #pragma unroll
@@ -192,7 +200,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
         PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
         const int ray_id = __float_as_int(sl.misc[7]);
         if (ray_id < 0) return;
-        float* dbg = GNERF_DBG_PTR(p.debug ? p.debug + int64_t(ray_id) * GNERF_DEBUG_SLOTS * n_all : nullptr);
+        float* dbg = debug ? debug + int64_t(ray_id) * GNERF_DEBUG_SLOTS * n_all : nullptr;
         float ws, wts;
         march(sl.t_e, sl.sig_e, sl.w_s, S, lane, ws, wts);
         lds_wave_sync();
@@ -258,7 +266,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
         PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
         const int ray_id = __float_as_int(sl.misc[7]);
         if (ray_id < 0) return;
-        float* dbg = GNERF_DBG_PTR(p.debug ? p.debug + int64_t(ray_id) * GNERF_DEBUG_SLOTS * n_all : nullptr);
+        float* dbg = debug ? debug + int64_t(ray_id) * GNERF_DEBUG_SLOTS * n_all : nullptr;
         // Stable rank in cat([coarse, fine]).  Coarse depths ascend by construction, so
         //   rank(coarse k) = k + #{fine < t_k}            rank(fine i) = #{coarse <= t_i} + #{fine before i}
         // (ties: coarse first, then lower index -- what a stable sort of the concatenation gives).
@@ -410,9 +418,9 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
 #pragma unroll
         for (int i = 0; i < TP; i++) {
             const int tile = wv + 3 * i;
-            if (TP > 1 && tile >= (fine ? P.tiles_f : P.tiles_c)) continue;       // wave-uniform: this wave has no such tile
-            if (!fine) coop_shade_tile<false, MLP>(P, L, R, sl.t_e, S, tile, tile < P.tiles_c, sl.sig_e, lane, wv, col[i], st);
-            else       coop_shade_tile<false, MLP>(P, L, R, sl.t_e + fine_e0, F, tile, tile < P.tiles_f, sl.sig_e + fine_e0, lane, wv, col[i], st);
+            if (TP > 1 && tile >= (fine ? tiles_f : tiles_c)) continue;       // wave-uniform: this wave has no such tile
+            if (!fine) coop_shade_tile<false, MLP>(P, L, R, sl.t_e, S, tile, tile < tiles_c, sl.sig_e, lane, wv, col[i], st);
+            else       coop_shade_tile<false, MLP>(P, L, R, sl.t_e + fine_e0, F, tile, tile < tiles_f, sl.sig_e + fine_e0, lane, wv, col[i], st);
         }
     };
     auto accumulate = [&](int r, const v4f (&cc)[TP][2], const v4f (&cf)[TP][2]) {
@@ -424,12 +432,12 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
 #pragma unroll
         for (int i = 0; i < TP; i++) {
             const int tile = wv + 3 * i;
-            if (tile < P.tiles_c) {
+            if (tile < tiles_c) {
                 const v4f v = *reinterpret_cast<const v4f*>(sl.v_e + 16 * tile + 4 * g);
 #pragma unroll
                 for (int n = 0; n < 2; n++) acc[n] += v[0] * cc[i][n][0] + v[1] * cc[i][n][1] + v[2] * cc[i][n][2] + v[3] * cc[i][n][3];
             }
-            if (tile < P.tiles_f) {
+            if (tile < tiles_f) {
                 const v4f v = *reinterpret_cast<const v4f*>(sl.v_e + fine_e0 + 16 * tile + 4 * g);
 #pragma unroll
                 for (int n = 0; n < 2; n++) acc[n] += v[0] * cf[i][n][0] + v[1] * cf[i][n][1] + v[2] * cf[i][n][2] + v[3] * cf[i][n][3];
@@ -509,13 +517,13 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
     if (wv == 3 && lane == 0) publish_depth_range(P, blk_min, blk_max);
 }
 
-template <int TP, int MLP>
+template <int TP, int MLP, bool FULL>
 __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD : (TP == 2 ? GNERF_PIPE2_WAVES_PER_SIMD : 2)) void render_kernel_pipe(Params P) {
     extern __shared__ __align__(16) float smem[];
     if constexpr (MLP == kMlpAuto) {            // see render_kernel_coop
-        if (choose_mlp(P, smem) == kMlpF32) render_pipe_body<TP, kMlpF32>(P, smem);
-        else                               render_pipe_body<TP, kMlpF16x3>(P, smem);
+        if (choose_mlp(P, smem) == kMlpF32) render_pipe_body<TP, kMlpF32, FULL>(P, smem);
+        else                               render_pipe_body<TP, kMlpF16x3, FULL>(P, smem);
     } else {
-        render_pipe_body<TP, MLP>(P, smem);
+        render_pipe_body<TP, MLP, FULL>(P, smem);
     }
 }

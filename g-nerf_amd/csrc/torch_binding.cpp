@@ -267,5 +267,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("filtered_lrelu", &filtered_lrelu);
     m.def("filtered_lrelu_act_", &filtered_lrelu_act_);
     m.def("render_forward", &render_forward);
-    m.def("abi_version", []() { return gnerf_abi_version(); });
+    // the header version THIS extension was compiled against (a compile-time constant: gnerf_abi_version() would resolve in
+    // libgnerf_hip.so at run time and compare the library with itself); gnerf_hip.ext() checks both against its own
+    m.def("abi_version", []() { return int(GNERF_ABI_VERSION); });
+    m.def("library_abi_version", []() { return gnerf_abi_version(); });
 }

@@ -773,5 +773,6 @@ extern "C" int gnerf_blur4_epilogue_nhwc(const void* x, const float* f, void* y,
              int64_t(out_h) * out_w * c, 1, int64_t(out_w) * c, c, 1, 1, 1, 1, padx0, pady0, flip ? 1 : 0, blur_gain};
     const BlurEpi ep{scale, bias, next_scale, alpha, gain, clamp};
     const int rc = dtype == GNERF_F16 ? launch_blur4_nhwc<__half>(a, as_stream(stream), &ep, act) : launch_blur4_nhwc<float>(a, as_stream(stream), &ep, act);
+    // rc < 0: launch_blur4_nhwc's check_launch() has already put "upfirdn2d(blur4, channels_last): <hip error>" into gnerf_last_error()
     return rc == 0 ? GNERF_OK : (rc < 0 ? GNERF_E_LAUNCH : fail(GNERF_E_ARG, "blur4_epilogue_nhwc: grid too large"));
 }

@@ -148,8 +148,11 @@ def ext():
             spec = importlib.util.spec_from_file_location('gnerf_torch_ext', EXT_PATH)
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
-            if mod.abi_version() != ABI_VERSION:
-                raise RuntimeError(f'gnerf_torch_ext.so was built against ABI {mod.abi_version()} != {ABI_VERSION}: rebuild (csrc/build.sh)')
+            # abi_version() is the header version compiled INTO the extension (its struct layouts); load() has already held the
+            # library to ABI_VERSION, and library_abi_version() is what the extension's own link resolved to
+            if mod.abi_version() != ABI_VERSION or mod.library_abi_version() != ABI_VERSION:
+                raise RuntimeError(f'gnerf_torch_ext.so was built against ABI {mod.abi_version()} (library it links: '
+                                   f'{mod.library_abi_version()}) != {ABI_VERSION}: rebuild (csrc/build.sh)')
             _ext = mod
     return _ext or None
 
@@ -470,7 +473,6 @@ def make_rays(cam2world, intrinsics, resolution):
 
 
 _workspaces = {}
-_stages = {}
 _EMPTY = torch.empty([0])          # "absent tensor" for the C++ binding, as the reference's _null_tensor (bias_act.py:38)
 
 
@@ -484,9 +486,8 @@ def _workspace(device):
 
 
 def release_workspaces():
-    """Drop the cached staging buffers of render_backward's two-pass scatter (up to rays x (S+F) x 132 bytes per device and stream:
-    830 MB at BASELINE config 2); the next call allocates afresh.  The small per-stream render workspaces stay."""
-    _stages.clear()
+    """Kept for callers of earlier versions: render_backward's staging buffer is allocated per call now (torch's caching
+    allocator owns it), so there is nothing cached to drop.  The small per-stream render workspaces stay."""
 
 
 # ---------------------------------------------------------------------------- surroundings of the modulated convolution
@@ -862,16 +863,15 @@ def render_backward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_
     g.grad_planes_nhwc = None if g_planes is None else g_planes.data_ptr()
     stage = None
     if g_planes is not None and staged_scatter:
-        # staging buffer of the two-pass scatter: S+F rows of 33 floats per ray (830 MB at BASELINE config 2), kept per (device, stream)
+        # Staging buffer of the two-pass scatter (gnerf_render_backward_stage_bytes: bounded, the passes run over batches of ray
+        # tiles).  Allocated per call on the current stream: torch's caching allocator hands the block back to the rest of the
+        # step afterwards (a buffer cached here would be invisible to it).  Out of memory -> the single-pass form, same result.
         nbytes = int(load().gnerf_render_backward_stage_bytes(ctypes.byref(p)))
-        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-        stage = _stages.get(key)
-        if stage is None or stage.numel() < nbytes:
-            stage = None
-            _stages.pop(key, None)
+        try:
             stage = torch.empty([nbytes], dtype=torch.uint8, device=dev)
-            _stages[key] = stage
-        g.scatter_stage = stage.data_ptr()
+            g.scatter_stage = stage.data_ptr()
+        except torch.OutOfMemoryError:
+            stage = None
     with _on_device(dev):
         code = load().gnerf_render_backward(ctypes.byref(p), ctypes.byref(g), _stream(planes_nhwc))
     _check(code, 'gnerf_render_backward')

@@ -224,7 +224,10 @@ class _UpsampleAddChannelsLast(torch.autograd.Function):
     def forward(ctx, img, y, f, flip_filter, gain):
         import gnerf_hip
         out, amax = gnerf_hip.upsample2x_add_nhwc(img, y, f, flip=flip_filter, gain=gain, with_absmax=True)
-        out._gnerf_absmax = (out._version, amax)              # max |out|, for the renderer's decoder-arithmetic choice
+        # max |out|, for the renderer's decoder-arithmetic choice.  Inference tensors (torch.inference_mode) have no version
+        # counter to validate the tag against: they go untagged and the render launcher measures max |planes| itself.
+        if not out.is_inference():
+            out._gnerf_absmax = (out._version, amax)
         ctx.save_for_backward(f)
         ctx.has_y = y is not None
         ctx.cfg_t = _transposed(_Config(2, 2, 1, 1, 2, 1, 2, 1, flip_filter, gain), f, img.shape[2:], out.shape[2:])

@@ -296,6 +296,19 @@ def test_render_full_size_properties(dev):
     ref_rgb, ref_depth, ref_w = R.render(planes, dec, o[:, idx], d[:, idx], opts, nc[:, idx], sub_nf)
     assert float(((rgb.cpu()[:, idx] - ref_rgb) ** 2).mean()) < 1e-8
     np.testing.assert_allclose(wsum.cpu()[:, idx].numpy(), ref_w.numpy(), atol=2e-4)
+    # bench.py's producer-layout step at its own size: the interleaved [4,256,256,96] planes (channels_last memory of the
+    # backbone's [N,96,H,W] output) with a caller-supplied max |planes|, and the NCHW-input step (repack + absmax inside the
+    # step), must both give the [12,256,256,32] result bit for bit -- and therefore pass the oracle check above
+    inter = pl.reshape(N, 96, 256, 256).permute(0, 2, 3, 1).contiguous()
+    assert inter.shape == (4, 256, 256, 96)
+    amax = gnerf_hip.planes_absmax(inter)
+    assert float(amax) == float(pl.abs().max())
+    c = gnerf_hip.render_forward(inter, N, de, od, dd, ncd, nfd, image_width=res, planes_absmax=amax, **kw)
+    nhwc2, amax2 = gnerf_hip.planes_to_nhwc(pl, with_absmax=True)
+    e = gnerf_hip.render_forward(nhwc2, N, de, od, dd, ncd, nfd, image_width=res, planes_absmax=amax2, **kw)
+    assert float(amax2) == float(amax) and gnerf_hip.last_mlp_choice(dev) == 'f16x3'
+    for x, y, z in zip(a, c, e):
+        assert torch.equal(x, y) and torch.equal(x, z)
 
 
 def _scaled_scene(plane_scale, weight_scale, S, F, res=8):
@@ -1175,6 +1188,26 @@ def test_generator_fast_modconv_path_equals_plain_path(dev, monkeypatch):
             for k in ('image', 'image_raw', 'image_depth'):
                 mse = float(((outs[0][k] - outs[1][k]) ** 2).mean())
                 assert mse < (1e-5 if k != 'image_depth' else 1e-6), (nb, k, mse)
+
+
+def test_generator_synthesis_under_inference_mode(dev):
+    """G.synthesis under torch.inference_mode(): the channels_last plane producer's output is an inference tensor there (no
+    version counter -> it goes untagged and the render launcher measures max |planes| itself), and the result must be the
+    torch.no_grad() one bit for bit (same kernels, same uniform draws)."""
+    import gnerf_generator as GG
+    import gnerf_harness as H
+    torch.manual_seed(2)
+    G = GG.Generator().eval().requires_grad_(False).to(dev)
+    z = torch.randn(2, 512, device=dev)
+    c = torch.cat([H.camera_label(H.orbit_pose(7 + 11 * i, 120)) for i in range(2)]).to(dev)
+    outs = []
+    for ctx in (torch.no_grad, torch.inference_mode):
+        with ctx():
+            torch.manual_seed(5)
+            outs.append(G.synthesis(G.mapping(z, c), c, noise_mode='const', neural_rendering_resolution=64))
+    assert outs[1]['image'].is_inference() and not outs[0]['image'].is_inference()
+    for k in ('image', 'image_raw', 'image_depth'):
+        assert torch.equal(outs[0][k], outs[1][k].clone()), k
 
 
 # ---- the whole generator around the hot path (callers in PyTorch/MIOpen, renderer + ops native) ----------------------

@@ -6,7 +6,7 @@ import collections, glob, json, os, sqlite3, sys
 d, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, 'profiles')
-KERNEL = 'render_kernel_pipe<1, 0>'        # TP = 1, MLP = auto: what the headline step launches (it runs the f16x3 body at config 2)
+KERNEL = 'render_kernel_pipe<1, 0'         # TP = 1, MLP = auto: what the headline step launches (it runs the f16x3 body at config 2)
 
 
 def db(name):

@@ -21,7 +21,7 @@ else:
 ms = None
 with open(os.path.join(root, 'profiles', f'{tag}_kernel_stats.csv')) as fh:
     for row in csv.DictReader(fh):
-        if 'render_kernel_pipe<1, 0>' in row['Name'] and int(row['Calls']) > 0:          # the auto-arithmetic kernel of the headline step
+        if 'render_kernel_pipe<1, 0' in row['Name'] and int(row['Calls']) > 0:          # the auto-arithmetic kernel of the headline step
             ms = float(row['AverageUs']) / 1e3
 traffic = json.load(open(os.path.join(root, 'profiles', 'traffic.json'))).get('render_kernel_hbm_bytes_per_launch')
 out = bench.roofline(ms, bench.N_ITEMS * bench.RES * bench.RES, bench.S_COARSE, bench.S_FINE, bench.PLANE, bench.N_ITEMS, pmc, src, traffic)
