@@ -35,26 +35,33 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 constexpr float kLog2e = 1.44269504088896341f, kLn2 = 0.693147180559945309f;
 
 // hi/lo f16 split of eight fp32 values into two MFMA operands: hi = f16(x), lo = f16(x - hi), packed in order.
-// Twelve instructions (v_cvt_pk_f16_f32 per pair; v_fma_mixlo/hi_f16 take the f16 half and the fp32 value in one fused
-// operation and write one half of the destination) where the compiler's lowering of the same expression is thirty-two.
+// Sixteen instructions, none of them quarter-rate: v_cvt_pk_f16_f32 per pair for hi, v_fma_mix_f32 (f16 half x -1 + fp32 value, one fused
+// fp32 operation) per value for x - hi, v_cvt_pk_f16_f32 per pair for lo.  The first version formed lo directly with v_fma_mixlo/hi_f16
+// (twelve instructions), but tools/probes/valu_issue_probe measures those at 8.6 SIMD cycles apiece against 4.4 for v_fma_mix_f32 and
+// 4.25 for the conversion: 86 -> 69 cycles per split (the compiler's own lowering of the expression is thirty-two instructions).
 // ONE asm block, ending in s_nop 1: the consumers are MFMAs, which need two wait states after a VALU write of an operand,
 // and the compiler's hazard recogniser does not look inside inline asm.
 __device__ __forceinline__ void split_f16x8(const float (&x)[8], unsigned (&hi)[4], unsigned (&lo)[4]) {
+    float y0 = x[0], y1 = x[1], y2 = x[2], y3 = x[3], y4 = x[4], y5 = x[5], y6 = x[6], y7 = x[7];       // x - hi is formed in place
     asm("v_cvt_pk_f16_f32 %0, %8, %9\n\t"
         "v_cvt_pk_f16_f32 %1, %10, %11\n\t"
         "v_cvt_pk_f16_f32 %2, %12, %13\n\t"
         "v_cvt_pk_f16_f32 %3, %14, %15\n\t"
-        "v_fma_mixlo_f16 %4, %0, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %5, %1, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %6, %2, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %7, %3, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %4, %0, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %5, %1, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %6, %2, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %7, %3, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %8, %0, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %9, %0, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %10, %1, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %11, %1, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %12, %2, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %13, %2, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %14, %3, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %15, %3, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_f16_f32 %4, %8, %9\n\t"
+        "v_cvt_pk_f16_f32 %5, %10, %11\n\t"
+        "v_cvt_pk_f16_f32 %6, %12, %13\n\t"
+        "v_cvt_pk_f16_f32 %7, %14, %15\n\t"
         "s_nop 1"
-        : "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3])
-        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+        : "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]),
+          "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7));
 }
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ h8 as_h8(u4v v) { return __builtin_bit_cast(h8, v); }
@@ -302,6 +309,11 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     // NOTE: the obvious cheaper form -- one fused multiply-add per tap chained through all 12 taps -- is NOT used: with
     // hipcc 7.2's code for it (v_pk_fma_f32 chains) lanes 48-63 of ~3 % of the rays differed from run to run, while the same
     // chain written with scalar v_fmac_f32 was bit-stable (tools/determinism.py; no wait state or s_waitcnt changed that).
+    // (Round 3: the same sum written with inline-asm v_pk_mul / v_pk_fma_f32 whose op_sel bits broadcast one weight of a register pair
+    // -- to save the copies the compiler makes to build (w, w) pairs -- reproduced that run-to-run difference: ~1 % of the samples got
+    // a wrong feature, on rays of the second half of each item only, although the four-instruction chain is bit-exact in isolation
+    // (tools/probes/scratch/pk_test.hip) and its destination was kept off its sources.  It also removed no instruction: the tile's
+    // v_mov_b32 are accumulator initialisations and permlane copies.  The compiler's form stays.)
     auto blend = [&](int a, int pl, v4f& acc) {
         const v4f sum = tex[a][pl][0] * wgt[a][pl][0] + tex[a][pl][1] * wgt[a][pl][1] + tex[a][pl][2] * wgt[a][pl][2] + tex[a][pl][3] * wgt[a][pl][3];
         if (pl == 0) acc = sum; else acc += sum;
@@ -446,14 +458,18 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     v4f hv[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) {
-        // h' = log2(1 + 2^p'); beyond p' = 126 the sum overflows and h' = p' takes over (it is exact from p' = 25 on)
+        // h' = log2(1 + 2^p') = max(p', 0) + l with l = log2(1 + 2^-|p'|) = max(p' + l, l): no overflow for any p' (so no clamp in
+        // front of the exp2), and both operands of the max are arithmetic results (no canonicalising v_max in IEEE mode).  Per value:
+        // v_exp_f32 (-|p'| as source modifiers), v_add_f32, v_log_f32, v_add_f32, v_max_f32 = 2 quarter-rate + 2 full-rate + 1
+        // half-rate instruction (tools/probes/valu_issue_probe: 8.4 + 2.3 + 8.3 + 2.3 + 4.5 SIMD cycles) where
+        // min / [canonicalise] / exp2 / add / log2 / max was 2 quarter-rate + 1 full-rate + 3 half-rate.
         v4f e;
 #pragma unroll
-        for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(min_nn(h[m][r], 126.f));
+        for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(-fabsf(h[m][r]));
 #pragma unroll
         for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_logf(1.0f + e[r]);
 #pragma unroll
-        for (int r = 0; r < 4; r++) hv[m][r] = act_softplus(max_nn(e[r], h[m][r]), h[m][r]);
+        for (int r = 0; r < 4; r++) hv[m][r] = act_softplus(fmaxf(h[m][r] + e[r], e[r]), h[m][r]);
         const v4f ws = *reinterpret_cast<const v4f*>(L.w2 + 16 * m + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; r++) sig = fmaf(ws[r], hv[m][r], sig);

@@ -65,6 +65,33 @@
 #define I_READLANE(n) "v_readlane_b32 s30, v" #n ", 3\n\t"
 #define I_READFIRST(n) "v_readfirstlane_b32 s30, v" #n "\n\t"
 #define I_MULLO(n) "v_mul_lo_u32 v" #n ", v" #n ", v42\n\t"
+#define I_DOT2(n)  "v_dot2_f32_f16 v" #n ", v42, v43, v" #n "\n\t"
+#define I_CVTF16(n) "v_cvt_f32_f16 v" #n ", v" #n "\n\t"
+#define I_FMAMIX32(n) "v_fma_mix_f32 v" #n ", v" #n ", v42, v43 op_sel_hi:[1,0,0]\n\t"
+#define I_PKFMA16(n) "v_pk_fma_f16 v" #n ", v" #n ", v42, v43\n\t"
+#define I_SUBU(n)  "v_sub_u32 v" #n ", v" #n ", v42\n\t"
+#define I_OR(n)    "v_or_b32 v" #n ", v" #n ", v42\n\t"
+#define I_XOR(n)   "v_xor_b32 v" #n ", v" #n ", v42\n\t"
+#define I_ADD3(n)  "v_add3_u32 v" #n ", v" #n ", v42, v43\n\t"
+#define I_LSHLOR(n) "v_lshl_or_b32 v" #n ", v" #n ", 2, v42\n\t"
+#define I_BFE(n)   "v_bfe_u32 v" #n ", v" #n ", 3, 5\n\t"
+#define I_CVTFI(n) "v_cvt_f32_i32 v" #n ", v" #n "\n\t"
+#define I_CVTUF(n) "v_cvt_u32_f32 v" #n ", v" #n "\n\t"
+#define I_LDEXP(n) "v_ldexp_f32 v" #n ", v" #n ", v42\n\t"
+#define I_FRACT(n) "v_fract_f32 v" #n ", v" #n "\n\t"
+#define I_CMPI(n)  "v_cmp_lt_i32 vcc, v" #n ", v42\n\t"
+#define I_PERMB(n) "v_perm_b32 v" #n ", v" #n ", v42, v43\n\t"
+#define I_ALIGN(n) "v_alignbit_b32 v" #n ", v" #n ", v42, 16\n\t"
+#define I_MADI24(n) "v_mad_i32_i24 v" #n ", v" #n ", v42, v43\n\t"
+#define I_ASHR(n)  "v_ashrrev_i32 v" #n ", 3, v" #n "\n\t"
+#define I_LSHR(n)  "v_lshrrev_b32 v" #n ", 3, v" #n "\n\t"
+#define I_ADDNEG(n) "v_add_f32_e64 v" #n ", -|v" #n "|, v42\n\t"
+#define I_MIN3(n)  "v_min3_f32 v" #n ", v" #n ", v42, v43\n\t"
+#define I_FMAK(n)  "v_fma_f32 v" #n ", v" #n ", 0.5, v43\n\t"
+#define I_MADAK(n) "v_fmaak_f32 v" #n ", v" #n ", v42, 0x3f9d70a4\n\t"
+#define I_SUBREV(n) "v_subrev_f32 v" #n ", v42, v" #n "\n\t"
+#define I_EXPMOD(n) "v_exp_f32_e64 v" #n ", -|v" #n "|\n\t"
+#define I_WRITELANE(n) "v_writelane_b32 v" #n ", s20, 3\n\t"
 #define I_PERM16(a, b) "v_permlane16_swap_b32 v" #a ", v" #b "\n\t"
 #define I_PKMUL(a, b) "v_pk_mul_f32 v[" #a ":" #b "], v[" #a ":" #b "], v[42:43]\n\t"
 // packed: 16 register pairs
@@ -134,6 +161,12 @@ static const Stream kStreams[] = {
     {"v_log_f32", 32, ""}, {"v_rcp_f32", 32, ""}, {"v_fma_mixlo_f16", 32, ""}, {"v_add_f32_dpp", 32, "v_add_f32 row_shr:1 (the scan step)"},
     {"v_readlane_b32", 32, ""}, {"v_readfirstlane_b32", 32, ""}, {"v_mul_lo_u32", 32, ""},
     {"v_permlane16_swap", 16, ""}, {"v_pk_mul_f32", 16, ""},
+    {"v_dot2_f32_f16", 32, ""}, {"v_cvt_f32_f16", 32, ""}, {"v_fma_mix_f32", 32, ""}, {"v_pk_fma_f16", 32, ""}, {"v_sub_u32", 32, ""},
+    {"v_or_b32", 32, ""}, {"v_xor_b32", 32, ""}, {"v_add3_u32", 32, ""}, {"v_lshl_or_b32", 32, ""}, {"v_bfe_u32", 32, ""},
+    {"v_cvt_f32_i32", 32, ""}, {"v_cvt_u32_f32", 32, ""}, {"v_ldexp_f32", 32, ""}, {"v_fract_f32", 32, ""}, {"v_cmp_lt_i32", 32, ""},
+    {"v_perm_b32", 32, ""}, {"v_alignbit_b32", 32, ""}, {"v_mad_i32_i24", 32, ""}, {"v_ashrrev_i32", 32, ""}, {"v_lshrrev_b32", 32, ""},
+    {"v_add_f32_negabs", 32, "v_add_f32_e64 with neg+abs source modifiers"}, {"v_min3_f32", 32, ""}, {"v_fma_f32_const", 32, "v_fma_f32 with an inline constant"},
+    {"v_fmaak_f32", 32, "v_fmaak_f32 (32-bit literal)"}, {"v_subrev_f32", 32, ""}, {"v_exp_f32_negabs", 32, "v_exp_f32_e64 with neg+abs"}, {"v_writelane_b32", 32, ""},
     {"ds_read_b128_bcast", 16, "16 ds_read_b128, all lanes the same address (the key scans)"},
     {"ds_read_b32", 16, "16 ds_read_b32, lane i at 4 i bytes"},
     {"ds_write_b128", 16, "16 ds_write_b128, lane i at 16 i bytes"},
@@ -219,11 +252,38 @@ __global__ __launch_bounds__(1024) void probe(int stream, int iters, unsigned lo
         case 49: TIMED_LOOP(X32(I_MULLO)); break;
         case 50: TIMED_LOOP(X16P(I_PERM16)); break;
         case 51: TIMED_LOOP(X16P(I_PKMUL)); break;
-        case 52: {
+        case 52: TIMED_LOOP(X32(I_DOT2)); break;
+        case 53: TIMED_LOOP(X32(I_CVTF16)); break;
+        case 54: TIMED_LOOP(X32(I_FMAMIX32)); break;
+        case 55: TIMED_LOOP(X32(I_PKFMA16)); break;
+        case 56: TIMED_LOOP(X32(I_SUBU)); break;
+        case 57: TIMED_LOOP(X32(I_OR)); break;
+        case 58: TIMED_LOOP(X32(I_XOR)); break;
+        case 59: TIMED_LOOP(X32(I_ADD3)); break;
+        case 60: TIMED_LOOP(X32(I_LSHLOR)); break;
+        case 61: TIMED_LOOP(X32(I_BFE)); break;
+        case 62: TIMED_LOOP(X32(I_CVTFI)); break;
+        case 63: TIMED_LOOP(X32(I_CVTUF)); break;
+        case 64: TIMED_LOOP(X32(I_LDEXP)); break;
+        case 65: TIMED_LOOP(X32(I_FRACT)); break;
+        case 66: TIMED_LOOP(X32(I_CMPI)); break;
+        case 67: TIMED_LOOP(X32(I_PERMB)); break;
+        case 68: TIMED_LOOP(X32(I_ALIGN)); break;
+        case 69: TIMED_LOOP(X32(I_MADI24)); break;
+        case 70: TIMED_LOOP(X32(I_ASHR)); break;
+        case 71: TIMED_LOOP(X32(I_LSHR)); break;
+        case 72: TIMED_LOOP(X32(I_ADDNEG)); break;
+        case 73: TIMED_LOOP(X32(I_MIN3)); break;
+        case 74: TIMED_LOOP(X32(I_FMAK)); break;
+        case 75: TIMED_LOOP(X32(I_MADAK)); break;
+        case 76: TIMED_LOOP(X32(I_SUBREV)); break;
+        case 77: TIMED_LOOP(X32(I_EXPMOD)); break;
+        case 78: TIMED_LOOP(X32(I_WRITELANE)); break;
+        case 79: {
             asm volatile("v_mov_b32 v58, 64" ::: "v58");
             TIMED_LOOP(DS16("ds_read_b128", "v58"));
         } break;
-        case 53: {
+        case 80: {
             const unsigned addr = (threadIdx.x & 63) * 4;
             asm volatile("v_mov_b32 v58, %0" :: "v"(addr) : "v58");
             TIMED_LOOP("ds_read_b32 v10, v58\n\tds_read_b32 v11, v58 offset:256\n\tds_read_b32 v12, v58 offset:512\n\tds_read_b32 v13, v58 offset:768\n\t"
