@@ -5,14 +5,17 @@
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One step = one pass of the hot path over one batch, exactly what ImportanceRenderer.forward does per
-call on the GPU: ray generation from the cameras, the reference's two uniform draws (torch.rand, same
-shapes/order as renderer.py:190/:241), the device-side choice of the decoder arithmetic, and the fused
-render kernel (+ its depth-clamp epilogue).  Inputs (planes, decoder, cameras) are resident in HBM before
-the timed region, the planes in the layout their producer writes (channels_last [N,H,W,96], read in place;
-`--nchw-input` adds the round-1 NCHW->NHWC layout change to every step).  Rays shard embarrassingly: each rank renders its own batch (weak scaling, no data-path
-collective); the only collectives are the barriers bracketing the timed region and the max-reduce of
-the elapsed time.
+One step = one pass of the hot path over one batch, what ImportanceRenderer.forward does per call on the
+GPU when it is handed BASELINE.md section 2's input -- planes `torch.randn(4,3,32,256,256)`, i.e. the
+reference API's NCHW tensor: ray generation from the cameras, the NCHW -> [3N,H,W,32] layout change with
+max |planes| riding on it, the reference's two uniform draws (torch.rand, same shapes/order as
+renderer.py:190/:241), the device-side choice of the decoder arithmetic, and the fused render kernel (+ its
+depth-clamp epilogue).  Inputs (planes, decoder, cameras) are resident in HBM before the timed region.
+`value` is that step.  `producer_layout_step` (top level, and `config.producer_layout_value`) is the same
+step when the planes arrive in the layout this repo's plane producer writes (channels_last [N,H,W,96] +
+max |planes|, read in place: no layout change inside the step; `--producer-layout` makes it the headline).
+Rays shard embarrassingly: each rank renders its own batch (weak scaling, no data-path collective); the only
+collectives are the barriers bracketing the timed region and the max-reduce of the elapsed time.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = render_kernel, timed with HIP events
 on the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample
@@ -42,54 +45,89 @@ PEAK_F16_MFMA_TFLOPS = 2500.0                             # dense f16/bf16 matri
 PEAK_HBM_GBS = 8000.0
 PEAK_L2_GBS = 34500.0                                     # aggregate L2 read bandwidth (MI355X_MICROARCH.md)
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
-# vector-instruction ISSUE cost on one SIMD (MI355X_MICROARCH.md, cycle-constants table): plain VALU 4 cycles, transcendentals
-# (v_exp / v_log / v_rcp) 8, an MFMA holds the issue port for 8 of its 16
-CYC_VALU, CYC_TRANS, CYC_MFMA = 4, 8, 8
+# SIMD cycles per wave64 instruction at the render kernel's occupancy (4 waves per SIMD), MEASURED on the device by
+# tools/probes/valu_issue_probe.hip (profiles/r03_valu_issue_probe.json; s_memtime around streams of independent instructions).
+# Four classes -- the guide's "2 cycles (SIMD-32) / 4 for one wave alone" turned out to depend on the OPCODE, not on the wave count:
+#   full     v_add / v_sub / v_mul / v_fma / v_fmac_f32, v_mov, v_and / v_or / v_xor, v_add / v_sub_u32, right shifts       2.3 - 2.6
+#   half     v_min / v_max / v_med3, v_cmp, v_cndmask, conversions, v_floor, left shifts, 24-bit and 32-bit integer multiplies,
+#            DPP moves / adds, v_readlane, v_fma_mix_f32, and every packed-fp32 op (v_pk_fma_f32 = two FMAs in 4.4)              4.2 - 4.7
+#   quarter  v_exp / v_log / v_rcp_f32, v_fma_mixlo / hi_f16, v_permlane*_swap                                               8.3 - 8.9
+#   mfma     v_mfma_f32_16x16x32_f16 16.5 (v_mfma_f32_16x16x4_f32 32.1); next to VALU work of other waves the costs ADD
+#            (one MFMA + 8 v_fma_f32 per wave: 34.7 cycles against 16.5 + 8 x 2.4 = 36): the matrix pipe is not a free second port
+# The fall-back numbers below are that file's values; roofline() re-reads the file when it is there.
+ISSUE_CYCLES = {'full': 2.44, 'half': 4.40, 'quarter': 8.60, 'mfma_f16': 16.5}
+PROBE_JSON = os.path.join(ROOT, 'profiles', 'r03_valu_issue_probe.json')
+GATHER_BYTES_PER_CYCLE_PER_CU = 64.0                      # same probe: 8 lanes per 128-byte line, any line order, L1 or L2 resident
+
+
+def issue_cycles():
+    """(prices, source): SIMD cycles per wave64 instruction of each class at 4 waves per SIMD, from the committed probe."""
+    try:
+        rows = {(r['stream'], r['waves_per_simd']): r['simd_cyc_per_inst'] for r in json.load(open(PROBE_JSON))['streams']}
+        mean = lambda names: sum(rows[(n, 4)] for n in names) / len(names)
+        return ({'full': mean(['v_fma_f32', 'v_add_f32', 'v_mul_f32', 'v_mov_b32', 'v_add_u32', 'v_and_b32']),
+                 'half': mean(['v_max_f32', 'v_cmp_lt_f32_vcc', 'v_cndmask_b32_sgpr', 'v_cvt_pk_f16_f32', 'v_fma_mix_f32', 'v_mad_u32_u24', 'v_floor_f32']),
+                 'quarter': mean(['v_exp_f32', 'v_log_f32', 'v_rcp_f32']), 'mfma_f16': rows[('mfma_f16_16x16x32', 4)]},
+                'profiles/r03_valu_issue_probe.json')
+    except Exception:
+        return dict(ISSUE_CYCLES), 'bench.py constants (probe file missing)'
 
 
 def algorithmic_valu_per_ray(s=48, f=48):
-    """Vector instructions a PERFECT schedule of this algorithm needs per ray, as (plain lane-ops, transcendental lane-ops,
-    MFMA wave-instructions): every lane useful, no address/staging/LDS-handoff overhead, nothing recomputed.  This is the
-    numerator of roofline.frac (bound = VALU issue); DESIGN.md section 4 carries the same table."""
+    """Vector instructions a PERFECT schedule of this algorithm needs per ray: lane-operations per issue class (every lane useful,
+    no address / staging / LDS hand-off overhead, nothing recomputed) and MFMA wave-instructions.  Numerator of roofline.frac."""
     n = s + f
-    per_sample_plain = (
-        6                       # position o + t d (3 fma) and the box scale (3 mul)
-        + 3 * 32                # per plane: pixel coordinates 2, floor 2, fractions 4, four tap weights 4, zero-padding masks 8,
-                                #   integer coordinates + clamps 8, tap addresses 4
-        + 12 * 32               # the blend: 12 taps x 32 channels, one FMA each
-        + 48                    # hi/lo f16 split of the 32 features (1.5 instructions per value)
-        + 64 * 3                # softplus of the 64 hidden units: clamp, add, max around its exp2 / log2
-        + 64                    # density row: 64 FMAs (a 33rd MFMA column would cost a third more matrix instructions)
-        + 96                    # hi/lo split of the 64 activations
-        + 32 * 2                # sigmoid of the 32 colours: add, fma around its exp2 / rcp
-        + 32)                   # composite: one FMA per channel
-    per_sample_trans = 64 * 2 + 32 * 2
+    per_sample = {
+        'full': 6                   # position o + t d (3 fma) and the box scale (3 mul)
+                + 3 * 16            # per plane: pixel coordinates 2, fractions and 1 - f 4, four tap weights 4, x1 / y1 2, tap addresses 4
+                + 12 * 32           # the blend: 12 taps x 32 channels, one FMA each (packed or not: 2.2 cycles per FMA either way)
+                + 64 * 2            # softplus log2(1 + 2^-|p|) + max(p + l, l): two adds per hidden unit
+                + 64                # density row: 64 FMAs
+                + 32 * 2            # sigmoid 1.002 / (1 + 2^o) - 0.001: add, fma
+                + 32,               # composite: one FMA per channel
+        'half': 3 * 16              # per plane: floor 2, float->int 2, zero-padding compares + selects 8, clamps 4
+                + 32 * 2            # hi/lo f16 split of the 32 features: 2 instructions per value (cvt_pk 1/2, fma_mix 1, cvt_pk 1/2)
+                + 64                # softplus: the max
+                + 64 * 2,           # hi/lo split of the 64 activations
+        'quarter': 64 * 2 + 32 * 2,     # exp2 + log2 per hidden unit, exp2 + rcp per colour
+    }
     intervals = (s - 1) + (n - 1)                       # coarse march + final march (ray_marcher.py:26-42)
-    per_ray_plain = intervals * 30 + (f * 24 + 300) + (n * 12 + f * 10) + s * 4 + 64     # marches, importance, merge, proposals, outputs
-    per_ray_trans = intervals * 3                       # softplus (exp2, log2) and exp of every interval
-    mfma = 24 * ((s + 15) // 16 + (f + 15) // 16)       # 24 v_mfma_f32_16x16x32_f16 per 16-sample tile
-    return per_sample_plain * n + per_ray_plain, per_sample_trans * n + per_ray_trans, mfma
+    per_ray = {'full': intervals * 20 + s * 4 + 64,     # marches (differences, midpoints, products), proposals, outputs
+               'half': intervals * 10 + (f * 24 + 300) + (n * 12 + f * 10),      # scans (DPP), importance (compare + count), merge ranks
+               'quarter': intervals * 3}                # softplus (exp2, log2) and exp of every interval
+    out = {k: per_sample[k] * n + per_ray[k] for k in per_sample}
+    out['mfma_f16'] = 24 * ((s + 15) // 16 + (f + 15) // 16)       # 24 v_mfma_f32_16x16x32_f16 per 16-sample tile (wave instructions)
+    return out
 
 
-def roofline(kernel_ms, rays, s, f, plane, n_items, pmc=None, pmc_source=None, traffic=None):
+def roofline(kernel_ms, rays, s, f, plane, n_items, pmc=None, pmc_source=None, traffic=None, kernel_name='render_kernel_pipe<1, auto, full>'):
     """The `roofline` object of the result line for the render kernel at `kernel_ms` per launch.  `pmc`: mean counters per
     launch from a committed rocprofv3 pass of this same command (profiles/rNN_final*_pmc.json; tools/prof_forward.sh)."""
     k_s = kernel_ms * 1e-3
     samples = rays * (s + f)
     flops = samples * FLOP_MLP_PER_SAMPLE
-    plain, trans, mfma = algorithmic_valu_per_ray(s, f)
-    alg_cycles_per_ray = plain / 64 * CYC_VALU + trans / 64 * CYC_TRANS + mfma * CYC_MFMA
+    alg = algorithmic_valu_per_ray(s, f)
+    price, price_src = issue_cycles()
+    alg_cycles_per_ray = sum(alg[k] / 64 * price[k] for k in ('full', 'half', 'quarter')) + alg['mfma_f16'] * price['mfma_f16']
     alg_floor_ms = alg_cycles_per_ray * rays / (N_SIMD * CLOCK_HZ) * 1e3
+    gather_floor_ms = samples * GATHER_BYTES_PER_SAMPLE / (GATHER_BYTES_PER_CYCLE_PER_CU * 256 * CLOCK_HZ) * 1e3
     out = {
-        'kernel': 'render_kernel_pipe<1, f16x3>', 'bound': 'valu_issue',
-        # achieved = algorithmic vector-issue cycles retired per second; peak = issue cycles the chip has per second
+        'kernel': kernel_name, 'bound': 'valu_issue',
+        # achieved = SIMD issue cycles of the ALGORITHM's instructions retired per second, every instruction priced at the rate the
+        # device sustains for its class at this kernel's occupancy (measured, see `pricing`); peak = issue cycles the chip has per second
         'achieved': alg_cycles_per_ray * rays / k_s / 1e9, 'peak': N_SIMD * CLOCK_HZ / 1e9, 'unit': 'G SIMD issue cycles/s',
         'frac': alg_floor_ms / kernel_ms, 'traffic': traffic, 'kernel_ms': kernel_ms,
         'algorithmic_valu_floor': {
-            'plain_lane_ops_per_ray': plain, 'transcendental_lane_ops_per_ray': trans, 'mfma_per_ray': mfma,
+            'lane_ops_per_ray': {k: alg[k] for k in ('full', 'half', 'quarter')}, 'mfma_per_ray': alg['mfma_f16'],
             'issue_cycles_per_ray': alg_cycles_per_ray, 'floor_ms': alg_floor_ms, 'frac': alg_floor_ms / kernel_ms,
-            'pricing': f'{CYC_VALU} cycles per wave64 VALU instruction, {CYC_TRANS} per transcendental, {CYC_MFMA} of issue per MFMA; '
-                       f'{N_SIMD} SIMDs at {CLOCK_HZ / 1e9} GHz'},
+            'pricing': {'simd_cycles_per_wave64_instruction': price, 'source': price_src,
+                        'note': 'measured at 4 waves per SIMD (the kernel\'s occupancy); MFMA and VALU issue cycles of co-resident waves add '
+                                f'(probe: mfma_f16+8fma); {N_SIMD} SIMDs at {CLOCK_HZ / 1e9} GHz'},
+            'frac_if_every_valu_cost_2_cycles': ((alg['full'] + alg['half']) / 64 * 2 + alg['quarter'] / 64 * 8 + alg['mfma_f16'] * 8)
+                                                * rays / (N_SIMD * CLOCK_HZ) * 1e3 / kernel_ms},
+        'l1_gather_floor': {'floor_ms': gather_floor_ms, 'frac': gather_floor_ms / kernel_ms,
+                            'note': f'12 taps x 128 B per sample at the measured {GATHER_BYTES_PER_CYCLE_PER_CU:.0f} B/cycle/CU of the vector-memory path '
+                                    '(probe `gather`): the second-busiest unit, overlapped with the vector issue'},
         'fp32_matrix_yardstick': {'TFLOPs': flops / k_s / 1e12, 'peak_TFLOPs': PEAK_FP32_MFMA_TFLOPS, 'frac': flops / k_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                   'note': 'algorithmic MLP FLOPs (8320 per sample) / kernel time against the fp32-input MFMA peak: a speed yardstick '
                                           '(the results are fp32-grade), NOT utilisation of a pipe the kernel uses'},
@@ -101,19 +139,21 @@ def roofline(kernel_ms, rays, s, f, plane, n_items, pmc=None, pmc_source=None, t
         'l2_gather': {'algorithmic_bytes_per_launch': samples * GATHER_BYTES_PER_SAMPLE,
                       'algorithmic_GBs': samples * GATHER_BYTES_PER_SAMPLE / k_s / 1e9,
                       'algorithmic_frac_of_34_5TBs': samples * GATHER_BYTES_PER_SAMPLE / k_s / 1e9 / PEAK_L2_GBS},
-        'note': 'The kernel is bound by vector-instruction issue (PMC: VALU busy ~74 % of SIMD cycles, MFMA pipe ~11 %, L2 hit 98 %, HBM 3 % '
-                'of peak).  frac = issue time of the instructions a perfect schedule of the algorithm needs / measured kernel time; '
-                'measured_issue (below) prices the instructions the kernel actually executes the same way.',
+        'note': 'Bound by vector-instruction issue (HBM 3 % of peak, L2 hit 98 %).  frac = SIMD cycles the algorithm\'s own instructions need at '
+                'the measured per-class issue rates / SIMD cycles of the kernel; measured_issue prices the EXECUTED instruction count.',
     }
     if pmc:
         valu, n_mfma = pmc.get('SQ_INSTS_VALU'), pmc.get('SQ_INSTS_MFMA')
-        trans_exec = trans / 64 * rays                     # the transcendentals are all algorithmic; the rest is counted plain
         if valu and n_mfma:
-            cyc = (valu - trans_exec) * CYC_VALU + trans_exec * CYC_TRANS + n_mfma * CYC_MFMA
+            # SQ_INSTS_VALU includes the MFMAs.  The algorithm's own instructions are priced by class; what the kernel executes beyond
+            # them (addressing, selects, conversions, LDS hand-offs, scalar-wave bookkeeping: integer / compare / select work) at the half rate
+            alg_insts = (alg['full'] + alg['half'] + alg['quarter']) / 64 * rays
+            extra = max(0.0, valu - n_mfma - alg_insts)
+            cyc = alg_cycles_per_ray * rays + extra * price['half']
             floor_ms = cyc / (N_SIMD * CLOCK_HZ) * 1e3
-            out['measured_issue'] = {'source': pmc_source, 'insts_valu_per_ray': valu / rays, 'insts_mfma_per_ray': n_mfma / rays,
-                                     'issue_floor_ms': floor_ms, 'frac_of_issue_floor': floor_ms / kernel_ms,
-                                     'algorithmic_over_executed_valu': (plain + trans) / 64 * rays / valu}
+            out['measured_issue'] = {'source': pmc_source, 'insts_valu_per_ray': (valu - n_mfma) / rays, 'insts_mfma_per_ray': n_mfma / rays,
+                                     'issue_ms_of_executed_instructions': floor_ms, 'issue_busy_frac': floor_ms / kernel_ms,
+                                     'algorithmic_over_executed_valu': alg_insts / (valu - n_mfma)}
         if pmc.get('TCP_TCC_READ_REQ_sum'):
             b = pmc['TCP_TCC_READ_REQ_sum'] * 128
             out['l2_gather'].update({'counter_bytes_per_launch': b, 'counter_GBs': b / k_s / 1e9, 'counter_frac_of_34_5TBs': b / k_s / 1e9 / PEAK_L2_GBS,
@@ -238,15 +278,65 @@ def gen_videos_secondary(rank, world, dev, n_frames=240):
                         'value = the faster of the two'}
 
 
+PEAK_ATOMIC_GBS = 1300.0          # chip-wide float-atomic rate (MI355X_MICROARCH.md, Global float atomics: 1.26-1.36 TB/s of added bytes)
+FLOP_BWD_PER_SAMPLE = 3 * FLOP_MLP_PER_SAMPLE       # one forward recomputation + dX / dW products of both layers (fp32 MFMA)
+
+
+def backward_times(dev, planes_cl, dec, c2w, intr, reps=5):
+    """Renderer backward at config 2, timed with HIP events on the launch stream around gnerf_render_backward:
+    the whole call (staged scatter: pass 1 render_bwd_kernel + pass 2 plane_scatter_kernel), the single-pass form, and the
+    decoder-only request (= pass 1's compute without any plane scatter).  Returns the `roofline_backward` object."""
+    import gnerf_hip
+    o, d = gnerf_hip.make_rays(c2w, intr, RES)
+    rays = N_ITEMS * RES * RES
+    nc = torch.rand([N_ITEMS, RES * RES, S_COARSE, 1], device=dev)
+    nf = torch.rand(rays, S_FINE, device=dev)
+    g = [torch.randn(N_ITEMS, RES * RES, k, device=dev) for k in (32, 1, 1)]
+    kw = dict(depth_resolution=S_COARSE, depth_resolution_importance=S_FINE, ray_start=RAY_START, ray_end=RAY_END, box_warp=BOX_WARP, image_width=RES)
+
+    def timed(**extra):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ms = []
+        for i in range(reps + 1):
+            e0.record()
+            gnerf_hip.render_backward(planes_cl, N_ITEMS, dec, o, d, nc, nf, *g, **kw, **extra)
+            e1.record()
+            torch.cuda.synchronize()
+            if i:
+                ms.append(e0.elapsed_time(e1))           # includes zero-filling the gradient buffers (100 MB memset, ~15 us)
+        return sorted(ms)[len(ms) // 2]
+
+    staged, direct, dec_only = timed(), timed(staged_scatter=False), timed(need_planes=False)
+    samples = rays * (S_COARSE + S_FINE)
+    flops = samples * FLOP_BWD_PER_SAMPLE
+    atom_bytes = samples * 12 * 32 * 4                  # one 4-byte add per tap and channel: what grid_sampler_2d_backward issues too
+    passes = gnerf_hip.last_backward_pass_ms() if hasattr(gnerf_hip, 'last_backward_pass_ms') else None
+    out = {'workload': 'gnerf_render_backward at config 2 (4 x 128^2 rays, 48+48 samples), planes in the producer layout',
+           'call_ms': {'staged_scatter': staged, 'single_pass': direct, 'decoder_gradients_only': dec_only},
+           'ratio_to_forward_kernel': None,
+           'pass1_fp32_mfma': {'algorithmic_TFLOPs': flops / (dec_only * 1e-3) / 1e12, 'peak_TFLOPs': PEAK_FP32_MFMA_TFLOPS,
+                               'frac': flops / (dec_only * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                               'note': f'{FLOP_BWD_PER_SAMPLE} FLOP per sample (forward recomputation + the four gradient products) over the decoder-only call'},
+           'scatter_atomics': {'algorithmic_GBs_single_pass': atom_bytes / (direct * 1e-3) / 1e9, 'peak_GBs': PEAK_ATOMIC_GBS,
+                               'frac_single_pass': atom_bytes / (direct * 1e-3) / 1e9 / PEAK_ATOMIC_GBS,
+                               'note': 'one fp32 atomic per tap and channel (147 KB per ray) against the chip-wide float-atomic rate; the staged form issues '
+                                       '~3.8x fewer (profiles/r02_backward_profile.json: TCC_EA0_ATOMIC 149.2 M -> 39.9 M per launch)'}}
+    if passes:
+        out['pass_ms'] = passes
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--reps', type=int, default=5, help='repetitions of the timed K-step region (the median is reported)')
-    ap.add_argument('--nchw-input', action='store_true', help='planes arrive NCHW and are repacked inside every step (the round-1 step)')
+    ap.add_argument('--reps', type=int, default=5, help='minimum repetitions of the timed K-step region (the median is reported; more are run until 0.3 s are covered)')
+    ap.add_argument('--producer-layout', action='store_true', help='headline = the step on channels_last planes + max |planes| from the plane producer (no layout change in the step)')
+    ap.add_argument('--nchw-input', action='store_true', help='(default since round 3; kept for old command lines)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the gen_videos frames/sec measurement')
+    ap.add_argument('--no-backward', action='store_true', help='skip the renderer-backward timing behind roofline_backward')
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON result: libraries that chat on fd 1 (RCCL's version banner at communicator
@@ -276,15 +366,15 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     timed_steps = [i for i in range(args.steps) if i % EV_STRIDE == 0]
 
-    # The planes as their PRODUCER hands them over: the backbone's last step, gnerf_upsample2x_add_nhwc, writes
-    # channels_last memory [N,H,W,96] = the interleaved plane layout the render kernels address in place, and max |planes| with it.
-    # (`--nchw-input` times the round-1 step instead: NCHW planes + the 100 MB NCHW->NHWC layout change inside every step.)
+    # The planes as this repo's plane PRODUCER hands them over: the backbone's last step, gnerf_upsample2x_add_nhwc,
+    # writes channels_last memory [N,H,W,96] = the interleaved plane layout the render kernels address in place, and max |planes| with it.
     planes_cl = planes.reshape(N_ITEMS, 96, PLANE, PLANE).permute(0, 2, 3, 1).contiguous()
     amax_cl = gnerf_hip.planes_absmax(planes_cl)
+    headline_nchw = not args.producer_layout
 
-    def step(i=None, mlp='auto', nchw_input=False):
+    def step(i=None, mlp='auto', nchw_input=True):
         o, d = gnerf_hip.make_rays(c2w, intr, RES)
-        if nchw_input or args.nchw_input:
+        if nchw_input:
             nhwc, amax = gnerf_hip.planes_to_nhwc(planes, with_absmax=True)   # max |planes| rides on the repack: it picks the decoder arithmetic
         else:
             nhwc, amax = planes_cl, amax_cl
@@ -303,52 +393,75 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def timed_region(mlp='auto', nchw_input=False):
-        """EXACTLY args.steps steps between barrier + synchronize on both sides; (max-over-ranks seconds, mean render ms by HIP events)."""
+    def timed_region(mlp='auto', nchw_input=True, n_steps=None):
+        """EXACTLY n_steps (default args.steps) steps between barrier + synchronize on both sides; (max-over-ranks seconds, this rank's
+        seconds, mean render ms by HIP events on this rank)."""
+        n_steps = args.steps if n_steps is None else n_steps
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = step(i, mlp, nchw_input)
+        for i in range(n_steps):
+            out = step(i if n_steps == args.steps else None, mlp, nchw_input)
         torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
         barrier()
         elapsed = gnerf_harness.max_over_ranks(time.perf_counter() - t0, dev)
         assert torch.isfinite(out[0]).all()
-        return elapsed, sum(ev[i][0].elapsed_time(ev[i][1]) for i in timed_steps) / len(timed_steps)      # events sit on the launch stream around the render call
+        kms = sum(ev[i][0].elapsed_time(ev[i][1]) for i in timed_steps) / len(timed_steps) if n_steps == args.steps else None
+        return elapsed, mine, kms      # events sit on the launch stream around the render call
 
     for _ in range(args.warmup):
-        step()
+        step(None, 'auto', headline_nchw)
     # The GPU's clocks take ~50 ms of load to settle (the first repetitions of a cold run measured 0.73, 0.75, 0.69 ms per step, every
     # later one 0.65): keep stepping, untimed, until 0.2 s have passed, so that the timed repetitions measure the settled state
     torch.cuda.synchronize()
     t_ramp, ramp_steps = time.perf_counter(), 0
     while time.perf_counter() - t_ramp < 0.2:
         for _ in range(10):
-            step()
+            step(None, 'auto', headline_nchw)
         torch.cuda.synchronize()
         ramp_steps += 10
-    chrono = [timed_region() for _ in range(max(1, args.reps))]
+    # Repetitions of the K-step region: at least --reps, and as many as cover 0.3 s of stepping (K = 20 steps are 12 ms: five of them
+    # gave the driver's round-2 run a 19 % spread; the median of ~25 does not move).  Every repetition is exactly K steps.
+    chrono = [timed_region(nchw_input=headline_nchw)]
+    n_reps = max(args.reps, min(60, int(0.3 / max(chrono[0][0], 1e-4)) + 1))
+    if world > 1:
+        n_reps = int(gnerf_harness.max_over_ranks(float(n_reps), dev))          # same count on every rank (the regions hold barriers)
+    chrono += [timed_region(nchw_input=headline_nchw) for _ in range(n_reps - 1)]
     regions = sorted(chrono)                                                     # by elapsed time
-    elapsed, kernel_ms = regions[len(regions) // 2]                              # the median repetition is the one reported
+    elapsed, mine, kernel_ms = regions[len(regions) // 2]                        # the median repetition is the one reported
     assert gnerf_hip.last_mlp_choice(dev) == 'f16x3', 'config 2 is inside the f16 hi/lo range: the device-side choice must pick it'
-    # render-call time of each shipped decoder arithmetic when forced (auto = select kernel + both launches, one of which returns at once)
+    # one long region (>= 100 ms of steps, whatever --steps is) as a cross-check of the K-step median
+    n_long = max(args.steps, int(0.1 / (elapsed / args.steps)) + 1)
+    if world > 1:
+        n_long = int(gnerf_harness.max_over_ranks(float(n_long), dev))
+    long_elapsed = sorted(timed_region(nchw_input=headline_nchw, n_steps=n_long)[0] for _ in range(3))[1]
+    # the other plane layout, and the render call with each shipped decoder arithmetic forced
+    other = sorted(timed_region(nchw_input=not headline_nchw) for _ in range(5))[2]
     kernel_ms_by_mlp = {'auto': kernel_ms}
     for mlp in ('f16x3', 'f32'):
-        step(None, mlp)
-        kernel_ms_by_mlp[mlp] = sorted(timed_region(mlp)[1] for _ in range(3))[1]
-    nchw_elapsed = sorted(timed_region(nchw_input=True)[0] for _ in range(3))[1]
-    per_rank_ms = [kernel_ms]
+        step(None, mlp, headline_nchw)
+        kernel_ms_by_mlp[mlp] = sorted(timed_region(mlp, headline_nchw)[2] for _ in range(3))[1]
+    per_rank = [{'rank': rank, 'value': rays_per_call * args.steps / mine, 'render_call_ms': kernel_ms}]
     if world > 1:
-        t = torch.tensor([kernel_ms], device=dev)
+        t = torch.tensor([rays_per_call * args.steps / mine, kernel_ms], device=dev, dtype=torch.float64)
         allk = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allk, t)
-        per_rank_ms = [float(x) for x in allk]
+        per_rank = [{'rank': r, 'value': float(x[0]), 'render_call_ms': float(x[1])} for r, x in enumerate(allk)]
+
+    backward = None
+    if not args.no_backward:
+        try:
+            backward = backward_times(dev, planes_cl, dec, c2w, intr)
+            backward['ratio_to_forward_kernel'] = backward['call_ms']['staged_scatter'] / kernel_ms
+        except Exception as e:
+            backward = {'error': f'{type(e).__name__}: {e}'[:300]}
 
     secondary = None
     if not args.no_secondary:
         try:
-            del planes
+            del planes, planes_cl
             torch.cuda.empty_cache()
             secondary = gen_videos_secondary(rank, world, dev)
         except Exception as e:                                           # never lose the headline line to the secondary metric
@@ -361,32 +474,41 @@ def main():
         if os.path.isfile(tpath):
             traffic = json.load(open(tpath)).get('render_kernel_hbm_bytes_per_launch')
         pmc, pmc_source = latest_pmc()
-        roof = roofline(kernel_ms_by_mlp['f16x3'], rays_per_call, S_COARSE, S_FINE, PLANE, N_ITEMS, pmc, pmc_source, traffic)
+        roof = roofline(kernel_ms_by_mlp['auto'], rays_per_call, S_COARSE, S_FINE, PLANE, N_ITEMS, pmc, pmc_source, traffic)     # the kernel the headline runs
         roof['render_call_ms'] = kernel_ms_by_mlp
-        roof['render_call_ms_note'] = ('HIP events around the render call of every 5th step inside the timed regions (instrumenting every step cost '
-                                       '~10 us per step): auto = what the headline runs (every workgroup '
-                                       'evaluates the range bounds itself and runs the f16x3 body here), f16x3 / f32 = that arithmetic forced; each '
-                                       'includes the depth-clamp epilogue')
-        roof['render_call_ms_per_rank'] = per_rank_ms
+        roof['render_call_ms_note'] = ('HIP events around the render call of every 5th step inside the timed regions: auto = what the headline runs (every '
+                                       'workgroup evaluates the range bounds itself and runs the f16x3 body here; `frac` is computed on it), f16x3 / f32 = '
+                                       'that arithmetic forced; each includes the depth-clamp epilogue')
+        nchw_name = 'NCHW planes as BASELINE.md section 2 defines the input; the NCHW -> [3N,H,W,32] layout change (100 MB read + written) and max |planes| inside every step'
+        cl_name = 'planes as gnerf_upsample2x_add_nhwc writes them (channels_last [N,H,W,96] + max |planes|), read in place: no layout change inside the step'
+        other_step = {'ms_per_step': 1e3 * other[0] / args.steps, 'value': total_rays / other[0], 'planes': nchw_name if not headline_nchw else cl_name}
         line = {
             'metric': 'rays/sec at 128^2 neural render, 96 depth samples',
             'value': total_rays / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (MLP products as compensated f16 hi/lo splits on MFMA, fp32 accumulate; exact-fp32 MFMA when the device-side range '
                      'check says so)', 'data': 'synthetic',
-            'repetitions': {'n': len(regions), 'reported': 'median', 'untimed_clock_ramp_steps': ramp_steps, 'ms_per_step_all': [1e3 * e / args.steps for e, _ in regions],
-                            'ms_per_step_in_run_order': [1e3 * e / args.steps for e, _ in chrono], 'render_call_ms_in_run_order': [k for _, k in chrono],
+            'repetitions': {'n': len(regions), 'reported': 'median', 'untimed_clock_ramp_steps': ramp_steps,
+                            'ms_per_step_min_median_max': [1e3 * regions[0][0] / args.steps, 1e3 * elapsed / args.steps, 1e3 * regions[-1][0] / args.steps],
+                            'ms_per_step_in_run_order': [round(1e3 * e / args.steps, 4) for e, _, _ in chrono],
                             'value_min': total_rays / regions[-1][0], 'value_max': total_rays / regions[0][0],
-                            'spread_frac': (regions[-1][0] - regions[0][0]) / elapsed},
-            'config': {'workload': 'config 2: renderer-only, 128x128 rays x (48+48) samples, 3x32x256x256 fp32 tri-planes, batch 4 per GPU; '
-                                   'step = make_rays + 2 torch.rand draws + decoder-arithmetic choice + fused render kernel; planes resident in HBM in their '
-                                   'producer\'s layout' + (' (NCHW: + the NCHW->NHWC layout change in every step)' if args.nchw_input else
-                                                          ' (channels_last [N,H,W,96] as gnerf_upsample2x_add_nhwc writes them: read in place)'),
+                            'spread_frac': (regions[-1][0] - regions[0][0]) / elapsed,
+                            'interquartile_spread_frac': (regions[(3 * len(regions)) // 4][0] - regions[len(regions) // 4][0]) / elapsed,
+                            'one_region_of_100ms': {'steps': n_long, 'ms_per_step': 1e3 * long_elapsed / n_long,
+                                                    'value': rays_per_call * n_long * world / long_elapsed}},
+            'config': {'workload': 'config 2: 128x128 rays x (48+48) samples, 3x32x256x256 fp32 tri-planes, batch 4 per GPU; '
+                                   + ('NCHW planes, repacked in every step' if headline_nchw else 'channels_last planes read in place'),
+                       'step': 'make_rays + ' + ('NCHW->NHWC repack with max|planes| + ' if headline_nchw else '') + '2 torch.rand draws + fused render kernel (device-side decoder-arithmetic choice) + depth clamp',
+                       'planes': nchw_name if headline_nchw else cl_name,
                        'rays_per_step_per_gpu': rays_per_call, 'parallelism': f'rays sharded over {world} GPU(s), no data-path collective',
-                       'nchw_input_step': {'ms_per_step': 1e3 * nchw_elapsed / args.steps, 'value': total_rays / nchw_elapsed,
-                                           'note': 'the same step with NCHW planes repacked (100 MB) inside every step, as in round 1'}},
+                       'producer_layout_value' if headline_nchw else 'nchw_input_value': other_step['value'],
+                       'producer_layout_ms_per_step' if headline_nchw else 'nchw_input_ms_per_step': other_step['ms_per_step']},
+            'producer_layout_step' if headline_nchw else 'nchw_input_step': other_step,
+            'per_rank': per_rank,
             'roofline': roof,
         }
+        if backward is not None:
+            line['roofline_backward'] = backward
         line['secondary'] = secondary
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline()

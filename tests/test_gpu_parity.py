@@ -1531,13 +1531,16 @@ def test_bench_two_ranks_on_one_gpu(dev):
     env = dict(os.environ, GNERF_DIST_BACKEND='gloo', OMP_NUM_THREADS='1')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
                         '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
-                        '--no-cpu-baseline', '--no-secondary'], capture_output=True, text=True, env=env, cwd=root, timeout=600)
+                        '--no-cpu-baseline', '--no-secondary', '--no-backward'], capture_output=True, text=True, env=env, cwd=root, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines                      # library chatter (gloo / RCCL banners) must not reach stdout
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['steps'] == 5 and line['scaling'] == 'weak' and line['value'] > 1e6
     assert line['roofline']['kernel_ms'] > 0 and line['cpu_baseline'] is None and line['secondary'] is None
+    # per-rank values (so that a scaling run explains itself) and both plane layouts at top level
+    assert [r['rank'] for r in line['per_rank']] == [0, 1] and all(r['value'] > 5e5 and r['render_call_ms'] > 0 for r in line['per_rank'])
+    assert line['producer_layout_step']['value'] > line['value'] * 0.9 and line['config']['producer_layout_value'] == line['producer_layout_step']['value']
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
