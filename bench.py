@@ -239,43 +239,58 @@ def cpu_baseline(seconds_budget=30.0):
 def gen_videos_secondary(rank, world, dev, n_frames=240):
     """BASELINE's second metric, frames/sec of gen_videos (config 4): the 240-frame orbit of gen_videos.py:154-171 sharded in
     contiguous blocks over the ranks (30 frames per GPU at 8 GPUs), 64x64 rays x (96+96) samples per frame (the CLI's doubled
-    sampling), cached backbone, superresolution to 512x512 in fp16, uint8 frames, ONE all-gather of the frames at the end (RCCL).
+    sampling), cached backbone, superresolution to 512x512 in fp16, uint8 frames, ONE gather of the frames to rank 0 at the end (RCCL).
     Generator: random-init FFHQ configuration (gnerf_generator.Generator -- the reference's layer graph around this repo's
     renderer and ops; there is no reference tree or checkpoint on the GPU box).  One untimed warm-up frame (MIOpen's
-    per-shape kernel search), then the orbit eagerly and replayed from a captured HIP graph.  Returns a dict (all ranks)."""
+    per-shape kernel search), then the orbit eagerly and replayed from a captured HIP graph, in TWO flows:
+      fast       gnerf_generator's own path: csrc/modconv.hip around the convolutions, channels_last planes from the producer kernel
+      reference  the layer code a G-NeRF checkout runs (GNERF_MODCONV_FAST=0: modulated_conv2d's PyTorch ops, convolutions through
+                 the overlay's torch_utils.ops.conv2d_resample / fma, native bias_act / upfirdn2d, fused renderer) with NCHW planes
+    Returns a dict (all ranks); `value` is the fast flow's better number, `reference_flow_value` the other flow's."""
     from torch_utils import custom_ops
     custom_ops.verbosity = 'none'                     # stdout carries exactly one JSON line
     import gnerf_harness as H
     import gen_videos_mi355x as gv
+    import gnerf_generator as GG
     if world > 1:
         import torch.distributed as dist
+    out = {}
     with torch.no_grad():
         G = gv.build_random_generator(0, dev)
         z = torch.randn(1, G.z_dim, generator=torch.Generator().manual_seed(1)).to(dev)
-        gv.render_orbit(G, z, n_frames, 64, dev, rank=0, world=n_frames, double_depth=True)         # warm-up: frame 0 (also sets 96+96)
-        # the frame's launch sequence is captured once per generator and latent, outside the timed orbit, like the warm-up frame
-        program = gv.FrameProgram(G, gv.orbit_latents(G, z, dev), 64, dev)
-        out = {}
-        for name, use_graph in (('eager', False), ('hip_graph', True)):
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            t0 = time.perf_counter()
-            frames, _, _ = gv.render_orbit(G, z, n_frames, 64, dev, rank, world, double_depth=False, program=program if use_graph else None)
-            full = H.gather_frames(frames, n_frames)
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            out[name] = n_frames / H.max_over_ranks(time.perf_counter() - t0, dev)
-            if rank == 0:
-                assert full.shape == (n_frames, 512, 512, 3) and full.dtype == torch.uint8
-    best = max(out, key=out.get)
-    return {'metric': 'frames/sec gen_videos', 'value': out[best], 'unit': 'frames/s', 'value_is': best, 'eager_value': out['eager'],
-            'hip_graph_value': out['hip_graph'], 'n_gpus': world,
+        last = G.backbone.synthesis.b256
+        for flow, fast in (('fast', True), ('reference', False)):
+            GG._MODCONV_FAST = fast
+            last.emit_channels_last = fast
+            gv.render_orbit(G, z, n_frames, 64, dev, rank=0, world=n_frames, double_depth=(flow == 'fast'))      # warm-up: frame 0 (the first also sets 96+96)
+            # the frame's launch sequence is captured once per generator, latent and flow, outside the timed orbit, like the warm-up frame
+            program = gv.FrameProgram(G, gv.orbit_latents(G, z, dev), 64, dev)
+            for name, use_graph in (('eager', False), ('hip_graph', True)):
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                frames, _, _ = gv.render_orbit(G, z, n_frames, 64, dev, rank, world, double_depth=False, program=program if use_graph else None)
+                full = H.gather_frames(frames, n_frames)
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                out[flow, name] = n_frames / H.max_over_ranks(time.perf_counter() - t0, dev)
+                if rank == 0:
+                    assert full.shape == (n_frames, 512, 512, 3) and full.dtype == torch.uint8
+            del program
+        GG._MODCONV_FAST = os.environ.get('GNERF_MODCONV_FAST', '1') != '0'
+        last.emit_channels_last = True
+    best = max(('eager', 'hip_graph'), key=lambda k: out['fast', k])
+    return {'metric': 'frames/sec gen_videos', 'value': out['fast', best], 'unit': 'frames/s', 'value_is': 'fast flow, ' + best,
+            'eager_value': out['fast', 'eager'], 'hip_graph_value': out['fast', 'hip_graph'],
+            'reference_flow_value': max(out['reference', 'eager'], out['reference', 'hip_graph']),
+            'reference_flow_eager_value': out['reference', 'eager'], 'reference_flow_hip_graph_value': out['reference', 'hip_graph'], 'n_gpus': world,
             'workload': f'config 4: {n_frames}-frame orbit sharded over {world} GPU(s), 64x64 rays x (96+96) samples, cached backbone, SR to '
-                        '512x512 fp16, uint8 frames, one all-gather; random-init FFHQ-config generator; hip_graph_value = HIP-graph replay of the '
-                        'per-frame sequence (captured once, before the timed orbit), eager_value = plain launches (backbone pass included); '
-                        'value = the faster of the two'}
+                        '512x512 fp16, uint8 frames, one gather to rank 0; random-init FFHQ-config generator; hip_graph = HIP-graph replay of the '
+                        'per-frame sequence (captured once, before the timed orbit), eager = plain launches (backbone pass included); '
+                        'fast = this repo\'s generator path (modconv kernels, channels_last planes), reference_flow = the reference\'s layer code '
+                        '(PyTorch-op modulation, conv2d_resample / fma / bias_act / upfirdn2d from the overlay, NCHW planes): what a G-NeRF checkout gets'}
 
 
 PEAK_ATOMIC_GBS = 1300.0          # chip-wide float-atomic rate (MI355X_MICROARCH.md, Global float atomics: 1.26-1.36 TB/s of added bytes)

@@ -103,7 +103,8 @@ template <class T> __host__ __device__ constexpr int batch_of() { return sizeof(
 
 template <class T, int ACT, int VEC, int kBatch>
 __device__ __forceinline__ void act_batch(const Args& a, const int64_t (&i0)[kBatch], const bool (&ok)[kBatch],
-                                          const typename Arith<T>::type (&bias)[kBatch], bool bias_per_elem) {
+                                          const typename Arith<T>::type (&bias)[kBatch], bool bias_per_elem,
+                                          const typename Arith<T>::type* bias_vec = nullptr) {
     typedef typename Arith<T>::type A;
     typedef Pack<T, VEC> P;
     const A alpha = A(a.alpha), gain = A(a.gain), clamp = A(a.clamp);
@@ -126,7 +127,8 @@ __device__ __forceinline__ void act_batch(const Args& a, const int64_t (&i0)[kBa
 #pragma unroll
         for (int k = 0; k < VEC; k++) {
             A bv = bias[t];
-            if (bias_per_elem) bv = load_as<T>(b, (unsigned(i0[t] + k) / a.step_b) % a.size_b);
+            if (bias_vec) bv = bias_vec[k];
+            else if (bias_per_elem) bv = load_as<T>(b, (unsigned(i0[t] + k) / a.step_b) % a.size_b);
             const A r = eval<A, ACT>(load_as<T>(px[t].v, k), bv,
                                      xref ? load_as<T>(pxr[t].v, k) : A(0), yref ? load_as<T>(pyr[t].v, k) : A(0),
                                      dy ? load_as<T>(pdy[t].v, k) : A(1), a.grad, alpha, gain, clamp);
@@ -204,6 +206,36 @@ __global__ __launch_bounds__(kThreads) void bias_act_rows_kernel(Args a) {
     act_batch<T, ACT, VEC, kBatch>(a, i0, ok, bias, false);
 }
 
+// Channels-last form (bias along the fastest axis: step_b = 1, e.g. a channels_last activation tensor biased per channel).  A 16-byte
+// vector then covers VEC consecutive channels, and with a grid stride that is a multiple of the vectors per pixel a lane meets the SAME
+// channels on every trip: its VEC biases are loaded once and live in registers.  The general kernel resolves the bias per ELEMENT here
+// (an integer modulo and a load each): 3.5 TB/s on the superresolution's [1,128,512,512] fp16 layers against the row form's 4.8+.
+template <class T, int ACT, int VEC>
+__global__ __launch_bounds__(kThreads) void bias_act_cl_kernel(Args a) {
+    typedef typename Arith<T>::type A;
+    constexpr int kBatch = batch_of<T>();
+    const int64_t nvec = a.numel / VEC;                                   // numel % size_b == 0 and size_b % VEC == 0: no ragged tail
+    const int64_t stride = int64_t(gridDim.x) * kThreads;                 // a multiple of size_b / VEC (the launcher checks)
+    const int64_t iv0 = int64_t(blockIdx.x) * kThreads + threadIdx.x;
+    A bvec[VEC];
+    const unsigned c0 = unsigned((iv0 * VEC) % a.size_b);
+#pragma unroll
+    for (int k = 0; k < VEC; k++) bvec[k] = load_as<T>(static_cast<const T*>(a.b), c0 + k);
+    for (int64_t iv = iv0; iv < nvec; iv += stride * kBatch) {
+        int64_t i0[kBatch];
+        bool ok[kBatch];
+        A bias[kBatch];
+#pragma unroll
+        for (int t = 0; t < kBatch; t++) {
+            const int64_t v = iv + t * stride;
+            ok[t] = v < nvec;
+            i0[t] = (ok[t] ? v : iv) * VEC;
+            bias[t] = A(0);
+        }
+        act_batch<T, ACT, VEC, kBatch>(a, i0, ok, bias, false, bvec);
+    }
+}
+
 template <class T, int VEC>
 int launch_act(const Args& a, int act, hipStream_t stream) {
     const int64_t nvec = (a.numel + VEC - 1) / VEC;
@@ -224,6 +256,16 @@ int launch_act(const Args& a, int act, hipStream_t stream) {
             default: return fail(GNERF_E_ARG, "bias_act: unknown activation %d", act);
         }
         return check_launch("bias_act(rows)");
+    }
+    if (VEC > 1 && a.b && a.step_b == 1 && a.size_b % VEC == 0 && a.numel % a.size_b == 0 && (blocks * kThreads) % (a.size_b / VEC) == 0) {
+        switch (act) {
+#define GNERF_CASE(A_) case A_: hipLaunchKernelGGL((bias_act_cl_kernel<T, A_, VEC>), g, t, 0, stream, a); break;
+            GNERF_CASE(1) GNERF_CASE(2) GNERF_CASE(3) GNERF_CASE(4) GNERF_CASE(5)
+            GNERF_CASE(6) GNERF_CASE(7) GNERF_CASE(8) GNERF_CASE(9)
+#undef GNERF_CASE
+            default: return fail(GNERF_E_ARG, "bias_act: unknown activation %d", act);
+        }
+        return check_launch("bias_act(channels_last)");
     }
     switch (act) {
 #define GNERF_CASE(A_) case A_: hipLaunchKernelGGL((bias_act_kernel<T, A_, VEC>), g, t, 0, stream, a); break;

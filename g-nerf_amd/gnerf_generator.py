@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from torch_utils.ops import bias_act, upfirdn2d
+from torch_utils.ops import bias_act, conv2d_resample, fma, upfirdn2d
 from training.volumetric_rendering.renderer import ImportanceRenderer
 from training.volumetric_rendering.ray_sampler import RaySampler
 
@@ -238,10 +238,15 @@ class StyledConv(nn.Module):
             if not done:
                 x = gnerf_hip.modconv_epilogue(x, self.bias, noise=noise, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
             return (x, folded) if next_layer is not None else x
+        # The reference's own flow (modulated_conv2d, networks_stylegan2.py:41-98, called from SynthesisLayer.forward :315-334 with
+        # padding = kernel_size // 2 and flip_weight = (up == 1)): PyTorch ops for the modulation, the convolution through
+        # torch_utils.ops.conv2d_resample and the demodulation through torch_utils.ops.fma -- the overlay's modules on a GPU, i.e. what
+        # a G-NeRF checkout gets from this repo without any of the kernels above.
         if fused:
             wts = _modulated_weights(self.weight, styles, True, x.dtype == torch.float16).to(x.dtype)          # [N,O,I,3,3]
             c_out = wts.shape[1]
-            x = self._resampled_conv(x.reshape(1, n * c_in, h, wd), wts.reshape(n * c_out, c_in, 3, 3), n)
+            x = conv2d_resample.conv2d_resample(x=x.reshape(1, n * c_in, h, wd), w=wts.reshape(n * c_out, c_in, 3, 3), f=self.resample_filter,
+                                                up=self.up, padding=1, groups=n, flip_weight=(self.up == 1))
             x = x.reshape(n, c_out, *x.shape[2:])
             if noise is not None:
                 x = x.add_(noise)
@@ -250,8 +255,9 @@ class StyledConv(nn.Module):
             if x.dtype == torch.float16:
                 weight, styles = _prenormalize(weight, styles)
             dcoefs = _demod_coefficients(weight, styles).to(x.dtype)[:, :, None, None]
-            x = self._resampled_conv(x * styles.to(x.dtype)[:, :, None, None], weight.to(x.dtype), 1)
-            x = torch.addcmul(noise.to(x.dtype), x, dcoefs) if noise is not None else x * dcoefs      # torch_utils/ops/fma.py
+            x = conv2d_resample.conv2d_resample(x=x * styles.to(x.dtype)[:, :, None, None], w=weight.to(x.dtype), f=self.resample_filter,
+                                                up=self.up, padding=1, flip_weight=(self.up == 1))
+            x = fma.fma(x, dcoefs, noise.to(x.dtype)) if noise is not None else x * dcoefs
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         x = bias_act.bias_act(x, self.bias.to(x.dtype), act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
         return (x, folded) if next_layer is not None else x
@@ -281,11 +287,11 @@ class ToRGB(nn.Module):
                 wts, _ = gnerf_hip.modulate_weights(self.weight, styles, False, out_dtype=x.dtype)
                 x = F.conv2d(x.reshape(1, n * c_in, h, wd), wts.reshape(-1, c_in, 1, 1), groups=n).reshape(n, -1, h, wd)
             return gnerf_hip.modconv_epilogue(x, self.bias, act='linear', gain=1.0, clamp=self.conv_clamp)
-        if fused:
+        if fused:                       # (the reference's flow, as in StyledConv.forward)
             wts = _modulated_weights(self.weight, styles, False, False).to(x.dtype)
-            x = F.conv2d(x.reshape(1, n * c_in, h, wd), wts.reshape(-1, c_in, 1, 1), groups=n).reshape(n, -1, h, wd)
+            x = conv2d_resample.conv2d_resample(x=x.reshape(1, n * c_in, h, wd), w=wts.reshape(-1, c_in, 1, 1), groups=n).reshape(n, -1, h, wd)
         else:
-            x = F.conv2d(x * styles.to(x.dtype)[:, :, None, None], self.weight.to(x.dtype))
+            x = conv2d_resample.conv2d_resample(x=x * styles.to(x.dtype)[:, :, None, None], w=self.weight.to(x.dtype))
         return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
 
 
@@ -316,8 +322,10 @@ class Block(nn.Module):
             x = self.const.to(dtype).unsqueeze(0).repeat(ws[0].shape[0], 1, 1, 1)
             x = self.conv1(x, ws[0], noise_mode, fused=fused)
         else:
-            x = x.to(dtype)
-            if dtype == torch.float16 and _FP16_CHANNELS_LAST and x.is_cuda and x.shape[1] % 8 == 0 and _fast_path(x, ws[0], self.conv0.weight, self.conv1.weight, self.torgb.weight):
+            fast = _fast_path(x, ws[0], self.conv0.weight, self.conv1.weight, self.torgb.weight)
+            # the reference's block entry fixes the layout as well as the type (networks_stylegan2.py:438, fp16_channels_last = False)
+            x = x.to(dtype) if fast else x.to(dtype=dtype, memory_format=torch.contiguous_format)
+            if dtype == torch.float16 and _FP16_CHANNELS_LAST and x.is_cuda and x.shape[1] % 8 == 0 and fast:
                 x = x.contiguous(memory_format=torch.channels_last)
             x, folded = self.conv0(x, ws[0], noise_mode, fused=fused, next_layer=self.conv1, next_w=ws[1])
             x = self.conv1(x, ws[1], noise_mode, fused=fused, prescaled=folded)

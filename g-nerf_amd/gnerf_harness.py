@@ -95,9 +95,10 @@ def shard_range(n_items, rank, world):
 
 
 def gather_frames(frames, n_total, dst=0):
-    """frames: this rank's uint8 block [n_local, ...] (its shard_range of n_total).  Returns the full
-    [n_total, ...] tensor on rank `dst` (None elsewhere).  One collective: an all_gather of equal-size padded
-    blocks of uint8 (RCCL over xGMI on GPUs; 189 MB in total for 240 frames of 512x512x3)."""
+    """frames: this rank's uint8 block [n_local, ...] (its shard_range of n_total).  Returns the full [n_total, ...] tensor on
+    rank `dst` (None elsewhere).  ONE collective, a `gather` to `dst` of equal-size padded uint8 blocks (RCCL over xGMI on GPUs):
+    every other rank sends its block once over its own link to `dst` -- 189 MB arrive there for 240 frames of 512x512x3, 23.6 MB
+    per link at 8 GPUs; an all_gather would deliver those 189 MB to every rank, 8x the traffic, for nothing."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return frames
@@ -105,8 +106,8 @@ def gather_frames(frames, n_total, dst=0):
     per = (n_total + world - 1) // world
     pad = torch.zeros((per,) + tuple(frames.shape[1:]), dtype=frames.dtype, device=frames.device)
     pad[:frames.shape[0]] = frames
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad)
+    out = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, gather_list=out, dst=dst)
     if rank != dst:
         return None
     parts = []

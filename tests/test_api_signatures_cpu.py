@@ -14,7 +14,7 @@ SCRIPT = r'''
 import sys, inspect, importlib, importlib.util, json
 sys.dont_write_bytecode = True
 MODS = ["torch_utils.ops.bias_act", "torch_utils.ops.upfirdn2d", "torch_utils.ops.filtered_lrelu", "torch_utils.ops.grid_sample_gradfix",
-        "torch_utils.custom_ops", "training.volumetric_rendering.renderer", "training.volumetric_rendering.ray_marcher",
+        "torch_utils.ops.conv2d_resample", "torch_utils.ops.fma", "torch_utils.custom_ops", "training.volumetric_rendering.renderer", "training.volumetric_rendering.ray_marcher",
         "training.volumetric_rendering.ray_sampler", "training.volumetric_rendering.math_utils"]
 
 

@@ -807,6 +807,25 @@ def test_bias_act_layouts_and_edges(dev):
     np.testing.assert_allclose(bias_act.bias_act(big, bb, act='lrelu', clamp=256).float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+def test_bias_act_channels_last_kernel(dev, dtype):
+    """The channels-last form (bias along the fastest axis, a lane keeps its VEC biases in registers) against the NCHW result of the
+    same values, bit for bit: forward for two activations, and the first-order gradient form that reads the saved output."""
+    from torch_utils.ops import bias_act
+    torch.manual_seed(4)
+    for shape in ((1, 128, 40, 24), (3, 32, 17, 9), (2, 264, 5, 7)):          # 264 channels: 33 (fp16) / 66 (fp32) vectors per pixel -> general kernel
+        x = torch.randn(*shape, device=dev, dtype=dtype, requires_grad=True)
+        b = torch.randn(shape[1], device=dev, dtype=dtype)
+        xc = x.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        for act, kw in (('lrelu', dict(clamp=1.5)), ('linear', dict(clamp=0.7)), ('sigmoid', {})):
+            ya, yb = bias_act.bias_act(x, b, act=act, **kw), bias_act.bias_act(xc, b, act=act, **kw)
+            assert yb.is_contiguous(memory_format=torch.channels_last) and torch.equal(ya, yb), (shape, act)
+            g = torch.randn_like(ya)
+            ga, = torch.autograd.grad(ya, x, g)
+            gb, = torch.autograd.grad(yb, xc, g.contiguous(memory_format=torch.channels_last))
+            assert torch.equal(ga, gb), (shape, act)
+
+
 UP_CASES = {
     'blur':      dict(f='f4', up=1, down=1, padding=[1, 1, 1, 1], gain=4.0),
     'up2':       dict(f='f4', up=2, down=1, padding=[2, 1, 2, 1], gain=4.0),
@@ -1271,6 +1290,44 @@ def test_config3_n4_gpu_vs_reference_fixture(dev, golden):
     with torch.no_grad(), C.DI.DetNoise('config3'):
         d = G.synthesis(G.mapping(b['z'], b['c']), b['c'], noise_mode='const', neural_rendering_resolution=64, only_depth=True)
     assert d['image'] is d['image_depth'] and torch.equal(d['image'], out['image_depth'])
+
+
+def test_config3_reference_flow_through_overlay_gpu_vs_fixture(dev, golden, monkeypatch):
+    """The flow a G-NeRF checkout runs after the swap: the layer code of the reference (gnerf_generator's plain path, GNERF_MODCONV_FAST=0:
+    PyTorch-op weight modulation, `modulated_conv2d`'s calls into torch_utils.ops.conv2d_resample and bias_act / upfirdn2d) with the
+    OVERLAY's modules on the GPU -- fp16 superresolution blocks convolved channels_last, ToRGB on the streaming kernel, NCHW planes into
+    the fused renderer -- against the fixture made from the reference's TriPlaneGenerator on the CPU (config 3, N=4 and N=1)."""
+    import gen_cases as C
+    import gnerf_generator as GG
+    from torch_utils.ops import conv2d_resample as CR
+    g = golden('generator_n4.npz')
+    G, _ = C.build(dev)
+    monkeypatch.setattr(GG, '_MODCONV_FAST', False)
+    G.backbone.synthesis.b256.emit_channels_last = False
+    seen = {'calls': 0, 'channels_last_out': 0, 'torgb_kernel': 0}
+    real = CR.conv2d_resample
+
+    def spy(x, w, **kw):
+        y = real(x=x, w=w, **kw)
+        seen['calls'] += 1
+        seen['channels_last_out'] += int(y.dtype == torch.float16 and y.shape[1] > 3 and CR._is_channels_last(y))
+        seen['torgb_kernel'] += int(y.dtype == torch.float16 and y.shape[1] == 3 and x.shape[0] == 1 and CR._is_channels_last(x))
+        return y
+    monkeypatch.setattr(CR, 'conv2d_resample', lambda x, w, **kw: spy(x, w, **kw))
+    ws, out = C.run_config3(G, dev)
+    assert seen['calls'] == 29 and seen['channels_last_out'] == 0, seen         # every modulated convolution and ToRGB; a batch keeps the reference's layout
+    mse = {'image': float(((out['image'][:, :, 4::8, 4::8].cpu().numpy() - g['image_sub']) ** 2).mean()),
+           'image_raw': float(((out['image_raw'].cpu().numpy() - g['image_raw']) ** 2).mean())}
+    assert mse['image'] < 1e-4 and mse['image_raw'] < 1e-4, mse
+    np.testing.assert_allclose(out['image_depth'].cpu().numpy(), g['image_depth'], atol=1e-3)
+    # batch 1 (an orbit frame): the grouped convolution degenerates to a plain one, x stays channels_last into ToRGB's streaming kernel
+    b = C.batch_on(dev)
+    seen.update(calls=0, channels_last_out=0, torgb_kernel=0)
+    with torch.no_grad(), C.DI.DetNoise('config3'):
+        one = G.synthesis(G.mapping(b['z'][:1], b['c'][:1]), b['c'][:1], noise_mode='const', neural_rendering_resolution=64)
+    assert seen['calls'] == 29 and seen['channels_last_out'] == 6 and seen['torgb_kernel'] == 3, seen      # the six fp16 convolutions stay channels_last
+    assert float(((one['image'][:, :, 4::8, 4::8].cpu().numpy() - g['image_sub'][:1]) ** 2).mean()) < 1e-4
+    np.testing.assert_allclose(one['image_depth'].cpu().numpy(), g['image_depth'][:1], atol=1e-3)
 
 
 def test_config5_training_step_gpu_vs_reference_fixture(dev, golden):

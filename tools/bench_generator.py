@@ -19,6 +19,7 @@ import gnerf_harness as H, gnerf_generator
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--ref-ops', action='store_true')
+ap.add_argument('--reference-flow', action='store_true', help="the reference's layer code (GNERF_MODCONV_FAST=0) on the overlay's ops, NCHW planes")
 ap.add_argument('--batch', type=int, default=4)
 ap.add_argument('--frames', type=int, default=30)
 ap.add_argument('--only', type=int, default=0, help='3 or 4: run only that configuration (for profiling)')
@@ -31,6 +32,9 @@ with torch.no_grad():
         if n.endswith('noise_strength') or n.endswith('.bias'):
             p.add_(torch.randn_like(p) * 0.1)
 
+if args.reference_flow:
+    gnerf_generator._MODCONV_FAST = False
+    G.backbone.synthesis.b256.emit_channels_last = False
 if args.ref_ops:
     from torch_utils.ops import bias_act, upfirdn2d
     _b, _u = bias_act.bias_act, upfirdn2d.upfirdn2d
@@ -95,7 +99,7 @@ with torch.no_grad():
             return torch.cat(frames)
         t, frames = timed(orbit, 1)
         line = {'config': 4, 'workload': f'orbit share of one GPU: {args.frames} frames, 64x64 rays x ({S}+{S}), cached backbone, SR to 512x512 fp16, uint8 frames',
-                'ops': 'pytorch-op forms' if args.ref_ops else 'native gfx950', 'frames_per_s': round(args.frames / t, 1), 'ms_per_frame': round(t / args.frames * 1e3, 3)}
+                'ops': 'pytorch-op forms' if args.ref_ops else ('native gfx950, reference layer code' if args.reference_flow else 'native gfx950'), 'frames_per_s': round(args.frames / t, 1), 'ms_per_frame': round(t / args.frames * 1e3, 3)}
         if not args.ref_ops:
             # the per-frame sequence replayed from a HIP graph (no entry point allocates or synchronises)
             cam = cams[:1].clone()

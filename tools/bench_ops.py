@@ -43,6 +43,9 @@ with torch.no_grad():
         b = torch.randn(128, device=dev, dtype=dt)
         ms = timeit(lambda: bias_act.bias_act(x, b, act='lrelu', clamp=256))
         report(f'bias_act lrelu+clamp [4,128,512,512] {nm}', ms, (2 * x.numel() + 128) * es)
+        xcl = x.contiguous(memory_format=torch.channels_last)
+        ms = timeit(lambda: bias_act.bias_act(xcl, b, act='lrelu', clamp=256))
+        report(f'bias_act lrelu+clamp [4,128,512,512] {nm} channels_last', ms, (2 * x.numel() + 128) * es)
         xb = torch.randn(4, 128, 513, 513, device=dev, dtype=dt)
         ms = timeit(lambda: upfirdn2d.upfirdn2d(xb, f, padding=[1, 1, 1, 1], gain=4))
         report(f'upfirdn2d blur 4x4 [4,128,513,513]->512 {nm}', ms, (xb.numel() + 4 * 128 * 512 * 512) * es)

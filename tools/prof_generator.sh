@@ -1,10 +1,11 @@
 #!/bin/bash
 # Kernel statistics of the config-3 generator forward (batch 4) under rocprofv3 (run on the GPU box through gpurun):
 #   -> gpurun_out/generator_kernel_stats.csv (Name, Calls, TotalDurationUs, AverageUs, Percentage)
+# usage: bash tools/prof_generator.sh [bench_generator.py arguments; default --only 3]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_g3
-timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_g3 -o run -- python3 $R/tools/bench_generator.py --only 3 > /tmp/g3.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_g3 -o run -- python3 $R/tools/bench_generator.py ${@:---only 3} > /tmp/g3.log 2>&1
 tail -2 /tmp/g3.log
 cd $R && python3 - <<'PY'
 import csv, glob, sqlite3
