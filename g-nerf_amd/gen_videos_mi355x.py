@@ -21,6 +21,7 @@ HIP graph captured once (FrameProgram); `--shapes out.npy` also extracts the 512
 """
 
 import argparse
+import sys
 import time
 
 import numpy as np
@@ -115,6 +116,9 @@ class FrameProgram:
         with torch.cuda.graph(self.graph):
             self.frame, self.raw = self._frame()
         self._decoder = G.renderer.__dict__.get('_gnerf_decoder_cache')
+        # ... and the per-latent constants of the layers (styles, modulated weights: gnerf_generator._per_latent), which the captured
+        # kernels read in place; another latent through the same generator replaces the cache entries, not these tensors
+        self._latent_constants = getattr(sys.modules.get(type(G).__module__), 'latent_cache_tensors', lambda g: [])(G)
 
     def _frame(self, cache=False, cached=True):
         out = self.G.synthesis(ws=self.ws, c=self.c, noise_mode='const', neural_rendering_resolution=self.res,

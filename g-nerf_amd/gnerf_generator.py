@@ -22,6 +22,7 @@ seven super-resolution variants, Freeze-D, pickling hooks.
 
 import math
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -72,6 +73,47 @@ def _prenormalised_weight(module, dtype, channels_last=False, transposed=False):
             hit = (key, v.contiguous(memory_format=torch.channels_last if channels_last else torch.contiguous_format))
         cache[key[2:]] = hit
     return hit[1]
+
+
+def _latent_token(w):
+    """What identifies a latent slice `w` (a view of the caller's ws) for caches of values that depend on it and on parameters alone:
+    (weak reference to the tensor that owns the memory, its version counter, the view's offset and shape) -- or None when changes
+    cannot be tracked (inference tensors have no version counter) or the values must stay in an autograd graph."""
+    base = w._base if w._base is not None else w
+    if base.is_inference() or (torch.is_grad_enabled() and base.requires_grad):
+        return None
+    return weakref.ref(base), (base._version, w.storage_offset(), tuple(w.shape), w.dtype)
+
+
+def _per_latent(module, w, tag, params, fn):
+    """fn() memoised per (latent slice, parameter versions) on `module`.  gen_videos.py renders a whole orbit from ONE ws
+    (gen_videos.py:150), so every style vector, every modulated weight tensor and every demodulation coefficient of the
+    superresolution layers is a constant of the orbit: without this each frame recomputes them (modulate_weights_kernel alone was
+    4.6 % of the GPU time of profiles/r02_generator_kernel_stats.csv).  The cached tensors are never written again; a FrameProgram
+    (gen_videos_mi355x.py) keeps references to the ones its graph captured."""
+    tok = _latent_token(w)
+    if tok is None or (torch.is_grad_enabled() and any(p.requires_grad for p in params)) or any(p.is_inference() for p in params):
+        return fn()
+    ref, state = tok
+    key = (state, tuple((p.data_ptr(), p._version) for p in params))
+    cache = module.__dict__.setdefault('_gnerf_latent_cache', {})
+    hit = cache.get(tag)
+    base = ref()
+    if hit is not None and hit[0]() is base and hit[1] == key:
+        return hit[2]
+    with torch.no_grad():
+        val = fn()
+    cache[tag] = (ref, key, val)
+    return val
+
+
+def latent_cache_tensors(root):
+    """Every tensor the per-latent caches under `root` currently hold (for a FrameProgram to keep alive)."""
+    out = []
+    for m in root.modules():
+        for _, _, val in m.__dict__.get('_gnerf_latent_cache', {}).values():
+            out.extend(v for v in (val if isinstance(val, (tuple, list)) else (val,)) if isinstance(v, torch.Tensor))
+    return out
 
 
 class Linear(nn.Module):
@@ -191,27 +233,31 @@ class StyledConv(nn.Module):
         into this layer's epilogue, and the call returns (x, folded) instead of x."""
         assert noise_mode in ('random', 'const', 'none')
         n, c_in, h, wd = x.shape
-        styles = self.affine(w)
+        aff = (self.affine.weight, self.affine.bias)
+        fast = _fast_path(x, self.weight, self.bias, self.noise_strength, *aff)
+        styles = _per_latent(self, w, 'styles', aff, lambda: self.affine(w)) if fast else self.affine(w)
         noise = None
         if noise_mode == 'random':
             noise = torch.randn([n, 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
         elif noise_mode == 'const':
             noise = self.noise_const * self.noise_strength
         folded = False
-        assert not prescaled or (_fast_path(x, self.weight, self.bias, self.noise_strength, styles) and x.dtype == torch.float16 and n > 1)
-        if _fast_path(x, self.weight, self.bias, self.noise_strength, styles):
+        assert not prescaled or (fast and x.dtype == torch.float16 and n > 1)
+        if fast:
             import gnerf_hip
             half = x.dtype == torch.float16
             cl = _is_channels_last(x)
             c_out = self.weight.shape[0]
             clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+            mine = aff + (self.weight,)
             if half and n > 1:          # shared-weight form: activations scaled by the styles, demodulation in the epilogue
-                _, dco = gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=x.dtype, want_weights=False, want_dcoefs=True)
+                dco = _per_latent(self, w, 'dco', mine, lambda: gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=x.dtype, want_weights=False, want_dcoefs=True)[1])
                 if not prescaled:
-                    x = gnerf_hip.scale_channels(x, gnerf_hip.normalise_styles(styles))
+                    x = gnerf_hip.scale_channels(x, _per_latent(self, w, 'nstyles', aff, lambda: gnerf_hip.normalise_styles(styles)))
                 nxt = None
                 if next_layer is not None and cl and _fast_path(x, next_layer.weight, next_layer.bias, next_layer.noise_strength):
-                    nxt = gnerf_hip.normalise_styles(next_layer.affine(next_w))
+                    nxt_aff = (next_layer.affine.weight, next_layer.affine.bias)
+                    nxt = _per_latent(next_layer, next_w, 'nstyles', nxt_aff, lambda: gnerf_hip.normalise_styles(next_layer.affine(next_w)))
                     folded = True
                 epi = dict(bias=self.bias, scale=dco, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp, next_scale=nxt) if noise is None else None
                 out = self._resampled_conv(x, _prenormalised_weight(self, x.dtype, cl), 1,
@@ -227,8 +273,9 @@ class StyledConv(nn.Module):
                 return (x, folded) if next_layer is not None else x
             # per-sample weights in one launch, already in the order and memory format the convolution takes them
             # ([N,O,I,3,3] for conv2d, [N,I,O,3,3] for conv_transpose2d: re-ordering 38 MB of fp32 weights per up-layer was a
-            # strided copy per call)
-            wts, _ = gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=x.dtype, transposed=self.up == 2, channels_last=cl)
+            # strided copy per call); constants of an orbit, like the styles
+            wts = _per_latent(self, w, ('wts', x.dtype, cl), mine,
+                              lambda: gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=x.dtype, transposed=self.up == 2, channels_last=cl)[0])
             wts = wts.reshape(-1, *wts.shape[2:]) if n > 1 else wts[0]
             epi = dict(bias=self.bias, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp) if (noise is None and n == 1) else None
             x = self._resampled_conv(x.reshape(1, n * c_in, h, wd) if n > 1 else x, None if self.up == 2 else wts, n, weight_t=wts if self.up == 2 else None,
@@ -276,15 +323,17 @@ class ToRGB(nn.Module):
 
     def forward(self, x, w, fused=True):
         n, c_in, h, wd = x.shape
-        styles = self.affine(w) * self.weight_gain
-        if _fast_path(x, self.weight, self.bias, styles):
+        aff = (self.affine.weight, self.affine.bias)
+        fast = _fast_path(x, self.weight, self.bias, *aff)
+        styles = _per_latent(self, w, 'styles', aff, lambda: self.affine(w) * self.weight_gain) if fast else self.affine(w) * self.weight_gain
+        if fast:
             import gnerf_hip
             if x.dtype == torch.float16 and _is_channels_last(x) and self.weight.shape[0] == 3 and c_in in gnerf_hip.TORGB_CHANNELS:
                 return gnerf_hip.torgb_channels_last(x, self.weight, styles, self.bias, clamp=self.conv_clamp)      # one streaming read of x
             if x.dtype == torch.float16 and n > 1:
                 x = F.conv2d(gnerf_hip.scale_channels(x, styles), self.weight.to(x.dtype))
             else:
-                wts, _ = gnerf_hip.modulate_weights(self.weight, styles, False, out_dtype=x.dtype)
+                wts = _per_latent(self, w, ('wts', x.dtype), aff + (self.weight,), lambda: gnerf_hip.modulate_weights(self.weight, styles, False, out_dtype=x.dtype)[0])
                 x = F.conv2d(x.reshape(1, n * c_in, h, wd), wts.reshape(-1, c_in, 1, 1), groups=n).reshape(n, -1, h, wd)
             return gnerf_hip.modconv_epilogue(x, self.bias, act='linear', gain=1.0, clamp=self.conv_clamp)
         if fused:                       # (the reference's flow, as in StyledConv.forward)
@@ -392,7 +441,8 @@ class SuperRes8XDC(nn.Module):
         self.block1 = Block(256, 128, w_dim, 512, 3, is_last=True, use_fp16=use_fp16, conv_clamp=clamp)
 
     def forward(self, rgb, x, ws, noise_mode='none', **block_kwargs):
-        ws = ws[:, -1:, :].repeat(1, 3, 1)
+        # (the same tensor OBJECT for the same ws: the layers below cache what depends on their latent slice by its identity)
+        ws = _per_latent(self, ws, 'ws3', (), lambda: ws[:, -1:, :].repeat(1, 3, 1))
         x_raw, image_raw = self.block64(x, rgb, ws, noise_mode, **block_kwargs)
         if x.shape[-1] != 128:
             x = F.interpolate(x_raw, size=(128, 128), mode='bilinear', align_corners=False, antialias=self.antialias)

@@ -1424,6 +1424,48 @@ def test_render_backward_full_size_properties(dev):
         assert _rel_l2(a.cpu(), b) < 1e-3, (name, _rel_l2(a.cpu(), b))
 
 
+def test_generator_per_latent_constants_are_cached_and_invalidated(dev):
+    """gen_videos.py renders an orbit from ONE ws (gen_videos.py:150): style vectors, modulated weights and demodulation coefficients are
+    constants of it and are cached per layer (gnerf_generator._per_latent).  A second frame must reuse them (no modulate_weights launch),
+    and a changed latent -- another tensor, or the same one modified in place -- or a changed parameter must not."""
+    import gnerf_generator as GG
+    import gnerf_harness as H
+    import gnerf_hip
+    torch.manual_seed(6)
+    G = GG.Generator().eval().requires_grad_(False).to(dev)
+    c = H.camera_label(H.orbit_pose(3, 120)).to(dev)
+    calls = {'n': 0}
+    real = gnerf_hip.modulate_weights
+
+    def counting(*a, **k):
+        calls['n'] += 1
+        return real(*a, **k)
+    gnerf_hip.modulate_weights = counting
+    try:
+        with torch.no_grad():
+            ws = G.mapping(torch.randn(1, 512, device=dev), c)
+            run = lambda w: G.synthesis(w, c, noise_mode='const', neural_rendering_resolution=64)
+            # (MIOpen's convolutions are not bit-reproducible from call to call here -- 7e-3 on these images -- hence the tolerances)
+            close = lambda p, q: float((p['image'] - q['image']).abs().max()) < 3e-2
+            torch.manual_seed(1); a = run(ws); first = calls['n']
+            torch.manual_seed(1); b = run(ws); second = calls['n'] - first
+            assert first > 0 and second == 0 and close(a, b)
+            ws2 = ws + 0.5 * torch.randn_like(ws[:, :1])             # another latent: everything is recomputed, and the image differs
+            torch.manual_seed(1); d = run(ws2)
+            assert calls['n'] - first == first and not close(d, a)
+            base = calls['n']
+            ws.copy_(ws2)                                            # the SAME tensor modified in place: its version counter invalidates
+            torch.manual_seed(1); e = run(ws)
+            assert calls['n'] - base == first and close(e, d)
+            base = calls['n']
+            w1 = G.superresolution.block1.conv1.weight
+            w1.add_(torch.randn_like(w1))                            # a parameter modified in place: that layer alone is recomputed
+            torch.manual_seed(1); f = run(ws)
+            assert calls['n'] - base == 1 and not close(f, e)
+    finally:
+        gnerf_hip.modulate_weights = real
+
+
 def test_density_volume_gpu_vs_cpu(dev):
     """gen_videos.py --shapes counterpart: the density lattice through the fused point-query kernel (chunked, ragged last chunk)
     against the same module's PyTorch-op path on the CPU."""
