@@ -835,6 +835,17 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
     if ((pipe || coop) && mlp == GNERF_MLP_AUTO) {
         // the choice is made on the device, by every workgroup for itself (no host round trip, graph-capturable): see choose_mlp
         P.absmax = p->planes_absmax;
+        if (P.absmax && getenv("GNERF_VERIFY_ABSMAX") && !strcmp(getenv("GNERF_VERIFY_ABSMAX"), "1")) {
+            // debug aid (include/gnerf_hip.h, planes_absmax contract): is the caller's value an upper bound of THESE planes?
+            float* own = reinterpret_cast<float*>(static_cast<int*>(p->workspace) + 5);
+            if (int e = gnerf_planes_absmax(p->planes_nhwc, int64_t(p->n_items) * 3 * p->plane_h * p->plane_w * 32, own, stream)) return e;
+            float mine = 0.f, theirs = 0.f;
+            if (hipMemcpyAsync(&mine, own, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipMemcpyAsync(&theirs, P.absmax, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess)
+                return fail(GNERF_E_LAUNCH, "render: GNERF_VERIFY_ABSMAX could not read the plane statistics back");
+            if (theirs < mine)                                  // (NaN on either side compares false: NaN planes / NaN bound both select fp32)
+                return fail(GNERF_E_ARG, "render: planes_absmax = %g is smaller than max |planes| = %g of this call's planes (stale value?)", theirs, mine);
+        }
         if (!P.absmax) {
             float* own = reinterpret_cast<float*>(static_cast<int*>(p->workspace) + 5);
             if (int e = gnerf_planes_absmax(p->planes_nhwc, int64_t(p->n_items) * 3 * p->plane_h * p->plane_w * 32, own, stream)) return e;

@@ -264,9 +264,17 @@ typedef struct gnerf_render_params {
        faster) -- only valid while features, weights and hidden activations are inside f16's range.
        GNERF_MLP_AUTO (0, default): decided ON THE DEVICE per call from max |planes| and the decoder's weights (bounds
        in DESIGN.md section 2.1): out-of-range or ill-conditioned inputs take the fp32 path, so results never depend on
-       f16's range.  planes_absmax: one device float from gnerf_planes_to_nhwc_stats / gnerf_planes_absmax; NULL makes
-       the AUTO launcher measure it itself (one extra pass over the planes).  The kernels that always compute in fp32
-       (more than 96+96 samples, gnerf_query_points, both backward passes) ignore these two fields. */
+       f16's range.  planes_absmax: one device float from gnerf_planes_to_nhwc_stats / gnerf_planes_absmax /
+       gnerf_upsample2x_add_nhwc; NULL makes the AUTO launcher measure it itself (one extra pass over the planes).
+       CONTRACT of a caller-supplied planes_absmax: at the time the render kernel runs (stream order) the float must be
+       >= max |planes_nhwc| of THIS call's planes -- an upper bound is fine (it only sends more calls to the fp32 body), a
+       value that is too small (a stale measurement of other or since-modified planes) is NOT detected: the f16x3 body then
+       runs on features outside the range its bounds were checked for and can return inf / NaN or lose its fp32-grade
+       accuracy.  NaN or +inf there selects the fp32 body.  Debug aid: with the environment variable GNERF_VERIFY_ABSMAX=1
+       gnerf_render_forward measures max |planes| itself, synchronises the stream, and fails with GNERF_E_ARG when the
+       supplied value is smaller (a test-suite switch: it costs a pass over the planes and a host round trip per call).
+       The kernels that always compute in fp32 (more than 144+144 samples or no importance pass beyond 96 samples: the generic
+       kernel, gnerf_query_points, both backward passes) ignore these two fields. */
     const float* planes_absmax;
     int32_t mlp_mode;
     /* Layout of `planes_nhwc` (and of gnerf_render_grads.grad_planes_nhwc, which always mirrors it):

@@ -61,3 +61,19 @@ def compare_norms(got, names, want, rel, what):
     worst = max((abs(got[str(n)] - w) / max(w, floor), str(n)) for n, w in zip(names, want))
     assert worst[0] < rel, (what, worst)
     return worst
+
+
+def compare_whole_gradients(G, D, grads, rel_l2, what):
+    """Three whole gradient tensors elementwise against tests/golden/train_step_grads.npz (relative L2 error; the fixture stores
+    float16 of value / max|value|: 3e-4 of storage rounding): a sign or permutation error inside a tensor keeps its norm."""
+    gp = dict(G.named_parameters())
+    got = {'g_backbone_b256_conv1_w': gp['backbone.synthesis.b256.conv1.weight'].grad, 'g_sr_block1_conv0_w': gp['superresolution.block1.conv0.weight'].grad,
+           'd_b4_out_w': D.b4.out.weight.grad}
+    worst = {}
+    for k, t in got.items():
+        want = torch.from_numpy(grads[k + '_f16'].astype(np.float32)) * float(grads[k + '_scale'])
+        assert tuple(t.shape) == tuple(want.shape), (what, k)
+        err = float((t.detach().double().cpu() - want.double()).norm() / want.double().norm())
+        assert err < rel_l2, (what, k, err)
+        worst[k] = err
+    return worst

@@ -303,7 +303,7 @@ def _ffhq_g_kwargs():
 def make_generator_cases():
     """BASELINE configs 3 and 5 from the reference's own classes on the CPU (fp32; the reference forces fp32 for CPU tensors):
     generator_n4.npz  TriPlaneGenerator.synthesis at N=4, render resolution 64, noise_mode='const' (config 3);
-    train_step.npz    one G + D step of training_loop.py:314-437 (SSIM / VGG terms dropped) on the same
+    train_step.npz, train_step_grads.npz    one G + D step of training_loop.py:314-437 (SSIM / VGG terms dropped) on the same
                       generator in training mode and Discriminator(c_dim=25, img_resolution=64, img_channels=1,
                       mbstd_group_size=4): loss terms and the norm of every parameter's gradient.
     Weights, noise and the batch are functions of names / call indices (det_init.py), so only outputs are stored."""
@@ -369,6 +369,18 @@ def make_generator_cases():
                         image_raw=np_(gen['image_raw']), image_depth=np_(gen['image_depth']), image_sub=np_(gen['image'][:, :, 4::8, 4::8]),
                         g_names=np.array(g_names), g_grad_norms=g_norms, d_names=np.array(d_names), d_grad_norms=d_norms,
                         g_grad_decoder_w1=np_(G.decoder.net[0].weight.grad), d_grad_out_w=np_(D.b4.out.weight.grad[:4, :64]))
+    # three WHOLE gradient tensors for elementwise comparison (a sign or permutation error inside a tensor keeps its norm): one of the
+    # backbone, one of the superresolution, one of the discriminator.  They are stored as float16 of value / max|value|
+    # (0.3 / 0.6 / 0.5 MB instead of twice that; the 2^-11 storage rounding is a relative L2 error of 3e-4, inside the tests' 1e-3).
+    gp = dict(G.named_parameters())
+    big = {'g_backbone_b256_conv1_w': gp['backbone.synthesis.b256.conv1.weight'].grad, 'g_sr_block1_conv0_w': gp['superresolution.block1.conv0.weight'].grad,
+           'd_b4_out_w': D.b4.out.weight.grad}
+    packed = {}
+    for k, t in big.items():
+        scale = float(t.abs().max())
+        packed[k + '_f16'] = (t / scale).to(torch.float16).numpy()
+        packed[k + '_scale'] = np.float32(scale)
+    np.savez_compressed(os.path.join(HERE, 'train_step_grads.npz'), **packed)
     print('train_step: loss', float(loss), 'gan', float(loss_gan), 'r1', float(loss_r1.mean()), '|dG|', float(np.sqrt((g_norms ** 2).sum())),
           '|dD|', float(np.sqrt((d_norms ** 2).sum())))
 

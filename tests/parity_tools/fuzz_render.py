@@ -2,81 +2,163 @@
 """Randomised parity sweep of the fused renderer against the CPU oracle: random sample counts (all three kernels and the three
 pipelined instantiations), ragged ray counts, plane sizes, white_back, disparity-space sampling and per-ray limits; a third of
 the cases with plane / decoder magnitudes drawn log-uniformly from 1e-4..1e4 (the device-side choice between the f16 hi/lo and
-the exact-fp32 decoder arithmetic; tolerance tied to the fp32 noise floor measured with the float64 oracle), half of the
-cases with the planes in the interleaved [N,H,W,96] layout.
-usage: python tests/parity_tools/fuzz_render.py [n_cases] [seed]"""
+the exact-fp32 decoder arithmetic), half of the cases with the planes in the interleaved [N,H,W,96] layout.
+
+Criterion.  Ordinary magnitudes: rgb MSE against the fp32 oracle < 1e-8, |wsum error| < 5e-4, depth error < 5e-4 on well-conditioned
+rays.  Wild magnitudes (|planes| |W| up to 1e8: pre-activations of 1e4..1e6 whose fp32 rounding noise is +-0.5, of which the handful
+of samples that cancel to within a few units of 0 decide a whole pixel, and a density that does so decides a whole ray): the HIP
+result is held to the FLOAT64 oracle, at 4 x the noise floor of the problem itself --
+  floor = the largest distance from the float64 result over (a) five mathematically identical fp32 evaluations of the oracle (the
+          reference order, three with the decoder's feature channels and hidden units permuted, one with both matrix products
+          accumulated term by term as a matrix-instruction chain does) and (b) three float64 evaluations whose inputs (planes, decoder)
+          carry a relative perturbation of 8 x 2^-24: what ANY backward-stable fp32 evaluation of a 32- and a 64-term product may show.
+Round 2 compared against the fp32 oracle at 4 x its own distance from float64 and saw 2 of 1 500 cases at 5 x and 24 x: in the first
+the HIP path and the fp32 oracle err by the same amount in OPPOSITE directions on the same two outputs (their mutual distance is then
+4 x either's), in the second one ray's weights hinge on a single cancelling density (all 32 channels of that ray shift together, in the
+fp32 oracle too).  `FUZZ_ONLY=591,1257 python tests/parity_tools/fuzz_render.py 1500 31` prints both dissections.
+usage: python tests/parity_tools/fuzz_render.py [n_cases] [seed]        (FUZZ_ONLY=i,j re-runs those cases of the sequence verbosely)"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, 'g-nerf_amd'), os.path.join(ROOT, 'tests'), ROOT]
 import numpy as np
 import torch
-import gnerf_hip
-from oracle import render_ref as R
-from test_gpu_parity import _random_scene
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-dev = torch.device('cuda', 0)
-worst = {'mse': 0.0, 'depth': 0.0, 'wsum': 0.0}
-fails = []
-only = set(int(v) for v in os.environ['FUZZ_ONLY'].split(',')) if os.environ.get('FUZZ_ONLY') else None     # re-run these cases of the sequence
-for case in range(n_cases):
-    S = int(rng.choice([rng.integers(4, 49), rng.integers(49, 97), rng.integers(97, 145), rng.integers(145, 200)], p=[0.35, 0.4, 0.2, 0.05]))
-    F = int(rng.choice([0, rng.integers(1, 49), rng.integers(49, 97), rng.integers(97, 145), rng.integers(145, 180)], p=[0.1, 0.35, 0.35, 0.15, 0.05]))
-    N, res = int(rng.integers(1, 4)), int(rng.integers(2, 7))
-    hw = (int(rng.integers(4, 40)), int(rng.integers(4, 40)))
-    white_back, disparity = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) == 0)
-    per_ray = (not disparity) and bool(rng.integers(0, 4) == 0)
-    planes, dec, o, d, nc, nf = _random_scene(int(rng.integers(1 << 30)), N, res, S, F, hw)
-    wild = bool(rng.integers(0, 3) == 0)
-    if wild:
-        planes = planes * float(10 ** rng.uniform(-4, 4))
-        ws = float(10 ** rng.uniform(-3, 3))
-        dec = [t * ws for t in dec]
-    interleaved = bool(rng.integers(0, 2))
-    if only is not None and case not in only:
-        continue
-    rs, re = 2.25, 3.3
-    if per_ray:
-        g = torch.Generator().manual_seed(case)
-        rs = 2.0 + 0.5 * torch.rand(N, res * res, 1, generator=g)
-        re = rs + 0.6 + 0.6 * torch.rand(N, res * res, 1, generator=g)
-    opts = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=rs, ray_end=re, box_warp=1.0, clamp_mode='softplus',
-                white_back=white_back, disparity_space_sampling=disparity)
-    ref_rgb, ref_depth, ref_w = R.render(planes, dec, o, d, opts, nc, nf)
-    floor = w_floor = 0.0
-    if wild:
-        dd = lambda t: t.double() if isinstance(t, torch.Tensor) else t
-        ex_rgb, _, ex_w = R.render(planes.double(), [t.double() for t in dec], o.double(), d.double(), dict(opts, ray_start=dd(rs), ray_end=dd(re)), nc.double(), nf.double())
-        floor, w_floor = float(((ref_rgb.double() - ex_rgb) ** 2).mean()), float((ref_w.double() - ex_w).abs().max())
-    if interleaved:
-        nhwc = planes.to(dev).reshape(N, 96, *hw).permute(0, 2, 3, 1).contiguous()
-    else:
-        nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
-    to = lambda t: t.to(dev) if isinstance(t, torch.Tensor) else t
-    rgb, depth, wsum = gnerf_hip.render_forward(nhwc, N, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev) if F else None,
-                                                depth_resolution=S, depth_resolution_importance=F, ray_start=to(rs), ray_end=to(re), box_warp=1.0,
-                                                white_back=white_back, disparity_space_sampling=disparity, image_width=res)
-    mse = float(((rgb.cpu() - ref_rgb) ** 2).mean())
-    # depth = sum(w t) / sum(w): where a ray's weight sum is tiny (wild magnitudes: density ~ 0) the quotient is ill-conditioned in fp32 --
-    # the fp32 oracle itself is then off by ~4e-7 in the weight sum against the float64 oracle -- so depth is compared on rays with
-    # a weight sum of at least 1e-2 (seed 31 found six such rays in 1 500 cases: weight sums of 3e-7 .. 3e-4, depth off by 1e-3 .. 4e-2)
-    well = ref_w >= 1e-2
-    de = float(((depth.cpu() - ref_depth).abs() * well).max())
-    we = float((wsum.cpu() - ref_w).abs().max())
-    worst = {'mse': max(worst['mse'], mse), 'depth': max(worst['depth'], de), 'wsum': max(worst['wsum'], we)}
-    if not torch.isfinite(rgb).all() or not torch.isfinite(wsum).all():
-        mse = float('inf')
-    if floor >= 1e-9:
-        de = 0.0                                # depth of an ill-conditioned scene is not compared
-    # colour tolerance: 1e-8, or -- wild magnitudes -- 32 x the fp32 oracle's own distance from the float64 oracle: one fp32 evaluation order
-    # (torch's blocked CPU sums) is a single sample of the rounding noise; the exact-fp32 MFMA path (sequential 4-wide accumulation, hardware
-    # exp2 / log2) was seen at 5 x and 24 x that sample in 2 of 1 500 cases, both with |planes| or |W1| in the hundreds to ten-thousands
-    if not (mse < max(1e-8, 32 * floor) and de < 5e-4 and we < max(5e-4, 4 * w_floor)):
-        if only is not None:
-            bad = (depth.cpu() - ref_depth).abs().flatten().argmax()
-            print(json.dumps(dict(case=case, floor=floor, w_floor=w_floor, mse=mse, de=de, we=we, ref_w_min=float(ref_w.min()), ref_w_at=float(ref_w.flatten()[bad]), w_at=float(wsum.cpu().flatten()[bad]),
-                                  ref_depth_at=float(ref_depth.flatten()[bad]), depth_at=float(depth.cpu().flatten()[bad]), planes_absmax=float(planes.abs().max()), w1_absmax=float(dec[0].abs().max()))))
-        fails.append(dict(case=case, wild=wild, interleaved=interleaved, floor=floor, choice=gnerf_hip.last_mlp_choice(dev), S=S, F=F, N=N, res=res, hw=hw, white_back=white_back, disparity=disparity, per_ray=per_ray, mse=mse, depth=de, wsum=we))
-print(json.dumps({'cases': n_cases, 'worst': worst, 'failures': fails}))
-sys.exit(1 if fails else 0)
+
+def permuted_decoders(dec, planes, n):
+    """n mathematically identical (planes, decoder) pairs: feature channels and hidden units permuted (folded decoder = (w1 [64,32], b1, w2 [33,64], b2))."""
+    w1, b1, w2, b2 = dec
+    g = torch.Generator().manual_seed(1234)
+    out = []
+    for _ in range(n):
+        pc, ph = torch.randperm(32, generator=g), torch.randperm(64, generator=g)
+        out.append((planes[:, :, pc], (w1[ph][:, pc], b1[ph], w2[:, ph], b2)))
+    return out
+
+
+class sequential_fp32_decoder:
+    """Context manager: the oracle's decoder with both matrix products accumulated one term after the other in fp32 (index order),
+    which is how a matrix instruction chain sums them (v_mfma_f32_16x16x4_f32: k = 0..3 into the accumulator, then the next four) --
+    torch's CPU addmm sums in vector-width blocks, closer to pairwise.  Same mathematics, a different draw of the rounding noise, and for
+    the long sums of a 32- and a 64-term product a systematically larger one (error ~ sqrt(n) eps instead of ~ sqrt(log n) eps)."""
+
+    def __enter__(self):
+        from oracle import render_ref as R
+        self.R, self.orig = R, R.decoder_mlp
+
+        def seq_mm(a, w, b):                       # a [P,K], w [O,K], b [O]
+            acc = b.expand(a.shape[0], -1).clone()
+            for k in range(a.shape[1]):
+                acc = torch.addcmul(acc, a[:, k:k + 1], w[None, :, k])
+            return acc
+
+        def decoder(x, W1, b1, W2, b2):
+            h = torch.nn.functional.softplus(seq_mm(x, W1, b1))
+            o = seq_mm(h, W2, b2)
+            return o[:, 0], torch.sigmoid(o[:, 1:]) * (1 + 2 * 0.001) - 0.001
+        R.decoder_mlp = decoder
+        return self
+
+    def __exit__(self, *exc):
+        self.R.decoder_mlp = self.orig
+
+
+def run(n_cases, seed, mult=4.0, orders=3, only=None, verbose=False, progress=None):
+    import gnerf_hip
+    from oracle import render_ref as R
+    from test_gpu_parity import _random_scene
+    rng = np.random.default_rng(seed)
+    dev = torch.device('cuda', 0)
+    worst = {'mse': 0.0, 'depth': 0.0, 'wsum': 0.0, 'mse_over_floor': 0.0}
+    fails = []
+    for case in range(n_cases):
+        S = int(rng.choice([rng.integers(4, 49), rng.integers(49, 97), rng.integers(97, 145), rng.integers(145, 200)], p=[0.35, 0.4, 0.2, 0.05]))
+        F = int(rng.choice([0, rng.integers(1, 49), rng.integers(49, 97), rng.integers(97, 145), rng.integers(145, 180)], p=[0.1, 0.35, 0.35, 0.15, 0.05]))
+        N, res = int(rng.integers(1, 4)), int(rng.integers(2, 7))
+        hw = (int(rng.integers(4, 40)), int(rng.integers(4, 40)))
+        white_back, disparity = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) == 0)
+        per_ray = (not disparity) and bool(rng.integers(0, 4) == 0)
+        planes, dec, o, d, nc, nf = _random_scene(int(rng.integers(1 << 30)), N, res, S, F, hw)
+        wild = bool(rng.integers(0, 3) == 0)
+        if wild:
+            planes = planes * float(10 ** rng.uniform(-4, 4))
+            ws = float(10 ** rng.uniform(-3, 3))
+            dec = [t * ws for t in dec]
+        interleaved = bool(rng.integers(0, 2))
+        if only is not None and case not in only:
+            continue
+        rs, re = 2.25, 3.3
+        if per_ray:
+            g = torch.Generator().manual_seed(case)
+            rs = 2.0 + 0.5 * torch.rand(N, res * res, 1, generator=g)
+            re = rs + 0.6 + 0.6 * torch.rand(N, res * res, 1, generator=g)
+        opts = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=rs, ray_end=re, box_warp=1.0, clamp_mode='softplus',
+                    white_back=white_back, disparity_space_sampling=disparity)
+        ref_rgb, ref_depth, ref_w = R.render(planes, dec, o, d, opts, nc, nf)
+        floor = w_floor = 0.0
+        floors = []
+        if wild:
+            dd = lambda t: t.double() if isinstance(t, torch.Tensor) else t
+            ex_rgb, _, ex_w = R.render(planes.double(), [t.double() for t in dec], o.double(), d.double(), dict(opts, ray_start=dd(rs), ray_end=dd(re)), nc.double(), nf.double())
+            floors = [float(((ref_rgb.double() - ex_rgb) ** 2).mean())]
+            w_floor = float((ref_w.double() - ex_w).abs().max())
+            for pl2, dec2 in permuted_decoders(dec, planes, orders):
+                v_rgb, _, v_w = R.render(pl2, list(dec2), o, d, opts, nc, nf)
+                # the 32 output colours keep their order (w2's rows are not permuted), so the images compare directly
+                floors.append(float(((v_rgb.double() - ex_rgb) ** 2).mean()))
+                w_floor = max(w_floor, float((v_w.double() - ex_w).abs().max()))
+            with sequential_fp32_decoder():
+                v_rgb, _, v_w = R.render(planes, dec, o, d, opts, nc, nf)
+            floors.append(float(((v_rgb.double() - ex_rgb) ** 2).mean()))
+            w_floor = max(w_floor, float((v_w.double() - ex_w).abs().max()))
+            gp = torch.Generator().manual_seed(4321)
+            jitter = lambda t: t.double() * (1 + 8 * 2.0 ** -24 * torch.randn(t.shape, generator=gp, dtype=torch.float64))
+            for _ in range(3):                      # (b) the conditioning of the problem: float64 on inputs perturbed at the fp32 level
+                p_rgb, _, p_w = R.render(jitter(planes), [jitter(t) for t in dec], o.double(), d.double(), dict(opts, ray_start=dd(rs), ray_end=dd(re)), nc.double(), nf.double())
+                floors.append(float(((p_rgb - ex_rgb) ** 2).mean()))
+                w_floor = max(w_floor, float((p_w - ex_w).abs().max()))
+            floor = max(floors)
+        if interleaved:
+            nhwc = planes.to(dev).reshape(N, 96, *hw).permute(0, 2, 3, 1).contiguous()
+        else:
+            nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
+        to = lambda t: t.to(dev) if isinstance(t, torch.Tensor) else t
+        rgb, depth, wsum = gnerf_hip.render_forward(nhwc, N, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev) if F else None,
+                                                    depth_resolution=S, depth_resolution_importance=F, ray_start=to(rs), ray_end=to(re), box_warp=1.0,
+                                                    white_back=white_back, disparity_space_sampling=disparity, image_width=res)
+        mse = float(((rgb.cpu() - ref_rgb) ** 2).mean()) if not wild else float(((rgb.cpu().double() - ex_rgb) ** 2).mean())
+        # depth = sum(w t) / sum(w): where a ray's weight sum is tiny (wild magnitudes: density ~ 0) the quotient is ill-conditioned in fp32 --
+        # the fp32 oracle itself is then off by ~4e-7 in the weight sum against the float64 oracle -- so depth is compared on rays with
+        # a weight sum of at least 1e-2 (seed 31 found six such rays in 1 500 cases: weight sums of 3e-7 .. 3e-4, depth off by 1e-3 .. 4e-2)
+        well = ref_w >= 1e-2
+        de = float(((depth.cpu() - ref_depth).abs() * well).max())
+        we = float((wsum.cpu() - ref_w).abs().max()) if not wild else float((wsum.cpu().double() - ex_w).abs().max())
+        worst = {'mse': max(worst['mse'], mse), 'depth': max(worst['depth'], de), 'wsum': max(worst['wsum'], we),
+                 'mse_over_floor': max(worst['mse_over_floor'], mse / floor if floor >= 2.5e-9 else 0.0)}
+        if not torch.isfinite(rgb).all() or not torch.isfinite(wsum).all():
+            mse = float('inf')
+        if floor >= 1e-9:
+            de = 0.0                                # depth of an ill-conditioned scene is not compared
+        if not (mse < max(1e-8, mult * floor) and de < 5e-4 and we < max(5e-4, mult * w_floor)):
+            rec = dict(case=case, wild=wild, interleaved=interleaved, floor=floor, floors=floors, choice=gnerf_hip.last_mlp_choice(dev), S=S, F=F, N=N, res=res, hw=hw,
+                       white_back=white_back, disparity=disparity, per_ray=per_ray, mse=mse, depth=de, wsum=we, planes_absmax=float(planes.abs().max()), w1_absmax=float(dec[0].abs().max()))
+            if verbose:
+                if wild:                            # where does the error sit?  the worst outputs of this path and of the fp32 oracle against float64
+                    eh, er = (rgb.cpu().double() - ex_rgb).abs(), (ref_rgb.double() - ex_rgb).abs()
+                    top = torch.topk(eh.flatten(), 5)
+                    rec['hip_vs_f64'] = dict(n_above_1e3=int((eh > 1e-3).sum()), n_above_1e4=int((eh > 1e-4).sum()), sum_sq=float((eh ** 2).sum()),
+                                             top=[(int(i), float(v), float(er.flatten()[i])) for v, i in zip(top.values, top.indices)])
+                    rec['ref32_vs_f64'] = dict(n_above_1e3=int((er > 1e-3).sum()), n_above_1e4=int((er > 1e-4).sum()), sum_sq=float((er ** 2).sum()), max=float(er.max()))
+                print(json.dumps(rec))
+            fails.append(rec)
+        if progress and (case + 1) % 50 == 0:
+            print(json.dumps({'done': case + 1, 'failures': len(fails), 'worst': worst}), file=progress, flush=True)
+    return {'cases': n_cases, 'seed': seed, 'criterion': f'wild cases against float64 at {mult} x the noise floor ({orders + 2} fp32 evaluation orders, 3 perturbed float64 evaluations); others 1e-8 against fp32', 'worst': worst, 'failures': fails}
+
+
+if __name__ == '__main__':
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    only = set(int(v) for v in os.environ['FUZZ_ONLY'].split(',')) if os.environ.get('FUZZ_ONLY') else None     # re-run these cases of the sequence
+    out = run(n_cases, seed, only=only, verbose=only is not None, progress=sys.stderr)
+    print(json.dumps(out))
+    sys.exit(1 if out['failures'] else 0)

@@ -41,3 +41,4 @@ def test_config5_training_step_matches_reference_fixture(golden):
     C.compare_norms(d_norms, g['d_names'], g['d_grad_norms'], 5e-3, 'D')
     np.testing.assert_allclose(G.decoder.net[0].weight.grad.numpy(), g['g_grad_decoder_w1'], rtol=5e-3, atol=1e-6)
     np.testing.assert_allclose(D.b4.out.weight.grad[:4, :64].numpy(), g['d_grad_out_w'], rtol=5e-3, atol=1e-7)
+    C.compare_whole_gradients(G, D, golden('train_step_grads.npz'), 1e-3, 'cpu fp32')

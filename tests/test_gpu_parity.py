@@ -311,6 +311,18 @@ def test_render_full_size_properties(dev):
         assert torch.equal(x, y) and torch.equal(x, z)
 
 
+def test_render_fuzz_slice(dev):
+    """The first 200 cases of tests/parity_tools/fuzz_render.py's seed-31 sequence (the sweep that profiles/r0N_fuzz.jsonl records at full
+    length) inside the suite, at the suite's own criterion: rgb MSE < max(1e-8, 4 x the fp32 noise floor), every kernel, both plane
+    layouts, a third of the cases at wild magnitudes (both decoder arithmetics)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'parity_tools'))
+    import fuzz_render
+    out = fuzz_render.run(200, 31, mult=4.0)
+    assert out['failures'] == [], out['failures'][:3]
+    assert out['worst']['mse'] < 1e-5 and out['worst']['wsum'] < 5e-3
+
+
 def _scaled_scene(plane_scale, weight_scale, S, F, res=8):
     planes, dec, o, d, nc, nf = _random_scene(31, N=2, res=res, S=S, F=F, hw=(24, 20), scale=1.0)
     return planes * plane_scale, [t * weight_scale for t in dec], o, d, nc, nf
@@ -397,6 +409,24 @@ def test_planes_absmax(dev):
     assert torch.isnan(gnerf_hip.planes_to_nhwc(x, with_absmax=True)[1]).all() and torch.isnan(gnerf_hip.planes_absmax(x)).all()
     x[0, 0, 0, 0, 0] = float('inf')
     assert float(gnerf_hip.planes_absmax(x)) == float('inf')
+
+
+def test_planes_absmax_contract_debug_check(dev, monkeypatch):
+    """include/gnerf_hip.h: a caller-supplied planes_absmax must bound max |planes| of the call's planes.  GNERF_VERIFY_ABSMAX=1 makes
+    gnerf_render_forward check it: an exact value and an upper bound pass, a stale (too small) value is refused."""
+    import gnerf_hip
+    planes, dec, o, d, nc, nf = _random_scene(3, N=1, res=4, S=48, F=48, hw=(16, 16))
+    nhwc, amax = gnerf_hip.planes_to_nhwc(planes.to(dev), with_absmax=True)
+    args = (nhwc, 1, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev))
+    kw = dict(depth_resolution=48, depth_resolution_importance=48, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=4)
+    monkeypatch.setenv('GNERF_VERIFY_ABSMAX', '1')
+    a = gnerf_hip.render_forward(*args, planes_absmax=amax, **kw)
+    b = gnerf_hip.render_forward(*args, planes_absmax=amax * 3, **kw)
+    assert torch.equal(a[0], b[0])
+    with pytest.raises(RuntimeError, match='planes_absmax'):
+        gnerf_hip.render_forward(*args, planes_absmax=amax * 0.5, **kw)
+    monkeypatch.delenv('GNERF_VERIFY_ABSMAX')
+    gnerf_hip.render_forward(*args, planes_absmax=amax * 0.5, **kw)          # unchecked in production: the caller's responsibility
 
 
 def test_render_interleaved_plane_layout(dev):
@@ -1351,6 +1381,8 @@ def test_config5_training_step_gpu_vs_reference_fixture(dev, golden):
     C.compare_norms(d_norms, g['d_names'], g['d_grad_norms'], 2e-2, 'D')
     w1g = G.decoder.net[0].weight.grad.cpu()
     assert _rel_l2(w1g, torch.from_numpy(g['g_grad_decoder_w1'])) < 5e-3
+    # three whole tensors elementwise (backbone, superresolution, discriminator): relative L2 <= 1e-3 in fp32
+    C.compare_whole_gradients(G, D, golden('train_step_grads.npz'), 1e-3, 'gpu fp32')
     # the reference's GPU precision policy: fp16 superresolution and discriminator blocks
     parts16, gen16, g16, d16 = C.run_config5(G, D, dev, force_fp32=False)
     assert gen16['image'].dtype == torch.float32 and all(np.isfinite(v) for v in parts16.values())
