@@ -270,8 +270,10 @@ extern "C" int gnerf_planes_absmax(const float* planes, int64_t numel, float* ab
     if (numel < 1) return fail(GNERF_E_ARG, "planes_absmax: empty tensor");
     if (reinterpret_cast<uintptr_t>(planes) & 15) return fail(GNERF_E_ARG, "planes_absmax: planes must be 16-byte aligned");
     if (hipMemsetAsync(absmax, 0, sizeof(float), as_stream(stream)) != hipSuccess) return fail(GNERF_E_LAUNCH, "planes_absmax: memset failed");
-    int64_t blocks = (numel / 4 + 255) / 256;
-    if (blocks > kNumCU * 8) blocks = kNumCU * 8;
+    // every lane makes `trips` trips of eight vectors: size the grid so that the trips cover the tensor without a mostly-clamped last one
+    const int64_t n4 = numel / 4, per_trip = int64_t(256) * 8;
+    const int64_t trips = (n4 + per_trip * kNumCU * 8 - 1) / (per_trip * kNumCU * 8);
+    int64_t blocks = trips > 0 ? (n4 + per_trip * trips - 1) / (per_trip * trips) : 1;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), planes, numel, reinterpret_cast<unsigned*>(absmax));
     return check_launch("planes_absmax");

@@ -234,12 +234,15 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
             const int i = lane + 64 * q;
             if (i < F) {
                 const float u = sl.nf[i];
-                int cnt = 0;                                               // searchsorted(cdf, u, right=True) = #{cdf <= u}
-#pragma unroll 4                                       // 16 keys in flight per batch: enough to cover the LDS latency, few registers
-                for (int o2 = 0; o2 < kPipeMaxS; o2 += 4) {                // cdf[n_w+1 ...] = +inf
-                    const v4f c4 = *reinterpret_cast<const v4f*>(sl.cdf + o2);
+                // searchsorted(cdf, u, right=True) = #{cdf <= u}.  The cdf ascends (a running sum of positive terms; its tail is +inf),
+                // so the count is found by bisection: log2 steps of one LDS word each instead of a compare + add-with-carry per key
+                // (96 vector instructions and 12 wide LDS reads per ray at 48 keys).  The reads are dependent, ~64 cycles apiece, on the
+                // wave that has the slack for them (tools/stamps.py: a third of its time is spent waiting at the step barriers).
+                int cnt = 0;
 #pragma unroll
-                    for (int c2 = 0; c2 < 4; c2++) cnt += (c4[c2] <= u) ? 1 : 0;
+                for (int step = (kPipeMaxS >= 64 ? (kPipeMaxS >= 128 ? 128 : 64) : 32); step > 0; step >>= 1) {
+                    const int probe = cnt + step;                          // is cdf[probe - 1] <= u, i.e. are there at least `probe` such entries?
+                    if (probe <= kPipeMaxS && sl.cdf[probe - 1] <= u) cnt = probe;
                 }
                 const int below = max(cnt - 1, 0), above = min(cnt, n_w);
                 sl.rank_e[fine_e0 + i] = below;                            // the sample's bin, for the merge (finalize)
