@@ -325,7 +325,18 @@ def backward_times(dev, planes_cl, dec, c2w, intr, reps=5):
     samples = rays * (S_COARSE + S_FINE)
     flops = samples * FLOP_BWD_PER_SAMPLE
     atom_bytes = samples * 12 * 32 * 4                  # one 4-byte add per tap and channel: what grid_sampler_2d_backward issues too
-    passes = gnerf_hip.last_backward_pass_ms() if hasattr(gnerf_hip, 'last_backward_pass_ms') else None
+    # the two passes of the staged form separately: from the committed rocprofv3 profile of the same call (tools/prof_bwd.sh)
+    passes = None
+    try:
+        prof = json.load(open(os.path.join(ROOT, 'profiles', 'r03_backward_profile.json')))['staged']
+        p1, p2 = prof['render_bwd_kernel<true>'], prof['plane_scatter_kernel']
+        passes = {'source': 'profiles/r03_backward_profile.json (rocprofv3 --kernel-trace --stats and --pmc TCC_EA0_ATOMIC_sum of tools/bench_bwd.py 4 128)',
+                  'pass1_render_bwd_kernel_ms': p1['avg_ms'], 'pass2_plane_scatter_kernel_ms': p2['avg_ms'],
+                  'pass1_fp32_mfma_frac': flops / (p1['avg_ms'] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                  'pass2_atomic_requests': p2['TCC_EA0_ATOMIC_sum'],
+                  'pass2_atomic_frac': p2['TCC_EA0_ATOMIC_sum'] * 64 / (p2['avg_ms'] * 1e-3) / 1e9 / PEAK_ATOMIC_GBS}
+    except Exception:
+        pass
     out = {'workload': 'gnerf_render_backward at config 2 (4 x 128^2 rays, 48+48 samples), planes in the producer layout',
            'call_ms': {'staged_scatter': staged, 'single_pass': direct, 'decoder_gradients_only': dec_only},
            'ratio_to_forward_kernel': None,
@@ -335,7 +346,7 @@ def backward_times(dev, planes_cl, dec, c2w, intr, reps=5):
            'scatter_atomics': {'algorithmic_GBs_single_pass': atom_bytes / (direct * 1e-3) / 1e9, 'peak_GBs': PEAK_ATOMIC_GBS,
                                'frac_single_pass': atom_bytes / (direct * 1e-3) / 1e9 / PEAK_ATOMIC_GBS,
                                'note': 'one fp32 atomic per tap and channel (147 KB per ray) against the chip-wide float-atomic rate; the staged form issues '
-                                       '~3.8x fewer (profiles/r02_backward_profile.json: TCC_EA0_ATOMIC 149.2 M -> 39.9 M per launch)'}}
+                                       '~3.8x fewer 64-byte requests (profiles/r03_backward_profile.json: TCC_EA0_ATOMIC 149.2 M -> 39.9 M per launch)'}}
     if passes:
         out['pass_ms'] = passes
     return out

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Backward kernels at BASELINE config 2 under rocprofv3 (run on the GPU box through gpurun): kernel stats, then the atomic
 # request counters in their own --pmc passes, for the staged (two-pass) and the single-pass forms.
-#   -> gpurun_out/r02_backward_profile.json
+#   -> gpurun_out/${RND:-r03}_backward_profile.json
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp BWD_TORCH=0
 out=$R/gpurun_out/prof_bwd
@@ -37,7 +37,7 @@ for form in ('staged', 'single'):
             for ctr, vals in ctrs.items():
                 r[k][ctr] = round(sum(vals) / len(vals), 1)
     res[form] = r
-json.dump(res, open('gpurun_out/r02_backward_profile.json', 'w'), indent=1)
+json.dump(res, open("gpurun_out/" + os.environ.get("RND", "r03") + "_backward_profile.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
 rm -rf $out
