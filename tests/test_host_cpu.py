@@ -288,7 +288,7 @@ def test_custom_ops_plugin_surface():
 @pytest.mark.skipif(not os.path.isdir('/root/reference/g_nerf'), reason='reference tree only exists in the build container')
 def test_overlay_resolves_reference_modules():
     """With g-nerf_amd/ BEFORE the reference's g_nerf/ on sys.path, hot-path modules come from this repo
-    and everything else (persistence, misc, conv2d_resample, triplane ...) from the reference -- the
+    and everything else (persistence, misc, conv2d_gradfix, triplane ...) from the reference -- the
     drop-in arrangement INTEGRATION.md describes.  Run in a child process to keep sys.path clean."""
     code = r'''
 import sys, types, torch
@@ -296,10 +296,11 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, "/root/reference/g_nerf"); sys.path.insert(0, %r)
 tvr = types.ModuleType("torchvision.models.resnet"); tvr.ResNet = type("ResNet", (torch.nn.Module,), {}); tvr.Bottleneck = type("B", (torch.nn.Module,), {})
 sys.modules.update({"torchvision": types.ModuleType("torchvision"), "torchvision.models": types.ModuleType("torchvision.models"), "torchvision.models.resnet": tvr})
-import torch_utils.ops.bias_act as ba, torch_utils.persistence as pe, torch_utils.ops.conv2d_resample as cr
+import torch_utils.ops.bias_act as ba, torch_utils.persistence as pe, torch_utils.ops.conv2d_resample as cr, torch_utils.ops.conv2d_gradfix as gf, torch_utils.ops.fma as fm
 import training.volumetric_rendering.renderer as rr, training.triplane as tp
 assert "g-nerf_amd" in ba.__file__ and "g-nerf_amd" in rr.__file__, (ba.__file__, rr.__file__)
-assert "/root/reference" in pe.__file__ and "/root/reference" in cr.__file__ and "/root/reference" in tp.__file__
+assert "/root/reference" in pe.__file__ and "/root/reference" in gf.__file__ and "/root/reference" in tp.__file__
+assert "g-nerf_amd" in cr.__file__ and "g-nerf_amd" in fm.__file__ and cr.conv2d_gradfix is gf          # round 3: the two caller modules are overlaid too
 assert tp.ImportanceRenderer is rr.ImportanceRenderer
 import torch_utils.ops.upfirdn2d as up
 assert cr.upfirdn2d is up and "g-nerf_amd" in up.__file__
