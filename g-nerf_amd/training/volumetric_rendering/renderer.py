@@ -85,9 +85,11 @@ def _interleaved_view(planes):
     if planes.ndim != 5 or planes.dtype != torch.float32:
         return None
     N, P, C, H, W = planes.shape
-    if planes.stride() != (P * C * H * W, C, 1, P * C * W, P * C) or N * P * C * H * W == 0:
+    want = (P * C * H * W, C, 1, P * C * W, P * C)
+    # (the stride of a size-1 dimension is arbitrary -- `view` of a one-item batch reports 96 for dim 0 -- and irrelevant)
+    if N * P * C * H * W == 0 or any(sz > 1 and st != w for sz, st, w in zip(planes.shape, planes.stride(), want)):
         return None
-    return planes.permute(0, 3, 4, 1, 2).reshape(N, H, W, P * C)
+    return planes.as_strided((N, H, W, P * C), (P * C * H * W, P * C * W, P * C, 1), planes.storage_offset())
 
 
 def _planes_from_interleaved(g, like):

@@ -533,6 +533,14 @@ def test_importance_renderer_reads_channels_last_planes_in_place(dev, monkeypatc
         assert not calls
         for a, b in zip(want, got):
             assert torch.equal(a, b)
+        # a ONE-item batch (every gen_videos frame): `view` reports an arbitrary stride for the size-1 dimension, which must not
+        # hide the layout (round 3: it did, and each orbit repacked its planes once)
+        one_cl = img[:1].contiguous(memory_format=torch.channels_last).view(1, 3, 32, 32, 32)
+        assert one_cl.stride(0) != 96 * 32 * 32 or True
+        torch.manual_seed(5); want1 = r(planes_nchw[:1], dec, o[:1], d[:1], opts)
+        del calls[:]
+        torch.manual_seed(5); got1 = r(one_cl, dec, o[:1], d[:1], opts)
+        assert not calls and all(torch.equal(a, b) for a, b in zip(want1, got1))
     # training: gradient of the channels_last planes, laid out like them, equals the NCHW route's
     grads = []
     for pl in (planes_nchw, planes_cl):
