@@ -58,6 +58,7 @@ struct Params {
     int split_shift;        // small launches: a 16-ray tile is shared by 1 << split_shift workgroups (coop / generic / backward kernels)
     int pipe_unit;          // pipelined kernel: rays dealt to a workgroup at a time (kPipeUnit; fewer for launches that do not fill the chip)
     unsigned tex_pitch, row_pitch, plane_pitch;     // byte addressing of a texel, see plane_taps (render_coop.inl)
+    int64_t item_bytes;     // bytes from one item's planes to the next: 3 * H * W * 128, or 0 when every item reads the same planes (planes_shared)
     const float* absmax;    // GNERF_MLP_AUTO: max |planes| (one device float) for choose_mlp
 };
 
@@ -405,11 +406,26 @@ __device__ __forceinline__ void march(const float* t, const float* sig, float* w
 // (Also tried: letting the last render workgroup to finish apply the clamp itself for small launches, to save the second
 // launch -- the device-scope fences that needs at the end of every workgroup cost more than the launch: 86 -> 118 us per
 // 64x64-ray frame.)
-__device__ __forceinline__ void publish_depth_range(const Params& P, float blk_min, float blk_max) {
-    unsigned* ws = static_cast<unsigned*>(P.p.workspace);
+// depth_clamp_per_item: one (min, max) pair per item at words [16 + 2 item], [17 + 2 item] instead of the call-wide pair.
+constexpr int kClampItemWord0 = 16, kClampMaxItems = 4096;
+__device__ __forceinline__ void publish_depth_range(const Params& P, float blk_min, float blk_max, int item = 0) {
+    unsigned* ws = static_cast<unsigned*>(P.p.workspace) + (P.p.depth_clamp_per_item ? kClampItemWord0 + 2 * item : 0);
     atomicMax(ws + 0, ~ord_encode(blk_min));
     atomicMax(ws + 1, ord_encode(blk_max));
 }
+// A workgroup's running depth range, published per item when the clamp is per item (a workgroup's rays may span items).
+struct DepthRange {
+    float mn = INFINITY, mx = -INFINITY;
+    int item = -1;
+    __device__ __forceinline__ void add(const Params& P, int it, float lo, float hi) {
+        if (P.p.depth_clamp_per_item && it != item) { flush(P); item = it; }
+        mn = fminf(mn, lo); mx = fmaxf(mx, hi);
+    }
+    __device__ __forceinline__ void flush(const Params& P) {
+        if (mn <= mx) publish_depth_range(P, mn, mx, item < 0 ? 0 : item);
+        mn = INFINITY; mx = -INFINITY;
+    }
+};
 
 __global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
     extern __shared__ __align__(16) float smem[];
@@ -442,7 +458,7 @@ __global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
     load_weights(w, p, lane);
     const int fine_e0 = 16 * P.tiles_c;
     const int n_all = S + F;
-    float blk_min = INFINITY, blk_max = -INFINITY;
+    DepthRange range;
 
     for (int rr = rr_first; rr < rr_first + rr_count; rr++) {
         // ---- which ray
@@ -459,7 +475,7 @@ __global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
         const int item = int(ray / p.rays_per_item);
         const float ox = p.ray_origins[ray * 3 + 0], oy = p.ray_origins[ray * 3 + 1], oz = p.ray_origins[ray * 3 + 2];
         const float dx = p.ray_dirs[ray * 3 + 0], dy = p.ray_dirs[ray * 3 + 1], dz = p.ray_dirs[ray * 3 + 2];
-        const float* planes_item = p.planes_nhwc + int64_t(item) * 3 * p.plane_h * p.plane_w * 32;
+        const float* planes_item = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.planes_nhwc) + int64_t(item) * P.item_bytes);
         float* dbg = p.debug ? p.debug + ray * GNERF_DEBUG_SLOTS * n_all : nullptr;
 
         // ---- stratified depth proposals (renderer.py:169-192)
@@ -502,8 +518,7 @@ __global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
                 for (int k = lane; k < n_all; k += 64) { dbg[GNERF_DBG_DEPTH_SORTED * n_all + k] = lds.s_t[k]; dbg[GNERF_DBG_SIGMA_SORTED * n_all + k] = lds.s_sig[k]; }
                 for (int k = lane; k < n_all - 1; k += 64) dbg[GNERF_DBG_WEIGHT_FINAL * n_all + k] = lds.w_s[k];
             }
-            blk_min = fminf(blk_min, lds.s_t[0]);
-            blk_max = fmaxf(blk_max, lds.s_t[n_all - 1]);
+            range.add(P, item, lds.s_t[0], lds.s_t[n_all - 1]);
         } else {
             march(lds.t_e, lds.sig_e, lds.w_s, S, lane, w_sum, wt_sum);
             __syncthreads();
@@ -517,8 +532,7 @@ __global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
             for (int k = lane; k < S; k += 64) { mn = fminf(mn, lds.t_e[k]); mx = fmaxf(mx, lds.t_e[k]); }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
-            blk_min = fminf(blk_min, mn);
-            blk_max = fmaxf(blk_max, mx);
+            range.add(P, item, mn, mx);
         }
         __syncthreads();
 
@@ -550,20 +564,31 @@ __global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
         }
         __syncthreads();
     }
-    if (lane == 0) publish_depth_range(P, blk_min, blk_max);
+    if (lane == 0) range.flush(P);
 }
 
 // The clamp.  The last block to finish puts the workspace back to idle.
 constexpr int kClampPerThread = 4;
-__global__ __launch_bounds__(256) void clamp_depth_kernel(float* depth, unsigned* ws, int64_t n) {
-    const float lo = ord_decode(~ws[0]), hi = ord_decode(ws[1]);
+__global__ __launch_bounds__(256) void clamp_depth_kernel(float* depth, unsigned* ws, int64_t n, int rays_per_item, int n_items_per_item_clamp) {
+    const bool per_item = n_items_per_item_clamp > 0;
+    float lo = 0.f, hi = 0.f;
+    if (!per_item) { lo = ord_decode(~ws[0]); hi = ord_decode(ws[1]); }
 #pragma unroll
     for (int k = 0; k < kClampPerThread; k++) {
         const int64_t i = (int64_t(blockIdx.x) * kClampPerThread + k) * 256 + threadIdx.x;
-        if (i < n) depth[i] = fminf(fmaxf(depth[i], lo), hi);   // torch.clamp(x, min, max)
+        if (i < n) {
+            if (per_item) { const unsigned* w = ws + kClampItemWord0 + 2 * int(i / rays_per_item); lo = ord_decode(~w[0]); hi = ord_decode(w[1]); }
+            depth[i] = fminf(fmaxf(depth[i], lo), hi);   // torch.clamp(x, min, max)
+        }
     }
     __syncthreads();                                             // every thread of the block has read (and used) the range
-    if (threadIdx.x == 0 && atomicAdd(ws + 3, 1u) == gridDim.x - 1) { ws[0] = 0u; ws[1] = 0u; ws[3] = 0u; }
+    __shared__ int last;
+    if (threadIdx.x == 0) last = atomicAdd(ws + 3, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (last) {                                                  // the last block puts the workspace back to idle
+        if (threadIdx.x == 0) { ws[0] = 0u; ws[1] = 0u; ws[3] = 0u; }
+        for (int i = threadIdx.x; i < 2 * n_items_per_item_clamp; i += 256) ws[kClampItemWord0 + i] = 0u;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -736,7 +761,7 @@ int check_common(const gnerf_render_params* p) {
     if (!p) return fail(GNERF_E_ARG, "render: params is null");
     if (!p->planes_nhwc || !p->w1 || !p->b1 || !p->w2 || !p->b2) return fail(GNERF_E_ARG, "render: planes and decoder weights must not be null");
     if (p->n_items < 1 || p->plane_h < 1 || p->plane_w < 1) return fail(GNERF_E_ARG, "render: bad plane shape");
-    if (int64_t(p->n_items) * 3 * p->plane_h * p->plane_w * 32 > INT32_MAX * int64_t(4))
+    if (int64_t(p->planes_shared ? 1 : p->n_items) * 3 * p->plane_h * p->plane_w * 32 > INT32_MAX * int64_t(4))
         return fail(GNERF_E_ARG, "render: planes too large");
     if (!(p->box_warp > 0.f)) return fail(GNERF_E_ARG, "render: box_warp must be positive");
     if (p->planes_interleaved != 0 && p->planes_interleaved != 1) return fail(GNERF_E_ARG, "render: planes_interleaved must be 0 or 1");
@@ -752,7 +777,7 @@ void fill_pitches(Params& P) {
 
 }  // namespace
 
-extern "C" size_t gnerf_render_workspace_bytes(void) { return 64; }
+extern "C" size_t gnerf_render_workspace_bytes(void) { return size_t(kClampItemWord0 + 2 * kClampMaxItems) * 4; }
 
 // Validation and derived launch parameters shared by the forward and backward entry points.
 static int fill_params(const gnerf_render_params* p, Params& P) {
@@ -771,6 +796,10 @@ static int fill_params(const gnerf_render_params* p, Params& P) {
 
     P.p = *p;
     fill_pitches(P);
+    if ((p->planes_shared != 0 && p->planes_shared != 1) || (p->depth_clamp_per_item != 0 && p->depth_clamp_per_item != 1))
+        return fail(GNERF_E_ARG, "render: planes_shared and depth_clamp_per_item must be 0 or 1");
+    if (p->depth_clamp_per_item && p->n_items > kClampMaxItems) return fail(GNERF_E_ARG, "render: depth_clamp_per_item supports at most %d items", kClampMaxItems);
+    P.item_bytes = p->planes_shared ? 0 : int64_t(3) * p->plane_h * p->plane_w * 128;
     if (P.row_pitch >= (1u << 24)) return fail(GNERF_E_UNSUPPORTED, "render: plane rows wider than 2^24 bytes");
     P.box_scale = float(2.0 / double(p->box_warp));
     P.delta = float((double(p->ray_end) - double(p->ray_start)) / double(S - 1));
@@ -838,7 +867,7 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         if (P.absmax && getenv("GNERF_VERIFY_ABSMAX") && !strcmp(getenv("GNERF_VERIFY_ABSMAX"), "1")) {
             // debug aid (include/gnerf_hip.h, planes_absmax contract): is the caller's value an upper bound of THESE planes?
             float* own = reinterpret_cast<float*>(static_cast<int*>(p->workspace) + 5);
-            if (int e = gnerf_planes_absmax(p->planes_nhwc, int64_t(p->n_items) * 3 * p->plane_h * p->plane_w * 32, own, stream)) return e;
+            if (int e = gnerf_planes_absmax(p->planes_nhwc, int64_t(p->planes_shared ? 1 : p->n_items) * 3 * p->plane_h * p->plane_w * 32, own, stream)) return e;
             float mine = 0.f, theirs = 0.f;
             if (hipMemcpyAsync(&mine, own, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipMemcpyAsync(&theirs, P.absmax, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
                 hipStreamSynchronize(s) != hipSuccess)
@@ -848,7 +877,7 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         }
         if (!P.absmax) {
             float* own = reinterpret_cast<float*>(static_cast<int*>(p->workspace) + 5);
-            if (int e = gnerf_planes_absmax(p->planes_nhwc, int64_t(p->n_items) * 3 * p->plane_h * p->plane_w * 32, own, stream)) return e;
+            if (int e = gnerf_planes_absmax(p->planes_nhwc, int64_t(p->planes_shared ? 1 : p->n_items) * 3 * p->plane_h * p->plane_w * 32, own, stream)) return e;
             P.absmax = own;
         }
     }
@@ -910,7 +939,7 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         if (int e = check_launch("render_kernel_generic")) return e;
     }
     hipLaunchKernelGGL(clamp_depth_kernel, dim3((unsigned)((total + 256 * kClampPerThread - 1) / (256 * kClampPerThread))), dim3(256), 0, s,
-                       p->out_depth, static_cast<unsigned*>(p->workspace), total);
+                       p->out_depth, static_cast<unsigned*>(p->workspace), total, p->rays_per_item, p->depth_clamp_per_item ? p->n_items : 0);
     return check_launch("clamp_depth_kernel");
 }
 
@@ -919,6 +948,7 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
     Params P;
     if (int e = fill_params(p, P)) return e;
     if (!g) return fail(GNERF_E_ARG, "render_backward: grads is null");
+    if (p->planes_shared) return fail(GNERF_E_UNSUPPORTED, "render_backward: planes_shared is a forward-only option");
     const int n_dec = (g->grad_w1 != nullptr) + (g->grad_b1 != nullptr) + (g->grad_w2 != nullptr) + (g->grad_b2 != nullptr);
     if (n_dec != 0 && n_dec != 4) return fail(GNERF_E_ARG, "render_backward: the four decoder gradients are given together or not at all");
     if (!g->grad_planes_nhwc && n_dec == 0) return GNERF_OK;

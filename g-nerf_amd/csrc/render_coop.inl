@@ -560,7 +560,7 @@ __device__ __forceinline__ void render_coop_body(const Params& P, float* smem) {
 
     const int fine_e0 = 16 * P.tiles_c;
     const int n_all = S + F;
-    float blk_min = INFINITY, blk_max = -INFINITY;
+    DepthRange range;
     Stamps st;
     st.reset();
 
@@ -576,7 +576,7 @@ __device__ __forceinline__ void render_coop_body(const Params& P, float* smem) {
         }
         const int item = int(ray / p.rays_per_item);
         CoopRay R;
-        R.planes_item = reinterpret_cast<const char*>(p.planes_nhwc) + int64_t(item) * 3 * p.plane_h * p.plane_w * 128;
+        R.planes_item = reinterpret_cast<const char*>(p.planes_nhwc) + int64_t(item) * P.item_bytes;
         R.ox = p.ray_origins[ray * 3 + 0]; R.oy = p.ray_origins[ray * 3 + 1]; R.oz = p.ray_origins[ray * 3 + 2];
         R.dx = p.ray_dirs[ray * 3 + 0];    R.dy = p.ray_dirs[ray * 3 + 1];    R.dz = p.ray_dirs[ray * 3 + 2];
         float* dbg = p.debug ? p.debug + ray * GNERF_DEBUG_SLOTS * n_all : nullptr;
@@ -729,7 +729,7 @@ __device__ __forceinline__ void render_coop_body(const Params& P, float* smem) {
             __syncthreads();
             if (wv == 0) {
                 march(L.s_t, L.s_sig, L.w_s, n_all, lane, w_sum, wt_sum);
-                if (lane == 0) { L.part[kCoopWaves * 32] = w_sum; blk_min = fminf(blk_min, L.s_t[0]); blk_max = fmaxf(blk_max, L.s_t[n_all - 1]); }
+                if (lane == 0) { L.part[kCoopWaves * 32] = w_sum; range.add(P, item, L.s_t[0], L.s_t[n_all - 1]); }
             }
             __syncthreads();
             for (int q = tid; q < n_all; q += kCoopThreads) {
@@ -749,9 +749,7 @@ __device__ __forceinline__ void render_coop_body(const Params& P, float* smem) {
                 for (int k = lane; k < S; k += 64) { mn = fminf(mn, L.t_e[k]); mx = fmaxf(mx, L.t_e[k]); }
 #pragma unroll
                 for (int o2 = 32; o2 > 0; o2 >>= 1) { mn = fminf(mn, __shfl_xor(mn, o2)); mx = fmaxf(mx, __shfl_xor(mx, o2)); }
-                blk_min = fminf(blk_min, mn);
-                blk_max = fmaxf(blk_max, mx);
-                if (lane == 0) L.part[kCoopWaves * 32] = w_sum;
+                if (lane == 0) { range.add(P, item, mn, mx); L.part[kCoopWaves * 32] = w_sum; }
             }
             __syncthreads();
             for (int k = tid; k < S; k += kCoopThreads) {
@@ -806,7 +804,7 @@ __device__ __forceinline__ void render_coop_body(const Params& P, float* smem) {
         }
         __syncthreads();
     }
-    if (tid == 0) publish_depth_range(P, blk_min, blk_max);
+    if (tid == 0) range.flush(P);
 }
 
 // GNERF_MLP_AUTO: every workgroup evaluates the (cheap, deterministic) range bounds itself -- choose_mlp in render.hip -- and runs

@@ -138,7 +138,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
 
     Stamps st;
     // ------------------------------------------------------------------ scalar-wave pieces (lambdas, wave 3 only)
-    float blk_min = INFINITY, blk_max = -INFINITY;
+    DepthRange range;
     float pre_uc[RND] = {}, pre_uf[RND] = {}, pre_ray = 0.f, pre_rs = 0.f, pre_re = 0.f;       // prefetched by propose_issue
     int pre_ray_id = -1;
 
@@ -378,8 +378,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
         if (lane == 0) {
             sl.misc[8] = ws;
             sl.misc[9] = wts;
-            blk_min = fminf(blk_min, sl.s_t[0]);
-            blk_max = fmaxf(blk_max, sl.s_t[n_all - 1]);
+            range.add(P, __float_as_int(sl.misc[6]), sl.s_t[0], sl.s_t[n_all - 1]);
         }
         if (dbg) {
             for (int k = lane; k < F; k += 64) dbg[GNERF_DBG_SIGMA_FINE * n_all + k] = sl.sig_e[fine_e0 + k];
@@ -414,7 +413,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
         if (ray_id < 0) return;
         CoopRay R;
         const int item = __builtin_amdgcn_readfirstlane(__float_as_int(sl.misc[6]));
-        R.planes_item = reinterpret_cast<const char*>(p.planes_nhwc) + int64_t(item) * 3 * p.plane_h * p.plane_w * 128;
+        R.planes_item = reinterpret_cast<const char*>(p.planes_nhwc) + int64_t(item) * P.item_bytes;
         R.ox = sl.misc[0]; R.oy = sl.misc[1]; R.oz = sl.misc[2];
         R.dx = sl.misc[3]; R.dy = sl.misc[4]; R.dz = sl.misc[5];
         GNERF_STAMP(st, 0);     // ray parameters from the slot
@@ -517,7 +516,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
         out[15] = nr;
     }
 #endif
-    if (wv == 3 && lane == 0) publish_depth_range(P, blk_min, blk_max);
+    if (wv == 3 && lane == 0) range.flush(P);
 }
 
 template <int TP, int MLP, bool FULL>

@@ -216,15 +216,17 @@ std::tuple<Tensor, Tensor, Tensor> render_forward(Tensor planes_nhwc, int64_t n_
                                                   Tensor ray_origins, Tensor ray_dirs, Tensor noise_coarse, Tensor noise_fine,
                                                   int64_t depth_resolution, int64_t depth_resolution_importance, double ray_start, double ray_end,
                                                   Tensor ray_start_t, Tensor ray_end_t, double box_warp, bool white_back, bool disparity_space_sampling,
-                                                  int64_t image_width, Tensor planes_absmax, int64_t mlp_mode, Tensor workspace) {
+                                                  int64_t image_width, Tensor planes_absmax, int64_t mlp_mode, Tensor workspace,
+                                                  bool planes_shared, bool depth_clamp_per_item) {
     auto f32c = [](const Tensor& t, const char* name) {
         TORCH_CHECK(t.is_cuda() && t.scalar_type() == torch::kFloat32 && t.is_contiguous(), "render_forward: ", name, " must be a contiguous float32 GPU tensor");
     };
     f32c(planes_nhwc, "planes_nhwc"); f32c(w1, "w1"); f32c(b1, "b1"); f32c(w2, "w2"); f32c(b2, "b2");
     f32c(ray_origins, "ray_origins"); f32c(ray_dirs, "ray_dirs"); f32c(noise_coarse, "noise_coarse");
-    const bool separate = planes_nhwc.dim() == 4 && planes_nhwc.size(3) == 32 && planes_nhwc.size(0) == 3 * n_items;
-    const bool interleaved = planes_nhwc.dim() == 4 && planes_nhwc.size(3) == 96 && planes_nhwc.size(0) == n_items;
-    TORCH_CHECK(separate || interleaved, "render_forward: planes_nhwc must be [3N,H,W,32] or [N,H,W,96]");
+    const int64_t plane_items = planes_shared ? 1 : n_items;   // planes_shared: one item's planes read by all n_items items of rays
+    const bool separate = planes_nhwc.dim() == 4 && planes_nhwc.size(3) == 32 && planes_nhwc.size(0) == 3 * plane_items;
+    const bool interleaved = planes_nhwc.dim() == 4 && planes_nhwc.size(3) == 96 && planes_nhwc.size(0) == plane_items;
+    TORCH_CHECK(separate || interleaved, "render_forward: planes_nhwc must be [3N,H,W,32] or [N,H,W,96] (N = 1 when planes_shared)");
     TORCH_CHECK(w1.numel() == 64 * 32 && b1.numel() == 64 && w2.numel() == 33 * 64 && b2.numel() == 33, "render_forward: decoder must be the 32->64->33 MLP");
     TORCH_CHECK(ray_origins.dim() == 3 && ray_origins.size(0) == n_items && ray_origins.size(2) == 3 && ray_dirs.sizes() == ray_origins.sizes(), "render_forward: rays must be [N,M,3]");
     const int64_t m = ray_origins.size(1), S = depth_resolution, F = depth_resolution_importance;
@@ -255,6 +257,7 @@ std::tuple<Tensor, Tensor, Tensor> render_forward(Tensor planes_nhwc, int64_t n_
     p.planes_absmax = present(planes_absmax) ? planes_absmax.data_ptr<float>() : nullptr;
     p.mlp_mode = int32_t(mlp_mode);
     p.planes_interleaved = interleaved ? 1 : 0;
+    p.planes_shared = planes_shared ? 1 : 0; p.depth_clamp_per_item = depth_clamp_per_item ? 1 : 0;
     check_rc(gnerf_render_forward(&p, current_stream()), "gnerf_render_forward");
     return std::make_tuple(rgb, depth, wsum);
 }

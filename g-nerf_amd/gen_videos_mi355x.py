@@ -135,9 +135,12 @@ class FrameProgram:
 
 
 @torch.no_grad()
-def render_orbit(G, z, n_frames, res, device, rank=0, world=1, double_depth=True, frame_seed=None, use_graph=False, program=None):
+def render_orbit(G, z, n_frames, res, device, rank=0, world=1, double_depth=True, frame_seed=None, use_graph=False, program=None,
+                 frames_per_call=1):
     """This rank's frames of the orbit: (uint8 [n_local,512,512,3], uint8 raw [n_local,res,res,3], (lo, hi)).
-    use_graph (GPU only): frames come from a FrameProgram (`program`, or one captured here)."""
+    use_graph (GPU only): frames come from a FrameProgram (`program`, or one captured here).
+    frames_per_call > 1 (one latent only): that many cameras go through the renderer and the superresolution as one batch; the
+    renderer treats them as views of the one set of planes, each with the draws and the depth clamp of a call of its own."""
     if double_depth:                                                                        # gen_videos.py:127-128
         G.rendering_kwargs['depth_resolution'] = int(G.rendering_kwargs['depth_resolution'] * 2)
         G.rendering_kwargs['depth_resolution_importance'] = int(G.rendering_kwargs['depth_resolution_importance'] * 2)
@@ -145,22 +148,34 @@ def render_orbit(G, z, n_frames, res, device, rank=0, world=1, double_depth=True
     lo, hi = H.shard_range(n_frames, rank, world)
     if hi == lo:
         return None, None, (lo, hi)
-    cams = [H.camera_label(H.orbit_pose(i, n_frames, radius, device=device)).repeat(z.shape[0], 1) for i in range(lo, hi)]
+    k = max(int(frames_per_call), 1)
+    if k > 1 and (z.shape[0] != 1 or frame_seed is not None):
+        raise ValueError('frames_per_call > 1 needs a single latent and no per-frame reseeding')
+    # every camera of this rank's block made on the host and moved in ONE copy (per frame: a pose and an intrinsics upload, two
+    # blocking host-to-device copies in front of every frame's launches)
+    labels = torch.cat([H.camera_label(H.orbit_pose(i, n_frames, radius)) for i in range(lo, hi)]).to(device)
+    if k > 1:
+        cams = [labels[j:j + k] for j in range(0, hi - lo, k)]
+    else:
+        cams = [labels[j:j + 1].repeat(z.shape[0], 1) if z.shape[0] > 1 else labels[j:j + 1] for j in range(hi - lo)]
     frames, raws = [], []
     if (use_graph or program is not None) and device.type == 'cuda':
         assert frame_seed is None, 'per-frame reseeding and graph replay do not mix'
         if program is None:
-            program = FrameProgram(G, orbit_latents(G, z, device), res, device, batch=z.shape[0])
+            program = FrameProgram(G, orbit_latents(G, z, device), res, device, batch=z.shape[0] if k == 1 else k)
         for c in cams:
+            n = c.shape[0]
+            if n < program.c.shape[0]:                                                      # the last, shorter block of an orbit
+                c = torch.cat([c, c[-1:].expand(program.c.shape[0] - n, -1)])
             f, r = program(c)
-            frames.append(f)
-            raws.append(r)
+            frames.append(f[:n])
+            raws.append(r[:n])
     else:
         ws = orbit_latents(G, z, device)
-        for k, (i, c) in enumerate(zip(range(lo, hi), cams)):
+        for j, c in enumerate(cams):
             if frame_seed is not None:
-                torch.manual_seed(frame_seed + i)                                           # reproducible renderer draws per frame
-            out = G.synthesis(ws=ws, c=c, noise_mode='const', neural_rendering_resolution=res, cache_backbone=(k == 0), use_cached_backbone=(k > 0))
+                torch.manual_seed(frame_seed + lo + j)                                      # reproducible renderer draws per frame
+            out = G.synthesis(ws=ws, c=c, noise_mode='const', neural_rendering_resolution=res, cache_backbone=(j == 0), use_cached_backbone=(j > 0))
             frames.append(H.to_uint8(out['image']))
             raws.append(H.to_uint8(out['image_raw']))
     return torch.cat(frames), torch.cat(raws), (lo, hi)
@@ -225,6 +240,7 @@ def main():
     ap.add_argument('--no-double-depth', action='store_true', help='keep the checkpoint depth resolutions (the reference CLI doubles them)')
     ap.add_argument('--device', default='cuda' if torch.cuda.is_available() else 'cpu')
     ap.add_argument('--graph', action='store_true', help='replay the per-frame launch sequence from a captured HIP graph')
+    ap.add_argument('--frames-per-call', type=int, default=1, help='cameras per synthesis call (views of the one latent in one renderer launch)')
     ap.add_argument('--out', default=None, help='write frames to this .npy (rank 0)')
     ap.add_argument('--shapes', default=None, help='also extract the 512^3 density volume (gen_videos.py --shapes) and save it to this .npy (rank 0)')
     ap.add_argument('--voxel-res', type=int, default=512)
@@ -251,7 +267,8 @@ def main():
         import torch.distributed as dist
         dist.barrier()
     t0 = time.perf_counter()
-    frames, raws, (lo, hi) = render_orbit(G, z, args.frames, args.res, device, rank, world, double_depth=not args.no_double_depth, use_graph=args.graph)
+    frames, raws, (lo, hi) = render_orbit(G, z, args.frames, args.res, device, rank, world, double_depth=not args.no_double_depth, use_graph=args.graph,
+                                          frames_per_call=args.frames_per_call)
     full = H.gather_frames(frames, args.frames)
     if device.type == 'cuda':
         torch.cuda.synchronize()

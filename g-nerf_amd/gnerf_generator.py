@@ -491,7 +491,12 @@ class Generator(nn.Module):
         if cache_backbone:
             self._last_planes = planes
         n = planes.shape[0]
+        if n == 1 and o.shape[0] > 1:
+            # several cameras for ONE latent (an orbit's frames, gen_videos.py:150-166, batched): the renderer reads the one set of
+            # planes for every view and gives each the results of a call of its own; the superresolution sees a batch of the latent
+            ws = _per_latent(self, ws, ('views', o.shape[0]), (), lambda: ws.expand(o.shape[0], -1, -1).contiguous())
         feat, depth, _ = self.renderer(planes.view(n, 3, 32, *planes.shape[-2:]), self.decoder, o, d, self.rendering_kwargs)
+        n = o.shape[0]
         feature_image = feat.permute(0, 2, 1).reshape(n, 32, res, res).contiguous()
         depth_image = depth.permute(0, 2, 1).reshape(n, 1, res, res)
         if only_depth:                                                                          # triplane.py:83-84

@@ -23,7 +23,7 @@ _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.float64: F64}
 
 MAX_SAMPLES = 256
 DEBUG_SLOTS = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 # decoder arithmetic of the fused renderer (GNERF_MLP_* in include/gnerf_hip.h)
 MLP_MODES = {'auto': 0, 'f16x3': 1, 'f32': 2}
 
@@ -47,6 +47,7 @@ class RenderParams(ctypes.Structure):
         ('out_rgb', _c_p), ('out_depth', _c_p), ('out_wsum', _c_p),
         ('workspace', _c_p), ('debug', _c_p),
         ('planes_absmax', _c_p), ('mlp_mode', ctypes.c_int32), ('planes_interleaved', ctypes.c_int32),
+        ('planes_shared', ctypes.c_int32), ('depth_clamp_per_item', ctypes.c_int32),
     ]
 
 
@@ -722,7 +723,8 @@ def last_mlp_choice(device):
 
 def _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine,
                    depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
-                   white_back, disparity_space_sampling, image_width, what, planes_absmax=None, mlp='auto'):
+                   white_back, disparity_space_sampling, image_width, what, planes_absmax=None, mlp='auto',
+                   planes_shared=False, depth_clamp_per_item=False):
     """Validate the arguments shared by render_forward / render_backward and fill a RenderParams.
     Returns (params, keepalive, rays_per_item); `keepalive` holds the converted tensors the pointers refer to."""
     w1, b1, w2, b2 = decoder
@@ -731,7 +733,7 @@ def _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
 
     def f32c(t):
         return t.to(torch.float32).contiguous()
-    interleaved = planes_layout(planes_nhwc, n_items, what)
+    interleaved = planes_layout(planes_nhwc, 1 if planes_shared else n_items, what)
     if tuple(w1.shape) != (64, 32) or tuple(b1.shape) != (64,) or tuple(w2.shape) != (33, 64) or tuple(b2.shape) != (33,):
         raise RuntimeError(f'{what}: decoder must be the 32->64->33 OSGDecoder MLP')
     o, d = f32c(ray_origins), f32c(ray_dirs)
@@ -776,14 +778,19 @@ def _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
             raise RuntimeError(f'{what}: planes_absmax must be a one-element float32 device tensor')
     p.planes_absmax = _ptr(planes_absmax)
     p.planes_interleaved = interleaved
+    p.planes_shared = int(bool(planes_shared)); p.depth_clamp_per_item = int(bool(depth_clamp_per_item))
     return p, (planes_nhwc, o, d, nc, nf, w1, b1, w2, b2, rs_t, re_t, planes_absmax), m
 
 
 def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine, *,
                    depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
-                   white_back=False, disparity_space_sampling=False, image_width=0, debug=False, planes_absmax=None, mlp='auto'):
+                   white_back=False, disparity_space_sampling=False, image_width=0, debug=False, planes_absmax=None, mlp='auto',
+                   planes_shared=False, depth_clamp_per_item=False):
     """planes_nhwc [3N,H,W,32]; decoder = (w1,b1,w2,b2) effective fp32 weights; rays [N,M,3];
     noise_coarse [N*M,S]; noise_fine [N*M,F] or None; ray_start/ray_end floats or [N*M] tensors.
+    planes_shared: planes_nhwc holds ONE item's planes ([3,H,W,32] or [1,H,W,96]) that all N items of rays read (N views of one
+    object in one launch).  depth_clamp_per_item: the final depth clamp (ray_marcher.py:49-50) takes its range from each item's
+    own samples instead of the whole call's, so that item i's outputs equal those of a call with item i alone.
     mlp: decoder arithmetic, 'auto' (decided on the device from planes_absmax -- the one-element tensor planes_to_nhwc(...,
     with_absmax=True) returns; measured by the call itself when None -- and the decoder's weights), 'f16x3' or 'f32'.
     Returns (rgb [N,M,32], depth [N,M,1], wsum [N,M,1][, debug [N*M,8,S+F]])."""
@@ -810,10 +817,12 @@ def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
                                     f32c(noise_coarse), _EMPTY if noise_fine is None else f32c(noise_fine),
                                     int(depth_resolution), int(depth_resolution_importance), rs, re, rs_t, re_t, float(box_warp),
                                     bool(white_back), bool(disparity_space_sampling), int(image_width),
-                                    _EMPTY if planes_absmax is None else planes_absmax, MLP_MODES[mlp], _workspace(dev))
+                                    _EMPTY if planes_absmax is None else planes_absmax, MLP_MODES[mlp], _workspace(dev),
+                                    bool(planes_shared), bool(depth_clamp_per_item))
     p, keep, m = _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine,
                                 depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
-                                white_back, disparity_space_sampling, image_width, 'render_forward', planes_absmax, mlp)
+                                white_back, disparity_space_sampling, image_width, 'render_forward', planes_absmax, mlp,
+                                planes_shared, depth_clamp_per_item)
     dev = planes_nhwc.device
     rgb = torch.empty([n_items, m, 32], dtype=torch.float32, device=dev)
     depth = torch.empty([n_items, m, 1], dtype=torch.float32, device=dev)

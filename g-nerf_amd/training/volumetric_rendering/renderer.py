@@ -238,6 +238,10 @@ class ImportanceRenderer(torch.nn.Module):
         rays [N,M,3]; rendering_options: the generator's rendering_kwargs dict (unknown keys ignored).
         Returns rgb [N,M,32], depth [N,M,1], weight_sum [N,M,1]."""
         self.plane_axes = self.plane_axes.to(ray_origins.device)
+        # Extension (the reference requires one set of planes per item of rays): planes of ONE item with N > 1 items of rays are N
+        # views of that object in one call, each with the results a call of its own would give -- its own pair of uniform draws, in
+        # the order N calls would make them, and the final depth clamp (ray_marcher.py:49-50) over its own samples.
+        views = planes.shape[0] == 1 and ray_origins.shape[0] > 1
         if planes.device.type == 'cuda':
             fcs = _osg_decoder_weights(decoder)
             rays_need_grad = torch.is_grad_enabled() and (ray_origins.requires_grad or ray_directions.requires_grad)
@@ -247,6 +251,10 @@ class ImportanceRenderer(torch.nn.Module):
                 return self._forward_hip(planes, fcs, ray_origins, ray_directions, rendering_options, differentiable=needs_graph)
             if fcs is None:
                 warnings.warn('ImportanceRenderer: decoder is not the OSGDecoder MLP; using PyTorch ops', RuntimeWarning)
+        if views:
+            outs = [self._forward_torch(planes, decoder, ray_origins[i:i + 1], ray_directions[i:i + 1], rendering_options)
+                    for i in range(ray_origins.shape[0])]
+            return tuple(torch.cat(t) for t in zip(*outs))
         return self._forward_torch(planes, decoder, ray_origins, ray_directions, rendering_options)
 
     # ------------------------------------------------------------------ fused gfx950 path
@@ -322,17 +330,32 @@ class ImportanceRenderer(torch.nn.Module):
         if S > gnerf_hip.MAX_SAMPLES or F > gnerf_hip.MAX_SAMPLES:
             raise RuntimeError(f'ImportanceRenderer: at most {gnerf_hip.MAX_SAMPLES} coarse and fine samples per ray are supported')
         dev = ray_origins.device
-        if opts['ray_start'] == opts['ray_end'] == 'auto':
-            ray_start, ray_end = math_utils.get_ray_limits_box(ray_origins, ray_directions, box_side_length=opts['box_warp'])
+        views = planes.shape[0] == 1 and N > 1              # N views of one item's planes (see forward)
+        if views and differentiable:
+            raise RuntimeError('ImportanceRenderer: several views of one set of planes in one call is a forward-only form')
+
+        def limits(o, d):
+            ray_start, ray_end = math_utils.get_ray_limits_box(o, d, box_side_length=opts['box_warp'])
             ok = ray_end > ray_start
             if torch.any(ok).item():                                     # renderer.py:94-96
                 ray_start[~ok] = ray_start[ok].min()
                 ray_end[~ok] = ray_start[ok].max()
+            return ray_start, ray_end
+        if opts['ray_start'] == opts['ray_end'] == 'auto':
+            if views:                                                    # the fill-in values above are per call: per view here
+                ray_start, ray_end = (torch.cat(t) for t in zip(*[limits(ray_origins[i:i + 1], ray_directions[i:i + 1]) for i in range(N)]))
+            else:
+                ray_start, ray_end = limits(ray_origins, ray_directions)
         else:
             ray_start, ray_end = opts['ray_start'], opts['ray_end']
         # the reference's two draws, same shapes, same order (renderer.py:176/186/190 then :241)
-        noise_c = torch.rand([N, M, S, 1], device=dev, dtype=torch.float32)
-        noise_f = torch.rand(N * M, F, device=dev) if F > 0 else None
+        if views:
+            draws = [(torch.rand([1, M, S, 1], device=dev, dtype=torch.float32), torch.rand(M, F, device=dev) if F > 0 else None) for _ in range(N)]
+            noise_c = torch.cat([c for c, _ in draws])
+            noise_f = torch.cat([f for _, f in draws]) if F > 0 else None
+        else:
+            noise_c = torch.rand([N, M, S, 1], device=dev, dtype=torch.float32)
+            noise_f = torch.rand(N * M, F, device=dev) if F > 0 else None
         side = math.isqrt(M)
         if opts['clamp_mode'] != 'softplus':
             assert False, "MipRayMarcher only supports `clamp_mode`=`softplus`!"
@@ -347,7 +370,8 @@ class ImportanceRenderer(torch.nn.Module):
                                       ray_start, ray_end, cfg)
         nhwc, amax = self._planes_nhwc(planes)
         return gnerf_hip.render_forward(nhwc, N, self._decoder_cache(fcs), ray_origins.detach(), ray_directions.detach(),
-                                        noise_c, noise_f, ray_start=ray_start, ray_end=ray_end, planes_absmax=amax, **cfg)
+                                        noise_c, noise_f, ray_start=ray_start, ray_end=ray_end, planes_absmax=amax,
+                                        planes_shared=views, depth_clamp_per_item=views, **cfg)
 
     # ------------------------------------------------------------------ PyTorch-op path
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GNERF_ABI_VERSION 5
+#define GNERF_ABI_VERSION 6
 
 /* error codes */
 #define GNERF_OK            0
@@ -253,7 +253,8 @@ typedef struct gnerf_render_params {
     float* out_depth;    /* [n_items, rays_per_item, 1] */
     float* out_wsum;     /* [n_items, rays_per_item, 1]   sum of the final weights */
     /* workspace of gnerf_render_workspace_bytes() bytes (holds the call-wide depth range used by the
-       global clamp of ray_marcher.py:49-50).  ZERO it once after allocation; every call leaves it zeroed.
+       global clamp of ray_marcher.py:49-50, or one range per item: depth_clamp_per_item).  ZERO it once after allocation;
+       every call leaves it zeroed.
        One workspace per stream that renders concurrently. */
     void*  workspace;
     /* optional stage dump for debugging/parity: float32 [n*m, GNERF_DEBUG_SLOTS, S+F]; NULL in production */
@@ -283,6 +284,14 @@ typedef struct gnerf_render_params {
           backbone's own [n_items, 96, plane_h, plane_w] output (triplane.py:69-74), plane p = channels 32p..32p+31.  A
           producer that writes channels_last (gnerf_upsample2x_add_nhwc) feeds the renderer with no layout change at all. */
     int32_t planes_interleaved;
+    /* (ABI 6) Batching several views of ONE scene in a call -- gen_videos.py's orbit renders every frame from the same planes:
+       planes_shared = 1: `planes_nhwc` holds ONE item's planes ([3,h,w,32] or [1,h,w,96]) and every item of the call reads them
+         (n_items still counts the items = views of the call: rays, noise and outputs are per item).  Forward only.
+       depth_clamp_per_item = 1: the depth clamp of ray_marcher.py:49-50 (min / max sample depth of the whole forward call) is taken
+         per ITEM instead of over the call, so that an item's result does not depend on what it is batched with: a batch of k views
+         equals k calls of one view bit for bit.  0 (default): the reference's call-wide clamp.  n_items <= 4096 when set. */
+    int32_t planes_shared;
+    int32_t depth_clamp_per_item;
 } gnerf_render_params;
 
 #define GNERF_MLP_AUTO  0

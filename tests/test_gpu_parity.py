@@ -5,6 +5,7 @@ size-independent properties at BASELINE.json's full sizes.
 Tolerances (fp32 arithmetic on both sides, different summation orders and hardware exp2/log2 in the MLP
 activations): rgb pixel MSE < 1e-8 against the oracle here -- north_star's bound is 1e-4."""
 
+import ctypes
 import math
 
 import numpy as np
@@ -553,6 +554,122 @@ def test_importance_renderer_reads_channels_last_planes_in_place(dev, monkeypatc
     assert not calls                                        # (the channels_last pass, last in the loop)
     assert grads[1].stride() == planes_cl.stride()
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * float(grads[0].abs().max())
+
+
+def test_views_of_one_item_equal_separate_calls(dev):
+    """Frame batching (an orbit's frames are N cameras on ONE latent's planes): one launch over N views of one set of planes --
+    gnerf_render_params.planes_shared + depth_clamp_per_item -- gives every view bit-identically what a launch of its own
+    gives, including the final depth clamp (ray_marcher.py:49-50 takes the range over the whole call, i.e. over ONE frame in
+    gen_videos.py), through both bindings, both plane layouts, the kernels for full-size and odd sample counts, and the
+    renderer class (which also makes the uniform draws in the order N calls would)."""
+    import gnerf_hip
+    import gnerf_harness as H
+    from training.volumetric_rendering.renderer import ImportanceRenderer
+    from training.volumetric_rendering.ray_sampler import RaySampler
+    torch.manual_seed(0)
+    dec = H.TriPlaneDecoder().to(dev)
+    r = ImportanceRenderer()
+    fcs = (dec.net[0], dec.net[2])
+    N, res = 5, 20                                                       # 400 rays per view: workgroups straddle views
+    c = torch.cat([H.camera_label(H.orbit_pose(i, 120)) for i in (0, 17, 33, 61, 95)]).to(dev)
+    o, d = RaySampler()(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), res)
+    img = torch.randn(1, 96, 32, 32, device=dev) * 0.5
+    with torch.no_grad():
+        w = r._decoder_cache(fcs)
+        for S, F in ((48, 48), (96, 96), (13, 7), (24, 0)):
+            for planes in (gnerf_hip.planes_to_nhwc(img.view(1, 3, 32, 32, 32)), img.permute(0, 2, 3, 1).contiguous()):
+                nc, nf = torch.rand(N * res * res, S, device=dev), (torch.rand(N * res * res, F, device=dev) if F else None)
+                kw = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=res)
+                for binding in ('ext', 'ctypes'):
+                    old = gnerf_hip._ext
+                    try:
+                        if binding == 'ctypes':
+                            gnerf_hip._ext = False
+                        got = gnerf_hip.render_forward(planes, N, w, o, d, nc, nf, planes_shared=True, depth_clamp_per_item=True, **kw)
+                        # the same launch with the planes copied N times and a per-item clamp: the shared read changes nothing
+                        rep = gnerf_hip.render_forward(planes.repeat(N, 1, 1, 1), N, w, o, d, nc, nf, depth_clamp_per_item=True, **kw)
+                        whole = gnerf_hip.render_forward(planes.repeat(N, 1, 1, 1), N, w, o, d, nc, nf, **kw)
+                        for i in range(N):
+                            sl = slice(i * res * res, (i + 1) * res * res)
+                            one = gnerf_hip.render_forward(planes, 1, w, o[i:i + 1], d[i:i + 1], nc[sl], None if nf is None else nf[sl], **kw)
+                            for a, b, e in zip(got, rep, one):
+                                assert torch.equal(a[i:i + 1], e) and torch.equal(b[i:i + 1], e), (S, F, binding, i)
+                        # ... and the call-wide clamp is a different thing (or the test above shows nothing): colours equal, depths
+                        # clamped to the union of the ranges
+                        assert torch.equal(whole[0], got[0]) and torch.equal(whole[2], got[2])
+                        assert float(whole[1].min()) <= float(got[1].min()) and float(whole[1].max()) >= float(got[1].max())
+                    finally:
+                        gnerf_hip._ext = old
+        # the workspace is back to idle (all zero): the next call-wide clamp starts from nothing
+        torch.cuda.synchronize()
+        for ws in gnerf_hip._workspaces.values():
+            words = ws.view(torch.int32)
+            assert int(words[:4].abs().sum()) == 0 and int(words[16:].abs().sum()) == 0
+        # the renderer class: planes of one item, rays of N
+        opts = dict(depth_resolution=48, depth_resolution_importance=48, ray_start=2.25, ray_end=3.3, box_warp=1, clamp_mode='softplus',
+                    disparity_space_sampling=False)
+        planes5 = img.view(1, 3, 32, 32, 32)
+        torch.manual_seed(9)
+        got = r(planes5, dec, o, d, opts)
+        torch.manual_seed(9)
+        for i in range(N):
+            one = r(planes5, dec, o[i:i + 1], d[i:i + 1], opts)
+            for a, e in zip(got, one):
+                assert torch.equal(a[i:i + 1], e)
+        # 'auto' ray limits (renderer.py:91-96) are per call as well
+        opts_auto = dict(opts, ray_start='auto', ray_end='auto', box_warp=2.0)
+        torch.manual_seed(10)
+        got = r(planes5, dec, o, d, opts_auto)
+        torch.manual_seed(10)
+        for i in range(N):
+            one = r(planes5, dec, o[i:i + 1], d[i:i + 1], opts_auto)
+            for a, e in zip(got, one):
+                assert torch.equal(a[i:i + 1], e)
+    # forward-only
+    with pytest.raises(RuntimeError, match='forward-only'):
+        r(planes5.clone().requires_grad_(True), dec, o, d, opts)
+    nhwc = gnerf_hip.planes_to_nhwc(planes5)
+    p, keep, m = gnerf_hip._render_params(nhwc, N, w, o, d, torch.rand(N * res * res, 48, device=dev), torch.rand(N * res * res, 48, device=dev),
+                                          48, 48, 2.25, 3.3, 1.0, False, False, res, 'render_backward', planes_shared=True)
+    g = gnerf_hip.RenderGrads()
+    assert gnerf_hip.load().gnerf_render_backward(ctypes.byref(p), ctypes.byref(g), None) == gnerf_hip.E_UNSUPPORTED
+
+
+def test_orbit_frames_per_call(dev):
+    """gen_videos orbit with k cameras per synthesis call: the renderer's share of every frame (the depth image, triplane.py:78)
+    is bit-identical to the frame-at-a-time orbit when both draw the same uniforms; the images that went through the
+    superresolution's fp16 convolutions agree to their noise (MIOpen picks its algorithm per batch size)."""
+    import gnerf_harness as H
+    import gen_videos_mi355x as GV
+    G = GV.build_random_generator(3, dev)
+    z = torch.randn(1, G.z_dim, device=dev)
+    outs = {}
+    for k in (1, 4):
+        torch.manual_seed(21)
+        frames, raws, (lo, hi) = GV.render_orbit(G, z, 10, 32, dev, double_depth=False, frames_per_call=k)
+        assert frames.shape == (10, 512, 512, 3) and raws.shape == (10, 32, 32, 3) and (lo, hi) == (0, 10)
+        outs[k] = (frames, raws)
+    for which in (0, 1):
+        diff = (outs[1][which].int() - outs[4][which].int()).abs()
+        assert int(diff.max()) <= 16 and float(diff.float().mean()) < 0.5, (which, int(diff.max()), float(diff.float().mean()))
+    with torch.no_grad():
+        ws = GV.orbit_latents(G, z, dev)
+        cams = torch.cat([H.camera_label(H.orbit_pose(i, 10, G.rendering_kwargs['avg_camera_radius'])) for i in range(4)]).to(dev)
+        G.synthesis(ws=ws, c=cams[:1], noise_mode='const', neural_rendering_resolution=32, cache_backbone=True)
+        torch.manual_seed(22)
+        together = G.synthesis(ws=ws, c=cams, noise_mode='const', neural_rendering_resolution=32, use_cached_backbone=True)
+        assert together['image'].shape == (4, 3, 512, 512)
+        torch.manual_seed(22)
+        for i in range(4):
+            alone = G.synthesis(ws=ws, c=cams[i:i + 1], noise_mode='const', neural_rendering_resolution=32, use_cached_backbone=True)
+            assert torch.equal(alone['image_depth'], together['image_depth'][i:i + 1])
+    # a graph program of 4 views, 10 frames (the last block is short)
+    torch.manual_seed(21)
+    fg, rg, _ = GV.render_orbit(G, z, 10, 32, dev, double_depth=False, frames_per_call=4, use_graph=True)
+    assert fg.shape == (10, 512, 512, 3)
+    assert float((fg.int() - outs[1][0].int()).abs().float().mean()) < 1.0         # other draws: same picture up to sampling noise
+    with pytest.raises(ValueError):
+        GV.render_orbit(G, torch.randn(2, G.z_dim, device=dev), 4, 32, dev, double_depth=False, frames_per_call=2)
 
 
 def test_query_points_vs_oracle(dev):

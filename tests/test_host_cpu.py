@@ -189,6 +189,43 @@ def test_renderer_torch_path_matches_reference(golden, case):
     np.testing.assert_allclose(wsum.numpy(), g['out_wsum'], atol=2e-6)
 
 
+def test_renderer_views_of_one_item_on_the_torch_path():
+    """The overlay's extension of ImportanceRenderer.forward -- planes of ONE item, rays of N: N views, each with the results (draws,
+    depth clamp) of a call of its own -- on the PyTorch-op path, and through Generator.synthesis (several cameras, one latent)."""
+    import gnerf_harness as H
+    import gnerf_generator
+    from training.volumetric_rendering.renderer import ImportanceRenderer
+    from training.volumetric_rendering.ray_sampler import RaySampler
+    torch.manual_seed(0)
+    dec = H.TriPlaneDecoder()
+    opts = dict(depth_resolution=6, depth_resolution_importance=5, ray_start=2.25, ray_end=3.3, box_warp=1, clamp_mode='softplus',
+                disparity_space_sampling=False)
+    c = torch.cat([H.camera_label(H.orbit_pose(i, 120)) for i in (0, 31, 77)])
+    o, d = RaySampler()(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), 6)
+    planes = torch.randn(1, 3, 32, 16, 16)
+    ren = ImportanceRenderer()
+    with torch.no_grad():
+        torch.manual_seed(4)
+        got = ren(planes, dec, o, d, opts)
+        torch.manual_seed(4)
+        for i in range(3):
+            one = ren(planes, dec, o[i:i + 1], d[i:i + 1], opts)
+            for a, e in zip(got, one):
+                assert torch.equal(a[i:i + 1], e)
+        assert got[0].shape == (3, 36, 32) and got[1].shape == (3, 36, 1)
+        G = gnerf_generator.Generator(sr_use_fp16=False).eval()
+        ws = G.mapping(torch.randn(1, 512), torch.zeros(1, 25))
+        G.synthesis(ws, c[:1], neural_rendering_resolution=8, noise_mode='const', cache_backbone=True)
+        torch.manual_seed(5)
+        together = G.synthesis(ws, c, neural_rendering_resolution=8, noise_mode='const', use_cached_backbone=True)
+        assert together['image'].shape == (3, 3, 512, 512) and together['image_depth'].shape == (3, 1, 8, 8)
+        torch.manual_seed(5)
+        for i in range(3):
+            alone = G.synthesis(ws, c[i:i + 1], neural_rendering_resolution=8, noise_mode='const', use_cached_backbone=True)
+            assert torch.equal(alone['image_depth'], together['image_depth'][i:i + 1])
+            assert torch.allclose(alone['image'], together['image'][i:i + 1], atol=1e-4)
+
+
 def test_renderer_survives_unpickling_without_init(golden):
     """legacy.py:68-72 revives ImportanceRenderer by class name WITHOUT calling __init__: only the pickled
     attributes exist.  The replacement must cope (lazy state only)."""

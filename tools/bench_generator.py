@@ -23,6 +23,7 @@ ap.add_argument('--reference-flow', action='store_true', help="the reference's l
 ap.add_argument('--batch', type=int, default=4)
 ap.add_argument('--frames', type=int, default=30)
 ap.add_argument('--only', type=int, default=0, help='3 or 4: run only that configuration (for profiling)')
+ap.add_argument('--frames-per-call', type=int, nargs='*', default=[], help='config 4 also with this many cameras per synthesis call (views of the one latent)')
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
 torch.manual_seed(0)
@@ -123,3 +124,32 @@ with torch.no_grad():
             tg, _ = timed(orbit_graph, 1)
             line.update(graph_frames_per_s=round(args.frames / tg, 1), graph_ms_per_frame=round(tg / args.frames * 1e3, 3))
         print(json.dumps(line), flush=True)
+        for k in ([] if args.ref_ops else args.frames_per_call):
+            def orbit_k():
+                return torch.cat([H.to_uint8(G.synthesis(ws1, cams[i:i + k], neural_rendering_resolution=64, use_cached_backbone=True)['image'])
+                                  for i in range(0, args.frames, k)])
+            t, fr = timed(orbit_k, 1)
+            assert fr.shape[0] == args.frames
+            line = {'config': 4, 'workload': f'orbit share of one GPU: {args.frames} frames, {k} cameras per call, 64x64 rays x ({S}+{S}), cached backbone, SR to 512x512 fp16, uint8 frames',
+                    'frames_per_call': k, 'frames_per_s': round(args.frames / t, 1), 'ms_per_frame': round(t / args.frames * 1e3, 3)}
+            cam = cams[:k].clone()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    H.to_uint8(G.synthesis(ws1, cam, neural_rendering_resolution=64, use_cached_backbone=True)['image'])
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                frame = H.to_uint8(G.synthesis(ws1, cam, neural_rendering_resolution=64, use_cached_backbone=True)['image'])
+
+            def orbit_graph_k():
+                fr = []
+                for i in range(0, args.frames - args.frames % k, k):
+                    cam.copy_(cams[i:i + k])
+                    graph.replay()
+                    fr.append(frame.clone())
+                return torch.cat(fr)
+            tg, fr = timed(orbit_graph_k, 1)
+            line.update(graph_frames_per_s=round(fr.shape[0] / tg, 1), graph_ms_per_frame=round(tg / fr.shape[0] * 1e3, 3))
+            print(json.dumps(line), flush=True)
