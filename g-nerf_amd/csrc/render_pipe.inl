@@ -430,6 +430,8 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
         PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
         if (__float_as_int(sl.misc[7]) < 0) return;
         const int j = lane & 15, g = lane >> 4;
+        // one explicit FMA chain per colour: left to the compiler's contraction, `acc += v0 c0 + v1 c1 + ...` rounds differently in
+        // the instantiation with compile-time tile counts (acc known to be zero at the first tile) -- 1 ulp between FULL and not
         float acc[2] = {0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < TP; i++) {
@@ -437,12 +439,16 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
             if (tile < tiles_c) {
                 const v4f v = *reinterpret_cast<const v4f*>(sl.v_e + 16 * tile + 4 * g);
 #pragma unroll
-                for (int n = 0; n < 2; n++) acc[n] += v[0] * cc[i][n][0] + v[1] * cc[i][n][1] + v[2] * cc[i][n][2] + v[3] * cc[i][n][3];
+                for (int n = 0; n < 2; n++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc[n] = __fmaf_rn(v[k], cc[i][n][k], acc[n]);
             }
             if (tile < tiles_f) {
                 const v4f v = *reinterpret_cast<const v4f*>(sl.v_e + fine_e0 + 16 * tile + 4 * g);
 #pragma unroll
-                for (int n = 0; n < 2; n++) acc[n] += v[0] * cf[i][n][0] + v[1] * cf[i][n][1] + v[2] * cf[i][n][2] + v[3] * cf[i][n][3];
+                for (int n = 0; n < 2; n++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc[n] = __fmaf_rn(v[k], cf[i][n][k], acc[n]);
             }
         }
 #pragma unroll

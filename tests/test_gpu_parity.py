@@ -556,6 +556,27 @@ def test_importance_renderer_reads_channels_last_planes_in_place(dev, monkeypatc
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * float(grads[0].abs().max())
 
 
+@pytest.mark.parametrize('S', [48, 96, 144])
+def test_pipe_kernel_instantiations_agree(dev, monkeypatch, S):
+    """render_kernel_pipe<TP, MLP, FULL>: the instantiation with compile-time sample counts (what a 48+48 / 96+96 / 144+144 call
+    runs), the general one (GNERF_PIPE_FULL=0) and the debug route give the same bits for every decoder arithmetic -- what the
+    stage dumps show is what production computed.  (Round 3: the colour composite, left to the compiler's FMA contraction, was
+    1 ulp apart between the two.)"""
+    import gnerf_hip
+    planes, dec, o, d, nc, nf = _random_scene(3, N=2, res=8, S=S, F=S, hw=(16, 16))
+    nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
+    args = (nhwc, 2, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev))
+    kw = dict(depth_resolution=S, depth_resolution_importance=S, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=8)
+    for mlp in ('auto', 'f16x3', 'f32'):
+        monkeypatch.delenv('GNERF_PIPE_FULL', raising=False)
+        full = gnerf_hip.render_forward(*args, mlp=mlp, **kw)
+        monkeypatch.setenv('GNERF_PIPE_FULL', '0')
+        general = gnerf_hip.render_forward(*args, mlp=mlp, **kw)
+        debug = gnerf_hip.render_forward(*args, mlp=mlp, debug=True, **kw)[:3]
+        for a, b, c in zip(full, general, debug):
+            assert torch.equal(a, b) and torch.equal(b, c), mlp
+
+
 def test_views_of_one_item_equal_separate_calls(dev):
     """Frame batching (an orbit's frames are N cameras on ONE latent's planes): one launch over N views of one set of planes --
     gnerf_render_params.planes_shared + depth_clamp_per_item -- gives every view bit-identically what a launch of its own
