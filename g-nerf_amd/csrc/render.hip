@@ -897,6 +897,9 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         const dim3 gd((unsigned)g), bd(kPipeThreads);
         // the instantiation with compile-time sample counts (render_pipe_body<.., FULL>) where the call fills the slots exactly
         bool full = S == 48 * pipe_tp && F == 48 * pipe_tp && !p->disparity_space_sampling && !p->ray_start_per_ray && !p->debug;
+#ifdef GNERF_STAMPS
+        full = full || (S == 48 * pipe_tp && F == 48 * pipe_tp && !p->disparity_space_sampling && !p->ray_start_per_ray);     // the timing build's `debug` is its stamp buffer
+#endif
         if (const char* f = getenv("GNERF_PIPE_FULL")) full = full && strcmp(f, "0") != 0;       // A/B runs and the tests' cross-check
 #define GNERF_PIPE2(TP, FULL) do { if (mlp == kMlpAuto) hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpAuto, FULL>), gd, bd, lds_bytes, s, P); \
                             else if (mlp == kMlpF16x3) hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpF16x3, FULL>), gd, bd, lds_bytes, s, P); \

@@ -98,7 +98,23 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
     constexpr int kPipeMaxS = D::kMaxS, kPipeSPad = D::kSPad, kSlotFloats = D::kSlotFloats, RND = D::kRounds;
     const gnerf_render_params& p = P.p;
     const int tid = threadIdx.x, lane = tid & 63;
+#if defined(GNERF_ROLE_ROT)
+    // experiment: which SIMD hosts the scalar wave.  Physical wave w of a workgroup sits on SIMD w; role = (w + rot) & 3 puts the scalar
+    // role of CU-mates on different SIMDs when their `rot` differ.  1: rot from the launch position (blockIdx / 256), 2: blockIdx / 8,
+    // 3: from the wave slot the hardware gave wave 0 (HW_ID.WAVE_ID)
+    int rot;
+    if (GNERF_ROLE_ROT == 1) rot = (blockIdx.x >> 8) & 3;
+    else if (GNERF_ROLE_ROT == 2) rot = (blockIdx.x >> 3) & 3;
+    else {
+        if (tid == 0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); reinterpret_cast<unsigned*>(smem)[0] = hw & 15u; }
+        __syncthreads();
+        rot = reinterpret_cast<const unsigned*>(smem)[0] & 3;
+        __syncthreads();
+    }
+    const int wv = __builtin_amdgcn_readfirstlane(((tid >> 6) + rot) & 3);
+#else
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
     const int S = FULL ? kPipeMaxS : p.depth_resolution, F = FULL ? kPipeMaxS : p.depth_resolution_importance;
     const int tiles_c = FULL ? 3 * TP : P.tiles_c, tiles_f = FULL ? 3 * TP : P.tiles_f;
     float* const debug = FULL ? nullptr : GNERF_DBG_PTR(p.debug);

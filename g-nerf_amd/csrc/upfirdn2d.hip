@@ -655,7 +655,12 @@ template <class T>
 int launch_blur4_nhwc(const UpArgs& a, hipStream_t stream, const BlurEpi* ep = nullptr, int act = 0) {
     constexpr int VEC = 16 / sizeof(T);
     const int cv = a.c / VEC;
-    const int rows_per_strip = a.out_h > 256 ? 64 : (a.out_h > 64 ? 32 : 16);
+    // Strip length: long strips re-read little ((R + 3) / R input rows per output row), but a lane is one (column, channel vector) of one
+    // strip, and ONE 512x512x64 image in 64-row strips is 512 waves -- two per CU (the orbit's frames: 50 us per call, 1.0 TB/s).  Take the
+    // longest strip that still gives every CU 16 waves; the re-read of short strips is served by the L2.  (The result does not depend on
+    // the strip length: an output row accumulates its four input rows in the same order wherever the strip starts.)
+    int rows_per_strip = a.out_h > 256 ? 64 : (a.out_h > 64 ? 32 : 16);
+    while (rows_per_strip > 8 && int64_t(a.out_w) * cv * ((a.out_h + rows_per_strip - 1) / rows_per_strip) * a.n < int64_t(kNumCU) * 16 * 64) rows_per_strip >>= 1;
     const int strips_y = (a.out_h + rows_per_strip - 1) / rows_per_strip;
     const int64_t threads = int64_t(a.out_w) * cv * strips_y * a.n;
     const int64_t blocks = (threads + 255) / 256;

@@ -58,6 +58,24 @@ def _fast_path(x, *params):
             and not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))))
 
 
+def _cast_param(module, name, dtype):
+    """getattr(module, name) in `dtype`, the converted copy cached per parameter version: the fp16 layers' biases are fp32 parameters,
+    and converting them inside every kernel wrapper was ten 4-us copy launches per orbit frame (4 % of its GPU time,
+    profiles/r03_orbit_fast_flow_kernel_stats.csv)."""
+    p = getattr(module, name)
+    if p is None or p.dtype == dtype:
+        return p
+    if p.is_inference() or (torch.is_grad_enabled() and p.requires_grad):
+        return p.to(dtype)
+    key = (p.data_ptr(), p._version, dtype)
+    cache = module.__dict__.setdefault('_gnerf_cast', {})
+    hit = cache.get(name)
+    if hit is None or hit[0] != key:
+        hit = (key, p.detach().to(dtype).contiguous())
+        cache[name] = hit
+    return hit[1]
+
+
 def _prenormalised_weight(module, dtype, channels_last=False, transposed=False):
     """weight / (sqrt(fan_in) max|weight[o]|) in `dtype` (networks_stylegan2.py:63), cached per weight version: a constant at inference.
     channels_last: in that memory format (for channels_last activations); transposed: as [I,O,k,k] for conv_transpose2d."""
@@ -259,16 +277,16 @@ class StyledConv(nn.Module):
                     nxt_aff = (next_layer.affine.weight, next_layer.affine.bias)
                     nxt = _per_latent(next_layer, next_w, 'nstyles', nxt_aff, lambda: gnerf_hip.normalise_styles(next_layer.affine(next_w)))
                     folded = True
-                epi = dict(bias=self.bias, scale=dco, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp, next_scale=nxt) if noise is None else None
+                epi = dict(bias=_cast_param(self, 'bias', x.dtype), scale=dco, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp, next_scale=nxt) if noise is None else None
                 out = self._resampled_conv(x, _prenormalised_weight(self, x.dtype, cl), 1,
                                            weight_t=_prenormalised_weight(self, x.dtype, cl, transposed=True) if self.up == 2 else None, epilogue=epi)
                 x, done = out if epi is not None else (out, False)
                 if not done:
                     if nxt is not None and not _is_channels_last(x):          # (the convolution gave back another layout: scale separately)
-                        x = gnerf_hip.modconv_epilogue(x, self.bias, scale=dco, noise=noise, round_noise=True, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
+                        x = gnerf_hip.modconv_epilogue(x, _cast_param(self, 'bias', x.dtype), scale=dco, noise=noise, round_noise=True, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
                         x = gnerf_hip.scale_channels(x, nxt)
                     else:
-                        x = gnerf_hip.modconv_epilogue(x, self.bias, scale=dco, noise=noise, round_noise=True, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp,
+                        x = gnerf_hip.modconv_epilogue(x, _cast_param(self, 'bias', x.dtype), scale=dco, noise=noise, round_noise=True, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp,
                                                        next_scale=nxt)
                 return (x, folded) if next_layer is not None else x
             # per-sample weights in one launch, already in the order and memory format the convolution takes them
@@ -277,13 +295,13 @@ class StyledConv(nn.Module):
             wts = _per_latent(self, w, ('wts', x.dtype, cl), mine,
                               lambda: gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=x.dtype, transposed=self.up == 2, channels_last=cl)[0])
             wts = wts.reshape(-1, *wts.shape[2:]) if n > 1 else wts[0]
-            epi = dict(bias=self.bias, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp) if (noise is None and n == 1) else None
+            epi = dict(bias=_cast_param(self, 'bias', x.dtype), act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp) if (noise is None and n == 1) else None
             x = self._resampled_conv(x.reshape(1, n * c_in, h, wd) if n > 1 else x, None if self.up == 2 else wts, n, weight_t=wts if self.up == 2 else None,
                                      epilogue=epi)
             x, done = x if epi is not None else (x, False)
             x = x.reshape(n, c_out, *x.shape[2:]) if n > 1 else x
             if not done:
-                x = gnerf_hip.modconv_epilogue(x, self.bias, noise=noise, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
+                x = gnerf_hip.modconv_epilogue(x, _cast_param(self, 'bias', x.dtype), noise=noise, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
             return (x, folded) if next_layer is not None else x
         # The reference's own flow (modulated_conv2d, networks_stylegan2.py:41-98, called from SynthesisLayer.forward :315-334 with
         # padding = kernel_size // 2 and flip_weight = (up == 1)): PyTorch ops for the modulation, the convolution through
@@ -329,13 +347,13 @@ class ToRGB(nn.Module):
         if fast:
             import gnerf_hip
             if x.dtype == torch.float16 and _is_channels_last(x) and self.weight.shape[0] == 3 and c_in in gnerf_hip.TORGB_CHANNELS:
-                return gnerf_hip.torgb_channels_last(x, self.weight, styles, self.bias, clamp=self.conv_clamp)      # one streaming read of x
+                return gnerf_hip.torgb_channels_last(x, self.weight, styles, _cast_param(self, 'bias', x.dtype), clamp=self.conv_clamp)      # one streaming read of x
             if x.dtype == torch.float16 and n > 1:
                 x = F.conv2d(gnerf_hip.scale_channels(x, styles), self.weight.to(x.dtype))
             else:
                 wts = _per_latent(self, w, ('wts', x.dtype), aff + (self.weight,), lambda: gnerf_hip.modulate_weights(self.weight, styles, False, out_dtype=x.dtype)[0])
                 x = F.conv2d(x.reshape(1, n * c_in, h, wd), wts.reshape(-1, c_in, 1, 1), groups=n).reshape(n, -1, h, wd)
-            return gnerf_hip.modconv_epilogue(x, self.bias, act='linear', gain=1.0, clamp=self.conv_clamp)
+            return gnerf_hip.modconv_epilogue(x, _cast_param(self, 'bias', x.dtype), act='linear', gain=1.0, clamp=self.conv_clamp)
         if fused:                       # (the reference's flow, as in StyledConv.forward)
             wts = _modulated_weights(self.weight, styles, False, False).to(x.dtype)
             x = conv2d_resample.conv2d_resample(x=x.reshape(1, n * c_in, h, wd), w=wts.reshape(-1, c_in, 1, 1), groups=n).reshape(n, -1, h, wd)
