@@ -255,6 +255,7 @@ def gen_videos_secondary(rank, world, dev, n_frames=240):
     if world > 1:
         import torch.distributed as dist
     out = {}
+    searched = H.configure_backend()                  # MIOpen solver search per shape, in the warm-up frames (GNERF_MIOPEN_FIND=0: off)
     with torch.no_grad():
         G = gv.build_random_generator(0, dev)
         z = torch.randn(1, G.z_dim, generator=torch.Generator().manual_seed(1)).to(dev)
@@ -292,7 +293,7 @@ def gen_videos_secondary(rank, world, dev, n_frames=240):
     best = max(('eager', 'hip_graph', 'eager_views'), key=lambda k: out['fast', k])
     return {'metric': 'frames/sec gen_videos', 'value': out['fast', best], 'unit': 'frames/s', 'value_is': 'fast flow, ' + best,
             'eager_value': out['fast', 'eager'], 'hip_graph_value': out['fast', 'hip_graph'],
-            'eager_views_value': out['fast', 'eager_views'], 'views_per_call': ORBIT_VIEWS,
+            'eager_views_value': out['fast', 'eager_views'], 'views_per_call': ORBIT_VIEWS, 'miopen_solver_search': searched,
             'reference_flow_value': max(out['reference', 'eager'], out['reference', 'hip_graph']),
             'reference_flow_eager_value': out['reference', 'eager'], 'reference_flow_hip_graph_value': out['reference', 'hip_graph'], 'n_gpus': world,
             'workload': f'config 4: {n_frames}-frame orbit sharded over {world} GPU(s), 64x64 rays x (96+96) samples, cached backbone, SR to '

@@ -244,7 +244,9 @@ def main():
     ap.add_argument('--out', default=None, help='write frames to this .npy (rank 0)')
     ap.add_argument('--shapes', default=None, help='also extract the 512^3 density volume (gen_videos.py --shapes) and save it to this .npy (rank 0)')
     ap.add_argument('--voxel-res', type=int, default=512)
+    ap.add_argument('--no-solver-search', action='store_true', help='leave torch.backends.cudnn.benchmark off (MIOpen takes its first heuristic pick per shape)')
     args = ap.parse_args()
+    H.configure_backend(False if args.no_solver_search else None)
 
     rank, world, local_rank = H.init_from_env()
     # (modulo: a rehearsal of several ranks on a one-GPU box with GNERF_DIST_BACKEND=gloo shares the card)

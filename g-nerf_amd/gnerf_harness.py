@@ -66,6 +66,19 @@ def to_uint8(img):
 # one process per GPU
 
 
+def configure_backend(solver_search=None):
+    """Process-wide library settings of the harnesses (gen_videos_mi355x.py, train_step_mi355x.py, bench.py's secondary, tools/).
+    solver_search: torch.backends.cudnn.benchmark -- on ROCm, MIOpen times its applicable solvers the first time it sees a
+    convolution shape and keeps the fastest, instead of taking its heuristic's first pick.  The reference's training loop turns it
+    on (training_loop.py:133,144); gen_videos.py leaves torch's default.  The generator's convolutions are 60 % of an orbit frame's
+    GPU time and the searched solvers are that much better on gfx950 (orbit +16 %, config 3 +12 %: profiles/r03_generator.jsonl),
+    at the price of a few seconds in the warm-up frame.  Default: on; GNERF_MIOPEN_FIND=0 turns it off."""
+    if solver_search is None:
+        solver_search = os.environ.get('GNERF_MIOPEN_FIND', '1') != '0'
+    torch.backends.cudnn.benchmark = bool(solver_search)
+    return bool(solver_search)
+
+
 def init_from_env():
     """(rank, world_size, local_rank).  Initialises torch.distributed from RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*
     when WORLD_SIZE > 1: backend 'nccl' (= RCCL on ROCm) if a GPU is visible, else 'gloo'."""

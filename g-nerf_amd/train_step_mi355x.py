@@ -208,7 +208,11 @@ def main():
     ap.add_argument('--bucket-mb', type=float, default=0.0, help='exchange the flat vector in pieces of this size (0 = one collective)')
     ap.add_argument('--force-fp32', action='store_true', help='full mode: no fp16 in the super-resolution and discriminator blocks')
     ap.add_argument('--device', default=None)
+    ap.add_argument('--solver-search', action='store_true',
+                    help='torch.backends.cudnn.benchmark on, as training_loop.py:133,144 has it.  Off by default here: MIOpen then times every solver of every '
+                         'forward / backward-data / backward-weights shape of G and D on first use, and the first step takes more than seven minutes')
     args = ap.parse_args()
+    H.configure_backend(bool(args.solver_search))
 
     rank, world, local_rank = H.init_from_env()
     use_gpu = torch.cuda.is_available() if args.device is None else args.device.startswith('cuda')

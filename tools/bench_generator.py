@@ -23,9 +23,11 @@ ap.add_argument('--reference-flow', action='store_true', help="the reference's l
 ap.add_argument('--batch', type=int, default=4)
 ap.add_argument('--frames', type=int, default=30)
 ap.add_argument('--only', type=int, default=0, help='3 or 4: run only that configuration (for profiling)')
+ap.add_argument('--miopen-find', type=int, default=1, help='torch.backends.cudnn.benchmark (MIOpen searches its solvers per shape on first use; training_loop.py:144 turns it on)')
 ap.add_argument('--frames-per-call', type=int, nargs='*', default=[], help='config 4 also with this many cameras per synthesis call (views of the one latent)')
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
+H.configure_backend(bool(args.miopen_find))
 torch.manual_seed(0)
 G = gnerf_generator.Generator().eval().requires_grad_(False).to(dev)
 with torch.no_grad():
