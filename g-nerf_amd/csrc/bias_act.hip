@@ -84,7 +84,10 @@ __device__ __forceinline__ A eval(A in, A bias, A xref, A yref, A dy2, int grad,
     }
     out *= gain * dy2;
     if (clamp >= zero) {
-        if (grad == 0) out = out > clamp ? clamp : (out < -clamp ? -clamp : out);
+        if (grad == 0) {                                        // NaN -> -clamp, as the reference's kernel has it (bias_act.cu:143)
+            if constexpr (sizeof(A) == 4) out = __builtin_amdgcn_fmed3f(out, -clamp, clamp);
+            else                          out = (out > -clamp && out < clamp) ? out : (out >= zero ? clamp : -clamp);
+        }
         else           out = (yref > -clamp && yref < clamp) ? out : zero;
     }
     return out;

@@ -87,13 +87,18 @@ __device__ __forceinline__ Pk<T, VEC> modconv_epilogue_vec(const Pk<T, VEC>& in,
         }
     }
     Pk<T, VEC> out;
+    // lrelu with a slope in [0, 1] is max(u, u * alpha) -- the same bits as the select for every u (signed zeros and NaN included),
+    // one full-rate and one half-rate instruction instead of one and two (tools/probes/valu_issue_probe.hip: v_cmp / v_cndmask cost
+    // 4.4 SIMD cycles each).  The clamp is v_med3_f32, which sends NaN to -clamp exactly like the reference's kernel
+    // (bias_act.cu:143: `(y > -clamp & y < clamp) ? y : (y >= 0) ? clamp : -clamp`), one instruction instead of four.
+    const bool slope01 = alpha >= 0.f && alpha <= 1.f;
 #pragma unroll
     for (int k = 0; k < VEC; k++) {
         const float uu = t[k] + bv[k];
         float r = uu;
-        if (ACT == 3) r = uu > 0.f ? uu : uu * alpha;          // lrelu
+        if (ACT == 3) r = slope01 ? fmaxf(uu, uu * alpha) : (uu > 0.f ? uu : uu * alpha);          // lrelu
         r *= gain;
-        if (clamp >= 0.f) r = r > clamp ? clamp : (r < -clamp ? -clamp : r);
+        if (clamp >= 0.f) r = __builtin_amdgcn_fmed3f(r, -clamp, clamp);
         if constexpr (NEXT) r = round_to<T>(r) * nx[k];
         store_as<T>(out.v, k, r);
     }

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kThreads) void torgb_nhwc_kernel(const __half* __re
                 for (int o = 0; o < 3; o++) acc[o] += __shfl_xor(acc[o], off);
             if (sub < 3 && p < pixels) {
                 float r = __half2float(__float2half(sub == 0 ? acc[0] : (sub == 1 ? acc[1] : acc[2]))) + b;
-                if (clamp >= 0.f) r = r > clamp ? clamp : (r < -clamp ? -clamp : r);
+                if (clamp >= 0.f) r = __builtin_amdgcn_fmed3f(r, -clamp, clamp);          // NaN -> -clamp (bias_act.cu:143)
                 yn[int64_t(sub) * pixels + p] = __float2half(r);
             }
         }

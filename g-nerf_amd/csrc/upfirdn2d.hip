@@ -543,12 +543,15 @@ struct BlurEpi {
 template <class T, int EPI>                                 // EPI: 0 none, 1 linear, 3 lrelu
 __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int cv, int strips_y, int rows_per_strip, BlurEpi ep) {
     constexpr int VEC = 16 / sizeof(T);
+    // grid = (column blocks, strips, images): strip and image are the workgroup's, so the row walk below (steps, row validity, row
+    // addresses) is wave-uniform -- with one flat index they were per-lane values, every `if (s < steps)` became an exec-masked
+    // region, and the vectors loaded for the next row passed through register copies (and a wait for everything in flight) at each
     const int64_t per_row = int64_t(a.out_w) * cv;
-    int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (t >= per_row * strips_y * a.n) return;
-    const int col = int(t % per_row); t /= per_row;
-    const int sy = int(t % strips_y);
-    const int img = int(t / strips_y);
+    const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= per_row) return;
+    const int col = int(t);
+    const int sy = blockIdx.y;
+    const int img = blockIdx.z;
     const int ox = col / cv, c0 = (col % cv) * VEC;
     const int oy0 = sy * rows_per_strip, rows = min(rows_per_strip, a.out_h - oy0);
     const T* x = static_cast<const T*>(a.x) + img * a.xs_n + c0;
@@ -560,6 +563,9 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int c
 #pragma unroll
         for (int kx = 0; kx < 4; kx++)
             tap[ky][kx] = a.f[(a.flip ? ky : 3 - ky) * a.fs_h + (a.flip ? kx : 3 - kx) * a.fs_w];
+    // (Measured and dropped: applying the rank-one binomial filter as a row pass + a column pass -- 8 FMAs per value and input row instead
+    // of 16, detected from the taps on the device -- made the plain blur SLOWER, 4.4 -> 3.75 TB/s, and left the fused form at 2.6: 150
+    // VGPRs instead of 137 and a dependent chain where the 2-D form has four independent ones.  The kernel is not bound by its FMA count.)
     const int ix0 = ox - a.padx0;
     bool col_ok[4];
     int64_t col_off[4];
@@ -568,12 +574,38 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int c
         col_ok[kx] = ix0 + kx >= 0 && ix0 + kx < a.in_w;
         col_off[kx] = int64_t(min(max(ix0 + kx, 0), a.in_w - 1)) * a.xs_w;          // clamped: loads are unconditional, values masked
     }
-    float e_sc[VEC], e_bv[VEC], e_nx[VEC];                       // this lane's channel vector of the epilogue operands
+    // this lane's channel vector of the epilogue operands, fetched as whole vectors under uniform branches: element-by-element
+    // conditional loads compiled to 24 dependent round trips in front of every strip (a global_load_dword + s_waitcnt vmcnt(0) each)
+    float e_sc[VEC], e_bv[VEC], e_nx[VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; k++) {
-        e_sc[k] = (EPI != 0 && ep.scale) ? ep.scale[int64_t(img) * a.c + c0 + k] : 1.f;
-        e_nx[k] = (EPI != 0 && ep.next_scale) ? round_to<T>(ep.next_scale[int64_t(img) * a.c + c0 + k]) : 1.f;
-        e_bv[k] = (EPI != 0 && ep.bias) ? float(load_as<T>(static_cast<const T*>(ep.bias), c0 + k)) : 0.f;
+    for (int k = 0; k < VEC; k++) { e_sc[k] = 1.f; e_nx[k] = 1.f; e_bv[k] = 0.f; }
+    if constexpr (EPI != 0) {
+        float4 sv[VEC / 4], nv[VEC / 4];
+        Pk<T, VEC> bv;
+        const bool has_s = ep.scale != nullptr, has_n = ep.next_scale != nullptr, has_b = ep.bias != nullptr;
+        if (has_s) {
+#pragma unroll
+            for (int q = 0; q < VEC / 4; q++) sv[q] = *reinterpret_cast<const float4*>(ep.scale + int64_t(img) * a.c + c0 + 4 * q);
+        }
+        if (has_n) {
+#pragma unroll
+            for (int q = 0; q < VEC / 4; q++) nv[q] = *reinterpret_cast<const float4*>(ep.next_scale + int64_t(img) * a.c + c0 + 4 * q);
+        }
+        if (has_b) bv = *reinterpret_cast<const Pk<T, VEC>*>(static_cast<const T*>(ep.bias) + c0);
+        if (has_s) {
+#pragma unroll
+            for (int q = 0; q < VEC / 4; q++) { e_sc[4 * q] = sv[q].x; e_sc[4 * q + 1] = sv[q].y; e_sc[4 * q + 2] = sv[q].z; e_sc[4 * q + 3] = sv[q].w; }
+        }
+        if (has_n) {
+#pragma unroll
+            for (int q = 0; q < VEC / 4; q++) {
+                e_nx[4 * q] = round_to<T>(nv[q].x); e_nx[4 * q + 1] = round_to<T>(nv[q].y); e_nx[4 * q + 2] = round_to<T>(nv[q].z); e_nx[4 * q + 3] = round_to<T>(nv[q].w);
+            }
+        }
+        if (has_b) {
+#pragma unroll
+            for (int k = 0; k < VEC; k++) e_bv[k] = float(load_as<T>(bv.v, k));
+        }
     }
     const int iy_first = oy0 - a.pady0;
     // fp32 arithmetic on PAIRS of channels (v_pk_fma_f32: the kernel is instruction-bound otherwise -- 128 scalar FMAs + 39 selects
@@ -583,7 +615,7 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int c
     constexpr int DW = 16 / 4;                                      // dwords per vector
     struct alignas(16) Raw { unsigned d[DW]; };
     f2 acc[4][VEC / 2];
-    Raw raw[4], nxt[4];
+    Raw raw[4];
     auto fetch_raw = [&](int iy, Raw (&dst)[4]) {
         const int64_t row = int64_t(min(max(iy, 0), a.in_h - 1)) * a.xs_h;
 #pragma unroll
@@ -591,12 +623,18 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int c
     };
     fetch_raw(iy_first, raw);
     const int steps = rows + 3;
+    // Order of a step, set by the ONE completion counter loads and stores share (vmcnt; the two kinds complete out of order with respect
+    // to each other, so a wait for a load with a store in flight is a wait for everything): [wait] convert the row that was loaded a
+    // step ago -> store the output row finished a step ago -> issue the next row's loads -> arithmetic -> epilogue into `pend`.
+    // Loads and the store are then both a whole step old when the next step waits.  (Storing a row as soon as it was finished put the
+    // store a few instructions in front of that wait: every step paid a store's round trip -- 2.6 TB/s fused, 4.4 plain.)
+    Pk<T, VEC> pend;
+    int pend_row = -1;
     for (int s4 = 0; s4 < steps; s4 += 4) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int s = s4 + u;                                   // input row iy_first + s
             if (s < steps) {                                        // (uniform over the strip's lanes)
-                if (s + 1 < steps) fetch_raw(iy_first + s + 1, nxt);
                 const bool row_ok = iy_first + s >= 0 && iy_first + s < a.in_h;
                 f2 in[4][VEC / 2];
 #pragma unroll
@@ -615,6 +653,16 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int c
                         }
                     }
                 }
+                // (pin the converted values in front of the store: left alone, the compiler sinks the masking below it, and the wait for
+                // the loaded row then follows the store it must not wait for)
+#pragma unroll
+                for (int kx = 0; kx < 4; kx++) {
+                    if constexpr (VEC == 8) asm volatile("" : "+v"(in[kx][0]), "+v"(in[kx][1]), "+v"(in[kx][2]), "+v"(in[kx][3]) :: "memory");
+                    else                    asm volatile("" : "+v"(in[kx][0]), "+v"(in[kx][1]) :: "memory");
+                }
+                if (pend_row >= 0) *reinterpret_cast<Pk<T, VEC>*>(y + int64_t(pend_row) * a.ys_h) = pend;
+                fetch_raw(iy_first + s + 1, raw);                   // (past the last step: a clamped, unused row -- no branch around the loads)
+                __builtin_amdgcn_sched_barrier(0);
                 // this row is tap row ky of output row s - ky; accumulator (s - ky) & 3 = (u - ky) & 3
 #pragma unroll
                 for (int ky = 0; ky < 4; ky++) {
@@ -628,6 +676,7 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int c
                     }
                 }
                 const int done = s - 3;                             // output row oy0 + done is complete
+                pend_row = -1;
                 if (done >= 0) {
                     Pk<T, VEC> out;
 #pragma unroll
@@ -642,13 +691,13 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int c
                         else if (ep.next_scale)        out = modconv_epilogue_vec<T, VEC, EPI, false, false, true>(out, e_sc, 0.f, false, e_bv, e_nx, ep.alpha, ep.gain, ep.clamp);
                         else                           out = modconv_epilogue_vec<T, VEC, EPI, false, false, false>(out, e_sc, 0.f, false, e_bv, e_nx, ep.alpha, ep.gain, ep.clamp);
                     }
-                    *reinterpret_cast<Pk<T, VEC>*>(y + int64_t(oy0 + done) * a.ys_h) = out;
+                    pend = out;
+                    pend_row = oy0 + done;
                 }
-#pragma unroll
-                for (int kx = 0; kx < 4; kx++) raw[kx] = nxt[kx];
             }
         }
     }
+    if (pend_row >= 0) *reinterpret_cast<Pk<T, VEC>*>(y + int64_t(pend_row) * a.ys_h) = pend;
 }
 
 template <class T>
@@ -662,10 +711,9 @@ int launch_blur4_nhwc(const UpArgs& a, hipStream_t stream, const BlurEpi* ep = n
     int rows_per_strip = a.out_h > 256 ? 64 : (a.out_h > 64 ? 32 : 16);
     while (rows_per_strip > 8 && int64_t(a.out_w) * cv * ((a.out_h + rows_per_strip - 1) / rows_per_strip) * a.n < int64_t(kNumCU) * 16 * 64) rows_per_strip >>= 1;
     const int strips_y = (a.out_h + rows_per_strip - 1) / rows_per_strip;
-    const int64_t threads = int64_t(a.out_w) * cv * strips_y * a.n;
-    const int64_t blocks = (threads + 255) / 256;
-    if (blocks > INT32_MAX) return 1;
-    const dim3 g((unsigned)blocks), b(256);
+    const int64_t blocks = (int64_t(a.out_w) * cv + 255) / 256;
+    if (blocks > INT32_MAX || strips_y > 65535 || a.n > 65535) return 1;
+    const dim3 g((unsigned)blocks, (unsigned)strips_y, (unsigned)a.n), b(256);
     const BlurEpi none = {nullptr, nullptr, nullptr, 0.f, 1.f, -1.f};
     if (!ep)           hipLaunchKernelGGL((upfirdn_blur4_nhwc_kernel<T, 0>), g, b, 0, stream, a, cv, strips_y, rows_per_strip, none);
     else if (act == 3) hipLaunchKernelGGL((upfirdn_blur4_nhwc_kernel<T, 3>), g, b, 0, stream, a, cv, strips_y, rows_per_strip, *ep);

@@ -8,7 +8,10 @@ import gnerf_hip
 from torch_utils.ops import upfirdn2d
 dev = torch.device('cuda', 0)
 f = upfirdn2d.setup_filter([1, 3, 3, 1], device=dev)
-for n, c, h in ((1, 64, 513), (1, 128, 257), (4, 64, 513), (4, 128, 257), (4, 128, 513)):
+shapes = ((1, 64, 513), (1, 128, 257), (4, 64, 513), (4, 128, 257), (4, 128, 513))
+if len(sys.argv) > 1:
+    shapes = (tuple(int(v) for v in sys.argv[1].split(',')),)
+for n, c, h in shapes:
     x = torch.randn(n, c, h, h, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
     sc, nx, b = torch.rand(n, c, device=dev) + 0.5, torch.rand(n, c, device=dev) + 0.5, torch.randn(c, device=dev, dtype=torch.float16)
     run = lambda: gnerf_hip.blur_epilogue_channels_last(x, f, [1, 1, 1, 1], blur_gain=4.0, bias=b, scale=sc, act='lrelu', gain=1.41, clamp=256.0, next_scale=nx)
