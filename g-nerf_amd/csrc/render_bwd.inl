@@ -591,7 +591,7 @@ __host__ __device__ inline size_t scatter_lds_floats() {
     return 16 * 8 + size_t(kScatterSamples) * 32 + 2 * size_t(kScatterSlots) + 2 + 2 * size_t(kScatterEntries) + 32;
 }
 
-__global__ __launch_bounds__(kScatterThreads, 2) void plane_scatter_kernel(Params P, const float* __restrict__ stage, float* __restrict__ grad_planes) {
+__global__ __launch_bounds__(kScatterThreads, 8) void plane_scatter_kernel(Params P, const float* __restrict__ stage, float* __restrict__ grad_planes) {
     extern __shared__ __align__(16) float smem[];
     const gnerf_render_params& p = P.p;
     float* rays = smem;                                                        // [16][o, d, ray id, -]
@@ -629,16 +629,48 @@ __global__ __launch_bounds__(kScatterThreads, 2) void plane_scatter_kernel(Param
     const int item = first_ray / p.rays_per_item;                             // a tile never straddles items (checked by the launcher)
     float* grad_item = grad_planes + int64_t(item) * 3 * H * W * 32;
 
+    // A chunk's staged values (its dX rows: eight per half-wave; the depth of this thread's sample) are fetched into registers one chunk
+    // AHEAD, at the top of the previous chunk, and made to land before that chunk's global atomics go out.  Loads, stores and
+    // returnless atomics share one completion counter (vmcnt) and complete out of order with respect to each other, so a wait for a
+    // load behind atomics is a wait for the atomics' acknowledgements too: fetching a chunk at its own top put every chunk behind the
+    // round trips of the previous chunk's atomics.
+    constexpr int kRowsPerHw = kScatterSamples / (kScatterThreads / 32);
+    static_assert(kRowsPerHw * (kScatterThreads / 32) == kScatterSamples, "dX rows divide over the half-waves");
+    float pre_dx[kRowsPerHw], pre_depth = 0.f;
+    auto prefetch = [&](int k0) {
+        const int nk = min(kScatterRanks, n_all - k0);
+        const int n_smp = 16 * nk;
+#pragma unroll
+        for (int q = 0; q < kRowsPerHw; q++) {
+            const int sr = hw + q * (kScatterThreads / 32);
+            pre_dx[q] = 0.f;
+            if (sr < n_smp) {
+                const int ray = reinterpret_cast<const int*>(rays + (sr / nk) * 8)[6];
+                if (ray >= 0) pre_dx[q] = stage[int64_t(ray) * n_all * 33 + n_all + int64_t(k0 + sr % nk) * 32 + ch];
+            }
+        }
+        const int sr3 = tid / 3;
+        pre_depth = 0.f;
+        if (sr3 < n_smp) {
+            const int ray = reinterpret_cast<const int*>(rays + (sr3 / nk) * 8)[6];
+            if (ray >= 0) pre_depth = stage[int64_t(ray) * n_all * 33 + k0 + sr3 % nk];
+        }
+    };
+    prefetch(0);
+
     for (int k0 = 0; k0 < n_all; k0 += kScatterRanks) {
         const int nk = min(kScatterRanks, n_all - k0);
         const int n_smp = 16 * nk;
         // ---- the chunk's dX rows into LDS (sample sr = ray-in-tile * nk + rank-in-chunk)
-        for (int sr = hw; sr < n_smp; sr += kScatterThreads / 32) {
-            const int ray = reinterpret_cast<const int*>(rays + (sr / nk) * 8)[6];
-            dx[sr * 32 + ch] = ray >= 0 ? stage[int64_t(ray) * n_all * 33 + n_all + int64_t(k0 + sr % nk) * 32 + ch] : 0.f;
+#pragma unroll
+        for (int q = 0; q < kRowsPerHw; q++) {
+            const int sr = hw + q * (kScatterThreads / 32);
+            if (sr < n_smp) dx[sr * 32 + ch] = pre_dx[q];
         }
+        const float my_depth = pre_depth;
+        if (k0 + kScatterRanks < n_all) prefetch(k0 + kScatterRanks);         // in flight during the table / prefix / bucket phases below
         // ---- one thread per (sample, plane): its four taps, a table slot and a place in the slot's bucket for each
-        int slot[4] = {-1, -1, -1, -1}, pos[4] = {0, 0, 0, 0};
+        int sp[4] = {-1, -1, -1, -1};                                        // table slot (low 12 bits) | place in its bucket << 12; -1 = no slot
         unsigned keys[4] = {0, 0, 0, 0};
         v4f wgt = {0.f, 0.f, 0.f, 0.f};
         const int my_sr = tid / 3, my_pl = tid % 3;
@@ -647,7 +679,7 @@ __global__ __launch_bounds__(kScatterThreads, 2) void plane_scatter_kernel(Param
             const float* r = rays + (my_sr / nk) * 8;
             const int ray = reinterpret_cast<const int*>(r)[6];
             if (ray >= 0) {
-                const float depth = stage[int64_t(ray) * n_all * 33 + k0 + my_sr % nk];
+                const float depth = my_depth;
                 const float px = __fadd_rn(r[0], __fmul_rn(depth, r[3])) * P.box_scale;
                 const float py = __fadd_rn(r[1], __fmul_rn(depth, r[4])) * P.box_scale;
                 const float pz = __fadd_rn(r[2], __fmul_rn(depth, r[5])) * P.box_scale;
@@ -663,9 +695,9 @@ __global__ __launch_bounds__(kScatterThreads, 2) void plane_scatter_kernel(Param
                         for (int pr = 0; pr < kScatterProbes; pr++) {
                             const unsigned s2 = (h + pr) & (kScatterSlots - 1);
                             const unsigned old = atomicCAS(tag + s2, kScatterEmpty, keys[t]);
-                            if (old == kScatterEmpty || old == keys[t]) { slot[t] = int(s2); break; }
+                            if (old == kScatterEmpty || old == keys[t]) { sp[t] = int(s2); break; }
                         }
-                        if (slot[t] >= 0) pos[t] = atomicAdd(cnt + slot[t], 1);
+                        if (sp[t] >= 0) sp[t] |= atomicAdd(cnt + sp[t], 1) << 12;
                     }
                 }
             }
@@ -691,8 +723,8 @@ __global__ __launch_bounds__(kScatterThreads, 2) void plane_scatter_kernel(Param
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 if (wgt[t] != 0.f) {
-                    if (slot[t] >= 0) {
-                        entry[cnt[slot[t]] + pos[t]] = make_float2(__int_as_float((slot[t] << 13) | (my_sr * 32)), wgt[t]);
+                    if (sp[t] >= 0) {
+                        entry[cnt[sp[t] & 4095] + (sp[t] >> 12)] = make_float2(__int_as_float(((sp[t] & 4095) << 13) | (my_sr * 32)), wgt[t]);
                     } else {
                         for (int c2 = 0; c2 < 32; c2++) {
                             const float c = dx[my_sr * 32 + c2] * wgt[t];
@@ -708,6 +740,11 @@ __global__ __launch_bounds__(kScatterThreads, 2) void plane_scatter_kernel(Param
         // Walking entries, four per LDS round trip, instead of the table's slots (two dependent reads per slot, most of them
         // empty) took this pass from 3.16 to 2.70 ms at config 2 (its atomic requests alone need 2.15 ms).
         {
+            // the next chunk's values have to be in their registers NOW, before this chunk's atomics are in flight (see above); an
+            // empty asm that "rewrites" them makes the compiler wait here and nowhere later
+#pragma unroll
+            for (int q = 0; q < kRowsPerHw; q++) asm volatile("" : "+v"(pre_dx[q]));
+            asm volatile("" : "+v"(pre_depth));
             const int total = cnt[kScatterSlots];
             const int share = (total + kScatterThreads / 32 - 1) / (kScatterThreads / 32);
             const int e0 = hw * share, e1 = min(total, e0 + share);
