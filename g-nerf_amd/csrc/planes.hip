@@ -33,6 +33,10 @@ __device__ __forceinline__ void publish_absmax(unsigned m, unsigned* out) {
     }
 }
 
+// (Measured and dropped, round 3: the same tile with 16-byte global accesses on both sides -- a lane reads four pixels of a channel and
+// writes four channels of a pixel.  Alone it is faster, 34.5 -> 29.8 us for 2 x 100 MB on a warm Infinity Cache; inside bench.py's step,
+// where the source comes from HBM and the render kernel reads the result next, the step got SLOWER: 0.578 -> 0.591 ms, two runs each
+// way on one box, render call unchanged.  The dword form stays.)
 template <bool STATS>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                            int c, int64_t hw, int tiles_p, int tiles_c, unsigned* absmax) {
