@@ -175,9 +175,14 @@ def render_orbit(G, z, n_frames, res, device, rank=0, world=1, double_depth=True
         for j, c in enumerate(cams):
             if frame_seed is not None:
                 torch.manual_seed(frame_seed + lo + j)                                      # reproducible renderer draws per frame
+            n = c.shape[0]
+            if k > 1 and n < k:
+                # the last, shorter block of an orbit keeps the batch size of the others (repeat its last camera, drop the extra frames):
+                # a new batch size is a new set of convolution shapes -- a MIOpen solver search in the middle of the orbit
+                c = torch.cat([c, c[-1:].expand(k - n, -1)])
             out = G.synthesis(ws=ws, c=c, noise_mode='const', neural_rendering_resolution=res, cache_backbone=(j == 0), use_cached_backbone=(j > 0))
-            frames.append(H.to_uint8(out['image']))
-            raws.append(H.to_uint8(out['image_raw']))
+            frames.append(H.to_uint8(out['image'][:n]))
+            raws.append(H.to_uint8(out['image_raw'][:n]))
     return torch.cat(frames), torch.cat(raws), (lo, hi)
 
 
