@@ -410,6 +410,9 @@ def main():
     amax_cl = gnerf_hip.planes_absmax(planes_cl)
     headline_nchw = not args.producer_layout
 
+    # (Measured and dropped: ray generation and the two draws on a second stream beside the 100 MB repack, joined in front of the render
+    # call -- 0.581 -> 0.616 ms per step, two runs each way on one box: the cross-stream dependencies cost more (the render call's own
+    # HIP-event time grows from 0.509 to 0.541 ms) than the 20 us of small launches they hide.)
     def step(i=None, mlp='auto', nchw_input=True):
         o, d = gnerf_hip.make_rays(c2w, intr, RES)
         if nchw_input:
