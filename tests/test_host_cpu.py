@@ -350,6 +350,57 @@ print("overlay ok")
     assert out.returncode == 0 and 'overlay ok' in out.stdout, out.stderr[-2000:]
 
 
+def test_generator_host_side_caches_and_backend_switch():
+    """Small host-side pieces of the generator harness: the per-parameter-version cache of converted parameters (the fp16 copies of
+    fp32 biases), the orbit's last short block keeping the batch size, and the MIOpen solver-search switch."""
+    import gnerf_generator as GG
+    import gnerf_harness as H
+    import gen_videos_mi355x as GV
+    m = torch.nn.Module()
+    m.bias = torch.nn.Parameter(torch.randn(8), requires_grad=False)
+    a = GG._cast_param(m, 'bias', torch.float16)
+    assert a.dtype == torch.float16 and GG._cast_param(m, 'bias', torch.float16) is a            # cached
+    assert GG._cast_param(m, 'bias', torch.float32) is m.bias                                    # nothing to convert
+    with torch.no_grad():
+        m.bias.add_(1.0)
+    b = GG._cast_param(m, 'bias', torch.float16)
+    assert b is not a and torch.equal(b, m.bias.half())                                          # the version moved: converted again
+    m.bias.requires_grad_(True)
+    assert GG._cast_param(m, 'bias', torch.float16).requires_grad                                # training: stays in the graph, not cached
+    m.none = None
+    assert GG._cast_param(m, 'none', torch.float16) is None
+    # orbit of 6 frames, 4 cameras per call: the second block is padded to 4 cameras and its 2 extra frames dropped
+    calls = []
+
+    class G:
+        rendering_kwargs = {'avg_camera_radius': 2.7, 'depth_resolution': 4, 'depth_resolution_importance': 4}
+        z_dim = 8
+
+        def mapping(self, z, c):
+            return torch.zeros(z.shape[0], 14, 8)
+
+        def synthesis(self, ws, c, **kw):
+            calls.append(c.shape[0])
+            n = c.shape[0]
+            return {'image': c[:, :3].reshape(n, 3, 1, 1).expand(n, 3, 4, 4), 'image_raw': torch.zeros(n, 3, 2, 2)}
+    frames, raws, (lo, hi) = GV.render_orbit(G(), torch.zeros(1, 8), 6, 2, torch.device('cpu'), double_depth=False, frames_per_call=4)
+    assert calls == [4, 4] and frames.shape == (6, 4, 4, 3) and raws.shape == (6, 2, 2, 3) and (lo, hi) == (0, 6)
+    singles, _, _ = GV.render_orbit(G(), torch.zeros(1, 8), 6, 2, torch.device('cpu'), double_depth=False)
+    assert torch.equal(frames, singles)
+    # solver search: argument wins over the environment, environment over the default (on)
+    old = torch.backends.cudnn.benchmark
+    try:
+        assert H.configure_backend(False) is False and torch.backends.cudnn.benchmark is False
+        assert H.configure_backend(True) is True and torch.backends.cudnn.benchmark is True
+        os.environ['GNERF_MIOPEN_FIND'] = '0'
+        assert H.configure_backend() is False
+        del os.environ['GNERF_MIOPEN_FIND']
+        assert H.configure_backend() is True
+    finally:
+        os.environ.pop('GNERF_MIOPEN_FIND', None)
+        torch.backends.cudnn.benchmark = old
+
+
 def test_bench_accounting_matches_survey():
     """bench.py's algorithmic-work constants are SURVEY.md section 8d's: 136 331 908 compulsory HBM bytes per config-2 call,
     8 320 MLP FLOP per sample, 1 536 gather bytes per sample; the scene builder gives config 2's shapes."""
