@@ -156,9 +156,9 @@ __global__ __launch_bounds__(kThreads) void modconv_epilogue_kernel(EpiArgs a) {
     for (int k = 0; k < VEC; k++) {
         const float u = t[k] + bv;
         float r = u;
-        if (ACT == 3) r = u > 0.f ? u : u * a.alpha;          // lrelu
+        if (ACT == 3) r = (a.alpha >= 0.f && a.alpha <= 1.f) ? fmaxf(u, u * a.alpha) : (u > 0.f ? u : u * a.alpha);          // lrelu (see common.h)
         r *= a.gain;
-        if (a.clamp >= 0.f) r = r > a.clamp ? a.clamp : (r < -a.clamp ? -a.clamp : r);
+        if (a.clamp >= 0.f) r = __builtin_amdgcn_fmed3f(r, -a.clamp, a.clamp);                     // NaN -> -clamp (bias_act.cu:143)
         store_as<T>(out.v, k, r);
     }
     *reinterpret_cast<P*>(y + v * VEC) = out;

@@ -983,6 +983,28 @@ def test_bias_act_layouts_and_edges(dev):
     np.testing.assert_allclose(bias_act.bias_act(big, bb, act='lrelu', clamp=256).float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-3, atol=2e-3)
 
 
+def test_clamp_sends_nan_to_minus_clamp_like_the_reference_kernel(dev):
+    """The forward clamp of bias_act and of the fused epilogues is v_med3_f32: NaN -> -clamp, which is what the reference's CUDA kernel
+    computes (bias_act.cu:143: `(y > -clamp & y < clamp) ? y : (y >= 0) ? clamp : -clamp`); +-inf clamp to +-clamp; without a clamp
+    NaN passes through.  (The CPU `_ref` path's torch.clamp keeps NaN, bias_act.py:121.)"""
+    import gnerf_hip
+    from torch_utils.ops import bias_act
+    for dtype in (torch.float32, torch.float16):
+        x = torch.tensor([float('nan'), float('inf'), -float('inf'), 0.5, -3.0, 300.0], device=dev, dtype=dtype).reshape(1, 6, 1, 1).expand(1, 6, 4, 4).contiguous()
+        b = torch.zeros(6, device=dev, dtype=dtype)
+        for act in ('linear', 'lrelu'):
+            y = bias_act.bias_act(x, b, act=act, gain=1.0, clamp=2.0)[0, :, 0, 0].float().cpu()
+            want = torch.tensor([-2.0, 2.0, -2.0, 0.5, -3.0 if act == 'linear' else -0.6, 2.0])
+            want = want.clamp(-2.0, 2.0)
+            assert torch.allclose(y, want, atol=2e-3), (dtype, act, y)
+            y = bias_act.bias_act(x, b, act=act, gain=1.0)[0, :, 0, 0].float().cpu()
+            assert torch.isnan(y[0]) and torch.isinf(y[1]) and y[1] > 0
+        e = gnerf_hip.modconv_epilogue(x, b, act='lrelu', gain=1.0, clamp=2.0)[0, :, 0, 0].float().cpu()
+        assert torch.allclose(e, torch.tensor([-2.0, 2.0, -2.0, 0.5, -0.6, 2.0]), atol=2e-3)
+        ec = gnerf_hip.modconv_epilogue(x.contiguous(memory_format=torch.channels_last), b, act='lrelu', gain=1.0, clamp=2.0)
+        assert torch.equal(ec.contiguous(), gnerf_hip.modconv_epilogue(x, b, act='lrelu', gain=1.0, clamp=2.0))
+
+
 @pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
 def test_bias_act_channels_last_kernel(dev, dtype):
     """The channels-last form (bias along the fastest axis, a lane keeps its VEC biases in registers) against the NCHW result of the
@@ -1895,6 +1917,20 @@ def test_blur_epilogue_fused_equals_two_passes(dev, dtype):
                         assert torch.equal(got, want), (n, c, pad, scale is None, nxt is None, act)
     with pytest.raises(RuntimeError):
         gnerf_hip.blur_epilogue_channels_last(x.contiguous(), f, [1, 1, 1, 1])
+    if dtype == torch.float16:
+        # one large image (an orbit frame's layers): the strip length follows the launch's parallelism (8 .. 64 rows), and the result
+        # must not -- against the PyTorch-op blur (upfirdn2d.py:168-213) + the separate epilogue, to the storage type's rounding
+        for (n, c, h) in [(1, 64, 513), (1, 32, 131), (2, 128, 257)]:
+            x = (torch.randn(n, c, h, h, generator=gen) * 3).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+            sc, nx, b = (torch.randn(n, c, generator=gen) + 1).to(dev), (torch.randn(n, c, generator=gen) + 1).to(dev), torch.randn(c, generator=gen).to(dev)
+            kw = dict(bias=b, scale=sc, act='lrelu', gain=1.3, clamp=256.0, next_scale=nx)
+            got = gnerf_hip.blur_epilogue_channels_last(x, f, [1, 1, 1, 1], blur_gain=4.0, **kw)
+            two = gnerf_hip.modconv_epilogue(upfirdn2d.upfirdn2d(x, f, padding=[1, 1, 1, 1], gain=4.0), **kw)
+            assert torch.equal(got, two)
+            ref = upfirdn2d.upfirdn2d(x.float(), f, padding=[1, 1, 1, 1], gain=4.0, impl='ref').to(dtype).contiguous(memory_format=torch.channels_last)
+            want = gnerf_hip.modconv_epilogue(ref, **kw)
+            diff = (got.float() - want.float()).abs()
+            assert float(diff.max()) <= 2e-2 * float(want.float().abs().max()) and float(diff.mean()) <= 2e-4 * float(want.float().abs().max())
 
 
 def test_torgb_channels_last_vs_composed_ops(dev):
