@@ -2,6 +2,7 @@
 Python modules (PyTorch-op paths, i.e. what the reference does for CPU tensors) reproduce the golden
 vectors; the overlay packages resolve the way the reference's imports need."""
 
+import ctypes
 import os
 import re
 import subprocess
@@ -399,6 +400,26 @@ def test_generator_host_side_caches_and_backend_switch():
     finally:
         os.environ.pop('GNERF_MIOPEN_FIND', None)
         torch.backends.cudnn.benchmark = old
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """include/gnerf_hip.h is a C header (the boundary a cgo / JNI / ctypes binding would bind): tests/cabi/cabi_smoke.c compiles against
+    it as strict C99 with gcc, links libgnerf_hip.so, and the entry points that need no GPU answer -- version = the header's, build
+    string, workspace size, argument errors with a message.  The same struct size as the ctypes mirror."""
+    import shutil
+    import subprocess
+    import gnerf_hip
+    if shutil.which('gcc') is None or not os.path.isfile(gnerf_hip.LIB_PATH):
+        pytest.skip('needs gcc and the built library')
+    exe = str(tmp_path / 'cabi_smoke')
+    libdir = os.path.dirname(gnerf_hip.LIB_PATH)
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-pedantic', '-I' + os.path.join(ROOT, 'include'),
+                    os.path.join(ROOT, 'tests', 'cabi', 'cabi_smoke.c'), '-o', exe, '-L' + libdir, '-lgnerf_hip',
+                    '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib'], check=True, capture_output=True, text=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert f'abi={gnerf_hip.ABI_VERSION} ' in out.stdout
+    assert f'sizeof(gnerf_render_params)={ctypes.sizeof(gnerf_hip.RenderParams)} ' in out.stdout
 
 
 def test_bench_accounting_matches_survey():
