@@ -270,9 +270,12 @@ __global__ __launch_bounds__(kThreads) void scale_channels_nhwc_kernel(const T* 
 // It is a streaming read of x: C/8 lanes share a pixel, one 16-byte vector each, three v_dot2_f32_f16 chains per lane on the packed
 // halves as loaded, a butterfly over the pixel's lanes, the first three lanes store (y is NCHW: it is added to the running image).
 // Replaces scale_channels (read + write of x) + MIOpen's 1x1 convolution + the bias/clamp pass: 0.22 -> 0.06 ms on [4,128,512,512].
-template <int LPP>                                         // lanes per pixel = C / 8
+// ACCUM: instead of storing y, add it to the running fp32 image `img` [n,3,pixels] in place -- the block's `img.add_(y.to(float32))`
+// (networks_stylegan2.py:461-463) with the same roundings (y rounded to fp16 first), without materialising y: two launches fewer per block.
+template <int LPP, bool ACCUM>                             // lanes per pixel = C / 8
 __global__ __launch_bounds__(kThreads) void torgb_nhwc_kernel(const __half* __restrict__ x, const float* __restrict__ weight, const float* __restrict__ styles,
-                                                              const __half* __restrict__ bias, __half* __restrict__ y, unsigned pixels, float clamp) {
+                                                              const __half* __restrict__ bias, __half* __restrict__ y, float* __restrict__ img,
+                                                              unsigned pixels, float clamp) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     constexpr int C = LPP * 8, PPB = kThreads / LPP;      // pixels per workgroup step
     constexpr int UNROLL = 4;
@@ -288,7 +291,8 @@ __global__ __launch_bounds__(kThreads) void torgb_nhwc_kernel(const __half* __re
         }
     const float b = sub < 3 && bias ? __half2float(bias[sub]) : 0.f;
     const __half* xn = x + int64_t(n) * pixels * C;
-    __half* yn = y + int64_t(n) * 3 * pixels;
+    __half* yn = ACCUM ? nullptr : y + int64_t(n) * 3 * pixels;
+    float* in_ = ACCUM ? img + int64_t(n) * 3 * pixels : nullptr;
     for (unsigned p0 = (blockIdx.x * UNROLL) * PPB; p0 < pixels; p0 += gridDim.x * UNROLL * PPB) {
         uint4 raw[UNROLL];
 #pragma unroll
@@ -314,7 +318,8 @@ __global__ __launch_bounds__(kThreads) void torgb_nhwc_kernel(const __half* __re
             if (sub < 3 && p < pixels) {
                 float r = __half2float(__float2half(sub == 0 ? acc[0] : (sub == 1 ? acc[1] : acc[2]))) + b;
                 if (clamp >= 0.f) r = __builtin_amdgcn_fmed3f(r, -clamp, clamp);          // NaN -> -clamp (bias_act.cu:143)
-                yn[int64_t(sub) * pixels + p] = __float2half(r);
+                if constexpr (ACCUM) in_[int64_t(sub) * pixels + p] += __half2float(__float2half(r));
+                else                 yn[int64_t(sub) * pixels + p] = __float2half(r);
             }
         }
     }
@@ -441,10 +446,10 @@ extern "C" int gnerf_modconv_epilogue_nhwc(const void* x, void* y, int dtype, in
     return check_launch("modconv_epilogue_nhwc");
 }
 
-extern "C" int gnerf_torgb_nhwc(const void* x, const float* weight, const float* styles, const void* bias, void* y,
-                                int n, int pixels, int channels, float clamp, gnerf_stream_t stream) {
+static int torgb_nhwc_impl(const void* x, const float* weight, const float* styles, const void* bias, void* y, float* img,
+                           int n, int pixels, int channels, float clamp, gnerf_stream_t stream) {
     using namespace gnerf;
-    if (!x || !weight || !styles || !y) return fail(GNERF_E_ARG, "torgb_nhwc: null pointer");
+    if (!x || !weight || !styles || (!y && !img)) return fail(GNERF_E_ARG, "torgb_nhwc: null pointer");
     if (n < 1 || n > 65535 || pixels < 1) return fail(GNERF_E_ARG, "torgb_nhwc: bad shape");
     if (reinterpret_cast<uintptr_t>(x) & 15) return fail(GNERF_E_ARG, "torgb_nhwc: x must be 16-byte aligned");
     hipStream_t s = as_stream(stream);
@@ -452,7 +457,8 @@ extern "C" int gnerf_torgb_nhwc(const void* x, const float* weight, const float*
     const __half* bh = static_cast<const __half*>(bias);
     __half* yh = static_cast<__half*>(y);
 #define GNERF_RGB(L_) do { const int ppb = kThreads / L_ * 4; int blocks = (pixels + ppb - 1) / ppb; if (blocks > kNumCU * 8) blocks = kNumCU * 8; \
-        hipLaunchKernelGGL((torgb_nhwc_kernel<L_>), dim3((unsigned)blocks, n), dim3(kThreads), 0, s, xh, weight, styles, bh, yh, unsigned(pixels), clamp); } while (0)
+        if (img) hipLaunchKernelGGL((torgb_nhwc_kernel<L_, true>), dim3((unsigned)blocks, n), dim3(kThreads), 0, s, xh, weight, styles, bh, yh, img, unsigned(pixels), clamp); \
+        else     hipLaunchKernelGGL((torgb_nhwc_kernel<L_, false>), dim3((unsigned)blocks, n), dim3(kThreads), 0, s, xh, weight, styles, bh, yh, img, unsigned(pixels), clamp); } while (0)
     switch (channels) {
         case 32: GNERF_RGB(4); break;
         case 64: GNERF_RGB(8); break;
@@ -463,4 +469,16 @@ extern "C" int gnerf_torgb_nhwc(const void* x, const float* weight, const float*
     }
 #undef GNERF_RGB
     return check_launch("torgb_nhwc");
+}
+
+extern "C" int gnerf_torgb_nhwc(const void* x, const float* weight, const float* styles, const void* bias, void* y,
+                                int n, int pixels, int channels, float clamp, gnerf_stream_t stream) {
+    if (!y) return gnerf::fail(GNERF_E_ARG, "torgb_nhwc: null pointer");
+    return torgb_nhwc_impl(x, weight, styles, bias, y, nullptr, n, pixels, channels, clamp, stream);
+}
+
+extern "C" int gnerf_torgb_nhwc_accumulate(const void* x, const float* weight, const float* styles, const void* bias, float* img,
+                                           int n, int pixels, int channels, float clamp, gnerf_stream_t stream) {
+    if (!img) return gnerf::fail(GNERF_E_ARG, "torgb_nhwc_accumulate: null pointer");
+    return torgb_nhwc_impl(x, weight, styles, bias, nullptr, img, n, pixels, channels, clamp, stream);
 }

@@ -339,15 +339,23 @@ class ToRGB(nn.Module):
         self.bias = nn.Parameter(torch.zeros(c_out))
         self.weight_gain = 1 / math.sqrt(c_in)
 
-    def forward(self, x, w, fused=True):
+    def streams_into_image(self, x):
+        """True when forward(x, ..., accumulate_into=img) adds the layer's output to the block's running image in its own launch."""
+        import gnerf_hip
+        return (_fast_path(x, self.weight, self.bias, self.affine.weight, self.affine.bias) and x.dtype == torch.float16 and _is_channels_last(x)
+                and self.weight.shape[0] == 3 and x.shape[1] in gnerf_hip.TORGB_CHANNELS)
+
+    def forward(self, x, w, fused=True, accumulate_into=None):
         n, c_in, h, wd = x.shape
         aff = (self.affine.weight, self.affine.bias)
         fast = _fast_path(x, self.weight, self.bias, *aff)
         styles = _per_latent(self, w, 'styles', aff, lambda: self.affine(w) * self.weight_gain) if fast else self.affine(w) * self.weight_gain
+        assert accumulate_into is None or self.streams_into_image(x)
         if fast:
             import gnerf_hip
             if x.dtype == torch.float16 and _is_channels_last(x) and self.weight.shape[0] == 3 and c_in in gnerf_hip.TORGB_CHANNELS:
-                return gnerf_hip.torgb_channels_last(x, self.weight, styles, _cast_param(self, 'bias', x.dtype), clamp=self.conv_clamp)      # one streaming read of x
+                return gnerf_hip.torgb_channels_last(x, self.weight, styles, _cast_param(self, 'bias', x.dtype), clamp=self.conv_clamp,
+                                                     accumulate_into=accumulate_into)      # one streaming read of x
             if x.dtype == torch.float16 and n > 1:
                 x = F.conv2d(gnerf_hip.scale_channels(x, styles), self.weight.to(x.dtype))
             else:
@@ -396,6 +404,15 @@ class Block(nn.Module):
                 x = x.contiguous(memory_format=torch.channels_last)
             x, folded = self.conv0(x, ws[0], noise_mode, fused=fused, next_layer=self.conv1, next_w=ws[1])
             x = self.conv1(x, ws[1], noise_mode, fused=fused, prescaled=folded)
+        if (img is not None and img.is_cuda and img.dtype == torch.float32 and not self.emit_channels_last and self.torgb.streams_into_image(x)
+                and not (torch.is_grad_enabled() and img.requires_grad)):
+            # upsample the running image, then let ToRGB add its output to it in its own launch (no fp16 y, no conversion, no add kernel)
+            if self.up == 2:
+                img = upfirdn2d.upsample2d(img, self.resample_filter)
+            if img.is_contiguous() and tuple(img.shape) == (x.shape[0], 3, x.shape[2], x.shape[3]):
+                return x, self.torgb(x, ws[-1], fused=fused, accumulate_into=img)
+            y = self.torgb(x, ws[-1], fused=fused).float()
+            return x, img.add_(y)
         y = self.torgb(x, ws[-1], fused=fused).float()
         if img is not None and self.up == 2 and self.emit_channels_last and img.is_cuda:
             return x, upfirdn2d.upsample2d_add_channels_last(img, y, self.resample_filter)

@@ -23,7 +23,7 @@ _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.float64: F64}
 
 MAX_SAMPLES = 256
 DEBUG_SLOTS = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 # decoder arithmetic of the fused renderer (GNERF_MLP_* in include/gnerf_hip.h)
 MLP_MODES = {'auto': 0, 'f16x3': 1, 'f32': 2}
 
@@ -96,6 +96,7 @@ SIGNATURES = {
     'gnerf_scale_channels_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_modconv_epilogue_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p, _c_i, _c_f, _c_f, _c_f, _c_p, _c_p]),
     'gnerf_torgb_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_p]),
+    'gnerf_torgb_nhwc_accumulate': (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_p]),
     'gnerf_blur4_epilogue_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_p, _c_p, _c_i, _c_f, _c_f, _c_f, _c_p, _c_p]),
 }
 
@@ -644,9 +645,11 @@ def blur_epilogue_channels_last(x, f, padding, blur_gain=1.0, bias=None, scale=N
 TORGB_CHANNELS = (32, 64, 128, 256, 512)
 
 
-def torgb_channels_last(x, weight, styles, bias=None, clamp=None):
+def torgb_channels_last(x, weight, styles, bias=None, clamp=None, accumulate_into=None):
     """ToRGBLayer to three channels on a channels_last float16 x [N,C,H,W] (networks_stylegan2.py:349-367): weight [3,C,1,1] or [3,C]
-    float32, styles [N,C] float32 (weight_gain applied), bias [3].  Returns float16 [N,3,H,W], NCHW.  See include/gnerf_hip.h."""
+    float32, styles [N,C] float32 (weight_gain applied), bias [3].  Returns float16 [N,3,H,W], NCHW.  See include/gnerf_hip.h.
+    accumulate_into: a contiguous float32 [N,3,H,W] image; the layer's output (rounded to float16) is added to it IN PLACE and the
+    image is returned -- the block's `img.add_(y.to(torch.float32))` in the same launch."""
     _require_cuda(x, weight, styles, bias)
     if x.dtype != torch.float16 or not is_channels_last(x) or x.shape[1] not in TORGB_CHANNELS:
         raise RuntimeError('torgb_channels_last: x must be a channels_last float16 tensor with 32, 64, 128, 256 or 512 channels')
@@ -656,6 +659,16 @@ def torgb_channels_last(x, weight, styles, bias=None, clamp=None):
     if w32.numel() != 3 * c or s32.numel() != n * c:
         raise RuntimeError('torgb_channels_last: weight must be [3,C] and styles [N,C]')
     b = None if bias is None else bias.detach().to(torch.float16).contiguous()
+    if accumulate_into is not None:
+        img = accumulate_into
+        _require_cuda(img)
+        if img.dtype != torch.float32 or tuple(img.shape) != (n, 3, h, w) or not img.is_contiguous():
+            raise RuntimeError('torgb_channels_last: accumulate_into must be a contiguous float32 [N,3,H,W] tensor')
+        with _on_device(x.device):
+            code = load().gnerf_torgb_nhwc_accumulate(_ptr(x), _ptr(w32), _ptr(s32), _ptr(b), _ptr(img), n, h * w, c,
+                                                      float(-1 if clamp is None else clamp), _stream(x))
+        _check(code, 'gnerf_torgb_nhwc_accumulate')
+        return img
     y = torch.empty([n, 3, h, w], dtype=torch.float16, device=x.device)
     with _on_device(x.device):
         code = load().gnerf_torgb_nhwc(_ptr(x), _ptr(w32), _ptr(s32), _ptr(b), _ptr(y), n, h * w, c, float(-1 if clamp is None else clamp), _stream(x))

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GNERF_ABI_VERSION 6
+#define GNERF_ABI_VERSION 7
 
 /* error codes */
 #define GNERF_OK            0
@@ -125,6 +125,11 @@ int gnerf_blur4_epilogue_nhwc(const void* x, const float* f, void* y, int dtype,
  * added to the running image); clamp < 0 = none.  One streaming read of x instead of scale pass + 1x1 convolution + bias pass. */
 int gnerf_torgb_nhwc(const void* x, const float* weight, const float* styles, const void* bias, void* y,
                      int n, int pixels, int channels, float clamp, gnerf_stream_t stream);
+/* (ABI 7) The same layer ADDED to the block's running image instead of stored: img[n, o, p] += float(y[n, o, p]) with y as above
+ * (rounded to float16 first), img float32 [n, 3, pixels] dense -- `img.add_(y.to(torch.float32))` of the 'skip' architecture
+ * (networks_stylegan2.py:461-463) without materialising y or converting it: two launches fewer per block. */
+int gnerf_torgb_nhwc_accumulate(const void* x, const float* weight, const float* styles, const void* bias, float* img,
+                                int n, int pixels, int channels, float clamp, gnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * upfirdn2d.  Zero-insert upsample, pad/crop, 2-D FIR, decimate (upfirdn2d.cpp:20-102).

@@ -1953,3 +1953,19 @@ def test_torgb_channels_last_vs_composed_ops(dev):
             np.testing.assert_allclose(got.float().cpu().numpy(), want.half().float().cpu().numpy(), rtol=2e-3, atol=2e-3 * float(want.abs().max()))
     with pytest.raises(RuntimeError):
         gnerf_hip.torgb_channels_last(x.contiguous(), weight, styles, bias)
+    # accumulate form: the layer added to the block's running fp32 image in the same launch == img.add_(y.to(float32)), bit for bit
+    for (n, c, h, w) in [(4, 128, 24, 40), (1, 64, 33, 17), (2, 32, 9, 13)]:
+        x = (torch.randn(n, c, h, w, generator=gen) * 2).to(dev).half().contiguous(memory_format=torch.channels_last)
+        weight = torch.randn(3, c, 1, 1, generator=gen).to(dev)
+        styles = ((torch.randn(n, c, generator=gen) + 1) / math.sqrt(c)).to(dev)
+        bias = torch.randn(3, generator=gen).to(dev)
+        img = torch.randn(n, 3, h, w, generator=gen).to(dev)
+        for clamp in (None, 0.75):
+            want = img + gnerf_hip.torgb_channels_last(x, weight, styles, bias, clamp=clamp).float()
+            acc = img.clone()
+            got = gnerf_hip.torgb_channels_last(x, weight, styles, bias, clamp=clamp, accumulate_into=acc)
+            assert got is acc and torch.equal(got, want)
+        with pytest.raises(RuntimeError):
+            gnerf_hip.torgb_channels_last(x, weight, styles, bias, accumulate_into=img.half())
+        with pytest.raises(RuntimeError):
+            gnerf_hip.torgb_channels_last(x, weight, styles, bias, accumulate_into=img[:, :, :, ::2])
