@@ -218,12 +218,45 @@ __global__ __launch_bounds__(kThreads) void modconv_epilogue_nhwc_kernel(EpiNhwc
         pix = v / cv; c0 = (v % cv) * VEC;
         pix_end = pix + 1; pix_step = 1;
     }
+    // the lane's channel vector of the per-channel operands: whole vectors under uniform conditions where the channel count allows
+    // (element-by-element conditional loads compile to one dependent round trip each -- 24 of them in front of 16 data vectors)
     float sc[VEC], nx[VEC], bv[VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; k++) {
-        sc[k] = SCALE ? a.scale[int64_t(n) * a.channels + c0 + k] : 1.f;
-        nx[k] = NEXT ? round_to<T>(a.next_scale[int64_t(n) * a.channels + c0 + k]) : 1.f;
-        bv[k] = a.bias ? float(load_as<T>(static_cast<const T*>(a.bias), c0 + k)) : 0.f;
+    for (int k = 0; k < VEC; k++) { sc[k] = 1.f; nx[k] = 1.f; bv[k] = 0.f; }
+    if constexpr (VEC % 4 == 0) {
+        float4 sv[VEC / 4], nv[VEC / 4];
+        P bb;
+        const bool has_b = a.bias != nullptr;
+        if constexpr (SCALE) {
+#pragma unroll
+            for (int q = 0; q < VEC / 4; q++) sv[q] = *reinterpret_cast<const float4*>(a.scale + int64_t(n) * a.channels + c0 + 4 * q);
+        }
+        if constexpr (NEXT) {
+#pragma unroll
+            for (int q = 0; q < VEC / 4; q++) nv[q] = *reinterpret_cast<const float4*>(a.next_scale + int64_t(n) * a.channels + c0 + 4 * q);
+        }
+        if (has_b) bb = *reinterpret_cast<const P*>(static_cast<const T*>(a.bias) + c0);
+        if constexpr (SCALE) {
+#pragma unroll
+            for (int q = 0; q < VEC / 4; q++) { sc[4 * q] = sv[q].x; sc[4 * q + 1] = sv[q].y; sc[4 * q + 2] = sv[q].z; sc[4 * q + 3] = sv[q].w; }
+        }
+        if constexpr (NEXT) {
+#pragma unroll
+            for (int q = 0; q < VEC / 4; q++) {
+                nx[4 * q] = round_to<T>(nv[q].x); nx[4 * q + 1] = round_to<T>(nv[q].y); nx[4 * q + 2] = round_to<T>(nv[q].z); nx[4 * q + 3] = round_to<T>(nv[q].w);
+            }
+        }
+        if (has_b) {
+#pragma unroll
+            for (int k = 0; k < VEC; k++) bv[k] = float(load_as<T>(bb.v, k));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+            sc[k] = SCALE ? a.scale[int64_t(n) * a.channels + c0 + k] : 1.f;
+            nx[k] = NEXT ? round_to<T>(a.next_scale[int64_t(n) * a.channels + c0 + k]) : 1.f;
+            bv[k] = a.bias ? float(load_as<T>(static_cast<const T*>(a.bias), c0 + k)) : 0.f;
+        }
     }
     const T* xn = static_cast<const T*>(a.x) + int64_t(n) * a.pixels * a.channels + c0;
     T* yn = static_cast<T*>(a.y) + int64_t(n) * a.pixels * a.channels + c0;
@@ -421,7 +454,9 @@ extern "C" int gnerf_modconv_epilogue_nhwc(const void* x, void* y, int dtype, in
     if (n < 1 || n > 65535 || pixels < 1 || channels < 1 || int64_t(pixels) * channels > INT32_MAX) return fail(GNERF_E_ARG, "modconv_epilogue_nhwc: bad shape");
     if (act != 1 && act != 3) return fail(GNERF_E_UNSUPPORTED, "modconv_epilogue_nhwc: only linear and lrelu");
     EpiNhwcArgs a{x, y, scale, noise, bias, next_scale, unsigned(pixels), unsigned(channels), noise_per_item, round_noise, act, alpha, gain, clamp};
-    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    // the vector form also fetches the per-channel operands as 16-byte vectors
+    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(scale) |
+                      reinterpret_cast<uintptr_t>(next_scale) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0;
     hipStream_t s = as_stream(stream);
 #define GNERF_EPI5(T_, V_, A_, S_, N_, X_) do { \
         if (fixed) hipLaunchKernelGGL((modconv_epilogue_nhwc_kernel<T_, V_, A_, S_, N_, X_, true>), g, dim3(kThreads), 0, s, a, ppb); \

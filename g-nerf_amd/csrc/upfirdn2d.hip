@@ -820,7 +820,8 @@ extern "C" int gnerf_blur4_epilogue_nhwc(const void* x, const float* f, void* y,
     if (int64_t(n) * c * out_h * out_w > INT32_MAX || int64_t(n) * c * in_h * in_w > INT32_MAX) return fail(GNERF_E_ARG, "blur4_epilogue_nhwc: tensor is too large");
     const int es = dtype == GNERF_F16 ? 2 : (dtype == GNERF_F32 ? 4 : 0);
     if (!es) return fail(GNERF_E_ARG, "blur4_epilogue_nhwc: dtype must be float32 or float16");
-    if (c % (16 / es) != 0 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15))
+    if (c % (16 / es) != 0 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(scale) |
+                                reinterpret_cast<uintptr_t>(next_scale) | reinterpret_cast<uintptr_t>(bias)) & 15))
         return fail(GNERF_E_UNSUPPORTED, "blur4_epilogue_nhwc: channels must fill 16-byte vectors and the tensors be 16-byte aligned");
     UpArgs a{x, f, y, n, c, in_h, in_w, int64_t(in_h) * in_w * c, 1, int64_t(in_w) * c, c, 4, 4, 4, 1, out_h, out_w,
              int64_t(out_h) * out_w * c, 1, int64_t(out_w) * c, c, 1, 1, 1, 1, padx0, pady0, flip ? 1 : 0, blur_gain};

@@ -628,9 +628,12 @@ def blur_epilogue_channels_last(x, f, padding, blur_gain=1.0, bias=None, scale=N
     oh, ow = h + py0 + py1 - 3, w + px0 + px1 - 3
     if oh < 1 or ow < 1:
         raise RuntimeError('blur_epilogue_channels_last: output must be at least 1x1')
-    s32 = None if scale is None else scale.detach().to(torch.float32).contiguous()
-    nx = None if next_scale is None else next_scale.detach().to(torch.float32).contiguous()
-    b = None if bias is None else bias.detach().to(x.dtype).contiguous()
+    def vec(t, dtype):          # dense, and 16-byte aligned (the kernel fetches the per-channel operands as vectors): a view at an odd offset is copied
+        if t is None:
+            return None
+        t = t.detach().to(dtype).contiguous()
+        return t if t.data_ptr() % 16 == 0 else t.clone()
+    s32, nx, b = vec(scale, torch.float32), vec(next_scale, torch.float32), vec(bias, x.dtype)
     if (s32 is not None and s32.numel() != n * c) or (nx is not None and nx.numel() != n * c) or (b is not None and b.numel() != c):
         raise RuntimeError('blur_epilogue_channels_last: scale / next_scale must have N*C and bias C elements')
     y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
