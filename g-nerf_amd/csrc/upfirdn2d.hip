@@ -546,12 +546,24 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int c
     // grid = (column blocks, strips, images): strip and image are the workgroup's, so the row walk below (steps, row validity, row
     // addresses) is wave-uniform -- with one flat index they were per-lane values, every `if (s < steps)` became an exec-masked
     // region, and the vectors loaded for the next row passed through register copies (and a wait for everything in flight) at each
+    // Workgroups are handed to the eight XCDs round-robin in launch order, and each XCD has its own L2: column-neighbours -- which share
+    // three of every 4..16 input columns -- and strip-neighbours would sit on different XCDs and each fetch the shared lines from HBM
+    // (FETCH x 2 + WRITE 1.13-1.25 x the algorithmic bytes).  Re-number so that every XCD owns a contiguous range of workgroups.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        if (total % kNumXCD == 0) {
+            const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
+            const unsigned re = (lin % kNumXCD) * (total / kNumXCD) + lin / kNumXCD;
+            bx = re % gridDim.x; by = (re / gridDim.x) % gridDim.y; bz = re / (gridDim.x * gridDim.y);
+        }
+    }
     const int64_t per_row = int64_t(a.out_w) * cv;
-    const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t t = int64_t(bx) * 256 + threadIdx.x;
     if (t >= per_row) return;
     const int col = int(t);
-    const int sy = blockIdx.y;
-    const int img = blockIdx.z;
+    const int sy = by;
+    const int img = bz;
     const int ox = col / cv, c0 = (col % cv) * VEC;
     const int oy0 = sy * rows_per_strip, rows = min(rows_per_strip, a.out_h - oy0);
     const T* x = static_cast<const T*>(a.x) + img * a.xs_n + c0;
