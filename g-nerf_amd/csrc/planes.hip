@@ -105,7 +105,10 @@ __global__ __launch_bounds__(256) void upsample2x_add_nhwc_kernel(const float* _
     __shared__ float ot[kUpRows * kUpCols * kUpOutPitch];
     const int OH = 2 * h, OW = 2 * w;
     const int tiles_x = OW / kUpCols, tiles_y = OH / kUpRows, groups = c / kUpCh;
+    // XCD-contiguous numbering (workgroups go to the eight XCDs round-robin, each with its own L2): vertical neighbours share two of
+    // their four input rows of `img`, horizontal ones two columns
     int b = blockIdx.x;
+    if (gridDim.x % kNumXCD == 0) b = (blockIdx.x % kNumXCD) * (gridDim.x / kNumXCD) + blockIdx.x / kNumXCD;
     const int tx0 = b % tiles_x; b /= tiles_x;
     const int ty0 = b % tiles_y; b /= tiles_y;
     const int cg0 = b % groups;  b /= groups;
