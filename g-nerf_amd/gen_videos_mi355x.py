@@ -151,9 +151,9 @@ def render_orbit(G, z, n_frames, res, device, rank=0, world=1, double_depth=True
     k = max(int(frames_per_call), 1)
     if k > 1 and (z.shape[0] != 1 or frame_seed is not None):
         raise ValueError('frames_per_call > 1 needs a single latent and no per-frame reseeding')
-    # every camera of this rank's block made on the host and moved in ONE copy (per frame: a pose and an intrinsics upload, two
-    # blocking host-to-device copies in front of every frame's launches)
-    labels = torch.cat([H.camera_label(H.orbit_pose(i, n_frames, radius)) for i in range(lo, hi)]).to(device)
+    # every camera of this rank's block made on the host in one set of batched ops (per frame: ~0.15 ms of small tensor ops each) and
+    # moved in ONE copy (per frame: a pose and an intrinsics upload, two blocking host-to-device copies in front of every frame's launches)
+    labels = H.orbit_labels(range(lo, hi), n_frames, radius).to(device)
     if k > 1:
         cams = [labels[j:j + k] for j in range(0, hi - lo, k)]
     else:

@@ -50,6 +50,34 @@ def orbit_pose(i, frame_num=120, radius=2.7, yaw_range=0.7, pitch_range=0.3, dev
     return lookat_pose(yaw, pitch, radius, device)
 
 
+def orbit_labels(frames, frame_num=120, radius=2.7, yaw_range=0.7, pitch_range=0.3, intrinsics=FFHQ_INTRINSICS):
+    """camera_label(orbit_pose(i, ...)) for every i of `frames`, [len(frames), 25] on the host, in ONE set of batched tensor ops: the
+    per-frame form costs ~0.15 ms of host time per camera (a 240-frame orbit: 30-45 ms in front of a 130 ms orbit).  Same arithmetic
+    per element as lookat_pose, so the rows equal the per-frame labels bit for bit (tests/test_gen_videos_cpu.py)."""
+    dt = torch.float32
+    frames = list(frames)
+    theta = torch.tensor([[3.14 / 2 + yaw_range * math.sin(2 * 3.14 * i / frame_num)] for i in frames], dtype=dt)
+    phi = torch.tensor([[3.14 / 2 - 0.05 + pitch_range * math.cos(2 * 3.14 * i / frame_num)] for i in frames], dtype=dt)
+    n = len(frames)
+    org = torch.zeros(n, 3, dtype=dt)
+    org[:, 0:1] = radius * torch.sin(phi) * torch.cos(math.pi - theta)
+    org[:, 2:3] = radius * torch.sin(phi) * torch.sin(math.pi - theta)
+    org[:, 1:2] = radius * torch.cos(phi)
+
+    def unit(v):
+        return v / torch.norm(v, dim=-1, keepdim=True)
+
+    fwd = unit(unit(-org))
+    up = torch.tensor([[0.0, 1.0, 0.0]], dtype=dt).expand(n, -1)
+    right = -unit(torch.cross(up, fwd, dim=-1))
+    up2 = unit(torch.cross(fwd, right, dim=-1))
+    rot = torch.eye(4, dtype=dt)[None].repeat(n, 1, 1)
+    rot[:, :3, :3] = torch.stack((right, up2, fwd), dim=-1)
+    trans = torch.eye(4, dtype=dt)[None].repeat(n, 1, 1)
+    trans[:, :3, 3] = org
+    return camera_label(trans @ rot, intrinsics)
+
+
 def camera_label(cam2world, intrinsics=FFHQ_INTRINSICS):
     """The 25-float conditioning vector c the generator's synthesis() takes."""
     k = torch.tensor(intrinsics, dtype=torch.float32, device=cam2world.device)

@@ -388,6 +388,10 @@ def test_generator_host_side_caches_and_backend_switch():
     assert calls == [4, 4] and frames.shape == (6, 4, 4, 3) and raws.shape == (6, 2, 2, 3) and (lo, hi) == (0, 6)
     singles, _, _ = GV.render_orbit(G(), torch.zeros(1, 8), 6, 2, torch.device('cpu'), double_depth=False)
     assert torch.equal(frames, singles)
+    # the orbit's camera labels in one batch == frame by frame, bit for bit
+    for fn, frames in ((240, range(240)), (120, range(30, 60)), (7, [6, 0, 3])):
+        want = torch.cat([H.camera_label(H.orbit_pose(i, fn, 2.7)) for i in frames])
+        assert torch.equal(H.orbit_labels(frames, fn, 2.7), want)
     # solver search: argument wins over the environment, environment over the default (on)
     old = torch.backends.cudnn.benchmark
     try:
