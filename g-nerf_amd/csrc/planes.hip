@@ -222,7 +222,35 @@ __global__ __launch_bounds__(256) void make_rays_kernel(const float* __restrict_
     }
 }
 
+// gen_videos.py:173 -- `(img * 127.5 + 128).clamp(0, 255).to(torch.uint8)` followed by the NCHW -> NHWC permute of the frame writer, in one
+// pass: one thread per pixel reads its c channel values (coalesced along x per channel plane) and writes c adjacent bytes.  The product
+// and the sum are rounded separately, as the two PyTorch ops round them; the cast truncates; NaN becomes 0.
+__global__ __launch_bounds__(256) void to_uint8_nhwc_kernel(const float* __restrict__ img, unsigned char* __restrict__ out, int c, int64_t hw, int64_t total) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;          // (image, pixel)
+    if (i >= total) return;
+    const int64_t n = i / hw, p = i - n * hw;
+    const float* src = img + n * c * hw + p;
+    unsigned char* dst = out + i * c;
+    for (int ch = 0; ch < c; ch++) {
+        float m = src[int64_t(ch) * hw] * 127.5f;
+        asm volatile("" : "+v"(m));                                 // the product is rounded on its own, as torch's mul kernel rounds it: no FMA with the add
+        const float v = m + 128.f;
+        dst[ch] = (unsigned char)fminf(fmaxf(v, 0.f), 255.f);
+    }
+}
+
 }  // namespace
+
+extern "C" int gnerf_to_uint8_nhwc(const float* img, unsigned char* out, int n, int c, int h, int w, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!img || !out) return fail(GNERF_E_ARG, "to_uint8_nhwc: null pointer");
+    if (n < 1 || c < 1 || c > 64 || h < 1 || w < 1) return fail(GNERF_E_ARG, "to_uint8_nhwc: bad shape (1 <= channels <= 64)");
+    const int64_t hw = int64_t(h) * w, total = hw * n;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > INT32_MAX) return fail(GNERF_E_ARG, "to_uint8_nhwc: tensor too large");
+    hipLaunchKernelGGL(to_uint8_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), img, out, c, hw, total);
+    return check_launch("to_uint8_nhwc");
+}
 
 static int planes_to_nhwc_impl(const float* planes_nchw, float* planes_nhwc, int np, int c, int h, int w, float* absmax, bool stats,
                                gnerf_stream_t stream) {

@@ -87,6 +87,9 @@ def camera_label(cam2world, intrinsics=FFHQ_INTRINSICS):
 
 def to_uint8(img):
     """[-1,1] float image(s) [N,C,H,W] -> uint8 [N,H,W,C] like gen_videos.py:173."""
+    if img.is_cuda and img.dtype == torch.float32 and img.ndim == 4 and img.shape[1] <= 64 and not (torch.is_grad_enabled() and img.requires_grad):
+        import gnerf_hip
+        return gnerf_hip.to_uint8_nhwc(img)             # the same arithmetic in one launch (csrc/planes.hip)
     return (img * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
 
 

@@ -81,6 +81,7 @@ SIGNATURES = {
     'gnerf_planes_absmax': (_c_i, [_c_p, _c_i64, _c_p, _c_p]),
     'gnerf_planes_from_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_make_rays': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_p, _c_p, _c_p]),
+    'gnerf_to_uint8_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_render_workspace_bytes': (ctypes.c_size_t, []),
     'gnerf_render_forward': (_c_i, [ctypes.POINTER(RenderParams), _c_p]),
     'gnerf_render_backward': (_c_i, [ctypes.POINTER(RenderParams), ctypes.POINTER(RenderGrads), _c_p]),
@@ -457,6 +458,21 @@ def planes_from_nhwc(planes_nhwc, n_items=None):
         code = load().gnerf_planes_from_nhwc(_ptr(planes_nhwc), _ptr(out), np_, c, h, w, _stream(planes_nhwc))
     _check(code, 'gnerf_planes_from_nhwc')
     return out if n_items is None else out.view(n_items, np_ // n_items, c, h, w)
+
+
+def to_uint8_nhwc(img):
+    """(img * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous() for a float32 [N,C,H,W] GPU tensor in one launch
+    (gen_videos.py:173 + the frame writer's layout).  Returns uint8 [N,H,W,C]."""
+    _require_cuda(img)
+    if img.dtype != torch.float32 or img.ndim != 4 or not (1 <= img.shape[1] <= 64):
+        raise RuntimeError('to_uint8_nhwc: expected a float32 [N,C,H,W] tensor with 1..64 channels')
+    x = img.detach().contiguous()
+    n, c, h, w = x.shape
+    out = torch.empty([n, h, w, c], dtype=torch.uint8, device=x.device)
+    with _on_device(x.device):
+        code = load().gnerf_to_uint8_nhwc(_ptr(x), _ptr(out), n, c, h, w, _stream(x))
+    _check(code, 'gnerf_to_uint8_nhwc')
+    return out
 
 
 def make_rays(cam2world, intrinsics, resolution):

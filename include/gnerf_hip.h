@@ -219,6 +219,11 @@ int gnerf_planes_from_nhwc(const float* planes_nhwc, float* planes_nchw, int np,
  * Ray generation (ray_sampler.py:24-63): cam2world [n,4,4], intrinsics [n,3,3] row-major ->
  * origins, dirs [n, res*res, 3]; ray m = row*res + col looks through pixel centre
  * ((col+.5)/res, (row+.5)/res). */
+/* Frame conversion of the video writer (gen_videos.py:173 and the permute in front of it): out[n, y, x, ch] =
+ * uint8(clamp(img[n, ch, y, x] * 127.5 + 128, 0, 255)), product and sum rounded separately, truncating cast, NaN -> 0.
+ * img float32 [n, c, h, w] dense, out uint8 [n, h, w, c] dense, 1 <= c <= 64.  One launch instead of four elementwise passes. */
+int gnerf_to_uint8_nhwc(const float* img, unsigned char* out, int n, int c, int h, int w, gnerf_stream_t stream);
+
 int gnerf_make_rays(const float* cam2world, const float* intrinsics, int n, int res,
                     float* origins, float* dirs, gnerf_stream_t stream);
 

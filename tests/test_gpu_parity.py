@@ -693,6 +693,29 @@ def test_orbit_frames_per_call(dev):
         GV.render_orbit(G, torch.randn(2, G.z_dim, device=dev), 4, 32, dev, double_depth=False, frames_per_call=2)
 
 
+def test_to_uint8_nhwc_matches_the_pytorch_ops(dev):
+    """gnerf_to_uint8_nhwc == (img * 127.5 + 128).clamp(0, 255).to(uint8).permute(0, 2, 3, 1) (gen_videos.py:173), byte for byte: random
+    images, values on and around every half-integer boundary of the product, +-inf, out-of-range values; NaN -> 0."""
+    import gnerf_hip
+    import gnerf_harness as H
+    gen = torch.Generator().manual_seed(11)
+    for shape in ((1, 3, 512, 512), (4, 3, 64, 64), (2, 1, 5, 7), (1, 32, 9, 3)):
+        img = (torch.randn(*shape, generator=gen) * 0.7).to(dev)
+        want = (img * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+        got = gnerf_hip.to_uint8_nhwc(img)
+        assert got.dtype == torch.uint8 and got.shape == want.shape and torch.equal(got, want)
+        assert torch.equal(H.to_uint8(img), want)
+    edges = torch.cat([(torch.arange(-2, 258, dtype=torch.float64) - 128) / 127.5 + d for d in (-1e-6, 0.0, 1e-6)]).float()
+    edges = torch.cat([edges, torch.tensor([float('inf'), -float('inf'), 1e30, -1e30, 3.0, -3.0])])
+    img = edges.reshape(1, 1, 1, -1).to(dev)
+    want = (img * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    assert torch.equal(gnerf_hip.to_uint8_nhwc(img), want)
+    nan = torch.full((1, 3, 2, 2), float('nan'), device=dev)
+    assert int(gnerf_hip.to_uint8_nhwc(nan).max()) == 0
+    with pytest.raises(RuntimeError):
+        gnerf_hip.to_uint8_nhwc(img.half())
+
+
 def test_query_points_vs_oracle(dev):
     import gnerf_hip
     from oracle import render_ref as R
