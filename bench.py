@@ -364,6 +364,104 @@ def backward_times(dev, planes_cl, dec, c2w, intr, reps=5):
     return out
 
 
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process -- which has made NO GPU call and makes none --
+    starts N fresh children of this same script, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what
+    torch.distributed.run would export; the reference's entry point spawns its per-GPU processes itself too, train.py:40-56,104-111),
+    relays rank 0's single JSON line and exits non-zero when any rank did.  Under an outer torch.distributed.run (WORLD_SIZE set) this
+    function is never reached.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               GNERF_BENCH_SELF_LAUNCHED='1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')               # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n_ranks) // n_ranks)))
+    procs = []
+    for r in range(n_ranks):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout is the result line (captured and relayed); the other ranks print nothing there by construction
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    # poll: once a rank has exited non-zero its peers may sit in a collective for ever -- give them 30 s, then end exactly those PIDs
+    deadline = None
+    while any(p.poll() is None for p in procs):
+        if deadline is None and any(p.poll() not in (None, 0) for p in procs):
+            deadline = time.time() + float(os.environ.get('GNERF_BENCH_PEER_GRACE_S', '30'))
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out0 = b''.join(chunks)
+    lines = [ln for ln in out0.decode(errors='replace').splitlines() if ln.strip()]
+    if lines:
+        sys.stdout.write(lines[-1] + '\n')
+        sys.stdout.flush()
+    if any(codes):
+        print(f'bench.py: rank exit codes {codes}', file=sys.stderr)
+        return max(1, next(c for c in codes if c))
+    return 0 if lines else 1
+
+
+def rank_identity(rank, world, dev):
+    """What every rank reports about itself, gathered to all ranks (one small all_gather_object): the result line's `ranks` list
+    proves which backend saw how many ranks on which devices."""
+    me = {'rank': rank, 'pid': os.getpid(), 'device': str(dev)}
+    if dev.type == 'cuda':
+        pr = torch.cuda.get_device_properties(dev)
+        me.update(device_name=pr.name, pci_bus_id=getattr(pr, 'pci_bus_id', None), uuid=str(getattr(pr, 'uuid', '')) or None)
+    if world == 1:
+        return [me]
+    import torch.distributed as dist
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    return everyone
+
+
+def stub_main(args, rank, world, result_fd):
+    """--stub-step: the launcher, the rendezvous, the barriers, the max-over-ranks reduction and the per-rank report of this file with a
+    step that does NO rendering (a 64-element CPU add), on the gloo backend, CPU only.  For the multi-rank rehearsal tests
+    (tests/test_dist_cpu.py: 8 ranks here; no GPU needed) -- the line says `stub: true`, carries no rays/s value and is not a measurement."""
+    import gnerf_harness
+    dev = torch.device('cpu')
+    if world > 1:
+        import torch.distributed as dist
+    x = torch.zeros(64)
+    for _ in range(args.warmup):
+        x += 1
+    if os.environ.get('GNERF_BENCH_STUB_FAIL_RANK') == str(rank):       # rehearsal of a rank that dies while its peers wait in a collective
+        os._exit(3)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x += 1
+    mine = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    elapsed = gnerf_harness.max_over_ranks(time.perf_counter() - t0, dev)
+    ranks = rank_identity(rank, world, dev)
+    assert float(x[0]) == args.steps + args.warmup and elapsed >= mine
+    if rank == 0:
+        line = {'metric': 'stub (no rendering): launcher / rendezvous / reduction rehearsal', 'stub': True, 'value': None, 'unit': None,
+                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+                'ranks_seen': dist.get_world_size() if world > 1 else 1, 'backend': dist.get_backend() if world > 1 else None,
+                'ranks': ranks, 'self_launched': os.environ.get('GNERF_BENCH_SELF_LAUNCHED') == '1'}
+        os.write(result_fd, (json.dumps(line) + '\n').encode())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -375,7 +473,17 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the gen_videos frames/sec measurement')
     ap.add_argument('--no-backward', action='store_true', help='skip the renderer-backward timing behind roofline_backward')
+    ap.add_argument('--stub-step', action='store_true', help=argparse.SUPPRESS)       # CPU rehearsal of the multi-rank plumbing (stub_main)
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # (device_count() does not initialise the GPU on this image; RCCL refuses two ranks on one device, so say it here, readably)
+        if not args.stub_step and os.environ.get('GNERF_DIST_BACKEND', 'nccl') == 'nccl' and torch.cuda.device_count() < args.gpus:
+            sys.exit(f'bench.py: --gpus {args.gpus} but {torch.cuda.device_count()} GPU(s) visible (RCCL needs one device per rank; '
+                     'GNERF_DIST_BACKEND=gloo rehearses several ranks on one card)')
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.stub_step:
+        os.environ['GNERF_DIST_BACKEND'] = 'gloo'
 
     # stdout carries exactly ONE line, the JSON result: libraries that chat on fd 1 (RCCL's version banner at communicator
     # creation, gloo's connection notes, plugin status lines) are sent to stderr for the whole run
@@ -387,7 +495,9 @@ def main():
     rank, world, local_rank = gnerf_harness.init_from_env()        # nccl (= RCCL) when WORLD_SIZE > 1
     if world > 1:
         import torch.distributed as dist
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N>1)'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if args.stub_step:
+        return stub_main(args, rank, world, result_fd)
     # (modulo only matters for a rehearsal of several ranks on a one-GPU box with GNERF_DIST_BACKEND=gloo)
     dev = torch.device('cuda', local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
@@ -491,6 +601,8 @@ def main():
         dist.all_gather(allk, t)
         per_rank = [{'rank': r, 'value': float(x[0]), 'render_call_ms': float(x[1])} for r, x in enumerate(allk)]
 
+    ranks = rank_identity(rank, world, dev)
+
     backward = None
     if not args.no_backward:
         try:
@@ -527,6 +639,9 @@ def main():
             'metric': 'rays/sec at 128^2 neural render, 96 depth samples',
             'value': total_rays / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            # proof of what ran: ranks the process group saw, its backend ('nccl' = RCCL; None for one process), every rank's device
+            'ranks_seen': dist.get_world_size() if world > 1 else 1, 'backend': dist.get_backend() if world > 1 else None,
+            'self_launched': os.environ.get('GNERF_BENCH_SELF_LAUNCHED') == '1', 'ranks': ranks,
             'dtype': 'f32 (MLP products as compensated f16 hi/lo splits on MFMA, fp32 accumulate; exact-fp32 MFMA when the device-side range '
                      'check says so)', 'data': 'synthetic',
             'repetitions': {'n': len(regions), 'reported': 'median', 'untimed_clock_ramp_steps': ramp_steps,

@@ -121,7 +121,7 @@ def init_from_env():
         if not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             # GNERF_DIST_BACKEND=gloo forces gloo although a GPU is visible (to exercise the multi-rank code on a one-GPU box)
-            use_gpu = torch.cuda.is_available() and os.environ.get('GNERF_DIST_BACKEND', 'nccl') == 'nccl'
+            use_gpu = os.environ.get('GNERF_DIST_BACKEND', 'nccl') == 'nccl' and torch.cuda.is_available()
             if use_gpu:
                 torch.cuda.set_device(local_rank)
                 dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))

@@ -174,3 +174,52 @@ def test_two_rank_training_step():
         assert moved > 0 and np.isfinite(loss)
     assert res[0][5] == 0.0 and res[1][5] > 0            # rank 1 started from different weights and now holds rank 0's
     assert res[1][4] and not res[0][4]                   # the diverged replica (rank 1) is the one that notices
+
+
+def _run_bench(args, env_extra=None, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS='1', **(env_extra or {}))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, capture_output=True, text=True, env=env, cwd=root, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_self_launch_eight_ranks_stub():
+    """`python bench.py --gpus 8` WITHOUT a launcher (the form the driver records for N = 1): the parent starts its eight ranks itself,
+    they rendezvous (gloo here, RCCL on GPUs), run the barriers / max-over-ranks / per-rank gather around a stub step, and exactly one
+    JSON line comes back naming the backend, the ranks the group saw and each rank's device."""
+    r, lines = _run_bench(['--gpus', '8', '--steps', '4', '--warmup', '1', '--stub-step'])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout
+    line = lines[0]
+    assert line['stub'] is True and line['value'] is None                      # a rehearsal line can not be mistaken for a measurement
+    assert line['n_gpus'] == 8 and line['ranks_seen'] == 8 and line['backend'] == 'gloo' and line['self_launched'] is True
+    assert [x['rank'] for x in line['ranks']] == list(range(8)) and len({x['pid'] for x in line['ranks']}) == 8
+
+
+def test_bench_self_launch_reports_a_dead_rank():
+    """A rank that dies leaves its peers in a collective: the launcher must end them and exit non-zero, with no result line."""
+    r, lines = _run_bench(['--gpus', '3', '--steps', '2', '--warmup', '1', '--stub-step'],
+                          {'GNERF_BENCH_STUB_FAIL_RANK': '1', 'GNERF_BENCH_PEER_GRACE_S': '3'}, timeout=300)
+    assert r.returncode != 0 and not lines, (r.returncode, r.stdout)
+    assert 'rank exit codes' in r.stderr
+
+
+def test_bench_under_outer_launcher_is_not_relaunched():
+    """Under torch.distributed.run (WORLD_SIZE set) bench.py is a plain rank: no second generation of processes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--stub-step'],
+                       capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip().startswith('{')]
+    assert len(lines) == 1 and lines[0]['ranks_seen'] == 2 and lines[0]['self_launched'] is False

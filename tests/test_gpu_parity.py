@@ -1836,10 +1836,12 @@ def test_render_fine_samples_on_bin_edges(dev, S, F):
     np.testing.assert_allclose(wsum.cpu().numpy(), ref_w.numpy(), atol=2e-4)
 
 
-def test_bench_two_ranks_on_one_gpu(dev):
+@pytest.mark.parametrize('launcher', ['torch.distributed.run', 'self'])
+def test_bench_two_ranks_on_one_gpu(dev, launcher):
     """The multi-rank path of bench.py end to end (rendezvous, per-rank scene, barriers, max-over-ranks timing, one JSON line from
     rank 0), rehearsed with two processes sharing this box's one GPU over gloo (GNERF_DIST_BACKEND; the driver's 8-GPU run uses
-    RCCL).  Not a scaling number."""
+    RCCL).  Not a scaling number.  launcher 'self': plain `python bench.py --gpus 2`, no torch.distributed.run around it -- the
+    parent (no GPU call) starts the ranks itself (bench.self_launch)."""
     import json
     import os
     import socket
@@ -1851,14 +1853,19 @@ def test_bench_two_ranks_on_one_gpu(dev):
     s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GNERF_DIST_BACKEND='gloo', OMP_NUM_THREADS='1')
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
-                        '--no-cpu-baseline', '--no-secondary', '--no-backward'], capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    head = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+            '--master-port', str(port)] if launcher != 'self' else [sys.executable]
+    r = subprocess.run(head + [os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
+                               '--no-cpu-baseline', '--no-secondary', '--no-backward'], capture_output=True, text=True, env=env, cwd=root, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines                      # library chatter (gloo / RCCL banners) must not reach stdout
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['steps'] == 5 and line['scaling'] == 'weak' and line['value'] > 1e6
+    assert line['ranks_seen'] == 2 and line['backend'] == 'gloo' and line['self_launched'] == (launcher == 'self')
+    assert [x['rank'] for x in line['ranks']] == [0, 1] and all(x['device'].startswith('cuda') for x in line['ranks'])
     assert line['roofline']['kernel_ms'] > 0 and line['cpu_baseline'] is None and line['secondary'] is None
     # per-rank values (so that a scaling run explains itself) and both plane layouts at top level
     assert [r['rank'] for r in line['per_rank']] == [0, 1] and all(r['value'] > 5e5 and r['render_call_ms'] > 0 for r in line['per_rank'])
