@@ -312,7 +312,7 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     // (Round 3: the same sum written with inline-asm v_pk_mul / v_pk_fma_f32 whose op_sel bits broadcast one weight of a register pair
     // -- to save the copies the compiler makes to build (w, w) pairs -- reproduced that run-to-run difference: ~1 % of the samples got
     // a wrong feature, on rays of the second half of each item only, although the four-instruction chain is bit-exact in isolation
-    // (tools/probes/scratch/pk_test.hip) and its destination was kept off its sources.  It also removed no instruction: the tile's
+    // (tools/probes/pk_fma_chain_probe.hip) and its destination was kept off its sources.  It also removed no instruction: the tile's
     // v_mov_b32 are accumulator initialisations and permlane copies.  The compiler's form stays.)
     auto blend = [&](int a, int pl, v4f& acc) {
         const v4f sum = tex[a][pl][0] * wgt[a][pl][0] + tex[a][pl][1] * wgt[a][pl][1] + tex[a][pl][2] * wgt[a][pl][2] + tex[a][pl][3] * wgt[a][pl][3];

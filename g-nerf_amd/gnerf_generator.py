@@ -252,7 +252,7 @@ class StyledConv(nn.Module):
         assert noise_mode in ('random', 'const', 'none')
         n, c_in, h, wd = x.shape
         aff = (self.affine.weight, self.affine.bias)
-        fast = _fast_path(x, self.weight, self.bias, self.noise_strength, *aff)
+        fast = _fast_path(x, w, self.weight, self.bias, self.noise_strength, *aff)      # w: a latent that needs a gradient takes the autograd forms
         styles = _per_latent(self, w, 'styles', aff, lambda: self.affine(w)) if fast else self.affine(w)
         noise = None
         if noise_mode == 'random':
@@ -273,7 +273,7 @@ class StyledConv(nn.Module):
                 if not prescaled:
                     x = gnerf_hip.scale_channels(x, _per_latent(self, w, 'nstyles', aff, lambda: gnerf_hip.normalise_styles(styles)))
                 nxt = None
-                if next_layer is not None and cl and _fast_path(x, next_layer.weight, next_layer.bias, next_layer.noise_strength):
+                if next_layer is not None and cl and _fast_path(x, next_w, next_layer.weight, next_layer.bias, next_layer.noise_strength, next_layer.affine.weight, next_layer.affine.bias):
                     nxt_aff = (next_layer.affine.weight, next_layer.affine.bias)
                     nxt = _per_latent(next_layer, next_w, 'nstyles', nxt_aff, lambda: gnerf_hip.normalise_styles(next_layer.affine(next_w)))
                     folded = True
@@ -339,18 +339,18 @@ class ToRGB(nn.Module):
         self.bias = nn.Parameter(torch.zeros(c_out))
         self.weight_gain = 1 / math.sqrt(c_in)
 
-    def streams_into_image(self, x):
-        """True when forward(x, ..., accumulate_into=img) adds the layer's output to the block's running image in its own launch."""
+    def streams_into_image(self, x, w):
+        """True when forward(x, w, ..., accumulate_into=img) adds the layer's output to the block's running image in its own launch."""
         import gnerf_hip
-        return (_fast_path(x, self.weight, self.bias, self.affine.weight, self.affine.bias) and x.dtype == torch.float16 and _is_channels_last(x)
+        return (_fast_path(x, w, self.weight, self.bias, self.affine.weight, self.affine.bias) and x.dtype == torch.float16 and _is_channels_last(x)
                 and self.weight.shape[0] == 3 and x.shape[1] in gnerf_hip.TORGB_CHANNELS)
 
     def forward(self, x, w, fused=True, accumulate_into=None):
         n, c_in, h, wd = x.shape
         aff = (self.affine.weight, self.affine.bias)
-        fast = _fast_path(x, self.weight, self.bias, *aff)
+        fast = _fast_path(x, w, self.weight, self.bias, *aff)
         styles = _per_latent(self, w, 'styles', aff, lambda: self.affine(w) * self.weight_gain) if fast else self.affine(w) * self.weight_gain
-        assert accumulate_into is None or self.streams_into_image(x)
+        assert accumulate_into is None or self.streams_into_image(x, w)
         if fast:
             import gnerf_hip
             if x.dtype == torch.float16 and _is_channels_last(x) and self.weight.shape[0] == 3 and c_in in gnerf_hip.TORGB_CHANNELS:
@@ -404,7 +404,7 @@ class Block(nn.Module):
                 x = x.contiguous(memory_format=torch.channels_last)
             x, folded = self.conv0(x, ws[0], noise_mode, fused=fused, next_layer=self.conv1, next_w=ws[1])
             x = self.conv1(x, ws[1], noise_mode, fused=fused, prescaled=folded)
-        if (img is not None and img.is_cuda and img.dtype == torch.float32 and not self.emit_channels_last and self.torgb.streams_into_image(x)
+        if (img is not None and img.is_cuda and img.dtype == torch.float32 and not self.emit_channels_last and self.torgb.streams_into_image(x, ws[-1])
                 and not (torch.is_grad_enabled() and img.requires_grad)):
             # upsample the running image, then let ToRGB add its output to it in its own launch (no fp16 y, no conversion, no add kernel)
             if self.up == 2:

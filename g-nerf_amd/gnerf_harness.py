@@ -53,7 +53,7 @@ def orbit_pose(i, frame_num=120, radius=2.7, yaw_range=0.7, pitch_range=0.3, dev
 def orbit_labels(frames, frame_num=120, radius=2.7, yaw_range=0.7, pitch_range=0.3, intrinsics=FFHQ_INTRINSICS):
     """camera_label(orbit_pose(i, ...)) for every i of `frames`, [len(frames), 25] on the host, in ONE set of batched tensor ops: the
     per-frame form costs ~0.15 ms of host time per camera (a 240-frame orbit: 30-45 ms in front of a 130 ms orbit).  Same arithmetic
-    per element as lookat_pose, so the rows equal the per-frame labels bit for bit (tests/test_gen_videos_cpu.py)."""
+    per element as lookat_pose, so the rows equal the per-frame labels bit for bit (tests/test_host_cpu.py)."""
     dt = torch.float32
     frames = list(frames)
     theta = torch.tensor([[3.14 / 2 + yaw_range * math.sin(2 * 3.14 * i / frame_num)] for i in frames], dtype=dt)

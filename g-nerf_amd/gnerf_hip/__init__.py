@@ -102,6 +102,24 @@ SIGNATURES = {
 }
 
 
+def profiled(name):
+    """Decorator: the call runs inside torch.autograd.profiler.record_function(name) WHILE a profiler is collecting (Kineto,
+    or emit_nvtx -> roctx ranges that rocprofv3 --marker-trace shows), and as a plain call otherwise -- a record_function entered with
+    no profiler attached still costs microseconds of host time per call, which an orbit frame of ~190 launches cannot afford.
+    The reference opens the same ranges with misc.profiled_function (misc.py:102-107; conv2d_resample.py:47, bias_act.py:92, ...)."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            if torch.autograd._profiler_enabled():
+                with torch.autograd.profiler.record_function(name):
+                    return fn(*args, **kwargs)
+            return fn(*args, **kwargs)
+        return wrapper
+    return deco
+
+
 def load():
     """Load the library once.  Raises RuntimeError (never falls back) if it cannot be loaded."""
     global _lib
@@ -231,6 +249,7 @@ def _require_cuda(*tensors):
 # ----------------------------------------------------------------------------
 
 
+@profiled('gnerf_hip::bias_act')
 def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
     """Same contract as bias_act_plugin.bias_act (reference bias_act.cpp:36): absent tensors are
     empty tensors (numel 0) or None; returns a new tensor laid out like x."""
@@ -260,6 +279,7 @@ def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
     return y
 
 
+@profiled('gnerf_hip::upfirdn2d')
 def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
     """Same contract as upfirdn2d_plugin.upfirdn2d (reference upfirdn2d.cpp:20): x [N,C,H,W] in NCHW or
     channels_last, f float32 [fh,fw] on x's device; returns y in x's memory format."""
@@ -286,6 +306,7 @@ def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
     return y
 
 
+@profiled('gnerf_hip::filtered_lrelu_act_')
 def filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, write_signs):
     """Same contract as filtered_lrelu_plugin.filtered_lrelu_act_ (reference filtered_lrelu.cpp:217):
     in-place on x; returns the sign tensor written (or an empty tensor)."""
@@ -318,6 +339,7 @@ def filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, write_signs):
 E_UNSUPPORTED = -3
 
 
+@profiled('gnerf_hip::filtered_lrelu')
 def filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, clamp, flip_filters, write_signs):
     """Same contract as filtered_lrelu_plugin.filtered_lrelu (reference filtered_lrelu.cpp:20-213): returns
     (y, so, rc); rc = -1 with empty tensors means "no fused kernel for this configuration" and the caller runs the
@@ -383,6 +405,7 @@ def grid_sample_supported(image, grid):
             and image.stride(2) > 0 and image.stride(3) > 0)
 
 
+@profiled('gnerf_hip::grid_sample_2d')
 def grid_sample_2d(image, grid):
     """Bilinear, zero padding, align_corners=False (what grid_sample_gradfix.grid_sample evaluates, grid_sample_gradfix.py:45):
     image [N,C,H,W], grid [N,Ho,Wo,2] -> [N,C,Ho,Wo] in image's dtype."""
@@ -397,6 +420,7 @@ def grid_sample_2d(image, grid):
     return out
 
 
+@profiled('gnerf_hip::grid_sample_2d_backward')
 def grid_sample_2d_backward(grad_out, image, grid, need_image=True, need_grid=True):
     """The adjoint (aten::grid_sampler_2d_backward upstream, grid_sample_gradfix.py:62-77): returns (grad_image, grad_grid), each
     None when not requested; grad_image in image's dtype, grad_grid in grid's."""
@@ -414,6 +438,7 @@ def grid_sample_2d_backward(grad_out, image, grid, need_image=True, need_grid=Tr
     return (None if gi is None else gi.to(image.dtype)), (None if gg is None else gg.to(grid.dtype))
 
 
+@profiled('gnerf_hip::planes_to_nhwc')
 def planes_to_nhwc(planes, with_absmax=False):
     """[N,3,C,H,W] (or [NP,C,H,W]) float32 NCHW -> [NP,H,W,C] contiguous.  with_absmax: also return max |planes| as a
     one-element device tensor, measured by the same pass (render_forward's planes_absmax)."""
@@ -435,6 +460,7 @@ def planes_to_nhwc(planes, with_absmax=False):
     return out
 
 
+@profiled('gnerf_hip::planes_absmax')
 def planes_absmax(planes):
     """max |x| of a contiguous float32 device tensor -> one-element device tensor (NaN if any element is NaN)."""
     _require_cuda(planes)
@@ -447,6 +473,7 @@ def planes_absmax(planes):
     return amax
 
 
+@profiled('gnerf_hip::planes_from_nhwc')
 def planes_from_nhwc(planes_nhwc, n_items=None):
     """[NP,H,W,C] float32 -> [NP,C,H,W] contiguous ([N,3,C,H,W] when n_items is given)."""
     _require_cuda(planes_nhwc)
@@ -460,6 +487,7 @@ def planes_from_nhwc(planes_nhwc, n_items=None):
     return out if n_items is None else out.view(n_items, np_ // n_items, c, h, w)
 
 
+@profiled('gnerf_hip::to_uint8_nhwc')
 def to_uint8_nhwc(img):
     """(img * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous() for a float32 [N,C,H,W] GPU tensor in one launch
     (gen_videos.py:173 + the frame writer's layout).  Returns uint8 [N,H,W,C]."""
@@ -475,6 +503,7 @@ def to_uint8_nhwc(img):
     return out
 
 
+@profiled('gnerf_hip::make_rays')
 def make_rays(cam2world, intrinsics, resolution):
     _require_cuda(cam2world, intrinsics)
     c2w = cam2world.to(torch.float32).contiguous()
@@ -511,6 +540,7 @@ def release_workspaces():
 # ---------------------------------------------------------------------------- surroundings of the modulated convolution
 
 
+@profiled('gnerf_hip::modulate_weights')
 def modulate_weights(weight, styles, demodulate=True, out_dtype=torch.float32, want_weights=True, want_dcoefs=False, transposed=False,
                      channels_last=False):
     """Per-sample modulated (+ demodulated) convolution weights in one launch (networks_stylegan2.py:61-75), with the fp16
@@ -541,6 +571,7 @@ def modulate_weights(weight, styles, demodulate=True, out_dtype=torch.float32, w
     return view, dco
 
 
+@profiled('gnerf_hip::normalise_styles')
 def normalise_styles(styles):
     """styles [N,I] / max|styles[n]| per row (networks_stylegan2.py:64)."""
     _require_cuda(styles)
@@ -568,6 +599,7 @@ def _activation_layout(x, what):
     raise RuntimeError(f'{what}: x must be contiguous (NCHW) or channels_last')
 
 
+@profiled('gnerf_hip::scale_channels')
 def scale_channels(x, scale):
     """x [N,C,H,W] (NCHW contiguous or channels_last, float16/32) * scale [N,C] float32, the product formed in x's dtype
     (networks_stylegan2.py:77).  The result has x's memory format."""
@@ -587,6 +619,7 @@ def scale_channels(x, scale):
     return y
 
 
+@profiled('gnerf_hip::modconv_epilogue')
 def modconv_epilogue(x, bias=None, scale=None, noise=None, round_noise=False, act='lrelu', alpha=0.2, gain=1.0, clamp=None, next_scale=None):
     """Everything after the modulated convolution in one pass (networks_stylegan2.py:79-83 / :96-97 then :331-333):
     t = x * scale[n,c] + noise (rounded to x's dtype; skipped when both are None), y = clamp(act(t + bias[c]) * gain).
@@ -626,6 +659,7 @@ def modconv_epilogue(x, bias=None, scale=None, noise=None, round_noise=False, ac
     return y
 
 
+@profiled('gnerf_hip::blur_epilogue_channels_last')
 def blur_epilogue_channels_last(x, f, padding, blur_gain=1.0, bias=None, scale=None, act='lrelu', alpha=0.2, gain=1.0, clamp=None, next_scale=None,
                                 flip_filter=False):
     """upfirdn2d(x, f, padding=padding, gain=blur_gain) with a 4x4 filter, then modconv_epilogue (no noise), in one pass over a
@@ -664,6 +698,7 @@ def blur_epilogue_channels_last(x, f, padding, blur_gain=1.0, bias=None, scale=N
 TORGB_CHANNELS = (32, 64, 128, 256, 512)
 
 
+@profiled('gnerf_hip::torgb_channels_last')
 def torgb_channels_last(x, weight, styles, bias=None, clamp=None, accumulate_into=None):
     """ToRGBLayer to three channels on a channels_last float16 x [N,C,H,W] (networks_stylegan2.py:349-367): weight [3,C,1,1] or [3,C]
     float32, styles [N,C] float32 (weight_gain applied), bias [3].  Returns float16 [N,3,H,W], NCHW.  See include/gnerf_hip.h.
@@ -707,6 +742,7 @@ def planes_layout(planes_nhwc, n_items, what):
     raise RuntimeError(f'{what}: planes_nhwc must be [3N,H,W,32] or [N,H,W,96] (3 planes of 32 channels per item)')
 
 
+@profiled('gnerf_hip::upsample2x_add_nhwc')
 def upsample2x_add_nhwc(img, y, f, flip=False, gain=4.0, with_absmax=False):
     """upfirdn2d(img, f, up=2, padding=[2,1,2,1], gain) + y written channels_last in one launch (the tri-plane producer's last
     step, networks_stylegan2.py:456-463).  img [N,C,h,w], y [N,C,2h,2w] or None, both float32 NCHW-contiguous; f the 4x4 filter.
@@ -814,6 +850,7 @@ def _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
     return p, (planes_nhwc, o, d, nc, nf, w1, b1, w2, b2, rs_t, re_t, planes_absmax), m
 
 
+@profiled('gnerf_hip::render_forward')
 def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine, *,
                    depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
                    white_back=False, disparity_space_sampling=False, image_width=0, debug=False, planes_absmax=None, mlp='auto',
@@ -872,6 +909,7 @@ def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
     return rgb, depth, wsum
 
 
+@profiled('gnerf_hip::render_backward')
 def render_backward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine, grad_rgb, grad_depth, grad_wsum, *,
                     depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
                     white_back=False, disparity_space_sampling=False, image_width=0, need_planes=True, need_decoder=True,
@@ -920,6 +958,7 @@ def render_backward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_
     return g_planes, g_dec
 
 
+@profiled('gnerf_hip::query_points')
 def query_points(planes_nhwc, n_items, decoder, points, box_warp, want_rgb=True):
     """run_model for arbitrary points [N,P,3] -> sigma [N,P,1], rgb [N,P,32] (rgb None when want_rgb is False)."""
     w1, b1, w2, b2 = [t.to(torch.float32).contiguous() for t in decoder]
@@ -938,6 +977,7 @@ def query_points(planes_nhwc, n_items, decoder, points, box_warp, want_rgb=True)
     return sigma, rgb
 
 
+@profiled('gnerf_hip::query_points_backward')
 def query_points_backward(planes_nhwc, n_items, decoder, points, box_warp, grad_sigma, grad_rgb, need_planes=True, need_decoder=True):
     """Gradient of query_points for the same arguments: grad_sigma [N,P,1] / grad_rgb [N,P,32] (either may be None).
     Returns (grad_planes_nhwc or None, (grad_w1, grad_b1, grad_w2, grad_b2) or None), float32."""

@@ -25,6 +25,7 @@ import torch
 
 from . import upfirdn2d
 from .upfirdn2d import _get_filter_size, _parse_padding
+from gnerf_hip import profiled as _profiled
 
 try:                                    # the reference's gradient-fix wrappers, when its tree is on the path
     from . import conv2d_gradfix
@@ -87,6 +88,7 @@ def _ones(c, device):
     return t
 
 
+@_profiled('conv2d_resample')                       # the reference's range name (conv2d_resample.py:47, misc.profiled_function)
 def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False):
     """2-D convolution of x [N, C_in, H, W] with w [C_out, C_in // groups, kh, kw], optionally preceded by `up`-fold upsampling and
     followed by `down`-fold downsampling, both through the low-pass filter f (from upfirdn2d.setup_filter(); None = identity).

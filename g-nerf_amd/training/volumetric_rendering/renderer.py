@@ -225,6 +225,17 @@ class _FusedQuery(torch.autograd.Function):
         return tuple(grads)
 
 
+_warned_fallbacks = set()
+
+
+def _warn_gpu_fallback(reason, what='ImportanceRenderer.forward'):
+    """One RuntimeWarning per (entry point, reason) and process when a call on GPU tensors runs the PyTorch-op form instead of the
+    fused gfx950 kernels: correct, the reference's own arithmetic, but ~100x slower -- it must not happen unseen."""
+    if (what, reason) not in _warned_fallbacks:
+        _warned_fallbacks.add((what, reason))
+        warnings.warn(f'{what}: GPU tensors, but {reason}: running the PyTorch-op form, not the fused HIP kernel', RuntimeWarning, stacklevel=3)
+
+
 class ImportanceRenderer(torch.nn.Module):
     def __init__(self):
         super().__init__()
@@ -248,9 +259,17 @@ class ImportanceRenderer(torch.nn.Module):
             if fcs is not None and not rays_need_grad and planes.ndim == 5 and planes.shape[1] == 3 and planes.shape[2] == 32 \
                     and rendering_options.get('density_noise', 0) == 0:
                 needs_graph = torch.is_grad_enabled() and (planes.requires_grad or any(p.requires_grad for p in decoder.parameters()))
+                if views and needs_graph:
+                    # the several-views launch is forward-only: with a graph, one differentiable call per view (same draws, same order)
+                    outs = [self._forward_hip(planes, fcs, ray_origins[i:i + 1], ray_directions[i:i + 1], rendering_options, differentiable=True)
+                            for i in range(ray_origins.shape[0])]
+                    return tuple(torch.cat(t) for t in zip(*outs))
                 return self._forward_hip(planes, fcs, ray_origins, ray_directions, rendering_options, differentiable=needs_graph)
-            if fcs is None:
-                warnings.warn('ImportanceRenderer: decoder is not the OSGDecoder MLP; using PyTorch ops', RuntimeWarning)
+            # A GPU call that leaves the fused kernel says so, once per reason (none of these occurs in gen_videos.py / train.py)
+            _warn_gpu_fallback('the decoder is not the OSGDecoder 32->64->33 MLP' if fcs is None else
+                               'the rays need a gradient' if rays_need_grad else
+                               'density_noise > 0 (renderer.py:146-147)' if rendering_options.get('density_noise', 0) != 0 else
+                               f'planes of shape {tuple(planes.shape)} are not [N,3,32,H,W]')
         if views:
             outs = [self._forward_torch(planes, decoder, ray_origins[i:i + 1], ray_directions[i:i + 1], rendering_options)
                     for i in range(ray_origins.shape[0])]
@@ -331,8 +350,7 @@ class ImportanceRenderer(torch.nn.Module):
             raise RuntimeError(f'ImportanceRenderer: at most {gnerf_hip.MAX_SAMPLES} coarse and fine samples per ray are supported')
         dev = ray_origins.device
         views = planes.shape[0] == 1 and N > 1              # N views of one item's planes (see forward)
-        if views and differentiable:
-            raise RuntimeError('ImportanceRenderer: several views of one set of planes in one call is a forward-only form')
+        assert not (views and differentiable)               # forward() makes one differentiable call per view
 
         def limits(o, d):
             ray_start, ray_end = math_utils.get_ray_limits_box(o, d, box_side_length=opts['box_warp'])
@@ -430,6 +448,8 @@ class ImportanceRenderer(torch.nn.Module):
                 if density_noise > 0:
                     out['sigma'] = out['sigma'] + torch.randn_like(out['sigma']) * density_noise
                 return out
+        if planes.device.type == 'cuda':
+            _warn_gpu_fallback('the points need a gradient, the decoder is not the OSGDecoder MLP or the planes are not [N,3,32,H,W]', 'ImportanceRenderer.run_model')
         feats = sample_from_planes(self.plane_axes, planes, sample_coordinates, padding_mode='zeros', box_warp=options['box_warp'])
         out = decoder(feats, sample_directions)
         if density_noise > 0:

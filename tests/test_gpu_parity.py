@@ -577,6 +577,36 @@ def test_pipe_kernel_instantiations_agree(dev, monkeypatch, S):
             assert torch.equal(a, b) and torch.equal(b, c), mlp
 
 
+def test_gpu_fallback_to_pytorch_ops_is_visible(dev):
+    """The three GPU calls that leave the fused kernel (rays with a gradient, density_noise > 0, a decoder that is not the OSGDecoder
+    MLP) run the PyTorch-op form -- and say so with a RuntimeWarning, once per reason (What's weak 9)."""
+    import warnings
+    import gnerf_harness as H
+    from training.volumetric_rendering import renderer as RM
+    r = RM.ImportanceRenderer()
+    dec = H.TriPlaneDecoder().to(dev).requires_grad_(False)
+    planes, _, o, d, _, _ = _random_scene(2, N=1, res=4, S=8, F=8, hw=(8, 8))
+    planes, o, d = planes.to(dev), o.to(dev), d.to(dev)
+    opts = dict(depth_resolution=8, depth_resolution_importance=8, ray_start=2.25, ray_end=3.3, box_warp=1, clamp_mode='softplus', disparity_space_sampling=False)
+    RM._warned_fallbacks.clear()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        r(planes, dec, o, d, opts)                                                  # the fused kernel: silent
+        assert not [w for w in rec if issubclass(w.category, RuntimeWarning)]
+        r(planes, dec, o, d, dict(opts, density_noise=0.5))
+        r(planes, dec, o, d, dict(opts, density_noise=0.5))                         # second time: no second warning
+        r(planes, dec, o.clone().requires_grad_(True), d, opts)
+
+        class Other(torch.nn.Module):
+            def forward(self, feats, dirs):
+                x = feats.mean(1)
+                return {'rgb': torch.sigmoid(x), 'sigma': x[..., :1]}
+        r(planes, Other(), o, d, opts)
+    msgs = [str(w.message) for w in rec if issubclass(w.category, RuntimeWarning)]
+    assert len(msgs) == 3 and all('PyTorch-op form' in m for m in msgs), msgs
+    assert 'density_noise' in msgs[0] and 'rays need a gradient' in msgs[1] and 'OSGDecoder' in msgs[2]
+
+
 def test_views_of_one_item_equal_separate_calls(dev):
     """Frame batching (an orbit's frames are N cameras on ONE latent's planes): one launch over N views of one set of planes --
     gnerf_render_params.planes_shared + depth_clamp_per_item -- gives every view bit-identically what a launch of its own
@@ -646,9 +676,25 @@ def test_views_of_one_item_equal_separate_calls(dev):
             one = r(planes5, dec, o[i:i + 1], d[i:i + 1], opts_auto)
             for a, e in zip(got, one):
                 assert torch.equal(a[i:i + 1], e)
-    # forward-only
-    with pytest.raises(RuntimeError, match='forward-only'):
-        r(planes5.clone().requires_grad_(True), dec, o, d, opts)
+    # the several-views LAUNCH is forward-only; with a graph the class makes one differentiable call per view: same values as the
+    # views launch on the same draws, and a plane gradient that is the sum over the views
+    pg = planes5.clone().requires_grad_(True)
+    torch.manual_seed(9)
+    with torch.enable_grad():
+        outs = r(pg, dec, o, d, opts)
+        (gp,) = torch.autograd.grad(outs[0].sum() + outs[1].sum(), pg)
+    torch.manual_seed(9)
+    want = r(planes5, dec, o, d, opts)
+    for a, e in zip(outs, want):
+        assert torch.equal(a.detach(), e)
+    acc = torch.zeros_like(gp)
+    torch.manual_seed(9)
+    for i in range(N):
+        pi = planes5.clone().requires_grad_(True)
+        with torch.enable_grad():
+            one = r(pi, dec, o[i:i + 1], d[i:i + 1], opts)
+            acc += torch.autograd.grad(one[0].sum() + one[1].sum(), pi)[0]
+    assert float((gp - acc).abs().max()) <= 1e-4 * float(acc.abs().max())
     nhwc = gnerf_hip.planes_to_nhwc(planes5)
     p, keep, m = gnerf_hip._render_params(nhwc, N, w, o, d, torch.rand(N * res * res, 48, device=dev), torch.rand(N * res * res, 48, device=dev),
                                           48, 48, 2.25, 3.3, 1.0, False, False, res, 'render_backward', planes_shared=True)
@@ -1428,6 +1474,48 @@ def test_generator_fast_modconv_path_equals_plain_path(dev, monkeypatch):
             for k in ('image', 'image_raw', 'image_depth'):
                 mse = float(((outs[0][k] - outs[1][k]) ** 2).mean())
                 assert mse < (1e-5 if k != 'image_depth' else 1e-6), (nb, k, mse)
+
+
+def test_frozen_generator_passes_gradient_to_latent(dev, monkeypatch):
+    """The reference's encoder phase (training_loop.py:172,318-322): G frozen (`requires_grad_(False)`), the latent `ws` produced by a
+    trainable identity encoder.  The const block's input carries no gradient then, so the fast-path predicate must look at the
+    LATENT: with csrc/modconv.hip's kernels (which detach the styles) the gradient image -> ws would be cut silently.  dImage/dws of
+    the default flow must equal the plain PyTorch-op flow's, and be non-zero for every layer's slice of ws."""
+    import gnerf_generator as GG
+    import gnerf_harness as H
+    torch.manual_seed(4)
+    G = GG.Generator().eval().requires_grad_(False).to(dev)
+    z = torch.randn(2, 512, device=dev)
+    c = torch.cat([H.camera_label(H.orbit_pose(3 + 13 * i, 120)) for i in range(2)]).to(dev)
+    with torch.no_grad():
+        ws0 = G.mapping(z, c)
+    probe = torch.randn(2, 3, 512, 512, device=dev)
+    grads, images = [], []
+    for fast in (True, False):
+        monkeypatch.setattr(GG, '_MODCONV_FAST', fast)
+        ws = ws0.clone().requires_grad_(True)
+        torch.manual_seed(6)
+        out = G.synthesis(ws, c, noise_mode='const', neural_rendering_resolution=32)
+        assert out['image'].requires_grad and out['image_raw'].requires_grad, fast
+        loss = (out['image'].float() * probe).mean() + out['image_raw'].float().mean() + out['image_depth'].mean()
+        (g,) = torch.autograd.grad(loss, ws)
+        grads.append(g)
+        images.append(out['image'].detach().float())
+    assert torch.isfinite(grads[0]).all()
+    per_layer = grads[0].abs().amax(dim=(0, 2))
+    assert (per_layer > 0).all(), per_layer                                        # every ws slice reaches the image through some layer
+    rel = float((grads[0] - grads[1]).norm() / grads[1].norm())
+    assert rel < 1e-4, rel                                                         # both settings take the same autograd forms here (float atomics reorder)
+    assert float(((images[0] - images[1]) ** 2).mean()) < 1e-10
+    # and without a gradient on the latent the fast kernels are still what runs (the predicate did not get stricter than needed)
+    monkeypatch.setattr(GG, '_MODCONV_FAST', True)
+    calls = []
+    import gnerf_hip
+    orig = gnerf_hip.modconv_epilogue
+    monkeypatch.setattr(gnerf_hip, 'modconv_epilogue', lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    with torch.no_grad():
+        G.synthesis(ws0, c, noise_mode='const', neural_rendering_resolution=32)
+    assert calls
 
 
 def test_generator_synthesis_under_inference_mode(dev):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fused channels_last blur + epilogue at the orbit's single-image shapes and at batch 4: us per call and GB/s of algorithmic bytes."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, 'g-nerf_amd'), ROOT]
 import torch
 import gnerf_hip
