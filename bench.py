@@ -304,6 +304,59 @@ def gen_videos_secondary(rank, world, dev, n_frames=240):
                         '(PyTorch-op modulation, conv2d_resample / fma / bias_act / upfirdn2d from the overlay, NCHW planes): what a G-NeRF checkout gets'}
 
 
+def realistic_planes_step(dev, c2w, intr, steps, rank=0):
+    """Config 2 a second time on planes a generator actually produces ("optionally a second run with real backbone
+    output to exercise realistic density"): planes = the random-init FFHQ StyleGAN2 backbone's output for 4 latents (triplane.py:69-77;
+    channels_last from the plane producer, max |planes| with them), decoder = the generator's default-init OSGDecoder, same cameras,
+    same step as the headline's producer-layout form (make_rays + 2 torch.rand + fused render + depth clamp).  Says which decoder
+    arithmetic the device-side check picks for such planes."""
+    import gnerf_hip
+    import gen_videos_mi355x as gv
+    from training.volumetric_rendering import renderer as RM
+    with torch.no_grad():
+        G = gv.build_random_generator(0, dev)
+        z = torch.randn(N_ITEMS, G.z_dim, generator=torch.Generator().manual_seed(11 + rank)).to(dev)
+        ws = G.mapping(z, torch.zeros(N_ITEMS, 25, device=dev))
+        img = G.backbone.synthesis(ws, noise_mode='const')                       # [4,96,256,256], channels_last memory on the fast path
+        planes5 = img.view(N_ITEMS, 3, 32, PLANE, PLANE)
+        nhwc, amax = G.renderer._planes_nhwc(planes5)
+        dec = G.renderer._decoder_cache(RM._osg_decoder_weights(G.decoder))
+        stats = {'absmax': float(planes5.abs().max()), 'std': float(planes5.std()), 'mean': float(planes5.mean())}
+        kw = dict(depth_resolution=S_COARSE, depth_resolution_importance=S_FINE, ray_start=RAY_START, ray_end=RAY_END, box_warp=BOX_WARP, image_width=RES)
+
+        def one(ev=None):
+            o, d = gnerf_hip.make_rays(c2w, intr, RES)
+            nc = torch.rand([N_ITEMS, RES * RES, S_COARSE, 1], device=dev)
+            nf = torch.rand(N_ITEMS * RES * RES, S_FINE, device=dev)
+            if ev:
+                ev[0].record()
+            out = gnerf_hip.render_forward(nhwc, N_ITEMS, dec, o, d, nc, nf, planes_absmax=amax, **kw)
+            if ev:
+                ev[1].record()
+            return out
+        for _ in range(10):
+            out = one()
+        torch.cuda.synchronize()
+        choice = gnerf_hip.last_mlp_choice(dev)
+        regions, calls = [], []
+        for _ in range(5):
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                out = one(evs[i] if i % 5 == 0 else None)
+            torch.cuda.synchronize()
+            regions.append(time.perf_counter() - t0)
+            calls.append(sum(a.elapsed_time(b) for a, b in evs[::5]) / len(evs[::5]))
+        el = sorted(regions)[2]
+        wsum = out[2]
+        return {'workload': 'config 2 on backbone-output planes: random-init FFHQ StyleGAN2 backbone (4 latents, noise_mode const) -> [4,96,256,256] channels_last '
+                            'planes + max |planes| from the plane producer, the generator\'s default-init OSGDecoder, same cameras and sampling as the headline',
+                'value': N_ITEMS * RES * RES * steps / el, 'unit': 'rays/s', 'ms_per_step': 1e3 * el / steps, 'render_call_ms': sorted(calls)[2],
+                'last_mlp_choice': choice, 'planes': stats,
+                'opacity': {'mean_weight_sum': float(wsum.mean()), 'frac_rays_weight_sum_above_0.5': float((wsum > 0.5).float().mean())}}
+
+
 ORBIT_VIEWS = 4                   # cameras per synthesis call of the batched orbit (tools/bench_generator.py --frames-per-call: 2 / 4 / 8 -> 1235 / 1357 / 1327 frames/s)
 PEAK_ATOMIC_GBS = 1300.0          # chip-wide float-atomic rate (MI355X_MICROARCH.md, Global float atomics: 1.26-1.36 TB/s of added bytes)
 FLOP_BWD_PER_SAMPLE = 3 * FLOP_MLP_PER_SAMPLE       # one forward recomputation + dX / dW products of both layers (fp32 MFMA)
@@ -523,19 +576,27 @@ def main():
     # (Measured and dropped: ray generation and the two draws on a second stream beside the 100 MB repack, joined in front of the render
     # call -- 0.581 -> 0.616 ms per step, two runs each way on one box: the cross-stream dependencies cost more (the render call's own
     # HIP-event time grows from 0.509 to 0.541 ms) than the 20 us of small launches they hide.)
-    def step(i=None, mlp='auto', nchw_input=True):
-        o, d = gnerf_hip.make_rays(c2w, intr, RES)
+    def step(i=None, mlp='auto', nchw_input=True, generated=False):
+        """generated: the render kernel makes its rays from the cameras and its two uniform draws from the device generator's Philox
+        stream itself (gnerf_render_params ABI 8; same values as make_rays + torch.rand bit for bit, generator advanced alike) --
+        no ray launch, no draw launches, no ray / noise tensors."""
         if nchw_input:
             nhwc, amax = gnerf_hip.planes_to_nhwc(planes, with_absmax=True)   # max |planes| rides on the repack: it picks the decoder arithmetic
         else:
             nhwc, amax = planes_cl, amax_cl
-        noise_c = torch.rand([N_ITEMS, RES * RES, S_COARSE, 1], device=dev)
-        noise_f = torch.rand(N_ITEMS * RES * RES, S_FINE, device=dev)
+        if generated:
+            o = d = noise_c = noise_f = None
+            extra = dict(cameras=(c2w, intr, RES), rng=gnerf_hip.torch_philox_plan(dev, N_ITEMS, RES * RES, S_COARSE, S_FINE))
+        else:
+            o, d = gnerf_hip.make_rays(c2w, intr, RES)
+            noise_c = torch.rand([N_ITEMS, RES * RES, S_COARSE, 1], device=dev)
+            noise_f = torch.rand(N_ITEMS * RES * RES, S_FINE, device=dev)
+            extra = {}
         if i is not None and i % EV_STRIDE == 0:
             ev[i][0].record()
         out = gnerf_hip.render_forward(nhwc, N_ITEMS, dec, o, d, noise_c, noise_f, depth_resolution=S_COARSE,
                                        depth_resolution_importance=S_FINE, ray_start=RAY_START, ray_end=RAY_END,
-                                       box_warp=BOX_WARP, image_width=RES, planes_absmax=amax, mlp=mlp)
+                                       box_warp=BOX_WARP, image_width=RES, planes_absmax=amax, mlp=mlp, **extra)
         if i is not None and i % EV_STRIDE == 0:
             ev[i][1].record()
         return out
@@ -544,7 +605,7 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def timed_region(mlp='auto', nchw_input=True, n_steps=None):
+    def timed_region(mlp='auto', nchw_input=True, n_steps=None, generated=False):
         """EXACTLY n_steps (default args.steps) steps between barrier + synchronize on both sides; (max-over-ranks seconds, this rank's
         seconds, mean render ms by HIP events on this rank)."""
         n_steps = args.steps if n_steps is None else n_steps
@@ -553,7 +614,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n_steps):
-            out = step(i if n_steps == args.steps else None, mlp, nchw_input)
+            out = step(i if n_steps == args.steps else None, mlp, nchw_input, generated)
         torch.cuda.synchronize()
         mine = time.perf_counter() - t0
         barrier()
@@ -590,6 +651,15 @@ def main():
     long_elapsed = sorted(timed_region(nchw_input=headline_nchw, n_steps=n_long)[0] for _ in range(3))[1]
     # the other plane layout, and the render call with each shipped decoder arithmetic forced
     other = sorted(timed_region(nchw_input=not headline_nchw) for _ in range(5))[2]
+    # the same two steps with rays and draws made inside the render kernel (SURVEY 8d "in-kernel Philox (throughput run -- state which)")
+    inkernel = {}
+    try:
+        for name, nchw in (('nchw_input', True), ('producer_layout', False)):
+            step(None, 'auto', nchw, True)
+            reg = sorted(timed_region(nchw_input=nchw, generated=True) for _ in range(5))[2]
+            inkernel[name] = {'ms_per_step': 1e3 * reg[0] / args.steps, 'value': rays_per_call * args.steps * world / reg[0], 'render_call_ms': reg[2]}
+    except Exception as e:
+        inkernel = {'error': f'{type(e).__name__}: {e}'[:300]}
     kernel_ms_by_mlp = {'auto': kernel_ms}
     for mlp in ('f16x3', 'f32'):
         step(None, mlp, headline_nchw)
@@ -611,11 +681,18 @@ def main():
         except Exception as e:
             backward = {'error': f'{type(e).__name__}: {e}'[:300]}
 
+    realistic = None
     secondary = None
     if not args.no_secondary:
         try:
             del planes, planes_cl
             torch.cuda.empty_cache()
+            try:
+                from torch_utils import custom_ops
+                custom_ops.verbosity = 'none'
+                realistic = realistic_planes_step(dev, c2w, intr, args.steps, rank)
+            except Exception as e:
+                realistic = {'error': f'{type(e).__name__}: {e}'[:300]}
             secondary = gen_videos_secondary(rank, world, dev)
         except Exception as e:                                           # never lose the headline line to the secondary metric
             secondary = {'metric': 'frames/sec gen_videos', 'value': None, 'error': f'{type(e).__name__}: {e}'[:300]}
@@ -660,9 +737,14 @@ def main():
                        'producer_layout_value' if headline_nchw else 'nchw_input_value': other_step['value'],
                        'producer_layout_ms_per_step' if headline_nchw else 'nchw_input_ms_per_step': other_step['ms_per_step']},
             'producer_layout_step' if headline_nchw else 'nchw_input_step': other_step,
+            'inkernel_rng_step': dict(inkernel, note='the step with ray generation and both uniform draws inside the render kernel (cameras + torch\'s Philox '
+                                      'stream at the generator\'s offset; outputs and generator state equal the explicit-noise step\'s bit for bit: '
+                                      'tests/test_gpu_parity.py::test_render_with_inkernel_rays_and_draws); `value` above is the explicit-noise step'),
             'per_rank': per_rank,
             'roofline': roof,
         }
+        if realistic is not None:
+            line['realistic_planes_step'] = realistic
         if backward is not None:
             line['roofline_backward'] = backward
         line['secondary'] = secondary

@@ -8,6 +8,7 @@
 // gnerf_make_rays: RaySampler.forward (training/volumetric_rendering/ray_sampler.py:24-63).
 
 #include "common.h"
+#include "raygen.h"
 
 namespace {
 
@@ -181,8 +182,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
     }
 }
 
-// One lane per ray.  Arithmetic order follows ray_sampler.py:43-59 (no fused multiply-adds, so that
-// the directions agree with the reference to the last bit or two).
+// One lane per ray; the arithmetic is camera_ray's (raygen.h), shared with the render kernels' in-kernel form.
 __global__ __launch_bounds__(256) void make_rays_kernel(const float* __restrict__ c2w, const float* __restrict__ intr,
                                                         int n, int res, float* __restrict__ origins, float* __restrict__ dirs) {
     const int64_t m_total = int64_t(res) * res;
@@ -190,36 +190,20 @@ __global__ __launch_bounds__(256) void make_rays_kernel(const float* __restrict_
     if (i >= m_total * n) return;
     const int item = int(i / m_total);
     const int m = int(i % m_total);
-    const int row = m / res, col = m % res;
     const float* M = c2w + item * 16;
-    const float* K = intr + item * 9;
-    const float fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
-    const float inv = 1.0f / float(res), half = 0.5f / float(res);
-    const float xc = __fadd_rn(__fmul_rn(float(col), inv), half);
-    const float yc = __fadd_rn(__fmul_rn(float(row), inv), half);
-    // x_lift = (x - cx + cy*sk/fy - sk*y/fy) / fx ;  y_lift = (y - cy) / fy          ray_sampler.py:51-52
-    float xl = __fsub_rn(xc, cx);
-    xl = __fadd_rn(xl, __fdiv_rn(__fmul_rn(cy, sk), fy));
-    xl = __fsub_rn(xl, __fdiv_rn(__fmul_rn(sk, yc), fy));
-    xl = __fdiv_rn(xl, fx);
-    const float yl = __fdiv_rn(__fsub_rn(yc, cy), fy);
-    float w[3];
+    float d[3];
+    camera_ray(M, intr + item * 9, res, m / res, m % res, d);
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        // row r of cam2world times (xl, yl, 1, 1)
-        float acc = __fmul_rn(M[r * 4 + 0], xl);
-        acc = __fadd_rn(acc, __fmul_rn(M[r * 4 + 1], yl));
-        acc = __fadd_rn(acc, M[r * 4 + 2]);
-        acc = __fadd_rn(acc, M[r * 4 + 3]);
-        w[r] = __fsub_rn(acc, M[r * 4 + 3]);
-    }
-    float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(w[0], w[0]), __fmul_rn(w[1], w[1])), __fmul_rn(w[2], w[2])));
-    nrm = fmaxf(nrm, 1e-12f);       // F.normalize eps
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        dirs[i * 3 + r] = __fdiv_rn(w[r], nrm);
+        dirs[i * 3 + r] = d[r];
         origins[i * 3 + r] = M[r * 4 + 3];
     }
+}
+
+// torch.rand(numel) at (seed, offset) as a stand-alone kernel: one element per lane, grid-stride free (numel <= 2^32 checked by the host)
+__global__ __launch_bounds__(256) void torch_rand_kernel(float* __restrict__ out, int64_t numel, TorchRandDraw d) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < numel) out[i] = torch_rand_element(d, uint64_t(i));
 }
 
 // gen_videos.py:173 -- `(img * 127.5 + 128).clamp(0, 255).to(torch.uint8)` followed by the NCHW -> NHWC permute of the frame writer, in one
@@ -337,4 +321,30 @@ extern "C" int gnerf_make_rays(const float* cam2world, const float* intrinsics, 
     hipLaunchKernelGGL(make_rays_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
                        cam2world, intrinsics, n, res, origins, dirs);
     return check_launch("make_rays");
+}
+
+extern "C" int gnerf_torch_rand_plan(int64_t numel, int multi_processor_count, int max_threads_per_multi_processor,
+                                     uint32_t* threads, uint64_t* offset_increment) {
+    using namespace gnerf;
+    if (numel < 1 || multi_processor_count < 1 || max_threads_per_multi_processor < 256 || !threads || !offset_increment)
+        return fail(GNERF_E_ARG, "torch_rand_plan: bad arguments");
+    // ATen/native/cuda/DistributionTemplates.h, calc_execution_policy (block 256, unroll 4)
+    const uint64_t blocks_cap = uint64_t(multi_processor_count) * uint64_t(max_threads_per_multi_processor / 256);
+    uint64_t blocks = (uint64_t(numel) + 255) / 256;
+    if (blocks > blocks_cap) blocks = blocks_cap;
+    if (blocks * 256 > 0xffffffffull) return fail(GNERF_E_UNSUPPORTED, "torch_rand_plan: grid too large");
+    *threads = uint32_t(blocks * 256);
+    *offset_increment = ((uint64_t(numel) - 1) / (uint64_t(*threads) * 4) + 1) * 4;
+    return GNERF_OK;
+}
+
+extern "C" int gnerf_torch_rand(float* out, int64_t numel, uint64_t seed, uint64_t offset, uint32_t threads, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!out || numel < 1) return fail(GNERF_E_ARG, "torch_rand: null output or numel < 1");
+    TorchRandDraw d;
+    if (!torch_rand_draw(seed, offset, threads, numel, d))
+        return fail(GNERF_E_UNSUPPORTED, "torch_rand: %u threads for %lld elements at offset %llu is not a geometry this kernel reproduces "
+                    "(threads must be a power of two or >= numel, offset a multiple of 4)", threads, (long long)numel, (unsigned long long)offset);
+    hipLaunchKernelGGL(torch_rand_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, as_stream(stream), out, numel, d);
+    return check_launch("torch_rand");
 }

@@ -33,6 +33,7 @@
 //    publish their extrema with two integer atomics, and a tiny second kernel applies the clamp.
 
 #include "common.h"
+#include "raygen.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -60,6 +61,8 @@ struct Params {
     unsigned tex_pitch, row_pitch, plane_pitch;     // byte addressing of a texel, see plane_taps (render_coop.inl)
     int64_t item_bytes;     // bytes from one item's planes to the next: 3 * H * W * 128, or 0 when every item reads the same planes (planes_shared)
     const float* absmax;    // GNERF_MLP_AUTO: max |planes| (one device float) for choose_mlp
+    TorchRandDraw draw_c, draw_f;   // rng_mode: the two draws torch's generator would have made (raygen.h)
+    uint64_t draw_item_ctr;         // rng_per_item: Philox counter stride from one item's draws to the next (offset stride / 4)
 };
 
 // ---- order-preserving float <-> uint so that integer atomics give float min/max
@@ -783,12 +786,18 @@ extern "C" size_t gnerf_render_workspace_bytes(void) { return size_t(kClampItemW
 static int fill_params(const gnerf_render_params* p, Params& P) {
     using namespace gnerf;
     if (int e = check_common(p)) return e;
-    if (!p->ray_origins || !p->ray_dirs || !p->noise_coarse) return fail(GNERF_E_ARG, "render: rays and noise_coarse must not be null");
+    const bool own_rays = !p->ray_origins && !p->ray_dirs && p->cam2world && p->intrinsics;
+    if (!own_rays && (!p->ray_origins || !p->ray_dirs)) return fail(GNERF_E_ARG, "render: rays must not be null (or both null with cam2world and intrinsics given)");
+    if (own_rays && (p->image_width < 1 || int64_t(p->image_width) * p->image_width != p->rays_per_item))
+        return fail(GNERF_E_ARG, "render: in-kernel rays need rays_per_item = image_width^2");
+    if (p->rng_mode != GNERF_RNG_TENSORS && p->rng_mode != GNERF_RNG_TORCH_PHILOX) return fail(GNERF_E_ARG, "render: rng_mode %d is not one of GNERF_RNG_*", p->rng_mode);
+    if (p->rng_mode == GNERF_RNG_TENSORS && !p->noise_coarse) return fail(GNERF_E_ARG, "render: noise_coarse must not be null");
+    if (p->rng_mode == GNERF_RNG_TORCH_PHILOX && (p->noise_coarse || p->noise_fine)) return fail(GNERF_E_ARG, "render: rng_mode = GNERF_RNG_TORCH_PHILOX takes no noise tensors");
     const int S = p->depth_resolution, F = p->depth_resolution_importance;
     if (S < 2 || S > GNERF_MAX_SAMPLES) return fail(GNERF_E_ARG, "render: depth_resolution %d outside [2, %d]", S, GNERF_MAX_SAMPLES);
     if (F < 0 || F > GNERF_MAX_SAMPLES) return fail(GNERF_E_ARG, "render: depth_resolution_importance %d outside [0, %d]", F, GNERF_MAX_SAMPLES);
     if (F > 0 && S < 4) return fail(GNERF_E_ARG, "render: importance sampling needs depth_resolution >= 4");
-    if (F > 0 && !p->noise_fine) return fail(GNERF_E_ARG, "render: noise_fine is null but depth_resolution_importance > 0");
+    if (F > 0 && !p->noise_fine && p->rng_mode == GNERF_RNG_TENSORS) return fail(GNERF_E_ARG, "render: noise_fine is null but depth_resolution_importance > 0");
     if (p->rays_per_item < 1) return fail(GNERF_E_ARG, "render: rays_per_item must be positive");
     if ((p->ray_start_per_ray == nullptr) != (p->ray_end_per_ray == nullptr)) return fail(GNERF_E_ARG, "render: per-ray start and end must be given together");
     const int64_t total = int64_t(p->n_items) * p->rays_per_item;
@@ -812,6 +821,18 @@ static int fill_params(const gnerf_render_params* p, Params& P) {
     P.split_shift = 0;
     P.pipe_unit = 8;
     P.absmax = nullptr;
+    P.draw_c = P.draw_f = TorchRandDraw{};
+    P.draw_item_ctr = 0;
+    if (p->rng_mode == GNERF_RNG_TORCH_PHILOX) {
+        const int64_t units = p->rng_per_item ? int64_t(p->rays_per_item) : total;       // rays one draw covers
+        if ((p->rng_per_item != 0 && p->rng_per_item != 1) || p->rng_offset_item_stride % 4 != 0)
+            return fail(GNERF_E_ARG, "render: rng_per_item must be 0 or 1 and rng_offset_item_stride a multiple of 4");
+        if (!torch_rand_draw(p->rng_seed, p->rng_offset_coarse, p->rng_threads_coarse, units * S, P.draw_c) ||
+            (F > 0 && !torch_rand_draw(p->rng_seed, p->rng_offset_fine, p->rng_threads_fine, units * F, P.draw_f)))
+            return fail(GNERF_E_UNSUPPORTED, "render: the generator geometry (threads %u / %u, offsets %llu / %llu) is not one the in-kernel draws reproduce",
+                        p->rng_threads_coarse, p->rng_threads_fine, (unsigned long long)p->rng_offset_coarse, (unsigned long long)p->rng_offset_fine);
+        P.draw_item_ctr = p->rng_per_item ? p->rng_offset_item_stride / 4 : 0;
+    }
     const int iw = p->image_width;
     if (iw > 0 && iw % 4 == 0 && p->rays_per_item % iw == 0 && (p->rays_per_item / iw) % 4 == 0) {
         P.tiles_y = p->rays_per_item / iw / 4;
@@ -893,7 +914,8 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         int64_t g = ((total_seq + P.pipe_unit - 1) / P.pipe_unit + kNumXCD - 1) / kNumXCD * kNumXCD;
         if (g < kNumXCD) g = kNumXCD;
         if (g > capacity) g = capacity;
-        const size_t lds_bytes = pipe_lds_floats(pipe_tp, mlp) * sizeof(float);
+        const bool gen = !p->ray_origins || p->rng_mode != GNERF_RNG_TENSORS;       // the call makes its rays and / or its draws in the kernel
+        const size_t lds_bytes = pipe_lds_floats(pipe_tp, mlp, gen) * sizeof(float);
         const dim3 gd((unsigned)g), bd(kPipeThreads);
         // the instantiation with compile-time sample counts (render_pipe_body<.., FULL>) where the call fills the slots exactly
         bool full = S == 48 * pipe_tp && F == 48 * pipe_tp && !p->disparity_space_sampling && !p->ray_start_per_ray && !p->debug;
@@ -901,6 +923,15 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         full = full || (S == 48 * pipe_tp && F == 48 * pipe_tp && !p->disparity_space_sampling && !p->ray_start_per_ray);     // the timing build's `debug` is its stamp buffer
 #endif
         if (const char* f = getenv("GNERF_PIPE_FULL")) full = full && strcmp(f, "0") != 0;       // A/B runs and the tests' cross-check
+        if (gen) {
+            if (!full || pipe_tp > 2)
+                return fail(GNERF_E_UNSUPPORTED, "render: in-kernel rays / draws are built for 48+48 and 96+96 samples with plain stratified sampling (got %d+%d)", S, F);
+#define GNERF_PIPE_GEN(TP) do { if (mlp == kMlpAuto) hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpAuto, true, true>), gd, bd, lds_bytes, s, P); \
+                                else if (mlp == kMlpF16x3) hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpF16x3, true, true>), gd, bd, lds_bytes, s, P); \
+                                else hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpF32, true, true>), gd, bd, lds_bytes, s, P); } while (0)
+            if (pipe_tp == 1) GNERF_PIPE_GEN(1); else GNERF_PIPE_GEN(2);
+#undef GNERF_PIPE_GEN
+        } else {
 #define GNERF_PIPE2(TP, FULL) do { if (mlp == kMlpAuto) hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpAuto, FULL>), gd, bd, lds_bytes, s, P); \
                             else if (mlp == kMlpF16x3) hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpF16x3, FULL>), gd, bd, lds_bytes, s, P); \
                             else hipLaunchKernelGGL((render_kernel_pipe<TP, kMlpF32, FULL>), gd, bd, lds_bytes, s, P); } while (0)
@@ -916,7 +947,11 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         }
 #undef GNERF_PIPE
 #undef GNERF_PIPE2
+        }
         if (int e = check_launch("render_kernel_pipe")) return e;
+    } else
+    if (!p->ray_origins || p->rng_mode != GNERF_RNG_TENSORS) {
+        return fail(GNERF_E_UNSUPPORTED, "render: in-kernel rays / draws need the pipelined kernel (48+48 or 96+96 samples); got %d+%d", S, F);
     } else
     if (coop) {
         const int tc1 = (P.tiles_c + kCoopWaves - 1) / kCoopWaves, tf1 = (P.tiles_f + kCoopWaves - 1) / kCoopWaves;
@@ -952,6 +987,7 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
     if (int e = fill_params(p, P)) return e;
     if (!g) return fail(GNERF_E_ARG, "render_backward: grads is null");
     if (p->planes_shared) return fail(GNERF_E_UNSUPPORTED, "render_backward: planes_shared is a forward-only option");
+    if (!p->ray_origins || p->rng_mode != GNERF_RNG_TENSORS) return fail(GNERF_E_UNSUPPORTED, "render_backward: in-kernel rays / draws are forward-only options");
     const int n_dec = (g->grad_w1 != nullptr) + (g->grad_b1 != nullptr) + (g->grad_w2 != nullptr) + (g->grad_b2 != nullptr);
     if (n_dec != 0 && n_dec != 4) return fail(GNERF_E_ARG, "render_backward: the four decoder gradients are given together or not at all");
     if (!g->grad_planes_nhwc && n_dec == 0) return GNERF_OK;

@@ -60,9 +60,10 @@ __device__ __forceinline__ PipeSlot pipe_slot(float* base, int slot) {
     return s;
 }
 
-__host__ __device__ inline size_t pipe_lds_floats(int tp, int mlp) {
+__host__ __device__ inline size_t pipe_lds_floats(int tp, int mlp, bool gen = false) {
     const size_t slot_floats = tp == 1 ? PipeDims<1>::kSlotFloats : (tp == 2 ? PipeDims<2>::kSlotFloats : PipeDims<3>::kSlotFloats);
-    return size_t(weight_floats(mlp)) + 64 + 36 + size_t(kPipeSlots) * slot_floats + 3 * 16 * kStagePitch;       // (tap records live in the staging rows)
+    return size_t(weight_floats(mlp)) + 64 + 36 + size_t(kPipeSlots) * slot_floats + 3 * 16 * kStagePitch       // (tap records live in the staging rows)
+           + (gen ? kPipeUnit * 8 : 0);                                                                            // GEN: the dealing unit's rays
 }
 
 // position `seq` of the locality-ordered ray sequence -> ray index (or -1 past the end)
@@ -92,7 +93,12 @@ __device__ __forceinline__ int pipe_seq_to_ray(const Params& P, int64_t seq) {
 // all.  Same arithmetic, same results (the tests run both instantiations on the same inputs); what it buys is the scalar wave's
 // instruction count and the scalar-register pressure: the general instantiation spills 227 SGPRs to VGPR lanes and reloads them
 // with v_readlane_b32 all over the scalar wave's loop.
-template <int TP, int MLP, bool FULL>
+// GEN: the instantiation that can make its rays and its uniform draws itself (gnerf_render_params.cam2world / rng_mode, ABI 8), each
+// chosen per launch: rays from the item's camera with gnerf_make_rays' arithmetic, draws as torch's device generator would have
+// made them (raygen.h).  Both run on the scalar wave, whose SIMD is the half-idle one: a ray's 96 draws are two
+// wave-wide Philox evaluations (~100 integer instructions each) in place of two loads, its direction is computed for a whole dealing
+// unit at a time (one lane per ray of the unit, parked in 256 bytes of LDS).
+template <int TP, int MLP, bool FULL, bool GEN>
 __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
     typedef PipeDims<TP> D;
     constexpr int kPipeMaxS = D::kMaxS, kPipeSPad = D::kSPad, kSlotFloats = D::kSlotFloats, RND = D::kRounds;
@@ -158,17 +164,51 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
     float pre_uc[RND] = {}, pre_uf[RND] = {}, pre_ray = 0.f, pre_rs = 0.f, pre_re = 0.f;       // prefetched by propose_issue
     int pre_ray_id = -1;
 
-    auto propose_issue = [&](int r) {           // P(r), first half: start the global loads
+    float* const unit_rays = L.taps + 3 * 16 * kStagePitch;        // GEN: [kPipeUnit][8] origin, direction of the current dealing unit's rays
+    auto propose_issue = [&](int r) {           // P(r), first half: start the global loads (or make the values: GEN)
         pre_ray_id = (r >= 0 && r < nr) ? local_to_ray(r) : -1;
+        if (GEN && p.cam2world && r >= 0 && r < nr && r % unit == 0 && lane < unit) {
+            // rays of this dealing unit, one lane each (r .. r + unit - 1 are consecutive positions of the sequence)
+            const int64_t seq = x0 + (int64_t(wg) + int64_t(r / unit) * W) * unit + lane;
+            const int id = seq < x1 ? pipe_seq_to_ray(P, seq) : -1;
+            if (id >= 0) {
+                const int item = id / p.rays_per_item, m = id - item * p.rays_per_item;
+                const float* M = p.cam2world + item * 16;
+                float d[3];
+                camera_ray(M, p.intrinsics + item * 9, p.image_width, m / p.image_width, m % p.image_width, d);
+#pragma unroll
+                for (int c = 0; c < 3; c++) { unit_rays[lane * 8 + c] = M[c * 4 + 3]; unit_rays[lane * 8 + 3 + c] = d[c]; }
+            }
+        }
         if (pre_ray_id < 0) return;
         const int64_t ray = pre_ray_id;
+        if (GEN && p.rng_mode) {
+            TorchRandDraw dc = P.draw_c, df = P.draw_f;
+            uint64_t first_c = uint64_t(ray) * S, first_f = uint64_t(ray) * F;
+            if (p.rng_per_item) {                                   // the draws of a call of this item alone
+                const int item = pre_ray_id / p.rays_per_item;
+                const uint64_t in_item = uint64_t(pre_ray_id - item * p.rays_per_item);
+                first_c = in_item * S; first_f = in_item * F;
+                dc.ctr += uint64_t(item) * P.draw_item_ctr; df.ctr += uint64_t(item) * P.draw_item_ctr;
+            }
 #pragma unroll
-        for (int q = 0; q < RND; q++) {
-            if (lane + 64 * q < S) pre_uc[q] = p.noise_coarse[ray * S + lane + 64 * q];
-            if (lane + 64 * q < F) pre_uf[q] = p.noise_fine[ray * F + lane + 64 * q];
+            for (int q = 0; q < RND; q++) {
+                if (lane + 64 * q < S) pre_uc[q] = torch_rand_element(dc, first_c + lane + 64 * q);
+                if (lane + 64 * q < F) pre_uf[q] = torch_rand_element(df, first_f + lane + 64 * q);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < RND; q++) {
+                if (lane + 64 * q < S) pre_uc[q] = p.noise_coarse[ray * S + lane + 64 * q];
+                if (lane + 64 * q < F) pre_uf[q] = p.noise_fine[ray * F + lane + 64 * q];
+            }
         }
-        if (lane < 3) pre_ray = p.ray_origins[ray * 3 + lane];
-        else if (lane < 6) pre_ray = p.ray_dirs[ray * 3 + lane - 3];
+        if (GEN && p.cam2world) {
+            if (lane < 6) pre_ray = unit_rays[(r % unit) * 8 + lane];       // (LDS operations of one wave execute in order)
+        } else {
+            if (lane < 3) pre_ray = p.ray_origins[ray * 3 + lane];
+            else if (lane < 6) pre_ray = p.ray_dirs[ray * 3 + lane - 3];
+        }
         if (!FULL && p.ray_start_per_ray) { pre_rs = p.ray_start_per_ray[ray]; pre_re = p.ray_end_per_ray[ray]; }
     };
     auto propose_finish = [&](int r) {          // P(r), second half: depth proposals (renderer.py:169-192) into the slot
@@ -541,13 +581,13 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
     if (wv == 3 && lane == 0) range.flush(P);
 }
 
-template <int TP, int MLP, bool FULL>
+template <int TP, int MLP, bool FULL, bool GEN = false>
 __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD : (TP == 2 ? GNERF_PIPE2_WAVES_PER_SIMD : 2)) void render_kernel_pipe(Params P) {
     extern __shared__ __align__(16) float smem[];
     if constexpr (MLP == kMlpAuto) {            // see render_kernel_coop
-        if (choose_mlp(P, smem) == kMlpF32) render_pipe_body<TP, kMlpF32, FULL>(P, smem);
-        else                               render_pipe_body<TP, kMlpF16x3, FULL>(P, smem);
+        if (choose_mlp(P, smem) == kMlpF32) render_pipe_body<TP, kMlpF32, FULL, GEN>(P, smem);
+        else                               render_pipe_body<TP, kMlpF16x3, FULL, GEN>(P, smem);
     } else {
-        render_pipe_body<TP, MLP, FULL>(P, smem);
+        render_pipe_body<TP, MLP, FULL, GEN>(P, smem);
     }
 }

@@ -23,7 +23,7 @@ _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.float64: F64}
 
 MAX_SAMPLES = 256
 DEBUG_SLOTS = 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 # decoder arithmetic of the fused renderer (GNERF_MLP_* in include/gnerf_hip.h)
 MLP_MODES = {'auto': 0, 'f16x3': 1, 'f32': 2}
 
@@ -48,6 +48,9 @@ class RenderParams(ctypes.Structure):
         ('workspace', _c_p), ('debug', _c_p),
         ('planes_absmax', _c_p), ('mlp_mode', ctypes.c_int32), ('planes_interleaved', ctypes.c_int32),
         ('planes_shared', ctypes.c_int32), ('depth_clamp_per_item', ctypes.c_int32),
+        ('cam2world', _c_p), ('intrinsics', _c_p), ('rng_mode', ctypes.c_int32), ('rng_per_item', ctypes.c_int32),
+        ('rng_seed', ctypes.c_uint64), ('rng_offset_coarse', ctypes.c_uint64), ('rng_offset_fine', ctypes.c_uint64),
+        ('rng_offset_item_stride', ctypes.c_uint64), ('rng_threads_coarse', ctypes.c_uint32), ('rng_threads_fine', ctypes.c_uint32),
     ]
 
 
@@ -81,6 +84,8 @@ SIGNATURES = {
     'gnerf_planes_absmax': (_c_i, [_c_p, _c_i64, _c_p, _c_p]),
     'gnerf_planes_from_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_make_rays': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_p, _c_p, _c_p]),
+    'gnerf_torch_rand_plan': (_c_i, [_c_i64, _c_i, _c_i, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)]),
+    'gnerf_torch_rand': (_c_i, [_c_p, _c_i64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _c_p]),
     'gnerf_to_uint8_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_render_workspace_bytes': (ctypes.c_size_t, []),
     'gnerf_render_forward': (_c_i, [ctypes.POINTER(RenderParams), _c_p]),
@@ -792,12 +797,19 @@ def last_mlp_choice(device):
 def _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine,
                    depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
                    white_back, disparity_space_sampling, image_width, what, planes_absmax=None, mlp='auto',
-                   planes_shared=False, depth_clamp_per_item=False):
+                   planes_shared=False, depth_clamp_per_item=False, cameras=None, rng=None):
     """Validate the arguments shared by render_forward / render_backward and fill a RenderParams.
-    Returns (params, keepalive, rays_per_item); `keepalive` holds the converted tensors the pointers refer to."""
+    Returns (params, keepalive, rays_per_item); `keepalive` holds the converted tensors the pointers refer to.
+    cameras = (cam2world [N,4,4], intrinsics [N,3,3], res) with ray_origins = ray_dirs = None: rays made in the kernel;
+    rng = a TorchPhiloxPlan with noise_coarse = noise_fine = None: draws made in the kernel (gnerf_render_params, ABI 8)."""
     w1, b1, w2, b2 = decoder
     _require_cuda(planes_nhwc, ray_origins, ray_dirs, noise_coarse, noise_fine, w1, b1, w2, b2)
     dev = planes_nhwc.device
+    if cameras is not None or rng is not None:
+        return _render_params_generated(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine,
+                                        depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp, white_back,
+                                        disparity_space_sampling, image_width, what, planes_absmax, mlp, planes_shared, depth_clamp_per_item,
+                                        cameras, rng)
 
     def f32c(t):
         return t.to(torch.float32).contiguous()
@@ -850,12 +862,145 @@ def _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
     return p, (planes_nhwc, o, d, nc, nf, w1, b1, w2, b2, rs_t, re_t, planes_absmax), m
 
 
+class TorchPhiloxPlan:
+    """Where torch's device generator stands before the renderer's two uniform draws (renderer.py:190 rand_like([N,M,S,1]), :241
+    rand(N*M, F)) and how ATen would have laid them out on this device -- what gnerf_render_params.rng_* carry (include/gnerf_hip.h,
+    oracle/philox_ref.py).  per_item: N separate calls of one item each (the draws of the batched-views form)."""
+    __slots__ = ('seed', 'offset_coarse', 'offset_fine', 'item_stride', 'threads_coarse', 'threads_fine', 'per_item', 'end_offset')
+
+
+_device_geometry = {}
+
+
+def torch_rand_geometry(numel, device):
+    """(threads, philox offset increment) of `torch.rand(numel, device=device)` (gnerf_torch_rand_plan)."""
+    geo = _device_geometry.get(device.index)
+    if geo is None:
+        pr = torch.cuda.get_device_properties(device)
+        geo = _device_geometry[device.index] = (int(pr.multi_processor_count), int(pr.max_threads_per_multi_processor))
+    thr, inc = ctypes.c_uint32(0), ctypes.c_uint64(0)
+    _check(load().gnerf_torch_rand_plan(int(numel), geo[0], geo[1], ctypes.byref(thr), ctypes.byref(inc)), 'gnerf_torch_rand_plan')
+    return thr.value, inc.value
+
+
+def torch_philox_plan(device, n_items, rays_per_item, S, F, per_item=False, generator=None, advance=True):
+    """Plan the renderer's two draws on `device`'s generator (default: torch's default generator of that device) and -- advance=True --
+    move the generator past them, exactly as the torch.rand calls would have: a seeded run that renders with in-kernel draws leaves the
+    generator where the reference's run leaves it.  Not usable while the stream is capturing a graph (graph-safe generators keep their
+    offset on the device): the caller draws tensors then."""
+    gen = generator if generator is not None else torch.cuda.default_generators[device.index]
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError('torch_philox_plan: the stream is capturing a graph; draw with torch.rand instead')
+    plan = TorchPhiloxPlan()
+    plan.seed = int(gen.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+    plan.per_item = bool(per_item)
+    units = rays_per_item if per_item else n_items * rays_per_item
+    plan.threads_coarse, inc_c = torch_rand_geometry(units * S, device)
+    plan.threads_fine, inc_f = torch_rand_geometry(units * F, device) if F > 0 else (0, 0)
+    off = int(gen.get_offset())
+    plan.offset_coarse, plan.offset_fine = off, off + inc_c
+    plan.item_stride = inc_c + inc_f if per_item else 0
+    plan.end_offset = off + (inc_c + inc_f) * (n_items if per_item else 1)
+    if advance:
+        gen.set_offset(plan.end_offset)
+    return plan
+
+
+@profiled('gnerf_hip::torch_rand')
+def torch_rand(numel, device, seed, offset):
+    """Element for element what torch.rand(numel, device=device) returns with the device generator at (seed, offset): the render
+    kernels' in-kernel draw as a stand-alone kernel (gnerf_torch_rand).  The generator is not touched."""
+    threads, _ = torch_rand_geometry(numel, device)
+    out = torch.empty(int(numel), dtype=torch.float32, device=device)
+    with _on_device(device):
+        _check(load().gnerf_torch_rand(out.data_ptr(), int(numel), int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset), threads, _stream(out)), 'gnerf_torch_rand')
+    return out
+
+
+def _render_params_generated(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine,
+                             depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp, white_back,
+                             disparity_space_sampling, image_width, what, planes_absmax, mlp, planes_shared, depth_clamp_per_item, cameras, rng):
+    """_render_params for calls that make their rays and / or their draws in the kernel (ABI 8)."""
+    w1, b1, w2, b2 = decoder
+    dev = planes_nhwc.device
+
+    def f32c(t):
+        return t.to(torch.float32).contiguous()
+    interleaved = planes_layout(planes_nhwc, 1 if planes_shared else n_items, what)
+    if tuple(w1.shape) != (64, 32) or tuple(b1.shape) != (64,) or tuple(w2.shape) != (33, 64) or tuple(b2.shape) != (33,):
+        raise RuntimeError(f'{what}: decoder must be the 32->64->33 OSGDecoder MLP')
+    if isinstance(ray_start, torch.Tensor) or isinstance(ray_end, torch.Tensor):
+        raise RuntimeError(f'{what}: in-kernel rays / draws take scalar ray limits')
+    S, F = int(depth_resolution), int(depth_resolution_importance)
+    p = RenderParams()
+    keep = [planes_nhwc]
+    if cameras is not None:
+        if ray_origins is not None or ray_dirs is not None:
+            raise RuntimeError(f'{what}: give rays or cameras, not both')
+        c2w, intr, res = cameras
+        _require_cuda(c2w, intr)
+        c2w, intr = f32c(c2w), f32c(intr)
+        if tuple(c2w.shape) != (n_items, 4, 4) or tuple(intr.shape) != (n_items, 3, 3):
+            raise RuntimeError(f'{what}: cameras must be cam2world [N,4,4] and intrinsics [N,3,3]')
+        m, image_width = int(res) * int(res), int(res)
+        p.cam2world, p.intrinsics = c2w.data_ptr(), intr.data_ptr()
+        keep += [c2w, intr]
+    else:
+        o, d = f32c(ray_origins), f32c(ray_dirs)
+        if o.shape != d.shape or o.ndim != 3 or o.shape[0] != n_items or o.shape[2] != 3:
+            raise RuntimeError(f'{what}: rays must be [N,M,3]')
+        m = o.shape[1]
+        p.ray_origins, p.ray_dirs = o.data_ptr(), d.data_ptr()
+        keep += [o, d]
+    if rng is not None:
+        if noise_coarse is not None or noise_fine is not None:
+            raise RuntimeError(f'{what}: give noise tensors or an rng plan, not both')
+        p.rng_mode = 1
+        p.rng_per_item = int(rng.per_item)
+        p.rng_seed, p.rng_offset_coarse, p.rng_offset_fine = rng.seed, rng.offset_coarse, rng.offset_fine
+        p.rng_offset_item_stride, p.rng_threads_coarse, p.rng_threads_fine = rng.item_stride, rng.threads_coarse, rng.threads_fine
+    else:
+        nc = f32c(noise_coarse)
+        nf = f32c(noise_fine) if F > 0 else None
+        if nc.numel() != n_items * m * S or (nf is not None and nf.numel() != n_items * m * F):
+            raise RuntimeError(f'{what}: noise tensors must have N*M*S and N*M*F elements')
+        p.noise_coarse, p.noise_fine = nc.data_ptr(), None if nf is None else nf.data_ptr()
+        keep += [nc, nf]
+    w1, b1, w2, b2 = f32c(w1), f32c(b1), f32c(w2), f32c(b2)
+    keep += [w1, b1, w2, b2, planes_absmax]
+    p.planes_nhwc = planes_nhwc.data_ptr(); p.n_items = n_items; p.plane_h = planes_nhwc.shape[1]; p.plane_w = planes_nhwc.shape[2]
+    p.rays_per_item = m; p.image_width = int(image_width)
+    p.w1, p.b1, p.w2, p.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    p.depth_resolution = S; p.depth_resolution_importance = F
+    p.ray_start = float(ray_start); p.ray_end = float(ray_end)
+    p.box_warp = float(box_warp); p.white_back = int(bool(white_back)); p.disparity_space_sampling = int(bool(disparity_space_sampling))
+    if mlp not in MLP_MODES:
+        raise RuntimeError(f"{what}: mlp must be one of {sorted(MLP_MODES)}")
+    p.mlp_mode = MLP_MODES[mlp]
+    if planes_absmax is not None:
+        _require_cuda(planes_absmax)
+        if planes_absmax.dtype != torch.float32 or planes_absmax.numel() != 1:
+            raise RuntimeError(f'{what}: planes_absmax must be a one-element float32 device tensor')
+    p.planes_absmax = _ptr(planes_absmax)
+    p.planes_interleaved = interleaved
+    p.planes_shared = int(bool(planes_shared)); p.depth_clamp_per_item = int(bool(depth_clamp_per_item))
+    return p, tuple(keep), m
+
+
+def render_generated_supported(S, F, ray_start=0.0, ray_end=1.0, disparity_space_sampling=False):
+    """Do the render kernels make rays / draws themselves for these options?  (48+48 and 96+96 samples, plain stratified sampling.)"""
+    return int(S) == int(F) and int(S) in (48, 96) and not disparity_space_sampling and not isinstance(ray_start, torch.Tensor) and not isinstance(ray_end, torch.Tensor)
+
+
 @profiled('gnerf_hip::render_forward')
 def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine, *,
                    depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
                    white_back=False, disparity_space_sampling=False, image_width=0, debug=False, planes_absmax=None, mlp='auto',
-                   planes_shared=False, depth_clamp_per_item=False):
+                   planes_shared=False, depth_clamp_per_item=False, cameras=None, rng=None):
     """planes_nhwc [3N,H,W,32]; decoder = (w1,b1,w2,b2) effective fp32 weights; rays [N,M,3];
+    cameras = (cam2world [N,4,4], intrinsics [N,3,3], res) with ray_origins = ray_dirs = None: the kernel makes the rays gnerf_make_rays
+    would (RaySampler.forward); rng = torch_philox_plan(...) with noise_coarse = noise_fine = None: the kernel makes the draws torch.rand
+    would (both: render_generated_supported; bit-identical to the tensor forms, tests/test_gpu_parity.py).
     noise_coarse [N*M,S]; noise_fine [N*M,F] or None; ray_start/ray_end floats or [N*M] tensors.
     planes_shared: planes_nhwc holds ONE item's planes ([3,H,W,32] or [1,H,W,96]) that all N items of rays read (N views of one
     object in one launch).  depth_clamp_per_item: the final depth clamp (ray_marcher.py:49-50) takes its range from each item's
@@ -864,7 +1009,7 @@ def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
     with_absmax=True) returns; measured by the call itself when None -- and the decoder's weights), 'f16x3' or 'f32'.
     Returns (rgb [N,M,32], depth [N,M,1], wsum [N,M,1][, debug [N*M,8,S+F]])."""
     e = ext()
-    if e is not None and not debug and planes_nhwc.dtype == torch.float32 and planes_nhwc.is_contiguous():
+    if e is not None and not debug and planes_nhwc.dtype == torch.float32 and planes_nhwc.is_contiguous() and cameras is None and rng is None:
         # the C++ binding: same validation and the same C ABI call, without ctypes marshalling
         def f32c(t):
             return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
@@ -891,7 +1036,7 @@ def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
     p, keep, m = _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine,
                                 depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
                                 white_back, disparity_space_sampling, image_width, 'render_forward', planes_absmax, mlp,
-                                planes_shared, depth_clamp_per_item)
+                                planes_shared, depth_clamp_per_item, cameras, rng)
     dev = planes_nhwc.device
     rgb = torch.empty([n_items, m, 32], dtype=torch.float32, device=dev)
     depth = torch.empty([n_items, m, 1], dtype=torch.float32, device=dev)

@@ -37,6 +37,9 @@ import os
 import gnerf_hip
 
 _KEEP_NHWC = os.environ.get('GNERF_KEEP_NHWC', '1') != '0'
+# The two uniform draws made inside the render kernel (torch's own Philox stream, generator advanced as torch.rand would: same
+# image, same generator state afterwards) instead of by two torch.rand launches.  Inference calls at 48+48 / 96+96 samples only.
+_INKERNEL_RNG = os.environ.get('GNERF_INKERNEL_RNG', '0') == '1'
 _NHWC_HINT = os.environ.get('GNERF_NHWC_PLANES', '0') == '1'
 
 
@@ -366,6 +369,20 @@ class ImportanceRenderer(torch.nn.Module):
                 ray_start, ray_end = limits(ray_origins, ray_directions)
         else:
             ray_start, ray_end = opts['ray_start'], opts['ray_end']
+        side = math.isqrt(M)
+        if opts['clamp_mode'] != 'softplus':
+            assert False, "MipRayMarcher only supports `clamp_mode`=`softplus`!"
+        cfg = dict(depth_resolution=S, depth_resolution_importance=F, box_warp=opts['box_warp'],
+                   white_back=bool(opts.get('white_back', False)), disparity_space_sampling=bool(opts.get('disparity_space_sampling', False)),
+                   image_width=side if side * side == M else 0)
+        if _INKERNEL_RNG and not differentiable and gnerf_hip.render_generated_supported(S, F, ray_start, ray_end, cfg['disparity_space_sampling']) \
+                and not torch.cuda.is_current_stream_capturing():
+            # the same two draws (per view: the draws of a call of its own), made by the render kernel from the generator's state
+            plan = gnerf_hip.torch_philox_plan(dev, N, M, S, F, per_item=views)
+            nhwc, amax = self._planes_nhwc(planes)
+            return gnerf_hip.render_forward(nhwc, N, self._decoder_cache(fcs), ray_origins.detach(), ray_directions.detach(), None, None,
+                                            ray_start=ray_start, ray_end=ray_end, planes_absmax=amax, planes_shared=views, depth_clamp_per_item=views,
+                                            rng=plan, **cfg)
         # the reference's two draws, same shapes, same order (renderer.py:176/186/190 then :241)
         if views:
             draws = [(torch.rand([1, M, S, 1], device=dev, dtype=torch.float32), torch.rand(M, F, device=dev) if F > 0 else None) for _ in range(N)]
@@ -374,12 +391,6 @@ class ImportanceRenderer(torch.nn.Module):
         else:
             noise_c = torch.rand([N, M, S, 1], device=dev, dtype=torch.float32)
             noise_f = torch.rand(N * M, F, device=dev) if F > 0 else None
-        side = math.isqrt(M)
-        if opts['clamp_mode'] != 'softplus':
-            assert False, "MipRayMarcher only supports `clamp_mode`=`softplus`!"
-        cfg = dict(depth_resolution=S, depth_resolution_importance=F, box_warp=opts['box_warp'],
-                   white_back=bool(opts.get('white_back', False)), disparity_space_sampling=bool(opts.get('disparity_space_sampling', False)),
-                   image_width=side if side * side == M else 0)
         if differentiable:
             fc1, fc2 = fcs
             eff = (fc1.weight.float() * fc1.weight_gain, fc1.bias.float() * fc1.bias_gain,          # networks_stylegan2.py:121-127
@@ -410,7 +421,7 @@ class ImportanceRenderer(torch.nn.Module):
             count = depths.shape[2]
             pts = (ray_origins.unsqueeze(-2) + depths * ray_directions.unsqueeze(-2)).reshape(N, -1, 3)
             dirs = ray_directions.unsqueeze(-2).expand(-1, -1, count, -1).reshape(N, -1, 3)
-            out = self.run_model(planes, decoder, pts, dirs, rendering_options)
+            out = self._run_model(planes, decoder, pts, dirs, rendering_options, warn=False)        # (forward() has said why already)
             return out['rgb'].reshape(N, M, count, out['rgb'].shape[-1]), out['sigma'].reshape(N, M, count, 1)
 
         colors_coarse, densities_coarse = shade(depths_coarse)
@@ -429,6 +440,9 @@ class ImportanceRenderer(torch.nn.Module):
     def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):
         """Decoder outputs at arbitrary points [N,P,3] -> {'rgb' [N,P,32], 'sigma' [N,P,1]}
         (entry point of TriPlaneGenerator.sample / sample_mixed, triplane.py:91-102)."""
+        return self._run_model(planes, decoder, sample_coordinates, sample_directions, options)
+
+    def _run_model(self, planes, decoder, sample_coordinates, sample_directions, options, warn=True):
         self.plane_axes = self.plane_axes.to(sample_coordinates.device)
         density_noise = options.get('density_noise', 0)
         if planes.device.type == 'cuda' and planes.ndim == 5 and planes.shape[1] == 3 and planes.shape[2] == 32:
@@ -448,7 +462,7 @@ class ImportanceRenderer(torch.nn.Module):
                 if density_noise > 0:
                     out['sigma'] = out['sigma'] + torch.randn_like(out['sigma']) * density_noise
                 return out
-        if planes.device.type == 'cuda':
+        if warn and planes.device.type == 'cuda':
             _warn_gpu_fallback('the points need a gradient, the decoder is not the OSGDecoder MLP or the planes are not [N,3,32,H,W]', 'ImportanceRenderer.run_model')
         feats = sample_from_planes(self.plane_axes, planes, sample_coordinates, padding_mode='zeros', box_warp=options['box_warp'])
         out = decoder(feats, sample_directions)

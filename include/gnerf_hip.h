@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GNERF_ABI_VERSION 7
+#define GNERF_ABI_VERSION 8
 
 /* error codes */
 #define GNERF_OK            0
@@ -302,7 +302,42 @@ typedef struct gnerf_render_params {
          equals k calls of one view bit for bit.  0 (default): the reference's call-wide clamp.  n_items <= 4096 when set. */
     int32_t planes_shared;
     int32_t depth_clamp_per_item;
+    /* (ABI 8) Rays and uniform draws made INSIDE the render kernel (SURVEY.md section 8a row 1 / 8d "in-kernel Philox"): the call then
+       reads no ray tensors and no noise tensors (26.7 MB per 65 536 rays at 48+48) and needs no launch in front of it.
+       cam2world / intrinsics: [n_items,4,4] and [n_items,3,3] row-major device floats, used when ray_origins == ray_dirs == NULL.
+         Ray m of an item looks through pixel centre ((m % w + .5) / w, (m / w + .5) / w), w = image_width, which must be > 0 with
+         rays_per_item == w * w: the arithmetic of gnerf_make_rays (ray_sampler.py:24-63), same bits.
+       rng_mode = GNERF_RNG_TORCH_PHILOX: noise_coarse / noise_fine must be NULL; the kernel draws what torch's device generator
+         would have put into them -- `torch.rand_like([n,m,S,1])` then `torch.rand(n*m, F)` (renderer.py:190,241) -- Philox4x32-10
+         keyed by rng_seed, element li of a draw taken from thread li % threads of ATen's grid-stride kernel at the generator's
+         philox offset (oracle/philox_ref.py states the recipe; gnerf_torch_rand_plan gives threads and the offset increment of a
+         draw).  rng_offset_coarse / rng_offset_fine: philox offset of the generator BEFORE the respective draw (multiples of 4).
+         The caller advances its generator by the two increments afterwards, exactly as the two torch.rand calls would have.
+       rng_per_item = 1: the draws are per ITEM instead of per call (what n_items separate calls with one item each would draw:
+         the batched views of planes_shared): element indices count inside the item, and item i's offsets are
+         rng_offset_* + i * rng_offset_item_stride.
+       Supported by the pipelined kernels at their compile-time sample counts (48+48 and 96+96, no disparity sampling, no per-ray
+       limits, no stage dump): anything else returns GNERF_E_UNSUPPORTED and the caller passes tensors.  Forward only. */
+    const float* cam2world;
+    const float* intrinsics;
+    int32_t  rng_mode;
+    int32_t  rng_per_item;
+    uint64_t rng_seed;
+    uint64_t rng_offset_coarse, rng_offset_fine, rng_offset_item_stride;
+    uint32_t rng_threads_coarse, rng_threads_fine;
 } gnerf_render_params;
+
+#define GNERF_RNG_TENSORS      0
+#define GNERF_RNG_TORCH_PHILOX 1
+
+/* Launch geometry of ATen's uniform kernel for a draw of `numel` floats on a device whose torch properties are
+ * multi_processor_count / max_threads_per_multi_processor: *threads = 256 * min(ceil(numel / 256), mpc * (mtpm / 256)) and
+ * *offset_increment = 4 * ceil(numel / (4 * threads)), what the generator's philox offset advances by.  Host-only arithmetic. */
+int gnerf_torch_rand_plan(int64_t numel, int multi_processor_count, int max_threads_per_multi_processor,
+                          uint32_t* threads, uint64_t* offset_increment);
+/* The draw itself as a stand-alone kernel: out[i] = element i of torch.rand(numel) at (seed, offset) -- the same device function the
+ * render kernels use, exposed so that it can be held to torch.rand directly (tests) and for callers that want tensors. */
+int gnerf_torch_rand(float* out, int64_t numel, uint64_t seed, uint64_t offset, uint32_t threads, gnerf_stream_t stream);
 
 #define GNERF_MLP_AUTO  0
 #define GNERF_MLP_F16X3 1

@@ -312,6 +312,59 @@ def test_render_full_size_properties(dev):
         assert torch.equal(x, y) and torch.equal(x, z)
 
 
+def test_render_full_size_on_backbone_planes(dev):
+    """Config 2 on planes a generator produces (SURVEY 8d's "second run with real backbone output"; bench.py realistic_planes_step):
+    the random-init FFHQ backbone's [4,96,256,256] channels_last output with the generator's default-init decoder.  Properties at
+    full size -- the three plane routes (producer layout read in place with the producer's max |planes|; the same memory with the
+    launcher measuring it; NCHW copy repacked to [12,256,256,32]) give the same bits, runs repeat bit for bit, the in-kernel
+    rays / draws form agrees -- plus a strided subset of rays against the oracle on the same planes and decoder."""
+    import gnerf_hip
+    import gen_videos_mi355x as GV
+    from oracle import render_ref as R
+    from training.volumetric_rendering import renderer as RM
+    N, res, S = 4, 128, 48
+    with torch.no_grad():
+        G = GV.build_random_generator(0, dev)
+        z = torch.randn(N, G.z_dim, generator=torch.Generator().manual_seed(11)).to(dev)
+        img = G.backbone.synthesis(G.mapping(z, torch.zeros(N, 25, device=dev)), noise_mode='const')
+        planes5 = img.view(N, 3, 32, 256, 256)
+        inter, amax = G.renderer._planes_nhwc(planes5)
+        assert inter.shape == (N, 256, 256, 96) and inter.data_ptr() == img.data_ptr()         # the producer's memory, read in place
+        dec = G.renderer._decoder_cache(RM._osg_decoder_weights(G.decoder))
+    c2w = torch.cat([R.lookat_pose(3.14 / 2 + 0.3 * i, 3.14 / 2 - 0.05 * i, 2.7) for i in range(N)]).to(dev)
+    intr = torch.tensor([[4.2647, 0, 0.5], [0, 4.2647, 0.5], [0, 0, 1]]).repeat(N, 1, 1).to(dev)
+    o, d = gnerf_hip.make_rays(c2w, intr, res)
+    kw = dict(depth_resolution=S, depth_resolution_importance=S, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=res)
+    torch.manual_seed(3)
+    nc, nf = torch.rand([N, res * res, S, 1], device=dev), torch.rand(N * res * res, S, device=dev)
+    a = gnerf_hip.render_forward(inter, N, dec, o, d, nc, nf, planes_absmax=amax, **kw)
+    choice = gnerf_hip.last_mlp_choice(dev)
+    assert choice in ('f16x3', 'f32')
+    assert float(amax) == float(planes5.abs().max())
+    b = gnerf_hip.render_forward(inter, N, dec, o, d, nc, nf, **kw)                              # the launcher measures max |planes|
+    nchw = planes5.contiguous()                                                                  # a plain NCHW copy -> repack inside
+    nhwc2, amax2 = gnerf_hip.planes_to_nhwc(nchw, with_absmax=True)
+    c = gnerf_hip.render_forward(nhwc2, N, dec, o, d, nc, nf, planes_absmax=amax2, **kw)
+    e = gnerf_hip.render_forward(inter, N, dec, o, d, nc, nf, planes_absmax=amax, **kw)
+    for x, y, z_, w in zip(a, b, c, e):
+        assert torch.equal(x, y) and torch.equal(x, z_) and torch.equal(x, w)
+    assert gnerf_hip.last_mlp_choice(dev) == choice
+    # rays and draws made in the kernel: same generator state -> same bits
+    torch.manual_seed(3)
+    plan = gnerf_hip.torch_philox_plan(dev, N, res * res, S, S)
+    g = gnerf_hip.render_forward(inter, N, dec, None, None, None, None, planes_absmax=amax, cameras=(c2w, intr, res), rng=plan, **kw)
+    for x, y in zip(a, g):
+        assert torch.equal(x, y)
+    rgb, depth, wsum = a
+    assert torch.isfinite(rgb).all() and torch.isfinite(depth).all() and float(wsum.min()) >= 0 and float(wsum.max()) <= 1.0 + 1e-5
+    idx = torch.arange(0, res * res, 701)
+    ncc, nfc = nc.cpu().reshape(N, res * res, S), nf.cpu().reshape(N, res * res, S)
+    ref_rgb, ref_depth, ref_w = R.render(nchw.cpu(), [t.cpu() for t in dec], o.cpu()[:, idx], d.cpu()[:, idx], dict(kw, clamp_mode='softplus'),
+                                         ncc[:, idx], nfc[:, idx].reshape(-1, S))
+    assert float(((rgb.cpu()[:, idx] - ref_rgb) ** 2).mean()) < 1e-8
+    np.testing.assert_allclose(wsum.cpu()[:, idx].numpy(), ref_w.numpy(), atol=2e-4)
+
+
 def test_render_fuzz_slice(dev):
     """The first 200 cases of tests/parity_tools/fuzz_render.py's seed-31 sequence (the sweep that profiles/r0N_fuzz.jsonl records at full
     length) inside the suite, at the suite's own criterion: rgb MSE < max(1e-8, 4 x the fp32 noise floor), every kernel, both plane
@@ -605,6 +658,110 @@ def test_gpu_fallback_to_pytorch_ops_is_visible(dev):
     msgs = [str(w.message) for w in rec if issubclass(w.category, RuntimeWarning)]
     assert len(msgs) == 3 and all('PyTorch-op form' in m for m in msgs), msgs
     assert 'density_noise' in msgs[0] and 'rays need a gradient' in msgs[1] and 'OSGDecoder' in msgs[2]
+
+
+# ---- in-kernel rays and uniform draws (gnerf_render_params ABI 8; SURVEY section 8a row 1, 8d "in-kernel Philox") -------------------
+
+_RAND_CASES = [(0, (7,)), (123, (1000,)), (5, (4, 16384, 48, 1)), (5, (65536, 48)), (2 ** 40 + 17, (3, 333, 12)), (9, (1, 4096, 96, 1)), (11, (524288 + 3,))]
+
+
+def test_philox_restatement_matches_torch_rand(dev):
+    """oracle/philox_ref.py -- ATen's uniform kernel over Philox4x32-10, restated in numpy -- against the device generator itself:
+    every element of two consecutive torch.rand draws, and the generator's offset after each.  This is the pin of the restatement
+    (a device generator only exists on the GPU box); the in-kernel draws are then held to both."""
+    from oracle import philox_ref as P
+    pr = torch.cuda.get_device_properties(dev)
+    mp, mt = pr.multi_processor_count, pr.max_threads_per_multi_processor
+    gen = torch.cuda.default_generators[dev.index]
+    for seed, shape in _RAND_CASES:
+        torch.manual_seed(seed)
+        o0 = gen.get_offset()
+        a = torch.rand(shape, device=dev)
+        o1 = gen.get_offset()
+        b = torch.rand(shape, device=dev)
+        o2 = gen.get_offset()
+        n = a.numel()
+        wa, p1 = P.torch_rand(n, gen.initial_seed(), o0, mp, mt)
+        wb, p2 = P.torch_rand(n, gen.initial_seed(), o1, mp, mt)
+        assert (p1, p2) == (o1, o2), (seed, shape, (o0, o1, o2), (p1, p2))
+        assert np.array_equal(a.cpu().numpy().reshape(-1), wa) and np.array_equal(b.cpu().numpy().reshape(-1), wb), (seed, shape)
+
+
+def test_native_torch_rand_matches_torch_rand(dev):
+    """gnerf_torch_rand (the render kernels' draw function as a stand-alone kernel) == torch.rand bit for bit at the same generator
+    state, and gnerf_torch_rand_plan predicts the offset torch leaves behind."""
+    import gnerf_hip
+    gen = torch.cuda.default_generators[dev.index]
+    for seed, shape in _RAND_CASES:
+        n = int(np.prod(shape))
+        for skip in (0, 3):                                     # ... also from a generator that has been used before
+            torch.manual_seed(seed)
+            for _ in range(skip):
+                torch.rand(1000, device=dev)
+            o0 = gen.get_offset()
+            mine = gnerf_hip.torch_rand(n, dev, gen.initial_seed(), o0)
+            assert gen.get_offset() == o0                       # the native draw does not touch the generator
+            theirs = torch.rand(shape, device=dev)
+            assert torch.equal(mine, theirs.reshape(-1)), (seed, shape, skip)
+            assert gen.get_offset() == o0 + gnerf_hip.torch_rand_geometry(n, dev)[1]
+            assert float(mine.min()) >= 0.0 and float(mine.max()) < 1.0
+
+
+@pytest.mark.parametrize('S', [48, 96])
+def test_render_with_inkernel_rays_and_draws(dev, S):
+    """The render kernel making its rays (from the cameras) and its two uniform draws (torch's Philox stream) itself: outputs equal
+    the tensor forms' bit for bit -- rays only, draws only, both -- and the generator ends where the two torch.rand calls leave it."""
+    import gnerf_hip
+    from oracle import render_ref as R
+    N, res = 3, 12
+    g = torch.Generator().manual_seed(21)
+    planes = (torch.randn(N, 3, 32, 24, 20, generator=g) * 1.5).to(dev)
+    dec = [t.to(dev) for t in R.fold_decoder(torch.randn(64, 32, generator=g), torch.randn(64, generator=g) * 0.2,
+                                             torch.randn(33, 64, generator=g), torch.randn(33, generator=g) * 0.2)]
+    c2w = torch.cat([R.lookat_pose(3.14 / 2 + 0.4 * i, 3.14 / 2 - 0.1 * i, 2.7) for i in range(N)]).to(dev)
+    intr = torch.tensor([[4.2647, 0.01, 0.5], [0, 4.1, 0.49], [0, 0, 1]]).repeat(N, 1, 1).to(dev)        # skew and unequal focal lengths on purpose
+    nhwc = gnerf_hip.planes_to_nhwc(planes)
+    kw = dict(depth_resolution=S, depth_resolution_importance=S, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=res)
+    gen = torch.cuda.default_generators[dev.index]
+    assert gnerf_hip.render_generated_supported(S, S)
+    o, d = gnerf_hip.make_rays(c2w, intr, res)
+    for mlp in ('auto', 'f32'):
+        torch.manual_seed(77)
+        torch.rand(5, device=dev)                                   # a generator that is not at offset 0
+        nc = torch.rand([N, res * res, S, 1], device=dev)
+        nf = torch.rand(N * res * res, S, device=dev)
+        end = gen.get_offset()
+        want = gnerf_hip.render_forward(nhwc, N, dec, o, d, nc, nf, mlp=mlp, **kw)
+        # rays in the kernel, draws as tensors
+        got = gnerf_hip.render_forward(nhwc, N, dec, None, None, nc, nf, mlp=mlp, cameras=(c2w, intr, res), **kw)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), ('rays', mlp)
+        # draws in the kernel (generator put back where the tensor draws started), rays as tensors -- then both
+        for cams in (None, (c2w, intr, res)):
+            torch.manual_seed(77)
+            torch.rand(5, device=dev)
+            plan = gnerf_hip.torch_philox_plan(dev, N, res * res, S, S)
+            assert gen.get_offset() == end == plan.end_offset
+            got = gnerf_hip.render_forward(nhwc, N, dec, None if cams else o, None if cams else d, None, None, mlp=mlp, cameras=cams, rng=plan, **kw)
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), ('draws', cams is not None, mlp)
+    # per-item draws: what N calls of one item each would draw (the batched-views form of an orbit), one shared set of planes
+    one = gnerf_hip.planes_to_nhwc(planes[:1])
+    torch.manual_seed(78)
+    draws = [(torch.rand([1, res * res, S, 1], device=dev), torch.rand(res * res, S, device=dev)) for _ in range(N)]
+    end = gen.get_offset()
+    want = gnerf_hip.render_forward(one, N, dec, o, d, torch.cat([c for c, _ in draws]), torch.cat([f for _, f in draws]),
+                                    planes_shared=True, depth_clamp_per_item=True, **kw)
+    torch.manual_seed(78)
+    plan = gnerf_hip.torch_philox_plan(dev, N, res * res, S, S, per_item=True)
+    assert gen.get_offset() == end
+    got = gnerf_hip.render_forward(one, N, dec, None, None, None, None, planes_shared=True, depth_clamp_per_item=True, cameras=(c2w, intr, res), rng=plan, **kw)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b), 'per-item draws'
+    # shapes the generating instantiations are not built for are refused (the caller passes tensors), never rendered differently
+    with pytest.raises(RuntimeError):
+        gnerf_hip.render_forward(nhwc, N, dec, None, None, None, None, cameras=(c2w, intr, res), rng=gnerf_hip.torch_philox_plan(dev, N, res * res, 40, 40, advance=False),
+                                 **dict(kw, depth_resolution=40, depth_resolution_importance=40))
 
 
 def test_views_of_one_item_equal_separate_calls(dev):

@@ -183,3 +183,32 @@ def test_grid_sample_oracle_matches_torch():
     grid = torch.rand(2, 5, 6, 2, generator=g) * 2.6 - 1.3
     want = torch.nn.functional.grid_sample(img, grid, mode='bilinear', padding_mode='zeros', align_corners=False).numpy()
     np.testing.assert_allclose(O.grid_sample_2d(img.numpy(), grid.numpy()), want, rtol=1e-5, atol=1e-6)
+
+
+def test_philox_known_answers():
+    """oracle/philox_ref.philox4x32_10 against the Random123 known-answer vectors of Philox4x32-10 (Salmon et al., kat_vectors:
+    counter / key all zero, all ones, and the digits of pi) -- the generator under torch's device uniform draws."""
+    from oracle import philox_ref as P
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = P.philox4x32_10(*[np.array([c]) for c in ctr], *key)
+        assert tuple(int(g[0]) for g in got) == want
+    # the uniform mapping: (0, 1] from the bits, 1 sent back to 0; never negative, never 1
+    u = P.uniform_from_bits(np.array([0, 1, 2 ** 31, 2 ** 32 - 1, 2 ** 32 - 200], dtype=np.uint32))
+    assert u[0] == np.float32(2.0 ** -32) and u[3] == 0.0 and 0.0 <= u.min() and u.max() < 1.0
+
+
+def test_torch_rand_plan_matches_restatement():
+    """gnerf_torch_rand_plan (host arithmetic of the C ABI, no GPU) == oracle/philox_ref's launch geometry of ATen's uniform kernel."""
+    import ctypes
+    import gnerf_hip
+    from oracle import philox_ref as P
+    lib = gnerf_hip.load()
+    for numel in (1, 255, 256, 257, 4096, 2 ** 19, 2 ** 19 + 1, 4 * 16384 * 48, 65536 * 96, 10 ** 8):
+        for mp, mt in ((256, 2048), (304, 2048), (120, 2560), (1, 256)):
+            thr, inc = ctypes.c_uint32(0), ctypes.c_uint64(0)
+            assert lib.gnerf_torch_rand_plan(numel, mp, mt, ctypes.byref(thr), ctypes.byref(inc)) == 0
+            g = P.grid_threads(numel, mp, mt)
+            assert (thr.value, inc.value) == (g, P.offset_increment(numel, g)), (numel, mp, mt)
