@@ -733,7 +733,7 @@ __device__ __forceinline__ int choose_mlp(const Params& P, float* smem) {
                             && mb2 <= kMlpRangeLimit && e_o <= kMlpErrLimit;         // every comparison is false for NaN
             const int choice = ok ? 1 : 2;                                           // kMlpF16x3 : kMlpF32
             reinterpret_cast<int*>(smem)[0] = choice;
-            if (blockIdx.x == 0) static_cast<int*>(p.workspace)[4] = choice;         // diagnostics (gnerf_hip.last_mlp_choice)
+            if (blockIdx.x == 0 && p.workspace) static_cast<int*>(p.workspace)[4] = choice;         // diagnostics (gnerf_hip.last_mlp_choice)
         }
     }
     __syncthreads();
@@ -1010,9 +1010,58 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
     bool staged = g->scatter_stage != nullptr && g->grad_planes_nhwc != nullptr && tiles_ok;
     if (route && !strcmp(route, "direct")) staged = false;
     if (route && !strcmp(route, "staged") && !staged) return fail(GNERF_E_ARG, "render_backward: the staged scatter needs scatter_stage, a plane gradient and whole tiles per item");
+    // Pipelined path of the staged form (round 4): the ray-level part on the forward pipeline (render_kernel_pipe_bwd), the per-sample
+    // part as a kernel over sample tiles (render_bwd_tiles_kernel).  Shapes the pipelined kernels cover; GNERF_BWD_KERNEL=wave keeps the
+    // one-wave-per-ray kernel (A/B runs and the tests' cross-check).
+    const char* bwd_kernel = getenv("GNERF_BWD_KERNEL");
+    const bool small_planes = int64_t(p->plane_h) * p->plane_w * 3 * 128 < (int64_t(1) << 32);
+    const bool piped = staged && P.tiles_c <= 9 && P.tiles_f >= 1 && P.tiles_f <= 9 && small_planes && !(bwd_kernel && !strcmp(bwd_kernel, "wave"));
+    if (piped) {
+        hipStream_t s = as_stream(stream);
+        const int64_t total = P.total_rays;
+        const int n_all = p->depth_resolution + p->depth_resolution_importance;
+        // decoder arithmetic of the first pass: chosen on the device from max |planes| like the forward's (measured here into the
+        // 256 bytes behind the staged rows when the caller has none)
+        P.absmax = p->planes_absmax;
+        if (!P.absmax) {
+            float* own = g->scatter_stage + size_t(total) * n_all * 33;
+            if (int e = gnerf_planes_absmax(p->planes_nhwc, int64_t(p->n_items) * 3 * p->plane_h * p->plane_w * 32, own, stream)) return e;
+            P.absmax = own;
+        }
+        P.p.workspace = nullptr;                                   // (the backward's params carry no workspace)
+        P.p.mlp_mode = GNERF_MLP_AUTO;
+        const int pipe_tp = (P.tiles_c <= 3 && P.tiles_f <= 3) ? 1 : ((P.tiles_c <= 6 && P.tiles_f <= 6) ? 2 : 3);
+        const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : total;
+        const int per_cu = pipe_tp == 1 ? GNERF_PIPE_WAVES_PER_SIMD : (pipe_tp == 2 ? GNERF_PIPE2_WAVES_PER_SIMD : 2);
+        const int64_t capacity = int64_t(per_cu) * kNumCU;
+        P.pipe_unit = kPipeUnit;
+        if (total_seq < capacity * kPipeUnit) P.pipe_unit = int((total_seq + capacity - 1) / capacity);
+        int64_t gsz = ((total_seq + P.pipe_unit - 1) / P.pipe_unit + kNumXCD - 1) / kNumXCD * kNumXCD;
+        if (gsz < kNumXCD) gsz = kNumXCD;
+        if (gsz > capacity) gsz = capacity;
+        const size_t lds1 = pipe_lds_floats(pipe_tp, kMlpAuto) * sizeof(float);
+        if (pipe_tp == 1) hipLaunchKernelGGL(render_kernel_pipe_bwd<1>, dim3((unsigned)gsz), dim3(kPipeThreads), lds1, s, P, *g, g->scatter_stage);
+        else if (pipe_tp == 2) hipLaunchKernelGGL(render_kernel_pipe_bwd<2>, dim3((unsigned)gsz), dim3(kPipeThreads), lds1, s, P, *g, g->scatter_stage);
+        else {
+            static PerDeviceOnce once3;
+            if (int e = once3.raise_lds(render_kernel_pipe_bwd<3>, "render_backward")) return e;
+            hipLaunchKernelGGL(render_kernel_pipe_bwd<3>, dim3((unsigned)gsz), dim3(kPipeThreads), lds1, s, P, *g, g->scatter_stage);
+        }
+        if (int e = check_launch("render_kernel_pipe_bwd")) return e;
+        const size_t lds2 = (kBwdWeightFloats + kBwdWaves * bwd_tiles_wave_floats()) * sizeof(float);
+        static PerDeviceOnce once_tiles;
+        if (int e = once_tiles.raise_lds(render_bwd_tiles_kernel, "render_backward")) return e;
+        const int64_t sample_tiles = total_seq * ((n_all + 15) / 16);
+        int64_t g2 = (sample_tiles + kBwdWaves - 1) / kBwdWaves;
+        if (g2 > int64_t(kNumCU) * 2) g2 = int64_t(kNumCU) * 2;    // two workgroups of four waves per CU, each walking a contiguous run of tiles
+        g2 = (g2 + kNumXCD - 1) / kNumXCD * kNumXCD;
+        hipLaunchKernelGGL(render_bwd_tiles_kernel, dim3((unsigned)g2), dim3(kBwdThreads), lds2, s, P, *g, g->scatter_stage);
+        if (int e = check_launch("render_bwd_tiles_kernel")) return e;
+    } else {
     if (staged) hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(per_xcd * kNumXCD), dim3(kBwdThreads), lds_bytes, as_stream(stream), P, *g, g->scatter_stage);
     else        hipLaunchKernelGGL(render_bwd_kernel<false>, dim3(per_xcd * kNumXCD), dim3(kBwdThreads), lds_bytes, as_stream(stream), P, *g, static_cast<float*>(nullptr));
     if (int e = check_launch("render_bwd_kernel")) return e;
+    }
     if (staged) {
         static PerDeviceOnce once_scatter;
         if (int e = once_scatter.raise_lds(plane_scatter_kernel, "render_backward")) return e;
@@ -1026,7 +1075,7 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
 extern "C" size_t gnerf_render_backward_stage_bytes(const gnerf_render_params* p) {
     if (!p || p->n_items < 1 || p->rays_per_item < 1) return 0;
     const size_t n_all = size_t(p->depth_resolution) + size_t(p->depth_resolution_importance);
-    return size_t(p->n_items) * size_t(p->rays_per_item) * n_all * 33 * sizeof(float);
+    return size_t(p->n_items) * size_t(p->rays_per_item) * n_all * 33 * sizeof(float) + 256;      // (+ a spare line: max |planes| when the caller has none)
 }
 
 extern "C" int gnerf_query_points(const float* planes_nhwc, int n_items, int plane_h, int plane_w,

@@ -38,14 +38,6 @@ struct BwdLds {
     float* stage; float* tbuf; float* hbuf; float* taps;
 };
 
-// Sum over the 16 lanes of a DPP row; valid in lanes with (lane & 15) == 15.
-__device__ __forceinline__ float row_total(float v) {
-    v += dpp_mov<0x111, 0xf>(0.f, v);
-    v += dpp_mov<0x112, 0xf>(0.f, v);
-    v += dpp_mov<0x114, 0xf>(0.f, v);
-    v += dpp_mov<0x118, 0xf>(0.f, v);
-    return v;
-}
 
 #ifdef GNERF_ABLATE_ATOMIC       // timing-only build: plain stores instead of atomics (wrong results)
 #define GNERF_SCATTER_ADD(ptr, val) (*(ptr) = (val))
@@ -565,6 +557,112 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gn
         }
     }
 
+    bwd_reduce_decoder_grads(A, smem, Gr.grad_w1, Gr.grad_b1, Gr.grad_w2, Gr.grad_b2, tid, lane, j);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Second kernel of the staged backward on the pipelined path (round 4).  render_kernel_pipe_bwd (render_pipe.inl) has run the ray-level
+// part -- forward pipeline, merge, composite gradient -- at the forward kernel's speed and left, per ray and in depth order, the sample
+// depths, colour weights v_r and dL/dsigma_r in the staging buffer.  What is left is work per SAMPLE TILE with no ray-level state at all:
+// lookup + decoder forward (exact fp32) + the four gradient products + dX rows.  One wave per 16-rank tile, tiles dealt in contiguous
+// runs of the locality-ordered ray sequence; the dX rows of a tile are 2 KB of contiguous staging memory (the one-wave-per-ray kernel
+// above writes them rank by rank behind a second forward recomputation, with 12 per-sample arrays per wave in LDS).
+struct DepthListPos {
+    const BwdRay& R; const float* dep; float box_scale;
+    __device__ __forceinline__ void operator()(int j, float& px, float& py, float& pz) const {
+        const float depth = dep[j];
+        px = __fadd_rn(R.ox, __fmul_rn(depth, R.dx)) * box_scale;
+        py = __fadd_rn(R.oy, __fmul_rn(depth, R.dy)) * box_scale;
+        pz = __fadd_rn(R.oz, __fmul_rn(depth, R.dz)) * box_scale;
+    }
+};
+
+__host__ __device__ inline size_t bwd_tiles_wave_floats() { return 16 * kStagePitch + 16 * kTPitch + 16 * kHPitch + 48; }
+
+__global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_tiles_kernel(Params P, gnerf_render_grads Gr, float* stage) {
+    extern __shared__ __align__(16) float smem[];
+    const gnerf_render_params& p = P.p;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n_all = p.depth_resolution + p.depth_resolution_importance;
+    float* w1 = smem;
+    float* w2 = w1 + 64 * kW1Pitch;
+    float* b1 = w2 + 33 * kW2Pitch;
+    float* b2 = b1 + 64;
+    for (int i = tid; i < 64 * 32; i += kBwdThreads) w1[(i >> 5) * kW1Pitch + (i & 31)] = p.w1[i];
+    for (int i = tid; i < 33 * 64; i += kBwdThreads) w2[(i >> 6) * kW2Pitch + (i & 63)] = p.w2[i];
+    if (tid < 64) b1[tid] = p.b1[tid];
+    if (tid < 36) b2[tid] = tid < 33 ? p.b2[tid] : 0.f;
+    __syncthreads();
+    BwdLds L = {};
+    L.w1 = w1; L.w2 = w2; L.b1 = b1; L.b2 = b2;
+    float* base = smem + kBwdWeightFloats + size_t(wv) * bwd_tiles_wave_floats();
+    L.stage = base; L.tbuf = L.stage + 16 * kStagePitch; L.hbuf = L.tbuf + 16 * kTPitch;
+    float* dep = L.hbuf + 16 * kHPitch;            // [16] depths, [16] colour weights, [16] dL/dsigma of the tile
+    float* vw = dep + 16;
+    float* dsg = vw + 16;
+    BwdAcc A;
+#pragma unroll
+    for (int m = 0; m < 4; m++) A.w1[m][0] = A.w1[m][1] = A.w2[0][m] = A.w2[1][m] = A.w2s[m] = A.b1[m] = (v4f){0.f, 0.f, 0.f, 0.f};
+    A.b2[0] = A.b2[1] = A.b2s = 0.f;
+    BwdPending pend = {nullptr, 0};
+    const int j = lane & 15, g = lane >> 4;
+    const int64_t plane_floats = int64_t(3) * p.plane_h * p.plane_w * 32;
+    // tiles of the locality-ordered ray sequence (pipe_seq_to_ray): XCD x owns a contiguous eighth (workgroups b, b+8, ... share an
+    // XCD), cut into equal contiguous runs for the XCD's waves
+    const int tiles_per_ray = (n_all + 15) >> 4;
+    const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : int64_t(P.total_rays);
+    const int xcd = blockIdx.x % kNumXCD, wg = blockIdx.x / kNumXCD, wgs = gridDim.x / kNumXCD;
+    const int64_t x0 = total_seq * xcd / kNumXCD * tiles_per_ray, x1 = total_seq * (xcd + 1) / kNumXCD * tiles_per_ray;
+    const int64_t waves = int64_t(wgs) * kBwdWaves, me = int64_t(wg) * kBwdWaves + wv;
+    const int64_t t0 = x0 + (x1 - x0) * me / waves, t1 = x0 + (x1 - x0) * (me + 1) / waves;
+    for (int64_t t = t0; t < t1; t++) {
+        const int64_t seq = t / tiles_per_ray;
+        const int T = int(t - seq * tiles_per_ray);
+        const int ray = pipe_seq_to_ray(P, seq);
+        if (ray < 0) continue;
+        const int item = ray / p.rays_per_item;
+        const int live = min(16, n_all - 16 * T);
+        float* const ray_block = stage + int64_t(ray) * n_all * 33;
+        float* const rows = ray_block + n_all + T * 512;
+        if (lane < 16) dep[lane] = ray_block[16 * T + min(lane, live - 1)];
+        else if (lane < 48) dep[lane] = ((lane & 15) < live) ? rows[lane - 16] : 0.f;       // vw[0..15], dsg[0..15]
+        BwdRay R;
+        R.ox = p.ray_origins[int64_t(ray) * 3 + 0]; R.oy = p.ray_origins[int64_t(ray) * 3 + 1]; R.oz = p.ray_origins[int64_t(ray) * 3 + 2];
+        R.dx = p.ray_dirs[int64_t(ray) * 3 + 0]; R.dy = p.ray_dirs[int64_t(ray) * 3 + 1]; R.dz = p.ray_dirs[int64_t(ray) * 3 + 2];
+        R.planes = reinterpret_cast<const char*>(p.planes_nhwc + int64_t(item) * plane_floats);
+        float G[2];
+        G[0] = Gr.grad_rgb ? 2.f * Gr.grad_rgb[int64_t(ray) * 32 + j] : 0.f;
+        G[1] = Gr.grad_rgb ? 2.f * Gr.grad_rgb[int64_t(ray) * 32 + 16 + j] : 0.f;
+        lds_wave_sync();
+        bwd_gather_tile<false, DepthListPos, false>(P, L, R.planes, DepthListPos{R, dep, P.box_scale}, pend, lane);
+        v4f h[4], o[2];
+        float sig;
+        bwd_mlp_forward(L, lane, h, o, sig);
+        // ---- dO: colour c = 1.002 * s - 0.001 with s = sigmoid(o); dL/dc = G * v_sample  (triplane.py:134, ray_marcher.py:27-45)
+        const v4f vs = *reinterpret_cast<const v4f*>(vw + 4 * g);
+        const float dsig = dsg[j];
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float e = __builtin_amdgcn_exp2f(o[n][r] * -1.44269504088896341f);
+                const float s = __builtin_amdgcn_rcpf(1.0f + e);
+                const float d = G[n] * vs[r] * (1.002f * s * (1.f - s));
+                L.tbuf[(4 * g + r) * kTPitch + 16 * n + j] = d;
+                A.b2[n] += d;
+            }
+        }
+        bwd_tile_core(L, h, dsig, A, lane);
+        if (Gr.grad_planes_nhwc) {                                  // the tile's dX rows: 16 x 128 contiguous bytes
+            const int half = lane >> 5, ch = lane & 31;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int smp = 2 * q + half;
+                if (smp < live) rows[smp * 32 + ch] = L.tbuf[smp * kTPitch + ch];
+            }
+        }
+        lds_wave_sync();
+    }
     bwd_reduce_decoder_grads(A, smem, Gr.grad_w1, Gr.grad_b1, Gr.grad_w2, Gr.grad_b2, tid, lane, j);
 }
 

@@ -231,6 +231,15 @@ __device__ __forceinline__ float row_sum4(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// Sum over the 16 lanes of a DPP row; valid in lanes with (lane & 15) == 15.
+__device__ __forceinline__ float row_total(float v) {
+    v += dpp_mov<0x111, 0xf>(0.f, v);
+    v += dpp_mov<0x112, 0xf>(0.f, v);
+    v += dpp_mov<0x114, 0xf>(0.f, v);
+    v += dpp_mov<0x118, 0xf>(0.f, v);
+    return v;
+}
+
 struct CoopRay {
     const char* planes_item;    // uniform
     float ox, oy, oz, dx, dy, dz;

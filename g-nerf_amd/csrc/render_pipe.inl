@@ -98,8 +98,13 @@ __device__ __forceinline__ int pipe_seq_to_ray(const Params& P, int64_t seq) {
 // made them (raygen.h).  Both run on the scalar wave, whose SIMD is the half-idle one: a ray's 96 draws are two
 // wave-wide Philox evaluations (~100 integer instructions each) in place of two loads, its direction is computed for a whole dealing
 // unit at a time (one lane per ray of the unit, parked in 256 bytes of LDS).
-template <int TP, int MLP, bool FULL, bool GEN>
-__device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
+// BWD: the first pass of the renderer's backward (gnerf_render_backward, staged form) -- the same forward pipeline, but instead of
+// compositing colours it hands the backward's second kernel (render_bwd_tiles_kernel, render_bwd.inl) what it needs per sample, in
+// the ray's merged depth order: the depth, the colour weight v_r and dL/dsigma_r.  Shader waves reduce each sample's colours to
+// q = sum_c dL/dcolour[c] colour[c] (all the composite's gradient needs of them); the scalar wave runs the composite's gradient
+// (ray_marcher.py:25-57 backwards) as wave scans right after the merge.  Nothing else of the ray is kept.
+template <int TP, int MLP, bool FULL, bool GEN, bool BWD = false>
+__device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, const gnerf_render_grads* Gr = nullptr, float* bstage = nullptr) {
     typedef PipeDims<TP> D;
     constexpr int kPipeMaxS = D::kMaxS, kPipeSPad = D::kSPad, kSlotFloats = D::kSlotFloats, RND = D::kRounds;
     const gnerf_render_params& p = P.p;
@@ -123,7 +128,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
 #endif
     const int S = FULL ? kPipeMaxS : p.depth_resolution, F = FULL ? kPipeMaxS : p.depth_resolution_importance;
     const int tiles_c = FULL ? 3 * TP : P.tiles_c, tiles_f = FULL ? 3 * TP : P.tiles_f;
-    float* const debug = FULL ? nullptr : GNERF_DBG_PTR(p.debug);
+    float* const debug = (FULL || BWD) ? nullptr : GNERF_DBG_PTR(p.debug);       // (the backward's params carry no debug buffer)
     // fixed slot layout: coarse samples at [0,48), fine samples at [48,96); unused entries hold +inf depths so that the
     // fully unrolled 4-wide key scans below need no bounds checks
     constexpr int fine_e0 = kPipeMaxS, s_pad = kPipeSPad;
@@ -162,6 +167,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
     // ------------------------------------------------------------------ scalar-wave pieces (lambdas, wave 3 only)
     DepthRange range;
     float pre_uc[RND] = {}, pre_uf[RND] = {}, pre_ray = 0.f, pre_rs = 0.f, pre_re = 0.f;       // prefetched by propose_issue
+    float pre_g = 0.f;                                                                         // BWD: dL/d(colour sum) [0..31], dL/ddepth [32], dL/dwsum [33]
     int pre_ray_id = -1;
 
     float* const unit_rays = L.taps + 3 * 16 * kStagePitch;        // GEN: [kPipeUnit][8] origin, direction of the current dealing unit's rays
@@ -210,6 +216,12 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
             else if (lane < 6) pre_ray = p.ray_dirs[ray * 3 + lane - 3];
         }
         if (!FULL && p.ray_start_per_ray) { pre_rs = p.ray_start_per_ray[ray]; pre_re = p.ray_end_per_ray[ray]; }
+        if constexpr (BWD) {        // the ray's incoming gradients: rgb = 2 * composite - 1 (ray_marcher.py:55), depth, weight sum
+            pre_g = 0.f;
+            if (lane < 32) { if (Gr->grad_rgb) pre_g = 2.f * Gr->grad_rgb[ray * 32 + lane]; }
+            else if (lane == 32) { if (Gr->grad_depth) pre_g = Gr->grad_depth[ray]; }
+            else if (lane == 33) { if (Gr->grad_wsum) pre_g = Gr->grad_wsum[ray]; }
+        }
     };
     auto propose_finish = [&](int r) {          // P(r), second half: depth proposals (renderer.py:169-192) into the slot
         if (r < 0 || r >= nr) return;
@@ -246,6 +258,10 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
             if (lane + 64 * q < F) sl.nf[lane + 64 * q] = pre_uf[q];
         if (lane < 6) sl.misc[lane] = pre_ray;
         if (lane == 6) sl.misc[6] = __int_as_float(pre_ray_id / p.rays_per_item);
+        if constexpr (BWD) {
+            if (lane < 32) sl.part[lane] = pre_g;
+            else if (lane < 34) sl.misc[10 + lane - 32] = pre_g;
+        }
         for (int e = lane; e < s_pad; e += 64) {
             sl.v_e[e] = 0.f;
             if ((e >= S && e < fine_e0) || e >= fine_e0 + F) sl.t_e[e] = INFINITY;      // tile padding sorts last
@@ -342,6 +358,15 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
         // an owner table and repaired by a tie-broken recount (rare: needs two equal uniform draws or rounding collisions).
         int rank_f[RND], rank_c[RND];
         float key_f[RND], key_c[RND];
+        float q_c[RND] = {}, q_f[RND] = {};           // BWD: this lane's samples' q, read before v_e is reused below
+        if constexpr (BWD) {
+#pragma unroll
+            for (int q = 0; q < RND; q++) {
+                const int i = lane + 64 * q;
+                if (i < S) q_c[q] = sl.v_e[i];
+                if (i < F) q_f[q] = sl.v_e[fine_e0 + i];
+            }
+        }
 #pragma unroll
         for (int q = 0; q < RND; q++) {
             const int i = lane + 64 * q;
@@ -418,9 +443,91 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
             const int i = lane + 64 * q;
             if (i < F) { sl.s_t[rank_f[q]] = key_f[q]; sl.s_sig[rank_f[q]] = sl.sig_e[fine_e0 + i]; }
             if (i < S) { sl.s_t[rank_c[q]] = key_c[q]; sl.s_sig[rank_c[q]] = sl.sig_e[i]; }
+            if constexpr (BWD) {                // q in depth order; the histogram (cdf) and the fine noise behind it are dead: 2 kMaxS floats
+                if (i < F) sl.cdf[rank_f[q]] = q_f[q];
+                if (i < S) sl.cdf[rank_c[q]] = q_c[q];
+            }
         }
         lds_wave_sync();
         GNERF_STAMP(st, 13);    // merge ranks
+        if constexpr (BWD) {
+            // ---- final march keeping the transmittance in front of every interval (ray_marcher.py:26-42), then the composite's gradient
+            // (the arithmetic of render_bwd_kernel, render_bwd.inl).  Per-interval arrays go to this slot's dead element arrays:
+            // trans -> t_e, dL/d(interval density input) -> sig_e; the weights to w_s as in the forward.
+            const int n_int = n_all - 1;
+            float* const s_q = sl.cdf;
+            float* const trans = sl.t_e;
+            float* const ds = sl.sig_e;
+            float w_sum, wt_sum;
+            {
+                float carry = 1.f, acc_w = 0.f, acc_wt = 0.f;
+                for (int kb = 0; kb < n_int; kb += 64) {
+                    const int k = kb + lane;
+                    const bool ok = k < n_int;
+                    float alpha = 0.f, tmid = 0.f;
+                    if (ok) {
+                        const float t0 = sl.s_t[k], t1 = sl.s_t[k + 1];
+                        const float smid = softplus_march((sl.s_sig[k] + sl.s_sig[k + 1]) * 0.5f - 1.f);
+                        tmid = (t0 + t1) * 0.5f;
+                        alpha = 1.f - exp_hw(-(smid * (t1 - t0)));
+                    }
+                    const float x = ok ? (1.f - alpha + 1e-10f) : 1.f;
+                    const float incl = wave_scan_mul(x, lane);
+                    const float tr = wave_shift_up(incl, 1.f) * carry;
+                    carry *= wave_last(incl);
+                    if (ok) { const float wk = alpha * tr; sl.w_s[k] = wk; trans[k] = tr; acc_w += wk; acc_wt += wk * tmid; }
+                }
+                w_sum = wave_sum(acc_w);
+                wt_sum = wave_sum(acc_wt);
+            }
+            lds_wave_sync();
+            //   dL/dw_k = (q_k + q_{k+1}) / 2 - [white_back] sum_c G[c] + g_depth (tmid_k - depth) / W + g_wsum
+            //   dL/dalpha_k = dL/dw_k T_k - (sum_{m>k} dL/dw_m w_m) / (1 - alpha_k + 1e-10)
+            const float g_depth = sl.misc[10], g_wsum = sl.misc[11];
+            const float g_sum = p.white_back ? wave_sum(lane < 32 ? sl.part[lane] : 0.f) : 0.f;
+            const float depth = wt_sum / w_sum;
+            const float gd_scale = (w_sum > 0.f && depth == depth) ? g_depth / w_sum : 0.f;     // nan_to_num'd rays pass no depth gradient
+            const float gw_const = g_wsum - g_sum;
+            float carry = 0.f;
+            for (int kb = 0; kb < n_int; kb += 64) {               // from the far end: suffix sums are prefix sums here
+                const int k = n_int - 1 - (kb + lane);
+                const bool ok = k >= 0;
+                float gw = 0.f, wk = 0.f, t0 = 0.f, t1 = 0.f, smid_in = 0.f;
+                if (ok) {
+                    t0 = sl.s_t[k]; t1 = sl.s_t[k + 1];
+                    smid_in = (sl.s_sig[k] + sl.s_sig[k + 1]) * 0.5f - 1.f;
+                    wk = sl.w_s[k];
+                    gw = (s_q[k] + s_q[k + 1]) * 0.5f + gw_const + gd_scale * ((t0 + t1) * 0.5f - depth);
+                }
+                const float incl = wave_scan_add(gw * wk, lane) + carry;
+                carry = wave_last(incl);
+                if (ok) {
+                    const float after = incl - gw * wk;                      // sum over m > k
+                    const float delta = t1 - t0;
+                    const float dens = softplus_march(smid_in);
+                    const float one_minus_alpha = exp_hw(-(dens * delta));
+                    const float alpha = 1.f - one_minus_alpha;
+                    const float d_alpha = gw * trans[k] - after / (1.f - alpha + 1e-10f);
+                    const float d_dens = d_alpha * delta * one_minus_alpha;
+                    const float e = exp_hw(-smid_in);
+                    ds[k] = smid_in > 20.f ? d_dens : d_dens * __builtin_amdgcn_rcpf(1.f + e);      // softplus' = sigmoid
+                }
+            }
+            lds_wave_sync();
+            // ---- per sample, in depth order: depth, colour weight, dL/dsigma -> the staging buffer.  Depths at the head of the ray's
+            // block (where plane_scatter_kernel reads them); v and dL/dsigma of the 16 ranks of tile T in the first 32 floats of the
+            // tile's own dX rows, which render_bwd_tiles_kernel reads before it overwrites them with dX.
+            float* const ray_block = bstage + int64_t(ray_id) * n_all * 33;
+            for (int r = lane; r < n_all; r += 64) {
+                const float wl = r > 0 ? sl.w_s[r - 1] : 0.f, wr = r < n_int ? sl.w_s[r] : 0.f;
+                const float dl = r > 0 ? ds[r - 1] : 0.f, dr = r < n_int ? ds[r] : 0.f;
+                ray_block[r] = sl.s_t[r];
+                float* tile_rows = ray_block + n_all + (r >> 4) * 512;
+                tile_rows[r & 15] = (wl + wr) * 0.5f;            // colour of sample r enters intervals r-1 and r with weight 1/2 each
+                tile_rows[16 + (r & 15)] = (dl + dr) * 0.5f;     // so does its density
+            }
+            return;
+        }
         float ws, wts;
         march(sl.s_t, sl.s_sig, sl.w_s, n_all, lane, ws, wts);
         lds_wave_sync();
@@ -512,6 +619,23 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
         if (g < 2) sl.part[wv * 32 + 16 * g + j] = g == 0 ? acc[0] : acc[1];
     };
 
+    auto emit_q = [&](int r, bool fine, const v4f (&col)[TP][2]) {        // BWD: q = sum_c G[c] colour[c] of the samples just shaded -> v_e
+        if (r < 0 || r >= nr) return;
+        PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
+        if (__float_as_int(sl.misc[7]) < 0) return;
+        const int j = lane & 15, g = lane >> 4;
+        const float G0 = sl.part[j], G1 = sl.part[16 + j];
+#pragma unroll
+        for (int i = 0; i < TP; i++) {
+            const int tile = wv + 3 * i;
+            if (tile >= (fine ? tiles_f : tiles_c)) continue;
+            v4f q;
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[k] = row_total(G0 * col[i][0][k] + G1 * col[i][1][k]);
+            if (j == 15) *reinterpret_cast<v4f*>(sl.v_e + (fine ? fine_e0 : 0) + 16 * tile + 4 * g) = q;
+        }
+    };
+
     // ------------------------------------------------------------------ the pipeline
     // The scalar wave is one instruction stream against three, shares its SIMD's issue port with MFMA-heavy shader
     // waves, and every step ends when it does: give it issue priority (costs the shaders little, it is mostly waiting
@@ -529,6 +653,29 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem) {
     // precedes it, with depth proposals one ray earlier and five ray slots, so that the L2 round trip runs under the barrier
     // wait -- 0.617 ms: the two other waves of the SIMD already cover that latency, and the loads' registers are then live across
     // the barrier; its first version spilled two of the loaded vectors, i.e. waited for them on the spot: 0.71 ms.)
+    if constexpr (BWD) {
+        if (wv < 3) {
+            v4f cc[TP][2] = {}, cf[TP][2] = {};
+            for (int k = -1; k <= nr + 1; k++) {
+                shade(k + 1, false, cc);
+                emit_q(k + 1, false, cc);
+                __syncthreads();
+                shade(k, true, cf);
+                emit_q(k, true, cf);
+                __syncthreads();
+            }
+        } else {
+            for (int k = -1; k <= nr + 1; k++) {
+                finalize(k - 1);
+                __syncthreads();
+                propose_issue(k + 2);
+                importance(k + 1);
+                propose_finish(k + 2);
+                __syncthreads();
+            }
+        }
+        return;
+    }
     if (wv < 3) {
         v4f cc0[TP][2] = {}, cc1[TP][2] = {}, cc2[TP][2] = {}, cf[TP][2] = {};      // coarse colours of rays k-1, k, k+1; fine colours of ray k-1
         for (int k = -1; k <= nr + 1; k++) {
@@ -590,4 +737,13 @@ __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD :
     } else {
         render_pipe_body<TP, MLP, FULL, GEN>(P, smem);
     }
+}
+
+// First pass of the staged backward: the forward pipeline in its BWD form (see render_pipe_body).  General sample counts (FULL = false:
+// any S, F the pipelined kernels cover, disparity sampling, per-ray limits), decoder arithmetic chosen on the device as in the forward.
+template <int TP>
+__global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD : (TP == 2 ? GNERF_PIPE2_WAVES_PER_SIMD : 2)) void render_kernel_pipe_bwd(Params P, gnerf_render_grads Gr, float* stage) {
+    extern __shared__ __align__(16) float smem[];
+    if (choose_mlp(P, smem) == kMlpF32) render_pipe_body<TP, kMlpF32, false, false, true>(P, smem, &Gr, stage);
+    else                               render_pipe_body<TP, kMlpF16x3, false, false, true>(P, smem, &Gr, stage);
 }

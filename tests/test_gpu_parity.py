@@ -1003,7 +1003,7 @@ def _entrywise_ok(a, b, rtol=5e-3, floor=2e-4):
     dict(N=1, res=3, S=130, F=100, hw=(8, 8)),              # beyond 96+96, ragged tiles, 9 rays: partial workgroup
     dict(N=1, res=2, S=256, F=256, hw=(8, 8)),              # GNERF_MAX_SAMPLES on both passes (159 KB of LDS per workgroup)
 ])
-def test_render_backward_vs_oracle(dev, cfg):
+def test_render_backward_vs_oracle(dev, cfg, monkeypatch):
     """gnerf_render_backward against autograd through the fp64 oracle: plane, weight and bias gradients of a random
     linear functional of (rgb, depth, weight sum).  Tolerance: 2e-3 of each gradient's largest entry (fp32 kernel,
     hardware exp/log, atomics in arbitrary order, vs a float64 reference)."""
@@ -1021,18 +1021,25 @@ def test_render_backward_vs_oracle(dev, cfg):
                 white_back=white_back)
     ref_planes, ref_dec = _oracle_grads(planes, dec, o, d, nc, nf, opts, g_rgb, g_depth, g_wsum)
     nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
-    for staged in (True, False):                 # two-pass scatter with per-texel aggregation in LDS (the default) / single pass
+    # staged, pipelined first pass + sample-tile kernel (the default where the pipelined kernels cover the sample counts) / staged,
+    # one wave per ray (GNERF_BWD_KERNEL=wave; what every other shape runs) / single pass, one atomic per tap and channel
+    for staged, kernel in ((True, None), (True, 'wave'), (False, None)):
+        if kernel:
+            monkeypatch.setenv('GNERF_BWD_KERNEL', kernel)
+        else:
+            monkeypatch.delenv('GNERF_BWD_KERNEL', raising=False)
         gp, gdec = gnerf_hip.render_backward(nhwc, N, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev) if F else None,
                                              g_rgb.to(dev), g_depth.to(dev), g_wsum.to(dev),
                                              depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0,
                                              white_back=white_back, image_width=cfg['res'], staged_scatter=staged)
         gp_nchw = gp.reshape(N, 3, *cfg['hw'], 32).permute(0, 1, 4, 2, 3).cpu()
-        assert _rel(gp_nchw, ref_planes) < 2e-3, (staged, _rel(gp_nchw, ref_planes))
-        assert _rel_l2(gp_nchw, ref_planes) < 1e-3, (staged, _rel_l2(gp_nchw, ref_planes))
-        assert _entrywise_ok(gp_nchw, ref_planes), staged
+        assert _rel(gp_nchw, ref_planes) < 2e-3, (staged, kernel, _rel(gp_nchw, ref_planes))
+        assert _rel_l2(gp_nchw, ref_planes) < 1e-3, (staged, kernel, _rel_l2(gp_nchw, ref_planes))
+        assert _entrywise_ok(gp_nchw, ref_planes), (staged, kernel)
         for name, a, b in zip(['w1', 'b1', 'w2', 'b2'], gdec, ref_dec):
-            assert _rel(a.cpu(), b) < 2e-3, (name, _rel(a.cpu(), b))
-            assert _rel_l2(a.cpu(), b) < 1e-3, (name, _rel_l2(a.cpu(), b))
+            assert _rel(a.cpu(), b) < 2e-3, (name, kernel, _rel(a.cpu(), b))
+            assert _rel_l2(a.cpu(), b) < 1e-3, (name, kernel, _rel_l2(a.cpu(), b))
+    monkeypatch.delenv('GNERF_BWD_KERNEL', raising=False)
     # each input gradient alone (NULL pointers for the others) and planes-only / decoder-only requests
     gp2, none_dec = gnerf_hip.render_backward(nhwc, N, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev) if F else None,
                                               g_rgb.to(dev), None, None, depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3,
