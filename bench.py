@@ -372,6 +372,7 @@ def backward_times(dev, planes_cl, dec, c2w, intr, reps=5):
     nc = torch.rand([N_ITEMS, RES * RES, S_COARSE, 1], device=dev)
     nf = torch.rand(rays, S_FINE, device=dev)
     g = [torch.randn(N_ITEMS, RES * RES, k, device=dev) for k in (32, 1, 1)]
+    amax = gnerf_hip.planes_absmax(planes_cl)
     kw = dict(depth_resolution=S_COARSE, depth_resolution_importance=S_FINE, ray_start=RAY_START, ray_end=RAY_END, box_warp=BOX_WARP, image_width=RES)
 
     def timed(**extra):
@@ -379,7 +380,7 @@ def backward_times(dev, planes_cl, dec, c2w, intr, reps=5):
         ms = []
         for i in range(reps + 1):
             e0.record()
-            gnerf_hip.render_backward(planes_cl, N_ITEMS, dec, o, d, nc, nf, *g, **kw, **extra)
+            gnerf_hip.render_backward(planes_cl, N_ITEMS, dec, o, d, nc, nf, *g, planes_absmax=amax, **kw, **extra)
             e1.record()
             torch.cuda.synchronize()
             if i:

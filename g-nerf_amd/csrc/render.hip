@@ -63,6 +63,10 @@ struct Params {
     const float* absmax;    // GNERF_MLP_AUTO: max |planes| (one device float) for choose_mlp
     TorchRandDraw draw_c, draw_f;   // rng_mode: the two draws torch's generator would have made (raygen.h)
     uint64_t draw_item_ctr;         // rng_per_item: Philox counter stride from one item's draws to the next (offset stride / 4)
+    // staged backward on the pipelined path: floats per ray of the exchange / staging buffer and from one 16-rank tile's block to the
+    // next (33 n_all and 512 when the blocks are the dX rows of the staged scatter; n_all + 32 tiles and 32 for a decoder-only request)
+    int64_t bwd_ray_stride;
+    int bwd_tile_pitch;
 };
 
 // ---- order-preserving float <-> uint so that integer atomics give float min/max
@@ -1015,16 +1019,23 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
     // one-wave-per-ray kernel (A/B runs and the tests' cross-check).
     const char* bwd_kernel = getenv("GNERF_BWD_KERNEL");
     const bool small_planes = int64_t(p->plane_h) * p->plane_w * 3 * 128 < (int64_t(1) << 32);
-    const bool piped = staged && P.tiles_c <= 9 && P.tiles_f >= 1 && P.tiles_f <= 9 && small_planes && !(bwd_kernel && !strcmp(bwd_kernel, "wave"));
+    // (a decoder-only request with an exchange buffer -- gnerf_render_backward_exchange_bytes -- takes the same two kernels: no dX rows,
+    // no second pass)
+    const bool exchange_only = g->scatter_stage != nullptr && g->grad_planes_nhwc == nullptr && n_dec == 4;
+    const bool piped = (staged || exchange_only) && P.tiles_c <= 9 && P.tiles_f >= 1 && P.tiles_f <= 9 && small_planes && !(bwd_kernel && !strcmp(bwd_kernel, "wave"))
+                       && !(route && !strcmp(route, "direct"));
     if (piped) {
         hipStream_t s = as_stream(stream);
         const int64_t total = P.total_rays;
         const int n_all = p->depth_resolution + p->depth_resolution_importance;
         // decoder arithmetic of the first pass: chosen on the device from max |planes| like the forward's (measured here into the
         // 256 bytes behind the staged rows when the caller has none)
+        const int tiles_per_ray = (n_all + 15) / 16;
+        P.bwd_ray_stride = staged ? int64_t(n_all) * 33 : int64_t(n_all) + 32 * tiles_per_ray;
+        P.bwd_tile_pitch = staged ? 512 : 32;
         P.absmax = p->planes_absmax;
         if (!P.absmax) {
-            float* own = g->scatter_stage + size_t(total) * n_all * 33;
+            float* own = g->scatter_stage + size_t(total) * P.bwd_ray_stride;
             if (int e = gnerf_planes_absmax(p->planes_nhwc, int64_t(p->n_items) * 3 * p->plane_h * p->plane_w * 32, own, stream)) return e;
             P.absmax = own;
         }
@@ -1076,6 +1087,12 @@ extern "C" size_t gnerf_render_backward_stage_bytes(const gnerf_render_params* p
     if (!p || p->n_items < 1 || p->rays_per_item < 1) return 0;
     const size_t n_all = size_t(p->depth_resolution) + size_t(p->depth_resolution_importance);
     return size_t(p->n_items) * size_t(p->rays_per_item) * n_all * 33 * sizeof(float) + 256;      // (+ a spare line: max |planes| when the caller has none)
+}
+
+extern "C" size_t gnerf_render_backward_exchange_bytes(const gnerf_render_params* p) {
+    if (!p || p->n_items < 1 || p->rays_per_item < 1) return 0;
+    const size_t n_all = size_t(p->depth_resolution) + size_t(p->depth_resolution_importance);
+    return size_t(p->n_items) * size_t(p->rays_per_item) * (n_all + 32 * ((n_all + 15) / 16)) * sizeof(float) + 256;
 }
 
 extern "C" int gnerf_query_points(const float* planes_nhwc, int n_items, int plane_h, int plane_w,

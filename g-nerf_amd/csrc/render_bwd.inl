@@ -133,6 +133,64 @@ __device__ __forceinline__ void bwd_gather_tile(const Params& P, const BwdLds& L
     lds_wave_sync();
 }
 
+// The same lookup for kernels that hold no scatter state (render_bwd_tiles_kernel): the tile's 24 texel loads run as the forward's ROLLING
+// window (coop_shade_tile, render_coop.inl) -- the three planes of step 0 in flight together, and as soon as a plane of step 0 has been
+// blended the same plane of step 1 is issued -- instead of six dependent rounds of four loads: with two waves per SIMD a round trip to
+// L2 per round was a third of the tile's time.
+template <class PosFn>
+__device__ __forceinline__ void bwd_gather_tile_rolling(const Params& P, const BwdLds& L, const char* planes, PosFn pos, int lane) {
+    const int H = P.p.plane_h, W = P.p.plane_w;
+    if (lane < 48) {
+        const int j = lane & 15, pl = lane >> 4;
+        float px, py, pz;
+        pos(j, px, py, pz);
+        const float u = pl == 2 ? pz : px;
+        const float v = pl == 0 ? py : (pl == 1 ? pz : px);
+        uint4 my_off; v4f my_wgt;
+        plane_taps(H, W, u, v, P.tex_pitch, P.row_pitch, unsigned(pl) * P.plane_pitch, my_off, my_wgt);
+        float* rec = L.hbuf + j * kTapDwords + pl * 8;
+        *reinterpret_cast<uint4*>(rec) = my_off;
+        *reinterpret_cast<v4f*>(rec + 4) = my_wgt;
+    }
+    lds_wave_sync();
+    const int b = lane >> 3, cq16 = (lane & 7) * 16;
+    uint4 off[2][3];
+    v4f wgt[2][3], tex[2][3][4];
+    auto read_records = [&](int a) {
+        const float* rec = L.hbuf + (8 * a + b) * kTapDwords;
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            off[a][pl] = *reinterpret_cast<const uint4*>(rec + pl * 8);
+            wgt[a][pl] = *reinterpret_cast<const v4f*>(rec + pl * 8 + 4);
+        }
+    };
+    auto issue = [&](int a, int pl) {
+        tex[a][pl][0] = *reinterpret_cast<const v4f*>(planes + (off[a][pl].x + cq16));
+        tex[a][pl][1] = *reinterpret_cast<const v4f*>(planes + (off[a][pl].y + cq16));
+        tex[a][pl][2] = *reinterpret_cast<const v4f*>(planes + (off[a][pl].z + cq16));
+        tex[a][pl][3] = *reinterpret_cast<const v4f*>(planes + (off[a][pl].w + cq16));
+    };
+    auto blend = [&](int a, int pl, v4f& acc) {
+        const v4f sum = tex[a][pl][0] * wgt[a][pl][0] + tex[a][pl][1] * wgt[a][pl][1] + tex[a][pl][2] * wgt[a][pl][2] + tex[a][pl][3] * wgt[a][pl][3];
+        if (pl == 0) acc = sum; else acc += sum;
+    };
+    v4f acc0, acc1;
+    read_records(0);
+    issue(0, 0); issue(0, 1); issue(0, 2);
+    read_records(1);
+    __builtin_amdgcn_sched_barrier(0);
+    blend(0, 0, acc0); issue(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    blend(0, 1, acc0); issue(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    blend(0, 2, acc0); issue(1, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    *reinterpret_cast<v4f*>(L.stage + b * kStagePitch + (lane & 7) * 4) = acc0;
+    blend(1, 0, acc1); blend(1, 1, acc1); blend(1, 2, acc1);
+    *reinterpret_cast<v4f*>(L.stage + (8 + b) * kStagePitch + (lane & 7) * 4) = acc1;
+    lds_wave_sync();
+}
+
 // MLP forward on the staged tile: h = softplus(W1 x + b1) in the H^T layout (lane: sample j, hidden 16m+4g+r),
 // o = colour pre-activations (lane: sample 4g+r, output 1+16n+j), sig = density of sample j.
 __device__ __forceinline__ void bwd_mlp_forward(const BwdLds& L, int lane, v4f (&h)[4], v4f (&o)[2], float& sig) {
@@ -604,7 +662,6 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_tiles_kernel(Params
 #pragma unroll
     for (int m = 0; m < 4; m++) A.w1[m][0] = A.w1[m][1] = A.w2[0][m] = A.w2[1][m] = A.w2s[m] = A.b1[m] = (v4f){0.f, 0.f, 0.f, 0.f};
     A.b2[0] = A.b2[1] = A.b2s = 0.f;
-    BwdPending pend = {nullptr, 0};
     const int j = lane & 15, g = lane >> 4;
     const int64_t plane_floats = int64_t(3) * p.plane_h * p.plane_w * 32;
     // tiles of the locality-ordered ray sequence (pipe_seq_to_ray): XCD x owns a contiguous eighth (workgroups b, b+8, ... share an
@@ -622,8 +679,8 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_tiles_kernel(Params
         if (ray < 0) continue;
         const int item = ray / p.rays_per_item;
         const int live = min(16, n_all - 16 * T);
-        float* const ray_block = stage + int64_t(ray) * n_all * 33;
-        float* const rows = ray_block + n_all + T * 512;
+        float* const ray_block = stage + int64_t(ray) * P.bwd_ray_stride;
+        float* const rows = ray_block + n_all + T * P.bwd_tile_pitch;
         if (lane < 16) dep[lane] = ray_block[16 * T + min(lane, live - 1)];
         else if (lane < 48) dep[lane] = ((lane & 15) < live) ? rows[lane - 16] : 0.f;       // vw[0..15], dsg[0..15]
         BwdRay R;
@@ -634,7 +691,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_tiles_kernel(Params
         G[0] = Gr.grad_rgb ? 2.f * Gr.grad_rgb[int64_t(ray) * 32 + j] : 0.f;
         G[1] = Gr.grad_rgb ? 2.f * Gr.grad_rgb[int64_t(ray) * 32 + 16 + j] : 0.f;
         lds_wave_sync();
-        bwd_gather_tile<false, DepthListPos, false>(P, L, R.planes, DepthListPos{R, dep, P.box_scale}, pend, lane);
+        bwd_gather_tile_rolling(P, L, R.planes, DepthListPos{R, dep, P.box_scale}, lane);
         v4f h[4], o[2];
         float sig;
         bwd_mlp_forward(L, lane, h, o, sig);

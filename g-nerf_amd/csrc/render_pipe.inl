@@ -517,12 +517,12 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
             // ---- per sample, in depth order: depth, colour weight, dL/dsigma -> the staging buffer.  Depths at the head of the ray's
             // block (where plane_scatter_kernel reads them); v and dL/dsigma of the 16 ranks of tile T in the first 32 floats of the
             // tile's own dX rows, which render_bwd_tiles_kernel reads before it overwrites them with dX.
-            float* const ray_block = bstage + int64_t(ray_id) * n_all * 33;
+            float* const ray_block = bstage + int64_t(ray_id) * P.bwd_ray_stride;
             for (int r = lane; r < n_all; r += 64) {
                 const float wl = r > 0 ? sl.w_s[r - 1] : 0.f, wr = r < n_int ? sl.w_s[r] : 0.f;
                 const float dl = r > 0 ? ds[r - 1] : 0.f, dr = r < n_int ? ds[r] : 0.f;
                 ray_block[r] = sl.s_t[r];
-                float* tile_rows = ray_block + n_all + (r >> 4) * 512;
+                float* tile_rows = ray_block + n_all + (r >> 4) * P.bwd_tile_pitch;
                 tile_rows[r & 15] = (wl + wr) * 0.5f;            // colour of sample r enters intervals r-1 and r with weight 1/2 each
                 tile_rows[16 + (r & 15)] = (dl + dr) * 0.5f;     // so does its density
             }

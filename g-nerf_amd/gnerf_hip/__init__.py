@@ -91,6 +91,7 @@ SIGNATURES = {
     'gnerf_render_forward': (_c_i, [ctypes.POINTER(RenderParams), _c_p]),
     'gnerf_render_backward': (_c_i, [ctypes.POINTER(RenderParams), ctypes.POINTER(RenderGrads), _c_p]),
     'gnerf_render_backward_stage_bytes': (ctypes.c_size_t, [ctypes.POINTER(RenderParams)]),
+    'gnerf_render_backward_exchange_bytes': (ctypes.c_size_t, [ctypes.POINTER(RenderParams)]),
     'gnerf_query_points': (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_p]),
     'gnerf_query_points_backward': (_c_i, [_c_p, _c_i, _c_i, _c_i, _c_p, _c_i, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                            _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_p]),
@@ -1058,15 +1059,17 @@ def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
 def render_backward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine, grad_rgb, grad_depth, grad_wsum, *,
                     depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
                     white_back=False, disparity_space_sampling=False, image_width=0, need_planes=True, need_decoder=True,
-                    staged_scatter=True):
+                    staged_scatter=True, planes_absmax=None):
     """Gradient of render_forward for the same arguments (the forward pass is recomputed inside the kernel).
     grad_rgb [N,M,32], grad_depth [N,M,1], grad_wsum [N,M,1]; any of them may be None (zeros).
     staged_scatter: make the plane gradient in two passes through a staging buffer (per-texel aggregation in LDS before the
     atomics; see include/gnerf_hip.h) -- the default; False = the single-pass form.
+    planes_absmax: max |planes| as for render_forward (the staged form's first pass picks its decoder arithmetic from it on the
+    device; measured by the call when None).
     Returns (grad_planes_nhwc [3N,H,W,32] or None, (grad_w1, grad_b1, grad_w2, grad_b2) or None), all float32."""
     p, keep, m = _render_params(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine,
                                 depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
-                                white_back, disparity_space_sampling, image_width, 'render_backward')
+                                white_back, disparity_space_sampling, image_width, 'render_backward', planes_absmax)
     dev = planes_nhwc.device
     _require_cuda(grad_rgb, grad_depth, grad_wsum)
     grads_in = []
@@ -1093,6 +1096,13 @@ def render_backward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_
         nbytes = int(load().gnerf_render_backward_stage_bytes(ctypes.byref(p)))
         try:
             stage = torch.empty([nbytes], dtype=torch.uint8, device=dev)
+            g.scatter_stage = stage.data_ptr()
+        except torch.OutOfMemoryError:
+            stage = None
+    elif g_planes is None and g_dec is not None and staged_scatter:
+        # decoder gradients only: the small per-sample exchange buffer of the pipelined path (1.5 KB per ray at 48+48)
+        try:
+            stage = torch.empty([int(load().gnerf_render_backward_exchange_bytes(ctypes.byref(p)))], dtype=torch.uint8, device=dev)
             g.scatter_stage = stage.data_ptr()
         except torch.OutOfMemoryError:
             stage = None

@@ -135,6 +135,7 @@ class _FusedRender(torch.autograd.Function):
             nhwc, amax = gnerf_hip.planes_to_nhwc(planes.detach().float(), with_absmax=True)
         out = gnerf_hip.render_forward(nhwc, N, (w1, b1, w2, b2), ray_origins, ray_dirs, noise_c, noise_f,
                                        ray_start=ray_start, ray_end=ray_end, planes_absmax=amax, **cfg)
+        ctx.amax = amax if not ctx.interleaved else None     # (of the NHWC copy made here; a producer's tag is looked up again in backward)
         tensors = [planes, w1, b1, w2, b2, ray_origins, ray_dirs, noise_c]
         # The NHWC copy is kept for the backward pass (the planes' size again: 25 MB per item) unless GNERF_KEEP_NHWC=0, in
         # which case the backward pass repacks the saved NCHW planes a second time (37 us per 100 MB).
@@ -164,11 +165,13 @@ class _FusedRender(torch.autograd.Function):
         N = planes.shape[0]
         if ctx.interleaved:
             nhwc = _interleaved_view(planes.detach())
+            amax = _producer_absmax(planes)
         else:
             nhwc = ctx.nhwc if ctx.nhwc is not None else gnerf_hip.planes_to_nhwc(planes.detach().float())
+            amax = ctx.amax
         g_planes, g_dec = gnerf_hip.render_backward(nhwc, N, (w1, b1, w2, b2), ray_origins, ray_dirs, noise_c, noise_f, g_rgb, g_depth, g_wsum,
                                                     ray_start=ray_start, ray_end=ray_end, need_planes=need_planes, need_decoder=need_decoder,
-                                                    **ctx.cfg)
+                                                    planes_absmax=amax, **ctx.cfg)
         grads = [None] * 12
         if need_planes:
             if ctx.interleaved:

@@ -381,6 +381,10 @@ typedef struct gnerf_render_grads {
 } gnerf_render_grads;
 
 size_t gnerf_render_backward_stage_bytes(const gnerf_render_params* p);
+/* (ABI 8) A decoder-only request (grad_planes_nhwc NULL) may pass a much smaller buffer of this many bytes as scatter_stage: what the
+ * backward's two kernels on the pipelined path exchange per sample (depth, colour weight, dL/dsigma).  Without it such a request
+ * runs the one-wave-per-ray kernel. */
+size_t gnerf_render_backward_exchange_bytes(const gnerf_render_params* p);
 
 /* p: the forward call's params (outputs, workspace and debug are ignored). */
 int gnerf_render_backward(const gnerf_render_params* p, const gnerf_render_grads* g, gnerf_stream_t stream);

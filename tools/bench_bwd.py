@@ -22,7 +22,7 @@ o, d = gnerf_hip.make_rays(c2w.to(dev), intr.to(dev), res)
 M = res * res
 nc = torch.rand(N * M, S, device=dev); nf = torch.rand(N * M, F, device=dev)
 g_rgb = torch.randn(N, M, 32, device=dev); g_depth = torch.randn(N, M, 1, device=dev); g_w = torch.randn(N, M, 1, device=dev)
-nhwc = gnerf_hip.planes_to_nhwc(planes)
+nhwc, amax = gnerf_hip.planes_to_nhwc(planes, with_absmax=True)
 kw = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=res)
 
 def timeit(fn, n=10):
@@ -37,11 +37,11 @@ out = {'N': N, 'res': res, 'S': S, 'F': F}
 if os.environ.get('BWD_ONLY'):         # profiling aid: only the staged (two-pass) or only the single-pass form, 5 calls
     staged = os.environ['BWD_ONLY'] == 'staged'
     out['only'] = os.environ['BWD_ONLY']
-    out['bwd_ms'] = timeit(lambda: gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, g_rgb, g_depth, g_w, staged_scatter=staged, **kw), 4)
+    out['bwd_ms'] = timeit(lambda: gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, g_rgb, g_depth, g_w, staged_scatter=staged, planes_absmax=amax, **kw), 4)
     print(json.dumps(out))
     sys.exit(0)
 out['fwd_ms'] = timeit(lambda: gnerf_hip.render_forward(nhwc, N, dec, o, d, nc, nf, **kw))
-out['bwd_ms'] = timeit(lambda: gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, g_rgb, g_depth, g_w, **kw))
+out['bwd_ms'] = timeit(lambda: gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, g_rgb, g_depth, g_w, planes_absmax=amax, **kw))
 out['bwd_single_pass_ms'] = timeit(lambda: gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, g_rgb, g_depth, g_w, staged_scatter=False, **kw))
 a = gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, g_rgb, g_depth, g_w, **kw)[0]
 b = gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, g_rgb, g_depth, g_w, staged_scatter=False, **kw)[0]
