@@ -1040,7 +1040,10 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
             P.absmax = own;
         }
         P.p.workspace = nullptr;                                   // (the backward's params carry no workspace)
+        // words [1..3] behind the buffer: the maxima the first pass measures for the second pass's f16 scale (render_bwd.inl)
+        if (hipMemsetAsync(g->scatter_stage + size_t(total) * P.bwd_ray_stride + 1, 0, 12, s) != hipSuccess) return fail(GNERF_E_LAUNCH, "render_backward: memset failed");
         P.p.mlp_mode = GNERF_MLP_AUTO;
+        if (const char* fm = getenv("GNERF_BWD_MLP")) { if (!strcmp(fm, "f32")) P.p.mlp_mode = GNERF_MLP_F32; else if (!strcmp(fm, "f16x3")) P.p.mlp_mode = GNERF_MLP_F16X3; }
         const int pipe_tp = (P.tiles_c <= 3 && P.tiles_f <= 3) ? 1 : ((P.tiles_c <= 6 && P.tiles_f <= 6) ? 2 : 3);
         const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : total;
         const int per_cu = pipe_tp == 1 ? GNERF_PIPE_WAVES_PER_SIMD : (pipe_tp == 2 ? GNERF_PIPE2_WAVES_PER_SIMD : 2);
@@ -1059,7 +1062,7 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
             hipLaunchKernelGGL(render_kernel_pipe_bwd<3>, dim3((unsigned)gsz), dim3(kPipeThreads), lds1, s, P, *g, g->scatter_stage);
         }
         if (int e = check_launch("render_kernel_pipe_bwd")) return e;
-        const size_t lds2 = (kBwdWeightFloats + kBwdWaves * bwd_tiles_wave_floats()) * sizeof(float);
+        const size_t lds2 = (bwd_tiles_weight_floats() + kBwdWaves * bwd_tiles_wave_floats()) * sizeof(float);
         static PerDeviceOnce once_tiles;
         if (int e = once_tiles.raise_lds(render_bwd_tiles_kernel, "render_backward")) return e;
         const int64_t sample_tiles = total_seq * ((n_all + 15) / 16);

@@ -637,24 +637,342 @@ struct DepthListPos {
 
 __host__ __device__ inline size_t bwd_tiles_wave_floats() { return 16 * kStagePitch + 16 * kTPitch + 16 * kHPitch + 48; }
 
-__global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_tiles_kernel(Params P, gnerf_render_grads Gr, float* stage) {
-    extern __shared__ __align__(16) float smem[];
+// Decoder in LDS for the f16 hi/lo form of the tile kernel: the forward's fragments (stage_decoder<kMlpF16x3>: W1, W2 colour rows as
+// hi/lo halves in MFMA fragment order, biases and density row with the base-2 factors folded in), then the two STATIC operands of the
+// gradient products in the same hi/lo fragment form, then the density row in true units.
+//   g1 [hi|lo][m][lane][8]:      A of dH^T block m = W2c^T:  element e of lane (j, g) = W2[1 + 8g + e][16m + j]
+//   g3 [hi|lo][c][s][lane][8]:   A of dX^T block c, k-step s = W1^T: element jj of lane (j, g) = W1[32s + 16(jj>>2) + 4g + (jj&3)][16c + j]
+//                                (the k order in which a lane's dPRE registers come: the forward's layer-2 trick)
+constexpr int kBwdFragHalves = 4 * 64 * 8;          // one of g1 hi, g1 lo, g3 hi, g3 lo
+constexpr int kBwdF16WeightFloats = kWeightFloatsF16 + 64 + 36 + (4 * kBwdFragHalves) / 2 + 64 + 4;
+__host__ __device__ constexpr int bwd_tiles_weight_floats() { return kBwdF16WeightFloats > kBwdWeightFloats ? kBwdF16WeightFloats : kBwdWeightFloats; }
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h4 as_h4(unsigned a, unsigned b) { return __builtin_bit_cast(h4, (u2v){a, b}); }
+#define GNERF_MFMA16K16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0)
+
+// Word layout of the 256 spare bytes behind the exchange / staging buffer (floats): [0] max |planes| when the caller has none,
+// [1] max |dL/d colour sum| over the call, [2] max colour weight, [3] max |dL/dsigma| -- [1..3] as the bit patterns of non-negative floats
+// (unsigned atomicMax), zeroed by the launcher, written by render_kernel_pipe_bwd, read by the f16 form below for its power-of-two scale.
+
+// One 16-sample tile, exact fp32 products (v_mfma_f32_16x16x4_f32): any finite input.
+struct BwdTileF32 {
+    static constexpr int kMlp = kMlpF32;
+    BwdLds L;
+    float inv_scale;
+    __device__ __forceinline__ void setup(const Params& P, float* smem, const float*, int tid) {
+        const gnerf_render_params& p = P.p;
+        float* w1 = smem;
+        float* w2 = w1 + 64 * kW1Pitch;
+        float* b1 = w2 + 33 * kW2Pitch;
+        float* b2 = b1 + 64;
+        for (int i = tid; i < 64 * 32; i += kBwdThreads) w1[(i >> 5) * kW1Pitch + (i & 31)] = p.w1[i];
+        for (int i = tid; i < 33 * 64; i += kBwdThreads) w2[(i >> 6) * kW2Pitch + (i & 63)] = p.w2[i];
+        if (tid < 64) b1[tid] = p.b1[tid];
+        if (tid < 36) b2[tid] = tid < 33 ? p.b2[tid] : 0.f;
+        __syncthreads();
+        L = BwdLds{};
+        L.w1 = w1; L.w2 = w2; L.b1 = b1; L.b2 = b2;
+        inv_scale = 1.f;
+    }
+    // X in L.stage, the tile's colour weights in vw, dL/dsigma in dsg, G = dL/d colour sum of channels 16n + j  ->  dX[16][32] in L.tbuf
+    __device__ __forceinline__ void tile(const float* vw, const float* dsg, const float (&G)[2], BwdAcc& A, int lane) {
+        const int j = lane & 15, g = lane >> 4;
+        v4f h[4], o[2];
+        float sig;
+        bwd_mlp_forward(L, lane, h, o, sig);
+        // ---- dO: colour c = 1.002 * s - 0.001 with s = sigmoid(o); dL/dc = G * v_sample  (triplane.py:134, ray_marcher.py:27-45)
+        const v4f vs = *reinterpret_cast<const v4f*>(vw + 4 * g);
+        const float dsig = dsg[j];
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float e = __builtin_amdgcn_exp2f(o[n][r] * -1.44269504088896341f);
+                const float s = __builtin_amdgcn_rcpf(1.0f + e);
+                const float d = G[n] * vs[r] * (1.002f * s * (1.f - s));
+                L.tbuf[(4 * g + r) * kTPitch + 16 * n + j] = d;
+                A.b2[n] += d;
+            }
+        }
+        bwd_tile_core(L, h, dsig, A, lane);
+    }
+    __device__ __forceinline__ void finish(BwdAcc&) {}
+};
+
+// The same tile with every product as an error-compensated f16 hi/lo split on the f16 matrix instructions (fp32 accumulation): the
+// decoder forward as in the forward kernels (24 v_mfma_f32_16x16x32_f16), dH and dX against static hi/lo fragments (12 + 12), the two
+// weight-gradient products -- both operands made at run time, K = the tile's 16 samples -- on v_mfma_f32_16x16x16_f16 (24 + 24): 96
+// matrix instructions of 16.5 SIMD cycles where the fp32 form issues 192 of 32.  Everything on the gradient side (dO, dsigma, dH,
+// dPRE, dX, the weight-gradient accumulators) is carried MULTIPLIED BY `scale`, a power of two chosen per call from the maxima the
+// first pass measured so that the largest |dPRE| possible lands near 2^13: loss gradients of 1e-6 are f16-subnormal unscaled.  The
+// scale comes off, exactly, when dX leaves for the staging buffer and when the accumulators are reduced.  Valid under the same
+// guard as the forward's f16 arithmetic (choose_mlp: features, weights and activations inside f16's range).
+struct BwdTileF16 {
+    static constexpr int kMlp = kMlpF16x3;
+    CoopLds C;                       // the forward's fragments (w1 = fragment base, w2 = density row * ln2, b1 * log2e, b2 scaled)
+    const _Float16* g1; const _Float16* g3;
+    const float* ws_true;            // W2[0][:]
+    float* stage; float* tbuf; float* hbuf;
+    float scale, inv_scale;
+    __device__ __forceinline__ void setup(const Params& P, float* smem, const float* tail, int tid) {
+        const gnerf_render_params& p = P.p;
+        stage_decoder<kMlpF16x3>(C, smem, p, tid, kBwdThreads);
+        _Float16* gh = reinterpret_cast<_Float16*>(smem + kWeightFloatsF16 + 64 + 36);
+        g1 = gh; g3 = gh + 2 * kBwdFragHalves;
+        float* wst = smem + kWeightFloatsF16 + 64 + 36 + (4 * kBwdFragHalves) / 2;
+        ws_true = wst;
+        for (int i = tid; i < 2048; i += kBwdThreads) {
+            const int e = i & 7, j = (i >> 3) & 15, g = (i >> 7) & 3, m = i >> 9;             // lane 16 g + j of block m
+            const float x = p.w2[(1 + 8 * g + e) * 64 + 16 * m + j];
+            const _Float16 hi = (_Float16)x;
+            gh[i] = hi;
+            gh[kBwdFragHalves + i] = (_Float16)(x - (float)hi);
+        }
+        for (int i = tid; i < 2048; i += kBwdThreads) {
+            const int jj = i & 7, j = (i >> 3) & 15, g = (i >> 7) & 3, sx = (i >> 9) & 1, c = i >> 10;     // lane 16 g + j of fragment (c, s)
+            const float x = p.w1[(32 * sx + 16 * (jj >> 2) + 4 * g + (jj & 3)) * 32 + 16 * c + j];
+            const _Float16 hi = (_Float16)x;
+            gh[2 * kBwdFragHalves + i] = hi;
+            gh[3 * kBwdFragHalves + i] = (_Float16)(x - (float)hi);
+        }
+        if (tid < 64) wst[tid] = p.w2[tid];
+        __syncthreads();
+        // ---- the call's power-of-two scale.  Bounds: |dO| <= 0.2505 max|G| max v;  |dPRE| <= |dH| <= max_hid sum_out |W2c[out][hid]| max|dO|
+        // + max|W2[0]| max|dsigma|.  Every wave computes the same value from LDS and the three measured maxima.
+        const int lane = tid & 63;
+        float l1 = 0.f;
+        for (int o = 0; o < 32; o++) l1 += fabsf(p.w2[(1 + o) * 64 + lane]);
+        float wsm = fabsf(wst[lane]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { l1 = fmaxf(l1, __shfl_xor(l1, o)); wsm = fmaxf(wsm, __shfl_xor(wsm, o)); }
+        const float bo = 0.2505f * tail[1] * tail[2];
+        const float bound = fmaxf(bo, bo * l1 + wsm * tail[3]);
+        int ex = 0;
+        if (bound > 0.f && bound < INFINITY) { (void)frexpf(bound, &ex); ex = min(max(13 - ex, -100), 100); }
+        scale = ldexpf(1.f, ex);
+        inv_scale = ldexpf(1.f, -ex);
+    }
+    __device__ __forceinline__ void tile(const float* vw, const float* dsg, const float (&G)[2], BwdAcc& A, int lane) {
+        const int j = lane & 15, g = lane >> 4;
+        const _Float16* w1h = reinterpret_cast<const _Float16*>(C.w1);
+        const _Float16* w2h = w1h + 2 * kW1FragHalves;
+        // ---- decoder forward (coop_shade_tile's f16 branch): p' = log2(e) pre-activation, hv = log2(1 + 2^p') = H / ln 2, o' = -log2(e) o
+        const v4f f_lo = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g);
+        const v4f f_hi = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g + 4);
+        const float f[8] = {f_lo[0], f_lo[1], f_lo[2], f_lo[3], f_hi[0], f_hi[1], f_hi[2], f_hi[3]};
+        unsigned fh_u[4], fl_u[4];
+        split_f16x8(f, fh_u, fl_u);
+        const h8 fh = as_h8((u4v){fh_u[0], fh_u[1], fh_u[2], fh_u[3]}), fl = as_h8((u4v){fl_u[0], fl_u[1], fl_u[2], fl_u[3]});
+        v4f hv[4];
+        {
+            h8 a_hi[4], a_lo[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                hv[m] = *reinterpret_cast<const v4f*>(C.b1 + 16 * m + 4 * g);
+                a_hi[m] = *reinterpret_cast<const h8*>(w1h + (m * 64 + lane) * 8);
+                a_lo[m] = *reinterpret_cast<const h8*>(w1h + kW1FragHalves + (m * 64 + lane) * 8);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; m++) hv[m] = GNERF_MFMA16(a_hi[m], fh, hv[m]);
+#pragma unroll
+            for (int m = 0; m < 4; m++) hv[m] = GNERF_MFMA16(a_hi[m], fl, hv[m]);
+#pragma unroll
+            for (int m = 0; m < 4; m++) hv[m] = GNERF_MFMA16(a_lo[m], fh, hv[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            v4f e;
+#pragma unroll
+            for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(-fabsf(hv[m][r]));
+#pragma unroll
+            for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_logf(1.0f + e[r]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) hv[m][r] = fmaxf(hv[m][r] + e[r], e[r]);
+            *reinterpret_cast<v4f*>(hbuf + j * kHPitch + 16 * m + 4 * g) = hv[m];               // H / ln2 as [sample][hidden], for dW2's B operand
+        }
+        v4f o[2];
+        {
+            const float bc0 = C.b2[1 + j], bc1 = C.b2[17 + j];
+            o[0] = (v4f){bc0, bc0, bc0, bc0}; o[1] = (v4f){bc1, bc1, bc1, bc1};
+            h8 x_hi[2], x_lo[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                unsigned xh[4], xl[4];
+                const float xs[8] = {hv[2 * s][0], hv[2 * s][1], hv[2 * s][2], hv[2 * s][3], hv[2 * s + 1][0], hv[2 * s + 1][1], hv[2 * s + 1][2], hv[2 * s + 1][3]};
+                split_f16x8(xs, xh, xl);
+                x_hi[s] = as_h8((u4v){xh[0], xh[1], xh[2], xh[3]});
+                x_lo[s] = as_h8((u4v){xl[0], xl[1], xl[2], xl[3]});
+            }
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+#pragma unroll
+                for (int n = 0; n < 2; n++) {
+                    const h8 w_hi = *reinterpret_cast<const h8*>(w2h + ((n * 2 + s) * 64 + lane) * 8);
+                    const h8 w_lo = *reinterpret_cast<const h8*>(w2h + 2048 + ((n * 2 + s) * 64 + lane) * 8);
+                    o[n] = GNERF_MFMA16(x_hi[s], w_hi, o[n]);
+                    o[n] = GNERF_MFMA16(x_hi[s], w_lo, o[n]);
+                    o[n] = GNERF_MFMA16(x_lo[s], w_hi, o[n]);
+                }
+            }
+        }
+        // ---- dO (scaled): colour c = 1.002 s - 0.001, s = sigmoid(o) = 1 / (1 + 2^o'); kept in registers too (A operand of dW2)
+        const v4f vs = *reinterpret_cast<const v4f*>(vw + 4 * g);
+        const float dsig = dsg[j] * scale;
+        const float Gs[2] = {G[0] * scale, G[1] * scale};
+        float dO[8];
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(o[n][r]));
+                const float d = Gs[n] * vs[r] * (1.002f * s * (1.f - s));
+                dO[4 * n + r] = d;
+                tbuf[(4 * g + r) * kTPitch + 16 * n + j] = d;
+                A.b2[n] += d;
+            }
+        }
+        if (g == 0) A.b2s += dsig;
+        lds_wave_sync();
+        // ---- dH^T[hidden][sample] = W2c^T dO^T (+ the density row on the vector ALU): B = this lane's sample row of dO, outputs 8g..8g+7
+        v4f dh[4];
+        {
+            const v4f b_lo4 = *reinterpret_cast<const v4f*>(tbuf + j * kTPitch + 8 * g);
+            const v4f b_hi4 = *reinterpret_cast<const v4f*>(tbuf + j * kTPitch + 8 * g + 4);
+            const float bv[8] = {b_lo4[0], b_lo4[1], b_lo4[2], b_lo4[3], b_hi4[0], b_hi4[1], b_hi4[2], b_hi4[3]};
+            unsigned bh_u[4], bl_u[4];
+            split_f16x8(bv, bh_u, bl_u);
+            const h8 bh = as_h8((u4v){bh_u[0], bh_u[1], bh_u[2], bh_u[3]}), bl = as_h8((u4v){bl_u[0], bl_u[1], bl_u[2], bl_u[3]});
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const v4f ws = *reinterpret_cast<const v4f*>(ws_true + 16 * m + 4 * g);
+                dh[m] = ws * dsig;
+                A.w2s[m] += hv[m] * dsig;                                                        // (x ln2 at the end)
+                const h8 a_hi = *reinterpret_cast<const h8*>(g1 + (m * 64 + lane) * 8);
+                const h8 a_lo = *reinterpret_cast<const h8*>(g1 + kBwdFragHalves + (m * 64 + lane) * 8);
+                dh[m] = GNERF_MFMA16(a_hi, bh, dh[m]);
+                dh[m] = GNERF_MFMA16(a_hi, bl, dh[m]);
+                dh[m] = GNERF_MFMA16(a_lo, bh, dh[m]);
+            }
+        }
+        // ---- dW2c[out][hidden] += dO^T (H / ln2): A = the dO values this lane computed (samples 4g..4g+3 of outputs 16o + j), B from hbuf
+        {
+            unsigned ah_u[4], al_u[4];
+            split_f16x8(dO, ah_u, al_u);
+#pragma unroll
+            for (int np = 0; np < 2; np++) {                       // hidden blocks 2 np, 2 np + 1
+                float bvals[8];
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) bvals[4 * q + e] = hbuf[(4 * g + e) * kHPitch + 16 * (2 * np + q) + j];
+                unsigned bh_u[4], bl_u[4];
+                split_f16x8(bvals, bh_u, bl_u);
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const h4 b_hi = as_h4(bh_u[2 * q], bh_u[2 * q + 1]), b_lo = as_h4(bl_u[2 * q], bl_u[2 * q + 1]);
+#pragma unroll
+                    for (int oo = 0; oo < 2; oo++) {
+                        const h4 a_hi = as_h4(ah_u[2 * oo], ah_u[2 * oo + 1]), a_lo = as_h4(al_u[2 * oo], al_u[2 * oo + 1]);
+                        v4f acc = A.w2[oo][2 * np + q];
+                        acc = GNERF_MFMA16K16(a_hi, b_hi, acc);
+                        acc = GNERF_MFMA16K16(a_hi, b_lo, acc);
+                        acc = GNERF_MFMA16K16(a_lo, b_hi, acc);
+                        A.w2[oo][2 * np + q] = acc;
+                    }
+                }
+            }
+        }
+        // ---- through softplus: d/dpre softplus(pre) = 1 - exp(-H) = 1 - 2^-(H / ln2)
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) dh[m][r] *= 1.f - __builtin_amdgcn_exp2f(-hv[m][r]);
+            A.b1[m] += dh[m];
+        }
+        lds_wave_sync();                                            // every lane has read H from hbuf and its dO row from tbuf
+        // ---- dX^T[channel][sample] = W1^T dPRE^T: B straight from this lane's dPRE registers (k order of the g3 fragments)
+        v4f dx[2];
+        dx[0] = dx[1] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const float pv[8] = {dh[2 * s][0], dh[2 * s][1], dh[2 * s][2], dh[2 * s][3], dh[2 * s + 1][0], dh[2 * s + 1][1], dh[2 * s + 1][2], dh[2 * s + 1][3]};
+            unsigned ph_u[4], pl_u[4];
+            split_f16x8(pv, ph_u, pl_u);
+            const h8 p_hi = as_h8((u4v){ph_u[0], ph_u[1], ph_u[2], ph_u[3]}), p_lo = as_h8((u4v){pl_u[0], pl_u[1], pl_u[2], pl_u[3]});
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const h8 a_hi = *reinterpret_cast<const h8*>(g3 + ((c * 2 + s) * 64 + lane) * 8);
+                const h8 a_lo = *reinterpret_cast<const h8*>(g3 + kBwdFragHalves + ((c * 2 + s) * 64 + lane) * 8);
+                dx[c] = GNERF_MFMA16(a_hi, p_hi, dx[c]);
+                dx[c] = GNERF_MFMA16(a_hi, p_lo, dx[c]);
+                dx[c] = GNERF_MFMA16(a_lo, p_hi, dx[c]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) *reinterpret_cast<v4f*>(hbuf + j * kHPitch + 16 * m + 4 * g) = dh[m];         // dPRE[sample][hidden]
+        *reinterpret_cast<v4f*>(tbuf + j * kTPitch + 4 * g) = dx[0] * inv_scale;                                   // dX[sample][channel], true units
+        *reinterpret_cast<v4f*>(tbuf + j * kTPitch + 16 + 4 * g) = dx[1] * inv_scale;
+        lds_wave_sync();
+        // ---- dW1[hidden][channel] += dPRE^T X: A = dPRE^T from hbuf, B = X^T from the staged features
+        {
+            float xv[8];
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) xv[4 * c + e] = stage[(4 * g + e) * kStagePitch + 16 * c + j];
+            unsigned xh_u[4], xl_u[4];
+            split_f16x8(xv, xh_u, xl_u);
+#pragma unroll
+            for (int mp = 0; mp < 2; mp++) {
+                float av[8];
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) av[4 * q + e] = hbuf[(4 * g + e) * kHPitch + 16 * (2 * mp + q) + j];
+                unsigned ah_u[4], al_u[4];
+                split_f16x8(av, ah_u, al_u);
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const h4 a_hi = as_h4(ah_u[2 * q], ah_u[2 * q + 1]), a_lo = as_h4(al_u[2 * q], al_u[2 * q + 1]);
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        const h4 b_hi = as_h4(xh_u[2 * c], xh_u[2 * c + 1]), b_lo = as_h4(xl_u[2 * c], xl_u[2 * c + 1]);
+                        v4f acc = A.w1[2 * mp + q][c];
+                        acc = GNERF_MFMA16K16(a_hi, b_hi, acc);
+                        acc = GNERF_MFMA16K16(a_hi, b_lo, acc);
+                        acc = GNERF_MFMA16K16(a_lo, b_hi, acc);
+                        A.w1[2 * mp + q][c] = acc;
+                    }
+                }
+            }
+        }
+    }
+    // the accumulators carry `scale` (and H as H / ln2 where H is a factor): take both off, exactly / in fp32
+    __device__ __forceinline__ void finish(BwdAcc& A) {
+        const float k2 = inv_scale * kLn2;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            A.w1[m][0] *= inv_scale; A.w1[m][1] *= inv_scale; A.b1[m] *= inv_scale;
+            A.w2[0][m] *= k2; A.w2[1][m] *= k2; A.w2s[m] *= k2;
+        }
+        A.b2[0] *= inv_scale; A.b2[1] *= inv_scale; A.b2s *= inv_scale;
+    }
+};
+
+template <class Tile>
+__device__ __forceinline__ void render_bwd_tiles_body(const Params& P, const gnerf_render_grads& Gr, float* stage, float* smem) {
     const gnerf_render_params& p = P.p;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n_all = p.depth_resolution + p.depth_resolution_importance;
-    float* w1 = smem;
-    float* w2 = w1 + 64 * kW1Pitch;
-    float* b1 = w2 + 33 * kW2Pitch;
-    float* b2 = b1 + 64;
-    for (int i = tid; i < 64 * 32; i += kBwdThreads) w1[(i >> 5) * kW1Pitch + (i & 31)] = p.w1[i];
-    for (int i = tid; i < 33 * 64; i += kBwdThreads) w2[(i >> 6) * kW2Pitch + (i & 63)] = p.w2[i];
-    if (tid < 64) b1[tid] = p.b1[tid];
-    if (tid < 36) b2[tid] = tid < 33 ? p.b2[tid] : 0.f;
-    __syncthreads();
+    const float* tail = stage + int64_t(P.total_rays) * P.bwd_ray_stride;
+    Tile K;
+    K.setup(P, smem, tail, tid);
+    float* base = smem + bwd_tiles_weight_floats() + size_t(wv) * bwd_tiles_wave_floats();
     BwdLds L = {};
-    L.w1 = w1; L.w2 = w2; L.b1 = b1; L.b2 = b2;
-    float* base = smem + kBwdWeightFloats + size_t(wv) * bwd_tiles_wave_floats();
     L.stage = base; L.tbuf = L.stage + 16 * kStagePitch; L.hbuf = L.tbuf + 16 * kTPitch;
+    if constexpr (Tile::kMlp == kMlpF32) { K.L.stage = L.stage; K.L.tbuf = L.tbuf; K.L.hbuf = L.hbuf; }
+    else { K.stage = L.stage; K.tbuf = L.tbuf; K.hbuf = L.hbuf; }
     float* dep = L.hbuf + 16 * kHPitch;            // [16] depths, [16] colour weights, [16] dL/dsigma of the tile
     float* vw = dep + 16;
     float* dsg = vw + 16;
@@ -662,7 +980,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_tiles_kernel(Params
 #pragma unroll
     for (int m = 0; m < 4; m++) A.w1[m][0] = A.w1[m][1] = A.w2[0][m] = A.w2[1][m] = A.w2s[m] = A.b1[m] = (v4f){0.f, 0.f, 0.f, 0.f};
     A.b2[0] = A.b2[1] = A.b2s = 0.f;
-    const int j = lane & 15, g = lane >> 4;
+    const int j = lane & 15;
     const int64_t plane_floats = int64_t(3) * p.plane_h * p.plane_w * 32;
     // tiles of the locality-ordered ray sequence (pipe_seq_to_ray): XCD x owns a contiguous eighth (workgroups b, b+8, ... share an
     // XCD), cut into equal contiguous runs for the XCD's waves
@@ -692,24 +1010,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_tiles_kernel(Params
         G[1] = Gr.grad_rgb ? 2.f * Gr.grad_rgb[int64_t(ray) * 32 + 16 + j] : 0.f;
         lds_wave_sync();
         bwd_gather_tile_rolling(P, L, R.planes, DepthListPos{R, dep, P.box_scale}, lane);
-        v4f h[4], o[2];
-        float sig;
-        bwd_mlp_forward(L, lane, h, o, sig);
-        // ---- dO: colour c = 1.002 * s - 0.001 with s = sigmoid(o); dL/dc = G * v_sample  (triplane.py:134, ray_marcher.py:27-45)
-        const v4f vs = *reinterpret_cast<const v4f*>(vw + 4 * g);
-        const float dsig = dsg[j];
-#pragma unroll
-        for (int n = 0; n < 2; n++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float e = __builtin_amdgcn_exp2f(o[n][r] * -1.44269504088896341f);
-                const float s = __builtin_amdgcn_rcpf(1.0f + e);
-                const float d = G[n] * vs[r] * (1.002f * s * (1.f - s));
-                L.tbuf[(4 * g + r) * kTPitch + 16 * n + j] = d;
-                A.b2[n] += d;
-            }
-        }
-        bwd_tile_core(L, h, dsig, A, lane);
+        K.tile(vw, dsg, G, A, lane);
         if (Gr.grad_planes_nhwc) {                                  // the tile's dX rows: 16 x 128 contiguous bytes
             const int half = lane >> 5, ch = lane & 31;
 #pragma unroll
@@ -720,7 +1021,17 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_tiles_kernel(Params
         }
         lds_wave_sync();
     }
+    K.finish(A);
     bwd_reduce_decoder_grads(A, smem, Gr.grad_w1, Gr.grad_b1, Gr.grad_w2, Gr.grad_b2, tid, lane, j);
+}
+
+// decoder arithmetic chosen on the device like the forward's (choose_mlp); P.p.mlp_mode = GNERF_MLP_F32 forces the exact form
+__global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_tiles_kernel(Params P, gnerf_render_grads Gr, float* stage) {
+    extern __shared__ __align__(16) float smem[];
+    int mlp = P.p.mlp_mode;
+    if (mlp == kMlpAuto) mlp = choose_mlp(P, smem);
+    if (mlp == kMlpF32) render_bwd_tiles_body<BwdTileF32>(P, Gr, stage, smem);
+    else                render_bwd_tiles_body<BwdTileF16>(P, Gr, stage, smem);
 }
 
 // ---------------------------------------------------------------------------------------------

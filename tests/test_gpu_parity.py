@@ -1023,11 +1023,14 @@ def test_render_backward_vs_oracle(dev, cfg, monkeypatch):
     nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
     # staged, pipelined first pass + sample-tile kernel (the default where the pipelined kernels cover the sample counts) / staged,
     # one wave per ray (GNERF_BWD_KERNEL=wave; what every other shape runs) / single pass, one atomic per tap and channel
-    for staged, kernel in ((True, None), (True, 'wave'), (False, None)):
-        if kernel:
+    # (GNERF_BWD_MLP=f32: the pipelined path with exact-fp32 products in both kernels, what out-of-range planes / weights select)
+    for staged, kernel in ((True, None), (True, 'f32'), (True, 'wave'), (False, None)):
+        monkeypatch.delenv('GNERF_BWD_KERNEL', raising=False)
+        monkeypatch.delenv('GNERF_BWD_MLP', raising=False)
+        if kernel == 'wave':
             monkeypatch.setenv('GNERF_BWD_KERNEL', kernel)
-        else:
-            monkeypatch.delenv('GNERF_BWD_KERNEL', raising=False)
+        elif kernel == 'f32':
+            monkeypatch.setenv('GNERF_BWD_MLP', 'f32')
         gp, gdec = gnerf_hip.render_backward(nhwc, N, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev) if F else None,
                                              g_rgb.to(dev), g_depth.to(dev), g_wsum.to(dev),
                                              depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0,
@@ -1040,6 +1043,7 @@ def test_render_backward_vs_oracle(dev, cfg, monkeypatch):
             assert _rel(a.cpu(), b) < 2e-3, (name, kernel, _rel(a.cpu(), b))
             assert _rel_l2(a.cpu(), b) < 1e-3, (name, kernel, _rel_l2(a.cpu(), b))
     monkeypatch.delenv('GNERF_BWD_KERNEL', raising=False)
+    monkeypatch.delenv('GNERF_BWD_MLP', raising=False)
     # each input gradient alone (NULL pointers for the others) and planes-only / decoder-only requests
     gp2, none_dec = gnerf_hip.render_backward(nhwc, N, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev) if F else None,
                                               g_rgb.to(dev), None, None, depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3,

@@ -103,6 +103,8 @@
 #define X8M(OP) OP(10, 13) OP(14, 17) OP(18, 21) OP(22, 25) OP(26, 29) OP(30, 33) OP(34, 37) OP(38, 41)
 #define I_MFMA16(a, b) "v_mfma_f32_16x16x32_f16 v[" #a ":" #b "], v[42:45], v[46:49], v[" #a ":" #b "]\n\t"
 #define I_MFMA32(a, b) "v_mfma_f32_16x16x4_f32 v[" #a ":" #b "], v42, v46, v[" #a ":" #b "]\n\t"
+#define I_MFMA16K16(a, b) "v_mfma_f32_16x16x16_f16 v[" #a ":" #b "], v[42:43], v[46:47], v[" #a ":" #b "]\n\t"
+#define I_MULHI(r) "v_mul_hi_u32 v" #r ", v" #r ", v42\n\t"
 // fillers beside the MFMAs write v50..v57 (independent of the accumulators)
 #define F1 "v_fma_f32 v50, v50, v42, v43\n\t"
 #define F2 F1 "v_fma_f32 v51, v51, v42, v43\n\t"
@@ -170,6 +172,8 @@ static const Stream kStreams[] = {
     {"ds_read_b128_bcast", 16, "16 ds_read_b128, all lanes the same address (the key scans)"},
     {"ds_read_b32", 16, "16 ds_read_b32, lane i at 4 i bytes"},
     {"ds_write_b128", 16, "16 ds_write_b128, lane i at 16 i bytes"},
+    {"mfma_f16_16x16x16", 8, "8 independent v_mfma_f32_16x16x16_f16 (the K = 16 form: 4 halves per lane and operand)"},
+    {"v_mul_hi_u32", 32, "32 independent v_mul_hi_u32 (Philox rounds)"},
 };
 constexpr int kNumStreams = sizeof(kStreams) / sizeof(kStreams[0]);
 
@@ -292,6 +296,8 @@ __global__ __launch_bounds__(1024) void probe(int stream, int iters, unsigned lo
                        "ds_read_b32 v22, v58 offset:3072\n\tds_read_b32 v23, v58 offset:3328\n\tds_read_b32 v24, v58 offset:3584\n\tds_read_b32 v25, v58 offset:3840\n\t"
                        "s_waitcnt lgkmcnt(0)\n\t");
         } break;
+        case 82: TIMED_LOOP(X8M(I_MFMA16K16)); break;
+        case 83: TIMED_LOOP(X32(I_MULHI)); break;
         default: {
             const unsigned addr = (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 1024;        // every wave its own 1 KB: no write races that matter
             asm volatile("v_mov_b32 v58, %0" :: "v"(addr) : "v58");
