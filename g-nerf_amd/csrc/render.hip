@@ -1040,8 +1040,6 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
             P.absmax = own;
         }
         P.p.workspace = nullptr;                                   // (the backward's params carry no workspace)
-        // words [1..3] behind the buffer: the maxima the first pass measures for the second pass's f16 scale (render_bwd.inl)
-        if (hipMemsetAsync(g->scatter_stage + size_t(total) * P.bwd_ray_stride + 1, 0, 12, s) != hipSuccess) return fail(GNERF_E_LAUNCH, "render_backward: memset failed");
         P.p.mlp_mode = GNERF_MLP_AUTO;
         if (const char* fm = getenv("GNERF_BWD_MLP")) { if (!strcmp(fm, "f32")) P.p.mlp_mode = GNERF_MLP_F32; else if (!strcmp(fm, "f16x3")) P.p.mlp_mode = GNERF_MLP_F16X3; }
         const int pipe_tp = (P.tiles_c <= 3 && P.tiles_f <= 3) ? 1 : ((P.tiles_c <= 6 && P.tiles_f <= 6) ? 2 : 3);

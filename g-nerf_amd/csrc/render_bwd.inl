@@ -651,10 +651,6 @@ typedef unsigned u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ h4 as_h4(unsigned a, unsigned b) { return __builtin_bit_cast(h4, (u2v){a, b}); }
 #define GNERF_MFMA16K16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0)
 
-// Word layout of the 256 spare bytes behind the exchange / staging buffer (floats): [0] max |planes| when the caller has none,
-// [1] max |dL/d colour sum| over the call, [2] max colour weight, [3] max |dL/dsigma| -- [1..3] as the bit patterns of non-negative floats
-// (unsigned atomicMax), zeroed by the launcher, written by render_kernel_pipe_bwd, read by the f16 form below for its power-of-two scale.
-
 // One 16-sample tile, exact fp32 products (v_mfma_f32_16x16x4_f32): any finite input.
 struct BwdTileF32 {
     static constexpr int kMlp = kMlpF32;
@@ -703,19 +699,23 @@ struct BwdTileF32 {
 // The same tile with every product as an error-compensated f16 hi/lo split on the f16 matrix instructions (fp32 accumulation): the
 // decoder forward as in the forward kernels (24 v_mfma_f32_16x16x32_f16), dH and dX against static hi/lo fragments (12 + 12), the two
 // weight-gradient products -- both operands made at run time, K = the tile's 16 samples -- on v_mfma_f32_16x16x16_f16 (24 + 24): 96
-// matrix instructions of 16.5 SIMD cycles where the fp32 form issues 192 of 32.  Everything on the gradient side (dO, dsigma, dH,
-// dPRE, dX, the weight-gradient accumulators) is carried MULTIPLIED BY `scale`, a power of two chosen per call from the maxima the
-// first pass measured so that the largest |dPRE| possible lands near 2^13: loss gradients of 1e-6 are f16-subnormal unscaled.  The
-// scale comes off, exactly, when dX leaves for the staging buffer and when the accumulators are reduced.  Valid under the same
-// guard as the forward's f16 arithmetic (choose_mlp: features, weights and activations inside f16's range).
+// matrix instructions of 16.5 SIMD cycles where the fp32 form issues 192 of 32.  Loss gradients of 1e-6 are f16-subnormal, and a
+// call's gradients span many orders of magnitude (a ray whose weights sum to 1e-6 sends dL/ddepth / 1e-6 down its samples): every
+// matrix operand of the gradient side (dO, dsigma, dH, dPRE) is therefore carried MULTIPLIED BY A POWER OF TWO CHOSEN PER TILE from
+// the tile's own largest |dO| and |dsigma|, so that the largest |dPRE| possible lands near 2^13.  The scale comes off, exactly, when
+// dX is written; the wave's two matrix-accumulated weight gradients (dW1, dW2: 64 registers) are kept in the units of the CURRENT
+// tile's scale -- when the scale changes from one tile to the next they are multiplied by the ratio, a power of two (exact; fp32 has
+// the range) -- so that the matrix instructions accumulate into them directly.
+// Valid under the same guard as the forward's f16 arithmetic (choose_mlp: features, weights, activations in f16's range).
 struct BwdTileF16 {
     static constexpr int kMlp = kMlpF16x3;
     CoopLds C;                       // the forward's fragments (w1 = fragment base, w2 = density row * ln2, b1 * log2e, b2 scaled)
     const _Float16* g1; const _Float16* g3;
     const float* ws_true;            // W2[0][:]
     float* stage; float* tbuf; float* hbuf;
-    float scale, inv_scale;
-    __device__ __forceinline__ void setup(const Params& P, float* smem, const float* tail, int tid) {
+    float l1_w2c, max_ws;            // max_hid sum_out |W2c[out][hid]|, max |W2[0]|: |dPRE| <= |dH| <= l1_w2c max|dO| + max_ws max|dsigma|
+    float acc_scale;                 // the power of two A.w1 / A.w2 currently carry
+    __device__ __forceinline__ void setup(const Params& P, float* smem, const float*, int tid) {
         const gnerf_render_params& p = P.p;
         stage_decoder<kMlpF16x3>(C, smem, p, tid, kBwdThreads);
         _Float16* gh = reinterpret_cast<_Float16*>(smem + kWeightFloatsF16 + 64 + 36);
@@ -738,20 +738,13 @@ struct BwdTileF16 {
         }
         if (tid < 64) wst[tid] = p.w2[tid];
         __syncthreads();
-        // ---- the call's power-of-two scale.  Bounds: |dO| <= 0.2505 max|G| max v;  |dPRE| <= |dH| <= max_hid sum_out |W2c[out][hid]| max|dO|
-        // + max|W2[0]| max|dsigma|.  Every wave computes the same value from LDS and the three measured maxima.
         const int lane = tid & 63;
         float l1 = 0.f;
         for (int o = 0; o < 32; o++) l1 += fabsf(p.w2[(1 + o) * 64 + lane]);
         float wsm = fabsf(wst[lane]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { l1 = fmaxf(l1, __shfl_xor(l1, o)); wsm = fmaxf(wsm, __shfl_xor(wsm, o)); }
-        const float bo = 0.2505f * tail[1] * tail[2];
-        const float bound = fmaxf(bo, bo * l1 + wsm * tail[3]);
-        int ex = 0;
-        if (bound > 0.f && bound < INFINITY) { (void)frexpf(bound, &ex); ex = min(max(13 - ex, -100), 100); }
-        scale = ldexpf(1.f, ex);
-        inv_scale = ldexpf(1.f, -ex);
+        l1_w2c = l1; max_ws = wsm; acc_scale = 1.f;
     }
     __device__ __forceinline__ void tile(const float* vw, const float* dsg, const float (&G)[2], BwdAcc& A, int lane) {
         const int j = lane & 15, g = lane >> 4;
@@ -791,6 +784,7 @@ struct BwdTileF16 {
             for (int r = 0; r < 4; r++) hv[m][r] = fmaxf(hv[m][r] + e[r], e[r]);
             *reinterpret_cast<v4f*>(hbuf + j * kHPitch + 16 * m + 4 * g) = hv[m];               // H / ln2 as [sample][hidden], for dW2's B operand
         }
+        __builtin_amdgcn_sched_barrier(0);
         v4f o[2];
         {
             const float bc0 = C.b2[1 + j], bc1 = C.b2[17 + j];
@@ -816,24 +810,47 @@ struct BwdTileF16 {
                 }
             }
         }
-        // ---- dO (scaled): colour c = 1.002 s - 0.001, s = sigmoid(o) = 1 / (1 + 2^o'); kept in registers too (A operand of dW2)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dO: colour c = 1.002 s - 0.001, s = sigmoid(o) = 1 / (1 + 2^o'); kept in registers too (A operand of dW2)
         const v4f vs = *reinterpret_cast<const v4f*>(vw + 4 * g);
-        const float dsig = dsg[j] * scale;
-        const float Gs[2] = {G[0] * scale, G[1] * scale};
+        const float dsig_true = dsg[j];
         float dO[8];
+        float big = max_ws * fabsf(dsig_true);
 #pragma unroll
         for (int n = 0; n < 2; n++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(o[n][r]));
-                const float d = Gs[n] * vs[r] * (1.002f * s * (1.f - s));
+                const float d = G[n] * vs[r] * (1.002f * s * (1.f - s));
                 dO[4 * n + r] = d;
-                tbuf[(4 * g + r) * kTPitch + 16 * n + j] = d;
                 A.b2[n] += d;
+                big = fmaxf(big, l1_w2c * fabsf(d));
             }
         }
-        if (g == 0) A.b2s += dsig;
+        if (g == 0) A.b2s += dsig_true;
+        // the tile's scale: |dPRE| <= l1 max|dO| + max_ws max|dsigma| <= 2 max over the lanes of `big`  ->  scaled below 2^13
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) big = fmaxf(big, __shfl_xor(big, o2));
+        int ex = 0;
+        if (big > 0.f && big < INFINITY) { (void)frexpf(big, &ex); ex = min(max(12 - ex, -60), 60); }
+        const float scale = ldexpf(1.f, ex), inv = ldexpf(1.f, -ex);
+        if (scale != acc_scale) {                                   // wave-uniform: bring the matrix accumulators to this tile's units
+            const float ratio = scale * (1.f / acc_scale);          // both powers of two within 2^+-60: exact
+#pragma unroll
+            for (int m = 0; m < 4; m++) { A.w1[m][0] *= ratio; A.w1[m][1] *= ratio; A.w2[0][m] *= ratio; A.w2[1][m] *= ratio; }
+            acc_scale = scale;
+        }
+        const float dsig = dsig_true * scale;
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                dO[4 * n + r] *= scale;
+                tbuf[(4 * g + r) * kTPitch + 16 * n + j] = dO[4 * n + r];
+            }
+        }
         lds_wave_sync();
+        __builtin_amdgcn_sched_barrier(0);
         // ---- dH^T[hidden][sample] = W2c^T dO^T (+ the density row on the vector ALU): B = this lane's sample row of dO, outputs 8g..8g+7
         v4f dh[4];
         {
@@ -847,7 +864,7 @@ struct BwdTileF16 {
             for (int m = 0; m < 4; m++) {
                 const v4f ws = *reinterpret_cast<const v4f*>(ws_true + 16 * m + 4 * g);
                 dh[m] = ws * dsig;
-                A.w2s[m] += hv[m] * dsig;                                                        // (x ln2 at the end)
+                A.w2s[m] += hv[m] * dsig_true;                                                   // (x ln2 at the end)
                 const h8 a_hi = *reinterpret_cast<const h8*>(g1 + (m * 64 + lane) * 8);
                 const h8 a_lo = *reinterpret_cast<const h8*>(g1 + kBwdFragHalves + (m * 64 + lane) * 8);
                 dh[m] = GNERF_MFMA16(a_hi, bh, dh[m]);
@@ -855,6 +872,7 @@ struct BwdTileF16 {
                 dh[m] = GNERF_MFMA16(a_lo, bh, dh[m]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- dW2c[out][hidden] += dO^T (H / ln2): A = the dO values this lane computed (samples 4g..4g+3 of outputs 16o + j), B from hbuf
         {
             unsigned ah_u[4], al_u[4];
@@ -883,14 +901,16 @@ struct BwdTileF16 {
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- through softplus: d/dpre softplus(pre) = 1 - exp(-H) = 1 - 2^-(H / ln2)
 #pragma unroll
         for (int m = 0; m < 4; m++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) dh[m][r] *= 1.f - __builtin_amdgcn_exp2f(-hv[m][r]);
-            A.b1[m] += dh[m];
+            A.b1[m] += dh[m] * inv;
         }
         lds_wave_sync();                                            // every lane has read H from hbuf and its dO row from tbuf
+        __builtin_amdgcn_sched_barrier(0);
         // ---- dX^T[channel][sample] = W1^T dPRE^T: B straight from this lane's dPRE registers (k order of the g3 fragments)
         v4f dx[2];
         dx[0] = dx[1] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -911,9 +931,10 @@ struct BwdTileF16 {
         }
 #pragma unroll
         for (int m = 0; m < 4; m++) *reinterpret_cast<v4f*>(hbuf + j * kHPitch + 16 * m + 4 * g) = dh[m];         // dPRE[sample][hidden]
-        *reinterpret_cast<v4f*>(tbuf + j * kTPitch + 4 * g) = dx[0] * inv_scale;                                   // dX[sample][channel], true units
-        *reinterpret_cast<v4f*>(tbuf + j * kTPitch + 16 + 4 * g) = dx[1] * inv_scale;
+        *reinterpret_cast<v4f*>(tbuf + j * kTPitch + 4 * g) = dx[0] * inv;                                         // dX[sample][channel], true units
+        *reinterpret_cast<v4f*>(tbuf + j * kTPitch + 16 + 4 * g) = dx[1] * inv;
         lds_wave_sync();
+        __builtin_amdgcn_sched_barrier(0);
         // ---- dW1[hidden][channel] += dPRE^T X: A = dPRE^T from hbuf, B = X^T from the staged features
         {
             float xv[8];
@@ -948,15 +969,11 @@ struct BwdTileF16 {
             }
         }
     }
-    // the accumulators carry `scale` (and H as H / ln2 where H is a factor): take both off, exactly / in fp32
+    // the matrix accumulators carry acc_scale, and dW2 was accumulated against H / ln2
     __device__ __forceinline__ void finish(BwdAcc& A) {
-        const float k2 = inv_scale * kLn2;
+        const float k1 = 1.f / acc_scale, k2 = k1 * kLn2;
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            A.w1[m][0] *= inv_scale; A.w1[m][1] *= inv_scale; A.b1[m] *= inv_scale;
-            A.w2[0][m] *= k2; A.w2[1][m] *= k2; A.w2s[m] *= k2;
-        }
-        A.b2[0] *= inv_scale; A.b2[1] *= inv_scale; A.b2s *= inv_scale;
+        for (int m = 0; m < 4; m++) { A.w1[m][0] *= k1; A.w1[m][1] *= k1; A.w2[0][m] *= k2; A.w2[1][m] *= k2; A.w2s[m] *= kLn2; }
     }
 };
 
@@ -1030,8 +1047,14 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_tiles_kernel(Params
     extern __shared__ __align__(16) float smem[];
     int mlp = P.p.mlp_mode;
     if (mlp == kMlpAuto) mlp = choose_mlp(P, smem);
+#if defined(GNERF_K2_ONLY) && GNERF_K2_ONLY == 16
+    render_bwd_tiles_body<BwdTileF16>(P, Gr, stage, smem);
+#elif defined(GNERF_K2_ONLY)
+    render_bwd_tiles_body<BwdTileF32>(P, Gr, stage, smem);
+#else
     if (mlp == kMlpF32) render_bwd_tiles_body<BwdTileF32>(P, Gr, stage, smem);
     else                render_bwd_tiles_body<BwdTileF16>(P, Gr, stage, smem);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

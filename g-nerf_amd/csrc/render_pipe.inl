@@ -168,7 +168,6 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
     DepthRange range;
     float pre_uc[RND] = {}, pre_uf[RND] = {}, pre_ray = 0.f, pre_rs = 0.f, pre_re = 0.f;       // prefetched by propose_issue
     float pre_g = 0.f;                                                                         // BWD: dL/d(colour sum) [0..31], dL/ddepth [32], dL/dwsum [33]
-    float bwd_mx_g = 0.f, bwd_mx_v = 0.f, bwd_mx_d = 0.f;                                      // BWD: running maxima for the second kernel's f16 scale
     int pre_ray_id = -1;
 
     float* const unit_rays = L.taps + 3 * 16 * kStagePitch;        // GEN: [kPipeUnit][8] origin, direction of the current dealing unit's rays
@@ -219,7 +218,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
         if (!FULL && p.ray_start_per_ray) { pre_rs = p.ray_start_per_ray[ray]; pre_re = p.ray_end_per_ray[ray]; }
         if constexpr (BWD) {        // the ray's incoming gradients: rgb = 2 * composite - 1 (ray_marcher.py:55), depth, weight sum
             pre_g = 0.f;
-            if (lane < 32) { if (Gr->grad_rgb) pre_g = 2.f * Gr->grad_rgb[ray * 32 + lane]; bwd_mx_g = fmaxf(bwd_mx_g, fabsf(pre_g)); }
+            if (lane < 32) { if (Gr->grad_rgb) pre_g = 2.f * Gr->grad_rgb[ray * 32 + lane]; }
             else if (lane == 32) { if (Gr->grad_depth) pre_g = Gr->grad_depth[ray]; }
             else if (lane == 33) { if (Gr->grad_wsum) pre_g = Gr->grad_wsum[ray]; }
         }
@@ -524,10 +523,8 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
                 const float dl = r > 0 ? ds[r - 1] : 0.f, dr = r < n_int ? ds[r] : 0.f;
                 ray_block[r] = sl.s_t[r];
                 float* tile_rows = ray_block + n_all + (r >> 4) * P.bwd_tile_pitch;
-                const float v_r = (wl + wr) * 0.5f, dsig_r = (dl + dr) * 0.5f;
-                tile_rows[r & 15] = v_r;                         // colour of sample r enters intervals r-1 and r with weight 1/2 each
-                tile_rows[16 + (r & 15)] = dsig_r;               // so does its density
-                bwd_mx_v = fmaxf(bwd_mx_v, v_r); bwd_mx_d = fmaxf(bwd_mx_d, fabsf(dsig_r));
+                tile_rows[r & 15] = (wl + wr) * 0.5f;            // colour of sample r enters intervals r-1 and r with weight 1/2 each
+                tile_rows[16 + (r & 15)] = (dl + dr) * 0.5f;     // so does its density
             }
             return;
         }
@@ -675,16 +672,6 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
                 importance(k + 1);
                 propose_finish(k + 2);
                 __syncthreads();
-            }
-            // this workgroup's maxima -> the spare words behind the buffer (non-negative floats order like their bit patterns; a NaN
-            // anywhere is dropped by fmaxf, which only makes the scale larger -- the f16 products then saturate where the fp32 ones are NaN)
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                bwd_mx_g = fmaxf(bwd_mx_g, __shfl_xor(bwd_mx_g, o)); bwd_mx_v = fmaxf(bwd_mx_v, __shfl_xor(bwd_mx_v, o)); bwd_mx_d = fmaxf(bwd_mx_d, __shfl_xor(bwd_mx_d, o));
-            }
-            if (lane == 0) {
-                unsigned* tail = reinterpret_cast<unsigned*>(bstage + int64_t(P.total_rays) * P.bwd_ray_stride);
-                atomicMax(tail + 1, __float_as_uint(bwd_mx_g)); atomicMax(tail + 2, __float_as_uint(bwd_mx_v)); atomicMax(tail + 3, __float_as_uint(bwd_mx_d));
             }
         }
         return;
