@@ -1042,6 +1042,9 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
         P.p.workspace = nullptr;                                   // (the backward's params carry no workspace)
         P.p.mlp_mode = GNERF_MLP_AUTO;
         if (const char* fm = getenv("GNERF_BWD_MLP")) { if (!strcmp(fm, "f32")) P.p.mlp_mode = GNERF_MLP_F32; else if (!strcmp(fm, "f16x3")) P.p.mlp_mode = GNERF_MLP_F16X3; }
+        Params P2 = P;                                              // (A/B: GNERF_BWD_MLP_K1 / _K2 force one kernel's arithmetic only)
+        if (const char* fm = getenv("GNERF_BWD_MLP_K1")) P.p.mlp_mode = !strcmp(fm, "f32") ? GNERF_MLP_F32 : GNERF_MLP_F16X3;
+        if (const char* fm = getenv("GNERF_BWD_MLP_K2")) P2.p.mlp_mode = !strcmp(fm, "f32") ? GNERF_MLP_F32 : GNERF_MLP_F16X3;
         const int pipe_tp = (P.tiles_c <= 3 && P.tiles_f <= 3) ? 1 : ((P.tiles_c <= 6 && P.tiles_f <= 6) ? 2 : 3);
         const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : total;
         const int per_cu = pipe_tp == 1 ? GNERF_PIPE_WAVES_PER_SIMD : (pipe_tp == 2 ? GNERF_PIPE2_WAVES_PER_SIMD : 2);
@@ -1067,7 +1070,8 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
         int64_t g2 = (sample_tiles + kBwdWaves - 1) / kBwdWaves;
         if (g2 > int64_t(kNumCU) * 2) g2 = int64_t(kNumCU) * 2;    // two workgroups of four waves per CU, each walking a contiguous run of tiles
         g2 = (g2 + kNumXCD - 1) / kNumXCD * kNumXCD;
-        hipLaunchKernelGGL(render_bwd_tiles_kernel, dim3((unsigned)g2), dim3(kBwdThreads), lds2, s, P, *g, g->scatter_stage);
+        P2.pipe_unit = P.pipe_unit;
+        hipLaunchKernelGGL(render_bwd_tiles_kernel, dim3((unsigned)g2), dim3(kBwdThreads), lds2, s, P2, *g, g->scatter_stage);
         if (int e = check_launch("render_bwd_tiles_kernel")) return e;
     } else {
     if (staged) hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(per_xcd * kNumXCD), dim3(kBwdThreads), lds_bytes, as_stream(stream), P, *g, g->scatter_stage);

@@ -794,7 +794,7 @@ struct BwdTileF16 {
             for (int s = 0; s < 2; s++) {
                 unsigned xh[4], xl[4];
                 const float xs[8] = {hv[2 * s][0], hv[2 * s][1], hv[2 * s][2], hv[2 * s][3], hv[2 * s + 1][0], hv[2 * s + 1][1], hv[2 * s + 1][2], hv[2 * s + 1][3]};
-                split_f16x8(xs, xh, xl);
+                split_f16x8_after_mfma(xs, xh, xl);
                 x_hi[s] = as_h8((u4v){xh[0], xh[1], xh[2], xh[3]});
                 x_lo[s] = as_h8((u4v){xl[0], xl[1], xl[2], xl[3]});
             }
@@ -858,7 +858,7 @@ struct BwdTileF16 {
             const v4f b_hi4 = *reinterpret_cast<const v4f*>(tbuf + j * kTPitch + 8 * g + 4);
             const float bv[8] = {b_lo4[0], b_lo4[1], b_lo4[2], b_lo4[3], b_hi4[0], b_hi4[1], b_hi4[2], b_hi4[3]};
             unsigned bh_u[4], bl_u[4];
-            split_f16x8(bv, bh_u, bl_u);
+            split_f16x8_after_mfma(bv, bh_u, bl_u);
             const h8 bh = as_h8((u4v){bh_u[0], bh_u[1], bh_u[2], bh_u[3]}), bl = as_h8((u4v){bl_u[0], bl_u[1], bl_u[2], bl_u[3]});
 #pragma unroll
             for (int m = 0; m < 4; m++) {
@@ -876,7 +876,7 @@ struct BwdTileF16 {
         // ---- dW2c[out][hidden] += dO^T (H / ln2): A = the dO values this lane computed (samples 4g..4g+3 of outputs 16o + j), B from hbuf
         {
             unsigned ah_u[4], al_u[4];
-            split_f16x8(dO, ah_u, al_u);
+            split_f16x8_after_mfma(dO, ah_u, al_u);
 #pragma unroll
             for (int np = 0; np < 2; np++) {                       // hidden blocks 2 np, 2 np + 1
                 float bvals[8];
@@ -885,7 +885,7 @@ struct BwdTileF16 {
 #pragma unroll
                     for (int e = 0; e < 4; e++) bvals[4 * q + e] = hbuf[(4 * g + e) * kHPitch + 16 * (2 * np + q) + j];
                 unsigned bh_u[4], bl_u[4];
-                split_f16x8(bvals, bh_u, bl_u);
+                split_f16x8_after_mfma(bvals, bh_u, bl_u);
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const h4 b_hi = as_h4(bh_u[2 * q], bh_u[2 * q + 1]), b_lo = as_h4(bl_u[2 * q], bl_u[2 * q + 1]);
@@ -918,7 +918,7 @@ struct BwdTileF16 {
         for (int s = 0; s < 2; s++) {
             const float pv[8] = {dh[2 * s][0], dh[2 * s][1], dh[2 * s][2], dh[2 * s][3], dh[2 * s + 1][0], dh[2 * s + 1][1], dh[2 * s + 1][2], dh[2 * s + 1][3]};
             unsigned ph_u[4], pl_u[4];
-            split_f16x8(pv, ph_u, pl_u);
+            split_f16x8_after_mfma(pv, ph_u, pl_u);
             const h8 p_hi = as_h8((u4v){ph_u[0], ph_u[1], ph_u[2], ph_u[3]}), p_lo = as_h8((u4v){pl_u[0], pl_u[1], pl_u[2], pl_u[3]});
 #pragma unroll
             for (int c = 0; c < 2; c++) {
@@ -943,7 +943,7 @@ struct BwdTileF16 {
 #pragma unroll
                 for (int e = 0; e < 4; e++) xv[4 * c + e] = stage[(4 * g + e) * kStagePitch + 16 * c + j];
             unsigned xh_u[4], xl_u[4];
-            split_f16x8(xv, xh_u, xl_u);
+            split_f16x8_after_mfma(xv, xh_u, xl_u);
 #pragma unroll
             for (int mp = 0; mp < 2; mp++) {
                 float av[8];
@@ -952,7 +952,7 @@ struct BwdTileF16 {
 #pragma unroll
                     for (int e = 0; e < 4; e++) av[4 * q + e] = hbuf[(4 * g + e) * kHPitch + 16 * (2 * mp + q) + j];
                 unsigned ah_u[4], al_u[4];
-                split_f16x8(av, ah_u, al_u);
+                split_f16x8_after_mfma(av, ah_u, al_u);
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const h4 a_hi = as_h4(ah_u[2 * q], ah_u[2 * q + 1]), a_lo = as_h4(al_u[2 * q], al_u[2 * q + 1]);

@@ -41,28 +41,36 @@ constexpr float kLog2e = 1.44269504088896341f, kLn2 = 0.693147180559945309f;
 // 4.25 for the conversion: 86 -> 69 cycles per split (the compiler's own lowering of the expression is thirty-two instructions).
 // ONE asm block, ending in s_nop 1: the consumers are MFMAs, which need two wait states after a VALU write of an operand,
 // and the compiler's hazard recogniser does not look inside inline asm.
-__device__ __forceinline__ void split_f16x8(const float (&x)[8], unsigned (&hi)[4], unsigned (&lo)[4]) {
-    float y0 = x[0], y1 = x[1], y2 = x[2], y3 = x[3], y4 = x[4], y5 = x[5], y6 = x[6], y7 = x[7];       // x - hi is formed in place
-    asm("v_cvt_pk_f16_f32 %0, %8, %9\n\t"
-        "v_cvt_pk_f16_f32 %1, %10, %11\n\t"
-        "v_cvt_pk_f16_f32 %2, %12, %13\n\t"
-        "v_cvt_pk_f16_f32 %3, %14, %15\n\t"
-        "v_fma_mix_f32 %8, %0, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %9, %0, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %10, %1, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %11, %1, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %12, %2, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %13, %2, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %14, %3, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %15, %3, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_cvt_pk_f16_f32 %4, %8, %9\n\t"
-        "v_cvt_pk_f16_f32 %5, %10, %11\n\t"
-        "v_cvt_pk_f16_f32 %6, %12, %13\n\t"
-        "v_cvt_pk_f16_f32 %7, %14, %15\n\t"
-        "s_nop 1"
-        : "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]),
-          "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7));
-}
+#define GNERF_SPLIT_BODY(HEAD)                                                                                                          \
+    float y0 = x[0], y1 = x[1], y2 = x[2], y3 = x[3], y4 = x[4], y5 = x[5], y6 = x[6], y7 = x[7];       /* x - hi is formed in place */   \
+    asm(HEAD                                                                                                                            \
+        "v_cvt_pk_f16_f32 %0, %8, %9\n\t"                                                                                               \
+        "v_cvt_pk_f16_f32 %1, %10, %11\n\t"                                                                                             \
+        "v_cvt_pk_f16_f32 %2, %12, %13\n\t"                                                                                             \
+        "v_cvt_pk_f16_f32 %3, %14, %15\n\t"                                                                                             \
+        "v_fma_mix_f32 %8, %0, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                                                           \
+        "v_fma_mix_f32 %9, %0, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                                                           \
+        "v_fma_mix_f32 %10, %1, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                                                         \
+        "v_fma_mix_f32 %11, %1, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                                                         \
+        "v_fma_mix_f32 %12, %2, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                                                         \
+        "v_fma_mix_f32 %13, %2, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                                                         \
+        "v_fma_mix_f32 %14, %3, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"                                                         \
+        "v_fma_mix_f32 %15, %3, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                                                         \
+        "v_cvt_pk_f16_f32 %4, %8, %9\n\t"                                                                                               \
+        "v_cvt_pk_f16_f32 %5, %10, %11\n\t"                                                                                             \
+        "v_cvt_pk_f16_f32 %6, %12, %13\n\t"                                                                                             \
+        "v_cvt_pk_f16_f32 %7, %14, %15\n\t"                                                                                             \
+        "s_nop 1"                                                                                                                       \
+        : "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]),               \
+          "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7))
+__device__ __forceinline__ void split_f16x8(const float (&x)[8], unsigned (&hi)[4], unsigned (&lo)[4]) { GNERF_SPLIT_BODY(""); }
+// The same split where matrix instructions may still be in flight whose A / B operands sit in the registers this split is about to
+// write: the compiler's hazard recogniser does not see inside inline asm, and the register allocator happily hands the split of loop
+// iteration s + 1 the operand registers of iteration s's MFMAs (the backward tile kernel's k-step loops).  A 4-pass MFMA reads its
+// operands while it executes; overwriting them early showed up as one wrong tile in ~1e5 (gradients off by 1e-3 of their largest
+// entry, on some runs only: tools/dbg_bwd_det.py).  Sixteen wait states in front, inside the same asm block, cover the instruction.
+__device__ __forceinline__ void split_f16x8_after_mfma(const float (&x)[8], unsigned (&hi)[4], unsigned (&lo)[4]) { GNERF_SPLIT_BODY("s_nop 7\n\ts_nop 7\n\t"); }
+#undef GNERF_SPLIT_BODY
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ h8 as_h8(u4v v) { return __builtin_bit_cast(h8, v); }
 // LDS layouts that a lane (j = lane & 15, g = lane >> 4) reads 16 bytes of are kept in FRAGMENT ORDER: the chunk of lane i at
