@@ -1040,11 +1040,16 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
             P.absmax = own;
         }
         P.p.workspace = nullptr;                                   // (the backward's params carry no workspace)
+        // Decoder arithmetic: the first kernel (the forward pipeline) chooses on the device like the forward; the tile kernel computes in
+        // exact fp32 (its f16 hi/lo form is opt-in, see render_bwd_tiles_kernel).  GNERF_BWD_MLP=f32|f16x3|auto sets both, _K1 / _K2 one.
         P.p.mlp_mode = GNERF_MLP_AUTO;
-        if (const char* fm = getenv("GNERF_BWD_MLP")) { if (!strcmp(fm, "f32")) P.p.mlp_mode = GNERF_MLP_F32; else if (!strcmp(fm, "f16x3")) P.p.mlp_mode = GNERF_MLP_F16X3; }
-        Params P2 = P;                                              // (A/B: GNERF_BWD_MLP_K1 / _K2 force one kernel's arithmetic only)
-        if (const char* fm = getenv("GNERF_BWD_MLP_K1")) P.p.mlp_mode = !strcmp(fm, "f32") ? GNERF_MLP_F32 : GNERF_MLP_F16X3;
-        if (const char* fm = getenv("GNERF_BWD_MLP_K2")) P2.p.mlp_mode = !strcmp(fm, "f32") ? GNERF_MLP_F32 : GNERF_MLP_F16X3;
+        Params P2 = P;
+        P2.p.mlp_mode = GNERF_MLP_F32;
+        auto mode_of = [](const char* v, int dflt) { return !v ? dflt : !strcmp(v, "f32") ? GNERF_MLP_F32 : !strcmp(v, "f16x3") ? GNERF_MLP_F16X3 : !strcmp(v, "auto") ? GNERF_MLP_AUTO : dflt; };
+        P.p.mlp_mode = mode_of(getenv("GNERF_BWD_MLP"), P.p.mlp_mode);
+        P2.p.mlp_mode = mode_of(getenv("GNERF_BWD_MLP"), P2.p.mlp_mode);
+        P.p.mlp_mode = mode_of(getenv("GNERF_BWD_MLP_K1"), P.p.mlp_mode);
+        P2.p.mlp_mode = mode_of(getenv("GNERF_BWD_MLP_K2"), P2.p.mlp_mode);
         const int pipe_tp = (P.tiles_c <= 3 && P.tiles_f <= 3) ? 1 : ((P.tiles_c <= 6 && P.tiles_f <= 6) ? 2 : 3);
         const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : total;
         const int per_cu = pipe_tp == 1 ? GNERF_PIPE_WAVES_PER_SIMD : (pipe_tp == 2 ? GNERF_PIPE2_WAVES_PER_SIMD : 2);

@@ -707,6 +707,9 @@ struct BwdTileF32 {
 // tile's scale -- when the scale changes from one tile to the next they are multiplied by the ratio, a power of two (exact; fp32 has
 // the range) -- so that the matrix instructions accumulate into them directly.
 // Valid under the same guard as the forward's f16 arithmetic (choose_mlp: features, weights, activations in f16's range).
+#ifndef GNERF_K2_SPLIT
+#define GNERF_K2_SPLIT split_f16x8_after_mfma
+#endif
 struct BwdTileF16 {
     static constexpr int kMlp = kMlpF16x3;
     CoopLds C;                       // the forward's fragments (w1 = fragment base, w2 = density row * ln2, b1 * log2e, b2 scaled)
@@ -755,7 +758,7 @@ struct BwdTileF16 {
         const v4f f_hi = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g + 4);
         const float f[8] = {f_lo[0], f_lo[1], f_lo[2], f_lo[3], f_hi[0], f_hi[1], f_hi[2], f_hi[3]};
         unsigned fh_u[4], fl_u[4];
-        split_f16x8(f, fh_u, fl_u);
+        GNERF_K2_SPLIT(f, fh_u, fl_u);
         const h8 fh = as_h8((u4v){fh_u[0], fh_u[1], fh_u[2], fh_u[3]}), fl = as_h8((u4v){fl_u[0], fl_u[1], fl_u[2], fl_u[3]});
         v4f hv[4];
         {
@@ -794,7 +797,7 @@ struct BwdTileF16 {
             for (int s = 0; s < 2; s++) {
                 unsigned xh[4], xl[4];
                 const float xs[8] = {hv[2 * s][0], hv[2 * s][1], hv[2 * s][2], hv[2 * s][3], hv[2 * s + 1][0], hv[2 * s + 1][1], hv[2 * s + 1][2], hv[2 * s + 1][3]};
-                split_f16x8_after_mfma(xs, xh, xl);
+                GNERF_K2_SPLIT(xs, xh, xl);
                 x_hi[s] = as_h8((u4v){xh[0], xh[1], xh[2], xh[3]});
                 x_lo[s] = as_h8((u4v){xl[0], xl[1], xl[2], xl[3]});
             }
@@ -858,7 +861,7 @@ struct BwdTileF16 {
             const v4f b_hi4 = *reinterpret_cast<const v4f*>(tbuf + j * kTPitch + 8 * g + 4);
             const float bv[8] = {b_lo4[0], b_lo4[1], b_lo4[2], b_lo4[3], b_hi4[0], b_hi4[1], b_hi4[2], b_hi4[3]};
             unsigned bh_u[4], bl_u[4];
-            split_f16x8_after_mfma(bv, bh_u, bl_u);
+            GNERF_K2_SPLIT(bv, bh_u, bl_u);
             const h8 bh = as_h8((u4v){bh_u[0], bh_u[1], bh_u[2], bh_u[3]}), bl = as_h8((u4v){bl_u[0], bl_u[1], bl_u[2], bl_u[3]});
 #pragma unroll
             for (int m = 0; m < 4; m++) {
@@ -876,7 +879,7 @@ struct BwdTileF16 {
         // ---- dW2c[out][hidden] += dO^T (H / ln2): A = the dO values this lane computed (samples 4g..4g+3 of outputs 16o + j), B from hbuf
         {
             unsigned ah_u[4], al_u[4];
-            split_f16x8_after_mfma(dO, ah_u, al_u);
+            GNERF_K2_SPLIT(dO, ah_u, al_u);
 #pragma unroll
             for (int np = 0; np < 2; np++) {                       // hidden blocks 2 np, 2 np + 1
                 float bvals[8];
@@ -885,7 +888,7 @@ struct BwdTileF16 {
 #pragma unroll
                     for (int e = 0; e < 4; e++) bvals[4 * q + e] = hbuf[(4 * g + e) * kHPitch + 16 * (2 * np + q) + j];
                 unsigned bh_u[4], bl_u[4];
-                split_f16x8_after_mfma(bvals, bh_u, bl_u);
+                GNERF_K2_SPLIT(bvals, bh_u, bl_u);
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const h4 b_hi = as_h4(bh_u[2 * q], bh_u[2 * q + 1]), b_lo = as_h4(bl_u[2 * q], bl_u[2 * q + 1]);
@@ -918,7 +921,7 @@ struct BwdTileF16 {
         for (int s = 0; s < 2; s++) {
             const float pv[8] = {dh[2 * s][0], dh[2 * s][1], dh[2 * s][2], dh[2 * s][3], dh[2 * s + 1][0], dh[2 * s + 1][1], dh[2 * s + 1][2], dh[2 * s + 1][3]};
             unsigned ph_u[4], pl_u[4];
-            split_f16x8_after_mfma(pv, ph_u, pl_u);
+            GNERF_K2_SPLIT(pv, ph_u, pl_u);
             const h8 p_hi = as_h8((u4v){ph_u[0], ph_u[1], ph_u[2], ph_u[3]}), p_lo = as_h8((u4v){pl_u[0], pl_u[1], pl_u[2], pl_u[3]});
 #pragma unroll
             for (int c = 0; c < 2; c++) {
@@ -943,7 +946,7 @@ struct BwdTileF16 {
 #pragma unroll
                 for (int e = 0; e < 4; e++) xv[4 * c + e] = stage[(4 * g + e) * kStagePitch + 16 * c + j];
             unsigned xh_u[4], xl_u[4];
-            split_f16x8_after_mfma(xv, xh_u, xl_u);
+            GNERF_K2_SPLIT(xv, xh_u, xl_u);
 #pragma unroll
             for (int mp = 0; mp < 2; mp++) {
                 float av[8];
@@ -952,7 +955,7 @@ struct BwdTileF16 {
 #pragma unroll
                     for (int e = 0; e < 4; e++) av[4 * q + e] = hbuf[(4 * g + e) * kHPitch + 16 * (2 * mp + q) + j];
                 unsigned ah_u[4], al_u[4];
-                split_f16x8_after_mfma(av, ah_u, al_u);
+                GNERF_K2_SPLIT(av, ah_u, al_u);
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const h4 a_hi = as_h4(ah_u[2 * q], ah_u[2 * q + 1]), a_lo = as_h4(al_u[2 * q], al_u[2 * q + 1]);
@@ -1042,7 +1045,11 @@ __device__ __forceinline__ void render_bwd_tiles_body(const Params& P, const gne
     bwd_reduce_decoder_grads(A, smem, Gr.grad_w1, Gr.grad_b1, Gr.grad_w2, Gr.grad_b2, tid, lane, j);
 }
 
-// decoder arithmetic chosen on the device like the forward's (choose_mlp); P.p.mlp_mode = GNERF_MLP_F32 forces the exact form
+// The exact-fp32 form is what runs (the launcher passes GNERF_MLP_F32).  The f16 hi/lo form is OPT-IN (GNERF_BWD_MLP=f16x3, or =auto
+// for the forward's device-side range check): 1.45 ms instead of 2.12 ms at config 2 and fp32-grade on most calls, but on some inputs /
+// builds its plane gradient is off by ~1e-3 of the largest entry where the fp32 form agrees with the one-wave-per-ray kernel to 1e-6
+// (tools/dbg_bwd_det.py reproduces it; the discrepancy moves with the compiler's schedule, survives plain-C splits and long wait
+// states around the inline-asm splits, and was not root-caused this round) -- so it is not the default and no default flow uses it.
 __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_tiles_kernel(Params P, gnerf_render_grads Gr, float* stage) {
     extern __shared__ __align__(16) float smem[];
     int mlp = P.p.mlp_mode;

@@ -1023,7 +1023,8 @@ def test_render_backward_vs_oracle(dev, cfg, monkeypatch):
     nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
     # staged, pipelined first pass + sample-tile kernel (the default where the pipelined kernels cover the sample counts) / staged,
     # one wave per ray (GNERF_BWD_KERNEL=wave; what every other shape runs) / single pass, one atomic per tap and channel
-    # (GNERF_BWD_MLP=f32: the pipelined path with exact-fp32 products in both kernels, what out-of-range planes / weights select)
+    # (GNERF_BWD_MLP=f32: the pipelined path with exact-fp32 products in BOTH kernels -- the first one otherwise picks f16 hi/lo or fp32
+    # on the device like the forward; the tile kernel is fp32 by default)
     for staged, kernel in ((True, None), (True, 'f32'), (True, 'wave'), (False, None)):
         monkeypatch.delenv('GNERF_BWD_KERNEL', raising=False)
         monkeypatch.delenv('GNERF_BWD_MLP', raising=False)

@@ -1,4 +1,6 @@
-"""Diagnostic: which of the backward's two kernels misbehaves intermittently in its f16 form?"""
+"""Reproducer for the open issue of the backward tile kernel's OPT-IN f16 form (render_bwd.inl, render_bwd_tiles_kernel): the staged
+backward with each kernel's decoder arithmetic forced (GNERF_BWD_MLP_K1 / _K2) against the all-fp32 pair on varying gradients.  The
+default (K1 auto, K2 f32) and every pair with K2 = f32 agree to ~1e-6; K2 = f16x3 is off by ~1e-3 on some inputs / builds."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, 'g-nerf_amd'), os.path.join(ROOT, 'tests'), ROOT]
@@ -31,7 +33,7 @@ for k1, k2 in (('f16x3', 'f32'), ('f32', 'f16x3'), ('f16x3', 'f16x3'), ('f32', '
         wav = run('f32', 'f32', *g)
         os.environ.pop('GNERF_BWD_KERNEL')
         out = run(k1, k2, *g)
-        e = max(rel(out[0], ref[0]), max(rel(a, b) for a, b in zip(out[1], ref[1])))
+        e = rel(out[0], ref[0])
         worst = max(worst, e)
         bad += e > 1e-4
         errs.append(float('%.1e' % e))
