@@ -1068,7 +1068,9 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
             hipLaunchKernelGGL(render_kernel_pipe_bwd<3>, dim3((unsigned)gsz), dim3(kPipeThreads), lds1, s, P, *g, g->scatter_stage);
         }
         if (int e = check_launch("render_kernel_pipe_bwd")) return e;
-        const size_t lds2 = (bwd_tiles_weight_floats() + kBwdWaves * bwd_tiles_wave_floats()) * sizeof(float);
+        // (GNERF_BWD_LDS_PAD: extra dynamic LDS per workgroup -- 27000 leaves ONE workgroup per CU, the setting under which the opt-in f16
+        // form of the tile kernel has shown no discrepancy; see render_bwd_tiles_kernel)
+        const size_t lds2 = (bwd_tiles_weight_floats() + kBwdWaves * bwd_tiles_wave_floats()) * sizeof(float) + (getenv("GNERF_BWD_LDS_PAD") ? size_t(atoi(getenv("GNERF_BWD_LDS_PAD"))) : 0);
         static PerDeviceOnce once_tiles;
         if (int e = once_tiles.raise_lds(render_bwd_tiles_kernel, "render_backward")) return e;
         const int64_t sample_tiles = total_seq * ((n_all + 15) / 16);

@@ -710,6 +710,15 @@ struct BwdTileF32 {
 #ifndef GNERF_K2_SPLIT
 #define GNERF_K2_SPLIT split_f16x8_after_mfma
 #endif
+#define GNERF_K2_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef GNERF_K2_SPLIT
+#define GNERF_K2_SPLIT split_f16x8_after_mfma
+#endif
+#ifdef GNERF_K2_FENCES          // hazard hunt: a full stop between the phases of the f16 tile
+#define GNERF_K2_PHASE_FENCE() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory")
+#else
+#define GNERF_K2_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 struct BwdTileF16 {
     static constexpr int kMlp = kMlpF16x3;
     CoopLds C;                       // the forward's fragments (w1 = fragment base, w2 = density row * ln2, b1 * log2e, b2 scaled)
@@ -787,7 +796,7 @@ struct BwdTileF16 {
             for (int r = 0; r < 4; r++) hv[m][r] = fmaxf(hv[m][r] + e[r], e[r]);
             *reinterpret_cast<v4f*>(hbuf + j * kHPitch + 16 * m + 4 * g) = hv[m];               // H / ln2 as [sample][hidden], for dW2's B operand
         }
-        __builtin_amdgcn_sched_barrier(0);
+        GNERF_K2_PHASE_FENCE();
         v4f o[2];
         {
             const float bc0 = C.b2[1 + j], bc1 = C.b2[17 + j];
@@ -813,7 +822,7 @@ struct BwdTileF16 {
                 }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        GNERF_K2_PHASE_FENCE();
         // ---- dO: colour c = 1.002 s - 0.001, s = sigmoid(o) = 1 / (1 + 2^o'); kept in registers too (A operand of dW2)
         const v4f vs = *reinterpret_cast<const v4f*>(vw + 4 * g);
         const float dsig_true = dsg[j];
@@ -832,10 +841,17 @@ struct BwdTileF16 {
         }
         if (g == 0) A.b2s += dsig_true;
         // the tile's scale: |dPRE| <= l1 max|dO| + max_ws max|dsigma| <= 2 max over the lanes of `big`  ->  scaled below 2^13
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) big = fmaxf(big, __shfl_xor(big, o2));
+        // wave maximum of non-negative values on the DPP network (the forward kernels' scan idiom; lane 63 ends up with the maximum)
+        big = fmaxf(big, dpp_mov<0x111, 0xf>(0.f, big));
+        big = fmaxf(big, dpp_mov<0x112, 0xf>(0.f, big));
+        big = fmaxf(big, dpp_mov<0x114, 0xf>(0.f, big));
+        big = fmaxf(big, dpp_mov<0x118, 0xf>(0.f, big));
+        big = fmaxf(big, dpp_mov<0x142, 0xa>(0.f, big));
+        big = fmaxf(big, dpp_mov<0x143, 0xc>(0.f, big));
+        big = wave_last(big);
         int ex = 0;
         if (big > 0.f && big < INFINITY) { (void)frexpf(big, &ex); ex = min(max(12 - ex, -60), 60); }
+        ex = __builtin_amdgcn_readfirstlane(ex);                    // one value for the wave, whatever the lanes think
         const float scale = ldexpf(1.f, ex), inv = ldexpf(1.f, -ex);
         if (scale != acc_scale) {                                   // wave-uniform: bring the matrix accumulators to this tile's units
             const float ratio = scale * (1.f / acc_scale);          // both powers of two within 2^+-60: exact
@@ -853,7 +869,7 @@ struct BwdTileF16 {
             }
         }
         lds_wave_sync();
-        __builtin_amdgcn_sched_barrier(0);
+        GNERF_K2_PHASE_FENCE();
         // ---- dH^T[hidden][sample] = W2c^T dO^T (+ the density row on the vector ALU): B = this lane's sample row of dO, outputs 8g..8g+7
         v4f dh[4];
         {
@@ -875,7 +891,7 @@ struct BwdTileF16 {
                 dh[m] = GNERF_MFMA16(a_lo, bh, dh[m]);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        GNERF_K2_PHASE_FENCE();
         // ---- dW2c[out][hidden] += dO^T (H / ln2): A = the dO values this lane computed (samples 4g..4g+3 of outputs 16o + j), B from hbuf
         {
             unsigned ah_u[4], al_u[4];
@@ -904,7 +920,7 @@ struct BwdTileF16 {
                 }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        GNERF_K2_PHASE_FENCE();
         // ---- through softplus: d/dpre softplus(pre) = 1 - exp(-H) = 1 - 2^-(H / ln2)
 #pragma unroll
         for (int m = 0; m < 4; m++) {
@@ -913,7 +929,7 @@ struct BwdTileF16 {
             A.b1[m] += dh[m] * inv;
         }
         lds_wave_sync();                                            // every lane has read H from hbuf and its dO row from tbuf
-        __builtin_amdgcn_sched_barrier(0);
+        GNERF_K2_PHASE_FENCE();
         // ---- dX^T[channel][sample] = W1^T dPRE^T: B straight from this lane's dPRE registers (k order of the g3 fragments)
         v4f dx[2];
         dx[0] = dx[1] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -937,7 +953,7 @@ struct BwdTileF16 {
         *reinterpret_cast<v4f*>(tbuf + j * kTPitch + 4 * g) = dx[0] * inv;                                         // dX[sample][channel], true units
         *reinterpret_cast<v4f*>(tbuf + j * kTPitch + 16 + 4 * g) = dx[1] * inv;
         lds_wave_sync();
-        __builtin_amdgcn_sched_barrier(0);
+        GNERF_K2_PHASE_FENCE();
         // ---- dW1[hidden][channel] += dPRE^T X: A = dPRE^T from hbuf, B = X^T from the staged features
         {
             float xv[8];
@@ -1045,11 +1061,16 @@ __device__ __forceinline__ void render_bwd_tiles_body(const Params& P, const gne
     bwd_reduce_decoder_grads(A, smem, Gr.grad_w1, Gr.grad_b1, Gr.grad_w2, Gr.grad_b2, tid, lane, j);
 }
 
-// The exact-fp32 form is what runs (the launcher passes GNERF_MLP_F32).  The f16 hi/lo form is OPT-IN (GNERF_BWD_MLP=f16x3, or =auto
-// for the forward's device-side range check): 1.45 ms instead of 2.12 ms at config 2 and fp32-grade on most calls, but on some inputs /
-// builds its plane gradient is off by ~1e-3 of the largest entry where the fp32 form agrees with the one-wave-per-ray kernel to 1e-6
-// (tools/dbg_bwd_det.py reproduces it; the discrepancy moves with the compiler's schedule, survives plain-C splits and long wait
-// states around the inline-asm splits, and was not root-caused this round) -- so it is not the default and no default flow uses it.
+// The exact-fp32 form is what runs (the launcher passes GNERF_MLP_F32).  The f16 hi/lo form is OPT-IN (GNERF_BWD_MLP_K2=f16x3, or =auto
+// for the forward's device-side range check): 1.45 ms instead of 2.12 ms at config 2, and fp32-grade (plane and decoder gradients
+// within 1e-6 of the fp32 form) whenever ONE workgroup is resident per CU.  With two -- the launch shape that gives the speed -- a
+// handful of samples per launch (of 2e5) come out wrong, different ones from run to run on identical inputs, about 1e-3 of the largest
+// gradient entry.  Ruled out this round (tools/dbg_bwd_det.py; profiles/README.md): the inline-asm splits (plain C++ splits behave the
+// same), wait states in front of and behind the splits, full s_waitcnt + s_nop fences between all phases of a tile, host
+// synchronisation between the backward's kernels, the wave reduction of the tile scale (butterfly or DPP, broadcast from lane 0), LDS
+// overrun at the end of the allocation (0.5 - 11 KB of padding change nothing; 27 KB -- one workgroup per CU -- cures it).  What is
+// left is an interaction of two waves on one SIMD that the exact-fp32 form, same launch shape, same LDS layout, does not have.  Not
+// root-caused: the form stays off by default, no default flow or test uses it.
 __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_tiles_kernel(Params P, gnerf_render_grads Gr, float* stage) {
     extern __shared__ __align__(16) float smem[];
     int mlp = P.p.mlp_mode;
