@@ -3,10 +3,10 @@
 #   bash tools/collect_round.sh a [tag]   rocprofv3 kernel stats + PMC passes of the bench command, the bench line itself, the backward profile
 #   bash tools/collect_round.sh b         per-op GB/s, backward times, training step, generator (configs 3 / 4), shapes, orbit, host overhead
 #   bash tools/collect_round.sh c         generator kernel statistics (fast and reference flows), layer / layout micro-benchmarks
-# Results land in gpurun_out/profiles/ and gpurun_out/$RND/ (copied into profiles/ afterwards).  RND defaults to r03.
+# Results land in gpurun_out/profiles/ and gpurun_out/$RND/ (copied into profiles/ afterwards).  RND defaults to r04.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
-export RND=${RND:-r03}
+export RND=${RND:-r04}
 part=${1:-a}
 mkdir -p gpurun_out/profiles gpurun_out/$RND
 case $part in
@@ -35,7 +35,10 @@ b)
   tail -5 $e ;;
 c)
   bash tools/prof_generator.sh --only 3 > gpurun_out/prof_generator.log 2>&1; cp gpurun_out/generator_kernel_stats.csv gpurun_out/$RND/generator_kernel_stats.csv
-  bash tools/prof_generator.sh --only 4 --reference-flow --frames 30 > gpurun_out/prof_generator_ref.log 2>&1; cp gpurun_out/generator_kernel_stats.csv gpurun_out/$RND/orbit_reference_flow_kernel_stats.csv
-  bash tools/prof_generator.sh --only 4 --frames 30 > gpurun_out/prof_generator_fast.log 2>&1; cp gpurun_out/generator_kernel_stats.csv gpurun_out/$RND/orbit_fast_flow_kernel_stats.csv
-  head -12 gpurun_out/$RND/*kernel_stats.csv | cut -c1-160 ;;
+  # the orbit with the warm-up (MIOpen's solver search) excluded: tools/prof_orbit.sh -> gpurun_out/${RND}_orbit_*_{kernel_stats.csv,summary.json}
+  bash tools/prof_orbit.sh ${RND}_orbit_fast_eager > gpurun_out/prof_orbit1.log 2>&1
+  bash tools/prof_orbit.sh ${RND}_orbit_fast_views4 --frames-per-call 4 > gpurun_out/prof_orbit2.log 2>&1
+  bash tools/prof_orbit.sh ${RND}_orbit_fast_graph --graph > gpurun_out/prof_orbit3.log 2>&1
+  bash tools/prof_orbit.sh ${RND}_orbit_reference_graph --flow reference --graph > gpurun_out/prof_orbit4.log 2>&1
+  head -8 gpurun_out/${RND}_orbit_*kernel_stats.csv | cut -c1-160 ;;
 esac
