@@ -87,10 +87,12 @@ __device__ __forceinline__ Pk<T, VEC> modconv_epilogue_vec(const Pk<T, VEC>& in,
         }
     }
     Pk<T, VEC> out;
-    // lrelu with a slope in [0, 1] is max(u, u * alpha) -- the same bits as the select for every u (signed zeros and NaN included),
-    // one full-rate and one half-rate instruction instead of one and two (tools/probes/valu_issue_probe.hip: v_cmp / v_cndmask cost
-    // 4.4 SIMD cycles each).  The clamp is v_med3_f32, which sends NaN to -clamp exactly like the reference's kernel
-    // (bias_act.cu:143: `(y > -clamp & y < clamp) ? y : (y >= 0) ? clamp : -clamp`), one instruction instead of four.
+    // lrelu with a slope in (0, 1] is max(u, u * alpha) -- the same bits as the select for every u (signed zeros and NaN included; at
+    // alpha == 0 the two differ for u = -inf only: the select gives -inf * 0 = NaN, the max -inf), one full-rate and one half-rate
+    // instruction instead of one and two (tools/probes/valu_issue_probe.hip: v_cmp / v_cndmask cost 4.4 SIMD cycles each).  The clamp
+    // is v_med3_f32, which sends NaN to -clamp exactly like the reference's kernel (bias_act.cu:143: `(y > -clamp & y < clamp) ? y :
+    // (y >= 0) ? clamp : -clamp`), one instruction instead of four -- so with a clamp a NaN input leaves a GPU epilogue as -clamp, where
+    // the PyTorch-op forms (CPU tensors; x.clamp) keep the NaN: include/gnerf_hip.h states it at gnerf_bias_act.
     const bool slope01 = alpha >= 0.f && alpha <= 1.f;
 #pragma unroll
     for (int k = 0; k < VEC; k++) {

@@ -125,6 +125,17 @@ def _per_latent(module, w, tag, params, fn):
     return val
 
 
+def clear_latent_caches(root):
+    """Drop every per-latent / per-parameter cache under `root` (modulated weights [N,O,I,3,3] per layer are ~38 MB per 512-channel
+    fp32 layer at batch 4: a few hundred MB over the backbone, held until another latent replaces them).  Call it when an orbit is
+    done and the memory is wanted back; a FrameProgram that captured the cached tensors keeps its own references and stays valid.
+    The caches assume ONE stream per generator: the tensors are made on whichever stream first asked for them and later read in
+    place (a HIP-graph capture of the same generator warms them up on its side stream before it captures: FrameProgram.__init__)."""
+    for m in root.modules():
+        for k in ('_gnerf_latent_cache', '_gnerf_prenorm', '_gnerf_cast'):
+            m.__dict__.pop(k, None)
+
+
 def latent_cache_tensors(root):
     """Every tensor the per-latent caches under `root` currently hold (for a FrameProgram to keep alive)."""
     out = []

@@ -63,7 +63,10 @@ const char* gnerf_build_info(void);          /* e.g. "gfx950 hipcc ..." , host p
  * 1 first order (x = dy, needs xref or yref as the activation dictates),
  * 2 second order (x = d_dx, dy = the first-order incoming gradient).
  * act: 1 linear 2 relu 3 lrelu 4 tanh 5 sigmoid 6 elu 7 selu 8 softplus 9 swish.
- * clamp < 0 disables clamping. */
+ * clamp < 0 disables clamping.
+ * NaN: with clamp >= 0 a NaN result is returned as -clamp (the clamp is one v_med3_f32; the reference's kernel does the same,
+ * bias_act.cu:143), in every native epilogue (gnerf_bias_act, gnerf_modconv_epilogue*, gnerf_torgb_nhwc*, gnerf_blur4_epilogue_nhwc); the
+ * PyTorch-op forms that CPU tensors take keep the NaN. */
 int gnerf_bias_act(const void* x, const void* b, const void* xref, const void* yref, const void* dy,
                    void* y, int dtype, int64_t numel, int size_b, int64_t step_b,
                    int grad, int act, float alpha, float gain, float clamp, gnerf_stream_t stream);

@@ -106,3 +106,17 @@ def test_density_volume_matches_reference_lattice(tmp_path):
         assert float(d[f'samples_{n}']) == 0.0, (n, float(d[f'samples_{n}']))
     assert float(d['volume']) <= 1e-5 * max(1.0, float(d['volume_scale']))
     assert float(d['crop_ok']) == 0.0 and float(d['crop_inner']) == 0.0
+
+
+def test_clear_latent_caches():
+    """gnerf_generator.clear_latent_caches drops the per-latent / per-parameter caches the fast path hangs on the modules (ADVICE r3:
+    several hundred MB over the backbone with no release hook)."""
+    import torch
+    import gnerf_generator as GG
+    m = torch.nn.Linear(2, 2)
+    m.__dict__['_gnerf_latent_cache'] = {'x': (None, None, torch.zeros(3))}
+    m.__dict__['_gnerf_prenorm'] = {'k': (None, torch.zeros(3))}
+    root = torch.nn.Sequential(m)
+    assert len(GG.latent_cache_tensors(root)) == 1
+    GG.clear_latent_caches(root)
+    assert '_gnerf_latent_cache' not in m.__dict__ and '_gnerf_prenorm' not in m.__dict__ and GG.latent_cache_tensors(root) == []
