@@ -1070,15 +1070,15 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
         if (int e = check_launch("render_kernel_pipe_bwd")) return e;
         // (GNERF_BWD_LDS_PAD: extra dynamic LDS per workgroup -- 27000 leaves ONE workgroup per CU, the setting under which the opt-in f16
         // form of the tile kernel has shown no discrepancy; see render_bwd_tiles_kernel)
-        const size_t lds2 = (bwd_tiles_weight_floats() + kBwdWaves * bwd_tiles_wave_floats()) * sizeof(float) + (getenv("GNERF_BWD_LDS_PAD") ? size_t(atoi(getenv("GNERF_BWD_LDS_PAD"))) : 0);
+        const size_t lds2 = (bwd_tiles_weight_floats() + kTileWaves * bwd_tiles_wave_floats()) * sizeof(float) + (getenv("GNERF_BWD_LDS_PAD") ? size_t(atoi(getenv("GNERF_BWD_LDS_PAD"))) : 0);
         static PerDeviceOnce once_tiles;
         if (int e = once_tiles.raise_lds(render_bwd_tiles_kernel, "render_backward")) return e;
         const int64_t sample_tiles = total_seq * ((n_all + 15) / 16);
-        int64_t g2 = (sample_tiles + kBwdWaves - 1) / kBwdWaves;
-        if (g2 > int64_t(kNumCU) * 2) g2 = int64_t(kNumCU) * 2;    // two workgroups of four waves per CU, each walking a contiguous run of tiles
+        int64_t g2 = (sample_tiles + kTileWaves - 1) / kTileWaves;
+        if (g2 > int64_t(kNumCU) * (kTileWaves == 4 ? 2 : 1)) g2 = int64_t(kNumCU) * (kTileWaves == 4 ? 2 : 1);    // two workgroups of four waves per CU, each walking a contiguous run of tiles
         g2 = (g2 + kNumXCD - 1) / kNumXCD * kNumXCD;
         P2.pipe_unit = P.pipe_unit;
-        hipLaunchKernelGGL(render_bwd_tiles_kernel, dim3((unsigned)g2), dim3(kBwdThreads), lds2, s, P2, *g, g->scatter_stage);
+        hipLaunchKernelGGL(render_bwd_tiles_kernel, dim3((unsigned)g2), dim3(kTileThreads), lds2, s, P2, *g, g->scatter_stage);
         if (int e = check_launch("render_bwd_tiles_kernel")) return e;
     } else {
     if (staged) hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(per_xcd * kNumXCD), dim3(kBwdThreads), lds_bytes, as_stream(stream), P, *g, g->scatter_stage);

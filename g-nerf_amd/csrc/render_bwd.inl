@@ -388,12 +388,12 @@ __device__ __forceinline__ void bwd_backward_tiles(const Params& P, const BwdLds
 // Decoder gradients: wave registers -> workgroup LDS (aliases the staged decoder) -> one global atomic per element.
 // Every thread of the workgroup must call (barriers inside).
 __device__ __forceinline__ void bwd_reduce_decoder_grads(const BwdAcc& A, float* smem, float* grad_w1, float* grad_b1, float* grad_w2, float* grad_b2,
-                                                         int tid, int lane, int j) {
+                                                         int tid, int lane, int j, int nthreads = kBwdThreads) {
     if (!grad_w1) return;
     __syncthreads();                                   // every wave is done with the LDS decoder
     float* red = smem;
     float* red_w1 = red, *red_b1 = red_w1 + 64 * 32, *red_w2 = red_b1 + 64, *red_b2 = red_w2 + 33 * 64;
-    for (int i = tid; i < kBwdGradFloats; i += kBwdThreads) red[i] = 0.f;
+    for (int i = tid; i < kBwdGradFloats; i += nthreads) red[i] = 0.f;
     __syncthreads();
     {
         const int g = lane >> 4;
@@ -424,8 +424,8 @@ __device__ __forceinline__ void bwd_reduce_decoder_grads(const BwdAcc& A, float*
         if (lane == 0) atomicAdd(red_b2, s);
     }
     __syncthreads();
-    for (int i = tid; i < 64 * 32; i += kBwdThreads) unsafeAtomicAdd(grad_w1 + i, red_w1[i]);
-    for (int i = tid; i < 33 * 64; i += kBwdThreads) unsafeAtomicAdd(grad_w2 + i, red_w2[i]);
+    for (int i = tid; i < 64 * 32; i += nthreads) unsafeAtomicAdd(grad_w1 + i, red_w1[i]);
+    for (int i = tid; i < 33 * 64; i += nthreads) unsafeAtomicAdd(grad_w2 + i, red_w2[i]);
     if (tid < 64) unsafeAtomicAdd(grad_b1 + tid, red_b1[tid]);
     if (tid < 33) unsafeAtomicAdd(grad_b2 + tid, red_b2[tid]);
 }
@@ -625,6 +625,10 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gn
 // lookup + decoder forward (exact fp32) + the four gradient products + dX rows.  One wave per 16-rank tile, tiles dealt in contiguous
 // runs of the locality-ordered ray sequence; the dX rows of a tile are 2 KB of contiguous staging memory (the one-wave-per-ray kernel
 // above writes them rank by rank behind a second forward recomputation, with 12 per-sample arrays per wave in LDS).
+#ifndef GNERF_K2_WAVES
+#define GNERF_K2_WAVES 4
+#endif
+constexpr int kTileWaves = GNERF_K2_WAVES, kTileThreads = 64 * kTileWaves;       // waves of a tile-kernel workgroup
 struct DepthListPos {
     const BwdRay& R; const float* dep; float box_scale;
     __device__ __forceinline__ void operator()(int j, float& px, float& py, float& pz) const {
@@ -662,8 +666,8 @@ struct BwdTileF32 {
         float* w2 = w1 + 64 * kW1Pitch;
         float* b1 = w2 + 33 * kW2Pitch;
         float* b2 = b1 + 64;
-        for (int i = tid; i < 64 * 32; i += kBwdThreads) w1[(i >> 5) * kW1Pitch + (i & 31)] = p.w1[i];
-        for (int i = tid; i < 33 * 64; i += kBwdThreads) w2[(i >> 6) * kW2Pitch + (i & 63)] = p.w2[i];
+        for (int i = tid; i < 64 * 32; i += kTileThreads) w1[(i >> 5) * kW1Pitch + (i & 31)] = p.w1[i];
+        for (int i = tid; i < 33 * 64; i += kTileThreads) w2[(i >> 6) * kW2Pitch + (i & 63)] = p.w2[i];
         if (tid < 64) b1[tid] = p.b1[tid];
         if (tid < 36) b2[tid] = tid < 33 ? p.b2[tid] : 0.f;
         __syncthreads();
@@ -714,11 +718,7 @@ struct BwdTileF32 {
 #ifndef GNERF_K2_SPLIT
 #define GNERF_K2_SPLIT split_f16x8_after_mfma
 #endif
-#ifdef GNERF_K2_FENCES          // hazard hunt: a full stop between the phases of the f16 tile
-#define GNERF_K2_PHASE_FENCE() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory")
-#else
 #define GNERF_K2_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 struct BwdTileF16 {
     static constexpr int kMlp = kMlpF16x3;
     CoopLds C;                       // the forward's fragments (w1 = fragment base, w2 = density row * ln2, b1 * log2e, b2 scaled)
@@ -729,19 +729,19 @@ struct BwdTileF16 {
     float acc_scale;                 // the power of two A.w1 / A.w2 currently carry
     __device__ __forceinline__ void setup(const Params& P, float* smem, const float*, int tid) {
         const gnerf_render_params& p = P.p;
-        stage_decoder<kMlpF16x3>(C, smem, p, tid, kBwdThreads);
+        stage_decoder<kMlpF16x3>(C, smem, p, tid, kTileThreads);
         _Float16* gh = reinterpret_cast<_Float16*>(smem + kWeightFloatsF16 + 64 + 36);
         g1 = gh; g3 = gh + 2 * kBwdFragHalves;
         float* wst = smem + kWeightFloatsF16 + 64 + 36 + (4 * kBwdFragHalves) / 2;
         ws_true = wst;
-        for (int i = tid; i < 2048; i += kBwdThreads) {
+        for (int i = tid; i < 2048; i += kTileThreads) {
             const int e = i & 7, j = (i >> 3) & 15, g = (i >> 7) & 3, m = i >> 9;             // lane 16 g + j of block m
             const float x = p.w2[(1 + 8 * g + e) * 64 + 16 * m + j];
             const _Float16 hi = (_Float16)x;
             gh[i] = hi;
             gh[kBwdFragHalves + i] = (_Float16)(x - (float)hi);
         }
-        for (int i = tid; i < 2048; i += kBwdThreads) {
+        for (int i = tid; i < 2048; i += kTileThreads) {
             const int jj = i & 7, j = (i >> 3) & 15, g = (i >> 7) & 3, sx = (i >> 9) & 1, c = i >> 10;     // lane 16 g + j of fragment (c, s)
             const float x = p.w1[(32 * sx + 16 * (jj >> 2) + 4 * g + (jj & 3)) * 32 + 16 * c + j];
             const _Float16 hi = (_Float16)x;
@@ -1024,7 +1024,7 @@ __device__ __forceinline__ void render_bwd_tiles_body(const Params& P, const gne
     const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : int64_t(P.total_rays);
     const int xcd = blockIdx.x % kNumXCD, wg = blockIdx.x / kNumXCD, wgs = gridDim.x / kNumXCD;
     const int64_t x0 = total_seq * xcd / kNumXCD * tiles_per_ray, x1 = total_seq * (xcd + 1) / kNumXCD * tiles_per_ray;
-    const int64_t waves = int64_t(wgs) * kBwdWaves, me = int64_t(wg) * kBwdWaves + wv;
+    const int64_t waves = int64_t(wgs) * kTileWaves, me = int64_t(wg) * kTileWaves + wv;
     const int64_t t0 = x0 + (x1 - x0) * me / waves, t1 = x0 + (x1 - x0) * (me + 1) / waves;
     for (int64_t t = t0; t < t1; t++) {
         const int64_t seq = t / tiles_per_ray;
@@ -1058,7 +1058,7 @@ __device__ __forceinline__ void render_bwd_tiles_body(const Params& P, const gne
         lds_wave_sync();
     }
     K.finish(A);
-    bwd_reduce_decoder_grads(A, smem, Gr.grad_w1, Gr.grad_b1, Gr.grad_w2, Gr.grad_b2, tid, lane, j);
+    bwd_reduce_decoder_grads(A, smem, Gr.grad_w1, Gr.grad_b1, Gr.grad_w2, Gr.grad_b2, tid, lane, j, kTileThreads);
 }
 
 // The exact-fp32 form is what runs (the launcher passes GNERF_MLP_F32).  The f16 hi/lo form is OPT-IN (GNERF_BWD_MLP_K2=f16x3, or =auto
@@ -1068,10 +1068,12 @@ __device__ __forceinline__ void render_bwd_tiles_body(const Params& P, const gne
 // gradient entry.  Ruled out this round (tools/dbg_bwd_det.py; profiles/README.md): the inline-asm splits (plain C++ splits behave the
 // same), wait states in front of and behind the splits, full s_waitcnt + s_nop fences between all phases of a tile, host
 // synchronisation between the backward's kernels, the wave reduction of the tile scale (butterfly or DPP, broadcast from lane 0), LDS
-// overrun at the end of the allocation (0.5 - 11 KB of padding change nothing; 27 KB -- one workgroup per CU -- cures it).  What is
-// left is an interaction of two waves on one SIMD that the exact-fp32 form, same launch shape, same LDS layout, does not have.  Not
-// root-caused: the form stays off by default, no default flow or test uses it.
-__global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_tiles_kernel(Params P, gnerf_render_grads Gr, float* stage) {
+// overrun at the end of the allocation (0.5 - 11 KB of padding change nothing; 27 KB -- one workgroup per CU -- cures it), two
+// workgroups sharing a CU as such (ONE workgroup of eight waves per CU, -DGNERF_K2_WAVES=8, fails every time), and the latency of
+// matrix results (a 512-cycle s_sleep between every group of matrix instructions and the first read of its results changes nothing).
+// What is left is that TWO WAVES SHARE A SIMD while both run this form -- the exact-fp32 form, same launch shape, same LDS layout,
+// same 256 registers, does not have the problem.  Not root-caused: the form stays off by default, no default flow or test uses it.
+__global__ __launch_bounds__(kTileThreads, kTileWaves == 4 ? 2 : 1) void render_bwd_tiles_kernel(Params P, gnerf_render_grads Gr, float* stage) {
     extern __shared__ __align__(16) float smem[];
     int mlp = P.p.mlp_mode;
     if (mlp == kMlpAuto) mlp = choose_mlp(P, smem);
