@@ -1072,7 +1072,7 @@ __device__ __forceinline__ void render_bwd_tiles_body(const Params& P, const gne
 // workgroups sharing a CU as such (ONE workgroup of eight waves per CU, -DGNERF_K2_WAVES=8, fails every time), and the latency of
 // matrix results (a 512-cycle s_sleep between every group of matrix instructions and the first read of its results changes nothing).
 // What is left is that TWO WAVES SHARE A SIMD while both run this form -- the exact-fp32 form, same launch shape, same LDS layout,
-// same 256 registers, does not have the problem.  Not root-caused: the form stays off by default, no default flow or test uses it.
+// same 256 registers, does not have the problem (capping this form at 232 registers does not cure it either).  Not root-caused: the form stays off by default, no default flow or test uses it.
 __global__ __launch_bounds__(kTileThreads, kTileWaves == 4 ? 2 : 1) void render_bwd_tiles_kernel(Params P, gnerf_render_grads Gr, float* stage) {
     extern __shared__ __align__(16) float smem[];
     int mlp = P.p.mlp_mode;
