@@ -311,10 +311,29 @@ def gen_videos_secondary(rank, world, dev, n_frames=240):
             del program
         GG._MODCONV_FAST = os.environ.get('GNERF_MODCONV_FAST', '1') != '0'
         last.emit_channels_last = True
+        # the backbone pass every rank runs once per orbit before its frames (ws is constant, gen_videos.py:150): the serial term of
+        # config 4's scaling -- 240 frames on one GPU against (backbone + 240 / N frames + gather) on N
+        ws = gv.orbit_latents(G, z, dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ms = []
+        for _ in range(4):
+            e0.record()
+            G.backbone.synthesis(ws, noise_mode='const')
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        backbone_ms = sorted(ms[1:])[1]
+    backbone_all = [backbone_ms]
+    if world > 1:
+        t = torch.tensor([backbone_ms], device=dev, dtype=torch.float64)
+        allb = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allb, t)
+        backbone_all = [float(x[0]) for x in allb]
     best = max(('eager', 'hip_graph', 'eager_views'), key=lambda k: out['fast', k])
     return {'metric': 'frames/sec gen_videos', 'value': out['fast', best], 'unit': 'frames/s', 'value_is': 'fast flow, ' + best,
             'eager_value': out['fast', 'eager'], 'hip_graph_value': out['fast', 'hip_graph'],
             'eager_views_value': out['fast', 'eager_views'], 'views_per_call': ORBIT_VIEWS, 'miopen_solver_search': searched,
+            'backbone_ms_per_rank': backbone_all,
             'reference_flow_value': max(out['reference', 'eager'], out['reference', 'hip_graph']),
             'reference_flow_eager_value': out['reference', 'eager'], 'reference_flow_hip_graph_value': out['reference', 'hip_graph'], 'n_gpus': world,
             'workload': f'config 4: {n_frames}-frame orbit sharded over {world} GPU(s), 64x64 rays x (96+96) samples, cached backbone, SR to '

@@ -98,12 +98,12 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 // LDS) makes the sums into an LDS tile; phase B (lanes along channels) writes whole 128-byte channel groups.
 struct Up2Taps { float k[4][4]; };      // effective taps: gain * (f flipped unless flip)
 
-constexpr int kUpCh = 32, kUpRows = 4, kUpCols = 32, kUpInPitch = 4 * 18 + 1, kUpOutPitch = kUpCh + 1;
+constexpr int kUpCh = 32, kUpRows = 4, kUpCols = 32, kUpInPitch = 4 * 18 + 1, kUpOutPitch = kUpCh + 4;      // (output rows 16-byte aligned: vector hand-off)
 
 __global__ __launch_bounds__(256) void upsample2x_add_nhwc_kernel(const float* __restrict__ img, const float* __restrict__ y, Up2Taps K,
                                                                   float* __restrict__ out, int c, int h, int w, unsigned* absmax) {
     __shared__ float in[kUpCh * kUpInPitch];
-    __shared__ float ot[kUpRows * kUpCols * kUpOutPitch];
+    __shared__ __align__(16) float ot[kUpRows * kUpCols * kUpOutPitch];
     const int OH = 2 * h, OW = 2 * w;
     const int tiles_x = OW / kUpCols, tiles_y = OH / kUpRows, groups = c / kUpCh;
     // XCD-contiguous numbering (workgroups go to the eight XCDs round-robin, each with its own L2): vertical neighbours share two of
@@ -125,32 +125,43 @@ __global__ __launch_bounds__(256) void upsample2x_add_nhwc_kernel(const float* _
         in[ch * kUpInPitch + r * 18 + cc] = v;
     }
     __syncthreads();
+    // Phase A (round 4: 16-byte global accesses in both phases; 3.4 -> see profiles/r04_ops_GBs.jsonl): a lane makes four consecutive
+    // output columns of four channels -- y arrives as one float4 per channel -- and hands them over as one float4 of channels per pixel.
     {
-        const int tx = threadIdx.x & 31, ty = (threadIdx.x >> 5) & 3, cg = threadIdx.x >> 7;
-        const int ry = ty & 1, rx = tx & 1;
-        const float k00 = K.k[ry][rx], k01 = K.k[ry][rx + 2], k10 = K.k[ry + 2][rx], k11 = K.k[ry + 2][rx + 2];
-        const int r = (ty >> 1) + ry, cc = (tx >> 1) + rx;
-        const int oy = oy0 + ty, ox = ox0 + tx;
-        const float* y_px = y ? y + ((int64_t(n) * c + c0) * OH + oy) * OW + ox : nullptr;
-#pragma unroll 4
-        for (int q = 0; q < 16; q++) {
-            const int ch = cg * 16 + q;
-            const float* win = in + ch * kUpInPitch + r * 18 + cc;
-            float v = k00 * win[0] + k01 * win[1] + k10 * win[18] + k11 * win[19];
-            if (y_px) v += y_px[int64_t(ch) * OH * OW];
-            ot[(ty * kUpCols + tx) * kUpOutPitch + ch] = v;
+        const int x4 = threadIdx.x & 7, ty = (threadIdx.x >> 3) & 3, chq = threadIdx.x >> 5;
+        const int ry = ty & 1, r = (ty >> 1) + ry;
+        const int oy = oy0 + ty;
+        float v[4][4];                                   // [channel][column]
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ch = chq * 4 + q;
+            const float* win = in + ch * kUpInPitch + r * 18 + 2 * x4;
+            const float a0 = win[0], a1 = win[1], a2 = win[2], a3 = win[3], b0 = win[18], b1 = win[19], b2 = win[20], b3 = win[21];
+            // column i of the four: rx = i & 1, window column (i >> 1) + rx; taps K[ry][rx], K[ry][rx + 2], K[ry + 2][rx], K[ry + 2][rx + 2]
+            v[q][0] = K.k[ry][0] * a0 + K.k[ry][2] * a1 + K.k[ry + 2][0] * b0 + K.k[ry + 2][2] * b1;
+            v[q][1] = K.k[ry][1] * a1 + K.k[ry][3] * a2 + K.k[ry + 2][1] * b1 + K.k[ry + 2][3] * b2;
+            v[q][2] = K.k[ry][0] * a1 + K.k[ry][2] * a2 + K.k[ry + 2][0] * b1 + K.k[ry + 2][2] * b2;
+            v[q][3] = K.k[ry][1] * a2 + K.k[ry][3] * a3 + K.k[ry + 2][1] * b2 + K.k[ry + 2][3] * b3;
+            if (y) {
+                const float4 yy = *reinterpret_cast<const float4*>(y + ((int64_t(n) * c + c0 + ch) * OH + oy) * OW + ox0 + 4 * x4);
+                v[q][0] += yy.x; v[q][1] += yy.y; v[q][2] += yy.z; v[q][3] += yy.w;
+            }
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            *reinterpret_cast<float4*>(ot + (ty * kUpCols + 4 * x4 + i) * kUpOutPitch + 4 * chq) = make_float4(v[0][i], v[1][i], v[2][i], v[3][i]);
     }
     __syncthreads();
+    // Phase B: eight lanes write one pixel's 32 channels (128 contiguous bytes), a float4 each
     unsigned amax = 0u;
     {
-        const int ch = threadIdx.x & 31, p0 = threadIdx.x >> 5;
-#pragma unroll 4
-        for (int q = 0; q < 16; q++) {
-            const int px = p0 + 8 * q;                          // pixel of the tile: row px / 32, column px % 32
-            const float v = ot[px * kUpOutPitch + ch];
-            out[((int64_t(n) * OH + oy0 + (px >> 5)) * OW + ox0 + (px & 31)) * c + c0 + ch] = v;
-            amax = max(amax, abs_bits(v));
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int item = threadIdx.x + 256 * q;
+            const int ch4 = item & 7, px = item >> 3;            // pixel of the tile: row px / 32, column px % 32
+            const float4 vv = *reinterpret_cast<const float4*>(ot + px * kUpOutPitch + 4 * ch4);
+            *reinterpret_cast<float4*>(out + ((int64_t(n) * OH + oy0 + (px >> 5)) * OW + ox0 + (px & 31)) * c + c0 + 4 * ch4) = vv;
+            amax = max(max(amax, abs_bits(vv.x)), max(max(abs_bits(vv.y), abs_bits(vv.z)), abs_bits(vv.w)));
         }
     }
     if (absmax) publish_absmax(amax, absmax);
