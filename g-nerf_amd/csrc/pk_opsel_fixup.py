@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Assembly pass of the gfx950 build (build.sh runs it on the device assembly of render.hip): no packed-fp32 instruction may take the
+LOW half of its result from the HIGH register of src1.
+
+Why.  On MI355X a `v_pk_mul_f32 D, S0, S1 op_sel:[0,1]` (low result = S0.lo * S1.hi) issued by one wave while ANOTHER wave of the same
+SIMD has a `v_mfma_f32_16x16x32_f16` (the gfx950 form with 128-bit A / B operands) in flight sometimes reads S1.hi as 0.0 in lanes
+48-63: one 16-lane quarter of one product comes out as a signed zero, about once per 2 000 executions under two waves per SIMD,
+never with one.  Measured with assembly-level variants of the backward tile kernel (profiles/r04_pk_opsel_hazard.md):
+the same product written `v_pk_mul_f32 D, S1, S0 op_sel:[1,0]` (the high register selected on src0) is exact in every run, as are two
+plain v_mul_f32; wait states in front of or behind the instruction, rewriting its operands first and replacing the DPP / v_readlane
+neighbours change nothing; replacing the 16x16x32 matrix instructions by the 16x16x16 form removes the failures.  The compiler knows
+nothing of this and picks the src1 form whenever register allocation leaves a broadcast value in an odd register.
+
+What.  Every `v_pk_{mul,add,fma}_f32` whose op_sel selects the high register for src1 has src0 and src1 exchanged (all three are
+commutative in src0 / src1) together with their op_sel / op_sel_hi / neg_lo / neg_hi entries.  An instruction that selects the high
+register on BOTH sources cannot be repaired this way: it stops the build when its kernel also contains the 128-bit matrix instruction
+(waves of one kernel are what share a SIMD here), and is counted otherwise.  `--check` only reports (used by the tests on the
+disassembly of the built library): exit status 1 if any such instruction is present.
+"""
+import re
+import sys
+
+INSTR = re.compile(r'^(\s*)(v_pk_(?:mul|add|fma)_f32)(?:_e64)?\s+(.*?)\s*(;.*|//.*)?$')
+MOD = re.compile(r'\b(op_sel|op_sel_hi|neg_lo|neg_hi):\[([01](?:,[01])*)\]')
+
+
+def split_operands(text):
+    """'v[1:2], v[3:4], 1.0 op_sel:[0,1]' -> (['v[1:2]', 'v[3:4]', '1.0'], {'op_sel': [0, 1]}, order of the modifiers)"""
+    mods, order = {}, []
+    def take(m):
+        mods[m.group(1)] = [int(x) for x in m.group(2).split(',')]
+        order.append(m.group(1))
+        return ''
+    ops = MOD.sub(take, text)
+    depth, cur, out = 0, '', []
+    for ch in ops:
+        if ch == '[': depth += 1
+        if ch == ']': depth -= 1
+        if ch == ',' and depth == 0:
+            out.append(cur.strip()); cur = ''
+        else:
+            cur += ch
+    if cur.strip(): out.append(cur.strip())
+    return out, mods, order
+
+
+def hazardous(mods):
+    sel = mods.get('op_sel')
+    return bool(sel) and len(sel) >= 2 and sel[1] == 1
+
+
+def fix_line(line):
+    """-> (new line, 'ok' | 'fixed' | 'unfixable')"""
+    m = INSTR.match(line)
+    if not m: return line, 'ok'
+    indent, op, rest, comment = m.group(1), m.group(2), m.group(3), m.group(4) or ''
+    ops, mods, order = split_operands(rest)
+    if not hazardous(mods): return line, 'ok'
+    if mods['op_sel'][0] == 1: return line, 'unfixable'
+    nsrc = len(ops) - 1
+    ops[1], ops[2] = ops[2], ops[1]
+    for name in order:
+        v = mods[name]
+        if len(v) != nsrc: return line, 'unfixable'
+        v[0], v[1] = v[1], v[0]
+    text = '%s%s %s' % (indent, op, ', '.join(ops))
+    for name in order:
+        v = mods[name]
+        default = 1 if name == 'op_sel_hi' else 0
+        if any(x != default for x in v): text += ' %s:[%s]' % (name, ','.join(str(x) for x in v))
+    return (text + (' ' + comment if comment else '')).rstrip(), 'fixed'
+
+
+def main(argv):
+    check = '--check' in argv
+    paths = [a for a in argv if not a.startswith('--')]
+    if len(paths) != 1:
+        print('usage: pk_opsel_fixup.py [--check] <assembly or disassembly>', file=sys.stderr)
+        return 2
+    lines = open(paths[0]).read().split('\n')
+    # function of each line (compiler assembly: `.type name,@function` ... `name:`; disassembly: `<name>:`), and the functions that
+    # contain the 128-bit matrix instruction
+    func, owner, has_mfma = None, [None] * len(lines), set()
+    for i, line in enumerate(lines):
+        m = re.match(r'^\s*\.type\s+([\w.$]+),@function', line) or re.match(r'^[0-9a-f]+ <(.+)>:$', line)
+        if m: func = m.group(1)
+        owner[i] = func
+        if 'v_mfma_f32_16x16x32' in line: has_mfma.add(func)
+    fixed = unfixable = tolerated = 0
+    for i, line in enumerate(lines):
+        if 'v_pk_' not in line: continue
+        if check:
+            m = INSTR.match(re.sub(r'^\s*[0-9a-f]+:\s*', '', re.sub(r'\s*//.*$', '', line)))       # objdump prefixes / suffixes
+            if m and hazardous(split_operands(m.group(3))[1]):
+                if owner[i] in has_mfma:
+                    fixed += 1
+                    if fixed <= 8: print('%s:%d: %s' % (paths[0], i + 1, line.strip()), file=sys.stderr)
+                else:
+                    tolerated += 1
+            continue
+        new, what = fix_line(line)
+        if what == 'fixed': lines[i] = new; fixed += 1
+        elif what == 'unfixable' and owner[i] in has_mfma:
+            unfixable += 1
+            print('%s:%d: cannot move the high-register select off src1: %s' % (paths[0], i + 1, line.strip()), file=sys.stderr)
+        elif what == 'unfixable':
+            tolerated += 1
+    note = ' (%d left that select it on both sources, in kernels without v_mfma_f32_16x16x32_*)' % tolerated if tolerated else ''
+    if check:
+        print('[pk_opsel] %d packed-fp32 instruction(s) select the high register of src1 in kernels with v_mfma_f32_16x16x32_*%s' % (fixed, note))
+        return 1 if fixed else 0
+    if unfixable: return 1
+    open(paths[0], 'w').write('\n'.join(lines))
+    print('[pk_opsel] exchanged src0 / src1 of %d packed-fp32 instruction(s)%s' % (fixed, note))
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main(sys.argv[1:]))

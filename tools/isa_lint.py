@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""ISA lint of the built library: disassembles every gfx950 code object bundled in libgnerf_hip.so and reports, per kernel, the
+packed-fp32 instructions that take the LOW half of their result from the HIGH register of src1 -- the form that reads 0.0 in lanes
+48-63 now and then while another wave of the SIMD runs v_mfma_f32_16x16x32_f16 (g-nerf_amd/csrc/pk_opsel_fixup.py has the
+measurements).  build.sh removes them from render.hip's kernels; any kernel that still has one AND can share a SIMD with the 128-bit
+matrix instruction (i.e. contains it) is an error.
+usage: tools/isa_lint.py [library]      exit status 1 on an error; --json for one JSON line"""
+import json, os, re, struct, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'g-nerf_amd', 'csrc'))
+import pk_opsel_fixup as FX
+LLVM = os.environ.get('LLVM_BIN', '/opt/rocm/lib/llvm/bin')
+MAGIC = b'__CLANG_OFFLOAD_BUNDLE__'
+
+
+def code_objects(lib):
+    """the gfx950 code objects of every offload bundle in the library's .hip_fatbin section (one bundle per translation unit)"""
+    tmp = tempfile.mkdtemp()
+    fat = os.path.join(tmp, 'fat.bin')
+    subprocess.run([os.path.join(LLVM, 'llvm-objcopy'), '--dump-section=.hip_fatbin=' + fat, lib], check=True, capture_output=True)
+    blob = open(fat, 'rb').read()
+    out, pos = [], blob.find(MAGIC)
+    while pos >= 0:
+        n = struct.unpack_from('<Q', blob, pos + len(MAGIC))[0]
+        q = pos + len(MAGIC) + 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from('<QQQ', blob, q)
+            triple = blob[q + 24:q + 24 + tl].decode()
+            q += 24 + tl
+            if 'gfx950' in triple and size:
+                path = os.path.join(tmp, 'co%d.co' % len(out))
+                open(path, 'wb').write(blob[pos + off:pos + off + size])
+                out.append(path)
+        pos = blob.find(MAGIC, pos + len(MAGIC))
+    return out
+
+
+def lint(lib):
+    kernels = {}
+    for co in code_objects(lib):
+        dis = subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '-d', '--no-show-raw-insn', co], check=True, capture_output=True, text=True).stdout
+        name = None
+        for line in dis.split('\n'):
+            m = re.match(r'^[0-9a-f]+ <(.+)>:$', line)
+            if m:
+                name = m.group(1)
+                kernels.setdefault(name, {'pk_src1_hi': 0, 'mfma_16x16x32': 0, 'first': None})
+                continue
+            if name is None: continue
+            if 'v_mfma_f32_16x16x32' in line: kernels[name]['mfma_16x16x32'] += 1
+            elif 'v_pk_' in line:
+                text = re.sub(r'\s*//.*$', '', line).strip()
+                m = FX.INSTR.match(text)
+                if m and FX.hazardous(FX.split_operands(m.group(3))[1]):
+                    kernels[name]['pk_src1_hi'] += 1
+                    kernels[name]['first'] = kernels[name]['first'] or text
+    return kernels
+
+
+def main(argv):
+    args = [a for a in argv if not a.startswith('--')]
+    lib = args[0] if args else os.path.join(ROOT, 'g-nerf_amd', 'gnerf_hip', 'libgnerf_hip.so')
+    k = lint(lib)
+    errors = {n: v for n, v in k.items() if v['pk_src1_hi'] and v['mfma_16x16x32']}
+    other = {n: v for n, v in k.items() if v['pk_src1_hi'] and not v['mfma_16x16x32']}
+    if '--json' in argv:
+        print(json.dumps({'library': os.path.basename(lib), 'kernels': len(k), 'with_mfma_16x16x32': sum(1 for v in k.values() if v['mfma_16x16x32']),
+                          'errors': {n: v['pk_src1_hi'] for n, v in errors.items()}, 'src1_hi_without_the_matrix_instruction': {n: v['pk_src1_hi'] for n, v in other.items()}}))
+    else:
+        print('%d kernels, %d with v_mfma_f32_16x16x32_*' % (len(k), sum(1 for v in k.values() if v['mfma_16x16x32'])))
+        for n, v in errors.items(): print('ERROR %s: %d packed-fp32 instruction(s) select the high register of src1, e.g. %s' % (n[:90], v['pk_src1_hi'], v['first']))
+        for n, v in other.items(): print('note  %s: %d such instruction(s), no 128-bit matrix instruction in the kernel' % (n[:90], v['pk_src1_hi']))
+    return 1 if errors else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main(sys.argv[1:]))
