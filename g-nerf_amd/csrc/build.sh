@@ -7,25 +7,7 @@ root="$(cd "$here/../.." && pwd)"
 out="$here/../gnerf_hip/libgnerf_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$root/include -I$here -Wall -Wno-unused-function -Wno-unused-command-line-argument ${GNERF_EXTRA_FLAGS:-}"
-LLVM="${LLVM_BIN:-/opt/rocm/lib/llvm/bin}"
-# Every translation unit goes through its device ASSEMBLY: pk_opsel_fixup.py exchanges src0 / src1 of each packed-fp32 instruction
-# that takes the low half of its result from the high register of src1 -- a form that, on MI355X, sometimes reads 0.0 in lanes 48-63
-# while another wave of the SIMD runs v_mfma_f32_16x16x32_f16 (the script's header has the measurements; tools/isa_lint.py checks the
-# built library).  The device side is then assembled, linked and bundled with the toolchain's own tools and handed to the host
-# compile; the instruction streams are otherwise the compiler's.
-compile_unit() {
-    local src="$1" t="$here/.build_$1"
-    rm -rf "$t" && mkdir -p "$t"
-    $HIPCC $FLAGS --cuda-device-only -S "$here/$src.hip" -o "$t/dev.s"
-    python3 "$here/pk_opsel_fixup.py" "$t/dev.s" > "$t/fixup.log"
-    sed "s/^/[build] $src.hip: /" "$t/fixup.log"
-    "$LLVM/clang" -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c "$t/dev.s" -o "$t/dev.o"
-    "$LLVM/lld" -flavor gnu -m elf64_amdgpu --no-undefined -shared "$t/dev.o" -o "$t/dev.co"
-    "$LLVM/clang-offload-bundler" -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 \
-        -input=/dev/null -input="$t/dev.co" -output="$t/dev.hipfb"
-    $HIPCC $FLAGS --cuda-host-only -c "$here/$src.hip" -Xclang -fcuda-include-gpubinary -Xclang "$t/dev.hipfb" -o "$here/$src.o"
-    rm -rf "$t"
-}
+. "$here/compile_unit.sh"
 objs=()
 pids=()
 for src in capi bias_act upfirdn2d filtered_lrelu filtered_lrelu_fused grid_sample planes modconv render; do
@@ -33,13 +15,13 @@ for src in capi bias_act upfirdn2d filtered_lrelu filtered_lrelu_fused grid_samp
     obj="$here/$src.o"
     stale=0
     [ -f "$obj" ] || stale=1
-    for dep in "$here/$src.hip" "$here"/*.h "$here"/*.inl "$root/include/gnerf_hip.h" "$here/build.sh" "$here/pk_opsel_fixup.py"; do
+    for dep in "$here/$src.hip" "$here"/*.h "$here"/*.inl "$root/include/gnerf_hip.h" "$here/build.sh" "$here/compile_unit.sh" "$here/pk_opsel_fixup.py"; do
         [ "$stale" = 1 ] || { [ "$dep" -nt "$obj" ] && stale=1; } || true
     done
     if [ "$stale" = 1 ]; then
         echo "[build] $src.hip"
         rm -f "$obj"                     # a failed compile must not leave a stale object for the link
-        compile_unit "$src" &
+        compile_unit "$src" "$obj" &
         pids+=($!)
     fi
     objs+=("$obj")

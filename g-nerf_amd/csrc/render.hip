@@ -1040,11 +1040,10 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
             P.absmax = own;
         }
         P.p.workspace = nullptr;                                   // (the backward's params carry no workspace)
-        // Decoder arithmetic: the first kernel (the forward pipeline) chooses on the device like the forward; the tile kernel computes in
-        // exact fp32 (its f16 hi/lo form is opt-in, see render_bwd_tiles_kernel).  GNERF_BWD_MLP=f32|f16x3|auto sets both, _K1 / _K2 one.
+        // Decoder arithmetic: both kernels choose on the device like the forward (f16 hi/lo products when features, weights and
+        // activations are in f16's range, exact fp32 otherwise).  GNERF_BWD_MLP=f32|f16x3|auto forces both, _K1 / _K2 one of them.
         P.p.mlp_mode = GNERF_MLP_AUTO;
         Params P2 = P;
-        P2.p.mlp_mode = GNERF_MLP_F32;
         auto mode_of = [](const char* v, int dflt) { return !v ? dflt : !strcmp(v, "f32") ? GNERF_MLP_F32 : !strcmp(v, "f16x3") ? GNERF_MLP_F16X3 : !strcmp(v, "auto") ? GNERF_MLP_AUTO : dflt; };
         P.p.mlp_mode = mode_of(getenv("GNERF_BWD_MLP"), P.p.mlp_mode);
         P2.p.mlp_mode = mode_of(getenv("GNERF_BWD_MLP"), P2.p.mlp_mode);
@@ -1068,9 +1067,7 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
             hipLaunchKernelGGL(render_kernel_pipe_bwd<3>, dim3((unsigned)gsz), dim3(kPipeThreads), lds1, s, P, *g, g->scatter_stage);
         }
         if (int e = check_launch("render_kernel_pipe_bwd")) return e;
-        // (GNERF_BWD_LDS_PAD: extra dynamic LDS per workgroup -- 27000 leaves ONE workgroup per CU, the setting under which the opt-in f16
-        // form of the tile kernel has shown no discrepancy; see render_bwd_tiles_kernel)
-        const size_t lds2 = (bwd_tiles_weight_floats() + kTileWaves * bwd_tiles_wave_floats()) * sizeof(float) + (getenv("GNERF_BWD_LDS_PAD") ? size_t(atoi(getenv("GNERF_BWD_LDS_PAD"))) : 0);
+        const size_t lds2 = (bwd_tiles_weight_floats() + kTileWaves * bwd_tiles_wave_floats()) * sizeof(float);
         static PerDeviceOnce once_tiles;
         if (int e = once_tiles.raise_lds(render_bwd_tiles_kernel, "render_backward")) return e;
         const int64_t sample_tiles = total_seq * ((n_all + 15) / 16);

@@ -712,13 +712,13 @@ struct BwdTileF32 {
 // the range) -- so that the matrix instructions accumulate into them directly.
 // Valid under the same guard as the forward's f16 arithmetic (choose_mlp: features, weights, activations in f16's range).
 #ifndef GNERF_K2_SPLIT
-#define GNERF_K2_SPLIT split_f16x8_after_mfma
+#define GNERF_K2_SPLIT split_f16x8
 #endif
+#ifdef GNERF_K2_NO_FENCE
+#define GNERF_K2_PHASE_FENCE()
+#else
 #define GNERF_K2_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
-#ifndef GNERF_K2_SPLIT
-#define GNERF_K2_SPLIT split_f16x8_after_mfma
 #endif
-#define GNERF_K2_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
 struct BwdTileF16 {
     static constexpr int kMlp = kMlpF16x3;
     CoopLds C;                       // the forward's fragments (w1 = fragment base, w2 = density row * ln2, b1 * log2e, b2 scaled)
@@ -1061,18 +1061,15 @@ __device__ __forceinline__ void render_bwd_tiles_body(const Params& P, const gne
     bwd_reduce_decoder_grads(A, smem, Gr.grad_w1, Gr.grad_b1, Gr.grad_w2, Gr.grad_b2, tid, lane, j, kTileThreads);
 }
 
-// The exact-fp32 form is what runs (the launcher passes GNERF_MLP_F32).  The f16 hi/lo form is OPT-IN (GNERF_BWD_MLP_K2=f16x3, or =auto
-// for the forward's device-side range check): 1.45 ms instead of 2.12 ms at config 2, and fp32-grade (plane and decoder gradients
-// within 1e-6 of the fp32 form) whenever ONE workgroup is resident per CU.  With two -- the launch shape that gives the speed -- a
-// handful of samples per launch (of 2e5) come out wrong, different ones from run to run on identical inputs, about 1e-3 of the largest
-// gradient entry.  Ruled out this round (tools/dbg_bwd_det.py; profiles/README.md): the inline-asm splits (plain C++ splits behave the
-// same), wait states in front of and behind the splits, full s_waitcnt + s_nop fences between all phases of a tile, host
-// synchronisation between the backward's kernels, the wave reduction of the tile scale (butterfly or DPP, broadcast from lane 0), LDS
-// overrun at the end of the allocation (0.5 - 11 KB of padding change nothing; 27 KB -- one workgroup per CU -- cures it), two
-// workgroups sharing a CU as such (ONE workgroup of eight waves per CU, -DGNERF_K2_WAVES=8, fails every time), and the latency of
-// matrix results (a 512-cycle s_sleep between every group of matrix instructions and the first read of its results changes nothing).
-// What is left is that TWO WAVES SHARE A SIMD while both run this form -- the exact-fp32 form, same launch shape, same LDS layout,
-// same 256 registers, does not have the problem (capping this form at 232 registers does not cure it either).  Not root-caused: the form stays off by default, no default flow or test uses it.
+// Decoder arithmetic as in the forward: the f16 hi/lo form (1.45 ms at config 2; plane and decoder gradients within 1e-6 of the fp32
+// form) when the device-side range check allows it, the exact-fp32 form (2.12 ms) otherwise.
+// Until the middle of round 4 the f16 form was opt-in: with two workgroups per CU -- the launch shape that gives the speed -- a
+// handful of samples per launch (of 2e5) came out wrong, different ones from run to run.  Root cause (tools/dbg_bwd_stage.py, assembly
+// variants of this kernel; profiles/r04_pk_opsel_hazard.md): ONE instruction of the dO block, `v_pk_mul_f32 D, S0, S1 op_sel:[0,1]`
+// (low half of the result from the HIGH register of src1), reads that register as 0.0 in lanes 48-63 now and then while the other
+// wave of its SIMD has a v_mfma_f32_16x16x32_f16 in flight: sample 13 of a tile lost its first 16 dO entries.  The product with
+// the operands exchanged (`op_sel:[1,0]`) is exact in every run; the build (csrc/compile_unit.sh, pk_opsel_fixup.py) rewrites every
+// such instruction of the library and tools/isa_lint.py checks the result.
 __global__ __launch_bounds__(kTileThreads, kTileWaves == 4 ? 2 : 1) void render_bwd_tiles_kernel(Params P, gnerf_render_grads Gr, float* stage) {
     extern __shared__ __align__(16) float smem[];
     int mlp = P.p.mlp_mode;

@@ -41,9 +41,9 @@ constexpr float kLog2e = 1.44269504088896341f, kLn2 = 0.693147180559945309f;
 // 4.25 for the conversion: 86 -> 69 cycles per split (the compiler's own lowering of the expression is thirty-two instructions).
 // ONE asm block, ending in s_nop 1: the consumers are MFMAs, which need two wait states after a VALU write of an operand,
 // and the compiler's hazard recogniser does not look inside inline asm.
-#define GNERF_SPLIT_BODY(HEAD)                                                                                                          \
+#define GNERF_SPLIT_BODY                                                                                                               \
     float y0 = x[0], y1 = x[1], y2 = x[2], y3 = x[3], y4 = x[4], y5 = x[5], y6 = x[6], y7 = x[7];       /* x - hi is formed in place */   \
-    asm(HEAD                                                                                                                            \
+    asm(                                                                                                                                \
         "v_cvt_pk_f16_f32 %0, %8, %9\n\t"                                                                                               \
         "v_cvt_pk_f16_f32 %1, %10, %11\n\t"                                                                                             \
         "v_cvt_pk_f16_f32 %2, %12, %13\n\t"                                                                                             \
@@ -63,13 +63,7 @@ constexpr float kLog2e = 1.44269504088896341f, kLn2 = 0.693147180559945309f;
         "s_nop 1"                                                                                                                       \
         : "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]),               \
           "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7))
-__device__ __forceinline__ void split_f16x8(const float (&x)[8], unsigned (&hi)[4], unsigned (&lo)[4]) { GNERF_SPLIT_BODY(""); }
-// The same split where matrix instructions may still be in flight whose A / B operands sit in the registers this split is about to
-// write: the compiler's hazard recogniser does not see inside inline asm, and the register allocator happily hands the split of loop
-// iteration s + 1 the operand registers of iteration s's MFMAs (the backward tile kernel's k-step loops).  A 4-pass MFMA reads its
-// operands while it executes; overwriting them early showed up as one wrong tile in ~1e5 (gradients off by 1e-3 of their largest
-// entry, on some runs only: tools/dbg_bwd_det.py).  Sixteen wait states in front, inside the same asm block, cover the instruction.
-__device__ __forceinline__ void split_f16x8_after_mfma(const float (&x)[8], unsigned (&hi)[4], unsigned (&lo)[4]) { GNERF_SPLIT_BODY("s_nop 7\n\ts_nop 7\n\t"); }
+__device__ __forceinline__ void split_f16x8(const float (&x)[8], unsigned (&hi)[4], unsigned (&lo)[4]) { GNERF_SPLIT_BODY; }
 #undef GNERF_SPLIT_BODY
 // ... and the split written in plain C++ (the compiler's own instruction selection: about twice the instructions, but every hazard
 // between them and their neighbours is the compiler's to track)
@@ -343,6 +337,9 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     // a wrong feature, on rays of the second half of each item only, although the four-instruction chain is bit-exact in isolation
     // (tools/probes/pk_fma_chain_probe.hip) and its destination was kept off its sources.  It also removed no instruction: the tile's
     // v_mov_b32 are accumulator initialisations and permlane copies.  The compiler's form stays.)
+    // (Round 4 found the mechanism -- both observations carry its signature, lanes 48-63: a packed-fp32 instruction that takes the low
+    // half of its result from the HIGH register of src1 reads 0.0 there now and then while another wave of the SIMD runs
+    // v_mfma_f32_16x16x32_f16; csrc/pk_opsel_fixup.py.  The build now exchanges the sources of every such instruction.)
     auto blend = [&](int a, int pl, v4f& acc) {
         const v4f sum = tex[a][pl][0] * wgt[a][pl][0] + tex[a][pl][1] * wgt[a][pl][1] + tex[a][pl][2] * wgt[a][pl][2] + tex[a][pl][3] * wgt[a][pl][3];
         if (pl == 0) acc = sum; else acc += sum;

@@ -1023,8 +1023,8 @@ def test_render_backward_vs_oracle(dev, cfg, monkeypatch):
     nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
     # staged, pipelined first pass + sample-tile kernel (the default where the pipelined kernels cover the sample counts) / staged,
     # one wave per ray (GNERF_BWD_KERNEL=wave; what every other shape runs) / single pass, one atomic per tap and channel
-    # (GNERF_BWD_MLP=f32: the pipelined path with exact-fp32 products in BOTH kernels -- the first one otherwise picks f16 hi/lo or fp32
-    # on the device like the forward; the tile kernel is fp32 by default)
+    # (GNERF_BWD_MLP=f32: the pipelined path with exact-fp32 products in BOTH kernels -- each otherwise picks f16 hi/lo or fp32 on the
+    # device like the forward)
     for staged, kernel in ((True, None), (True, 'f32'), (True, 'wave'), (False, None)):
         monkeypatch.delenv('GNERF_BWD_KERNEL', raising=False)
         monkeypatch.delenv('GNERF_BWD_MLP', raising=False)
@@ -1052,6 +1052,49 @@ def test_render_backward_vs_oracle(dev, cfg, monkeypatch):
     assert none_dec is None
     ref_planes2, _ = _oracle_grads(planes, dec, o, d, nc, nf, opts, g_rgb, torch.zeros_like(g_depth), torch.zeros_like(g_wsum))
     assert _rel(gp2.reshape(N, 3, *cfg['hw'], 32).permute(0, 1, 4, 2, 3).cpu(), ref_planes2) < 2e-3
+
+
+def test_render_backward_f16_tile_kernel_agrees_with_fp32_on_every_run(dev, monkeypatch):
+    """The backward tile kernel's f16 hi/lo form with two waves per SIMD, forced on (GNERF_BWD_MLP_K2=f16x3), against the all-fp32 pair
+    on 36 different incoming gradients spanning twelve orders of magnitude: every plane gradient within 1e-5 of the fp32 one's largest
+    entry, every run.  (The form lost 16 dO entries of a handful of sample tiles per launch -- ~1e-3 here, on most launches -- until the
+    build started rewriting the packed-fp32 instruction that reads 0.0 next to v_mfma_f32_16x16x32_f16: tests/test_isa_cpu.py.)"""
+    import gnerf_hip
+    import gnerf_harness as H
+    torch.manual_seed(0)
+    N, res, S = 2, 32, 48
+    M = res * res
+    planes = torch.randn(N, 3, 32, 64, 64, device=dev)
+    dec = [torch.randn(64, 32, device=dev) * 0.18, torch.randn(64, device=dev) * 0.1, torch.randn(33, 64, device=dev) * 0.12, torch.randn(33, device=dev) * 0.1]
+    c2w = torch.cat([H.lookat_pose(3.14 / 2 + 0.3 * i, 3.14 / 2 - 0.05, 2.7) for i in range(N)]).to(dev)
+    intr = torch.tensor([[4.2647, 0, 0.5], [0, 4.2647, 0.5], [0, 0, 1]]).repeat(N, 1, 1).to(dev)
+    o, d = gnerf_hip.make_rays(c2w, intr, res)
+    nc, nf = torch.rand(N * M, S, device=dev), torch.rand(N * M, S, device=dev)
+    nhwc, amax = gnerf_hip.planes_to_nhwc(planes, with_absmax=True)
+    kw = dict(depth_resolution=S, depth_resolution_importance=S, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=res, planes_absmax=amax)
+    g_rgb, g_depth, g_w = torch.randn(N, M, 32, device=dev), torch.randn(N, M, 1, device=dev), torch.zeros(N, M, 1, device=dev)
+
+    def run(k1, k2, *g):
+        monkeypatch.setenv('GNERF_BWD_MLP_K1', k1)
+        monkeypatch.setenv('GNERF_BWD_MLP_K2', k2)
+        return gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, *g, **kw)
+    worst = 0.0
+    for i in range(36):
+        sc = [1.0, 1e-6, 3.0, 1e6][i % 4]
+        g = (g_rgb * sc, torch.zeros_like(g_depth) if i % 2 else g_depth * sc, g_w)
+        ref_p, ref_d = run('f32', 'f32', *g)
+        out_p, out_d = run('f32', 'f16x3', *g)
+        e = float((out_p - ref_p).abs().max() / ref_p.abs().max())
+        worst = max(worst, e)
+        assert e < 1e-5, (i, sc, e)
+        for a, b in zip(out_d, ref_d):
+            assert _rel(a, b) < 1e-4, (i, sc, _rel(a, b))
+    monkeypatch.delenv('GNERF_BWD_MLP_K1', raising=False)
+    monkeypatch.delenv('GNERF_BWD_MLP_K2', raising=False)
+    # the default picks the f16 form here (features, weights and activations are inside f16's range): same bound against fp32
+    out_p, _ = gnerf_hip.render_backward(nhwc, N, dec, o, d, nc, nf, g_rgb, g_depth, g_w, **kw)
+    ref_p, _ = run('f32', 'f32', g_rgb, g_depth, g_w)
+    assert float((out_p - ref_p).abs().max() / ref_p.abs().max()) < 1e-5
 
 
 def _oracle_free_planes_grad(results, g_rgb, ren, dec, g, o, d, opts, dev):

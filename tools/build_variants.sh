@@ -1,16 +1,22 @@
 #!/bin/bash
-# Timing-only ablation builds of libgnerf_hip.so (outputs are WRONG by construction; never shipped, never tested
-# for parity).  Used with tools/ablate.py to see which part of the render kernel the time goes to.
+# Variant builds of libgnerf_hip.so for A/B timing and ablation (g-nerf_amd/gnerf_hip/variants/libgnerf_<v>.so, selected with
+# GNERF_HIP_LIB): render.hip recompiled with the variant's macros through the same assembly pass as the product build, the other
+# objects taken from the product build (run g-nerf_amd/csrc/build.sh first).  A variant is a '+'-joined list of parts: `base`,
+# `STAMPS` (-DGNERF_STAMPS), `D:MACRO[=v]` (-DMACRO[=v]), anything else X -> -DGNERF_ABLATE_X (timing only: outputs are WRONG).
 set -euo pipefail
 root="$(cd "$(dirname "$0")/.." && pwd)"
-src="$root/g-nerf_amd/csrc"
+here="$root/g-nerf_amd/csrc"
 out="$root/g-nerf_amd/gnerf_hip/variants"
 mkdir -p "$out"
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$root/include -I$src -Wno-unused-value"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$root/include -I$here -Wno-unused-value -Wno-unused-command-line-argument"
+. "$here/compile_unit.sh"
 for v in "$@"; do
   defs=""
   IFS='+' read -ra parts <<< "$v"
   for p in "${parts[@]}"; do if [ "$p" = STAMPS ]; then defs="$defs -DGNERF_STAMPS"; elif [ "${p#D:}" != "$p" ]; then defs="$defs -D${p#D:}"; elif [ "$p" != base ]; then defs="$defs -DGNERF_ABLATE_$p"; fi; done
-  ( /opt/rocm/bin/hipcc $FLAGS $defs -shared "$src"/capi.hip "$src"/planes.hip "$src"/modconv.hip "$src"/render.hip "$src"/bias_act.hip "$src"/upfirdn2d.hip "$src"/filtered_lrelu.hip "$src"/filtered_lrelu_fused.hip "$src"/grid_sample.hip -o "$out/libgnerf_$v.so" && echo "[variant] $v" ) &
+  ( compile_unit render "$out/render_$v.o" "$defs" > /dev/null
+    $HIPCC -shared -fPIC --offload-arch=gfx950 "$here"/{capi,bias_act,upfirdn2d,filtered_lrelu,filtered_lrelu_fused,grid_sample,planes,modconv}.o "$out/render_$v.o" -o "$out/libgnerf_$v.so"
+    rm -f "$out/render_$v.o"; echo "[variant] $v" ) &
 done
 wait
