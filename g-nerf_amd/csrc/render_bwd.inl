@@ -165,6 +165,11 @@ __device__ __forceinline__ void bwd_gather_tile_rolling(const Params& P, const B
         }
     };
     auto issue = [&](int a, int pl) {
+#ifdef GNERF_ABLATE_K2GATHER     // timing-only build: no texel loads (outputs are wrong)
+        tex[a][pl][0] = (v4f){float(off[a][pl].x + cq16), 1.f, 2.f, 3.f}; tex[a][pl][1] = (v4f){float(off[a][pl].y), 1.f, 2.f, 3.f};
+        tex[a][pl][2] = (v4f){float(off[a][pl].z), 1.f, 2.f, 3.f};        tex[a][pl][3] = (v4f){float(off[a][pl].w), 1.f, 2.f, 3.f};
+        return;
+#endif
         tex[a][pl][0] = *reinterpret_cast<const v4f*>(planes + (off[a][pl].x + cq16));
         tex[a][pl][1] = *reinterpret_cast<const v4f*>(planes + (off[a][pl].y + cq16));
         tex[a][pl][2] = *reinterpret_cast<const v4f*>(planes + (off[a][pl].z + cq16));
