@@ -175,9 +175,12 @@ __device__ __forceinline__ void bwd_gather_tile_rolling(const Params& P, const B
         tex[a][pl][2] = *reinterpret_cast<const v4f*>(planes + (off[a][pl].z + cq16));
         tex[a][pl][3] = *reinterpret_cast<const v4f*>(planes + (off[a][pl].w + cq16));
     };
-    auto blend = [&](int a, int pl, v4f& acc) {
-        const v4f sum = tex[a][pl][0] * wgt[a][pl][0] + tex[a][pl][1] * wgt[a][pl][1] + tex[a][pl][2] * wgt[a][pl][2] + tex[a][pl][3] * wgt[a][pl][3];
-        if (pl == 0) acc = sum; else acc += sum;
+    auto blend = [&](int a, int pl, v4f& acc) {                 // the forward's chain (coop_shade_tile): same features, same bits
+        auto bc = [](float w) { return (v4f){w, w, w, w}; };
+        acc = pl == 0 ? tex[a][pl][0] * wgt[a][pl][0] : __builtin_elementwise_fma(tex[a][pl][0], bc(wgt[a][pl][0]), acc);
+        acc = __builtin_elementwise_fma(tex[a][pl][1], bc(wgt[a][pl][1]), acc);
+        acc = __builtin_elementwise_fma(tex[a][pl][2], bc(wgt[a][pl][2]), acc);
+        acc = __builtin_elementwise_fma(tex[a][pl][3], bc(wgt[a][pl][3]), acc);
     };
     v4f acc0, acc1;
     read_records(0);

@@ -328,21 +328,19 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
         tex[a][pl][3] = *reinterpret_cast<const v4f*>(R.planes_item + (off[a][pl].w + cq16));
 #endif
     };
-    // Per plane: the four taps as one sum of products, then added to the sample's accumulator (the first plane starts it).
-    // NOTE: the obvious cheaper form -- one fused multiply-add per tap chained through all 12 taps -- is NOT used: with
-    // hipcc 7.2's code for it (v_pk_fma_f32 chains) lanes 48-63 of ~3 % of the rays differed from run to run, while the same
-    // chain written with scalar v_fmac_f32 was bit-stable (tools/determinism.py; no wait state or s_waitcnt changed that).
-    // (Round 3: the same sum written with inline-asm v_pk_mul / v_pk_fma_f32 whose op_sel bits broadcast one weight of a register pair
-    // -- to save the copies the compiler makes to build (w, w) pairs -- reproduced that run-to-run difference: ~1 % of the samples got
-    // a wrong feature, on rays of the second half of each item only, although the four-instruction chain is bit-exact in isolation
-    // (tools/probes/pk_fma_chain_probe.hip) and its destination was kept off its sources.  It also removed no instruction: the tile's
-    // v_mov_b32 are accumulator initialisations and permlane copies.  The compiler's form stays.)
-    // (Round 4 found the mechanism -- both observations carry its signature, lanes 48-63: a packed-fp32 instruction that takes the low
-    // half of its result from the HIGH register of src1 reads 0.0 there now and then while another wave of the SIMD runs
-    // v_mfma_f32_16x16x32_f16; csrc/pk_opsel_fixup.py.  The build now exchanges the sources of every such instruction.)
+    // One fused multiply-add per tap, chained through the sample's 12 taps (the first tap of the first plane starts the accumulator).
+    // History: round 1 had this form and dropped it -- with hipcc 7.2's code for it (v_pk_fma_f32 chains whose weight operand is the
+    // high register of a pair, selected on src1) lanes 48-63 of ~3 % of the rays differed from run to run; round 3's inline-asm op_sel
+    // broadcast reproduced that.  Round 4 found the mechanism (csrc/pk_opsel_fixup.py: that operand form reads 0.0 in lanes 48-63 now and
+    // then while another wave of the SIMD runs v_mfma_f32_16x16x32_f16); with the build exchanging the sources of every such
+    // instruction (2 550 of them in this form) the chain is bit-stable (tools/determinism.py: 0 of 10 x 65 536 rays) and 1 % faster
+    // than four products summed per plane (24 instead of 28 packed instructions per sample pair).
     auto blend = [&](int a, int pl, v4f& acc) {
-        const v4f sum = tex[a][pl][0] * wgt[a][pl][0] + tex[a][pl][1] * wgt[a][pl][1] + tex[a][pl][2] * wgt[a][pl][2] + tex[a][pl][3] * wgt[a][pl][3];
-        if (pl == 0) acc = sum; else acc += sum;
+        auto bc = [](float w) { return (v4f){w, w, w, w}; };
+        acc = pl == 0 ? tex[a][pl][0] * wgt[a][pl][0] : __builtin_elementwise_fma(tex[a][pl][0], bc(wgt[a][pl][0]), acc);
+        acc = __builtin_elementwise_fma(tex[a][pl][1], bc(wgt[a][pl][1]), acc);
+        acc = __builtin_elementwise_fma(tex[a][pl][2], bc(wgt[a][pl][2]), acc);
+        acc = __builtin_elementwise_fma(tex[a][pl][3], bc(wgt[a][pl][3]), acc);
     };
     v4f acc0, acc1;
     read_records(0);
