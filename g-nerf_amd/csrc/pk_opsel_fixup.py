@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""Assembly pass of the gfx950 build (build.sh runs it on the device assembly of render.hip): no packed-fp32 instruction may take the
-LOW half of its result from the HIGH register of src1.
+"""Assembly pass of the gfx950 build (compile_unit.sh runs it on the device assembly of every translation unit): no packed-fp32
+instruction may take the LOW half of its result from the HIGH register of src1.
 
 Why.  On MI355X a `v_pk_mul_f32 D, S0, S1 op_sel:[0,1]` (low result = S0.lo * S1.hi) issued by one wave while ANOTHER wave of the same
 SIMD has a `v_mfma_f32_16x16x32_f16` (the gfx950 form with 128-bit A / B operands) in flight sometimes reads S1.hi as 0.0 in lanes
-48-63: one 16-lane quarter of one product comes out as a signed zero, about once per 2 000 executions under two waves per SIMD,
-never with one.  Measured with assembly-level variants of the backward tile kernel (profiles/r04_pk_opsel_hazard.md):
-the same product written `v_pk_mul_f32 D, S1, S0 op_sel:[1,0]` (the high register selected on src0) is exact in every run, as are two
-plain v_mul_f32; wait states in front of or behind the instruction, rewriting its operands first and replacing the DPP / v_readlane
-neighbours change nothing; replacing the 16x16x32 matrix instructions by the 16x16x16 form removes the failures.  The compiler knows
-nothing of this and picks the src1 form whenever register allocation leaves a broadcast value in an odd register.
+48-63.  tools/probes/pk_opsel_hazard_probe.hip shows it in isolation (profiles/r04_pk_opsel_hazard_probe.txt): v_pk_mul / v_pk_fma /
+v_pk_add with that select are wrong in lanes 48-63 only and next to that matrix instruction only -- between 2e-6 and 23 % of the
+executions, depending on how the two waves' instruction streams line up; every wrong result examined had read 0.0 -- while the same
+select on src0 or on v_pk_fma's src2, op_sel_hi on src1, and every form next to v_mfma_f32_16x16x16_f16, v_mfma_f32_16x16x4_f32, plain
+VALU work or an idle partner give 0 errors in 6.6e9 lane-results each.  In the renderer it cost the backward tile kernel's f16 form a
+16-lane quarter of one product about once per 2 000 tiles (profiles/r04_pk_opsel_hazard.md: assembly-level
+variants of that kernel -- operands exchanged or two v_mul_f32: exact; wait states, fresh operands, other neighbours: no change).
+The compiler knows nothing of this and picks the src1 form whenever register allocation leaves a broadcast value in an odd register.
 
 What.  Every `v_pk_{mul,add,fma}_f32` whose op_sel selects the high register for src1 has src0 and src1 exchanged (all three are
 commutative in src0 / src1) together with their op_sel / op_sel_hi / neg_lo / neg_hi entries.  An instruction that selects the high
@@ -45,10 +47,10 @@ def split_operands(text):
 
 
 def hazardous(mods):
-    """the low half reads the high register of src1 -- or of src2 (v_pk_fma_f32's addend), which has not been measured either way and
-    cannot be exchanged: none exists in the library today, and one turning up in a kernel with the matrix instruction stops the build"""
+    """the low half of the result reads the high register of src1.  (The same select on src0, on v_pk_fma_f32's src2, and op_sel_hi
+    on any source are measured safe: tools/probes/pk_opsel_hazard_probe.hip.)"""
     sel = mods.get('op_sel')
-    return bool(sel) and len(sel) >= 2 and (sel[1] == 1 or (len(sel) == 3 and sel[2] == 1))
+    return bool(sel) and len(sel) >= 2 and sel[1] == 1
 
 
 def fix_line(line):
@@ -58,7 +60,7 @@ def fix_line(line):
     indent, op, rest, comment = m.group(1), m.group(2), m.group(3), m.group(4) or ''
     ops, mods, order = split_operands(rest)
     if not hazardous(mods): return line, 'ok'
-    if mods['op_sel'][0] == 1 or (len(mods['op_sel']) == 3 and mods['op_sel'][2] == 1): return line, 'unfixable'
+    if mods['op_sel'][0] == 1: return line, 'unfixable'
     nsrc = len(ops) - 1
     ops[1], ops[2] = ops[2], ops[1]
     for name in order:
