@@ -240,8 +240,10 @@ def main():
         D = gnerf_generator.Discriminator(c_dim=25, img_resolution=args.res, img_channels=1, mbstd_group_size=min(4, args.batch)).train().requires_grad_(False).to(dev)
         H.broadcast_module(G)                                               # ... and made sure of (training_loop.py:234-238)
         H.broadcast_module(D)
-        opt_G = torch.optim.Adam(G.parameters(), lr=0.0025, betas=(0.9, 0.999), eps=1e-8)          # training_loop.py:311
-        opt_D = torch.optim.Adam(D.parameters(), lr=0.002, betas=(0.0, 0.99), eps=1e-8)            # train.py:242
+        # (on the GPU: torch's fused Adam -- one kernel per optimiser instead of the multi-tensor form's passes; same update formula)
+        fused = dict(fused=True) if use_gpu and os.environ.get('GNERF_FUSED_ADAM', '1') == '1' else {}
+        opt_G = torch.optim.Adam(G.parameters(), lr=0.0025, betas=(0.9, 0.999), eps=1e-8, **fused)          # training_loop.py:311
+        opt_D = torch.optim.Adam(D.parameters(), lr=0.002, betas=(0.0, 0.99), eps=1e-8, **fused)            # train.py:242
         batch = synthetic_gd_batch(args.batch, dev, seed=100 + rank)
         torch.manual_seed(1000 + rank)                                      # per-rank noise (training_loop.py:142-143)
         kw = dict(synthesis_kwargs=dict(force_fp32=True), d_kwargs=dict(force_fp32=True)) if args.force_fp32 else {}
@@ -258,7 +260,8 @@ def main():
         ballast = max(0, int(args.grad_mb * 1e6 - own) // 4) if args.grad_mb > 0 else 0
         model = RendererTrainer(args.batch, args.plane_res, ballast).to(dev)
         H.broadcast_module(model)
-        opt = torch.optim.Adam(model.parameters(), lr=0.0025, betas=(0.0, 0.99), eps=1e-8)
+        fused = dict(fused=True) if use_gpu and os.environ.get('GNERF_FUSED_ADAM', '1') == '1' else {}
+        opt = torch.optim.Adam(model.parameters(), lr=0.0025, betas=(0.0, 0.99), eps=1e-8, **fused)
         c, target, target_depth = synthetic_batch(args.batch, args.res, dev, seed=100 + rank)
         torch.manual_seed(1000 + rank)
 
