@@ -1,6 +1,6 @@
-"""Reproducer for the open issue of the backward tile kernel's OPT-IN f16 form (render_bwd.inl, render_bwd_tiles_kernel): the staged
-backward with each kernel's decoder arithmetic forced (GNERF_BWD_MLP_K1 / _K2) against the all-fp32 pair on varying gradients.  The
-default (K1 auto, K2 f32) and every pair with K2 = f32 agree to ~1e-6; K2 = f16x3 is off by ~1e-3 on some inputs / builds."""
+"""Soak of the staged backward with each kernel's decoder arithmetic forced (GNERF_BWD_MLP_K1 / _K2) against the all-fp32 pair on varying
+gradients: every pair agrees to ~1e-6.  (Until the build removed the packed-fp32 hazard -- profiles/r04_pk_opsel_hazard.md -- K2 = f16x3
+was off by ~1e-3 on most launches; this was the reproducer.)"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, 'g-nerf_amd'), os.path.join(ROOT, 'tests'), ROOT]

@@ -1,5 +1,7 @@
-"""Where does the opt-in f16 form of the backward tile kernel (GNERF_BWD_MLP_K2=f16x3) differ from run to run?  Captures the staging
-buffer of render_backward (the per-sample dX rows the tile kernel writes) on identical inputs and lists the rows that differ."""
+"""Does the f16 form of the backward tile kernel (GNERF_BWD_MLP_K2=f16x3) differ from run to run, and where?  Captures the staging
+buffer of render_backward (the per-sample dX rows the tile kernel writes) on identical inputs and lists the rows that differ: the
+tool that located the packed-fp32 hazard (profiles/r04_pk_opsel_hazard.md; sample 13 of a tile, lanes 48-63).  0 rows since the build
+rewrites that instruction form.  (Arguments are labels of repeated passes; the GNERF_BWD_DBG stage flags they once selected are gone.)"""
 import os, sys, json
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path[:0] = [os.path.join(ROOT, 'g-nerf_amd'), os.path.join(ROOT, 'tests'), ROOT]
