@@ -1072,7 +1072,7 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
         if (int e = once_tiles.raise_lds(render_bwd_tiles_kernel, "render_backward")) return e;
         const int64_t sample_tiles = total_seq * ((n_all + 15) / 16);
         int64_t g2 = (sample_tiles + kTileWaves - 1) / kTileWaves;
-        if (g2 > int64_t(kNumCU) * (kTileWaves == 4 ? 2 : 1)) g2 = int64_t(kNumCU) * (kTileWaves == 4 ? 2 : 1);    // two workgroups of four waves per CU, each walking a contiguous run of tiles
+        if (g2 > int64_t(kNumCU) * 2) g2 = int64_t(kNumCU) * 2;    // two workgroups of four waves per CU, each walking a contiguous run of tiles
         g2 = (g2 + kNumXCD - 1) / kNumXCD * kNumXCD;
         P2.pipe_unit = P.pipe_unit;
         hipLaunchKernelGGL(render_bwd_tiles_kernel, dim3((unsigned)g2), dim3(kTileThreads), lds2, s, P2, *g, g->scatter_stage);

@@ -633,10 +633,7 @@ __global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gn
 // lookup + decoder forward (exact fp32) + the four gradient products + dX rows.  One wave per 16-rank tile, tiles dealt in contiguous
 // runs of the locality-ordered ray sequence; the dX rows of a tile are 2 KB of contiguous staging memory (the one-wave-per-ray kernel
 // above writes them rank by rank behind a second forward recomputation, with 12 per-sample arrays per wave in LDS).
-#ifndef GNERF_K2_WAVES
-#define GNERF_K2_WAVES 4
-#endif
-constexpr int kTileWaves = GNERF_K2_WAVES, kTileThreads = 64 * kTileWaves;       // waves of a tile-kernel workgroup
+constexpr int kTileWaves = 4, kTileThreads = 64 * kTileWaves;       // waves of a tile-kernel workgroup
 struct DepthListPos {
     const BwdRay& R; const float* dep; float box_scale;
     __device__ __forceinline__ void operator()(int j, float& px, float& py, float& pz) const {
@@ -1078,18 +1075,12 @@ __device__ __forceinline__ void render_bwd_tiles_body(const Params& P, const gne
 // wave of its SIMD has a v_mfma_f32_16x16x32_f16 in flight: sample 13 of a tile lost its first 16 dO entries.  The product with
 // the operands exchanged (`op_sel:[1,0]`) is exact in every run; the build (csrc/compile_unit.sh, pk_opsel_fixup.py) rewrites every
 // such instruction of the library and tools/isa_lint.py checks the result.
-__global__ __launch_bounds__(kTileThreads, kTileWaves == 4 ? 2 : 1) void render_bwd_tiles_kernel(Params P, gnerf_render_grads Gr, float* stage) {
+__global__ __launch_bounds__(kTileThreads, 2) void render_bwd_tiles_kernel(Params P, gnerf_render_grads Gr, float* stage) {
     extern __shared__ __align__(16) float smem[];
     int mlp = P.p.mlp_mode;
     if (mlp == kMlpAuto) mlp = choose_mlp(P, smem);
-#if defined(GNERF_K2_ONLY) && GNERF_K2_ONLY == 16
-    render_bwd_tiles_body<BwdTileF16>(P, Gr, stage, smem);
-#elif defined(GNERF_K2_ONLY)
-    render_bwd_tiles_body<BwdTileF32>(P, Gr, stage, smem);
-#else
     if (mlp == kMlpF32) render_bwd_tiles_body<BwdTileF32>(P, Gr, stage, smem);
     else                render_bwd_tiles_body<BwdTileF16>(P, Gr, stage, smem);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------

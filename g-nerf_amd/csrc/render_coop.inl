@@ -65,18 +65,6 @@ constexpr float kLog2e = 1.44269504088896341f, kLn2 = 0.693147180559945309f;
           "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7))
 __device__ __forceinline__ void split_f16x8(const float (&x)[8], unsigned (&hi)[4], unsigned (&lo)[4]) { GNERF_SPLIT_BODY; }
 #undef GNERF_SPLIT_BODY
-// ... and the split written in plain C++ (the compiler's own instruction selection: about twice the instructions, but every hazard
-// between them and their neighbours is the compiler's to track)
-__device__ __forceinline__ void split_f16x8_plain(const float (&x)[8], unsigned (&hi)[4], unsigned (&lo)[4]) {
-    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const _Float16 h0 = (_Float16)x[2 * i], h1 = (_Float16)x[2 * i + 1];
-        const _Float16 l0 = (_Float16)(x[2 * i] - (float)h0), l1 = (_Float16)(x[2 * i + 1] - (float)h1);
-        hi[i] = __builtin_bit_cast(unsigned, (h2v){h0, h1});
-        lo[i] = __builtin_bit_cast(unsigned, (h2v){l0, l1});
-    }
-}
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ h8 as_h8(u4v v) { return __builtin_bit_cast(h8, v); }
 // LDS layouts that a lane (j = lane & 15, g = lane >> 4) reads 16 bytes of are kept in FRAGMENT ORDER: the chunk of lane i at

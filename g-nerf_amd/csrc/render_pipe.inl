@@ -728,19 +728,12 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
     if (wv == 3 && lane == 0) range.flush(P);
 }
 
-#ifdef GNERF_PIPE_NOINLINE_BODIES
-template <int TP, int MLP, bool FULL, bool GEN>
-__device__ __attribute__((noinline)) void render_pipe_body_call(const Params& P, float* smem) { render_pipe_body<TP, MLP, FULL, GEN>(P, smem); }
-#else
-template <int TP, int MLP, bool FULL, bool GEN>
-__device__ __forceinline__ void render_pipe_body_call(const Params& P, float* smem) { render_pipe_body<TP, MLP, FULL, GEN>(P, smem); }
-#endif
 template <int TP, int MLP, bool FULL, bool GEN = false>
 __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD : (TP == 2 ? GNERF_PIPE2_WAVES_PER_SIMD : 2)) void render_kernel_pipe(Params P) {
     extern __shared__ __align__(16) float smem[];
     if constexpr (MLP == kMlpAuto) {            // see render_kernel_coop
-        if (choose_mlp(P, smem) == kMlpF32) render_pipe_body_call<TP, kMlpF32, FULL, GEN>(P, smem);
-        else                               render_pipe_body_call<TP, kMlpF16x3, FULL, GEN>(P, smem);
+        if (choose_mlp(P, smem) == kMlpF32) render_pipe_body<TP, kMlpF32, FULL, GEN>(P, smem);
+        else                               render_pipe_body<TP, kMlpF16x3, FULL, GEN>(P, smem);
     } else {
         render_pipe_body<TP, MLP, FULL, GEN>(P, smem);
     }

@@ -58,3 +58,13 @@ for chunk in (8,16,32,96):
     analyse('merged sorted', [ka], chunk)
 # per-ray only (no cross-ray): reduction within a ray
 hits=ka.reshape(len(idx),-1); print('per-ray reduction %.2f'% (hits.size/sum(len(np.unique(h)) for h in hits)))
+# per plane: how much of the reduction each plane contributes at 16-rank chunks, and what keeping a plane's table across the whole ray would give
+for pl, name in enumerate(('plane 0 (x,y)', 'plane 1 (x,z)', 'plane 2 (z,x)')):
+    kp = ka[..., 4 * pl:4 * pl + 4]
+    for chunk in (16, 96):
+        flushes = 0
+        for t in range(nt):
+            Kt = kp[t * 16:(t + 1) * 16]
+            for c0 in range(0, Kt.shape[1], chunk):
+                flushes += len(np.unique(Kt[:, c0:c0 + chunk].reshape(-1)))
+        print(name, 'chunk', chunk, 'hits', kp.size, 'flushes', flushes, 'reduction %.2f' % (kp.size / flushes))
