@@ -432,6 +432,9 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
                 const int i = lane + 64 * q;
                 if (i < F) {
                     int fix = 0;
+#ifndef GNERF_CLASH_UNROLL      // (rare path: unrolled at the compile-time counts it hoists 48 lane masks out of the ray loop -- 96 spilled SGPRs)
+#pragma nounroll
+#endif
                     for (int o2 = 0; o2 < F; o2++) fix += (sl.t_e[fine_e0 + o2] == key_f[q] && o2 < i) ? 1 : 0;
                     rank_f[q] += fix;
                     sl.rank_e[fine_e0 + i] = rank_f[q];
