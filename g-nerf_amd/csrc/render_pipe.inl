@@ -367,6 +367,16 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
                 if (i < F) q_f[q] = sl.v_e[fine_e0 + i];
             }
         }
+#ifdef GNERF_ABLATE_PIPERANK    // timing-only build: no rank merge on the scalar wave (coarse then fine in index order; outputs are wrong)
+#pragma unroll
+        for (int q = 0; q < RND; q++) {
+            const int i = lane + 64 * q;
+            rank_f[q] = S + i; key_f[q] = i < F ? sl.t_e[fine_e0 + i] : 0.f;
+            rank_c[q] = i; key_c[q] = i < S ? sl.t_e[i] : 0.f;
+            if (i < F) sl.rank_e[fine_e0 + i] = S + i;
+            if (i < S) sl.rank_e[i] = i;
+        }
+#else
 #pragma unroll
         for (int q = 0; q < RND; q++) {
             const int i = lane + 64 * q;
@@ -441,6 +451,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
                 }
             }
         }
+#endif
 #pragma unroll
         for (int q = 0; q < RND; q++) {
             const int i = lane + 64 * q;
