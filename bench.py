@@ -398,7 +398,7 @@ def realistic_planes_step(dev, c2w, intr, steps, rank=0):
 
 
 ORBIT_VIEWS = 4                   # cameras per synthesis call of the batched orbit (tools/bench_generator.py --frames-per-call: 2 / 4 / 8 -> 1235 / 1357 / 1327 frames/s)
-PEAK_ATOMIC_GBS = 1300.0          # chip-wide float-atomic rate (MI355X_MICROARCH.md, Global float atomics: 1.26-1.36 TB/s of added bytes)
+PEAK_ATOMIC_GBS = 1330.0          # chip-wide float-atomic rate: 20.8 G 64-byte requests/s on this device (profiles/r04_atomic_scope_probe.txt; MI355X_MICROARCH.md gives 1.26-1.36 TB/s of added bytes)
 FLOP_BWD_PER_SAMPLE = 3 * FLOP_MLP_PER_SAMPLE       # one forward recomputation + dX / dW products of both layers (fp32 MFMA)
 
 
