@@ -76,6 +76,8 @@ def test_fixup_leaves_safe_forms_alone_and_reports_what_it_cannot_repair(tmp_pat
     text = p.read_text()
     assert 'v_pk_mul_f32 v[0:1], v[4:5], v[2:3] op_sel:[1,0]' in text and 'op_sel:[1,1]' in text
     assert FX.main(['--check', str(p)]) == 0
+    before = p.read_text()
+    assert FX.main([str(p)]) == 0 and p.read_text() == before                    # a second pass changes nothing
     body[7] = '\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,1]'
     p.write_text('\n'.join(body))
     assert FX.main([str(p)]) == 1 and FX.main(['--check', str(p)]) == 1
