@@ -13,9 +13,9 @@ LLVM = os.environ.get('LLVM_BIN', '/opt/rocm/lib/llvm/bin')
 MAGIC = b'__CLANG_OFFLOAD_BUNDLE__'
 
 
-def code_objects(lib):
-    """the gfx950 code objects of every offload bundle in the library's .hip_fatbin section (one bundle per translation unit)"""
-    tmp = tempfile.mkdtemp()
+def code_objects(lib, tmp):
+    """the gfx950 code objects of every offload bundle in the library's .hip_fatbin section (one bundle per translation unit), written
+    into the directory `tmp`"""
     fat = os.path.join(tmp, 'fat.bin')
     subprocess.run([os.path.join(LLVM, 'llvm-objcopy'), '--dump-section=.hip_fatbin=' + fat, lib], check=True, capture_output=True)
     blob = open(fat, 'rb').read()
@@ -37,8 +37,10 @@ def code_objects(lib):
 
 def lint(lib):
     kernels = {}
-    for co in code_objects(lib):
-        dis = subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '-d', '--no-show-raw-insn', co], check=True, capture_output=True, text=True).stdout
+    with tempfile.TemporaryDirectory() as tmp:
+        dumps = [subprocess.run([os.path.join(LLVM, 'llvm-objdump'), '-d', '--no-show-raw-insn', co], check=True, capture_output=True, text=True).stdout
+                 for co in code_objects(lib, tmp)]
+    for dis in dumps:
         name = None
         for line in dis.split('\n'):
             m = re.match(r'^[0-9a-f]+ <(.+)>:$', line)
