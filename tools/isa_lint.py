@@ -2,8 +2,8 @@
 """ISA lint of the built library: disassembles every gfx950 code object bundled in libgnerf_hip.so and reports, per kernel, the
 packed-fp32 instructions that take the LOW half of their result from the HIGH register of src1 -- the form that reads 0.0 in lanes
 48-63 now and then while another wave of the SIMD runs v_mfma_f32_16x16x32_f16 (g-nerf_amd/csrc/pk_opsel_fixup.py has the
-measurements).  build.sh removes them from render.hip's kernels; any kernel that still has one AND can share a SIMD with the 128-bit
-matrix instruction (i.e. contains it) is an error.
+measurements).  The build exchanges their sources in every translation unit; a kernel that still has one AND contains the 128-bit
+matrix instruction (its own waves share SIMDs) is an error, one without the matrix instruction is listed.
 usage: tools/isa_lint.py [library]      exit status 1 on an error; --json for one JSON line"""
 import json, os, re, struct, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
