@@ -692,7 +692,11 @@ __global__ __launch_bounds__(64) void query_kernel(gnerf_render_params p, float 
 // default-init decoder) has e_o = 1.1e-5; planes scaled by ~20 or decoder weights by ~5 cross over to fp32.
 constexpr float kMlpRangeLimit = 30000.f;
 constexpr float kMlpErrLimit = 1.0f / 4096.f;
-__device__ __forceinline__ int choose_mlp(const Params& P, float* smem) {
+// ... and the f16 body's softplus may take its short form log2(1 + 2^p') -- exp2, add, log2 instead of exp2, add, log2, add, max per
+// hidden activation -- while no base-2 pre-activation can reach exp2's overflow: |p'| <= max_r ||W1'[r,:]||_1 A + max |b1'| <= 99
+// (config 2: 37; on a random-init generator's planes: 57).  Beyond that the body keeps the form that is safe for any p'.
+constexpr float kSoftplusDirectLimit = 100.f;
+__device__ __forceinline__ int choose_mlp(const Params& P, float* smem, bool* softplus_direct = nullptr) {
     const gnerf_render_params& p = P.p;
     constexpr float kL2e = 1.44269504088896341f;
     // the decoder into LDS with coalesced loads (rows padded to an odd pitch: the row sums below are conflict-free); a first
@@ -737,11 +741,13 @@ __device__ __forceinline__ int choose_mlp(const Params& P, float* smem) {
                             && mb2 <= kMlpRangeLimit && e_o <= kMlpErrLimit;         // every comparison is false for NaN
             const int choice = ok ? 1 : 2;                                           // kMlpF16x3 : kMlpF32
             reinterpret_cast<int*>(smem)[0] = choice;
+            reinterpret_cast<int*>(smem)[1] = (ok && h_hard <= kSoftplusDirectLimit) ? 1 : 0;
             if (blockIdx.x == 0 && p.workspace) static_cast<int*>(p.workspace)[4] = choice;         // diagnostics (gnerf_hip.last_mlp_choice)
         }
     }
     __syncthreads();
     const int choice = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(smem)[0]);
+    if (softplus_direct) *softplus_direct = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(smem)[1]) != 0;
     __syncthreads();                                     // smem is the body's from here on
     return choice;
 }

@@ -261,7 +261,7 @@ __device__ __forceinline__ void lds_wave_sync() {
 }
 template <bool BLOCK_SYNC, int MLP>
 __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& L, const CoopRay& R, const float* t_list, int count,
-                                                int tile, bool active, float* sig_list, int lane, int wv, v4f (&col)[2], Stamps& st) {
+                                                int tile, bool active, float* sig_list, int lane, int wv, v4f (&col)[2], Stamps& st, bool sp_direct = false) {
 #ifdef GNERF_ABLATE_SHADE       // timing-only build: no lookups, no MLP
     if (active && lane < 16 && 16 * tile + lane < count) sig_list[16 * tile + lane] = t_list[16 * tile + lane] - 2.7f;
     col[0] = (v4f){0.1f, 0.2f, 0.3f, 0.4f}; col[1] = col[0];
@@ -475,13 +475,22 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
         // v_exp_f32 (-|p'| as source modifiers), v_add_f32, v_log_f32, v_add_f32, v_max_f32 = 2 quarter-rate + 2 full-rate + 1
         // half-rate instruction (tools/probes/valu_issue_probe: 8.4 + 2.3 + 8.3 + 2.3 + 4.5 SIMD cycles) where
         // min / [canonicalise] / exp2 / add / log2 / max was 2 quarter-rate + 1 full-rate + 3 half-rate.
+        // When the decoder's norms bound every |p'| below exp2's overflow (choose_mlp: sp_direct, wave-uniform) the short form
+        // log2(1 + 2^p') does: exp2, add, log2 -- 16 v_add and 16 half-rate v_max fewer per tile, 3.3 % of the kernel at config 2.
         v4f e;
+        if (sp_direct) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(-fabsf(h[m][r]));
+            for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(h[m][r]);
 #pragma unroll
-        for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_logf(1.0f + e[r]);
+            for (int r = 0; r < 4; r++) hv[m][r] = act_softplus(__builtin_amdgcn_logf(1.0f + e[r]), h[m][r]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; r++) hv[m][r] = act_softplus(fmaxf(h[m][r] + e[r], e[r]), h[m][r]);
+            for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(-fabsf(h[m][r]));
+#pragma unroll
+            for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_logf(1.0f + e[r]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) hv[m][r] = act_softplus(fmaxf(h[m][r] + e[r], e[r]), h[m][r]);
+        }
         const v4f ws = *reinterpret_cast<const v4f*>(L.w2 + 16 * m + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; r++) sig = fmaf(ws[r], hv[m][r], sig);
@@ -540,7 +549,7 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
 }
 
 template <int TC1, int TF1, int MLP>
-__device__ __forceinline__ void render_coop_body(const Params& P, float* smem) {
+__device__ __forceinline__ void render_coop_body(const Params& P, float* smem, bool sp_direct = false) {
     const gnerf_render_params& p = P.p;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -627,7 +636,7 @@ __device__ __forceinline__ void render_coop_body(const Params& P, float* smem) {
 #pragma unroll
         for (int i = 0; i < TC1; i++) {
             const int t = wv + kCoopWaves * i;
-            coop_shade_tile<true, MLP>(P, L, R, L.t_e, S, t, t < P.tiles_c, L.sig_e, lane, wv, col_c[i], st);
+            coop_shade_tile<true, MLP>(P, L, R, L.t_e, S, t, t < P.tiles_c, L.sig_e, lane, wv, col_c[i], st, sp_direct);
         }
         __syncthreads();
         if (dbg) for (int k = tid; k < S; k += kCoopThreads) dbg[GNERF_DBG_SIGMA_COARSE * n_all + k] = L.sig_e[k];
@@ -684,7 +693,7 @@ __device__ __forceinline__ void render_coop_body(const Params& P, float* smem) {
 #pragma unroll
             for (int i = 0; i < TF1; i++) {
                 const int t = wv + kCoopWaves * i;
-                coop_shade_tile<true, MLP>(P, L, R, L.t_e + fine_e0, F, t, t < P.tiles_f, L.sig_e + fine_e0, lane, wv, col_f[i], st);
+                coop_shade_tile<true, MLP>(P, L, R, L.t_e + fine_e0, F, t, t < P.tiles_f, L.sig_e + fine_e0, lane, wv, col_f[i], st, sp_direct);
             }
             __syncthreads();
             if (dbg) for (int k = tid; k < F; k += kCoopThreads) dbg[GNERF_DBG_SIGMA_FINE * n_all + k] = L.sig_e[fine_e0 + k];
@@ -825,8 +834,9 @@ template <int TC1, int TF1, int MLP>
 __global__ __launch_bounds__(kCoopThreads, 3) void render_kernel_coop(Params P) {
     extern __shared__ __align__(16) float smem[];
     if constexpr (MLP == kMlpAuto) {
-        if (choose_mlp(P, smem) == kMlpF32) render_coop_body<TC1, TF1, kMlpF32>(P, smem);
-        else                               render_coop_body<TC1, TF1, kMlpF16x3>(P, smem);
+        bool sp_direct;
+        if (choose_mlp(P, smem, &sp_direct) == kMlpF32) render_coop_body<TC1, TF1, kMlpF32>(P, smem);
+        else                                           render_coop_body<TC1, TF1, kMlpF16x3>(P, smem, sp_direct);
     } else {
         render_coop_body<TC1, TF1, MLP>(P, smem);
     }

@@ -104,7 +104,7 @@ __device__ __forceinline__ int pipe_seq_to_ray(const Params& P, int64_t seq) {
 // q = sum_c dL/dcolour[c] colour[c] (all the composite's gradient needs of them); the scalar wave runs the composite's gradient
 // (ray_marcher.py:25-57 backwards) as wave scans right after the merge.  Nothing else of the ray is kept.
 template <int TP, int MLP, bool FULL, bool GEN, bool BWD = false>
-__device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, const gnerf_render_grads* Gr = nullptr, float* bstage = nullptr) {
+__device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, const gnerf_render_grads* Gr = nullptr, float* bstage = nullptr, bool sp_direct = false) {
     typedef PipeDims<TP> D;
     constexpr int kPipeMaxS = D::kMaxS, kPipeSPad = D::kSPad, kSlotFloats = D::kSlotFloats, RND = D::kRounds;
     const gnerf_render_params& p = P.p;
@@ -598,8 +598,8 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
         for (int i = 0; i < TP; i++) {
             const int tile = wv + 3 * i;
             if (TP > 1 && tile >= (fine ? tiles_f : tiles_c)) continue;       // wave-uniform: this wave has no such tile
-            if (!fine) coop_shade_tile<false, MLP>(P, L, R, sl.t_e, S, tile, tile < tiles_c, sl.sig_e, lane, wv, col[i], st);
-            else       coop_shade_tile<false, MLP>(P, L, R, sl.t_e + fine_e0, F, tile, tile < tiles_f, sl.sig_e + fine_e0, lane, wv, col[i], st);
+            if (!fine) coop_shade_tile<false, MLP>(P, L, R, sl.t_e, S, tile, tile < tiles_c, sl.sig_e, lane, wv, col[i], st, sp_direct);
+            else       coop_shade_tile<false, MLP>(P, L, R, sl.t_e + fine_e0, F, tile, tile < tiles_f, sl.sig_e + fine_e0, lane, wv, col[i], st, sp_direct);
         }
     };
     auto accumulate = [&](int r, const v4f (&cc)[TP][2], const v4f (&cf)[TP][2]) {
@@ -746,8 +746,9 @@ template <int TP, int MLP, bool FULL, bool GEN = false>
 __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD : (TP == 2 ? GNERF_PIPE2_WAVES_PER_SIMD : 2)) void render_kernel_pipe(Params P) {
     extern __shared__ __align__(16) float smem[];
     if constexpr (MLP == kMlpAuto) {            // see render_kernel_coop
-        if (choose_mlp(P, smem) == kMlpF32) render_pipe_body<TP, kMlpF32, FULL, GEN>(P, smem);
-        else                               render_pipe_body<TP, kMlpF16x3, FULL, GEN>(P, smem);
+        bool sp_direct;
+        if (choose_mlp(P, smem, &sp_direct) == kMlpF32) render_pipe_body<TP, kMlpF32, FULL, GEN>(P, smem);
+        else                                           render_pipe_body<TP, kMlpF16x3, FULL, GEN>(P, smem, nullptr, nullptr, sp_direct);
     } else {
         render_pipe_body<TP, MLP, FULL, GEN>(P, smem);
     }
@@ -759,7 +760,8 @@ template <int TP>
 __global__ __launch_bounds__(kPipeThreads, TP == 1 ? GNERF_PIPE_WAVES_PER_SIMD : (TP == 2 ? GNERF_PIPE2_WAVES_PER_SIMD : 2)) void render_kernel_pipe_bwd(Params P, gnerf_render_grads Gr, float* stage) {
     extern __shared__ __align__(16) float smem[];
     int mlp = P.p.mlp_mode;                     // (GNERF_BWD_MLP forces one; the launcher passes AUTO otherwise)
-    if (mlp == kMlpAuto) mlp = choose_mlp(P, smem);
+    bool sp_direct = false;
+    if (mlp == kMlpAuto) mlp = choose_mlp(P, smem, &sp_direct);
     if (mlp == kMlpF32) render_pipe_body<TP, kMlpF32, false, false, true>(P, smem, &Gr, stage);
-    else                render_pipe_body<TP, kMlpF16x3, false, false, true>(P, smem, &Gr, stage);
+    else                render_pipe_body<TP, kMlpF16x3, false, false, true>(P, smem, &Gr, stage, sp_direct);
 }
