@@ -81,13 +81,13 @@ def algorithmic_valu_per_ray(s=48, f=48):
         'full': 6                   # position o + t d (3 fma) and the box scale (3 mul)
                 + 3 * 16            # per plane: pixel coordinates 2, fractions and 1 - f 4, four tap weights 4, x1 / y1 2, tap addresses 4
                 + 12 * 32           # the blend: 12 taps x 32 channels, one FMA each (packed or not: 2.2 cycles per FMA either way)
-                + 64 * 2            # softplus log2(1 + 2^-|p|) + max(p + l, l): two adds per hidden unit
+                + 64                # softplus log2(1 + 2^p'): the add (round 4: the kernel runs this short form whenever the decoder's norms bound |p'|;
+                                    # until then the table charged the overflow-safe form's two adds and one max, which the kernel executed)
                 + 64                # density row: 64 FMAs
                 + 32 * 2            # sigmoid 1.002 / (1 + 2^o) - 0.001: add, fma
                 + 32,               # composite: one FMA per channel
         'half': 3 * 16              # per plane: floor 2, float->int 2, zero-padding compares + selects 8, clamps 4
                 + 32 * 2            # hi/lo f16 split of the 32 features: 2 instructions per value (cvt_pk 1/2, fma_mix 1, cvt_pk 1/2)
-                + 64                # softplus: the max
                 + 64 * 2,           # hi/lo split of the 64 activations
         'quarter': 64 * 2 + 32 * 2,     # exp2 + log2 per hidden unit, exp2 + rcp per colour
     }
