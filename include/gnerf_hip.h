@@ -278,7 +278,9 @@ typedef struct gnerf_render_params {
        faster) -- only valid while features, weights and hidden activations are inside f16's range.
        GNERF_MLP_AUTO (0, default): decided ON THE DEVICE per call from max |planes| and the decoder's weights (bounds
        in DESIGN.md section 2.1): out-of-range or ill-conditioned inputs take the fp32 path, so results never depend on
-       f16's range.  planes_absmax: one device float from gnerf_planes_to_nhwc_stats / gnerf_planes_absmax /
+       f16's range.  (AUTO's f16 body also evaluates softplus as log2(1 + 2^p') when the same norms keep every pre-activation
+       below exp2's overflow, and in the form that is safe for any p' otherwise -- as a forced GNERF_MLP_F16X3 always does: the
+       two forms differ by fp32 rounding.)  planes_absmax: one device float from gnerf_planes_to_nhwc_stats / gnerf_planes_absmax /
        gnerf_upsample2x_add_nhwc; NULL makes the AUTO launcher measure it itself (one extra pass over the planes).
        CONTRACT of a caller-supplied planes_absmax: at the time the render kernel runs (stream order) the float must be
        >= max |planes_nhwc| of THIS call's planes -- an upper bound is fine (it only sends more calls to the fp32 body, or to
