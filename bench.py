@@ -124,7 +124,11 @@ def roofline(kernel_ms, rays, s, f, plane, n_items, pmc=None, pmc_source=None, t
                         'note': 'measured at 4 waves per SIMD (the kernel\'s occupancy); MFMA and VALU issue cycles of co-resident waves add '
                                 f'(probe: mfma_f16+8fma); {N_SIMD} SIMDs at {CLOCK_HZ / 1e9} GHz'},
             'frac_if_every_valu_cost_2_cycles': ((alg['full'] + alg['half']) / 64 * 2 + alg['quarter'] / 64 * 8 + alg['mfma_f16'] * 8)
-                                                * rays / (N_SIMD * CLOCK_HZ) * 1e3 / kernel_ms},
+                                                * rays / (N_SIMD * CLOCK_HZ) * 1e3 / kernel_ms,
+            # continuity with the lines of rounds 1-3 and of the first half of round 4, whose table charged softplus the overflow-safe form
+            # the kernel executed then (one more full-rate add and one half-rate max per hidden unit and sample)
+            'frac_on_the_table_before_the_short_softplus': (alg_cycles_per_ray + (s + f) * 64 * (price['full'] + price['half']) / 64)
+                                                           * rays / (N_SIMD * CLOCK_HZ) * 1e3 / kernel_ms},
         'l1_gather_floor': {'floor_ms': gather_floor_ms, 'frac': gather_floor_ms / kernel_ms,
                             'note': f'12 taps x 128 B per sample at the measured {GATHER_BYTES_PER_CYCLE_PER_CU:.0f} B/cycle/CU of the vector-memory path '
                                     '(probe `gather`): the second-busiest unit, overlapped with the vector issue'},
