@@ -732,6 +732,7 @@ struct BwdTileF16 {
     float* stage; float* tbuf; float* hbuf;
     float l1_w2c, max_ws;            // max_hid sum_out |W2c[out][hid]|, max |W2[0]|: |dPRE| <= |dH| <= l1_w2c max|dO| + max_ws max|dsigma|
     float acc_scale;                 // the power of two A.w1 / A.w2 currently carry
+    bool sp_direct = false;          // softplus as log2(1 + 2^p') (choose_mlp: every |p'| below exp2's overflow), as the forward kernels take it
     __device__ __forceinline__ void setup(const Params& P, float* smem, const float*, int tid) {
         const gnerf_render_params& p = P.p;
         stage_decoder<kMlpF16x3>(C, smem, p, tid, kTileThreads);
@@ -793,12 +794,19 @@ struct BwdTileF16 {
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             v4f e;
+            if (sp_direct) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(-fabsf(hv[m][r]));
+                for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(hv[m][r]);
 #pragma unroll
-            for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_logf(1.0f + e[r]);
+                for (int r = 0; r < 4; r++) hv[m][r] = __builtin_amdgcn_logf(1.0f + e[r]);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; r++) hv[m][r] = fmaxf(hv[m][r] + e[r], e[r]);
+                for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_exp2f(-fabsf(hv[m][r]));
+#pragma unroll
+                for (int r = 0; r < 4; r++) e[r] = __builtin_amdgcn_logf(1.0f + e[r]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) hv[m][r] = fmaxf(hv[m][r] + e[r], e[r]);
+            }
             *reinterpret_cast<v4f*>(hbuf + j * kHPitch + 16 * m + 4 * g) = hv[m];               // H / ln2 as [sample][hidden], for dW2's B operand
         }
         GNERF_K2_PHASE_FENCE();
@@ -1002,13 +1010,14 @@ struct BwdTileF16 {
 };
 
 template <class Tile>
-__device__ __forceinline__ void render_bwd_tiles_body(const Params& P, const gnerf_render_grads& Gr, float* stage, float* smem) {
+__device__ __forceinline__ void render_bwd_tiles_body(const Params& P, const gnerf_render_grads& Gr, float* stage, float* smem, bool sp_direct = false) {
     const gnerf_render_params& p = P.p;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n_all = p.depth_resolution + p.depth_resolution_importance;
     const float* tail = stage + int64_t(P.total_rays) * P.bwd_ray_stride;
     Tile K;
     K.setup(P, smem, tail, tid);
+    if constexpr (Tile::kMlp != kMlpF32) K.sp_direct = sp_direct;
     float* base = smem + bwd_tiles_weight_floats() + size_t(wv) * bwd_tiles_wave_floats();
     BwdLds L = {};
     L.stage = base; L.tbuf = L.stage + 16 * kStagePitch; L.hbuf = L.tbuf + 16 * kTPitch;
@@ -1078,9 +1087,10 @@ __device__ __forceinline__ void render_bwd_tiles_body(const Params& P, const gne
 __global__ __launch_bounds__(kTileThreads, 2) void render_bwd_tiles_kernel(Params P, gnerf_render_grads Gr, float* stage) {
     extern __shared__ __align__(16) float smem[];
     int mlp = P.p.mlp_mode;
-    if (mlp == kMlpAuto) mlp = choose_mlp(P, smem);
+    bool sp_direct = false;
+    if (mlp == kMlpAuto) mlp = choose_mlp(P, smem, &sp_direct);
     if (mlp == kMlpF32) render_bwd_tiles_body<BwdTileF32>(P, Gr, stage, smem);
-    else                render_bwd_tiles_body<BwdTileF16>(P, Gr, stage, smem);
+    else                render_bwd_tiles_body<BwdTileF16>(P, Gr, stage, smem, sp_direct);
 }
 
 // ---------------------------------------------------------------------------------------------
