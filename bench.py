@@ -235,33 +235,88 @@ def _cpu_oracle_rays_per_s(threads, n_items, seconds_budget, max_passes=3):
             'warm_up_was_the_measurement': len(times) == 1}
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """The CPU oracle (a port of the reference's PyTorch path, pinned to it by tests/golden) on config 2 itself (4 items x 128x128 rays,
-    48+48 samples, 256x256x32 planes) with min(32, cores) threads -- the oracle is bandwidth-bound gather code and torch's CPU ops get
-    slower beyond ~32 threads -- in this process: `value`.  BASELINE.md section 2's setting, torch.set_num_threads(os.cpu_count()), is
-    measured BESIDE it (`all_cores`) on one item of the batch in a child process with a hard 60 s limit: on a box whose CPU share is
-    smaller than os.cpu_count() (the GPU pool gives 16 of 256 cores) that many threads oversubscribe the cores and a pass can take
-    minutes -- the limit keeps the default bench run inside its few minutes; a timeout is reported as such."""
-    import subprocess
-    host = os.cpu_count() or 1
-    main = _cpu_oracle_rays_per_s(max(1, min(host, 32)), N_ITEMS, seconds_budget * 0.6)
-    all_cores = None
-    if host > main['threads']:
+def host_cpu_topology():
+    """Logical CPUs, physical cores (distinct (physical id, core id) pairs of /proc/cpuinfo), the CPUs this process may run on
+    (affinity) and the cgroup's CPU quota in cores (cpu.max), each None where the host does not say."""
+    logical = os.cpu_count() or 1
+    phys = None
+    try:
+        pairs, cur = set(), {}
+        for ln in open('/proc/cpuinfo'):
+            if ':' in ln:
+                k, v = [x.strip() for x in ln.split(':', 1)]
+                cur[k] = v
+            elif cur:
+                pairs.add((cur.get('physical id', '0'), cur.get('core id', cur.get('processor'))))
+                cur = {}
+        if cur:
+            pairs.add((cur.get('physical id', '0'), cur.get('core id', cur.get('processor'))))
+        phys = len(pairs) or None
+    except OSError:
+        pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = None
+    quota = None
+    for f in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', str(host)], capture_output=True, text=True, timeout=60,
-                               env=dict(os.environ, HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES=''))
-            all_cores = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
-        except subprocess.TimeoutExpired:
-            all_cores = {'value': None, 'threads': host, 'note': 'one item of the batch did not finish inside 60 s with os.cpu_count() threads'}
-        except Exception as e:
-            all_cores = {'value': None, 'threads': host, 'note': f'{type(e).__name__}: {e}'[:200]}
-    return {'value': main['value'], 'unit': 'rays/s', 'cores': main['threads'], 'host_cpu_count': host, 'kind': 'port', 'all_cores': all_cores,
+            txt = open(f).read().split()
+            if f.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return {'logical_cpus': logical, 'physical_cores': phys, 'affinity_cpus': affinity, 'cgroup_quota_cores': quota}
+
+
+def _cpu_worker(threads, limit_s):
+    """The oracle on ONE item of config 2 with `threads` torch threads, in a child process that cannot see a GPU, under a hard limit."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', str(threads)], capture_output=True, text=True,
+                           timeout=limit_s, env=dict(os.environ, HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES=''))
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'threads': threads, 'note': f'one item of the batch did not finish inside {limit_s:.0f} s'}
+    except Exception as e:
+        return {'value': None, 'threads': threads, 'note': f'{type(e).__name__}: {e}'[:200]}
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The CPU oracle (a port of the reference's PyTorch path, pinned to it by tests/golden) timed on this host.
+    1. A thread-count SWEEP on one item of config 2's batch, each count in a child process with a hard limit: the cores this process is
+       actually given (cgroup quota / affinity), the physical cores, twice that, 32, in one pass each after a warm-up.
+    2. `value`: the WHOLE batch of config 2 (4 items x 128x128 rays, 48+48 samples, 256x256x32 planes) in this process at the sweep's
+       best count -- the oracle is bandwidth-bound gather code, torch's CPU ops get slower once threads outnumber the cores given.
+    3. `all_cores`: BASELINE.md section 2's literal setting, torch.set_num_threads(os.cpu_count()), on one item, child process, 45 s
+       limit (on a box whose CPU share is far below os.cpu_count() that oversubscribes and times out; reported as such)."""
+    topo = host_cpu_topology()
+    host = topo['logical_cpus']
+    given = topo['cgroup_quota_cores'] or topo['affinity_cpus'] or host
+    cand = {int(max(1, min(host, round(given)))), 32 if host >= 32 else host}
+    if topo['physical_cores']:
+        cand |= {min(host, topo['physical_cores']), min(host, 2 * topo['physical_cores'])}
+    sweep = [_cpu_worker(t, 40.0) for t in sorted(cand)]
+    ok = [r for r in sweep if r.get('value')]
+    best_threads = max(ok, key=lambda r: r['value'])['threads'] if ok else max(1, min(host, 32))
+    main = _cpu_oracle_rays_per_s(best_threads, N_ITEMS, seconds_budget * 0.6)
+    all_cores = next((r for r in sweep if r['threads'] == host), None) or _cpu_worker(host, 45.0)
+    return {'value': main['value'], 'unit': 'rays/s', 'cores': main['threads'], 'host_cpu_count': host, 'kind': 'port', 'host': topo,
+            'thread_sweep_one_item': [{'threads': r['threads'], 'value': r.get('value'), 'note': r.get('note')} for r in sweep],
+            'all_cores': all_cores,
             'sample': f'config 2 whole batch ({main["rays"]} rays, 48+48 samples, 4x3x32x256x256 planes); median of {main["passes_timed"]} pass(es) after 1 '
-                      f'warm-up, torch {torch.__version__} CPU fp32, {main["threads"]} threads of os.cpu_count() = {host}; all_cores = the same oracle with '
-                      f'os.cpu_count() threads (BASELINE.md section 2) on one item of the batch, in a child process with a 60 s limit'}
+                      f'warm-up, torch {torch.__version__} CPU fp32, {main["threads"]} threads = the best of a sweep over {sorted(cand)} threads on one item '
+                      f'(child processes, 40 s limit each); host: {host} logical CPUs, {topo["physical_cores"]} physical cores, '
+                      f'{given:g} given to this process; all_cores = os.cpu_count() threads (BASELINE.md section 2) on one item, child process'}
 
 
-def gen_videos_secondary(rank, world, dev, n_frames=240):
+def gen_videos_secondary(rank, world, dev, n_frames=240, flows=('fast', 'reference')):
     """BASELINE's second metric, frames/sec of gen_videos (config 4): the 240-frame orbit of gen_videos.py:154-171 sharded in
     contiguous blocks over the ranks (30 frames per GPU at 8 GPUs), 64x64 rays x (96+96) samples per frame (the CLI's doubled
     sampling), cached backbone, superresolution to 512x512 in fp16, uint8 frames, ONE gather of the frames to rank 0 at the end (RCCL).
@@ -285,7 +340,7 @@ def gen_videos_secondary(rank, world, dev, n_frames=240):
         G = gv.build_random_generator(0, dev)
         z = torch.randn(1, G.z_dim, generator=torch.Generator().manual_seed(1)).to(dev)
         last = G.backbone.synthesis.b256
-        for flow, fast in (('fast', True), ('reference', False)):
+        for flow, fast in [(f, f == 'fast') for f in flows]:
             GG._MODCONV_FAST = fast
             last.emit_channels_last = fast
             gv.render_orbit(G, z, n_frames, 64, dev, rank=0, world=n_frames, double_depth=(flow == 'fast'))      # warm-up: frame 0 (the first also sets 96+96)
@@ -338,8 +393,9 @@ def gen_videos_secondary(rank, world, dev, n_frames=240):
             'eager_value': out['fast', 'eager'], 'hip_graph_value': out['fast', 'hip_graph'],
             'eager_views_value': out['fast', 'eager_views'], 'views_per_call': ORBIT_VIEWS, 'miopen_solver_search': searched,
             'backbone_ms_per_rank': backbone_all,
-            'reference_flow_value': max(out['reference', 'eager'], out['reference', 'hip_graph']),
-            'reference_flow_eager_value': out['reference', 'eager'], 'reference_flow_hip_graph_value': out['reference', 'hip_graph'], 'n_gpus': world,
+            'reference_flow_value': max(out['reference', 'eager'], out['reference', 'hip_graph']) if 'reference' in flows else None,
+            'reference_flow_eager_value': out.get(('reference', 'eager')), 'reference_flow_hip_graph_value': out.get(('reference', 'hip_graph')),
+            'flows_measured': list(flows), 'n_gpus': world,
             'workload': f'config 4: {n_frames}-frame orbit sharded over {world} GPU(s), 64x64 rays x (96+96) samples, cached backbone, SR to '
                         '512x512 fp16, uint8 frames, one gather to rank 0; random-init FFHQ-config generator; hip_graph = HIP-graph replay of the '
                         'per-frame sequence (captured once, before the timed orbit), eager = plain launches (backbone pass included), '
@@ -474,6 +530,51 @@ def backward_times(dev, planes_cl, dec, c2w, intr, reps=5):
     return out
 
 
+def visible_gpus_no_hip(sysfs='/sys/class/kfd/kfd/topology/nodes', dev_dir='/dev/dri'):
+    """How many GPUs a child of this process could open, found WITHOUT a HIP / HSA call: the kernel driver's topology nodes with
+    `simd_count > 0` (CPU nodes have 0) whose render node this user can open, capped by the *_VISIBLE_DEVICES lists.  None when the
+    topology cannot be read (then nothing is refused here; the ranks find out themselves).  The self-launching parent must never touch
+    the GPU runtime -- a process that has opened it may only start fresh children or exit -- and torch.cuda.device_count() stays
+    outside HIP only while amdsmi answers; it falls through to hipGetDeviceCount() otherwise."""
+    import re
+    try:
+        nodes = sorted(os.listdir(sysfs), key=lambda x: (len(x), x))
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        try:
+            props = open(os.path.join(sysfs, node, 'properties')).read()
+        except OSError:
+            continue
+        simd = re.search(r'^simd_count\s+(\d+)', props, re.M)
+        if not simd or int(simd.group(1)) == 0:
+            continue
+        minor = re.search(r'^drm_render_minor\s+(\d+)', props, re.M)
+        if minor and int(minor.group(1)) > 0 and os.path.isdir(dev_dir):
+            if not os.access(os.path.join(dev_dir, f'renderD{minor.group(1)}'), os.R_OK | os.W_OK):
+                continue                # a GPU of the host that this container / user was not given
+        n += 1
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(',') if x.strip()]))
+    return n
+
+
+def per_rank_miopen_env(rank, env=None):
+    """MIOpen's user database and kernel cache in a directory of this rank's own (unless the caller set them): eight ranks that search
+    solvers for the same shapes at the same time would otherwise read and rewrite ONE sqlite file / cache directory under $HOME."""
+    import tempfile
+    env = os.environ if env is None else env
+    base = os.path.join(tempfile.gettempdir(), f'gnerf_miopen_{os.getuid()}', f'rank{rank}')
+    for var, sub in (('MIOPEN_USER_DB_PATH', 'db'), ('MIOPEN_CUSTOM_CACHE_DIR', 'cache')):
+        if var not in env:
+            os.makedirs(os.path.join(base, sub), exist_ok=True)
+            env[var] = os.path.join(base, sub)
+    return env
+
+
 def self_launch(n_ranks, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: this process -- which has made NO GPU call and makes none --
     starts N fresh children of this same script, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what
@@ -491,7 +592,7 @@ def self_launch(n_ranks, argv):
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n_ranks) // n_ranks)))
     procs = []
     for r in range(n_ranks):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        e = per_rank_miopen_env(r, dict(env, RANK=str(r), LOCAL_RANK=str(r)))
         # rank 0's stdout is the result line (captured and relayed); the other ranks print nothing there by construction
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
@@ -583,6 +684,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the gen_videos frames/sec measurement')
     ap.add_argument('--no-backward', action='store_true', help='skip the renderer-backward timing behind roofline_backward')
+    ap.add_argument('--full-line', action='store_true', help='with several ranks: every rank runs the whole line (forced arithmetics, in-kernel draws, '
+                    'backward, backbone-plane step, both orbit flows); by default those run on rank 0 alone and the others go straight to the orbit')
     ap.add_argument('--stub-step', action='store_true', help=argparse.SUPPRESS)       # CPU rehearsal of the multi-rank plumbing (stub_main)
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)      # child of cpu_baseline(): the all-cores figure
     args = ap.parse_args()
@@ -591,10 +694,13 @@ def main():
         print(json.dumps(_cpu_oracle_rays_per_s(args.cpu_baseline_worker, 1, 20.0, max_passes=1)))
         return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        # (device_count() does not initialise the GPU on this image; RCCL refuses two ranks on one device, so say it here, readably)
-        if not args.stub_step and os.environ.get('GNERF_DIST_BACKEND', 'nccl') == 'nccl' and torch.cuda.device_count() < args.gpus:
-            sys.exit(f'bench.py: --gpus {args.gpus} but {torch.cuda.device_count()} GPU(s) visible (RCCL needs one device per rank; '
-                     'GNERF_DIST_BACKEND=gloo rehearses several ranks on one card)')
+        # RCCL refuses two ranks on one device, so say it here, readably -- from the driver's topology files, not through torch / HIP:
+        # this parent makes no GPU-runtime call at all (visible_gpus_no_hip)
+        if not args.stub_step and os.environ.get('GNERF_DIST_BACKEND', 'nccl') == 'nccl':
+            seen = visible_gpus_no_hip()
+            if seen is not None and seen < args.gpus:
+                sys.exit(f'bench.py: --gpus {args.gpus} but {seen} GPU(s) visible (RCCL needs one device per rank; '
+                         'GNERF_DIST_BACKEND=gloo rehearses several ranks on one card)')
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
     if args.stub_step:
         os.environ['GNERF_DIST_BACKEND'] = 'gloo'
@@ -610,6 +716,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world > 1:
+        per_rank_miopen_env(rank)       # (a no-op under self_launch, which exported them; this covers torch.distributed.run)
     if args.stub_step:
         return stub_main(args, rank, world, result_fd)
     # (modulo only matters for a rehearsal of several ranks on a one-GPU box with GNERF_DIST_BACKEND=gloo)
@@ -666,20 +774,25 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def timed_region(mlp='auto', nchw_input=True, n_steps=None, generated=False):
+    def timed_region(mlp='auto', nchw_input=True, n_steps=None, generated=False, solo=False):
         """EXACTLY n_steps (default args.steps) steps between barrier + synchronize on both sides; (max-over-ranks seconds, this rank's
-        seconds, mean render ms by HIP events on this rank)."""
+        seconds, mean render ms by HIP events on this rank).  solo: this rank alone, no collective (the side measurements rank 0 makes
+        while the other ranks of a multi-GPU run wait at the orbit's first barrier)."""
         n_steps = args.steps if n_steps is None else n_steps
         torch.cuda.synchronize()
-        barrier()
+        if not solo:
+            barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n_steps):
             out = step(i if n_steps == args.steps else None, mlp, nchw_input, generated)
         torch.cuda.synchronize()
         mine = time.perf_counter() - t0
-        barrier()
-        elapsed = gnerf_harness.max_over_ranks(time.perf_counter() - t0, dev)
+        if solo:
+            elapsed = mine
+        else:
+            barrier()
+            elapsed = gnerf_harness.max_over_ranks(time.perf_counter() - t0, dev)
         assert torch.isfinite(out[0]).all()
         kms = sum(ev[i][0].elapsed_time(ev[i][1]) for i in timed_steps) / len(timed_steps) if n_steps == args.steps else None
         return elapsed, mine, kms      # events sit on the launch stream around the render call
@@ -718,19 +831,28 @@ def main():
     # the other plane layout, and the render call with each shipped decoder arithmetic forced
     other = sorted(timed_region(nchw_input=not headline_nchw) for _ in range(5))[2]
     progress('headline regions done; in-kernel rays / draws, forced arithmetics')
+    # With several ranks the side measurements below (nothing in them scales: they describe the kernel) run on rank 0 ALONE, without
+    # collectives, while the others go on to the orbit and wait at its first barrier: eight copies of them -- and eight concurrent
+    # MIOpen solver searches for a flow nobody reads at N > 1 -- are what could push the first multi-GPU run over its time limit.
+    # --full-line restores "every rank runs everything" (then with barriers, as at N = 1).
+    full = world == 1 or args.full_line
+    extras_here, solo = full or rank == 0, not full
+    side_ranks = world if full else 1
     # the same two steps with rays and draws made inside the render kernel (SURVEY 8d "in-kernel Philox (throughput run -- state which)")
     inkernel = {}
-    try:
-        for name, nchw in (('nchw_input', True), ('producer_layout', False)):
-            step(None, 'auto', nchw, True)
-            reg = sorted(timed_region(nchw_input=nchw, generated=True) for _ in range(5))[2]
-            inkernel[name] = {'ms_per_step': 1e3 * reg[0] / args.steps, 'value': rays_per_call * args.steps * world / reg[0], 'render_call_ms': reg[2]}
-    except Exception as e:
-        inkernel = {'error': f'{type(e).__name__}: {e}'[:300]}
     kernel_ms_by_mlp = {'auto': kernel_ms}
-    for mlp in ('f16x3', 'f32'):
-        step(None, mlp, headline_nchw)
-        kernel_ms_by_mlp[mlp] = sorted(timed_region(mlp, headline_nchw)[2] for _ in range(3))[1]
+    if extras_here:
+        try:
+            for name, nchw in (('nchw_input', True), ('producer_layout', False)):
+                step(None, 'auto', nchw, True)
+                reg = sorted(timed_region(nchw_input=nchw, generated=True, solo=solo) for _ in range(5))[2]
+                inkernel[name] = {'ms_per_step': 1e3 * reg[0] / args.steps, 'value': rays_per_call * args.steps * side_ranks / reg[0], 'render_call_ms': reg[2],
+                                  'ranks_measured': side_ranks}
+        except Exception as e:
+            inkernel = {'error': f'{type(e).__name__}: {e}'[:300]}
+        for mlp in ('f16x3', 'f32'):
+            step(None, mlp, headline_nchw)
+            kernel_ms_by_mlp[mlp] = sorted(timed_region(mlp, headline_nchw, solo=solo)[2] for _ in range(3))[1]
     per_rank = [{'rank': rank, 'value': rays_per_call * args.steps / mine, 'render_call_ms': kernel_ms}]
     if world > 1:
         t = torch.tensor([rays_per_call * args.steps / mine, kernel_ms], device=dev, dtype=torch.float64)
@@ -742,7 +864,7 @@ def main():
 
     progress('renderer backward')
     backward = None
-    if not args.no_backward:
+    if not args.no_backward and extras_here:
         try:
             backward = backward_times(dev, planes_cl, dec, c2w, intr)
             backward['ratio_to_forward_kernel'] = backward['call_ms']['staged_scatter'] / kernel_ms
@@ -755,15 +877,16 @@ def main():
         try:
             del planes, planes_cl
             torch.cuda.empty_cache()
-            try:
-                from torch_utils import custom_ops
-                custom_ops.verbosity = 'none'
-                progress('config 2 on backbone-output planes')
-                realistic = realistic_planes_step(dev, c2w, intr, args.steps, rank)
-            except Exception as e:
-                realistic = {'error': f'{type(e).__name__}: {e}'[:300]}
-            progress('gen_videos orbit (config 4), two flows')
-            secondary = gen_videos_secondary(rank, world, dev)
+            if extras_here:
+                try:
+                    from torch_utils import custom_ops
+                    custom_ops.verbosity = 'none'
+                    progress('config 2 on backbone-output planes')
+                    realistic = realistic_planes_step(dev, c2w, intr, args.steps, rank)
+                except Exception as e:
+                    realistic = {'error': f'{type(e).__name__}: {e}'[:300]}
+            progress('gen_videos orbit (config 4)' + (', two flows' if full else ', fast flow (the reference flow is an N = 1 / --full-line figure)'))
+            secondary = gen_videos_secondary(rank, world, dev, flows=('fast', 'reference') if full else ('fast',))
         except Exception as e:                                           # never lose the headline line to the secondary metric
             secondary = {'metric': 'frames/sec gen_videos', 'value': None, 'error': f'{type(e).__name__}: {e}'[:300]}
 
@@ -818,16 +941,22 @@ def main():
         if backward is not None:
             line['roofline_backward'] = backward
         line['secondary'] = secondary
-        if not args.no_cpu_baseline and world == 1:
-            progress('CPU oracle baseline')
-            line['cpu_baseline'] = cpu_baseline()
-        else:
-            line['cpu_baseline'] = None
-        sys.stdout.flush()
-        os.write(result_fd, (json.dumps(line) + '\n').encode())
+        line['side_measurements'] = 'every rank' if full else 'rank 0 alone, without collectives (inkernel_rng_step, forced arithmetics, roofline_backward, realistic_planes_step; orbit: fast flow only)'
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the CPU oracle on this host's cores, in the same run at every N (north_star): after the process group is gone, so the other
+        # ranks are not held in a collective while rank 0 computes on the CPU for half a minute
+        line['cpu_baseline'] = None
+        if not args.no_cpu_baseline:
+            progress('CPU oracle baseline')
+            try:
+                line['cpu_baseline'] = cpu_baseline()
+            except Exception as e:                                      # never lose the line to the baseline
+                line['cpu_baseline'] = {'value': None, 'error': f'{type(e).__name__}: {e}'[:300]}
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + '\n').encode())
 
 
 if __name__ == '__main__':

@@ -19,6 +19,30 @@ constexpr int kCoopThreads = 64 * kCoopWaves;
 constexpr int kW1Pitch = 36;        // floats per LDS row of W1 [64 x 32]
 constexpr int kW2Pitch = 68;        // floats per LDS row of W2 [33 x 64]
 constexpr int kTapDwords = 24;      // per sample: 3 planes x (4 byte offsets + 4 weights)
+// LDS layout knobs of the forward shade tile (tools/build_variants.sh D:GNERF_TAP_STRIDE=.. / D:GNERF_STAGE_SWZ=..):
+//  * record stride in dwords.  ds_write_b128 is serviced in groups of 8 consecutive lanes on 32 banks: the 8 samples of a group
+//    write 16 bytes each at j * stride, conflict-free when stride / 4 is odd (28: yes, 24: 2-way).  The 8 lanes that read a record
+//    share an address; a ds_read_b128 group (16 lanes, 64 banks) sees 4 distinct records: b * stride / 4 mod 16 distinct for b = 0..3.
+//  * staging rows: pitch 32 with the 16-byte chunk index XORed by ((row >> 1) & 5) makes both the 8-lane row writes and the
+//    (sample j, k-group g) reads of the MFMA operand conflict-free; the round-1 layout (pitch 36, no swizzle) has 2-way conflicts in
+//    two of the sixteen slots of every read group.
+// Round 5 defaults: stride 28, swizzled rows, the lookup window pinned plane by plane (GNERF_LOOKUP_ROLL, see coop_shade_tile).
+// Counters at config 2 (profiles/r05_lds_attribution.json): SQ_LDS_BANK_CONFLICT 12.10 M -> 4.24 M per launch, of which 4.23 M are
+// the scalar wave's (a build without the shade tile shows them alone): conflicts / LDS-active 0.33 -> 0.12.  The round-4 layout is
+// -DGNERF_TAP_STRIDE=24 -DGNERF_STAGE_SWZ=0 -DGNERF_LOOKUP_ROLL=0.
+#ifndef GNERF_TAP_STRIDE
+#define GNERF_TAP_STRIDE 28
+#endif
+#ifndef GNERF_STAGE_SWZ
+#define GNERF_STAGE_SWZ 1
+#endif
+#ifndef GNERF_LOOKUP_ROLL
+#define GNERF_LOOKUP_ROLL 4
+#endif
+constexpr int kFwdTapStride = GNERF_TAP_STRIDE;
+constexpr int kFwdStagePitch = GNERF_STAGE_SWZ ? 32 : kStagePitch;
+static_assert(kFwdTapStride >= 24 && kFwdTapStride <= kStagePitch && kFwdTapStride % 4 == 0, "tap records live in the staging rows");
+__device__ __forceinline__ int stage_swz(int row) { return GNERF_STAGE_SWZ ? ((row >> 1) & 5) : 0; }
 
 // Decoder weights in LDS.  Two formats, BOTH shipped (template parameter MLP of the kernels; chosen per call, see
 // choose_mlp in render.hip):
@@ -90,7 +114,7 @@ struct CoopLds {
 
 __host__ __device__ inline size_t coop_lds_floats(int s_pad, int mlp) {
     return size_t(weight_floats(mlp)) + 64 + 36 + size_t(8) * s_pad +
-           kCoopWaves * 16 * kTapDwords + kCoopWaves * 16 * kStagePitch + kCoopWaves * 32 + 4;
+           kCoopWaves * 16 * kFwdTapStride + kCoopWaves * 16 * kStagePitch + kCoopWaves * 32 + 4;
 }
 
 #ifdef GNERF_ABLATE_MFMA         // timing-only build: one FMA per lane instead of a matrix instruction
@@ -261,7 +285,8 @@ __device__ __forceinline__ void lds_wave_sync() {
 }
 template <bool BLOCK_SYNC, int MLP>
 __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& L, const CoopRay& R, const float* t_list, int count,
-                                                int tile, bool active, float* sig_list, int lane, int wv, v4f (&col)[2], Stamps& st, bool sp_direct = false) {
+                                                int tile, bool active, float* sig_list, int lane, int wv, v4f (&col)[2], Stamps& st, bool sp_direct = false,
+                                                bool have_depth = false, float depth_in = 0.f) {
 #ifdef GNERF_ABLATE_SHADE       // timing-only build: no lookups, no MLP
     if (active && lane < 16 && 16 * tile + lane < count) sig_list[16 * tile + lane] = t_list[16 * tile + lane] - 2.7f;
     col[0] = (v4f){0.1f, 0.2f, 0.3f, 0.4f}; col[1] = col[0];
@@ -274,7 +299,7 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     if (lane < 48) {
         const int j = lane & 15, pl = lane >> 4;
         const int idx = min(16 * tile + j, count - 1);
-        const float depth = t_list[idx];
+        const float depth = have_depth ? depth_in : t_list[idx];       // (the pipelined kernels fetch it with the ray's parameters, one round trip)
         const float px = __fadd_rn(R.ox, __fmul_rn(depth, R.dx)) * P.box_scale;
         const float py = __fadd_rn(R.oy, __fmul_rn(depth, R.dy)) * P.box_scale;
         const float pz = __fadd_rn(R.oz, __fmul_rn(depth, R.dz)) * P.box_scale;
@@ -282,7 +307,7 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
         const float v = pl == 0 ? py : (pl == 1 ? pz : px);
         uint4 off; v4f wgt;
         plane_taps(H, W, u, v, P.tex_pitch, P.row_pitch, unsigned(pl) * P.plane_pitch, off, wgt);
-        float* rec = taps + j * kTapDwords + pl * 8;
+        float* rec = taps + j * kFwdTapStride + pl * 8;
         *reinterpret_cast<uint4*>(rec) = off;
         *reinterpret_cast<v4f*>(rec + 4) = wgt;
     }
@@ -298,7 +323,7 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     uint4 off[2][3];
     v4f wgt[2][3], tex[2][3][4];
     auto read_records = [&](int a) {
-        const float* rec = taps + (8 * a + b) * kTapDwords;
+        const float* rec = taps + (8 * a + b) * kFwdTapStride;
 #pragma unroll
         for (int pl = 0; pl < 3; pl++) {
             off[a][pl] = *reinterpret_cast<const uint4*>(rec + pl * 8);
@@ -331,6 +356,9 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
         acc = __builtin_elementwise_fma(tex[a][pl][3], bc(wgt[a][pl][3]), acc);
     };
     v4f acc0, acc1;
+    float* const row0 = stage + b * kFwdStagePitch + (((lane & 7) ^ stage_swz(b)) * 4);
+    float* const row1 = stage + (8 + b) * kFwdStagePitch + (((lane & 7) ^ stage_swz(8 + b)) * 4);
+#if GNERF_LOOKUP_ROLL == 0
     read_records(0);
     issue(0, 0); issue(0, 1); issue(0, 2);
     read_records(1);
@@ -343,14 +371,74 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     __builtin_amdgcn_sched_barrier(0);
     // (the staging rows stay [sample][kStagePitch]: 2-way conflicts on the writes and on the reads; fragment order for the reads makes
     //  the writes 8-way -- 8 lanes of a sample land on one bank group -- and was 3 % slower overall)
-    *reinterpret_cast<v4f*>(stage + b * kStagePitch + (lane & 7) * 4) = acc0;
+    *reinterpret_cast<v4f*>(row0) = acc0;
     blend(1, 0, acc1); blend(1, 1, acc1); blend(1, 2, acc1);
-    *reinterpret_cast<v4f*>(stage + (8 + b) * kStagePitch + (lane & 7) * 4) = acc1;
+    *reinterpret_cast<v4f*>(row1) = acc1;
+#else
+    // The rolling window, PINNED.  __builtin_amdgcn_sched_barrier only stops the machine scheduler: the blends are pure arithmetic
+    // with no chain to it, and instruction selection linearised all of step 0's blends in front of the first barrier -- the emitted
+    // stream was 12 loads, 12 waits + blends, 12 loads, 12 waits + blends: two exposed round trips per tile.  An empty asm that takes
+    // the accumulator in and out and clobbers memory has a data edge to the blend before and after it and an order edge to the loads.
+    auto pin = [](v4f& a) { asm volatile("" : "+v"(a) :: "memory"); };
+    // Records are fetched from LDS where they are needed (offsets right before a plane's loads leave, step 1's weights right before
+    // its blend): with both steps' records held in registers (48) next to the window (48) and the colours (32) the pinned order spills.
+    const float* const rec0 = taps + b * kFwdTapStride;
+    const float* const rec1 = taps + (8 + b) * kFwdTapStride;
+    auto bc = [](float w) { return (v4f){w, w, w, w}; };
+    auto load4 = [&](v4f (&t)[4], uint4 o) {
+        t[0] = *reinterpret_cast<const v4f*>(R.planes_item + (o.x + cq16));
+        t[1] = *reinterpret_cast<const v4f*>(R.planes_item + (o.y + cq16));
+        t[2] = *reinterpret_cast<const v4f*>(R.planes_item + (o.z + cq16));
+        t[3] = *reinterpret_cast<const v4f*>(R.planes_item + (o.w + cq16));
+    };
+    v4f win[3][4], w0[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) {
+        load4(win[pl], *reinterpret_cast<const uint4*>(rec0 + pl * 8));
+        w0[pl] = *reinterpret_cast<const v4f*>(rec0 + pl * 8 + 4);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) {
+        const uint4 o1 = *reinterpret_cast<const uint4*>(rec1 + pl * 8);
+#if GNERF_LOOKUP_ROLL == 4          // a plane's four taps at a time
+        acc0 = pl == 0 ? win[pl][0] * w0[pl][0] : __builtin_elementwise_fma(win[pl][0], bc(w0[pl][0]), acc0);
+        acc0 = __builtin_elementwise_fma(win[pl][1], bc(w0[pl][1]), acc0);
+        acc0 = __builtin_elementwise_fma(win[pl][2], bc(w0[pl][2]), acc0);
+        acc0 = __builtin_elementwise_fma(win[pl][3], bc(w0[pl][3]), acc0);
+        pin(acc0);
+        load4(win[pl], o1);
+        pin(acc0);
+#else                               // tap by tap: a load of step 1 leaves as soon as the same tap of step 0 has been consumed
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            acc0 = (pl == 0 && t == 0) ? win[pl][t] * w0[pl][t] : __builtin_elementwise_fma(win[pl][t], bc(w0[pl][t]), acc0);
+            pin(acc0);
+            const unsigned ot = t == 0 ? o1.x : (t == 1 ? o1.y : (t == 2 ? o1.z : o1.w));
+            win[pl][t] = *reinterpret_cast<const v4f*>(R.planes_item + (ot + cq16));
+            pin(acc0);
+        }
+#endif
+    }
+    // (the records share their LDS with the staging rows: step 1's weights leave it BEFORE the first row is written over them)
+    v4f w1[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) w1[pl] = *reinterpret_cast<const v4f*>(rec1 + pl * 8 + 4);
+    pin(acc0);
+    *reinterpret_cast<v4f*>(row0) = acc0;
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) {
+        acc1 = pl == 0 ? win[pl][0] * w1[pl][0] : __builtin_elementwise_fma(win[pl][0], bc(w1[pl][0]), acc1);
+        acc1 = __builtin_elementwise_fma(win[pl][1], bc(w1[pl][1]), acc1);
+        acc1 = __builtin_elementwise_fma(win[pl][2], bc(w1[pl][2]), acc1);
+        acc1 = __builtin_elementwise_fma(win[pl][3], bc(w1[pl][3]), acc1);
+    }
+    *reinterpret_cast<v4f*>(row1) = acc1;
+#endif
     if (BLOCK_SYNC) __syncthreads(); else lds_wave_sync();
     GNERF_STAMP(st, 2);         // lookups (tap records, texel loads, blend, staging)
     const int j = lane & 15, g = lane >> 4;
-    const v4f f_lo = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g);
-    const v4f f_hi = *reinterpret_cast<const v4f*>(stage + j * kStagePitch + 8 * g + 4);
+    const v4f f_lo = *reinterpret_cast<const v4f*>(stage + j * kFwdStagePitch + (((2 * g) ^ stage_swz(j)) * 4));
+    const v4f f_hi = *reinterpret_cast<const v4f*>(stage + j * kFwdStagePitch + (((2 * g + 1) ^ stage_swz(j)) * 4));
     const float f[8] = {f_lo[0], f_lo[1], f_lo[2], f_lo[3], f_hi[0], f_hi[1], f_hi[2], f_hi[3]};
     float sig = 0.f;
     v4f o[2];
@@ -565,8 +653,8 @@ __device__ __forceinline__ void render_coop_body(const Params& P, float* smem, b
     L.w_s = L.s_sig + s_pad;
     L.cdf = L.w_s + s_pad;
     L.taps = L.cdf + s_pad;
-    L.stage = L.taps + kCoopWaves * 16 * kTapDwords;
-    L.wave_pitch_taps = 16 * kTapDwords; L.wave_pitch_stage = 16 * kStagePitch;
+    L.stage = L.taps + kCoopWaves * 16 * kFwdTapStride;
+    L.wave_pitch_taps = 16 * kFwdTapStride; L.wave_pitch_stage = 16 * kStagePitch;
     L.part = L.stage + kCoopWaves * 16 * kStagePitch;
 
     const int n_groups = P.n_tiles << P.split_shift;

@@ -583,29 +583,37 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
     };
 
     // ------------------------------------------------------------------ shader-wave pieces (waves 0..2)
-    auto shade = [&](int r, bool fine, v4f (&col)[TP][2]) {
-        if (r < 0 || r >= nr) return;
+    // Returns whether ray r exists (a run's last dealing unit can be short).  Everything the head of the tile needs from the slot --
+    // origin, direction, item, ray id and this lane's depth -- is fetched in ONE LDS round trip (two broadcast ds_read_b128 and the
+    // depth word issued together); round 4 read the ray id, the item and the rest one after the other, each behind a wait and a
+    // v_readfirstlane: three dependent round trips in front of every tile (tools/stamps.py "slot params": 5 % of a shader wave's time).
+    auto shade = [&](int r, bool fine, v4f (&col)[TP][2]) -> bool {
+        if (r < 0 || r >= nr) return false;
         PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
-        const int ray_id = __builtin_amdgcn_readfirstlane(__float_as_int(sl.misc[7]));
-        if (ray_id < 0) return;
+        const float* t_list = fine ? sl.t_e + fine_e0 : sl.t_e;
+        const int count = fine ? F : S;
+        const v4f m0 = *reinterpret_cast<const v4f*>(sl.misc), m1 = *reinterpret_cast<const v4f*>(sl.misc + 4);
+        const float depth0 = t_list[min(16 * wv + (lane & 15), count - 1)];          // tile wv (the first of this wave's tiles)
+        const int ray_id = __builtin_amdgcn_readfirstlane(__float_as_int(m1[3]));
+        if (ray_id < 0) return false;
         CoopRay R;
-        const int item = __builtin_amdgcn_readfirstlane(__float_as_int(sl.misc[6]));
+        const int item = __builtin_amdgcn_readfirstlane(__float_as_int(m1[2]));
         R.planes_item = reinterpret_cast<const char*>(p.planes_nhwc) + int64_t(item) * P.item_bytes;
-        R.ox = sl.misc[0]; R.oy = sl.misc[1]; R.oz = sl.misc[2];
-        R.dx = sl.misc[3]; R.dy = sl.misc[4]; R.dz = sl.misc[5];
+        R.ox = m0[0]; R.oy = m0[1]; R.oz = m0[2];
+        R.dx = m0[3]; R.dy = m1[0]; R.dz = m1[1];
         GNERF_STAMP(st, 0);     // ray parameters from the slot
 #pragma unroll
         for (int i = 0; i < TP; i++) {
             const int tile = wv + 3 * i;
             if (TP > 1 && tile >= (fine ? tiles_f : tiles_c)) continue;       // wave-uniform: this wave has no such tile
-            if (!fine) coop_shade_tile<false, MLP>(P, L, R, sl.t_e, S, tile, tile < tiles_c, sl.sig_e, lane, wv, col[i], st, sp_direct);
-            else       coop_shade_tile<false, MLP>(P, L, R, sl.t_e + fine_e0, F, tile, tile < tiles_f, sl.sig_e + fine_e0, lane, wv, col[i], st, sp_direct);
+            coop_shade_tile<false, MLP>(P, L, R, t_list, count, tile, tile < (fine ? tiles_f : tiles_c), (fine ? sl.sig_e + fine_e0 : sl.sig_e), lane, wv, col[i], st, sp_direct,
+                                        i == 0, depth0);
         }
+        return true;
     };
-    auto accumulate = [&](int r, const v4f (&cc)[TP][2], const v4f (&cf)[TP][2]) {
-        if (r < 0 || r >= nr) return;
+    auto accumulate = [&](int r, bool valid, const v4f (&cc)[TP][2], const v4f (&cf)[TP][2]) {
+        if (!valid) return;                 // (what shade(r) returned: no LDS round trip for the ray id)
         PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
-        if (__float_as_int(sl.misc[7]) < 0) return;
         const int j = lane & 15, g = lane >> 4;
         // one explicit FMA chain per colour: left to the compiler's contraction, `acc += v0 c0 + v1 c1 + ...` rounds differently in
         // the instantiation with compile-time tile counts (acc known to be zero at the first tile) -- 1 ulp between FULL and not
@@ -659,6 +667,10 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
     if (wv == 3) { propose_issue(0); propose_finish(0); }
     __syncthreads();
     st.reset();
+#ifdef GNERF_STAMPS
+    // clock of the timed part: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime), and where the wave sits (HW_ID)
+    const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // Two loops with the same barrier count, one per role.  The roles never change, and with ONE loop and `if (wv < 3)` inside
     // every step the compiler must assume that a wave can enter the scalar branch with the shader branch's registers live (the
     // 32 colour registers) and the other way round: splitting the loops took pipe<2> from 242 to 174 VGPRs and pipe<1> from
@@ -692,14 +704,15 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
     }
     if (wv < 3) {
         v4f cc0[TP][2] = {}, cc1[TP][2] = {}, cc2[TP][2] = {}, cf[TP][2] = {};      // coarse colours of rays k-1, k, k+1; fine colours of ray k-1
+        bool live0 = false, live1 = false, live2 = false;                            // do rays k-1, k, k+1 exist (from their coarse pass)
         for (int k = -1; k <= nr + 1; k++) {
             // ---- step 2k+2
-            shade(k + 1, false, cc2);
+            live2 = shade(k + 1, false, cc2);
             GNERF_STAMP(st, 5);
             __syncthreads();
             GNERF_STAMP(st, 6);         // barrier wait, even step
             // ---- step 2k+3
-            accumulate(k - 1, cc0, cf);
+            accumulate(k - 1, live0, cc0, cf);
             GNERF_STAMP(st, 10);        // colour accumulate
             shade(k, true, cf);
 #pragma unroll
@@ -707,6 +720,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
 #pragma unroll
                 for (int n = 0; n < 2; n++) { cc0[i][n] = cc1[i][n]; cc1[i][n] = cc2[i][n]; }
             }
+            live0 = live1; live1 = live2;
             GNERF_STAMP(st, 5);
             __syncthreads();
             GNERF_STAMP(st, 7);         // barrier wait, odd step
@@ -737,6 +751,14 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
         unsigned long long* out = reinterpret_cast<unsigned long long*>(p.debug) + (size_t(blockIdx.x) * 4 + wv) * 16;
         for (int i = 0; i < 16; i++) out[i] = st.acc[i];
         out[15] = nr;
+        unsigned long long* ext = reinterpret_cast<unsigned long long*>(p.debug) + size_t(gridDim.x) * 4 * 16 + (size_t(blockIdx.x) * 4 + wv) * 4;
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        ext[0] = hw | ((unsigned long long)(xcc & 15u) << 32);
+        ext[1] = __builtin_amdgcn_s_memtime() - clk_c0;
+        ext[2] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        ext[3] = clk_r0;
     }
 #endif
     if (wv == 3 && lane == 0) range.flush(P);

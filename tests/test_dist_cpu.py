@@ -223,3 +223,77 @@ def test_bench_under_outer_launcher_is_not_relaunched():
     import json
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip().startswith('{')]
     assert len(lines) == 1 and lines[0]['ranks_seen'] == 2 and lines[0]['self_launched'] is False
+
+
+def _fake_kfd(tmp_path, nodes):
+    """A driver topology tree like /sys/class/kfd/kfd/topology/nodes: nodes = [(simd_count, drm_render_minor, render node present)]."""
+    base, dri = tmp_path / 'nodes', tmp_path / 'dri'
+    dri.mkdir()
+    for i, (simd, minor, present) in enumerate(nodes):
+        d = base / str(i)
+        d.mkdir(parents=True)
+        (d / 'properties').write_text(f'cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\ndrm_render_minor {minor}\n')
+        if present and minor:
+            (dri / f'renderD{minor}').write_text('')
+    return str(base), str(dri)
+
+
+def test_visible_gpus_are_counted_from_the_driver_topology(tmp_path, monkeypatch):
+    """The self-launching parent counts GPUs from the kernel driver's files: CPU nodes (simd_count 0) and GPUs whose render node this
+    container was not given do not count, and the *_VISIBLE_DEVICES lists cap the number."""
+    import bench
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        monkeypatch.delenv(var, raising=False)
+    sysfs, dri = _fake_kfd(tmp_path, [(0, 0, False), (0, 0, False)] + [(1024, 128 + i, i != 5) for i in range(8)])
+    assert bench.visible_gpus_no_hip(sysfs, dri) == 7
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1,2')
+    assert bench.visible_gpus_no_hip(sysfs, dri) == 3
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '')
+    assert bench.visible_gpus_no_hip(sysfs, dri) == 0
+    assert bench.visible_gpus_no_hip(str(tmp_path / 'absent'), dri) is None            # unreadable topology: nothing is refused
+
+
+def test_self_launching_parent_never_asks_torch_for_the_device_count(monkeypatch):
+    """`python bench.py --gpus N` without a launcher: the parent decides and spawns without one GPU-runtime call -- with
+    torch.cuda.device_count (whose amdsmi route falls through to hipGetDeviceCount when amdsmi fails) and the HIP initialisation
+    rigged to raise, it still reaches self_launch, and refuses readably when the driver's topology shows fewer GPUs than ranks."""
+    import sys
+    import bench
+
+    def boom(*a, **k):
+        raise AssertionError('the self-launching parent touched the GPU runtime')
+    monkeypatch.setattr(torch.cuda, 'device_count', boom)
+    monkeypatch.setattr(torch.cuda, 'is_available', boom)
+    monkeypatch.setattr(torch.cuda, '_lazy_init', boom)
+    if hasattr(torch._C, '_cuda_getDeviceCount'):
+        monkeypatch.setattr(torch._C, '_cuda_getDeviceCount', boom)
+    for var in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'GNERF_DIST_BACKEND'):
+        monkeypatch.delenv(var, raising=False)
+    launched = []
+    monkeypatch.setattr(bench, 'self_launch', lambda n, argv: launched.append((n, list(argv))) or 0)
+    monkeypatch.setattr(bench, 'visible_gpus_no_hip', lambda *a: 8)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '2'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and launched == [(8, ['--gpus', '8', '--steps', '2'])]
+    monkeypatch.setattr(bench, 'visible_gpus_no_hip', lambda *a: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert '1 GPU(s) visible' in str(e.value.code) and len(launched) == 1
+
+
+def test_every_rank_gets_its_own_miopen_directories(tmp_path, monkeypatch):
+    """Ranks that search MIOpen solvers at the same time must not share one user database / kernel cache."""
+    import bench
+    monkeypatch.setattr('tempfile.tempdir', str(tmp_path))
+    envs = [bench.per_rank_miopen_env(r, {}) for r in range(3)]
+    assert len({e['MIOPEN_USER_DB_PATH'] for e in envs}) == 3 and len({e['MIOPEN_CUSTOM_CACHE_DIR'] for e in envs}) == 3
+    assert all(os.path.isdir(e['MIOPEN_USER_DB_PATH']) for e in envs)
+    kept = bench.per_rank_miopen_env(0, {'MIOPEN_USER_DB_PATH': '/somewhere'})
+    assert kept['MIOPEN_USER_DB_PATH'] == '/somewhere'                                  # a caller's choice is left alone
+
+
+def test_cpu_topology_reads_this_host():
+    import bench
+    t = bench.host_cpu_topology()
+    assert t['logical_cpus'] >= 1 and (t['physical_cores'] is None or 1 <= t['physical_cores'] <= t['logical_cpus'])

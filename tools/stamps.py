@@ -33,3 +33,20 @@ for role, sel in (('shader waves', st[:, :3].reshape(-1, 16)), ('scalar wave', s
         v = sel[:, i].mean()
         if v > 0:
             print(f'   {names.get(i, i):28s} {v / nr:9.0f} cyc/ray  {100 * v / tot:5.1f} %')
+
+# where the waves sit and what clock the kernel ran at (GNERF_STAMPS builds write these behind the stamp table)
+ext = dbg[G * 4 * 16:G * 4 * 16 + G * 4 * 4].reshape(G, 4, 4)
+hw = ext[:, :, 0].astype(np.int64)
+simd = (hw >> 4) & 3
+cu = ((hw >> 8) & 15) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (((hw >> 32) & 15) << 8)
+import collections
+per_cu = collections.defaultdict(list)
+for wg in range(G):
+    per_cu[int(cu[wg, 0])].append(int(simd[wg, 3]))
+print('SIMDs hosting the scalar waves of a CU\'s workgroups (count of CUs):', dict(collections.Counter(tuple(sorted(v)) for v in per_cu.values()).most_common(8)))
+print('SIMD of waves 0..3 (count of workgroups):', dict(collections.Counter(''.join(map(str, r)) for r in simd.tolist()).most_common(8)))
+cyc, ticks = ext[:, :, 1].astype(np.float64), ext[:, :, 2].astype(np.float64)
+ok = ticks > 0
+print(f'in-kernel clock: {np.median(cyc[ok] / ticks[ok]) * 100:.0f} MHz median over waves (s_memtime / s_memrealtime x 100 MHz), {cyc[ok].mean():.0f} cycles per wave run')
+start = ext[:, 0, 3].astype(np.float64)
+print(f'workgroup start spread: {(start.max() - start.min()) / 100:.1f} us; first-to-last end: {((start + ticks[:, 0]).max() - start.min()) / 100:.1f} us')
