@@ -788,6 +788,8 @@ void fill_pitches(Params& P) {
     P.plane_pitch = P.p.planes_interleaved ? 128u : H * W * 128u;
 }
 
+#include "scatter_binned.inl"
+
 }  // namespace
 
 extern "C" size_t gnerf_render_workspace_bytes(void) { return size_t(kClampItemWord0 + 2 * kClampMaxItems) * 4; }
@@ -1088,7 +1090,18 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
     else        hipLaunchKernelGGL(render_bwd_kernel<false>, dim3(per_xcd * kNumXCD), dim3(kBwdThreads), lds_bytes, as_stream(stream), P, *g, static_cast<float*>(nullptr));
     if (int e = check_launch("render_bwd_kernel")) return e;
     }
+    // Second pass of the staged form.  Round 5: bin the rows by plane tile and sum each tile in LDS (scatter_binned.inl: no global float
+    // atomics, bit-reproducible); GNERF_BWD_SCATTER=sorted keeps round 2's per-ray-tile sort with one atomic per texel and chunk
+    // (plane_scatter_kernel), which also takes the calls the binned form does not cover.
     if (staged) {
+        const int n_all_s = p->depth_resolution + p->depth_resolution_importance;
+        P.bwd_ray_stride = int64_t(n_all_s) * 33;
+        const bool binned_ok = int64_t(P.total_rays) * n_all_s * 33 < (int64_t(1) << 32) &&
+                               (2 * size_t(3) * ((p->plane_h + kBinTile - 1) / kBinTile) * ((p->plane_w + kBinTile - 1) / kBinTile) + 128) * 4 <= 150 * 1024;
+        if (binned_ok && !(route && !strcmp(route, "sorted"))) {
+            char* ws = reinterpret_cast<char*>(g->scatter_stage) + bin_workspace_offset(P.total_rays, n_all_s);
+            return launch_binned_scatter(P, g->scatter_stage, ws, g->grad_planes_nhwc, as_stream(stream));
+        }
         static PerDeviceOnce once_scatter;
         if (int e = once_scatter.raise_lds(plane_scatter_kernel, "render_backward")) return e;
         hipLaunchKernelGGL(plane_scatter_kernel, dim3(P.n_tiles), dim3(kScatterThreads), scatter_lds_floats() * sizeof(float), as_stream(stream),
@@ -1101,7 +1114,10 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
 extern "C" size_t gnerf_render_backward_stage_bytes(const gnerf_render_params* p) {
     if (!p || p->n_items < 1 || p->rays_per_item < 1) return 0;
     const size_t n_all = size_t(p->depth_resolution) + size_t(p->depth_resolution_importance);
-    return size_t(p->n_items) * size_t(p->rays_per_item) * n_all * 33 * sizeof(float) + 256;      // (+ a spare line: max |planes| when the caller has none)
+    const int64_t rays = int64_t(p->n_items) * p->rays_per_item;
+    // the staged rows (+ a spare line: max |planes| when the caller has none), then the binned scatter's workspace: counters, the
+    // record array (16 bytes per sample and plane) and the tiles' halos (scatter_binned.inl)
+    return bin_workspace_offset(rays, int(n_all)) + bin_workspace_bytes(rays, int(n_all), p->n_items, p->plane_h > 0 ? p->plane_h : 1, p->plane_w > 0 ? p->plane_w : 1);
 }
 
 extern "C" size_t gnerf_render_backward_exchange_bytes(const gnerf_render_params* p) {

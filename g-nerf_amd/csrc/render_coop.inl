@@ -355,6 +355,7 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
         acc = __builtin_elementwise_fma(tex[a][pl][2], bc(wgt[a][pl][2]), acc);
         acc = __builtin_elementwise_fma(tex[a][pl][3], bc(wgt[a][pl][3]), acc);
     };
+    (void)read_records; (void)issue; (void)blend;       // (the pinned orders below fetch records where they are needed)
     v4f acc0, acc1;
     float* const row0 = stage + b * kFwdStagePitch + (((lane & 7) ^ stage_swz(b)) * 4);
     float* const row1 = stage + (8 + b) * kFwdStagePitch + (((lane & 7) ^ stage_swz(8 + b)) * 4);

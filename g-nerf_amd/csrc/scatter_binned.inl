@@ -1,0 +1,410 @@
+// Plane-gradient scatter WITHOUT global float atomics (round 5).  Included by render.hip after render_bwd.inl.
+//
+// The reference's plane gradient is F.grid_sample's backward (renderer.py:55-65 through autograd; grid_sample_gradfix.py:57-77 is the
+// same operator): one float atomic per tap and channel.  plane_scatter_kernel (render_bwd.inl) cut the atomics 3.8x by merging a ray
+// tile's taps in LDS, and then sat at 0.79 of the device's float-atomic rate -- 1.33 TB/s of 64-byte requests, all resolved at the
+// memory side (profiles/r04_atomic_scope_probe.txt): the approach, not the kernel, was the ceiling.  Here the staged dX rows are
+// BINNED by plane tile and each tile's sum is formed in LDS by the one workgroup that owns the tile, then written with plain stores:
+//
+//   bin_count      one workgroup per 16-ray tile: every (sample, plane) whose footprint has a non-zero tap is a RECORD of the plane tile
+//                  (16 x 16 texels) its top-left tap falls in; per tile: record count and max |dX| over its records
+//   bin_scan       exclusive scan of the counts -> each tile's segment of the record array; work order (largest tiles first)
+//   bin_fill       the same walk again; records (dX row, footprint position in the tile, fx, fy) into their tile's segment
+//   bin_accumulate persistent workgroups pull tiles: 17 x 17 texels x 32 channels of 64-bit FIXED-POINT accumulators in LDS (the tile
+//                  plus the one-texel halo a footprint can reach to the right / below); a half-wave per record (lane = channel) reads
+//                  the record's 128-byte dX row and adds its four weighted taps with ds_add_u64; the tile's own 16 x 16 texels are
+//                  then converted to fp32 and ADDED to grad_planes with plain loads / stores, the halo goes to a side buffer
+//   bin_halo       every tile adds the halos of its left, upper and upper-left neighbours (fixed order) to its first column / row
+//
+// Fixed point: a contribution c = w * dx is added as trunc(c * 2^s) with ONE scale per tile, s = 61 - ceil(log2(n_t)) - exponent(B_t)
+// from the tile's record count n_t and bound B_t >= |dx| (so that n_t contributions cannot overflow 63 bits).  Integer addition is
+// associative: the sum does not depend on the order in which records arrive, i.e. plane gradients are BIT-REPRODUCIBLE from run to
+// run -- which neither the float-atomic forms nor the reference's grid_sampler_2d_backward are -- and each texel is rounded to fp32
+// once, from 49 or more significant bits below the tile's bound, instead of once per addition.
+// Not covered (the caller falls back to plane_scatter_kernel): staging buffers of 2^32 floats or more, ray tiles that straddle items.
+
+constexpr int kBinTile = 16;                            // texels per side of a plane tile
+constexpr int kBinHalo = kBinTile + 1;                  // LDS tile side incl. the right / bottom halo
+constexpr int kBinCountThreads = 256;
+constexpr int kBinAccThreads = 1024;
+constexpr int kBinHaloTexels = 2 * kBinTile + 1;        // halo texels of a tile: right column (16), bottom row (16), corner
+
+struct BinRecord { unsigned row; unsigned pack; float fx, fy; };       // row: float index of the dX row in the staging buffer
+static_assert(sizeof(BinRecord) == 16, "records are read as one 16-byte load");
+
+struct BinArgs {
+    const float* stage;         // the staged dX rows (gnerf_render_backward's scatter_stage)
+    float* grad_planes;
+    int* count;                 // [n_ptiles + 1] records per plane tile; bin_scan turns it into segment starts (exclusive scan)
+    int* cursor;                // [n_ptiles] fill position inside the segment
+    unsigned* bound;            // [n_ptiles] float bits of max |dX| over the tile's records (non-negative floats order like unsigned)
+    int* order;                 // [n_ptiles] tiles in processing order (largest first);  order[n_ptiles] = the pull counter
+    BinRecord* records;         // [3 * rays * n_all]
+    float* halo;                // [n_ptiles][kBinHaloTexels][32]
+    int n_ptiles, tiles_x, tiles_y, tiles_per_plane;
+};
+
+// where the workspace starts: behind the staged rows and the spare line of gnerf_render_backward (256-byte aligned)
+__host__ inline size_t bin_workspace_offset(int64_t rays, int n_all) {
+    return (size_t(rays) * size_t(n_all) * 33 * sizeof(float) + 256 + 255) / 256 * 256;
+}
+// bytes of the workspace behind the staged rows (gnerf_render_backward_stage_bytes adds them)
+__host__ inline size_t bin_workspace_bytes(int64_t rays, int n_all, int n_items, int H, int W) {
+    const int64_t tx = (W + kBinTile - 1) / kBinTile, ty = (H + kBinTile - 1) / kBinTile, nt = int64_t(n_items) * 3 * tx * ty;
+    auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
+    return size_t(up((nt + 1) * 4) + up(nt * 4) + up(nt * 4) + up((nt + 1) * 4) + up(3 * rays * n_all * int64_t(sizeof(BinRecord))) + up(nt * kBinHaloTexels * 32 * 4));
+}
+__host__ inline BinArgs bin_carve(char* base, const float* stage, float* grad, int64_t rays, int n_all, int n_items, int H, int W) {
+    BinArgs A;
+    A.tiles_x = (W + kBinTile - 1) / kBinTile; A.tiles_y = (H + kBinTile - 1) / kBinTile;
+    A.tiles_per_plane = A.tiles_x * A.tiles_y;
+    A.n_ptiles = n_items * 3 * A.tiles_per_plane;
+    auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
+    A.stage = stage; A.grad_planes = grad;
+    A.count = reinterpret_cast<int*>(base);            base += up((int64_t(A.n_ptiles) + 1) * 4);
+    A.cursor = reinterpret_cast<int*>(base);           base += up(int64_t(A.n_ptiles) * 4);
+    A.bound = reinterpret_cast<unsigned*>(base);       base += up(int64_t(A.n_ptiles) * 4);
+    A.order = reinterpret_cast<int*>(base);            base += up((int64_t(A.n_ptiles) + 1) * 4);
+    A.records = reinterpret_cast<BinRecord*>(base);    base += up(3 * rays * n_all * int64_t(sizeof(BinRecord)));
+    A.halo = reinterpret_cast<float*>(base);
+    return A;
+}
+
+// The bilinear footprint of one (sample, plane): plane_taps' arithmetic (render_coop.inl), kept in the form the records store.
+struct TapGeom { int x0, y0; float fx, fy; unsigned valid; };            // valid: bit 0 x0, 1 x1, 2 y0, 3 y1 inside the plane
+__device__ __forceinline__ TapGeom tap_geom(int H, int W, float u, float v) {
+    float ix = ((u + 1.f) * float(W) - 1.f) * 0.5f;
+    float iy = ((v + 1.f) * float(H) - 1.f) * 0.5f;
+    ix = clamp_nn(ix, -1.5f, float(W) + 0.5f);
+    iy = clamp_nn(iy, -1.5f, float(H) + 0.5f);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    TapGeom g;
+    g.fx = ix - x0f; g.fy = iy - y0f;
+    g.x0 = int(x0f); g.y0 = int(y0f);
+    const int x1 = g.x0 + 1, y1 = g.y0 + 1;
+    g.valid = (g.x0 >= 0 && g.x0 < W ? 1u : 0u) | (x1 >= 0 && x1 < W ? 2u : 0u) | (g.y0 >= 0 && g.y0 < H ? 4u : 0u) | (y1 >= 0 && y1 < H ? 8u : 0u);
+    return g;
+}
+// the four tap weights from (fx, fy, valid): the expressions of plane_taps, so that a record's contributions are the products the
+// other scatter forms add (x0y0, x1y0, x0y1, x1y1)
+__device__ __forceinline__ v4f tap_weights(float fx, float fy, unsigned valid) {
+    const float wx0 = (valid & 1u) ? 1.f - fx : 0.f, wx1 = (valid & 2u) ? fx : 0.f;
+    const float wy0 = (valid & 4u) ? (1.f - fy) * (1.f / 3.f) : 0.f, wy1 = (valid & 8u) ? fy * (1.f / 3.f) : 0.f;
+    return (v4f){wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+}
+
+__device__ __forceinline__ int64_t bin_tile_ray(const Params& P, int tile, int i) {        // ray i (0..15) of ray tile `tile`, or -1
+    const gnerf_render_params& p = P.p;
+    if (P.tiles_per_item > 0) {
+        const int item = tile / P.tiles_per_item, tt = tile % P.tiles_per_item;
+        const int tx = tt / P.tiles_y, ty = tt % P.tiles_y;
+        return int64_t(item) * p.rays_per_item + int64_t(ty * 4 + (i >> 2)) * p.image_width + tx * 4 + (i & 3);
+    }
+    const int64_t ray = int64_t(tile) * 16 + i;
+    return ray < P.total_rays ? ray : -1;
+}
+
+// One (sample, plane) of the walk shared by bin_count and bin_fill: plane tile (or -1: every tap has weight zero) and the record fields.
+struct BinHit { int ptile; unsigned pack; float fx, fy; };
+__device__ __forceinline__ BinHit bin_hit(const Params& P, const BinArgs& A, int item, int pl, float px, float py, float pz) {
+    const float u = pl == 2 ? pz : px;
+    const float v = pl == 0 ? py : (pl == 1 ? pz : px);
+    const TapGeom g = tap_geom(P.p.plane_h, P.p.plane_w, u, v);
+    BinHit h;
+    h.fx = g.fx; h.fy = g.fy;
+    const v4f w = tap_weights(g.fx, g.fy, g.valid);
+    if (!(w[0] != 0.f || w[1] != 0.f || w[2] != 0.f || w[3] != 0.f)) { h.ptile = -1; h.pack = 0; return h; }       // (NaN weights count as taps: they reach the sum)
+    const int cx = min(max(g.x0, 0), P.p.plane_w - 1), cy = min(max(g.y0, 0), P.p.plane_h - 1);
+    const int tx = cx / kBinTile, ty = cy / kBinTile;
+    h.ptile = (item * 3 + pl) * A.tiles_per_plane + ty * A.tiles_x + tx;
+    h.pack = unsigned(g.x0 - tx * kBinTile + 1) | (unsigned(g.y0 - ty * kBinTile + 1) << 5) | (g.valid << 10);      // lx + 1, ly + 1 in 0..16
+    return h;
+}
+
+// ---- pass 1 and pass 3: FILL = false counts records and bounds per plane tile, FILL = true writes the records.
+// LDS: [3 * tiles_per_plane] ints (this ray tile's records per plane tile of its item), then the same number of words for the bound
+// (count pass) or the segment base reserved for this workgroup (fill pass), then 16 rays x 8 floats.
+template <bool FILL>
+__global__ __launch_bounds__(kBinCountThreads) void bin_walk_kernel(Params P, BinArgs A) {
+    extern __shared__ __align__(16) float smem[];
+    const gnerf_render_params& p = P.p;
+    const int tid = threadIdx.x, n_loc = 3 * A.tiles_per_plane;
+    int* hist = reinterpret_cast<int*>(smem);
+    unsigned* aux = reinterpret_cast<unsigned*>(smem) + n_loc;
+    float* rays = smem + 2 * n_loc;
+    const int n_all = p.depth_resolution + p.depth_resolution_importance;
+    const int tile = blockIdx.x;
+    if (tid < 16) {
+        const int64_t ray = bin_tile_ray(P, tile, tid);
+        float* r = rays + tid * 8;
+        if (ray >= 0) {
+            r[0] = p.ray_origins[ray * 3 + 0]; r[1] = p.ray_origins[ray * 3 + 1]; r[2] = p.ray_origins[ray * 3 + 2];
+            r[3] = p.ray_dirs[ray * 3 + 0];    r[4] = p.ray_dirs[ray * 3 + 1];    r[5] = p.ray_dirs[ray * 3 + 2];
+        }
+        reinterpret_cast<int*>(r)[6] = int(ray);
+    }
+    for (int i = tid; i < n_loc; i += kBinCountThreads) { hist[i] = 0; aux[i] = 0; }
+    __syncthreads();
+    const int first_ray = reinterpret_cast<const int*>(rays)[6];
+    if (first_ray < 0) return;
+    const int item = first_ray / p.rays_per_item;              // a ray tile never straddles items (checked by the launcher)
+    const int loc0 = item * n_loc;                             // this item's plane tiles are [loc0, loc0 + n_loc)
+    const int n_smp = 16 * n_all;
+
+    // ---- sweep 1: this workgroup's records per plane tile (and, count pass, the bound: max |dX| of the rows behind them)
+    for (int s = tid; s < n_smp; s += kBinCountThreads) {
+        const int ri = s / n_all, rank = s - ri * n_all;
+        const float* r = rays + ri * 8;
+        const int ray = reinterpret_cast<const int*>(r)[6];
+        if (ray < 0) continue;
+        const float* ray_block = A.stage + int64_t(ray) * P.bwd_ray_stride;
+        const float depth = ray_block[rank];
+        const float px = __fadd_rn(r[0], __fmul_rn(depth, r[3])) * P.box_scale;
+        const float py = __fadd_rn(r[1], __fmul_rn(depth, r[4])) * P.box_scale;
+        const float pz = __fadd_rn(r[2], __fmul_rn(depth, r[5])) * P.box_scale;
+        int hit[3];
+        bool any = false;
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) { hit[pl] = bin_hit(P, A, item, pl, px, py, pz).ptile; any = any || hit[pl] >= 0; }
+        if (!any) continue;
+        unsigned bits = 0;
+        if (!FILL) {
+            const v4f* row = reinterpret_cast<const v4f*>(ray_block + n_all + rank * 32);
+            float m = 0.f;
+            bool nan = false;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const v4f x = row[q];
+#pragma unroll
+                for (int e = 0; e < 4; e++) { m = fmaxf(m, fabsf(x[e])); nan = nan || (x[e] != x[e]); }
+            }
+            bits = nan ? 0x7fc00000u : __float_as_uint(m);     // (a NaN orders above every finite bound and above +inf)
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+            if (hit[pl] >= 0) {
+                atomicAdd(hist + (hit[pl] - loc0), 1);
+                if (!FILL) atomicMax(aux + (hit[pl] - loc0), bits);
+            }
+    }
+    __syncthreads();
+    // ---- publish: one global atomic per plane tile this ray tile touches
+    for (int i = tid; i < n_loc; i += kBinCountThreads) {
+        const int c = hist[i];
+        if (c == 0) continue;
+        if (!FILL) {
+            atomicAdd(A.count + loc0 + i, c);
+            atomicMax(A.bound + loc0 + i, aux[i]);
+        } else {
+            aux[i] = unsigned(A.count[loc0 + i] + atomicAdd(A.cursor + loc0 + i, c));      // this workgroup's run inside the tile's segment
+            hist[i] = 0;                                                                    // becomes the position inside the run
+        }
+    }
+    if (!FILL) return;
+    __syncthreads();
+    // ---- sweep 2 (fill pass): the records
+    for (int s = tid; s < n_smp; s += kBinCountThreads) {
+        const int ri = s / n_all, rank = s - ri * n_all;
+        const float* r = rays + ri * 8;
+        const int ray = reinterpret_cast<const int*>(r)[6];
+        if (ray < 0) continue;
+        const int64_t block = int64_t(ray) * P.bwd_ray_stride;
+        const float depth = A.stage[block + rank];
+        const float px = __fadd_rn(r[0], __fmul_rn(depth, r[3])) * P.box_scale;
+        const float py = __fadd_rn(r[1], __fmul_rn(depth, r[4])) * P.box_scale;
+        const float pz = __fadd_rn(r[2], __fmul_rn(depth, r[5])) * P.box_scale;
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            const BinHit h = bin_hit(P, A, item, pl, px, py, pz);
+            if (h.ptile < 0) continue;
+            const int loc = h.ptile - loc0;
+            const unsigned at = aux[loc] + unsigned(atomicAdd(hist + loc, 1));
+            BinRecord rec;
+            rec.row = unsigned(block + n_all + int64_t(rank) * 32);
+            rec.pack = h.pack; rec.fx = h.fx; rec.fy = h.fy;
+            *reinterpret_cast<uint4*>(A.records + at) = *reinterpret_cast<const uint4*>(&rec);
+        }
+    }
+}
+
+// ---- pass 2: exclusive scan of the counts (one workgroup), and the processing order: tiles by size class (floor(log2(count)) + 1,
+// largest first), so that the persistent workgroups of bin_accumulate do not end on the biggest tiles.  The order inside a class is
+// whatever the atomics give: it schedules work, no result depends on it.
+__global__ __launch_bounds__(1024) void bin_scan_kernel(BinArgs A) {
+    __shared__ int wave_tot[16];
+    __shared__ int class_n[33], class_at[33];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 33) class_n[tid] = 0;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < A.n_ptiles; base += 1024) {
+        const int i = base + tid;
+        const int c = i < A.n_ptiles ? A.count[i] : 0;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        int before = carry_s;
+        for (int w = 0; w < wv; w++) before += wave_tot[w];
+        if (i < A.n_ptiles) {
+            A.count[i] = before + incl - c;                               // segment start
+            atomicAdd(class_n + (c > 0 ? 32 - __clz(c) : 0), 1);          // class 0: empty tiles, class k: 2^(k-1) <= count < 2^k
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        A.count[A.n_ptiles] = carry_s;
+        A.order[A.n_ptiles] = 0;                                          // the pull counter of bin_accumulate
+        int at = 0;
+        for (int k = 32; k >= 0; k--) { class_at[k] = at; at += class_n[k]; }
+    }
+    __syncthreads();                                                      // (one workgroup: its own global writes are visible to it after the barrier)
+    for (int i = tid; i < A.n_ptiles; i += 1024) {
+        const int c = A.count[i + 1] - A.count[i];
+        A.order[atomicAdd(class_at + (c > 0 ? 32 - __clz(c) : 0), 1)] = i;
+    }
+}
+
+// fp32 -> 64-bit fixed point: trunc-to-floor of c * 2^s as {low word, high word}.  |c * 2^s| < 2^61 by the choice of s.
+__device__ __forceinline__ unsigned long long bin_to_fixed(float c, int s) {
+    const float t = ldexpf(c, s);
+    const float hi = floorf(t * 2.3283064365386963e-10f);                 // floor(t / 2^32): |hi| < 2^29, exact
+    const float lo = fmaf(hi, -4294967296.f, t);                          // t - hi 2^32 in [0, 2^32): exact (a 24-bit value minus its upper part)
+    const unsigned lo_u = __float2uint_rz(lo);
+    const int hi_i = __float2int_rz(hi);
+    return (static_cast<unsigned long long>(static_cast<unsigned>(hi_i)) << 32) | lo_u;
+}
+__device__ __forceinline__ float bin_from_fixed(unsigned long long v, int s) {
+    return ldexpf(__ll2float_rn(static_cast<long long>(v)), -s);
+}
+
+// ---- pass 4: persistent workgroups, one plane tile at a time.
+__global__ __launch_bounds__(kBinAccThreads, 8) void bin_accumulate_kernel(Params P, BinArgs A) {
+    extern __shared__ __align__(16) unsigned long long acc[];             // [17][17][32]
+    __shared__ int s_next;
+    const gnerf_render_params& p = P.p;
+    const int tid = threadIdx.x, ch = tid & 31, hw = tid >> 5;
+    constexpr int kHalfWaves = kBinAccThreads / 32, kCells = kBinHalo * kBinHalo * 32;
+    const int H = p.plane_h, W = p.plane_w;
+    for (;;) {
+        if (tid == 0) s_next = atomicAdd(A.order + A.n_ptiles, 1);
+        __syncthreads();
+        const int q = s_next;
+        if (q >= A.n_ptiles) break;
+        const int t = A.order[q];
+        const int start = A.count[t], n = A.count[t + 1] - start;
+        if (n == 0) { __syncthreads(); continue; }                        // empty tile: nothing to add, its halo is never read (bin_halo checks the count)
+        for (int i = tid; i < kCells; i += kBinAccThreads) acc[i] = 0;
+        const unsigned bbits = A.bound[t];
+        const bool as_float = bbits >= 0x7f800000u;                       // inf / NaN among the rows: plain fp32 LDS adds (order-dependent, as the values are garbage anyway)
+        int s = 0;
+        if (!as_float && bbits != 0) {
+            int e;
+            (void)frexpf(__uint_as_float(bbits), &e);                     // bound < 2^e
+            const int nbits = n > 1 ? 32 - __clz(n - 1) : 0;              // n <= 2^nbits
+            s = 61 - nbits - e;
+        }
+        __syncthreads();
+        if (bbits != 0) {                                                 // (all rows zero: the sums are zero)
+            float* accf = reinterpret_cast<float*>(acc);
+            const uint4* recs = reinterpret_cast<const uint4*>(A.records + start);
+            // records two ahead, dX one ahead: the row address of record i + 32 is in a register when record i is being added
+            uint4 r0 = hw < n ? recs[hw] : make_uint4(0, 0, 0, 0);
+            uint4 r1 = hw + kHalfWaves < n ? recs[hw + kHalfWaves] : make_uint4(0, 0, 0, 0);
+            float d0 = hw < n ? A.stage[r0.x + ch] : 0.f;
+            for (int i = hw; i < n; i += kHalfWaves) {
+                const uint4 r2 = i + 2 * kHalfWaves < n ? recs[i + 2 * kHalfWaves] : make_uint4(0, 0, 0, 0);
+                const float d1 = i + kHalfWaves < n ? A.stage[r1.x + ch] : 0.f;
+                const unsigned pack = r0.y, valid = pack >> 10;
+                const int lx = int(pack & 31u) - 1, ly = int((pack >> 5) & 31u) - 1;
+                const v4f w = tap_weights(__uint_as_float(r0.z), __uint_as_float(r0.w), valid);
+                const int cell = (ly * kBinHalo + lx) * 32 + ch;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    // taps outside the plane have weight zero (and may sit outside the LDS tile: lx = -1): skipped, they add nothing
+                    if (!((valid >> (k & 1)) & (valid >> (2 + (k >> 1))) & 1u)) continue;
+                    const float c = w[k] * d0;
+                    const int at = cell + ((k & 1) + (k >> 1) * kBinHalo) * 32;
+                    if (as_float) unsafeAtomicAdd(accf + 2 * at, c);
+                    else __hip_atomic_fetch_add(acc + at, bin_to_fixed(c, s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                r0 = r1; r1 = r2; d0 = d1;
+            }
+        }
+        __syncthreads();
+        // ---- the tile's own texels: added to grad_planes (plain load + store: this workgroup is the only writer of them)
+        const int tpp = A.tiles_per_plane, ip = t / tpp, tt = t - ip * tpp;
+        const int item = ip / 3, pl = ip - item * 3, ty = tt / A.tiles_x, tx = tt - ty * A.tiles_x;
+        float* grad_item = A.grad_planes + int64_t(item) * 3 * H * W * 32;
+        const float* accf = reinterpret_cast<const float*>(acc);
+        for (int e = tid; e < kBinTile * kBinTile * 32; e += kBinAccThreads) {
+            const int c2 = e & 31, lx = (e >> 5) & (kBinTile - 1), ly = e >> 9;
+            const int x = tx * kBinTile + lx, y = ty * kBinTile + ly;
+            if (x < W && y < H) {
+                const int at = (ly * kBinHalo + lx) * 32 + c2;
+                const float v = as_float ? accf[2 * at] : bin_from_fixed(acc[at], s);
+                float* dst = grad_item + ((unsigned(y) * P.row_pitch + unsigned(x) * P.tex_pitch + unsigned(pl) * P.plane_pitch) >> 2) + c2;
+                *dst += v;
+            }
+        }
+        // ---- the halo (right column, bottom row, corner): to the side buffer, added by bin_halo to the neighbours' texels
+        for (int e = tid; e < kBinHaloTexels * 32; e += kBinAccThreads) {
+            const int c2 = e & 31, h = e >> 5;
+            const int ly = h < kBinTile ? h : kBinTile, lx = h < kBinTile ? kBinTile : (h < 2 * kBinTile ? h - kBinTile : kBinTile);
+            const int at = (ly * kBinHalo + lx) * 32 + c2;
+            A.halo[(int64_t(t) * kBinHaloTexels + h) * 32 + c2] = as_float ? accf[2 * at] : bin_from_fixed(acc[at], s);
+        }
+        // (the barrier at the top of the next round separates these reads from its zero fill)
+    }
+}
+
+// ---- pass 5: each plane tile adds, in a fixed order, what its left, upper and upper-left neighbours accumulated for its first
+// column / first row.  One workgroup per tile; thread = (texel of the first column or row, channel).
+__global__ __launch_bounds__(1024) void bin_halo_kernel(Params P, BinArgs A) {
+    const gnerf_render_params& p = P.p;
+    const int t = blockIdx.x, tid = threadIdx.x, c2 = tid & 31, k = tid >> 5;         // k: 0..15 first column (row k), 16..30 first row (column k - 15)
+    if (k >= 2 * kBinTile - 1) return;
+    const int H = p.plane_h, W = p.plane_w;
+    const int tpp = A.tiles_per_plane, ip = t / tpp, tt = t - ip * tpp;
+    const int item = ip / 3, pl = ip - item * 3, ty = tt / A.tiles_x, tx = tt - ty * A.tiles_x;
+    const int lx = k < kBinTile ? 0 : k - (kBinTile - 1), ly = k < kBinTile ? k : 0;
+    const int x = tx * kBinTile + lx, y = ty * kBinTile + ly;
+    if (x >= W || y >= H) return;
+    auto from = [&](int nt, int h) -> float {                               // halo texel h of tile nt, if that tile accumulated anything
+        if (A.count[nt + 1] == A.count[nt]) return 0.f;
+        return A.halo[(int64_t(nt) * kBinHaloTexels + h) * 32 + c2];
+    };
+    float add = 0.f;
+    bool any = false;
+    if (lx == 0 && tx > 0) { add += from(t - 1, ly); any = true; }                                  // left neighbour's right column
+    if (ly == 0 && ty > 0) { add += from(t - A.tiles_x, kBinTile + lx); any = true; }               // upper neighbour's bottom row
+    if (lx == 0 && ly == 0 && tx > 0 && ty > 0) { add += from(t - A.tiles_x - 1, 2 * kBinTile); any = true; }   // corner
+    if (!any || add == 0.f) return;
+    float* dst = A.grad_planes + int64_t(item) * 3 * H * W * 32 + ((unsigned(y) * P.row_pitch + unsigned(x) * P.tex_pitch + unsigned(pl) * P.plane_pitch) >> 2) + c2;
+    *dst += add;
+}
+
+// The launch sequence.  `ws`: bin_workspace_bytes() behind the staged rows, zeroed here where it has to be.
+static int launch_binned_scatter(const Params& P, float* stage, char* ws, float* grad_planes, hipStream_t s) {
+    const gnerf_render_params& p = P.p;
+    const int n_all = p.depth_resolution + p.depth_resolution_importance;
+    BinArgs A = bin_carve(ws, stage, grad_planes, P.total_rays, n_all, p.n_items, p.plane_h, p.plane_w);
+    const size_t head = reinterpret_cast<char*>(A.records) - ws;          // counts, cursors, bounds, order
+    if (hipMemsetAsync(ws, 0, head, s) != hipSuccess) return gnerf::fail(GNERF_E_LAUNCH, "render_backward: cannot clear the bin counters");
+    const size_t lds_walk = (2 * size_t(3) * A.tiles_per_plane + 16 * 8) * sizeof(float);
+    static PerDeviceOnce once_c, once_f, once_a;
+    if (int e = once_c.raise_lds(bin_walk_kernel<false>, "render_backward")) return e;
+    if (int e = once_f.raise_lds(bin_walk_kernel<true>, "render_backward")) return e;
+    if (int e = once_a.raise_lds(bin_accumulate_kernel, "render_backward")) return e;
+    hipLaunchKernelGGL(bin_walk_kernel<false>, dim3(P.n_tiles), dim3(kBinCountThreads), lds_walk, s, P, A);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, A);
+    hipLaunchKernelGGL(bin_walk_kernel<true>, dim3(P.n_tiles), dim3(kBinCountThreads), lds_walk, s, P, A);
+    const int acc_blocks = min(A.n_ptiles, 2 * gnerf::kNumCU);
+    hipLaunchKernelGGL(bin_accumulate_kernel, dim3(acc_blocks), dim3(kBinAccThreads), size_t(kBinHalo) * kBinHalo * 32 * 8, s, P, A);
+    hipLaunchKernelGGL(bin_halo_kernel, dim3(A.n_ptiles), dim3(1024), 0, s, P, A);
+    return gnerf::check_launch("binned plane scatter");
+}
