@@ -10,7 +10,7 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$root/include -I$here -Wall 
 . "$here/compile_unit.sh"
 objs=()
 pids=()
-for src in capi bias_act upfirdn2d filtered_lrelu filtered_lrelu_fused grid_sample planes modconv render; do
+for src in capi bias_act upfirdn2d filtered_lrelu filtered_lrelu_fused grid_sample planes modconv conv3x3 render; do
     [ -f "$here/$src.hip" ] || continue
     obj="$here/$src.o"
     stale=0

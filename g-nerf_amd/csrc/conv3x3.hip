@@ -1,0 +1,269 @@
+// Fused 3x3 convolution + modulated-convolution epilogue for the superresolution's fp16 channels_last layers (SURVEY.md section 8(f)3:
+// the convolution inside modulated_conv2d, networks_stylegan2.py:41-98, as SynthesisLayer.forward calls it, :315-334, for
+// superresolution.py:285-303's blocks).
+//
+// In gnerf_generator's shared-weight form (one latent per batch) a layer is
+//     x' = x * styles[n, c]            (folded into the previous layer's epilogue)
+//     y  = conv3x3(x', w)              <- MIOpen / CK until round 4: 0.31-0.35 of the f16 matrix peak on these shapes
+//     y  = clamp(lrelu(y * dcoefs[n, o] + noise + bias[o]) * gain) * next_styles[n, o]      <- gnerf_modconv_epilogue_nhwc
+// This kernel does the last two lines in one launch: an implicit GEMM on v_mfma_f32_16x16x32_f16 whose accumulators go through the
+// epilogue in registers (the same device function as the stand-alone pass, csrc/common.h: same roundings, in the same order) and
+// leave as fp16 channels_last.
+//
+// Decomposition.  One workgroup (4 waves, 1 per SIMD, one workgroup per CU: 152 KB of LDS) computes an 8 x 32 tile of output pixels for
+// 128 output channels.  The 10 x 34 input pixels the tile's nine taps touch are staged ONCE per 128 input channels (87 KB; image
+// borders come in as zeros from the buffer load's range check) and every tap reads them at a shifted position; the weights of one
+// (tap, 128 input channels) -- 32 KB -- stream through a double buffer while the previous tap is being multiplied.  Both are filled by
+// LDS-DMA (buffer_load / global_load ... lds: no registers, no ds_write), whose LDS image is lane-linear, so the bank-conflict swizzle
+// (16-byte slot ^ (row & 15)) is applied to the SOURCE address and again when the fragments are read.
+// Orientation: A = weights (M = 16 output channels), B = input (N = 16 pixels of a row), K = 32 input channels per instruction; a lane's
+// four accumulator registers are then four CONSECUTIVE output channels of one pixel -- an 8-byte piece of the channels_last result.
+// A wave owns two rows of the tile: 64 pixels x 128 channels = 128 accumulator registers, 32 MFMAs per 12 ds_read_b128.
+
+#include "common.h"
+
+namespace {
+
+using namespace gnerf;
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kTH = 8, kTW = 32;                    // output pixels of a tile
+constexpr int kIH = kTH + 2, kIW = kTW + 2;         // input pixels incl. the one-pixel halo
+constexpr int kCK = 128;                            // input channels resident in LDS
+constexpr int kCO = 128;                            // output channels per workgroup
+constexpr int kConvThreads = 256;
+constexpr int kXPieces = kIH * kIW * (kCK / 8);     // 16-byte pieces of the input tile
+constexpr int kXRounds = (kXPieces + kConvThreads - 1) / kConvThreads;
+constexpr int kXBytes = kXRounds * kConvThreads * 16;
+constexpr int kWBytes = kCO * kCK * 2;
+constexpr int kWRounds = kWBytes / 16 / kConvThreads;
+constexpr int kConvLds = kXBytes + 2 * kWBytes;
+static_assert(kTH * kTW * kCO * 2 <= kXBytes, "the output tile is staged where the input tile was");
+
+struct ConvArgs {
+    const _Float16* x;          // [n, h, w, cin]    channels_last activations
+    const _Float16* wpk;        // [9, cout, cin]     tap-major weights: tap = ky * 3 + kx of the correlation form
+    _Float16* y;                // [n, h, w, cout]
+    const float* scale;         // [n, cout] or NULL  (demodulation coefficients)
+    const float* noise;         // [h * w] or NULL
+    const __half* bias;         // [cout] or NULL
+    const float* next_scale;    // [n, cout] or NULL
+    int n, h, w, cin, cout;
+    int tiles_x, tiles_y, n_tiles;
+    int round_noise;
+    float alpha, gain, clamp;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <bool SCALE, bool NOISE, bool NEXT>
+__global__ __launch_bounds__(kConvThreads, 1) void conv3x3_epilogue_kernel(ConvArgs a) {
+    extern __shared__ __align__(16) char lds[];
+    char* const xs = lds;                           // [340 pixels][16 slots of 16 bytes], slot ^= pixel & 15
+    char* const wb = lds + kXBytes;                 // 2 x [128 output channels][16 slots], slot ^= channel & 15
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, hq = lane >> 4;
+
+    // tile of this workgroup: XCD b % 8 gets a contiguous eighth of the tile sequence (neighbouring tiles share halo pixels in its L2)
+    const int per_xcd = (a.n_tiles + kNumXCD - 1) / kNumXCD;
+    const int tile = (blockIdx.x % kNumXCD) * per_xcd + blockIdx.x / kNumXCD;
+    if (tile >= a.n_tiles) return;
+    const int tiles_img = a.tiles_x * a.tiles_y;
+    const int n = tile / tiles_img, tt = tile - n * tiles_img;
+    const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+    const int y0 = ty * kTH, x0 = tx * kTW;
+    const int co0 = blockIdx.y * kCO;
+    const int H = a.h, W = a.w, Cin = a.cin, Cout = a.cout;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(a.x) + size_t(n) * H * W * Cin, 0, int(size_t(H) * W * Cin * 2), 0x00020000);
+
+    auto stage_x = [&](int cin0) {
+#pragma unroll
+        for (int it = 0; it < kXRounds; it++) {
+            const int q = it * kConvThreads + tid;
+            const int pix = q >> 4, slot = q & 15;
+            const int py = pix / kIW, px = pix - py * kIW;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            const bool ok = pix < kIH * kIW && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const unsigned off = ok ? unsigned(((iy * W + ix) * Cin + cin0 + ((slot ^ (pix & 15)) << 3)) * 2) : 0x80000000u;     // out of range: zeros
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(xs + (it * kConvThreads + wv * 64) * 16), 16, off, 0, 0, 0);
+        }
+    };
+    auto stage_w = [&](int tap, int cin0, int buf) {
+        const _Float16* src = a.wpk + (size_t(tap) * Cout + co0) * Cin + cin0;
+#pragma unroll
+        for (int it = 0; it < kWRounds; it++) {
+            const int q = it * kConvThreads + tid;
+            const int co = q >> 4, slot = q & 15;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + size_t(co) * Cin + ((slot ^ (co & 15)) << 3)),
+                                             (lds_ptr_t)(wb + buf * kWBytes + (it * kConvThreads + wv * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    v4f acc[8][4];
+#pragma unroll
+    for (int cb = 0; cb < 8; cb++)
+#pragma unroll
+        for (int pb = 0; pb < 4; pb++) acc[cb][pb] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    const int n_chunks = Cin / kCK, total = n_chunks * 9;
+    stage_x(0);
+    stage_w(0, 0, 0);
+    for (int s = 0; s < total; s++) {
+        const int chunk = s / 9, tap = s - chunk * 9;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this step's weights (and, at a chunk's first tap, its input tile) have landed
+        __syncthreads();                                            // ... for every wave; and every wave is done with the other weight buffer
+        if (s + 1 < total) {
+            const int c1 = (s + 1) / 9;
+            stage_w(s + 1 - c1 * 9, c1 * kCK, (s + 1) & 1);        // streams in under this step's MFMAs
+        }
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const char* wbuf = wb + (s & 1) * kWBytes + r * 256;
+        int xrow[4], xm[4];
+#pragma unroll
+        for (int pb = 0; pb < 4; pb++) {
+            const int pi = (2 * wv + (pb >> 1) + dy) * kIW + (pb & 1) * 16 + r + dx;
+            xrow[pb] = pi * 256;
+            xm[pb] = pi & 15;
+        }
+        // The four 32-channel k-steps of the tap as a software pipeline: the twelve fragment reads of step kc + 1 are issued, one per
+        // two or three MFMAs, among the 32 MFMAs of step kc.  (Left to itself hipcc re-used ONE register quad for every weight
+        // fragment -- read, wait, four MFMAs, read, wait ... -- which exposes an LDS round trip per four MFMAs: with one wave per SIMD
+        // nothing else covers it.)
+        h8 A[2][8], B[2][4];
+        // fragment f of k-step kc: f = 0..3 the input fragments of the wave's four pixel blocks, f = 4..11 the eight weight fragments
+        auto load_frag = [&](int kc, int f, h8 (&Af)[8], h8 (&Bf)[4]) {
+            const int ks = kc * 4 + hq;
+            if (f < 4) Bf[f] = *reinterpret_cast<const h8*>(xs + xrow[f] + ((ks ^ xm[f]) << 4));
+            else       Af[f - 4] = *reinterpret_cast<const h8*>(wbuf + (f - 4) * 4096 + ((ks ^ r) << 4));
+        };
+#pragma unroll
+        for (int f = 0; f < 12; f++) load_frag(0, f, A[0], B[0]);
+#pragma unroll
+        for (int kc = 0; kc < kCK / 32; kc++) {
+            // {8 MFMAs, six reads for the next k-step} twice, then 16 MFMAs -- fenced so that the compiler keeps the order.  The reads
+            // issue in the shadow of the MFMA in front of them, and the last of them has 24 MFMAs to come back behind: the wait at the
+            // next k-step's first MFMA (the compiler makes it lgkmcnt(0)) finds nothing outstanding.
+            auto mfma_group = [&](int g) {
+#pragma unroll
+                for (int cb = 2 * g; cb < 2 * g + 2; cb++)
+#pragma unroll
+                    for (int pb = 0; pb < 4; pb++) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[kc & 1][cb], B[kc & 1][pb], acc[cb][pb], 0, 0, 0);
+            };
+            auto read_group = [&](int f0) {
+                if (kc + 1 < kCK / 32) {
+#pragma unroll
+                    for (int f = f0; f < f0 + 6; f++) load_frag(kc + 1, f, A[(kc + 1) & 1], B[(kc + 1) & 1]);
+                }
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_group(0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(1);
+            __builtin_amdgcn_sched_barrier(0);
+            read_group(6);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(2);
+            mfma_group(3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap == 8 && chunk + 1 < n_chunks) {
+            __syncthreads();                                        // every wave has read the last of this chunk's input tile
+            stage_x((chunk + 1) * kCK);
+        }
+    }
+    __syncthreads();                                                // the input tile is dead: its LDS takes the output tile
+
+    // ---- epilogue in registers, then through LDS for 16-byte coalesced stores.  Output image: [256 pixels][16 slots], slot ^= pixel & 15.
+    char* const os = lds;
+#pragma unroll
+    for (int cb = 0; cb < 8; cb++) {
+        const int c4 = cb * 16 + hq * 4;                           // this lane's four consecutive output channels (of the workgroup's 128)
+        float sc[4] = {1.f, 1.f, 1.f, 1.f}, nx[4] = {1.f, 1.f, 1.f, 1.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (SCALE) { const float4 v = *reinterpret_cast<const float4*>(a.scale + size_t(n) * Cout + co0 + c4); sc[0] = v.x; sc[1] = v.y; sc[2] = v.z; sc[3] = v.w; }
+        if constexpr (NEXT) {
+            const float4 v = *reinterpret_cast<const float4*>(a.next_scale + size_t(n) * Cout + co0 + c4);
+            nx[0] = round_to<__half>(v.x); nx[1] = round_to<__half>(v.y); nx[2] = round_to<__half>(v.z); nx[3] = round_to<__half>(v.w);
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) bv[k] = __half2float(a.bias[co0 + c4 + k]);
+        }
+#pragma unroll
+        for (int pb = 0; pb < 4; pb++) {
+            const int prow = 2 * wv + (pb >> 1), pcol = (pb & 1) * 16 + r;
+            const int p = prow * kTW + pcol;
+            Pk<__half, 4> in;
+#pragma unroll
+            for (int k = 0; k < 4; k++) in.v[k] = __float2half(acc[cb][pb][k]);          // what the convolution alone would have stored
+            float nz = 0.f;
+            if constexpr (NOISE) nz = a.noise[(y0 + prow) * W + x0 + pcol];
+            const Pk<__half, 4> out = modconv_epilogue_vec<__half, 4, 3, SCALE, NOISE, NEXT>(in, sc, nz, a.round_noise != 0, bv, nx, a.alpha, a.gain, a.clamp);
+            *reinterpret_cast<uint2*>(os + p * 256 + (((c4 >> 3) ^ (p & 15)) << 4) + ((c4 >> 2) & 1) * 8) = *reinterpret_cast<const uint2*>(&out);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kTH * kTW * 16 / kConvThreads; it++) {
+        const int q = it * kConvThreads + tid;
+        const int p = q >> 4, slot = q & 15;
+        const uint4 v = *reinterpret_cast<const uint4*>(os + p * 256 + ((slot ^ (p & 15)) << 4));
+        const int yy = y0 + p / kTW, xx = x0 + (p & (kTW - 1));
+        *reinterpret_cast<uint4*>(a.y + (size_t(n) * H * W + size_t(yy) * W + xx) * Cout + co0 + slot * 8) = v;
+    }
+}
+
+}  // namespace
+
+// y = epilogue(conv3x3(x, w)) on float16 channels_last tensors; see include/gnerf_hip.h.
+extern "C" int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, void* y, int n, int h, int w, int cin, int cout,
+                                           const float* scale, const float* noise, int round_noise, const void* bias,
+                                           float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!x || !w_packed || !y) return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: null pointer");
+    if (n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: empty tensor");
+    if (h % kTH || w % kTW || cin % kCK || cout % kCO)
+        return fail(GNERF_E_UNSUPPORTED, "conv3x3_epilogue_nhwc: needs height %% 8 == 0, width %% 32 == 0, channels %% 128 == 0 (got %dx%d, %d -> %d)", h, w, cin, cout);
+    if (size_t(h) * w * cin * 2 >= (size_t(1) << 31)) return fail(GNERF_E_UNSUPPORTED, "conv3x3_epilogue_nhwc: one image of x must stay below 2 GB");
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(y)) & 15)
+        return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: x, w and y must be 16-byte aligned");
+    if ((scale && (reinterpret_cast<uintptr_t>(scale) & 15)) || (next_scale && (reinterpret_cast<uintptr_t>(next_scale) & 15)))
+        return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: scale and next_scale must be 16-byte aligned");
+    ConvArgs a;
+    a.x = static_cast<const _Float16*>(x); a.wpk = static_cast<const _Float16*>(w_packed); a.y = static_cast<_Float16*>(y);
+    a.scale = scale; a.noise = noise; a.bias = static_cast<const __half*>(bias); a.next_scale = next_scale;
+    a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
+    a.tiles_x = w / kTW; a.tiles_y = h / kTH; a.n_tiles = n * a.tiles_x * a.tiles_y;
+    a.round_noise = round_noise; a.alpha = alpha; a.gain = gain; a.clamp = clamp;
+    const dim3 grid((a.n_tiles + kNumXCD - 1) / kNumXCD * kNumXCD, cout / kCO), block(kConvThreads);
+    hipStream_t s = as_stream(stream);
+#define GNERF_CONV(SC, NZ, NX) do { \
+        static bool raised[64] = {}; \
+        int dev = 0; \
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0; \
+        if (!raised[dev]) { \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_epilogue_kernel<SC, NZ, NX>), hipFuncAttributeMaxDynamicSharedMemorySize, kConvLds) != hipSuccess) \
+                return fail(GNERF_E_LAUNCH, "conv3x3_epilogue_nhwc: cannot raise the dynamic LDS limit"); \
+            raised[dev] = true; \
+        } \
+        hipLaunchKernelGGL((conv3x3_epilogue_kernel<SC, NZ, NX>), grid, block, kConvLds, s, a); } while (0)
+    const int key = (scale ? 4 : 0) | (noise ? 2 : 0) | (next_scale ? 1 : 0);
+    switch (key) {
+        case 0: GNERF_CONV(false, false, false); break;
+        case 1: GNERF_CONV(false, false, true); break;
+        case 2: GNERF_CONV(false, true, false); break;
+        case 3: GNERF_CONV(false, true, true); break;
+        case 4: GNERF_CONV(true, false, false); break;
+        case 5: GNERF_CONV(true, false, true); break;
+        case 6: GNERF_CONV(true, true, false); break;
+        default: GNERF_CONV(true, true, true); break;
+    }
+#undef GNERF_CONV
+    return check_launch("conv3x3_epilogue_nhwc");
+}

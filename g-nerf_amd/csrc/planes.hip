@@ -283,6 +283,10 @@ extern "C" int gnerf_upsample2x_add_nhwc(const float* img, const float* y, const
     if (!img || !f_host || !out) return fail(GNERF_E_ARG, "upsample2x_add_nhwc: null pointer");
     if (n < 1 || c < 1 || h < 1 || w < 1) return fail(GNERF_E_ARG, "upsample2x_add_nhwc: empty tensor");
     if (c % kUpCh != 0 || (2 * w) % kUpCols != 0 || (2 * h) % kUpRows != 0) return fail(GNERF_E_UNSUPPORTED, "upsample2x_add_nhwc: needs channels %% 32 == 0, width %% 16 == 0, height %% 2 == 0");
+    // the kernel reads y and writes out as 16-byte vectors: a contiguous view at a storage offset that is no multiple of four floats
+    // is not for it (the wrapper composes the PyTorch ops then, as for any other unsupported shape)
+    if ((y && (reinterpret_cast<uintptr_t>(y) & 15)) || (reinterpret_cast<uintptr_t>(out) & 15))
+        return fail(GNERF_E_UNSUPPORTED, "upsample2x_add_nhwc: y and out must be 16-byte aligned");
     const int64_t blocks = int64_t(n) * (c / kUpCh) * (2 * h / kUpRows) * (2 * w / kUpCols);
     if (blocks > INT32_MAX || int64_t(n) * c * 4 * h * w > INT32_MAX * int64_t(2)) return fail(GNERF_E_ARG, "upsample2x_add_nhwc: tensor too large");
     Up2Taps K;

@@ -800,6 +800,9 @@ static int fill_params(const gnerf_render_params* p, Params& P) {
     if (int e = check_common(p)) return e;
     const bool own_rays = !p->ray_origins && !p->ray_dirs && p->cam2world && p->intrinsics;
     if (!own_rays && (!p->ray_origins || !p->ray_dirs)) return fail(GNERF_E_ARG, "render: rays must not be null (or both null with cam2world and intrinsics given)");
+    // ray tensors AND cameras: the generating instantiation keys on cam2world and would replace the caller's rays by camera rays
+    // (and divide by image_width, which nothing has checked for this combination): one source of rays per call
+    if (!own_rays && (p->cam2world || p->intrinsics)) return fail(GNERF_E_ARG, "render: give ray tensors or cam2world / intrinsics, not both");
     if (own_rays && (p->image_width < 1 || int64_t(p->image_width) * p->image_width != p->rays_per_item))
         return fail(GNERF_E_ARG, "render: in-kernel rays need rays_per_item = image_width^2");
     if (p->rng_mode != GNERF_RNG_TENSORS && p->rng_mode != GNERF_RNG_TORCH_PHILOX) return fail(GNERF_E_ARG, "render: rng_mode %d is not one of GNERF_RNG_*", p->rng_mode);

@@ -8,42 +8,55 @@
 //
 //   bin_count      one workgroup per 16-ray tile: every (sample, plane) whose footprint has a non-zero tap is a RECORD of the plane tile
 //                  (16 x 16 texels) its top-left tap falls in; per tile: record count and max |dX| over its records
-//   bin_scan       exclusive scan of the counts -> each tile's segment of the record array; work order (largest tiles first)
-//   bin_fill       the same walk again; records (dX row, footprint position in the tile, fx, fy) into their tile's segment
+//   bin_scan       exclusive scan of the counts (rounded up to whole batches of four records) -> each tile's segment of the record
+//                  arrays; the fixed-point scale of every tile; work order (largest tiles first)
+//   bin_fill       the same walk again: per record the float index of its dX row, its cell in the tile, and its four tap weights
+//                  already multiplied by the tile's scale
 //   bin_accumulate persistent workgroups pull tiles: 17 x 17 texels x 32 channels of 64-bit FIXED-POINT accumulators in LDS (the tile
-//                  plus the one-texel halo a footprint can reach to the right / below); a half-wave per record (lane = channel) reads
-//                  the record's 128-byte dX row and adds its four weighted taps with ds_add_u64; the tile's own 16 x 16 texels are
-//                  then converted to fp32 and ADDED to grad_planes with plain loads / stores, the halo goes to a side buffer
+//                  plus the one-texel halo a footprint can reach to the right / below).  A WAVE takes a record at a time: the record
+//                  comes through the scalar cache (s_load: row, cell and weights are wave-uniform, no vector instruction touches
+//                  them), the 32 lanes of each half read the record's 128-byte dX row, half h adds the two taps of footprint row h with
+//                  ds_add_u64.  The tile's own 16 x 16 texels are then converted to fp32 and ADDED to grad_planes with plain loads /
+//                  stores, the halo goes to a side buffer
 //   bin_halo       every tile adds the halos of its left, upper and upper-left neighbours (fixed order) to its first column / row
 //
-// Fixed point: a contribution c = w * dx is added as trunc(c * 2^s) with ONE scale per tile, s = 61 - ceil(log2(n_t)) - exponent(B_t)
+// Fixed point: a contribution c = w * dx is added as floor(c * 2^s) with ONE scale per tile, s = 61 - ceil(log2(n_t)) - exponent(B_t)
 // from the tile's record count n_t and bound B_t >= |dx| (so that n_t contributions cannot overflow 63 bits).  Integer addition is
 // associative: the sum does not depend on the order in which records arrive, i.e. plane gradients are BIT-REPRODUCIBLE from run to
 // run -- which neither the float-atomic forms nor the reference's grid_sampler_2d_backward are -- and each texel is rounded to fp32
 // once, from 49 or more significant bits below the tile's bound, instead of once per addition.
+// Why integers and not ds_add_f32: tools/probes/lds_atomic_probe.hip (profiles/r05_lds_atomic_probe.json) -- a wave64 ds_add_f32
+// takes 192 CU cycles whatever its addresses (three per lane: the float LDS atomic is serialised), ds_add_u64 takes 6, ds_add_u32 4.
 // Not covered (the caller falls back to plane_scatter_kernel): staging buffers of 2^32 floats or more, ray tiles that straddle items.
 
 constexpr int kBinTile = 16;                            // texels per side of a plane tile
 constexpr int kBinHalo = kBinTile + 1;                  // LDS tile side incl. the right / bottom halo
 constexpr int kBinCountThreads = 256;
 constexpr int kBinAccThreads = 1024;
+constexpr int kBinAccWaves = kBinAccThreads / 64;
 constexpr int kBinHaloTexels = 2 * kBinTile + 1;        // halo texels of a tile: right column (16), bottom row (16), corner
+constexpr int kBinBatch = 4;                            // records per scalar-load batch; segments are padded to whole batches
 
-struct BinRecord { unsigned row; unsigned pack; float fx, fy; };       // row: float index of the dX row in the staging buffer
-static_assert(sizeof(BinRecord) == 16, "records are read as one 16-byte load");
+struct BinRowCell { unsigned row, cell; };              // row: float index of the record's dX row in the staging buffer; cell: (ly * 17 + lx) * 32
+typedef float BinWeights __attribute__((ext_vector_type(4)));      // the four tap weights x 2^min(s, 64): x0y0, x1y0, x0y1, x1y1
 
 struct BinArgs {
     const float* stage;         // the staged dX rows (gnerf_render_backward's scatter_stage)
     float* grad_planes;
-    int* count;                 // [n_ptiles + 1] records per plane tile; bin_scan turns it into segment starts (exclusive scan)
+    int* count;                 // [n_ptiles] records per plane tile
+    int* start;                 // [n_ptiles + 1] first record of the tile's segment (multiples of kBinBatch)
     int* cursor;                // [n_ptiles] fill position inside the segment
     unsigned* bound;            // [n_ptiles] float bits of max |dX| over the tile's records (non-negative floats order like unsigned)
+    int* scale;                 // [n_ptiles] fixed-point exponent s of the tile (kBinFloat: accumulate in fp32 -- inf / NaN among the rows)
     int* order;                 // [n_ptiles] tiles in processing order (largest first);  order[n_ptiles] = the pull counter
-    BinRecord* records;         // [3 * rays * n_all]
+    BinRowCell* rc;             // [capacity]
+    BinWeights* wt;             // [capacity]
     float* halo;                // [n_ptiles][kBinHaloTexels][32]
     int n_ptiles, tiles_x, tiles_y, tiles_per_plane;
 };
+constexpr int kBinFloat = 0x7fffffff;
 
+__host__ inline int64_t bin_capacity(int64_t rays, int n_all, int64_t n_ptiles) { return 3 * rays * n_all + (kBinBatch - 1) * n_ptiles + kBinBatch; }
 // where the workspace starts: behind the staged rows and the spare line of gnerf_render_backward (256-byte aligned)
 __host__ inline size_t bin_workspace_offset(int64_t rays, int n_all) {
     return (size_t(rays) * size_t(n_all) * 33 * sizeof(float) + 256 + 255) / 256 * 256;
@@ -52,7 +65,8 @@ __host__ inline size_t bin_workspace_offset(int64_t rays, int n_all) {
 __host__ inline size_t bin_workspace_bytes(int64_t rays, int n_all, int n_items, int H, int W) {
     const int64_t tx = (W + kBinTile - 1) / kBinTile, ty = (H + kBinTile - 1) / kBinTile, nt = int64_t(n_items) * 3 * tx * ty;
     auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
-    return size_t(up((nt + 1) * 4) + up(nt * 4) + up(nt * 4) + up((nt + 1) * 4) + up(3 * rays * n_all * int64_t(sizeof(BinRecord))) + up(nt * kBinHaloTexels * 32 * 4));
+    const int64_t cap = bin_capacity(rays, n_all, nt);
+    return size_t(6 * up((nt + 1) * 4) + up(cap * int64_t(sizeof(BinRowCell))) + up(cap * int64_t(sizeof(BinWeights))) + up(nt * kBinHaloTexels * 32 * 4));
 }
 __host__ inline BinArgs bin_carve(char* base, const float* stage, float* grad, int64_t rays, int n_all, int n_items, int H, int W) {
     BinArgs A;
@@ -60,12 +74,16 @@ __host__ inline BinArgs bin_carve(char* base, const float* stage, float* grad, i
     A.tiles_per_plane = A.tiles_x * A.tiles_y;
     A.n_ptiles = n_items * 3 * A.tiles_per_plane;
     auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
+    const int64_t words = up((int64_t(A.n_ptiles) + 1) * 4), cap = bin_capacity(rays, n_all, A.n_ptiles);
     A.stage = stage; A.grad_planes = grad;
-    A.count = reinterpret_cast<int*>(base);            base += up((int64_t(A.n_ptiles) + 1) * 4);
-    A.cursor = reinterpret_cast<int*>(base);           base += up(int64_t(A.n_ptiles) * 4);
-    A.bound = reinterpret_cast<unsigned*>(base);       base += up(int64_t(A.n_ptiles) * 4);
-    A.order = reinterpret_cast<int*>(base);            base += up((int64_t(A.n_ptiles) + 1) * 4);
-    A.records = reinterpret_cast<BinRecord*>(base);    base += up(3 * rays * n_all * int64_t(sizeof(BinRecord)));
+    A.count = reinterpret_cast<int*>(base);            base += words;
+    A.start = reinterpret_cast<int*>(base);            base += words;
+    A.cursor = reinterpret_cast<int*>(base);           base += words;
+    A.bound = reinterpret_cast<unsigned*>(base);       base += words;
+    A.scale = reinterpret_cast<int*>(base);            base += words;
+    A.order = reinterpret_cast<int*>(base);            base += words;
+    A.rc = reinterpret_cast<BinRowCell*>(base);        base += up(cap * int64_t(sizeof(BinRowCell)));
+    A.wt = reinterpret_cast<BinWeights*>(base);        base += up(cap * int64_t(sizeof(BinWeights)));
     A.halo = reinterpret_cast<float*>(base);
     return A;
 }
@@ -104,22 +122,40 @@ __device__ __forceinline__ int64_t bin_tile_ray(const Params& P, int tile, int i
     return ray < P.total_rays ? ray : -1;
 }
 
-// One (sample, plane) of the walk shared by bin_count and bin_fill: plane tile (or -1: every tap has weight zero) and the record fields.
-struct BinHit { int ptile; unsigned pack; float fx, fy; };
+// One (sample, plane) of the walk shared by bin_count and bin_fill: plane tile (or -1: every tap has weight zero), the footprint's
+// cell in the tile and its weights.  A footprint that starts one texel left of / above the plane (x0 = -1 or y0 = -1: those taps have
+// weight zero) is moved onto the plane -- its x1 / y1 taps become the x0 / y0 taps -- so that all four cells of EVERY record lie
+// inside the 17 x 17 LDS tile and the accumulation needs no validity test (a zero weight adds zero).
+struct BinHit { int ptile; unsigned cell; v4f w; };
 __device__ __forceinline__ BinHit bin_hit(const Params& P, const BinArgs& A, int item, int pl, float px, float py, float pz) {
     const float u = pl == 2 ? pz : px;
     const float v = pl == 0 ? py : (pl == 1 ? pz : px);
     const TapGeom g = tap_geom(P.p.plane_h, P.p.plane_w, u, v);
     BinHit h;
-    h.fx = g.fx; h.fy = g.fy;
-    const v4f w = tap_weights(g.fx, g.fy, g.valid);
-    if (!(w[0] != 0.f || w[1] != 0.f || w[2] != 0.f || w[3] != 0.f)) { h.ptile = -1; h.pack = 0; return h; }       // (NaN weights count as taps: they reach the sum)
+    h.w = tap_weights(g.fx, g.fy, g.valid);
+    h.cell = 0;
+    if (!(h.w[0] != 0.f || h.w[1] != 0.f || h.w[2] != 0.f || h.w[3] != 0.f)) { h.ptile = -1; return h; }       // (NaN weights count as taps: they reach the sum)
     const int cx = min(max(g.x0, 0), P.p.plane_w - 1), cy = min(max(g.y0, 0), P.p.plane_h - 1);
     const int tx = cx / kBinTile, ty = cy / kBinTile;
     h.ptile = (item * 3 + pl) * A.tiles_per_plane + ty * A.tiles_x + tx;
-    h.pack = unsigned(g.x0 - tx * kBinTile + 1) | (unsigned(g.y0 - ty * kBinTile + 1) << 5) | (g.valid << 10);      // lx + 1, ly + 1 in 0..16
+    int lx = g.x0 - tx * kBinTile, ly = g.y0 - ty * kBinTile;              // -1 .. 15
+    if (lx < 0) { lx = 0; h.w[0] = h.w[1]; h.w[1] = 0.f; h.w[2] = h.w[3]; h.w[3] = 0.f; }
+    if (ly < 0) { ly = 0; h.w[0] = h.w[2]; h.w[1] = h.w[3]; h.w[2] = 0.f; h.w[3] = 0.f; }
+    h.cell = unsigned((ly * kBinHalo + lx) * 32);
     return h;
 }
+
+// the fixed-point exponent of a tile from its record count and the float bits of its bound
+__device__ __forceinline__ int bin_scale_of(int n, unsigned bbits) {
+    if (bbits >= 0x7f800000u) return kBinFloat;                               // inf / NaN among the rows
+    if (bbits == 0 || n == 0) return 0;
+    int e;
+    (void)frexpf(__uint_as_float(bbits), &e);                                 // bound < 2^e
+    const int nbits = n > 1 ? 32 - __clz(n - 1) : 0;                          // n <= 2^nbits
+    return 61 - nbits - e;
+}
+// the part of the scale the stored weights carry (the rest, for bounds below 2^-3, multiplies dx in the accumulation)
+__device__ __forceinline__ int bin_weight_scale(int s) { return s == kBinFloat ? 0 : min(s, 64); }
 
 // ---- pass 1 and pass 3: FILL = false counts records and bounds per plane tile, FILL = true writes the records.
 // LDS: [3 * tiles_per_plane] ints (this ray tile's records per plane tile of its item), then the same number of words for the bound
@@ -196,7 +232,7 @@ __global__ __launch_bounds__(kBinCountThreads) void bin_walk_kernel(Params P, Bi
             atomicAdd(A.count + loc0 + i, c);
             atomicMax(A.bound + loc0 + i, aux[i]);
         } else {
-            aux[i] = unsigned(A.count[loc0 + i] + atomicAdd(A.cursor + loc0 + i, c));      // this workgroup's run inside the tile's segment
+            aux[i] = unsigned(A.start[loc0 + i] + atomicAdd(A.cursor + loc0 + i, c));      // this workgroup's run inside the tile's segment
             hist[i] = 0;                                                                    // becomes the position inside the run
         }
     }
@@ -219,17 +255,17 @@ __global__ __launch_bounds__(kBinCountThreads) void bin_walk_kernel(Params P, Bi
             if (h.ptile < 0) continue;
             const int loc = h.ptile - loc0;
             const unsigned at = aux[loc] + unsigned(atomicAdd(hist + loc, 1));
-            BinRecord rec;
-            rec.row = unsigned(block + n_all + int64_t(rank) * 32);
-            rec.pack = h.pack; rec.fx = h.fx; rec.fy = h.fy;
-            *reinterpret_cast<uint4*>(A.records + at) = *reinterpret_cast<const uint4*>(&rec);
+            const int sw = bin_weight_scale(A.scale[h.ptile]);
+            A.rc[at] = BinRowCell{unsigned(block + n_all + int64_t(rank) * 32), h.cell};
+            A.wt[at] = (BinWeights){ldexpf(h.w[0], sw), ldexpf(h.w[1], sw), ldexpf(h.w[2], sw), ldexpf(h.w[3], sw)};
         }
     }
 }
 
-// ---- pass 2: exclusive scan of the counts (one workgroup), and the processing order: tiles by size class (floor(log2(count)) + 1,
-// largest first), so that the persistent workgroups of bin_accumulate do not end on the biggest tiles.  The order inside a class is
-// whatever the atomics give: it schedules work, no result depends on it.
+// ---- pass 2 (one workgroup): segment starts = exclusive scan of the counts rounded up to whole batches, the padding records of every
+// segment (row 0, weight zero: they add zero), every tile's scale, and the processing order: tiles by size class (floor(log2(count))
+// + 1, largest first), so that the persistent workgroups of bin_accumulate do not end on the biggest tiles.  The order inside a class
+// is whatever the atomics give: it schedules work, no result depends on it.
 __global__ __launch_bounds__(1024) void bin_scan_kernel(BinArgs A) {
     __shared__ int wave_tot[16];
     __shared__ int class_n[33], class_at[33];
@@ -241,7 +277,8 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(BinArgs A) {
     for (int base = 0; base < A.n_ptiles; base += 1024) {
         const int i = base + tid;
         const int c = i < A.n_ptiles ? A.count[i] : 0;
-        int incl = c;
+        const int padded = (c + kBinBatch - 1) / kBinBatch * kBinBatch;
+        int incl = padded;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
         if (lane == 63) wave_tot[wv] = incl;
@@ -249,7 +286,10 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(BinArgs A) {
         int before = carry_s;
         for (int w = 0; w < wv; w++) before += wave_tot[w];
         if (i < A.n_ptiles) {
-            A.count[i] = before + incl - c;                               // segment start
+            const int st = before + incl - padded;
+            A.start[i] = st;
+            A.scale[i] = bin_scale_of(c, A.bound[i]);
+            for (int k = c; k < padded; k++) { A.rc[st + k] = BinRowCell{0u, 0u}; A.wt[st + k] = (BinWeights){0.f, 0.f, 0.f, 0.f}; }
             atomicAdd(class_n + (c > 0 ? 32 - __clz(c) : 0), 1);          // class 0: empty tiles, class k: 2^(k-1) <= count < 2^k
         }
         __syncthreads();
@@ -257,21 +297,20 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(BinArgs A) {
         __syncthreads();
     }
     if (tid == 0) {
-        A.count[A.n_ptiles] = carry_s;
+        A.start[A.n_ptiles] = carry_s;
         A.order[A.n_ptiles] = 0;                                          // the pull counter of bin_accumulate
         int at = 0;
         for (int k = 32; k >= 0; k--) { class_at[k] = at; at += class_n[k]; }
     }
-    __syncthreads();                                                      // (one workgroup: its own global writes are visible to it after the barrier)
+    __syncthreads();
     for (int i = tid; i < A.n_ptiles; i += 1024) {
-        const int c = A.count[i + 1] - A.count[i];
+        const int c = A.count[i];
         A.order[atomicAdd(class_at + (c > 0 ? 32 - __clz(c) : 0), 1)] = i;
     }
 }
 
-// fp32 -> 64-bit fixed point: trunc-to-floor of c * 2^s as {low word, high word}.  |c * 2^s| < 2^61 by the choice of s.
-__device__ __forceinline__ unsigned long long bin_to_fixed(float c, int s) {
-    const float t = ldexpf(c, s);
+// fp32 -> 64-bit fixed point: floor of t (|t| < 2^61) as {low word, high word}
+__device__ __forceinline__ unsigned long long bin_to_fixed(float t) {
     const float hi = floorf(t * 2.3283064365386963e-10f);                 // floor(t / 2^32): |hi| < 2^29, exact
     const float lo = fmaf(hi, -4294967296.f, t);                          // t - hi 2^32 in [0, 2^32): exact (a 24-bit value minus its upper part)
     const unsigned lo_u = __float2uint_rz(lo);
@@ -282,57 +321,100 @@ __device__ __forceinline__ float bin_from_fixed(unsigned long long v, int s) {
     return ldexpf(__ll2float_rn(static_cast<long long>(v)), -s);
 }
 
-// ---- pass 4: persistent workgroups, one plane tile at a time.
-__global__ __launch_bounds__(kBinAccThreads, 8) void bin_accumulate_kernel(Params P, BinArgs A) {
-    extern __shared__ __align__(16) unsigned long long acc[];             // [17][17][32]
-    __shared__ int s_next;
-    const gnerf_render_params& p = P.p;
-    const int tid = threadIdx.x, ch = tid & 31, hw = tid >> 5;
-    constexpr int kHalfWaves = kBinAccThreads / 32, kCells = kBinHalo * kBinHalo * 32;
-    const int H = p.plane_h, W = p.plane_w;
+// A batch of kBinBatch records through the scalar cache: four (row, cell) pairs and four weight quadruples are wave-uniform, so they
+// live in SGPRs and cost no vector instruction.  hipcc knows nothing of loads inside an asm statement: the values may only be used
+// behind bin_smem_wait, which names them as in/out operands.
+typedef unsigned u8v __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ u8v bin_sload_rc(const BinRowCell* p) { u8v v; asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory"); return v; }
+__device__ __forceinline__ f16v bin_sload_wt(const BinWeights* p) { f16v v; asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory"); return v; }
+__device__ __forceinline__ void bin_smem_wait(u8v& a, f16v& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b) :: "memory"); }
+
+// ---- pass 4: persistent workgroups, one plane tile at a time.  (Its own small argument block: with the render kernels' Params in
+// scalar registers next to the 56 of the record pipeline the compiler spilled a hundred of them to vector lanes.)
+struct BinAccArgs {
+    const float* stage; float* grad_planes; float* halo;
+    const int* count; const int* start; const int* scale; const unsigned* bound; const int* order; int* pull;
+    const BinRowCell* rc; const BinWeights* wt;
+    int n_ptiles, tiles_x, tiles_per_plane, H, W;
+    unsigned row_pitch, tex_pitch, plane_pitch;
+};
+
+// One record's two taps of this lane's footprint row, in fixed point.  d0 / d1: the lane's dX value for lanes of half 0 / half 1 and
+// zero for the other half, so that a0 d0 + a2 d1 is EXACTLY the product with this half's weight (one term is an exact zero) -- the
+// weights sit in scalar registers, and a per-half select between two of them costs two moves and a select per weight.
+__device__ __forceinline__ void bin_add_fixed(unsigned long long* acc, int at, float a0, float a1, float a2, float a3, float d0, float d1) {
+    __hip_atomic_fetch_add(acc + at, bin_to_fixed(__fmaf_rn(a0, d0, __fmul_rn(a2, d1))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(acc + at + 32, bin_to_fixed(__fmaf_rn(a1, d0, __fmul_rn(a3, d1))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ __launch_bounds__(kBinAccThreads, 8) void bin_accumulate_kernel(BinAccArgs A) {
+    extern __shared__ __align__(16) unsigned long long acc[];             // [17][17][32], then one word: the tile this round works on
+    // (all LDS of the kernel is dynamic: a static object on top of it would push the raised 160 KB limit over the hardware's)
+    int& s_next = *reinterpret_cast<int*>(acc + kBinHalo * kBinHalo * 32);
+    const int tid = threadIdx.x, lane = tid & 63, ch = lane & 31, half = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int kCells = kBinHalo * kBinHalo * 32;
+    const int H = A.H, W = A.W;
+    const int lane_cell = half * kBinHalo * 32 + ch;                       // half h adds the two taps of footprint row h
+    const float m0 = half ? 0.f : 1.f, m1 = half ? 1.f : 0.f;
     for (;;) {
-        if (tid == 0) s_next = atomicAdd(A.order + A.n_ptiles, 1);
+        if (tid == 0) s_next = atomicAdd(A.pull, 1);
         __syncthreads();
-        const int q = s_next;
+        const int q = __builtin_amdgcn_readfirstlane(s_next);
         if (q >= A.n_ptiles) break;
-        const int t = A.order[q];
-        const int start = A.count[t], n = A.count[t + 1] - start;
+        const int t = __builtin_amdgcn_readfirstlane(A.order[q]);
+        const int n = __builtin_amdgcn_readfirstlane(A.count[t]);
         if (n == 0) { __syncthreads(); continue; }                        // empty tile: nothing to add, its halo is never read (bin_halo checks the count)
         for (int i = tid; i < kCells; i += kBinAccThreads) acc[i] = 0;
-        const unsigned bbits = A.bound[t];
-        const bool as_float = bbits >= 0x7f800000u;                       // inf / NaN among the rows: plain fp32 LDS adds (order-dependent, as the values are garbage anyway)
-        int s = 0;
-        if (!as_float && bbits != 0) {
-            int e;
-            (void)frexpf(__uint_as_float(bbits), &e);                     // bound < 2^e
-            const int nbits = n > 1 ? 32 - __clz(n - 1) : 0;              // n <= 2^nbits
-            s = 61 - nbits - e;
-        }
+        const int s = __builtin_amdgcn_readfirstlane(A.scale[t]);
+        const bool as_float = s == kBinFloat;                             // inf / NaN among the rows: plain fp32 LDS adds (order-dependent; the values are garbage anyway)
+        const int s_dx = as_float ? 0 : s - bin_weight_scale(s);          // what the stored weights do not carry (> 0 for bounds below 2^-3 only)
+        const bool any = __builtin_amdgcn_readfirstlane(A.bound[t]) != 0; // (all rows zero: the sums are zero)
+        const int nb = (n + kBinBatch - 1) / kBinBatch;                   // batches; wave w takes w, w + 16, ...
+        const int first = __builtin_amdgcn_readfirstlane(A.start[t]);
+        const BinRowCell* rc0 = A.rc + first;
+        const BinWeights* wt0 = A.wt + first;
         __syncthreads();
-        if (bbits != 0) {                                                 // (all rows zero: the sums are zero)
+        if (any && as_float) {
             float* accf = reinterpret_cast<float*>(acc);
-            const uint4* recs = reinterpret_cast<const uint4*>(A.records + start);
-            // records two ahead, dX one ahead: the row address of record i + 32 is in a register when record i is being added
-            uint4 r0 = hw < n ? recs[hw] : make_uint4(0, 0, 0, 0);
-            uint4 r1 = hw + kHalfWaves < n ? recs[hw + kHalfWaves] : make_uint4(0, 0, 0, 0);
-            float d0 = hw < n ? A.stage[r0.x + ch] : 0.f;
-            for (int i = hw; i < n; i += kHalfWaves) {
-                const uint4 r2 = i + 2 * kHalfWaves < n ? recs[i + 2 * kHalfWaves] : make_uint4(0, 0, 0, 0);
-                const float d1 = i + kHalfWaves < n ? A.stage[r1.x + ch] : 0.f;
-                const unsigned pack = r0.y, valid = pack >> 10;
-                const int lx = int(pack & 31u) - 1, ly = int((pack >> 5) & 31u) - 1;
-                const v4f w = tap_weights(__uint_as_float(r0.z), __uint_as_float(r0.w), valid);
-                const int cell = (ly * kBinHalo + lx) * 32 + ch;
+            for (int i = wv; i < n; i += kBinAccWaves) {
+                const BinRowCell r = rc0[i];
+                const BinWeights w = wt0[i];
+                const float d = (A.stage + r.row)[ch];
+                const int at = int(r.cell) + lane_cell;
+                unsafeAtomicAdd(accf + 2 * at, (half ? w[2] : w[0]) * d);
+                unsafeAtomicAdd(accf + 2 * (at + 32), (half ? w[3] : w[1]) * d);
+            }
+        } else if (any && wv < nb) {
+            auto batch_of = [&](int k) { return min(wv + k * kBinAccWaves, nb - 1) * kBinBatch; };     // (past the end: the last batch again, loaded and not used)
+            // Three stages in flight: (row, cell) of batch k+2 and the weights of batch k+1 on their way through the scalar cache, the
+            // four dX rows of batch k+1 on their way through the vector cache, batch k being added.
+            u8v rcA = bin_sload_rc(rc0 + batch_of(0)), rcB = bin_sload_rc(rc0 + batch_of(1));
+            f16v wA = bin_sload_wt(wt0 + batch_of(0));
+            bin_smem_wait(rcA, wA);
+            asm volatile("" : "+s"(rcB));                                  // (behind the wait above: asm volatile statements keep their order)
+            float dA[kBinBatch], dB[kBinBatch];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    // taps outside the plane have weight zero (and may sit outside the LDS tile: lx = -1): skipped, they add nothing
-                    if (!((valid >> (k & 1)) & (valid >> (2 + (k >> 1))) & 1u)) continue;
-                    const float c = w[k] * d0;
-                    const int at = cell + ((k & 1) + (k >> 1) * kBinHalo) * 32;
-                    if (as_float) unsafeAtomicAdd(accf + 2 * at, c);
-                    else __hip_atomic_fetch_add(acc + at, bin_to_fixed(c, s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int u = 0; u < kBinBatch; u++) dA[u] = (A.stage + rcA[2 * u])[ch];
+            for (int k = 0; wv + k * kBinAccWaves < nb; k++) {
+                u8v rcC = bin_sload_rc(rc0 + batch_of(k + 2));
+                f16v wB = bin_sload_wt(wt0 + batch_of(k + 1));
+#pragma unroll
+                for (int u = 0; u < kBinBatch; u++) dB[u] = (A.stage + rcB[2 * u])[ch];
+#pragma unroll
+                for (int u = 0; u < kBinBatch; u++) {
+                    const float d = ldexpf(dA[u], s_dx);                 // (s_dx = 0 unless the tile's bound is below 2^-3)
+                    // (the four weights as scalars of their own: written `half ? wA[4u+2] : wA[4u]` the select becomes a DYNAMIC index into
+                    //  the 16-register vector, which the compiler lowers to a chain of sixteen compares and selects per weight)
+                    float a0 = wA[4 * u], a1 = wA[4 * u + 1], a2 = wA[4 * u + 2], a3 = wA[4 * u + 3];
+                    asm volatile("" : "+s"(a0), "+s"(a1), "+s"(a2), "+s"(a3));
+                    bin_add_fixed(acc, int(rcA[2 * u + 1]) + lane_cell, a0, a1, a2, a3, d * m0, d * m1);
                 }
-                r0 = r1; r1 = r2; d0 = d1;
+                bin_smem_wait(rcC, wB);                                     // (also retires this batch's LDS adds: one counter)
+                rcA = rcB; rcB = rcC; wA = wB;
+#pragma unroll
+                for (int u = 0; u < kBinBatch; u++) dA[u] = dB[u];
             }
         }
         __syncthreads();
@@ -340,14 +422,14 @@ __global__ __launch_bounds__(kBinAccThreads, 8) void bin_accumulate_kernel(Param
         const int tpp = A.tiles_per_plane, ip = t / tpp, tt = t - ip * tpp;
         const int item = ip / 3, pl = ip - item * 3, ty = tt / A.tiles_x, tx = tt - ty * A.tiles_x;
         float* grad_item = A.grad_planes + int64_t(item) * 3 * H * W * 32;
-        const float* accf = reinterpret_cast<const float*>(acc);
+        const float* accr = reinterpret_cast<const float*>(acc);
         for (int e = tid; e < kBinTile * kBinTile * 32; e += kBinAccThreads) {
             const int c2 = e & 31, lx = (e >> 5) & (kBinTile - 1), ly = e >> 9;
             const int x = tx * kBinTile + lx, y = ty * kBinTile + ly;
             if (x < W && y < H) {
                 const int at = (ly * kBinHalo + lx) * 32 + c2;
-                const float v = as_float ? accf[2 * at] : bin_from_fixed(acc[at], s);
-                float* dst = grad_item + ((unsigned(y) * P.row_pitch + unsigned(x) * P.tex_pitch + unsigned(pl) * P.plane_pitch) >> 2) + c2;
+                const float v = as_float ? accr[2 * at] : bin_from_fixed(acc[at], s);
+                float* dst = grad_item + ((unsigned(y) * A.row_pitch + unsigned(x) * A.tex_pitch + unsigned(pl) * A.plane_pitch) >> 2) + c2;
                 *dst += v;
             }
         }
@@ -356,7 +438,7 @@ __global__ __launch_bounds__(kBinAccThreads, 8) void bin_accumulate_kernel(Param
             const int c2 = e & 31, h = e >> 5;
             const int ly = h < kBinTile ? h : kBinTile, lx = h < kBinTile ? kBinTile : (h < 2 * kBinTile ? h - kBinTile : kBinTile);
             const int at = (ly * kBinHalo + lx) * 32 + c2;
-            A.halo[(int64_t(t) * kBinHaloTexels + h) * 32 + c2] = as_float ? accf[2 * at] : bin_from_fixed(acc[at], s);
+            A.halo[(int64_t(t) * kBinHaloTexels + h) * 32 + c2] = as_float ? accr[2 * at] : bin_from_fixed(acc[at], s);
         }
         // (the barrier at the top of the next round separates these reads from its zero fill)
     }
@@ -375,7 +457,7 @@ __global__ __launch_bounds__(1024) void bin_halo_kernel(Params P, BinArgs A) {
     const int x = tx * kBinTile + lx, y = ty * kBinTile + ly;
     if (x >= W || y >= H) return;
     auto from = [&](int nt, int h) -> float {                               // halo texel h of tile nt, if that tile accumulated anything
-        if (A.count[nt + 1] == A.count[nt]) return 0.f;
+        if (A.count[nt] == 0) return 0.f;
         return A.halo[(int64_t(nt) * kBinHaloTexels + h) * 32 + c2];
     };
     float add = 0.f;
@@ -393,7 +475,7 @@ static int launch_binned_scatter(const Params& P, float* stage, char* ws, float*
     const gnerf_render_params& p = P.p;
     const int n_all = p.depth_resolution + p.depth_resolution_importance;
     BinArgs A = bin_carve(ws, stage, grad_planes, P.total_rays, n_all, p.n_items, p.plane_h, p.plane_w);
-    const size_t head = reinterpret_cast<char*>(A.records) - ws;          // counts, cursors, bounds, order
+    const size_t head = reinterpret_cast<char*>(A.rc) - ws;               // counts, starts, cursors, bounds, scales, order
     if (hipMemsetAsync(ws, 0, head, s) != hipSuccess) return gnerf::fail(GNERF_E_LAUNCH, "render_backward: cannot clear the bin counters");
     const size_t lds_walk = (2 * size_t(3) * A.tiles_per_plane + 16 * 8) * sizeof(float);
     static PerDeviceOnce once_c, once_f, once_a;
@@ -404,7 +486,13 @@ static int launch_binned_scatter(const Params& P, float* stage, char* ws, float*
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, A);
     hipLaunchKernelGGL(bin_walk_kernel<true>, dim3(P.n_tiles), dim3(kBinCountThreads), lds_walk, s, P, A);
     const int acc_blocks = min(A.n_ptiles, 2 * gnerf::kNumCU);
-    hipLaunchKernelGGL(bin_accumulate_kernel, dim3(acc_blocks), dim3(kBinAccThreads), size_t(kBinHalo) * kBinHalo * 32 * 8, s, P, A);
+    BinAccArgs C;
+    C.stage = A.stage; C.grad_planes = A.grad_planes; C.halo = A.halo;
+    C.count = A.count; C.start = A.start; C.scale = A.scale; C.bound = A.bound; C.order = A.order; C.pull = A.order + A.n_ptiles;
+    C.rc = A.rc; C.wt = A.wt;
+    C.n_ptiles = A.n_ptiles; C.tiles_x = A.tiles_x; C.tiles_per_plane = A.tiles_per_plane; C.H = p.plane_h; C.W = p.plane_w;
+    C.row_pitch = P.row_pitch; C.tex_pitch = P.tex_pitch; C.plane_pitch = P.plane_pitch;
+    hipLaunchKernelGGL(bin_accumulate_kernel, dim3(acc_blocks), dim3(kBinAccThreads), size_t(kBinHalo) * kBinHalo * 32 * 8 + 16, s, C);
     hipLaunchKernelGGL(bin_halo_kernel, dim3(A.n_ptiles), dim3(1024), 0, s, P, A);
     return gnerf::check_launch("binned plane scatter");
 }

@@ -93,6 +93,24 @@ def _prenormalised_weight(module, dtype, channels_last=False, transposed=False):
     return hit[1]
 
 
+def _packed_prenormalised_weight(module, dtype):
+    """The pre-normalised weight in the tap-major [9, O, I] form of gnerf_hip.conv3x3_epilogue (csrc/conv3x3.hip), cached like the
+    convolution forms above."""
+    w = module.weight
+    key = (w.data_ptr(), w._version if not w.is_inference() else None, dtype)
+    hit = module.__dict__.get('_gnerf_prenorm_packed')
+    if hit is None or hit[0] != key:
+        import gnerf_hip
+        hit = (key, gnerf_hip.pack_conv3x3_weights(_prenormalised_weight(module, dtype), dtype))
+        module.__dict__['_gnerf_prenorm_packed'] = hit
+    return hit[1]
+
+
+# GNERF_FUSED_CONV=0: the 3x3 layers of the shared-weight form go to MIOpen + gnerf_modconv_epilogue_nhwc (round 4's flow) instead of
+# the one-launch kernel of csrc/conv3x3.hip
+_FUSED_CONV = os.environ.get('GNERF_FUSED_CONV', '1') != '0'
+
+
 def _latent_token(w):
     """What identifies a latent slice `w` (a view of the caller's ws) for caches of values that depend on it and on parameters alone:
     (weak reference to the tensor that owns the memory, its version counter, the view's offset and shape) -- or None when changes
@@ -288,6 +306,11 @@ class StyledConv(nn.Module):
                     nxt_aff = (next_layer.affine.weight, next_layer.affine.bias)
                     nxt = _per_latent(next_layer, next_w, 'nstyles', nxt_aff, lambda: gnerf_hip.normalise_styles(next_layer.affine(next_w)))
                     folded = True
+                if _FUSED_CONV and self.up == 1 and cl and gnerf_hip.conv3x3_epilogue_supported(x, c_out) and (noise is None or noise.numel() == h * wd):
+                    # convolution + demodulation + noise + bias + lrelu + clamp (+ the next layer's input scaling) in one launch
+                    x = gnerf_hip.conv3x3_epilogue(x, _packed_prenormalised_weight(self, x.dtype), _cast_param(self, 'bias', x.dtype), scale=dco, noise=noise,
+                                                   round_noise=True, gain=LRELU_GAIN * gain, clamp=clamp, next_scale=nxt)
+                    return (x, folded) if next_layer is not None else x
                 epi = dict(bias=_cast_param(self, 'bias', x.dtype), scale=dco, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp, next_scale=nxt) if noise is None else None
                 out = self._resampled_conv(x, _prenormalised_weight(self, x.dtype, cl), 1,
                                            weight_t=_prenormalised_weight(self, x.dtype, cl, transposed=True) if self.up == 2 else None, epilogue=epi)

@@ -23,7 +23,7 @@ _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.float64: F64}
 
 MAX_SAMPLES = 256
 DEBUG_SLOTS = 8
-ABI_VERSION = 8
+ABI_VERSION = 9
 # decoder arithmetic of the fused renderer (GNERF_MLP_* in include/gnerf_hip.h)
 MLP_MODES = {'auto': 0, 'f16x3': 1, 'f32': 2}
 
@@ -99,6 +99,7 @@ SIGNATURES = {
     'gnerf_normalise_styles': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_p]),
     'gnerf_scale_channels': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_modconv_epilogue': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p, _c_i, _c_f, _c_f, _c_f, _c_p]),
+    'gnerf_conv3x3_epilogue_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_p, _c_f, _c_f, _c_f, _c_p, _c_p]),
     'gnerf_upsample2x_add_nhwc': (_c_i, [_c_p, _c_p, ctypes.POINTER(_c_f), _c_i, _c_f, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
     'gnerf_scale_channels_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_modconv_epilogue_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p, _c_i, _c_f, _c_f, _c_f, _c_p, _c_p]),
@@ -665,6 +666,48 @@ def modconv_epilogue(x, bias=None, scale=None, noise=None, round_noise=False, ac
     return y
 
 
+def pack_conv3x3_weights(weight, dtype=torch.float16):
+    """[O, I, 3, 3] -> the tap-major [9, O, I] form gnerf_conv3x3_epilogue_nhwc reads (w_packed[ky * 3 + kx, o, c] = weight[o, c, ky, kx])."""
+    o, i = weight.shape[:2]
+    return weight.detach().to(dtype).permute(2, 3, 0, 1).reshape(9, o, i).contiguous()
+
+
+def conv3x3_epilogue_supported(x, c_out):
+    """Does the fused convolution + epilogue kernel take this activation tensor?  (float16, channels_last, 8 x 32 pixel tiles, channels
+    in blocks of 128.)"""
+    return (x.is_cuda and x.dtype == torch.float16 and x.ndim == 4 and is_channels_last(x) and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0
+            and x.shape[1] % 128 == 0 and c_out % 128 == 0 and x.shape[1] * x.shape[2] * x.shape[3] * 2 < (1 << 31))
+
+
+@profiled('gnerf_hip::conv3x3_epilogue')
+def conv3x3_epilogue(x, w_packed, bias=None, scale=None, noise=None, round_noise=False, alpha=0.2, gain=1.0, clamp=None, next_scale=None):
+    """conv2d(x, w, padding=1) followed by modconv_epilogue(act='lrelu') in ONE launch (csrc/conv3x3.hip): x [N,C,H,W] float16
+    channels_last, w_packed = pack_conv3x3_weights(w) [9,O,C] float16; scale / next_scale [N,O] float32, noise float32 [H,W], bias [O].
+    Returns a channels_last [N,O,H,W] float16 tensor.  Shapes outside conv3x3_epilogue_supported raise (GNERF_E_UNSUPPORTED)."""
+    _require_cuda(x, w_packed, bias, scale, noise, next_scale)
+    n, c, h, w = x.shape
+    o = w_packed.shape[1]
+    if not is_channels_last(x) or x.dtype != torch.float16 or tuple(w_packed.shape) != (9, o, c) or w_packed.dtype != torch.float16 or not w_packed.is_contiguous():
+        raise RuntimeError('conv3x3_epilogue: x must be channels_last float16 [N,C,H,W] and w_packed contiguous float16 [9,O,C]')
+    def f32(t, numel, what):
+        if t is None:
+            return None
+        t = t.detach().to(torch.float32).contiguous()
+        if t.numel() != numel:
+            raise RuntimeError(f'conv3x3_epilogue: {what} must have {numel} elements')
+        return t if t.data_ptr() % 16 == 0 else t.clone()
+    s32, nx, nz = f32(scale, n * o, 'scale'), f32(next_scale, n * o, 'next_scale'), f32(noise, h * w, 'noise')
+    b = None if bias is None else bias.detach().to(torch.float16).contiguous()
+    if b is not None and b.numel() != o:
+        raise RuntimeError('conv3x3_epilogue: bias must have O elements')
+    y = torch.empty([n, o, h, w], dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    with _on_device(x.device):
+        code = load().gnerf_conv3x3_epilogue_nhwc(_ptr(x), _ptr(w_packed), _ptr(y), n, h, w, c, o, _ptr(s32), _ptr(nz), 1 if round_noise else 0, _ptr(b),
+                                                  float(alpha), float(gain), float(-1 if clamp is None else clamp), _ptr(nx), _stream(x))
+    _check(code, 'gnerf_conv3x3_epilogue_nhwc')
+    return y
+
+
 @profiled('gnerf_hip::blur_epilogue_channels_last')
 def blur_epilogue_channels_last(x, f, padding, blur_gain=1.0, bias=None, scale=None, act='lrelu', alpha=0.2, gain=1.0, clamp=None, next_scale=None,
                                 flip_filter=False):
@@ -867,7 +910,8 @@ class TorchPhiloxPlan:
     """Where torch's device generator stands before the renderer's two uniform draws (renderer.py:190 rand_like([N,M,S,1]), :241
     rand(N*M, F)) and how ATen would have laid them out on this device -- what gnerf_render_params.rng_* carry (include/gnerf_hip.h,
     oracle/philox_ref.py).  per_item: N separate calls of one item each (the draws of the batched-views form)."""
-    __slots__ = ('seed', 'offset_coarse', 'offset_fine', 'item_stride', 'threads_coarse', 'threads_fine', 'per_item', 'end_offset')
+    __slots__ = ('seed', 'offset_coarse', 'offset_fine', 'item_stride', 'threads_coarse', 'threads_fine', 'per_item', 'end_offset',
+                 'numel_coarse', 'numel_fine', 'generator')
 
 
 _device_geometry = {}
@@ -898,6 +942,8 @@ def torch_philox_plan(device, n_items, rays_per_item, S, F, per_item=False, gene
     units = rays_per_item if per_item else n_items * rays_per_item
     plan.threads_coarse, inc_c = torch_rand_geometry(units * S, device)
     plan.threads_fine, inc_f = torch_rand_geometry(units * F, device) if F > 0 else (0, 0)
+    plan.numel_coarse, plan.numel_fine = units * S, units * F
+    plan.generator = gen
     off = int(gen.get_offset())
     plan.offset_coarse, plan.offset_fine = off, off + inc_c
     plan.item_stride = inc_c + inc_f if per_item else 0
@@ -905,6 +951,12 @@ def torch_philox_plan(device, n_items, rays_per_item, S, F, per_item=False, gene
     if advance:
         gen.set_offset(plan.end_offset)
     return plan
+
+
+def commit_philox_plan(plan):
+    """Move the plan's generator past its two draws (for plans made with advance=False: a caller that wants to know that the launch was
+    accepted before the generator moves)."""
+    plan.generator.set_offset(plan.end_offset)
 
 
 @profiled('gnerf_hip::torch_rand')
@@ -988,9 +1040,24 @@ def _render_params_generated(planes_nhwc, n_items, decoder, ray_origins, ray_dir
     return p, tuple(keep), m
 
 
-def render_generated_supported(S, F, ray_start=0.0, ray_end=1.0, disparity_space_sampling=False):
-    """Do the render kernels make rays / draws themselves for these options?  (48+48 and 96+96 samples, plain stratified sampling.)"""
-    return int(S) == int(F) and int(S) in (48, 96) and not disparity_space_sampling and not isinstance(ray_start, torch.Tensor) and not isinstance(ray_end, torch.Tensor)
+def render_generated_supported(S, F, ray_start=0.0, ray_end=1.0, disparity_space_sampling=False, plan=None, numel_planes=None):
+    """Do the render kernels make rays / draws themselves for these options?  (48+48 and 96+96 samples, plain stratified sampling; the
+    pipelined kernel at its compile-time sample counts, which GNERF_RENDER_KERNEL / GNERF_PIPE_FULL=0 can take away; planes of one item
+    below 4 GB.)  plan: a TorchPhiloxPlan whose generator geometry is checked too -- the kernel reproduces ATen's draw only when its
+    thread count is a power of two or covers the draw (raygen.h: torch_rand_draw), which depends on the device's CU count."""
+    if not (int(S) == int(F) and int(S) in (48, 96) and not disparity_space_sampling and not isinstance(ray_start, torch.Tensor) and not isinstance(ray_end, torch.Tensor)):
+        return False
+    if os.environ.get('GNERF_RENDER_KERNEL', 'pipe') != 'pipe' or os.environ.get('GNERF_PIPE_FULL', '1') == '0':
+        return False
+    if numel_planes is not None and int(numel_planes) * 4 >= (1 << 32):
+        return False
+    if plan is not None:
+        for thr, numel in ((plan.threads_coarse, plan.numel_coarse), (plan.threads_fine, plan.numel_fine)):
+            if numel and not (thr >= numel or (thr > 0 and thr & (thr - 1) == 0)):
+                return False
+        if plan.offset_coarse % 4 or plan.offset_fine % 4 or plan.item_stride % 4:
+            return False
+    return True
 
 
 @profiled('gnerf_hip::render_forward')

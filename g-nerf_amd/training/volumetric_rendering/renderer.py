@@ -380,12 +380,23 @@ class ImportanceRenderer(torch.nn.Module):
                    image_width=side if side * side == M else 0)
         if _INKERNEL_RNG and not differentiable and gnerf_hip.render_generated_supported(S, F, ray_start, ray_end, cfg['disparity_space_sampling']) \
                 and not torch.cuda.is_current_stream_capturing():
-            # the same two draws (per view: the draws of a call of its own), made by the render kernel from the generator's state
-            plan = gnerf_hip.torch_philox_plan(dev, N, M, S, F, per_item=views)
+            # the same two draws (per view: the draws of a call of its own), made by the render kernel from the generator's state.  The
+            # generator moves only once the launch has been accepted: a geometry the kernel does not reproduce (a device whose CU count
+            # makes ATen's grid neither a power of two nor as large as the draw), an environment override of the kernel choice or planes
+            # beyond 4 GB leave it where it was, and the call draws tensors below like any other.
+            plan = gnerf_hip.torch_philox_plan(dev, N, M, S, F, per_item=views, advance=False)
             nhwc, amax = self._planes_nhwc(planes)
-            return gnerf_hip.render_forward(nhwc, N, self._decoder_cache(fcs), ray_origins.detach(), ray_directions.detach(), None, None,
-                                            ray_start=ray_start, ray_end=ray_end, planes_absmax=amax, planes_shared=views, depth_clamp_per_item=views,
-                                            rng=plan, **cfg)
+            if gnerf_hip.render_generated_supported(S, F, ray_start, ray_end, cfg['disparity_space_sampling'], plan=plan, numel_planes=nhwc.numel() // (1 if views else N)):
+                try:
+                    out = gnerf_hip.render_forward(nhwc, N, self._decoder_cache(fcs), ray_origins.detach(), ray_directions.detach(), None, None,
+                                                   ray_start=ray_start, ray_end=ray_end, planes_absmax=amax, planes_shared=views, depth_clamp_per_item=views,
+                                                   rng=plan, **cfg)
+                except RuntimeError as e:
+                    if 'failed (-3)' not in str(e):              # GNERF_E_UNSUPPORTED: the tensor form below; anything else is an error
+                        raise
+                else:
+                    gnerf_hip.commit_philox_plan(plan)
+                    return out
         # the reference's two draws, same shapes, same order (renderer.py:176/186/190 then :241)
         if views:
             draws = [(torch.rand([1, M, S, 1], device=dev, dtype=torch.float32), torch.rand(M, F, device=dev) if F > 0 else None) for _ in range(N)]

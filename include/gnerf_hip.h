@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GNERF_ABI_VERSION 8
+#define GNERF_ABI_VERSION 9
 
 /* error codes */
 #define GNERF_OK            0
@@ -121,6 +121,19 @@ int gnerf_blur4_epilogue_nhwc(const void* x, const float* f, void* y, int dtype,
                               int padx0, int pady0, int flip, float blur_gain,
                               const float* scale, const void* bias, int act, float alpha, float gain, float clamp, const float* next_scale,
                               gnerf_stream_t stream);
+/* (ABI 9) The 3x3 convolution of a modulated-convolution layer AND its epilogue in one launch, for float16 channels_last activations
+ * in the shared-weight form (networks_stylegan2.py:41-98 as called from :315-334; the superresolution's 128 -> 128 @ 512^2 and
+ * 256 -> 256 @ 256^2 layers, superresolution.py:285-303):
+ *   y[n, p, o] = epilogue( half( sum_{ky,kx,c} w[o, c, ky, kx] * x[n, p + (ky - 1, kx - 1), c] ) )      zero padding, stride 1
+ * with the epilogue of gnerf_modconv_epilogue_nhwc (act = lrelu; the convolution's fp32 accumulator is rounded to float16 first, as
+ * a stand-alone convolution would have stored it, so the roundings match that function applied to the convolution's output).
+ * x: [n, h, w, cin] float16; w_packed: [9, cout, cin] float16, tap-major (tap = ky * 3 + kx of the correlation form torch's conv2d
+ * computes: w_packed[t, o, c] = weight[o, c, t / 3, t % 3]); y: [n, h, w, cout] float16; scale / next_scale: float32 [n, cout] or
+ * NULL; noise: float32 [h * w] or NULL; bias: float16 [cout] or NULL; clamp < 0: none.  All 16-byte aligned.
+ * GNERF_E_UNSUPPORTED unless h % 8 == 0, w % 32 == 0, cin % 128 == 0, cout % 128 == 0 (the caller runs the two-launch form). */
+int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, void* y, int n, int h, int w, int cin, int cout,
+                                const float* scale, const float* noise, int round_noise, const void* bias,
+                                float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream);
 /* ToRGBLayer with three output channels on a channels_last float16 tensor (networks_stylegan2.py:349-367, modulation as in the
  * fused form :89-96): y[n, o, p] = clamp(half(sum_c x[n, p, c] * half(weight[o, c] * styles[n, c])) + bias[o]), products exact, fp32
  * accumulation.  x: float16 [n, pixels, channels] (channels 32, 64, 128, 256 or 512, 16-byte aligned); weight float32 [3, channels];

@@ -1712,6 +1712,50 @@ def test_modconv_kernels_vs_composed_ops(dev, dtype):
         gnerf_hip.modconv_epilogue(x, b, act='relu')
 
 
+def test_conv3x3_epilogue_vs_composed_ops(dev):
+    """csrc/conv3x3.hip -- the 3x3 convolution of a modulated-convolution layer and its epilogue in one launch (SURVEY 8(f)3;
+    networks_stylegan2.py:41-98 as SynthesisLayer.forward calls it, :315-334) -- against the two launches it replaces: torch's
+    conv2d on the same fp16 channels_last tensors followed by gnerf_hip.modconv_epilogue, for every combination of demodulation scale,
+    noise and next-layer scale; tiles at every image border (zero padding), two channel chunks, two output-channel groups.  Both are
+    fp16 results of an fp32-accumulated convolution: they may differ by the rounding of a sum taken in another order (one fp16 ulp on
+    few elements), and each is held to an fp32 evaluation of the whole chain."""
+    import gnerf_hip
+    from torch_utils.ops import bias_act
+    gen = torch.Generator().manual_seed(2)
+    for (n, cin, cout, h, w) in [(2, 128, 128, 16, 64), (1, 256, 128, 8, 32), (3, 128, 256, 24, 32)]:
+        x = (torch.randn(n, cin, h, w, generator=gen) * 0.7).to(dev).half().contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn(cout, cin, 3, 3, generator=gen) / (3 * cin ** 0.5)).to(dev)
+        w16 = wt.half().contiguous(memory_format=torch.channels_last)
+        wpk = gnerf_hip.pack_conv3x3_weights(wt)
+        assert wpk.shape == (9, cout, cin) and torch.equal(wpk[5], wt.half()[:, :, 1, 2])
+        assert gnerf_hip.conv3x3_epilogue_supported(x, cout)
+        sc, nx = (torch.rand(n, cout, generator=gen) + 0.5).to(dev), (torch.rand(n, cout, generator=gen) + 0.5).to(dev)
+        bias = (torch.randn(cout, generator=gen) * 0.2).to(dev)
+        noise = (torch.randn(h, w, generator=gen) * 0.1).to(dev)
+        y32 = torch.nn.functional.conv2d(x.float(), w16.float(), padding=1)
+        for scale in (None, sc):
+            for nz in (None, noise):
+                for nxt in (None, nx):
+                    for clamp in (None, 0.75):
+                        kw = dict(scale=scale, noise=nz, round_noise=True, gain=1.3, clamp=clamp, next_scale=nxt)
+                        got = gnerf_hip.conv3x3_epilogue(x, wpk, bias, **kw)
+                        assert got.shape == (n, cout, h, w) and got.dtype == torch.float16 and gnerf_hip.is_channels_last(got)
+                        want = gnerf_hip.modconv_epilogue(torch.nn.functional.conv2d(x, w16, padding=1), bias, act='lrelu', **kw)
+                        # the chain in fp32 on the same fp16 operands
+                        t = y32 * (scale[:, :, None, None] if scale is not None else 1.0) + (nz if nz is not None else 0.0)
+                        ref = bias_act.bias_act(t, bias, act='lrelu', gain=1.3, clamp=clamp) * (nxt[:, :, None, None] if nxt is not None else 1.0)
+                        top = float(ref.abs().max())
+                        e_got, e_want = float((got.float() - ref).abs().max()), float((want.float() - ref).abs().max())
+                        assert e_got <= max(1.5 * e_want, 4e-3 * top), (n, cin, cout, scale is not None, nz is not None, nxt is not None, clamp, e_got, e_want, top)
+                        diff = (got.float() - want.float()).abs()
+                        assert float(diff.max()) <= 6e-3 * top and float((diff > 2e-3 * top).float().mean()) < 1e-3
+    # shapes the kernel does not tile are refused, not approximated
+    bad = torch.zeros(1, 64, 8, 32, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    assert not gnerf_hip.conv3x3_epilogue_supported(bad, 128)
+    with pytest.raises(RuntimeError):
+        gnerf_hip.conv3x3_epilogue(bad, torch.zeros(9, 128, 64, device=dev, dtype=torch.float16))
+
+
 def test_generator_fast_modconv_path_equals_plain_path(dev, monkeypatch):
     """The generator with csrc/modconv.hip around its convolutions (and the shared-weight convolution form for fp16 batches)
     against the same generator on the plain PyTorch-op chains: batch 1 (grouped form) and batch 3 (shared-weight form)."""

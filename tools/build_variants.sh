@@ -16,7 +16,7 @@ for v in "$@"; do
   IFS='+' read -ra parts <<< "$v"
   for p in "${parts[@]}"; do if [ "$p" = STAMPS ]; then defs="$defs -DGNERF_STAMPS"; elif [ "${p#D:}" != "$p" ]; then defs="$defs -D${p#D:}"; elif [ "$p" != base ]; then defs="$defs -DGNERF_ABLATE_$p"; fi; done
   ( compile_unit render "$out/render_$v.o" "$defs" > /dev/null
-    $HIPCC -shared -fPIC --offload-arch=gfx950 "$here"/{capi,bias_act,upfirdn2d,filtered_lrelu,filtered_lrelu_fused,grid_sample,planes,modconv}.o "$out/render_$v.o" -o "$out/libgnerf_$v.so"
+    $HIPCC -shared -fPIC --offload-arch=gfx950 "$here"/{capi,bias_act,upfirdn2d,filtered_lrelu,filtered_lrelu_fused,grid_sample,planes,modconv,conv3x3}.o "$out/render_$v.o" -o "$out/libgnerf_$v.so"
     python3 "$root/tools/kernel_resources.py" "$out/render_$v.o" > "$out/resources_$v.txt" 2>/dev/null || true
     rm -f "$out/render_$v.o"; echo "[variant] $v" ) &
 done
