@@ -69,6 +69,7 @@ SIGNATURES = {
     'gnerf_abi_version': (_c_i, []),
     'gnerf_last_error': (ctypes.c_char_p, []),
     'gnerf_build_info': (ctypes.c_char_p, []),
+    'gnerf_clock_sample': (_c_i, [_c_p, ctypes.c_double, _c_p]),
     'gnerf_bias_act': (_c_i, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i64, _c_i, _c_i64, _c_i, _c_i, _c_f, _c_f, _c_f, _c_p]),
     'gnerf_upfirdn2d': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, ctypes.POINTER(_c_i64), _c_i, _c_i, ctypes.POINTER(_c_i64),
                                _c_i, _c_i, ctypes.POINTER(_c_i64), _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_p]),
@@ -664,6 +665,21 @@ def modconv_epilogue(x, bias=None, scale=None, noise=None, round_noise=False, ac
                                                  float(-1 if clamp is None else clamp), _stream(x))
     _check(code, 'gnerf_modconv_epilogue')
     return y
+
+
+def clock_under_load(run, microseconds=3000.0, device=None):
+    """MHz the shader clock holds while `run()` (which enqueues work on the current stream for at least `microseconds`) executes: a
+    one-wave sampler on a side stream (gnerf_clock_sample) reads the shader-cycle counter against the 100 MHz reference meanwhile."""
+    dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+    out = torch.zeros(2, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    run()                                                   # the load is already running when the sampler starts (it does not wait for it)
+    with _on_device(dev):
+        _check(load().gnerf_clock_sample(out.data_ptr(), float(microseconds), ctypes.c_void_p(side.cuda_stream)), 'gnerf_clock_sample')
+    run()
+    torch.cuda.synchronize(dev)
+    cyc, ticks = [int(v) for v in out.tolist()]
+    return 100.0 * cyc / ticks if ticks else None
 
 
 def pack_conv3x3_weights(weight, dtype=torch.float16):

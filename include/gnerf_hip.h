@@ -53,6 +53,10 @@ typedef void* gnerf_stream_t;   /* hipStream_t */
 
 int         gnerf_abi_version(void);
 const char* gnerf_last_error(void);          /* thread-local, host pointer */
+/* (ABI 9) Measurement aid: one wave samples the shader-cycle counter against the 100 MHz reference counter for `microseconds` and writes
+ * out[0] = shader cycles, out[1] = reference ticks (device memory, 16 bytes): clock = out[0] / out[1] x 100 MHz.  Launch it on a side
+ * stream while the kernels of interest run: the chip's clock under THAT load (bench.py's roofline quotes it). */
+int gnerf_clock_sample(unsigned long long* out, double microseconds, gnerf_stream_t stream);
 const char* gnerf_build_info(void);          /* e.g. "gfx950 hipcc ..." , host pointer */
 
 /* ------------------------------------------------------------------------------------------
