@@ -174,9 +174,20 @@ def latest_pmc():
     try:
         named = [(re.fullmatch(r'r(\d+)_final(\d*)_pmc\.json', f), f) for f in os.listdir(pdir)]
         latest = sorted((int(m.group(1)), int(m.group(2) or 0), f) for m, f in named if m)[-1][2]
-        return json.load(open(os.path.join(pdir, latest)))['counters_mean_per_launch'], 'profiles/' + latest
+        doc = json.load(open(os.path.join(pdir, latest)))
+        # profile_head: the commit the counters were collected on (tools/prof_collect.py records it), so that a reader can see when a
+        # quoted counter is older than the kernel this run timed
+        return doc['counters_mean_per_launch'], f"profiles/{latest} (collected at {doc.get('head', 'an unrecorded commit')})"
     except Exception:
         return None, None
+
+
+def build_head():
+    """The commit the running library was built from (g-nerf_amd/gnerf_hip/BUILD_HEAD, written by csrc/build.sh), or None."""
+    try:
+        return open(os.path.join(ROOT, 'g-nerf_amd', 'gnerf_hip', 'BUILD_HEAD')).read().strip() or None
+    except OSError:
+        return None
 
 
 def hbm_bytes_per_call(n_items, rays, s, f, plane):
@@ -502,17 +513,30 @@ def backward_times(dev, planes_cl, dec, c2w, intr, reps=5):
     try:
         pdir = os.path.join(ROOT, 'profiles')
         name = sorted(f for f in os.listdir(pdir) if f.endswith('_backward_profile.json'))[-1]
-        prof = json.load(open(os.path.join(pdir, name)))['staged']
-        p2 = prof['plane_scatter_kernel']
+        doc = json.load(open(os.path.join(pdir, name)))
+        prof = doc['staged']
         k1 = next((v for k, v in prof.items() if k.startswith('render_kernel_pipe_bwd')), None)
         k2 = prof.get('render_bwd_tiles_kernel')
         p1_ms = (k1['avg_ms'] + k2['avg_ms']) if (k1 and k2) else prof['render_bwd_kernel<true>']['avg_ms']
-        passes = {'source': f'profiles/{name} (rocprofv3 --kernel-trace --stats and --pmc TCC_EA0_ATOMIC_sum of tools/bench_bwd.py 4 128)',
+        bins = {k: v['avg_ms'] * (v.get('calls_per_launch', 1)) for k, v in prof.items() if k.startswith('bin_')}
+        passes = {'source': f'profiles/{name} (rocprofv3 --kernel-trace --stats and --pmc TCC_EA0_ATOMIC_sum of tools/bench_bwd.py 4 128; collected at {doc.get("head", "an unrecorded commit")})',
                   'pass1_ms': p1_ms, 'pass1_ray_level_kernel_ms': k1 and k1['avg_ms'], 'pass1_tile_kernel_ms': k2 and k2['avg_ms'],
-                  'pass2_plane_scatter_kernel_ms': p2['avg_ms'],
-                  'pass1_fp32_mfma_frac': flops / (p1_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                  'pass2_atomic_requests': p2['TCC_EA0_ATOMIC_sum'],
-                  'pass2_atomic_frac': p2['TCC_EA0_ATOMIC_sum'] * 64 / (p2['avg_ms'] * 1e-3) / 1e9 / PEAK_ATOMIC_GBS}
+                  'pass1_fp32_mfma_frac': flops / (p1_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+        if bins:                # round 5: the binned scatter (csrc/scatter_binned.inl): no global float atomics
+            p2_ms = sum(bins.values())
+            rows_bytes = samples * 3 * 128 + samples * 3 * 24 + 3 * 32 * 4 * N_ITEMS * PLANE * PLANE * 2       # dX rows read per (sample, plane) + 24-byte records + the gradient read and written
+            passes.update({'pass2_binned_scatter_ms': p2_ms, 'pass2_kernels_ms': bins,
+                           'pass2_hbm': {'algorithmic_bytes': rows_bytes, 'GBs': rows_bytes / (p2_ms * 1e-3) / 1e9, 'frac_of_8TBs': rows_bytes / (p2_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                         'note': 'every dX row is read once per plane it contributes to (3 x 128 B per sample) next to its 24-byte record; the '
+                                                 'sums are formed in LDS in 64-bit fixed point (ds_add_u64) and leave as plain stores'}})
+            srt = doc.get('sorted', {}).get('plane_scatter_kernel')
+            if srt:
+                passes['pass2_sorted_form_ms'] = srt['avg_ms']
+                passes['pass2_sorted_form_atomic_requests'] = srt.get('TCC_EA0_ATOMIC_sum')
+        else:
+            p2 = prof['plane_scatter_kernel']
+            passes.update({'pass2_plane_scatter_kernel_ms': p2['avg_ms'], 'pass2_atomic_requests': p2['TCC_EA0_ATOMIC_sum'],
+                           'pass2_atomic_frac': p2['TCC_EA0_ATOMIC_sum'] * 64 / (p2['avg_ms'] * 1e-3) / 1e9 / PEAK_ATOMIC_GBS})
     except Exception:
         pass
     out = {'workload': 'gnerf_render_backward at config 2 (4 x 128^2 rays, 48+48 samples), planes in the producer layout',
@@ -830,6 +854,15 @@ def main():
     long_elapsed = sorted(timed_region(nchw_input=headline_nchw, n_steps=n_long)[0] for _ in range(3))[1]
     # the other plane layout, and the render call with each shipped decoder arithmetic forced
     other = sorted(timed_region(nchw_input=not headline_nchw) for _ in range(5))[2]
+    # the shader clock while the bench step runs (a one-wave sampler on a side stream: gnerf_clock_sample): the roofline's peak is
+    # cycles per second, and the chip holds well under the data sheet's 2.4 GHz under this kernel's load
+    clock_mhz = None
+    if rank == 0:
+        try:
+            clock_mhz = gnerf_hip.clock_under_load(lambda: [step(None, 'auto', headline_nchw) for _ in range(8)], microseconds=3000.0, device=dev)
+        except Exception as e:
+            clock_mhz = None
+            progress(f'clock sample failed: {type(e).__name__}: {e}')
     progress('headline regions done; in-kernel rays / draws, forced arithmetics')
     # With several ranks the side measurements below (nothing in them scales: they describe the kernel) run on rank 0 ALONE, without
     # collectives, while the others go on to the orbit and wait at its first barrier: eight copies of them -- and eight concurrent
@@ -898,6 +931,12 @@ def main():
             traffic = json.load(open(tpath)).get('render_kernel_hbm_bytes_per_launch')
         pmc, pmc_source = latest_pmc()
         roof = roofline(kernel_ms_by_mlp['auto'], rays_per_call, S_COARSE, S_FINE, PLANE, N_ITEMS, pmc, pmc_source, traffic)     # the kernel the headline runs
+        roof['clock'] = {'mhz_while_the_step_runs': clock_mhz, 'mhz_the_peak_is_priced_at': CLOCK_HZ / 1e6,
+                         'frac_at_the_measured_clock': roof['frac'] * (CLOCK_HZ / 1e6) / clock_mhz if clock_mhz else None,
+                         'note': 'gnerf_clock_sample: one wave on a side stream reads s_memtime against the 100 MHz s_memrealtime for 3 ms of steps.  `frac` stays '
+                                 'priced at 2.4 GHz; at the clock the chip actually holds under this load the same kernel covers that much more of the '
+                                 'cycles it is given (profiles/r05_stamps.txt: 1.94-2.00 GHz inside the render kernel itself)'}
+        roof['build_head'] = build_head()
         roof['render_call_ms'] = kernel_ms_by_mlp
         roof['render_call_ms_note'] = ('HIP events around the render call of every 5th step inside the timed regions: auto = what the headline runs (every '
                                        'workgroup evaluates the range bounds itself and runs the f16x3 body here; `frac` is computed on it), f16x3 / f32 = '

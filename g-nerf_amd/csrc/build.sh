@@ -32,6 +32,10 @@ for pid in "${pids[@]}"; do
 done
 $HIPCC -shared -fPIC --offload-arch=gfx950 "${objs[@]}" -o "$out"
 echo "[build] $out"
+# which commit this library was built from (profiles and bench lines quote it; the GPU box has no .git)
+if git -C "$root" rev-parse --short HEAD > /dev/null 2>&1; then
+    echo "$(git -C "$root" rev-parse --short HEAD)$(git -C "$root" diff --quiet HEAD -- g-nerf_amd include 2> /dev/null || echo '+local changes')" > "$here/../gnerf_hip/BUILD_HEAD"
+fi
 
 # ---- the thin PyTorch-ROCm C++ extension over the same C ABI (host code only: g++, no device code)
 ext="$here/../gnerf_hip/gnerf_torch_ext.so"

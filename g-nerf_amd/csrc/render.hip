@@ -900,7 +900,9 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
     if ((pipe || coop) && mlp == GNERF_MLP_AUTO) {
         // the choice is made on the device, by every workgroup for itself (no host round trip, graph-capturable): see choose_mlp
         P.absmax = p->planes_absmax;
-        if (P.absmax && getenv("GNERF_VERIFY_ABSMAX") && !strcmp(getenv("GNERF_VERIFY_ABSMAX"), "1")) {
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &capturing);                   // (the check synchronises the stream: not inside a graph capture)
+        if (P.absmax && capturing == hipStreamCaptureStatusNone && getenv("GNERF_VERIFY_ABSMAX") && !strcmp(getenv("GNERF_VERIFY_ABSMAX"), "1")) {
             // debug aid (include/gnerf_hip.h, planes_absmax contract): is the caller's value an upper bound of THESE planes?
             float* own = reinterpret_cast<float*>(static_cast<int*>(p->workspace) + 5);
             if (int e = gnerf_planes_absmax(p->planes_nhwc, int64_t(p->planes_shared ? 1 : p->n_items) * 3 * p->plane_h * p->plane_w * 32, own, stream)) return e;

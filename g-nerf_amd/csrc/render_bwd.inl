@@ -440,8 +440,11 @@ __device__ __forceinline__ void bwd_reduce_decoder_grads(const BwdAcc& A, float*
 
 // STAGED: the plane gradient leaves through the staging buffer (`stage` != NULL, a plane gradient is requested): no tap records are
 // kept and no scatter code is compiled in.
+#ifndef GNERF_BWD_WAVE_OCC
+#define GNERF_BWD_WAVE_OCC 2        // waves per SIMD the one-wave-per-ray kernel is compiled for (1: up to 512 registers, no spills)
+#endif
 template <bool STAGED>
-__global__ __launch_bounds__(kBwdThreads, 2) void render_bwd_kernel(Params P, gnerf_render_grads Gr, float* stage) {
+__global__ __launch_bounds__(kBwdThreads, GNERF_BWD_WAVE_OCC) void render_bwd_kernel(Params P, gnerf_render_grads Gr, float* stage) {
     extern __shared__ __align__(16) float smem[];
     const gnerf_render_params& p = P.p;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;

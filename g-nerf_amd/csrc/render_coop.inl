@@ -387,10 +387,15 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     const float* const rec1 = taps + (8 + b) * kFwdTapStride;
     auto bc = [](float w) { return (v4f){w, w, w, w}; };
     auto load4 = [&](v4f (&t)[4], uint4 o) {
+#ifdef GNERF_ABLATE_GATHER      // timing-only build: no texel loads (outputs are wrong): what a perfect load latency could return
+        t[0] = (v4f){float(o.x + cq16), 1.f, 2.f, 3.f}; t[1] = (v4f){float(o.y), 1.f, 2.f, 3.f};
+        t[2] = (v4f){float(o.z), 1.f, 2.f, 3.f};        t[3] = (v4f){float(o.w), 1.f, 2.f, 3.f};
+#else
         t[0] = *reinterpret_cast<const v4f*>(R.planes_item + (o.x + cq16));
         t[1] = *reinterpret_cast<const v4f*>(R.planes_item + (o.y + cq16));
         t[2] = *reinterpret_cast<const v4f*>(R.planes_item + (o.z + cq16));
         t[3] = *reinterpret_cast<const v4f*>(R.planes_item + (o.w + cq16));
+#endif
     };
     v4f win[3][4], w0[3];
 #pragma unroll

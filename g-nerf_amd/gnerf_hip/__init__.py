@@ -689,10 +689,10 @@ def pack_conv3x3_weights(weight, dtype=torch.float16):
 
 
 def conv3x3_epilogue_supported(x, c_out):
-    """Does the fused convolution + epilogue kernel take this activation tensor?  (float16, channels_last, 8 x 32 pixel tiles, channels
-    in blocks of 128.)"""
+    """Does the fused convolution + epilogue kernel take this activation tensor?  (float16, channels_last, 8 x 32 pixel tiles, input channels
+    in blocks of 64, output channels in blocks of 128.)"""
     return (x.is_cuda and x.dtype == torch.float16 and x.ndim == 4 and is_channels_last(x) and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0
-            and x.shape[1] % 128 == 0 and c_out % 128 == 0 and x.shape[1] * x.shape[2] * x.shape[3] * 2 < (1 << 31))
+            and x.shape[1] % 64 == 0 and c_out % 128 == 0 and x.shape[1] * x.shape[2] * x.shape[3] * 2 < (1 << 31))
 
 
 @profiled('gnerf_hip::conv3x3_epilogue')

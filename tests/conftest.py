@@ -32,3 +32,15 @@ def has_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+@pytest.fixture(autouse=True)
+def _verify_planes_absmax(request, monkeypatch):
+    """Every GPU test runs with GNERF_VERIFY_ABSMAX=1: gnerf_render_forward then measures max |planes| itself and refuses a caller-supplied
+    planes_absmax that is too small (include/gnerf_hip.h: an under-stated value would let the f16 decoder body and its short softplus run
+    outside the range their bounds were checked for -- silently).  So every route by which the suite hands planes to the renderer -- the
+    repack, the plane producer, the renderer class's cached measurement, tensors passed by hand -- is held to the contract on every call.
+    (Off in production: it costs a pass over the planes and a host round trip.  Not applied inside HIP-graph captures.)"""
+    if request.node.get_closest_marker('gpu') is not None:
+        monkeypatch.setenv('GNERF_VERIFY_ABSMAX', '1')
+    yield

@@ -169,8 +169,10 @@ int main(int argc, char** argv) {
                    kFormName[f], kPartnerName[p], o.wrong[0], o.wrong[1], o.wrong[2], o.wrong[3], o.wrong_zero[0], o.wrong_zero[1], o.wrong_zero[2], o.wrong_zero[3],
                    o.wrong_hi_half, total, o.simd_pairs_shared, blocks * 4);
             for (unsigned k = 0; k < (o.n_samples < 6 ? o.n_samples : 6); k++)
-                printf("    lane %2.0f: got %.9g, want %.9g; src0.lo %.9g, src1.lo %.9g, src1.hi %.9g -> the instruction multiplied / added %.9g\n", o.sample[k][0], o.sample[k][1],
-                       o.sample[k][2], o.sample[k][3], o.sample[k][4], o.sample[k][5], (f == 5) ? o.sample[k][1] - o.sample[k][3] : o.sample[k][1] / o.sample[k][3]);
+                printf("    lane %2.0f: got %.9g, want %.9g; src0.lo %.9g, src1.lo %.9g, src1.hi %.9g -> the factor / addend the instruction used in place of src1.hi: %.9g\n", o.sample[k][0], o.sample[k][1],
+                       o.sample[k][2], o.sample[k][3], o.sample[k][4], o.sample[k][5], (f == 5) ? o.sample[k][1] - o.sample[k][3]                                            // v_pk_add: got - src0.lo
+                       : (f == 3 || f == 4) ? (o.sample[k][1] - 0.1f * o.sample[k][3]) / o.sample[k][3]      // v_pk_fma: src2.lo = 0.125 s = 0.1 * src0.lo is the addend
+                       : o.sample[k][1] / o.sample[k][3]);
             if (js) {
                 fprintf(js, "%s {\"form\": \"%s\", \"partner\": \"%s\", \"wrong_low_by_lane_quarter\": [%u, %u, %u, %u], \"of_which_zero\": [%u, %u, %u, %u], \"wrong_high\": %u, "
                             "\"lane_results\": %.0f, \"checker_waves_sharing_partner_simd\": %u, \"checker_waves\": %d}",

@@ -38,12 +38,16 @@ for name in ('sq1', 'sq2', 'tcc', 'fetch', 'write'):
         vals = [v for (v,) in c.execute("select sum(value) from counters_collection where kernel_name like '%nchw_to_nhwc%' "
                                          "and counter_name = 'FETCH_SIZE' group by dispatch_id")]
         repack_fetch = sum(vals) / len(vals) if vals else None
-json.dump({'kernel': KERNEL, 'workload': 'bench.py config 2 (65536 rays x 96 samples per launch)', 'counters_mean_per_launch': counters},
+try:
+    head = open(os.path.join(root, 'g-nerf_amd', 'gnerf_hip', 'BUILD_HEAD')).read().strip()
+except OSError:
+    head = None
+json.dump({'kernel': KERNEL, 'workload': 'bench.py config 2 (65536 rays x 96 samples per launch)', 'head': head, 'counters_mean_per_launch': counters},
           open(os.path.join(prof, f'{tag}_pmc.json'), 'w'), indent=1)
 if 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
     json.dump({'render_kernel_hbm_bytes_per_launch': int(counters['FETCH_SIZE'] * 1024 * 2 + counters['WRITE_SIZE'] * 1024),
                'fetch_size_raw_KB': counters['FETCH_SIZE'], 'write_size_raw_KB': counters['WRITE_SIZE'],
-               'repack_kernel_fetch_size_raw_KB': repack_fetch,
+               'repack_kernel_fetch_size_raw_KB': repack_fetch, 'head': head,
                'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = FETCH_SIZE*1024*2 (gfx950 reports half '
                        'the bytes of 16-B/lane loads; calibrated on nchw_to_nhwc_kernel in the same run, which reads 100.66 MB) + WRITE_SIZE*1024'},
               open(os.path.join(prof, 'traffic.json'), 'w'), indent=1)
