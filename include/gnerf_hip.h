@@ -396,10 +396,17 @@ typedef struct gnerf_render_grads {
     float* grad_b1;             /* [64] */
     float* grad_w2;             /* [33,64] */
     float* grad_b2;             /* [33] */
-    /* Optional workspace of gnerf_render_backward_stage_bytes(p) bytes (contents irrelevant before and after the call).  With it
-       the plane gradient is made in two passes: the backward kernel writes every sample's feature gradient in its ray's depth
-       order, and a second kernel aggregates each 4x4-ray tile's contributions per texel in LDS before they reach memory --
-       3-4x fewer float atomics, which is what bounds the single-pass form.  NULL: single pass (one atomic per tap and channel). */
+    /* Optional workspace (contents irrelevant before and after the call; 256-byte aligned).  The struct carries no size field: what the
+       buffer must hold follows from the request, and the call trusts that it was sized by the matching function for the SAME params:
+         * with grad_planes_nhwc: gnerf_render_backward_stage_bytes(p) bytes; the plane gradient is made in two passes.  Layout: [rays * (S + F)] rows of 33
+           floats (32 feature gradients in the ray's depth order + one spare), one spare 256-byte line, then (ABI 9) the binned
+           scatter's workspace: per-plane-tile counts / starts / scales / order, the record arrays (8 + 16 bytes per (sample, plane)
+           record) and the tile halos.  The second pass sums every 16 x 16-texel plane tile in LDS in 64-bit fixed point and writes it
+           with plain stores -- no float atomics, bit-identical gradients from run to run (GNERF_BWD_SCATTER=sorted selects round 4's
+           LDS-merged atomic pass instead, which uses only the rows);
+         * without grad_planes_nhwc (decoder gradients only): gnerf_render_backward_exchange_bytes(p) bytes suffice (below): per sample
+           depth, colour weight, dL/dsigma.
+       NULL: single pass (one float atomic per tap and channel). */
     float* scatter_stage;
 } gnerf_render_grads;
 
