@@ -3,10 +3,10 @@
 #   bash tools/collect_round.sh a [tag]   rocprofv3 kernel stats + PMC passes of the bench command, the bench line itself, the backward profile
 #   bash tools/collect_round.sh b         per-op GB/s, backward times, training step, generator (configs 3 / 4), shapes, orbit, host overhead
 #   bash tools/collect_round.sh c         generator kernel statistics (fast and reference flows), layer / layout micro-benchmarks
-# Results land in gpurun_out/profiles/ and gpurun_out/$RND/ (copied into profiles/ afterwards).  RND defaults to r04.
+# Results land in gpurun_out/profiles/ and gpurun_out/$RND/ (copied into profiles/ afterwards).  RND defaults to r05.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
-export RND=${RND:-r04}
+export RND=${RND:-r05}
 part=${1:-a}
 mkdir -p gpurun_out/profiles gpurun_out/$RND
 case $part in

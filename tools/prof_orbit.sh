@@ -23,6 +23,7 @@ frames = run['frames']
 def family(name):
     n = name
     if 'render_kernel' in n: return 'ours: fused renderer'
+    if 'conv3x3_epilogue_kernel' in n: return 'ours: fused 3x3 convolution + epilogue (MFMA)'
     if 'clamp_depth' in n or 'make_rays' in n or 'to_uint8' in n or 'planes_absmax' in n or 'absmax_kernel' in n: return 'ours: renderer side kernels'
     if 'blur4' in n or 'upfirdn' in n: return 'ours: upfirdn2d / blur (+ epilogue)'
     if 'bias_act' in n: return 'ours: bias_act'
