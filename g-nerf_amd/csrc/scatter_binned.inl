@@ -29,7 +29,10 @@
 // takes 192 CU cycles whatever its addresses (three per lane: the float LDS atomic is serialised), ds_add_u64 takes 6, ds_add_u32 4.
 // Not covered (the caller falls back to plane_scatter_kernel): staging buffers of 2^32 floats or more, ray tiles that straddle items.
 
-constexpr int kBinTile = 16;                            // texels per side of a plane tile
+#ifndef GNERF_BIN_TILE
+#define GNERF_BIN_TILE 16
+#endif
+constexpr int kBinTile = GNERF_BIN_TILE;                // texels per side of a plane tile (a power of two)
 constexpr int kBinHalo = kBinTile + 1;                  // LDS tile side incl. the right / bottom halo
 constexpr int kBinCountThreads = 256;
 constexpr int kBinAccThreads = 1024;
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(kBinAccThreads, 8) void bin_accumulate_kernel(BinAc
         float* grad_item = A.grad_planes + int64_t(item) * 3 * H * W * 32;
         const float* accr = reinterpret_cast<const float*>(acc);
         for (int e = tid; e < kBinTile * kBinTile * 32; e += kBinAccThreads) {
-            const int c2 = e & 31, lx = (e >> 5) & (kBinTile - 1), ly = e >> 9;
+            const int c2 = e & 31, lx = (e >> 5) & (kBinTile - 1), ly = e / (32 * kBinTile);
             const int x = tx * kBinTile + lx, y = ty * kBinTile + ly;
             if (x < W && y < H) {
                 const int at = (ly * kBinHalo + lx) * 32 + c2;

@@ -134,7 +134,7 @@ int gnerf_blur4_epilogue_nhwc(const void* x, const float* f, void* y, int dtype,
  * x: [n, h, w, cin] float16; w_packed: [9, cout, cin] float16, tap-major (tap = ky * 3 + kx of the correlation form torch's conv2d
  * computes: w_packed[t, o, c] = weight[o, c, t / 3, t % 3]); y: [n, h, w, cout] float16; scale / next_scale: float32 [n, cout] or
  * NULL; noise: float32 [h * w] or NULL; bias: float16 [cout] or NULL; clamp < 0: none.  All 16-byte aligned.
- * GNERF_E_UNSUPPORTED unless h % 8 == 0, w % 32 == 0, cin % 128 == 0, cout % 128 == 0 (the caller runs the two-launch form). */
+ * GNERF_E_UNSUPPORTED unless h % 8 == 0, w % 32 == 0, cin % 64 == 0, cout % 128 == 0 (the caller runs the two-launch form). */
 int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, void* y, int n, int h, int w, int cin, int cout,
                                 const float* scale, const float* noise, int round_noise, const void* bias,
                                 float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream);

@@ -16,6 +16,7 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass sq1 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 pass sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE
+pass mfma SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCP_TCC_READ_REQ_sum TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum
 cd $R && python3 - "$out" "$tag" "$needle" <<'PY'
 import collections, glob, json, os, sqlite3, sys
@@ -26,7 +27,7 @@ if f:
     for name, calls, tot, avg, pct in sqlite3.connect(f[0]).execute('select name, total_calls, total_duration, average, percentage from top_kernels'):
         if needle in name:
             res[name[:160]].update(calls=calls, avg_us=round(avg / 1000.0, 2) if avg > 1e5 else round(avg, 2))
-for grp in ('fetch', 'write', 'sq1', 'sq2', 'tcc'):
+for grp in ('fetch', 'write', 'sq1', 'sq2', 'mfma', 'tcc'):
     f = glob.glob(os.path.join(d, grp, '**', '*.db'), recursive=True)
     if not f:
         continue
