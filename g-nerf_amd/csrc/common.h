@@ -54,6 +54,10 @@ template <class T, int VEC> struct alignas(sizeof(T) * VEC) Pk { T v[VEC]; };
 template <class T> __device__ __forceinline__ float round_to(float v) { return v; }
 template <> __device__ __forceinline__ float round_to<__half>(float v) { return __half2float(__float2half(v)); }
 
+// ACT: 1 linear, 3 lrelu, kActLrelu01 = lrelu whose slope the LAUNCHER has found in [0, 1] (the same bits as ACT 3 for such a slope:
+// written with ACT 3 the test is a uniform branch in front of every element -- four scalar branches per 8-byte store in the fused
+// convolution's epilogue, eight per vector in the blur's).
+constexpr int kActLrelu01 = 13;
 template <class T, int VEC, int ACT, bool SCALE, bool NOISE, bool NEXT>
 __device__ __forceinline__ Pk<T, VEC> modconv_epilogue_vec(const Pk<T, VEC>& in, const float (&sc)[VEC], float nz, bool round_noise, const float (&bv)[VEC],
                                                           const float (&nx)[VEC], float alpha, float gain, float clamp) {
@@ -99,6 +103,7 @@ __device__ __forceinline__ Pk<T, VEC> modconv_epilogue_vec(const Pk<T, VEC>& in,
         const float uu = t[k] + bv[k];
         float r = uu;
         if (ACT == 3) r = slope01 ? fmaxf(uu, uu * alpha) : (uu > 0.f ? uu : uu * alpha);          // lrelu
+        if (ACT == kActLrelu01) r = fmaxf(uu, uu * alpha);                                       // lrelu, slope checked by the launcher
         r *= gain;
         if (clamp >= 0.f) r = __builtin_amdgcn_fmed3f(r, -clamp, clamp);
         if constexpr (NEXT) r = round_to<T>(r) * nx[k];

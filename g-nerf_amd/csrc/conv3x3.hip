@@ -10,12 +10,21 @@
 // epilogue in registers (the same device function as the stand-alone pass, csrc/common.h: same roundings, in the same order) and
 // leave as fp16 channels_last.
 //
-// Decomposition.  One workgroup (4 waves, 1 per SIMD, one workgroup per CU: 152 KB of LDS) computes an 8 x 32 tile of output pixels for
-// 128 output channels.  The 10 x 34 input pixels the tile's nine taps touch are staged ONCE per 128 input channels (87 KB; image
-// borders come in as zeros from the buffer load's range check) and every tap reads them at a shifted position; the weights of one
-// (tap, 128 input channels) -- 32 KB -- stream through a double buffer while the previous tap is being multiplied.  Both are filled by
-// LDS-DMA (buffer_load / global_load ... lds: no registers, no ds_write), whose LDS image is lane-linear, so the bank-conflict swizzle
-// (16-byte slot ^ (row & 15)) is applied to the SOURCE address and again when the fragments are read.
+// Decomposition.  A workgroup (4 waves; 77.5 KB of LDS and 256 registers per lane, so TWO workgroups share a CU: two waves per SIMD, and
+// one workgroup's barriers, input-tile loads and epilogue hide under the other's MFMAs) computes an 8 x 32 tile of output pixels for 128
+// output channels.  The 10 x 34 input pixels the tile's nine taps touch are staged once per 64 input channels (43.5 KB; image borders
+// come in as zeros from the buffer load's range check) and every tap reads them at a shifted position; the weights of one (tap, 64
+// input channels) -- 16 KB -- stream through a double buffer while the previous tap is being multiplied.  Both are filled by LDS-DMA
+// (buffer_load / global_load ... lds: no registers, no ds_write), whose LDS image is lane-linear, so the bank swizzle is applied to
+// the SOURCE address and again when the fragments are read: in 128-byte rows, 16-byte slot ^ (pixel & 7) for the input tile and
+// ^ ((channel >> 1) & 7) for the weights.  A ds_read_b128 is served in four groups of sixteen NON-contiguous lanes ({0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31}, ... -- MI355X_MICROARCH.md, LDS): with lane = 16 * (k quarter) + row, a group is eight rows at one k slot and
+// the eight rows between them at the next; tools/lds_bank_model.py evaluates the formulas against those groups (both conflict-free
+// at every tile position; the weights' formula on the input tile is two-way at three positions of four, and was what round 5's
+// first two-workgroup build ran: SQ_LDS_BANK_CONFLICT 640 cycles per wave of ~2 500).
+// (History, profiles/r05_conv3x3_*.txt: one workgroup per CU with 128-channel chunks 0.49 ms; + software-pipelined fragment reads 0.42;
+// persistent workgroups with a four-deep weight ring 0.62; this form 0.32 -- at one wave per SIMD every stall of the only wave is the
+// SIMD's, and no hand-built pipeline beat two independent workgroups.)
 // Orientation: A = weights (M = 16 output channels), B = input (N = 16 pixels of a row), K = 32 input channels per instruction; a lane's
 // four accumulator registers are then four CONSECUTIVE output channels of one pixel -- an 8-byte piece of the channels_last result.
 // A wave owns two rows of the tile: 64 pixels x 128 channels = 128 accumulator registers, 32 MFMAs per 12 ds_read_b128.
@@ -40,8 +49,9 @@ constexpr int kXRounds = (kXPieces + kConvThreads - 1) / kConvThreads;
 constexpr int kXBytes = kXRounds * kConvThreads * 16;
 constexpr int kWBytes = kCO * kCK * 2;
 constexpr int kWRounds = kWBytes / 16 / kConvThreads;
-constexpr int kConvLds = kXBytes + 2 * kWBytes;
-static_assert(kTH * kTW * kCO * 2 <= kConvLds, "the output tile is staged where the input tile and the weights were");
+constexpr int kOperands = kXBytes + 2 * kWBytes;                  // LDS offset of the epilogue's per-channel operands
+constexpr int kConvLds = kOperands + 1536;                        // [128] float scale, [128] float next_scale, [128] half bias
+static_assert(kTH * kTW * kCO * 2 <= kOperands, "the output tile is staged where the input tile and the weights were");
 static_assert(2 * kConvLds <= 160 * 1024, "two workgroups per CU");
 static_assert(kCK == 64, "two k-steps per tap; the swizzles assume 128-byte rows");
 
@@ -64,7 +74,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <bool SCALE, bool NOISE, bool NEXT>
 __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvArgs a) {
     extern __shared__ __align__(16) char lds[];
-    char* const xs = lds;                           // [340 pixels][8 slots of 16 bytes], slot ^= (pixel >> 1) & 7
+    char* const xs = lds;                           // [340 pixels][8 slots of 16 bytes], slot ^= pixel & 7
     char* const wb = lds + kXBytes;                 // 2 x [128 output channels][8 slots], slot ^= (channel >> 1) & 7
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,7 +102,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             const int py = pix / kIW, px = pix - py * kIW;
             const int iy = y0 - 1 + py, ix = x0 - 1 + px;
             const bool ok = pix < kIH * kIW && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const unsigned off = ok ? unsigned(((iy * W + ix) * Cin + cin0 + ((slot ^ ((pix >> 1) & 7)) << 3)) * 2) : 0x80000000u;     // out of range: zeros
+            const unsigned off = ok ? unsigned(((iy * W + ix) * Cin + cin0 + ((slot ^ (pix & 7)) << 3)) * 2) : 0x80000000u;     // out of range: zeros
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(xs + (it * kConvThreads + wv * 64) * 16), 16, off, 0, 0, 0);
         }
     };
@@ -113,6 +123,19 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
 #pragma unroll
         for (int pb = 0; pb < 4; pb++) acc[cb][pb] = (v4f){0.f, 0.f, 0.f, 0.f};
 
+    // The epilogue's per-channel operands (demodulation scale, next layer's scale, bias of this workgroup's 128 channels: 1.25 KB) come in
+    // by LDS-DMA right here and are read from LDS at the end.  (As ordinary loads at the point of use they were up to 24 dependent
+    // round trips at the end of every tile; ordinary loads issued early make hipcc put `s_waitcnt vmcnt(0)` between the LDS-DMA
+    // instructions of the main loop -- its wait insertion does not count the two kinds of load apart.)
+    char* const ep = lds + kOperands;
+    if (wv < 2) {                                                  // (wave-uniform: threads 0..127, one float each)
+        if constexpr (SCALE) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.scale + size_t(n) * Cout + co0 + tid),
+                                                              (lds_ptr_t)(ep + wv * 256), 4, 0, 0);
+        if constexpr (NEXT) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.next_scale + size_t(n) * Cout + co0 + tid),
+                                                             (lds_ptr_t)(ep + 512 + wv * 256), 4, 0, 0);
+    }
+    if (wv == 0 && a.bias) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + co0 + 2 * tid),
+                                                            (lds_ptr_t)(ep + 1024), 4, 0, 0);
     const int n_chunks = Cin / kCK, total = n_chunks * 9;
     stage_x(0);
     stage_w(0, 0, 0);
@@ -131,7 +154,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
         for (int pb = 0; pb < 4; pb++) {
             const int pi = (2 * wv + (pb >> 1) + dy) * kIW + (pb & 1) * 16 + r + dx;
             xrow[pb] = pi * kRow;
-            xm[pb] = (pi >> 1) & 7;
+            xm[pb] = pi & 7;
         }
         // The four 32-channel k-steps of the tap as a software pipeline: the twelve fragment reads of step kc + 1 are issued, one per
         // two or three MFMAs, among the 32 MFMAs of step kc.  (Left to itself hipcc re-used ONE register quad for every weight
@@ -189,14 +212,16 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     for (int cb = 0; cb < 8; cb++) {
         const int c4 = cb * 16 + hq * 4;                           // this lane's four consecutive output channels (of the workgroup's 128)
         float sc[4] = {1.f, 1.f, 1.f, 1.f}, nx[4] = {1.f, 1.f, 1.f, 1.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (SCALE) { const float4 v = *reinterpret_cast<const float4*>(a.scale + size_t(n) * Cout + co0 + c4); sc[0] = v.x; sc[1] = v.y; sc[2] = v.z; sc[3] = v.w; }
+        if constexpr (SCALE) { const float4 v = *reinterpret_cast<const float4*>(ep + c4 * 4); sc[0] = v.x; sc[1] = v.y; sc[2] = v.z; sc[3] = v.w; }
         if constexpr (NEXT) {
-            const float4 v = *reinterpret_cast<const float4*>(a.next_scale + size_t(n) * Cout + co0 + c4);
+            const float4 v = *reinterpret_cast<const float4*>(ep + 512 + c4 * 4);
             nx[0] = round_to<__half>(v.x); nx[1] = round_to<__half>(v.y); nx[2] = round_to<__half>(v.z); nx[3] = round_to<__half>(v.w);
         }
         if (a.bias) {
+            const uint2 hb2 = *reinterpret_cast<const uint2*>(ep + 1024 + c4 * 2);
+            const __half* hb = reinterpret_cast<const __half*>(&hb2);
 #pragma unroll
-            for (int k = 0; k < 4; k++) bv[k] = __half2float(a.bias[co0 + c4 + k]);
+            for (int k = 0; k < 4; k++) bv[k] = __half2float(hb[k]);
         }
 #pragma unroll
         for (int pb = 0; pb < 4; pb++) {
@@ -207,7 +232,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             for (int k = 0; k < 4; k++) in.v[k] = __float2half(acc[cb][pb][k]);          // what the convolution alone would have stored
             float nz = 0.f;
             if constexpr (NOISE) nz = a.noise[(y0 + prow) * W + x0 + pcol];
-            const Pk<__half, 4> out = modconv_epilogue_vec<__half, 4, 3, SCALE, NOISE, NEXT>(in, sc, nz, a.round_noise != 0, bv, nx, a.alpha, a.gain, a.clamp);
+            const Pk<__half, 4> out = modconv_epilogue_vec<__half, 4, kActLrelu01, SCALE, NOISE, NEXT>(in, sc, nz, a.round_noise != 0, bv, nx, a.alpha, a.gain, a.clamp);
             *reinterpret_cast<uint2*>(os + p * 256 + (((c4 >> 3) ^ (p & 15)) << 4) + ((c4 >> 2) & 1) * 8) = *reinterpret_cast<const uint2*>(&out);
         }
     }
@@ -238,6 +263,8 @@ extern "C" int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, 
         return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: x, w and y must be 16-byte aligned");
     if ((scale && (reinterpret_cast<uintptr_t>(scale) & 15)) || (next_scale && (reinterpret_cast<uintptr_t>(next_scale) & 15)))
         return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: scale and next_scale must be 16-byte aligned");
+    if (!(alpha >= 0.f && alpha <= 1.f)) return fail(GNERF_E_UNSUPPORTED, "conv3x3_epilogue_nhwc: the lrelu slope must lie in [0, 1] (got %g)", double(alpha));
+    if (bias && (reinterpret_cast<uintptr_t>(bias) & 3)) return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: bias must be 4-byte aligned");
     ConvArgs a;
     a.x = static_cast<const _Float16*>(x); a.wpk = static_cast<const _Float16*>(w_packed); a.y = static_cast<_Float16*>(y);
     a.scale = scale; a.noise = noise; a.bias = static_cast<const __half*>(bias); a.next_scale = next_scale;

@@ -728,6 +728,7 @@ int launch_blur4_nhwc(const UpArgs& a, hipStream_t stream, const BlurEpi* ep = n
     const dim3 g((unsigned)blocks, (unsigned)strips_y, (unsigned)a.n), b(256);
     const BlurEpi none = {nullptr, nullptr, nullptr, 0.f, 1.f, -1.f};
     if (!ep)           hipLaunchKernelGGL((upfirdn_blur4_nhwc_kernel<T, 0>), g, b, 0, stream, a, cv, strips_y, rows_per_strip, none);
+    else if (act == 3 && ep->alpha >= 0.f && ep->alpha <= 1.f) hipLaunchKernelGGL((upfirdn_blur4_nhwc_kernel<T, kActLrelu01>), g, b, 0, stream, a, cv, strips_y, rows_per_strip, *ep);
     else if (act == 3) hipLaunchKernelGGL((upfirdn_blur4_nhwc_kernel<T, 3>), g, b, 0, stream, a, cv, strips_y, rows_per_strip, *ep);
     else               hipLaunchKernelGGL((upfirdn_blur4_nhwc_kernel<T, 1>), g, b, 0, stream, a, cv, strips_y, rows_per_strip, *ep);
     return check_launch("upfirdn2d(blur4, channels_last)") == GNERF_OK ? 0 : -1;

@@ -44,3 +44,4 @@ for key, r in res.items():
 json.dump(res, open(os.path.join('gpurun_out', f'{tag}_kernel_profile.json'), 'w'), indent=1)
 print(json.dumps(res, indent=1)[:6000])
 PY
+rm -rf $out            # the raw rocpd files are large: gpurun copies back at most 64 MiB
