@@ -142,8 +142,14 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     for (int s = 0; s < total; s++) {
         const int chunk = s / 9, tap = s - chunk * 9;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this step's weights (and, at a chunk's first tap, its input tile) have landed
-        __syncthreads();                                            // ... for every wave; and every wave is done with the other weight buffer
+#ifndef GNERF_ABLATE_CONVBAR       // timing only: no workgroup barrier per step (LDS races: wrong values, no wild addresses)
+        __syncthreads();
+#endif                                            // ... for every wave; and every wave is done with the other weight buffer
+#ifdef GNERF_ABLATE_CONVW          // timing only: the weights are fetched for the first step alone
+        if (false) {
+#else
         if (s + 1 < total) {
+#endif
             const int c1 = (s + 1) / 9;
             stage_w(s + 1 - c1 * 9, c1 * kCK, (s + 1) & 1);        // streams in under this step's MFMAs
         }
@@ -199,7 +205,11 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             mfma_group(3);
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef GNERF_ABLATE_CONVX          // timing only: the input tile's later chunks are not fetched
+        if (false) {
+#else
         if (tap == 8 && chunk + 1 < n_chunks) {
+#endif
             __syncthreads();                                        // every wave has read the last of this chunk's input tile
             stage_x((chunk + 1) * kCK);
         }
