@@ -31,6 +31,10 @@
 
 #include "common.h"
 
+#ifndef GNERF_CONV_PIPE
+#define GNERF_CONV_PIPE 1            // 0: round 5's first two-workgroup loop (fragments of a step read at its top), kept for A/B builds
+#endif
+
 namespace {
 
 using namespace gnerf;
@@ -95,9 +99,13 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
         const_cast<_Float16*>(a.x) + size_t(n) * H * W * Cin, 0, int(size_t(H) * W * Cin * 2), 0x00020000);
 
     auto stage_x = [&](int cin0) {
+        // (the eleven source offsets depend on the lane and the tile only: left visible, the compiler computes them once in front of the
+        //  main loop and keeps them -- or rather spills them, and a scratch reload in the loop waits for every LDS-DMA in flight)
+        int t = tid;
+        asm volatile("" : "+v"(t));
 #pragma unroll
         for (int it = 0; it < kXRounds; it++) {
-            const int q = it * kConvThreads + tid;
+            const int q = it * kConvThreads + t;
             const int pix = q >> 3, slot = q & 7;
             const int py = pix / kIW, px = pix - py * kIW;
             const int iy = y0 - 1 + py, ix = x0 - 1 + px;
@@ -137,6 +145,87 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     if (wv == 0 && a.bias) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + co0 + 2 * tid),
                                                             (lds_ptr_t)(ep + 1024), 4, 0, 0);
     const int n_chunks = Cin / kCK, total = n_chunks * 9;
+#if GNERF_CONV_PIPE
+    // ---- main loop, software-pipelined ACROSS steps.  A step (one tap of one 64-channel chunk) is two k-steps of 32 MFMAs; while
+    // the MFMAs of one k-step issue, the twelve fragments of the NEXT k-step are read -- the second k-step of this step, or the first
+    // of the next step.  The one barrier of a step sits between its two k-steps: there the next step's weights (requested a step
+    // ago) have landed, every wave has read the last of this step's weights (their buffer takes the step after next) and, at a
+    // chunk's last tap, the last of the input tile (the next chunk is requested right there and arrives under 32 MFMAs).
+    // (Round 5's first form read a step's first twelve fragments at the step's top, behind the barrier, with nothing to cover them.)
+    h8 A[2][8], B[2][4];
+    // fragment f of k-step kc of step s: f = 0..3 the input fragments of the wave's four pixel blocks, f = 4..11 the eight weight fragments.
+    // Addresses from two lane constants and wave-uniform terms (the tap's shift, the weight buffer); pixel block f ^ 1 and the weight
+    // fragments sit at constant offsets (16 pixels / 16 channels further: the swizzle's period is 8 rows), k-step 1 flips bit 6.
+    const int xlane = (2 * wv * kIW + r) * kRow;                   // byte offset of this lane's pixel row (tile row 2 wv, column r) without the tap's shift
+    const int alane = r * kRow + ((hq ^ ((r >> 1) & 7)) << 4);
+    auto load_frag = [&](int s, int kc, int f, h8 (&Af)[8], h8 (&Bf)[4]) {
+        if (f < 4) {
+            const int chunk = s / 9, tap = s - chunk * 9, dy = tap / 3, dx = tap - dy * 3;
+            const int row = xlane + (((f >> 1) + dy) * kIW + dx) * kRow;          // pixel index * 128
+            const int slot = (hq ^ (row >> 7)) & 7;
+            Bf[f] = *reinterpret_cast<const h8*>(xs + ((row + (slot << 4)) ^ (kc << 6)) + (f & 1) * 16 * kRow);
+        } else {
+            Af[f - 4] = *reinterpret_cast<const h8*>(wb + (s & 1) * kWBytes + (alane ^ (kc << 6)) + (f - 4) * 16 * kRow);
+        }
+    };
+    auto mfma_group = [&](int g, const h8 (&Af)[8], const h8 (&Bf)[4]) {
+#pragma unroll
+        for (int cb = 2 * g; cb < 2 * g + 2; cb++)
+#pragma unroll
+            for (int pb = 0; pb < 4; pb++) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[cb], Bf[pb], acc[cb][pb], 0, 0, 0);
+    };
+    // 32 MFMAs from (Ac, Bc) with the twelve reads of (s2, kc2) into (An, Bn) among them: {8 MFMAs, six reads} twice, then 16 MFMAs --
+    // fenced so that the compiler keeps the order; the last read has 24 MFMAs to come back behind
+    auto phase = [&](const h8 (&Ac)[8], const h8 (&Bc)[4], bool reads, int s2, int kc2, h8 (&An)[8], h8 (&Bn)[4]) {
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(0, Ac, Bc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (reads) {
+#pragma unroll
+            for (int f = 0; f < 6; f++) load_frag(s2, kc2, f, An, Bn);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(1, Ac, Bc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (reads) {
+#pragma unroll
+            for (int f = 6; f < 12; f++) load_frag(s2, kc2, f, An, Bn);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(2, Ac, Bc);
+        mfma_group(3, Ac, Bc);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stage_w_step = [&](int s) { const int c = s / 9; stage_w(s - c * 9, c * kCK, s & 1); };
+    stage_x(0);
+    stage_w_step(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (total > 1) stage_w_step(1);
+#pragma unroll
+    for (int f = 0; f < 12; f++) load_frag(0, 0, f, A[0], B[0]);
+    for (int s = 0; s < total; s++) {
+        const int chunk = s / 9, tap = s - chunk * 9;
+        phase(A[0], B[0], true, s, 1, A[1], B[1]);
+        // (bare waits and barrier: __syncthreads() would drain vmcnt where the compiler sees fit)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool more = s + 1 < total, new_chunk = more && tap == 8;
+        if (s + 2 < total) stage_w_step(s + 2);
+        if (new_chunk) stage_x((chunk + 1) * kCK);
+        phase(A[1], B[1], more && !new_chunk, s + 1, 0, A[0], B[0]);
+        if (new_chunk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int f = 0; f < 12; f++) load_frag(s + 1, 0, f, A[0], B[0]);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     stage_x(0);
     stage_w(0, 0, 0);
     for (int s = 0; s < total; s++) {
@@ -214,6 +303,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             stage_x((chunk + 1) * kCK);
         }
     }
+#endif
     __syncthreads();                                                // the input tile is dead: its LDS takes the output tile
 
     // ---- epilogue in registers, then through LDS for 16-byte coalesced stores.  Output image: [256 pixels][16 slots], slot ^= pixel & 15.
