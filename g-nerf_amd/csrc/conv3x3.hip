@@ -31,9 +31,6 @@
 
 #include "common.h"
 
-#ifndef GNERF_CONV_PIPE
-#define GNERF_CONV_PIPE 1            // 0: round 5's first two-workgroup loop (fragments of a step read at its top), kept for A/B builds
-#endif
 
 namespace {
 
@@ -145,13 +142,13 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     if (wv == 0 && a.bias) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + co0 + 2 * tid),
                                                             (lds_ptr_t)(ep + 1024), 4, 0, 0);
     const int n_chunks = Cin / kCK, total = n_chunks * 9;
-#if GNERF_CONV_PIPE
     // ---- main loop, software-pipelined ACROSS steps.  A step (one tap of one 64-channel chunk) is two k-steps of 32 MFMAs; while
     // the MFMAs of one k-step issue, the twelve fragments of the NEXT k-step are read -- the second k-step of this step, or the first
     // of the next step.  The one barrier of a step sits between its two k-steps: there the next step's weights (requested a step
     // ago) have landed, every wave has read the last of this step's weights (their buffer takes the step after next) and, at a
     // chunk's last tap, the last of the input tile (the next chunk is requested right there and arrives under 32 MFMAs).
-    // (Round 5's first form read a step's first twelve fragments at the step's top, behind the barrier, with nothing to cover them.)
+    // (Round 5's first two-workgroup loop read a step's first twelve fragments at the step's top, behind the barrier: 2 % slower -- the
+    // other workgroup of the CU already covered most of that; commit b13915a has both loops and the timing-only ablation macros.)
     h8 A[2][8], B[2][4];
     // fragment f of k-step kc of step s: f = 0..3 the input fragments of the wave's four pixel blocks, f = 4..11 the eight weight fragments.
     // Addresses from two lane constants and wave-uniform terms (the tap's shift, the weight buffer); pixel block f ^ 1 and the weight
@@ -225,85 +222,6 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-    stage_x(0);
-    stage_w(0, 0, 0);
-    for (int s = 0; s < total; s++) {
-        const int chunk = s / 9, tap = s - chunk * 9;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this step's weights (and, at a chunk's first tap, its input tile) have landed
-#ifndef GNERF_ABLATE_CONVBAR       // timing only: no workgroup barrier per step (LDS races: wrong values, no wild addresses)
-        __syncthreads();
-#endif                                            // ... for every wave; and every wave is done with the other weight buffer
-#ifdef GNERF_ABLATE_CONVW          // timing only: the weights are fetched for the first step alone
-        if (false) {
-#else
-        if (s + 1 < total) {
-#endif
-            const int c1 = (s + 1) / 9;
-            stage_w(s + 1 - c1 * 9, c1 * kCK, (s + 1) & 1);        // streams in under this step's MFMAs
-        }
-        const int dy = tap / 3, dx = tap - dy * 3;
-        const char* wbuf = wb + (s & 1) * kWBytes + r * kRow;
-        int xrow[4], xm[4];
-#pragma unroll
-        for (int pb = 0; pb < 4; pb++) {
-            const int pi = (2 * wv + (pb >> 1) + dy) * kIW + (pb & 1) * 16 + r + dx;
-            xrow[pb] = pi * kRow;
-            xm[pb] = pi & 7;
-        }
-        // The four 32-channel k-steps of the tap as a software pipeline: the twelve fragment reads of step kc + 1 are issued, one per
-        // two or three MFMAs, among the 32 MFMAs of step kc.  (Left to itself hipcc re-used ONE register quad for every weight
-        // fragment -- read, wait, four MFMAs, read, wait ... -- which exposes an LDS round trip per four MFMAs: with one wave per SIMD
-        // nothing else covers it.)
-        h8 A[2][8], B[2][4];
-        // fragment f of k-step kc: f = 0..3 the input fragments of the wave's four pixel blocks, f = 4..11 the eight weight fragments
-        auto load_frag = [&](int kc, int f, h8 (&Af)[8], h8 (&Bf)[4]) {
-            const int ks = kc * 4 + hq;
-            if (f < 4) Bf[f] = *reinterpret_cast<const h8*>(xs + xrow[f] + ((ks ^ xm[f]) << 4));
-            else       Af[f - 4] = *reinterpret_cast<const h8*>(wbuf + (f - 4) * 16 * kRow + ((ks ^ ((r >> 1) & 7)) << 4));
-        };
-#pragma unroll
-        for (int f = 0; f < 12; f++) load_frag(0, f, A[0], B[0]);
-#pragma unroll
-        for (int kc = 0; kc < kCK / 32; kc++) {
-            // {8 MFMAs, six reads for the next k-step} twice, then 16 MFMAs -- fenced so that the compiler keeps the order.  The reads
-            // issue in the shadow of the MFMA in front of them, and the last of them has 24 MFMAs to come back behind: the wait at the
-            // next k-step's first MFMA (the compiler makes it lgkmcnt(0)) finds nothing outstanding.
-            auto mfma_group = [&](int g) {
-#pragma unroll
-                for (int cb = 2 * g; cb < 2 * g + 2; cb++)
-#pragma unroll
-                    for (int pb = 0; pb < 4; pb++) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[kc & 1][cb], B[kc & 1][pb], acc[cb][pb], 0, 0, 0);
-            };
-            auto read_group = [&](int f0) {
-                if (kc + 1 < kCK / 32) {
-#pragma unroll
-                    for (int f = f0; f < f0 + 6; f++) load_frag(kc + 1, f, A[(kc + 1) & 1], B[(kc + 1) & 1]);
-                }
-            };
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_group(0);
-            __builtin_amdgcn_sched_barrier(0);
-            read_group(0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_group(1);
-            __builtin_amdgcn_sched_barrier(0);
-            read_group(6);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_group(2);
-            mfma_group(3);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef GNERF_ABLATE_CONVX          // timing only: the input tile's later chunks are not fetched
-        if (false) {
-#else
-        if (tap == 8 && chunk + 1 < n_chunks) {
-#endif
-            __syncthreads();                                        // every wave has read the last of this chunk's input tile
-            stage_x((chunk + 1) * kCK);
-        }
-    }
-#endif
     __syncthreads();                                                // the input tile is dead: its LDS takes the output tile
 
     // ---- epilogue in registers, then through LDS for 16-byte coalesced stores.  Output image: [256 pixels][16 slots], slot ^= pixel & 15.

@@ -5,9 +5,9 @@ cd $R
 O=$R/gpurun_out/r05_exp10
 mkdir -p $O
 echo "== parity" | tee $O/parity.txt
-timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "conv3x3 or fast_modconv or config3" 2>&1 | tail -4 | tee -a $O/parity.txt
+echo skipped | tee -a $O/parity.txt
 : > $O/ab.txt
-for v in default "D:GNERF_CONV_PIPE=0" default "D:GNERF_CONV_PIPE=0"; do
+for v in default "D:GNERF_CONV_STAGGER=1" "D:GNERF_CONV_STAGGER=2" default "D:GNERF_CONV_STAGGER=1" "D:GNERF_CONV_STAGGER=2"; do
   if [ "$v" = default ]; then unset GNERF_HIP_LIB; else export GNERF_HIP_LIB="$R/g-nerf_amd/gnerf_hip/variants/libgnerf_$v.so"; fi
   timeout -k 10 200 python3 tools/bench_conv3x3.py --shapes sr --search 0 2>/dev/null | python3 -c "
 import sys, json
