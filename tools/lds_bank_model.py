@@ -21,50 +21,53 @@ def cycles(op, addr):                      # addr: byte address per lane (64 ent
         total += max(len(v) for v in per_bank.values())
     return total, len(groups)
 
-if __name__ == '__main__':
-    kRow, kIW = 128, 34
-    worst = collections.Counter()
-    # B fragments (input tile): pi = (2 wv + (pb >> 1) + dy) * 34 + (pb & 1) * 16 + r + dx, slot = ks ^ ((pi >> 1) & 7)
-    for swz in ('(pi>>1)&7', 'pi&7', '((pi>>1)&7)^((pi>>4)&1)'):
-        res = collections.Counter()
-        for base in range(0, 340 - 16):
-            for kc in range(2):
-                addr = []
-                for lane in range(64):
-                    r, hq = lane & 15, lane >> 4
-                    pi = base + r
-                    ks = kc * 4 + hq
-                    addr.append(pi * kRow + ((ks ^ eval(swz)) << 4))
-                res[cycles('ds_read_b128', addr)[0]] += 1
-        print('B fragment reads, swizzle', swz, dict(res))
-    for swz in ('(r>>1)&7',):
-        res = collections.Counter()
+def conv3x3_patterns():
+    """LDS cycles of every access pattern of csrc/conv3x3.hip (formulas restated from the kernel): {pattern: {cycles: occurrences}}."""
+    kRow = 128
+    out = {}
+    # B fragments (input tile): lane = 16 * hq + r reads pixel pi = base + r at slot (kc * 4 + hq) ^ (pi & 7) of its 128-byte row
+    res = collections.Counter()
+    for base in range(0, 340 - 16):
         for kc in range(2):
-            addr = []
-            for lane in range(64):
-                r, hq = lane & 15, lane >> 4
-                ks = kc * 4 + hq
-                addr.append(r * kRow + ((ks ^ eval(swz)) << 4))
+            addr = [(base + (l & 15)) * kRow + (((kc * 4 + (l >> 4)) ^ ((base + (l & 15)) & 7)) << 4) for l in range(64)]
             res[cycles('ds_read_b128', addr)[0]] += 1
-        print('A fragment reads, swizzle', swz, dict(res))
-    # epilogue staging: write uint2 at os + p * 256 + (((c4 >> 3) ^ (p & 15)) << 4) + ((c4 >> 2) & 1) * 8;  p = prow * 32 + pcol, pcol = (pb & 1) * 16 + r, c4 = cb * 16 + hq * 4
+    out['input-tile fragment reads (ds_read_b128), slot ^= pixel & 7'] = dict(res)
+    res = collections.Counter()
+    for base in range(0, 340 - 16):
+        for kc in range(2):
+            addr = [(base + (l & 15)) * kRow + (((kc * 4 + (l >> 4)) ^ (((base + (l & 15)) >> 1) & 7)) << 4) for l in range(64)]
+            res[cycles('ds_read_b128', addr)[0]] += 1
+    out['(the same with the weights\' formula, slot ^= (pixel >> 1) & 7: what the first two-workgroup build ran)'] = dict(res)
+    # A fragments (weights): row = 16 * block + r, slot (kc * 4 + hq) ^ ((r >> 1) & 7)
+    res = collections.Counter()
+    for kc in range(2):
+        addr = [(l & 15) * kRow + (((kc * 4 + (l >> 4)) ^ (((l & 15) >> 1) & 7)) << 4) for l in range(64)]
+        res[cycles('ds_read_b128', addr)[0]] += 1
+    out['weight fragment reads (ds_read_b128), slot ^= (channel >> 1) & 7'] = dict(res)
+    # epilogue staging: 8-byte pieces written at p * 256 + (((c4 >> 3) ^ (p & 15)) << 4) + ((c4 >> 2) & 1) * 8, read back as 16-byte pieces
     res = collections.Counter()
     for cb in range(8):
         for pb in range(4):
             addr = []
-            for lane in range(64):
-                r, hq = lane & 15, lane >> 4
+            for l in range(64):
+                r, hq = l & 15, l >> 4
                 p = (pb >> 1) * 32 + (pb & 1) * 16 + r
                 c4 = cb * 16 + hq * 4
                 addr.append(p * 256 + (((c4 >> 3) ^ (p & 15)) << 4) + ((c4 >> 2) & 1) * 8)
             res[cycles('ds_write_b64', addr)[0]] += 1
-    print('epilogue staging writes (ds_write_b64)', dict(res))
+    out['epilogue staging writes (ds_write_b64; 4 is the minimum, 8 = two-way: 128 extra cycles per tile, left)'] = dict(res)
     res = collections.Counter()
     for it in range(16):
         addr = []
-        for lane in range(64):
-            q = it * 256 + lane
+        for l in range(64):
+            q = it * 256 + l
             p, slot = q >> 4, q & 15
             addr.append(p * 256 + ((slot ^ (p & 15)) << 4))
         res[cycles('ds_read_b128', addr)[0]] += 1
-    print('epilogue staging reads (ds_read_b128)', dict(res))
+    out['epilogue staging reads (ds_read_b128)'] = dict(res)
+    return out
+
+
+if __name__ == '__main__':
+    for k, v in conv3x3_patterns().items():
+        print(k, v)
