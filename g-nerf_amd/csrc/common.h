@@ -106,8 +106,25 @@ __device__ __forceinline__ Pk<T, VEC> modconv_epilogue_vec(const Pk<T, VEC>& in,
         if (ACT == kActLrelu01) r = fmaxf(uu, uu * alpha);                                       // lrelu, slope checked by the launcher
         r *= gain;
         if (clamp >= 0.f) r = __builtin_amdgcn_fmed3f(r, -clamp, clamp);
-        if constexpr (NEXT) r = round_to<T>(r) * nx[k];
-        store_as<T>(out.v, k, r);
+        if constexpr (sizeof(T) == 2 && VEC % 2 == 0) {
+            t[k] = r;                                                 // rounded and scaled in pairs below
+        } else {
+            if constexpr (NEXT) r = round_to<T>(r) * nx[k];
+            store_as<T>(out.v, k, r);
+        }
+    }
+    if constexpr (sizeof(T) == 2 && VEC % 2 == 0) {
+        // fp16: round two values with one v_cvt_pk_f16_f32 (round to nearest even, as the single conversion) and scale the pair with one
+        // v_pk_mul_f16 -- the same bits as element by element (nx holds fp16 values), 1.5 instructions per pair instead of 4
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        struct alignas(sizeof(T) * VEC) Words { unsigned w[VEC / 2]; } packed;
+#pragma unroll
+        for (int k = 0; k < VEC; k += 2) {
+            h2 rr = {(_Float16)t[k], (_Float16)t[k + 1]};
+            if constexpr (NEXT) rr = rr * (h2){(_Float16)nx[k], (_Float16)nx[k + 1]};
+            packed.w[k / 2] = __builtin_bit_cast(unsigned, rr);
+        }
+        return __builtin_bit_cast(Pk<T, VEC>, packed);
     }
     return out;
 }

@@ -30,6 +30,7 @@
 // A wave owns two rows of the tile: 64 pixels x 128 channels = 128 accumulator registers, 32 MFMAs per 12 ds_read_b128.
 
 #include "common.h"
+#include <type_traits>
 
 
 namespace {
@@ -226,6 +227,11 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
 
     // ---- epilogue in registers, then through LDS for 16-byte coalesced stores.  Output image: [256 pixels][16 slots], slot ^= pixel & 15.
     char* const os = lds;
+    // (two copies of the register part, chosen once per workgroup: with the clamp's presence a run-time value the compiler keeps a
+    //  compare-and-select per element behind every v_med3_f32 -- 128 of a wave's ~2 000 epilogue instructions)
+    auto registers_to_lds = [&](auto has_clamp) {
+    const float clampv = decltype(has_clamp)::value ? fabsf(a.clamp) : -1.f;
+    if constexpr (decltype(has_clamp)::value) __builtin_assume(clampv >= 0.f);
 #pragma unroll
     for (int cb = 0; cb < 8; cb++) {
         const int c4 = cb * 16 + hq * 4;                           // this lane's four consecutive output channels (of the workgroup's 128)
@@ -236,10 +242,10 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             nx[0] = round_to<__half>(v.x); nx[1] = round_to<__half>(v.y); nx[2] = round_to<__half>(v.z); nx[3] = round_to<__half>(v.w);
         }
         if (a.bias) {
-            const uint2 hb2 = *reinterpret_cast<const uint2*>(ep + 1024 + c4 * 2);
-            const __half* hb = reinterpret_cast<const __half*>(&hb2);
+            typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+            const h4v hb = __builtin_bit_cast(h4v, *reinterpret_cast<const uint2*>(ep + 1024 + c4 * 2));
 #pragma unroll
-            for (int k = 0; k < 4; k++) bv[k] = __half2float(hb[k]);
+            for (int k = 0; k < 4; k++) bv[k] = float(hb[k]);
         }
 #pragma unroll
         for (int pb = 0; pb < 4; pb++) {
@@ -250,10 +256,12 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             for (int k = 0; k < 4; k++) in.v[k] = __float2half(acc[cb][pb][k]);          // what the convolution alone would have stored
             float nz = 0.f;
             if constexpr (NOISE) nz = a.noise[(y0 + prow) * W + x0 + pcol];
-            const Pk<__half, 4> out = modconv_epilogue_vec<__half, 4, kActLrelu01, SCALE, NOISE, NEXT>(in, sc, nz, a.round_noise != 0, bv, nx, a.alpha, a.gain, a.clamp);
-            *reinterpret_cast<uint2*>(os + p * 256 + (((c4 >> 3) ^ (p & 15)) << 4) + ((c4 >> 2) & 1) * 8) = *reinterpret_cast<const uint2*>(&out);
+            const Pk<__half, 4> out = modconv_epilogue_vec<__half, 4, kActLrelu01, SCALE, NOISE, NEXT>(in, sc, nz, a.round_noise != 0, bv, nx, a.alpha, a.gain, clampv);
+            *reinterpret_cast<uint2*>(os + p * 256 + (((c4 >> 3) ^ (p & 15)) << 4) + ((c4 >> 2) & 1) * 8) = __builtin_bit_cast(uint2, out);
         }
     }
+    };
+    if (a.clamp >= 0.f) registers_to_lds(std::true_type{}); else registers_to_lds(std::false_type{});
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < kTH * kTW * 16 / kConvThreads; it++) {
