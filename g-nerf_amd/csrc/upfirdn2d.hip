@@ -578,6 +578,27 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int c
     // (Measured and dropped: applying the rank-one binomial filter as a row pass + a column pass -- 8 FMAs per value and input row instead
     // of 16, detected from the taps on the device -- made the plain blur SLOWER, 4.4 -> 3.75 TB/s, and left the fused form at 2.6: 150
     // VGPRs instead of 137 and a dependent chain where the 2-D form has four independent ones.  The kernel is not bound by its FMA count.)
+    // float16 (round 5): the taps as packed halves for v_dot2_f32_f16 -- two COLUMNS of one channel per instruction, repacked from the
+    // loaded (channel, channel + 1) dwords by v_perm_b32 -- instead of 32 conversions + 64 packed fp32 FMAs per input row: the kernel is
+    // bound by its vector instructions, and this is the blur of csrc's NCHW kernel, which has formed its products this
+    // way since round 2.  Taps are split hi + lo, so any fp32 filter is applied to ~2^-22; the networks' [1,3,3,1] filters have lo = 0
+    // and that half is skipped by a wave-uniform branch.  The plain and the fused form are the same instantiation family: still bit-identical.
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 th[4][2], tl[4][2];
+    bool has_lo = false;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ky = 0; ky < 4; ky++)
+#pragma unroll
+            for (int kp = 0; kp < 2; kp++) {
+                const float t0 = tap[ky][2 * kp], t1 = tap[ky][2 * kp + 1];
+                const _Float16 h0 = (_Float16)t0, h1 = (_Float16)t1;
+                const _Float16 l0 = (_Float16)(t0 - (float)h0), l1 = (_Float16)(t1 - (float)h1);
+                th[ky][kp] = (h2){h0, h1};
+                tl[ky][kp] = (h2){l0, l1};
+                has_lo = has_lo || (float)l0 != 0.f || (float)l1 != 0.f;
+            }
+    }
     const int ix0 = ox - a.padx0;
     bool col_ok[4];
     int64_t col_off[4];
@@ -626,7 +647,8 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int c
     typedef float f2 __attribute__((ext_vector_type(2)));
     constexpr int DW = 16 / 4;                                      // dwords per vector
     struct alignas(16) Raw { unsigned d[DW]; };
-    f2 acc[4][VEC / 2];
+    f2 acc[4][VEC / 2];                                             // (fp32 tensors)
+    float hacc[4][VEC];                                             // (fp16 tensors: one fp32 accumulator per channel)
     Raw raw[4];
     auto fetch_raw = [&](int iy, Raw (&dst)[4]) {
         const int64_t row = int64_t(min(max(iy, 0), a.in_h - 1)) * a.xs_h;
@@ -648,6 +670,57 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int c
             const int s = s4 + u;                                   // input row iy_first + s
             if (s < steps) {                                        // (uniform over the strip's lanes)
                 const bool row_ok = iy_first + s >= 0 && iy_first + s < a.in_h;
+                if constexpr (sizeof(T) == 2) {
+                    unsigned p01[VEC], p23[VEC];                    // (column 0, column 1) and (column 2, column 3) of channel c
+                    {
+                        unsigned m[4][DW];
+#pragma unroll
+                        for (int kx = 0; kx < 4; kx++) {
+                            unsigned keep = (row_ok && col_ok[kx]) ? ~0u : 0u;
+                            asm volatile("" : "+v"(keep));            // keep it a mask: one AND per dword
+#pragma unroll
+                            for (int q = 0; q < DW; q++) m[kx][q] = raw[kx].d[q] & keep;
+                        }
+#pragma unroll
+                        for (int q = 0; q < DW; q++) {
+                            p01[2 * q]     = __builtin_amdgcn_perm(m[1][q], m[0][q], 0x05040100u);
+                            p01[2 * q + 1] = __builtin_amdgcn_perm(m[1][q], m[0][q], 0x07060302u);
+                            p23[2 * q]     = __builtin_amdgcn_perm(m[3][q], m[2][q], 0x05040100u);
+                            p23[2 * q + 1] = __builtin_amdgcn_perm(m[3][q], m[2][q], 0x07060302u);
+                        }
+                    }
+                    // (pin the repacked values in front of the store: left alone, the compiler sinks the masking below it, and the wait
+                    // for the loaded row then follows the store it must not wait for)
+#pragma unroll
+                    for (int c = 0; c < VEC; c += 4)
+                        asm volatile("" : "+v"(p01[c]), "+v"(p01[c + 1]), "+v"(p01[c + 2]), "+v"(p01[c + 3]), "+v"(p23[c]), "+v"(p23[c + 1]), "+v"(p23[c + 2]), "+v"(p23[c + 3]) :: "memory");
+                    if (pend_row >= 0) *reinterpret_cast<Pk<T, VEC>*>(y + int64_t(pend_row) * a.ys_h) = pend;
+                    fetch_raw(iy_first + s + 1, raw);               // (past the last step: a clamped, unused row -- no branch around the loads)
+                    __builtin_amdgcn_sched_barrier(0);
+                    // this row is tap row ky of output row s - ky; accumulator (s - ky) & 3 = (u - ky) & 3
+#pragma unroll
+                    for (int ky = 0; ky < 4; ky++) {
+                        float (&ac)[VEC] = hacc[(u - ky) & 3];
+#pragma unroll
+                        for (int c = 0; c < VEC; c++) {
+                            float v = ky == 0 ? 0.f : ac[c];
+                            v = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, p01[c]), th[ky][0], v, false);
+                            v = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, p23[c]), th[ky][1], v, false);
+                            ac[c] = v;
+                        }
+                    }
+                    if (has_lo) {                                   // wave-uniform: taps that are not exact in fp16
+#pragma unroll
+                        for (int ky = 0; ky < 4; ky++) {
+                            float (&ac)[VEC] = hacc[(u - ky) & 3];
+#pragma unroll
+                            for (int c = 0; c < VEC; c++) {
+                                ac[c] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, p01[c]), tl[ky][0], ac[c], false);
+                                ac[c] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, p23[c]), tl[ky][1], ac[c], false);
+                            }
+                        }
+                    }
+                } else {
                 f2 in[4][VEC / 2];
 #pragma unroll
                 for (int kx = 0; kx < 4; kx++) {
@@ -687,13 +760,16 @@ __global__ __launch_bounds__(256) void upfirdn_blur4_nhwc_kernel(UpArgs a, int c
                         ac[k] = v;
                     }
                 }
+                }
                 const int done = s - 3;                             // output row oy0 + done is complete
                 pend_row = -1;
                 if (done >= 0) {
                     Pk<T, VEC> out;
 #pragma unroll
                     for (int k = 0; k < VEC / 2; k++) {
-                        const f2 r = acc[(u - 3) & 3][k] * (f2){a.gain, a.gain};
+                        f2 r;
+                        if constexpr (sizeof(T) == 2) r = (f2){hacc[(u - 3) & 3][2 * k], hacc[(u - 3) & 3][2 * k + 1]} * (f2){a.gain, a.gain};
+                        else                          r = acc[(u - 3) & 3][k] * (f2){a.gain, a.gain};
                         store_as<T>(out.v, 2 * k, r[0]);
                         store_as<T>(out.v, 2 * k + 1, r[1]);
                     }
