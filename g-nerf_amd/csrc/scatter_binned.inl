@@ -38,6 +38,10 @@ constexpr int kBinCountThreads = 256;
 constexpr int kBinAccThreads = 1024;
 constexpr int kBinAccWaves = kBinAccThreads / 64;
 constexpr int kBinHaloTexels = 2 * kBinTile + 1;        // halo texels of a tile: right column (16), bottom row (16), corner
+#ifndef GNERF_BIN_WALK_UNROLL
+#define GNERF_BIN_WALK_UNROLL 1
+#endif
+constexpr int kBinWalkUnroll = GNERF_BIN_WALK_UNROLL;                       // samples per thread and trip of the walk kernels (loads of a trip issued together)
 constexpr int kBinBatch = 4;                            // records per scalar-load batch; segments are padded to whole batches
 
 struct BinRowCell { unsigned row, cell; };              // row: float index of the record's dX row in the staging buffer; cell: (ly * 17 + lx) * 32
@@ -190,41 +194,70 @@ __global__ __launch_bounds__(kBinCountThreads) void bin_walk_kernel(Params P, Bi
     const int loc0 = item * n_loc;                             // this item's plane tiles are [loc0, loc0 + n_loc)
     const int n_smp = 16 * n_all;
 
-    // ---- sweep 1: this workgroup's records per plane tile (and, count pass, the bound: max |dX| of the rows behind them)
-    for (int s = tid; s < n_smp; s += kBinCountThreads) {
-        const int ri = s / n_all, rank = s - ri * n_all;
-        const float* r = rays + ri * 8;
-        const int ray = reinterpret_cast<const int*>(r)[6];
-        if (ray < 0) continue;
-        const float* ray_block = A.stage + int64_t(ray) * P.bwd_ray_stride;
-        const float depth = ray_block[rank];
-        const float px = __fadd_rn(r[0], __fmul_rn(depth, r[3])) * P.box_scale;
-        const float py = __fadd_rn(r[1], __fmul_rn(depth, r[4])) * P.box_scale;
-        const float pz = __fadd_rn(r[2], __fmul_rn(depth, r[5])) * P.box_scale;
-        int hit[3];
-        bool any = false;
+    // ---- sweep 1: this workgroup's records per plane tile (and, count pass, the bound: max |dX| of the rows behind them).
+    // kBinWalkUnroll samples per thread at a time, every load of the group issued before the first is used.  (Measured with 1 / 2 / 3 / 6
+    // in flight: no difference -- the count pass reads every dX row once, 0.8 GB in 0.18 ms = 4.6 TB/s, and the fill pass writes 0.55 GB of
+    // records in 0.15 ms: both sit at the memory system's rate, not at its latency; profiles/r05_bin_walk_unroll.txt.  1 is shipped.)
+    for (int s0 = tid; s0 < n_smp; s0 += kBinWalkUnroll * kBinCountThreads) {
+        int rank[kBinWalkUnroll];
+        const float* block[kBinWalkUnroll];
+        const float* rayp[kBinWalkUnroll];
+        float depth[kBinWalkUnroll];
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) { hit[pl] = bin_hit(P, A, item, pl, px, py, pz).ptile; any = any || hit[pl] >= 0; }
-        if (!any) continue;
-        unsigned bits = 0;
-        if (!FILL) {
-            const v4f* row = reinterpret_cast<const v4f*>(ray_block + n_all + rank * 32);
-            float m = 0.f;
-            bool nan = false;
+        for (int u = 0; u < kBinWalkUnroll; u++) {
+            const int s = s0 + u * kBinCountThreads;
+            const int ri = min(s, n_smp - 1) / n_all;
+            rank[u] = min(s, n_smp - 1) - ri * n_all;
+            rayp[u] = rays + ri * 8;
+            const int ray = s < n_smp ? reinterpret_cast<const int*>(rayp[u])[6] : -1;
+            block[u] = ray >= 0 ? A.stage + int64_t(ray) * P.bwd_ray_stride : nullptr;
+            depth[u] = block[u] ? block[u][rank[u]] : 0.f;
+        }
+        int hit[kBinWalkUnroll][3];
+        bool any[kBinWalkUnroll];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const v4f x = row[q];
+        for (int u = 0; u < kBinWalkUnroll; u++) {
+            const float* r = rayp[u];
+            const float px = __fadd_rn(r[0], __fmul_rn(depth[u], r[3])) * P.box_scale;
+            const float py = __fadd_rn(r[1], __fmul_rn(depth[u], r[4])) * P.box_scale;
+            const float pz = __fadd_rn(r[2], __fmul_rn(depth[u], r[5])) * P.box_scale;
+            any[u] = false;
 #pragma unroll
-                for (int e = 0; e < 4; e++) { m = fmaxf(m, fabsf(x[e])); nan = nan || (x[e] != x[e]); }
+            for (int pl = 0; pl < 3; pl++) {
+                hit[u][pl] = block[u] ? bin_hit(P, A, item, pl, px, py, pz).ptile : -1;
+                any[u] = any[u] || hit[u][pl] >= 0;
             }
-            bits = nan ? 0x7fc00000u : __float_as_uint(m);     // (a NaN orders above every finite bound and above +inf)
+        }
+        unsigned bits[kBinWalkUnroll];
+        if (!FILL) {
+            v4f row[kBinWalkUnroll][8];
+#pragma unroll
+            for (int u = 0; u < kBinWalkUnroll; u++) {
+                const v4f* src = reinterpret_cast<const v4f*>((any[u] ? block[u] : A.stage) + n_all + (any[u] ? rank[u] : 0) * 32);      // (no record: any valid row, unused)
+#pragma unroll
+                for (int q = 0; q < 8; q++) row[u][q] = src[q];
+            }
+#pragma unroll
+            for (int u = 0; u < kBinWalkUnroll; u++) {
+                float m = 0.f;
+                bool nan = false;
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { m = fmaxf(m, fabsf(row[u][q][e])); nan = nan || (row[u][q][e] != row[u][q][e]); }
+                bits[u] = nan ? 0x7fc00000u : __float_as_uint(m);     // (a NaN orders above every finite bound and above +inf)
+            }
         }
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++)
-            if (hit[pl] >= 0) {
-                atomicAdd(hist + (hit[pl] - loc0), 1);
-                if (!FILL) atomicMax(aux + (hit[pl] - loc0), bits);
-            }
+        for (int u = 0; u < kBinWalkUnroll; u++) {
+            if (!any[u]) continue;
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+                if (hit[u][pl] >= 0) {
+                    atomicAdd(hist + (hit[u][pl] - loc0), 1);
+                    if (!FILL) atomicMax(aux + (hit[u][pl] - loc0), bits[u]);
+                }
+        }
     }
     __syncthreads();
     // ---- publish: one global atomic per plane tile this ray tile touches
@@ -241,26 +274,39 @@ __global__ __launch_bounds__(kBinCountThreads) void bin_walk_kernel(Params P, Bi
     }
     if (!FILL) return;
     __syncthreads();
-    // ---- sweep 2 (fill pass): the records
-    for (int s = tid; s < n_smp; s += kBinCountThreads) {
-        const int ri = s / n_all, rank = s - ri * n_all;
-        const float* r = rays + ri * 8;
-        const int ray = reinterpret_cast<const int*>(r)[6];
-        if (ray < 0) continue;
-        const int64_t block = int64_t(ray) * P.bwd_ray_stride;
-        const float depth = A.stage[block + rank];
-        const float px = __fadd_rn(r[0], __fmul_rn(depth, r[3])) * P.box_scale;
-        const float py = __fadd_rn(r[1], __fmul_rn(depth, r[4])) * P.box_scale;
-        const float pz = __fadd_rn(r[2], __fmul_rn(depth, r[5])) * P.box_scale;
+    // ---- sweep 2 (fill pass): the records, the same kBinWalkUnroll samples per thread at a time
+    for (int s0 = tid; s0 < n_smp; s0 += kBinWalkUnroll * kBinCountThreads) {
+        int rank[kBinWalkUnroll];
+        int64_t block[kBinWalkUnroll];
+        const float* rayp[kBinWalkUnroll];
+        float depth[kBinWalkUnroll];
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-            const BinHit h = bin_hit(P, A, item, pl, px, py, pz);
-            if (h.ptile < 0) continue;
-            const int loc = h.ptile - loc0;
-            const unsigned at = aux[loc] + unsigned(atomicAdd(hist + loc, 1));
-            const int sw = bin_weight_scale(A.scale[h.ptile]);
-            A.rc[at] = BinRowCell{unsigned(block + n_all + int64_t(rank) * 32), h.cell};
-            A.wt[at] = (BinWeights){ldexpf(h.w[0], sw), ldexpf(h.w[1], sw), ldexpf(h.w[2], sw), ldexpf(h.w[3], sw)};
+        for (int u = 0; u < kBinWalkUnroll; u++) {
+            const int s = s0 + u * kBinCountThreads;
+            const int ri = min(s, n_smp - 1) / n_all;
+            rank[u] = min(s, n_smp - 1) - ri * n_all;
+            rayp[u] = rays + ri * 8;
+            const int ray = s < n_smp ? reinterpret_cast<const int*>(rayp[u])[6] : -1;
+            block[u] = ray >= 0 ? int64_t(ray) * P.bwd_ray_stride : -1;
+            depth[u] = block[u] >= 0 ? A.stage[block[u] + rank[u]] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kBinWalkUnroll; u++) {
+            if (block[u] < 0) continue;
+            const float* r = rayp[u];
+            const float px = __fadd_rn(r[0], __fmul_rn(depth[u], r[3])) * P.box_scale;
+            const float py = __fadd_rn(r[1], __fmul_rn(depth[u], r[4])) * P.box_scale;
+            const float pz = __fadd_rn(r[2], __fmul_rn(depth[u], r[5])) * P.box_scale;
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                const BinHit h = bin_hit(P, A, item, pl, px, py, pz);
+                if (h.ptile < 0) continue;
+                const int loc = h.ptile - loc0;
+                const unsigned at = aux[loc] + unsigned(atomicAdd(hist + loc, 1));
+                const int sw = bin_weight_scale(A.scale[h.ptile]);
+                A.rc[at] = BinRowCell{unsigned(block[u] + n_all + int64_t(rank[u]) * 32), h.cell};
+                A.wt[at] = (BinWeights){ldexpf(h.w[0], sw), ldexpf(h.w[1], sw), ldexpf(h.w[2], sw), ldexpf(h.w[3], sw)};
+            }
         }
     }
 }
@@ -393,32 +439,37 @@ __global__ __launch_bounds__(kBinAccThreads, 8) void bin_accumulate_kernel(BinAc
             auto batch_of = [&](int k) { return min(wv + k * kBinAccWaves, nb - 1) * kBinBatch; };     // (past the end: the last batch again, loaded and not used)
             // Three stages in flight: (row, cell) of batch k+2 and the weights of batch k+1 on their way through the scalar cache, the
             // four dX rows of batch k+1 on their way through the vector cache, batch k being added.
-            u8v rcA = bin_sload_rc(rc0 + batch_of(0)), rcB = bin_sload_rc(rc0 + batch_of(1));
-            f16v wA = bin_sload_wt(wt0 + batch_of(0));
-            bin_smem_wait(rcA, wA);
-            asm volatile("" : "+s"(rcB));                                  // (behind the wait above: asm volatile statements keep their order)
-            float dA[kBinBatch], dB[kBinBatch];
-#pragma unroll
-            for (int u = 0; u < kBinBatch; u++) dA[u] = (A.stage + rcA[2 * u])[ch];
-            for (int k = 0; wv + k * kBinAccWaves < nb; k++) {
-                u8v rcC = bin_sload_rc(rc0 + batch_of(k + 2));
-                f16v wB = bin_sload_wt(wt0 + batch_of(k + 1));
-#pragma unroll
-                for (int u = 0; u < kBinBatch; u++) dB[u] = (A.stage + rcB[2 * u])[ch];
-#pragma unroll
-                for (int u = 0; u < kBinBatch; u++) {
-                    const float d = ldexpf(dA[u], s_dx);                 // (s_dx = 0 unless the tile's bound is below 2^-3)
-                    // (the four weights as scalars of their own: written `half ? wA[4u+2] : wA[4u]` the select becomes a DYNAMIC index into
-                    //  the 16-register vector, which the compiler lowers to a chain of sixteen compares and selects per weight)
-                    float a0 = wA[4 * u], a1 = wA[4 * u + 1], a2 = wA[4 * u + 2], a3 = wA[4 * u + 3];
-                    asm volatile("" : "+s"(a0), "+s"(a1), "+s"(a2), "+s"(a3));
-                    bin_add_fixed(acc, int(rcA[2 * u + 1]) + lane_cell, a0, a1, a2, a3, d * m0, d * m1);
+            // (two copies of the loop, chosen per tile: with the rescaling a run-time no-op the compiler keeps a v_ldexp_f32 and a select per
+            //  record -- 2 of 21 vector instructions in a kernel whose time IS its vector instructions, profiles/r05_backward_kernel_counters.json)
+            auto run = [&](auto rescale) {
+                u8v rcA = bin_sload_rc(rc0 + batch_of(0)), rcB = bin_sload_rc(rc0 + batch_of(1));
+                f16v wA = bin_sload_wt(wt0 + batch_of(0));
+                bin_smem_wait(rcA, wA);
+                asm volatile("" : "+s"(rcB));                                  // (behind the wait above: asm volatile statements keep their order)
+                float dA[kBinBatch], dB[kBinBatch];
+    #pragma unroll
+                for (int u = 0; u < kBinBatch; u++) dA[u] = (A.stage + rcA[2 * u])[ch];
+                for (int k = 0; wv + k * kBinAccWaves < nb; k++) {
+                    u8v rcC = bin_sload_rc(rc0 + batch_of(k + 2));
+                    f16v wB = bin_sload_wt(wt0 + batch_of(k + 1));
+    #pragma unroll
+                    for (int u = 0; u < kBinBatch; u++) dB[u] = (A.stage + rcB[2 * u])[ch];
+    #pragma unroll
+                    for (int u = 0; u < kBinBatch; u++) {
+                        const float d = decltype(rescale)::value ? ldexpf(dA[u], s_dx) : dA[u];      // (s_dx = 0 unless the tile's bound is below 2^-3)
+                        // (the four weights as scalars of their own: written `half ? wA[4u+2] : wA[4u]` the select becomes a DYNAMIC index into
+                        //  the 16-register vector, which the compiler lowers to a chain of sixteen compares and selects per weight)
+                        float a0 = wA[4 * u], a1 = wA[4 * u + 1], a2 = wA[4 * u + 2], a3 = wA[4 * u + 3];
+                        asm volatile("" : "+s"(a0), "+s"(a1), "+s"(a2), "+s"(a3));
+                        bin_add_fixed(acc, int(rcA[2 * u + 1]) + lane_cell, a0, a1, a2, a3, d * m0, d * m1);
+                    }
+                    bin_smem_wait(rcC, wB);                                     // (also retires this batch's LDS adds: one counter)
+                    rcA = rcB; rcB = rcC; wA = wB;
+    #pragma unroll
+                    for (int u = 0; u < kBinBatch; u++) dA[u] = dB[u];
                 }
-                bin_smem_wait(rcC, wB);                                     // (also retires this batch's LDS adds: one counter)
-                rcA = rcB; rcB = rcC; wA = wB;
-#pragma unroll
-                for (int u = 0; u < kBinBatch; u++) dA[u] = dB[u];
-            }
+            };
+            if (s_dx != 0) run(std::true_type{}); else run(std::false_type{});
         }
         __syncthreads();
         // ---- the tile's own texels: added to grad_planes (plain load + store: this workgroup is the only writer of them)

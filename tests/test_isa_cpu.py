@@ -205,3 +205,28 @@ def test_built_library_has_no_such_instruction_anywhere():
     assert not blind, blind
     assert not any(v['text_pk_src1_hi'] for v in kernels.values())
     assert sum(1 for v in kernels.values() if v['pk_mov_src1_hi']) == 0           # v_pk_mov_b32 with OP_SEL[1]: none today (it would be listed, not rewritten)
+    # no kernel names the destination of a scalar load in front of the s_waitcnt lgkmcnt(0) that covers it (the kernels that issue
+    # s_load from asm statements -- bin_accumulate_kernel -- are the ones the compiler cannot protect)
+    early = {n: v['smem_read_before_wait'] for n, v in kernels.items() if v['smem_read_before_wait']}
+    assert not early, early
+    assert any('bin_accumulate_kernel' in n for n in kernels)
+
+
+def test_scalar_load_tracker_flags_a_copy_in_front_of_the_wait():
+    """The pattern that faulted in round 5: the register allocator coalesced `rcB = rcC` into the wait's operand and copied the
+    registers of an s_load issued from an asm statement BEFORE the wait."""
+    import isa_lint
+    bad = isa_lint.SmemTracker()
+    for line in ('s_load_dwordx8 s[52:59], s[52:53], 0x0', 'v_mul_f32_e32 v1, v2, v3', 's_mov_b64 s[36:37], s[52:53]', 's_waitcnt lgkmcnt(0)', 's_mov_b64 s[38:39], s[54:55]'):
+        bad.feed(line)
+    assert len(bad.hits) == 1 and 's52' in bad.hits[0]
+    good = isa_lint.SmemTracker()
+    for line in ('s_load_dwordx8 s[52:59], s[52:53], 0x0', 's_load_dwordx2 s[4:5], s[0:1], 0x10', 'ds_read_b32 v1, v2', 's_waitcnt lgkmcnt(1)',
+                 'v_add_u32_e32 v1, s60, v1', 's_waitcnt vmcnt(0) lgkmcnt(0)', 's_add_u32 s4, s4, s52', 's_load_dword s7, s[4:5], 0x0', 's_endpgm'):
+        good.feed(line)
+    assert not good.hits
+    # an lgkmcnt above zero does not cover a scalar load (they return out of order); a load whose ADDRESS is in flight is flagged too
+    t = isa_lint.SmemTracker()
+    for line in ('s_load_dwordx2 s[4:5], s[0:1], 0x0', 's_waitcnt lgkmcnt(1)', 's_load_dword s7, s[4:5], 0x0'):
+        t.feed(line)
+    assert len(t.hits) == 1

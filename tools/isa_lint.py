@@ -12,6 +12,8 @@ Two readers that share NOTHING but the instruction boundaries llvm-objdump print
     what the pass itself would see.  A disagreement between the two readers on any instruction is an error of its own: it means the
     pass is blind (or this decoder is wrong), whichever way round.
 The opcode numbers are the toolchain's: tests/test_isa_cpu.py assembles one instruction of each kind and holds this table to it.
+Round 5 adds a second check on the same disassembly: no instruction may name the destination of a scalar load in front of the
+s_waitcnt lgkmcnt(0) that covers it (class SmemTracker: what an s_load inside an asm statement can lead the register allocator into).
 usage: tools/isa_lint.py [library]      exit status 1 on an error; --json for one JSON line"""
 import json, os, re, struct, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,6 +48,50 @@ def decode(w0):
 
 def src1_high_for_low(op_sel):
     return bool(op_sel & 2)                                     # OP_SEL[1]: the low result takes the high register of src1
+
+
+SREG = re.compile(r'\bs(\d+)\b|\bs\[(\d+):(\d+)\]')
+
+
+def sgprs(text):
+    """the scalar registers an operand text names"""
+    out = set()
+    for m in SREG.finditer(text):
+        if m.group(1) is not None: out.add(int(m.group(1)))
+        else: out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+class SmemTracker:
+    """Scalar loads complete out of order and only `s_waitcnt lgkmcnt(0)` covers them.  The compiler obeys that for its own loads; an
+    s_load inside an `asm` statement is invisible to it, and a register copy the allocator places between the asm statement and the
+    wait reads registers that have not landed (csrc/scatter_binned.inl met exactly that: a memory fault).  A linear scan per kernel:
+    destinations of s_load / s_buffer_load stay `in flight` until an s_waitcnt whose lgkmcnt is 0; any instruction that names one of
+    them meanwhile is reported.  (Straight-line approximation: the set is dropped at unconditional branches and at the program's end.)"""
+    def __init__(self):
+        self.inflight, self.hits = set(), []
+
+    def feed(self, text):
+        parts = text.split(None, 1)
+        if not parts: return
+        op, rest = parts[0], (parts[1] if len(parts) > 1 else '')
+        if op == 's_waitcnt':
+            if re.search(r'lgkmcnt\(0\)', rest) or re.fullmatch(r'0(x0)?', rest.strip()): self.inflight.clear()
+            return
+        if op in ('s_branch', 's_endpgm', 's_setpc_b64', 's_swappc_b64'):
+            self.inflight.clear()
+            return
+        named = sgprs(rest)
+        if op.startswith('s_load_dword') or op.startswith('s_buffer_load_dword'):
+            ops = [o.strip() for o in rest.split(',')]
+            dst = sgprs(ops[0]) if ops else set()
+            src = named - dst if len(ops) > 1 and not (sgprs(','.join(ops[1:])) & dst) else sgprs(','.join(ops[1:]))
+            bad = src & self.inflight
+            if bad and len(self.hits) < 4: self.hits.append('%s   // reads s%s of a scalar load still in flight' % (text[:100], sorted(bad)[0]))
+            self.inflight |= dst
+            return
+        bad = named & self.inflight
+        if bad and len(self.hits) < 4: self.hits.append('%s   // names s%s of a scalar load still in flight' % (text[:100], sorted(bad)[0]))
 
 
 def code_objects(lib, tmp):
@@ -85,7 +131,8 @@ def lint(lib):
             m = re.match(r'^[0-9a-f]+ <(.+)>:$', line)
             if m:
                 name = m.group(1)
-                kernels.setdefault(name, {'pk_src1_hi': 0, 'pk_mov_src1_hi': 0, 'mfma_16x16x32': 0, 'first': None, 'text_pk_src1_hi': 0, 'disagree': []})
+                kernels.setdefault(name, {'pk_src1_hi': 0, 'pk_mov_src1_hi': 0, 'mfma_16x16x32': 0, 'first': None, 'text_pk_src1_hi': 0, 'disagree': [],
+                                          'smem': SmemTracker()})
                 continue
             if name is None: continue
             k = kernels[name]
@@ -102,11 +149,13 @@ def lint(lib):
                         k['first'] = k['first'] or ('%s op_sel=%s  // %s' % (detail[0], format(detail[1], '03b')[::-1], w.group(2).strip()))
             # the text reader: exactly what the build's pass would match
             text = re.sub(r'\s*//.*$', '', line).strip()
+            k['smem'].feed(text)
             t = FX.INSTR.match(text) if 'v_pk_' in line else None
             by_text = bool(t and FX.hazardous(FX.split_operands(t.group(3))[1])) if t else None
             if by_text: k['text_pk_src1_hi'] += 1
             if (by_words is None) != (by_text is None) or (by_words is not None and by_words != by_text):
                 if len(k['disagree']) < 4: k['disagree'].append(line.strip()[:160])
+    for v in kernels.values(): v['smem_read_before_wait'] = v.pop('smem').hits
     return kernels
 
 
@@ -117,17 +166,20 @@ def main(argv):
     errors = {n: v for n, v in k.items() if v['pk_src1_hi']}                 # anywhere in the library: waves of other kernels share SIMDs too
     blind = {n: v['disagree'] for n, v in k.items() if v['disagree']}
     movs = {n: v['pk_mov_src1_hi'] for n, v in k.items() if v['pk_mov_src1_hi']}
+    early = {n: v['smem_read_before_wait'] for n, v in k.items() if v['smem_read_before_wait']}
     if '--json' in argv:
         print(json.dumps({'library': os.path.basename(lib), 'kernels': len(k), 'with_mfma_16x16x32': sum(1 for v in k.values() if v['mfma_16x16x32']),
-                          'errors': {n: v['pk_src1_hi'] for n, v in errors.items()}, 'readers_disagree': blind, 'v_pk_mov_b32_op_sel1': movs}))
+                          'errors': {n: v['pk_src1_hi'] for n, v in errors.items()}, 'readers_disagree': blind, 'v_pk_mov_b32_op_sel1': movs,
+                          'scalar_load_read_before_wait': early}))
     else:
         print('%d kernels, %d with a 16x16x32 matrix instruction (decoded from the instruction words)' % (len(k), sum(1 for v in k.values() if v['mfma_16x16x32'])))
         for n, v in errors.items():
             print('ERROR %s: %d packed-fp32 instruction(s) select the high register of src1%s, e.g. %s' %
                   (n[:90], v['pk_src1_hi'], '' if v['mfma_16x16x32'] else ' (no 16x16x32 matrix instruction in this kernel)', v['first']))
         for n, v in blind.items(): print('ERROR %s: the word decoder and the build pass\'s text parser disagree on %s' % (n[:90], v))
+        for n, v in early.items(): print('ERROR %s: a scalar load\'s destination is used in front of the s_waitcnt lgkmcnt(0) that covers it: %s' % (n[:90], v))
         for n, c in movs.items(): print('note  %s: %d v_pk_mov_b32 with OP_SEL[1] (its low result reads src0 only)' % (n[:90], c))
-    return 1 if errors or blind else 0
+    return 1 if errors or blind or early else 0
 
 
 if __name__ == '__main__':
