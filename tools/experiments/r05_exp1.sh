@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 experiment 1 (GPU box): A/B of the shade tile's lookup order and LDS layouts, the clock / placement stamps, and
 # the counter attribution of LDS bank conflicts and waits.   bash tools/r05_exp1.sh
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
 O=$R/gpurun_out/r05_exp1
 mkdir -p $O

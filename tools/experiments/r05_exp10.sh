@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 experiment 10: fused conv with fragment reads pipelined across steps (GNERF_CONV_PIPE=1, the default) against the first two-workgroup loop.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
 O=$R/gpurun_out/r05_exp10
 mkdir -p $O

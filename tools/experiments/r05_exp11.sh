@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 experiment 11: the shared epilogue with paired fp16 rounding / scaling and the conv's clamp unswitched: GPU suite, conv and blur timings.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
 O=$R/gpurun_out/r05_exp11
 mkdir -p $O

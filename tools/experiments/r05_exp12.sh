@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 experiment 12: channels_last fp16 blur on v_dot2_f32_f16 (pairs of columns): parity of everything that blurs, then the op timings.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
 O=$R/gpurun_out/r05_exp12
 mkdir -p $O

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 experiment 14: the binned scatter after the accumulate kernel's instruction diet: parity first (stop at the first failure), then timing.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
 O=$R/gpurun_out/r05_exp14
 mkdir -p $O

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 experiment 2: slot reads in one round trip (new base) vs the round-4 kernel, with the pinned lookup orders / LDS layouts.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
 O=$R/gpurun_out/r05_exp2
 mkdir -p $O

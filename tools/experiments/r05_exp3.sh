@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 experiment 3: the binned plane-gradient scatter -- parity, timing against the sorted form, kernel times.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
 O=$R/gpurun_out/r05_exp3
 mkdir -p $O

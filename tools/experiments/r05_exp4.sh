@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 experiment 4: binned scatter v2 (scalar-load records) + the fused conv's first light.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
 O=$R/gpurun_out/r05_exp4
 mkdir -p $O

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 experiment 5: fused conv v2 (software-pipelined k-steps): parity test, SR-shape timing, generator tests with the fused conv.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
 O=$R/gpurun_out/r05_exp5
 mkdir -p $O

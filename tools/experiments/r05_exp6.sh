@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 experiment 6: fused conv as two workgroups per CU (64-channel chunks, 76 KB of LDS each); then the whole GPU suite on this build.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
 O=$R/gpurun_out/r05_exp6
 mkdir -p $O

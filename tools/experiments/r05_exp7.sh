@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 experiment 7: clocks under different loads; counters of the fused conv; binned scatter with 8 x 8 plane tiles; orbit profile.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
 O=$R/gpurun_out/r05_exp7
 mkdir -p $O

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 experiment 8: conv with conflict-free input-tile swizzle, operands by LDS-DMA, launcher-checked lrelu slope; blur + epilogue with the same.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
 O=$R/gpurun_out/r05_exp8
 mkdir -p $O

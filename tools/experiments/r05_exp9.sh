@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 experiment 9: what the fused conv waits for -- timing-only builds without the per-step weight fetch / the later input chunks / the per-step barrier.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
 O=$R/gpurun_out/r05_exp9
 mkdir -p $O
