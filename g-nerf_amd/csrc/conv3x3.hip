@@ -67,13 +67,22 @@ struct ConvArgs {
     const float* next_scale;    // [n, cout] or NULL
     int n, h, w, cin, cout;
     int tiles_x, tiles_y, n_tiles;
+    int out_h, out_w;           // transposed form: 2 h + 1, 2 w + 1 (the convolution: h, w)
     int round_noise;
     float alpha, gain, clamp;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <bool SCALE, bool NOISE, bool NEXT>
+// MODE 0: the 3x3 convolution (padding 1) with the epilogue.
+// MODE 1 (round 5): the stride-2 TRANSPOSED 3x3 convolution of the x2 layers (conv_transpose2d(x, w, stride 2): 2H + 1 outputs per axis; what
+// conv2d_resample.py:109-119 hands to the framework's transposed convolution), as its four output phases: output (2m + py, 2n + px) =
+// sum over a in A(py), b in A(px) of x[m - a, n - b] . w[ky = py + 2a, kx = px + 2b], A(0) = {0, 1}, A(1) = {0} -- an ordinary
+// convolution over the INPUT grid with 4, 2, 2 or 1 of the taps (dy, dx) = (1 - a, 1 - b) of the 3x3 stencil, so the staging, the
+// fragment addressing and the MFMA loop are the convolution's; a job is (phase, tile of 8 x 32 positions (m, n)), the result goes out
+// as plain fp16 at stride 2 (the blur + epilogue pass that follows reads it).  Weights arrive packed per phase: [9][cout][cin] in the order
+// phase (0,0): taps (a,b) = (0,0), (0,1), (1,0), (1,1); phase (0,1): a = 0, 1; phase (1,0): b = 0, 1; phase (1,1): the one tap.
+template <int MODE, bool SCALE, bool NOISE, bool NEXT>
 __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvArgs a) {
     extern __shared__ __align__(16) char lds[];
     char* const xs = lds;                           // [340 pixels][8 slots of 16 bytes], slot ^= pixel & 7
@@ -87,11 +96,28 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     const int tile = (blockIdx.x % kNumXCD) * per_xcd + blockIdx.x / kNumXCD;
     if (tile >= a.n_tiles) return;
     const int tiles_img = a.tiles_x * a.tiles_y;
-    const int n = tile / tiles_img, tt = tile - n * tiles_img;
+    const int H = a.h, W = a.w, Cin = a.cin, Cout = a.cout;
+    // transposed form: the phase is the slowest index of the job sequence (the four-tap phase first: the longest jobs start first)
+    const int ph = MODE == 1 ? tile / (a.n * tiles_img) : 0;
+    const int tile_p = MODE == 1 ? tile - ph * (a.n * tiles_img) : tile;
+    const int ph_y = ph >> 1, ph_x = ph & 1;                            // (py, px)
+    const int n_taps = MODE == 1 ? (2 - ph_y) * (2 - ph_x) : 9;
+    const int tap_base = MODE == 1 ? (ph == 0 ? 0 : ph == 1 ? 4 : ph == 2 ? 6 : 8) : 0;
+    const int n = tile_p / tiles_img, tt = tile_p - n * tiles_img;
     const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
     const int y0 = ty * kTH, x0 = tx * kTW;
     const int co0 = blockIdx.y * kCO;
-    const int H = a.h, W = a.w, Cin = a.cin, Cout = a.cout;
+    const int Hp = MODE == 1 ? H + 1 - ph_y : H, Wp = MODE == 1 ? W + 1 - ph_x : W;      // positions of this phase per axis
+    if (MODE == 1 && (y0 >= Hp || x0 >= Wp)) return;                   // a tile of the 8 x 32 grid over (H + 1) x (W + 1) that an odd phase does not have
+    // (dy, dx) of tap t of this job in the staged input tile (whose origin is one pixel up and left of the tile's first position)
+    auto tap_shift = [&](int t, int& dy, int& dx) {
+        if (MODE == 1) {
+            const int ta = ph_y ? 0 : (ph_x ? t : t >> 1), tb = ph_x ? 0 : (ph_y ? t : t & 1);
+            dy = 1 - ta; dx = 1 - tb;
+        } else {
+            dy = t / 3; dx = t - dy * 3;
+        }
+    };
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<_Float16*>(a.x) + size_t(n) * H * W * Cin, 0, int(size_t(H) * W * Cin * 2), 0x00020000);
@@ -113,7 +139,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
         }
     };
     auto stage_w = [&](int tap, int cin0, int buf) {
-        const _Float16* src = a.wpk + (size_t(tap) * Cout + co0) * Cin + cin0;
+        const _Float16* src = a.wpk + (size_t(tap_base + tap) * Cout + co0) * Cin + cin0;
 #pragma unroll
         for (int it = 0; it < kWRounds; it++) {
             const int q = it * kConvThreads + tid;
@@ -142,7 +168,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     }
     if (wv == 0 && a.bias) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + co0 + 2 * tid),
                                                             (lds_ptr_t)(ep + 1024), 4, 0, 0);
-    const int n_chunks = Cin / kCK, total = n_chunks * 9;
+    const int n_chunks = Cin / kCK, total = n_chunks * n_taps;
     // ---- main loop, software-pipelined ACROSS steps.  A step (one tap of one 64-channel chunk) is two k-steps of 32 MFMAs; while
     // the MFMAs of one k-step issue, the twelve fragments of the NEXT k-step are read -- the second k-step of this step, or the first
     // of the next step.  The one barrier of a step sits between its two k-steps: there the next step's weights (requested a step
@@ -158,7 +184,9 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     const int alane = r * kRow + ((hq ^ ((r >> 1) & 7)) << 4);
     auto load_frag = [&](int s, int kc, int f, h8 (&Af)[8], h8 (&Bf)[4]) {
         if (f < 4) {
-            const int chunk = s / 9, tap = s - chunk * 9, dy = tap / 3, dx = tap - dy * 3;
+            const int chunk = s / n_taps, tap = s - chunk * n_taps;
+            int dy, dx;
+            tap_shift(tap, dy, dx);
             const int row = xlane + (((f >> 1) + dy) * kIW + dx) * kRow;          // pixel index * 128
             const int slot = (hq ^ (row >> 7)) & 7;
             Bf[f] = *reinterpret_cast<const h8*>(xs + ((row + (slot << 4)) ^ (kc << 6)) + (f & 1) * 16 * kRow);
@@ -194,7 +222,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
         mfma_group(3, Ac, Bc);
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto stage_w_step = [&](int s) { const int c = s / 9; stage_w(s - c * 9, c * kCK, s & 1); };
+    auto stage_w_step = [&](int s) { const int c = s / n_taps; stage_w(s - c * n_taps, c * kCK, s & 1); };
     stage_x(0);
     stage_w_step(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -204,13 +232,13 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
 #pragma unroll
     for (int f = 0; f < 12; f++) load_frag(0, 0, f, A[0], B[0]);
     for (int s = 0; s < total; s++) {
-        const int chunk = s / 9, tap = s - chunk * 9;
+        const int chunk = s / n_taps, tap = s - chunk * n_taps;
         phase(A[0], B[0], true, s, 1, A[1], B[1]);
         // (bare waits and barrier: __syncthreads() would drain vmcnt where the compiler sees fit)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const bool more = s + 1 < total, new_chunk = more && tap == 8;
+        const bool more = s + 1 < total, new_chunk = more && tap == n_taps - 1;
         if (s + 2 < total) stage_w_step(s + 2);
         if (new_chunk) stage_x((chunk + 1) * kCK);
         phase(A[1], B[1], more && !new_chunk, s + 1, 0, A[0], B[0]);
@@ -256,12 +284,14 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             for (int k = 0; k < 4; k++) in.v[k] = __float2half(acc[cb][pb][k]);          // what the convolution alone would have stored
             float nz = 0.f;
             if constexpr (NOISE) nz = a.noise[(y0 + prow) * W + x0 + pcol];
-            const Pk<__half, 4> out = modconv_epilogue_vec<__half, 4, kActLrelu01, SCALE, NOISE, NEXT>(in, sc, nz, a.round_noise != 0, bv, nx, a.alpha, a.gain, clampv);
+            Pk<__half, 4> out;
+            if constexpr (MODE == 1) out = in;                         // the transposed convolution leaves as plain fp16 (blur + epilogue follow)
+            else out = modconv_epilogue_vec<__half, 4, kActLrelu01, SCALE, NOISE, NEXT>(in, sc, nz, a.round_noise != 0, bv, nx, a.alpha, a.gain, clampv);
             *reinterpret_cast<uint2*>(os + p * 256 + (((c4 >> 3) ^ (p & 15)) << 4) + ((c4 >> 2) & 1) * 8) = __builtin_bit_cast(uint2, out);
         }
     }
     };
-    if (a.clamp >= 0.f) registers_to_lds(std::true_type{}); else registers_to_lds(std::false_type{});
+    if (MODE == 0 && a.clamp >= 0.f) registers_to_lds(std::true_type{}); else registers_to_lds(std::false_type{});
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < kTH * kTW * 16 / kConvThreads; it++) {
@@ -269,7 +299,12 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
         const int p = q >> 4, slot = q & 15;
         const uint4 v = *reinterpret_cast<const uint4*>(os + p * 256 + ((slot ^ (p & 15)) << 4));
         const int yy = y0 + p / kTW, xx = x0 + (p & (kTW - 1));
-        *reinterpret_cast<uint4*>(a.y + (size_t(n) * H * W + size_t(yy) * W + xx) * Cout + co0 + slot * 8) = v;
+        if constexpr (MODE == 1) {                                     // position (yy, xx) of phase (py, px) -> output pixel (2 yy + py, 2 xx + px); the grid of tiles overhangs
+            if (yy < Hp && xx < Wp)
+                *reinterpret_cast<uint4*>(a.y + ((size_t(n) * a.out_h + size_t(2 * yy + ph_y)) * a.out_w + size_t(2 * xx + ph_x)) * Cout + co0 + slot * 8) = v;
+        } else {
+            *reinterpret_cast<uint4*>(a.y + (size_t(n) * H * W + size_t(yy) * W + xx) * Cout + co0 + slot * 8) = v;
+        }
     }
 }
 
@@ -296,6 +331,7 @@ extern "C" int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, 
     a.scale = scale; a.noise = noise; a.bias = static_cast<const __half*>(bias); a.next_scale = next_scale;
     a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
     a.tiles_x = w / kTW; a.tiles_y = h / kTH; a.n_tiles = n * a.tiles_x * a.tiles_y;
+    a.out_h = h; a.out_w = w;
     a.round_noise = round_noise; a.alpha = alpha; a.gain = gain; a.clamp = clamp;
     const dim3 grid((a.n_tiles + kNumXCD - 1) / kNumXCD * kNumXCD, cout / kCO), block(kConvThreads);
     hipStream_t s = as_stream(stream);
@@ -304,11 +340,11 @@ extern "C" int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, 
         int dev = 0; \
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0; \
         if (!raised[dev]) { \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_epilogue_kernel<SC, NZ, NX>), hipFuncAttributeMaxDynamicSharedMemorySize, kConvLds) != hipSuccess) \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_epilogue_kernel<0, SC, NZ, NX>), hipFuncAttributeMaxDynamicSharedMemorySize, kConvLds) != hipSuccess) \
                 return fail(GNERF_E_LAUNCH, "conv3x3_epilogue_nhwc: cannot raise the dynamic LDS limit"); \
             raised[dev] = true; \
         } \
-        hipLaunchKernelGGL((conv3x3_epilogue_kernel<SC, NZ, NX>), grid, block, kConvLds, s, a); } while (0)
+        hipLaunchKernelGGL((conv3x3_epilogue_kernel<0, SC, NZ, NX>), grid, block, kConvLds, s, a); } while (0)
     const int key = (scale ? 4 : 0) | (noise ? 2 : 0) | (next_scale ? 1 : 0);
     switch (key) {
         case 0: GNERF_CONV(false, false, false); break;
@@ -322,4 +358,37 @@ extern "C" int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, 
     }
 #undef GNERF_CONV
     return check_launch("conv3x3_epilogue_nhwc");
+}
+
+// y = conv_transpose2d(x, w, stride = 2) for 3x3 kernels on float16 channels_last tensors, as four phase convolutions; see include/gnerf_hip.h.
+extern "C" int gnerf_conv_transpose3x3_s2_nhwc(const void* x, const void* w_phases, void* y, int n, int h, int w, int cin, int cout, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!x || !w_phases || !y) return fail(GNERF_E_ARG, "conv_transpose3x3_s2_nhwc: null pointer");
+    if (n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return fail(GNERF_E_ARG, "conv_transpose3x3_s2_nhwc: empty tensor");
+    if (cin % kCK || cout % kCO)
+        return fail(GNERF_E_UNSUPPORTED, "conv_transpose3x3_s2_nhwc: needs input channels %% 64 == 0, output channels %% 128 == 0 (got %d -> %d)", cin, cout);
+    if (size_t(h) * w * cin * 2 >= (size_t(1) << 31)) return fail(GNERF_E_UNSUPPORTED, "conv_transpose3x3_s2_nhwc: one image of x must stay below 2 GB");
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_phases) | reinterpret_cast<uintptr_t>(y)) & 15)
+        return fail(GNERF_E_ARG, "conv_transpose3x3_s2_nhwc: x, w and y must be 16-byte aligned");
+    ConvArgs a;
+    a.x = static_cast<const _Float16*>(x); a.wpk = static_cast<const _Float16*>(w_phases); a.y = static_cast<_Float16*>(y);
+    a.scale = nullptr; a.noise = nullptr; a.bias = nullptr; a.next_scale = nullptr;
+    a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
+    a.tiles_x = (w + 1 + kTW - 1) / kTW; a.tiles_y = (h + 1 + kTH - 1) / kTH;         // tiles over the (h + 1) x (w + 1) positions of the even phases
+    const int64_t jobs = int64_t(4) * n * a.tiles_x * a.tiles_y;
+    if (jobs > (int64_t(1) << 30)) return fail(GNERF_E_UNSUPPORTED, "conv_transpose3x3_s2_nhwc: too many tiles");
+    a.n_tiles = int(jobs);
+    a.out_h = 2 * h + 1; a.out_w = 2 * w + 1;
+    a.round_noise = 0; a.alpha = 0.f; a.gain = 1.f; a.clamp = -1.f;
+    const dim3 grid((a.n_tiles + kNumXCD - 1) / kNumXCD * kNumXCD, cout / kCO), block(kConvThreads);
+    static bool raised[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!raised[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_epilogue_kernel<1, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kConvLds) != hipSuccess)
+            return fail(GNERF_E_LAUNCH, "conv_transpose3x3_s2_nhwc: cannot raise the dynamic LDS limit");
+        raised[dev] = true;
+    }
+    hipLaunchKernelGGL((conv3x3_epilogue_kernel<1, false, false, false>), grid, block, kConvLds, as_stream(stream), a);
+    return check_launch("conv_transpose3x3_s2_nhwc");
 }

@@ -93,16 +93,18 @@ def _prenormalised_weight(module, dtype, channels_last=False, transposed=False):
     return hit[1]
 
 
-def _packed_prenormalised_weight(module, dtype):
-    """The pre-normalised weight in the tap-major [9, O, I] form of gnerf_hip.conv3x3_epilogue (csrc/conv3x3.hip), cached like the
-    convolution forms above."""
+def _packed_prenormalised_weight(module, dtype, transposed=False):
+    """The pre-normalised weight in the tap-major [9, O, I] form of gnerf_hip.conv3x3_epilogue (csrc/conv3x3.hip) -- transposed: in the
+    by-output-phase form of gnerf_hip.conv_transpose3x3_s2 -- cached like the convolution forms above."""
     w = module.weight
     key = (w.data_ptr(), w._version if not w.is_inference() else None, dtype)
-    hit = module.__dict__.get('_gnerf_prenorm_packed')
+    name = '_gnerf_prenorm_packed_t' if transposed else '_gnerf_prenorm_packed'
+    hit = module.__dict__.get(name)
     if hit is None or hit[0] != key:
         import gnerf_hip
-        hit = (key, gnerf_hip.pack_conv3x3_weights(_prenormalised_weight(module, dtype), dtype))
-        module.__dict__['_gnerf_prenorm_packed'] = hit
+        pack = gnerf_hip.pack_conv_transpose3x3_weights if transposed else gnerf_hip.pack_conv3x3_weights
+        hit = (key, pack(_prenormalised_weight(module, dtype), dtype))
+        module.__dict__[name] = hit
     return hit[1]
 
 
@@ -262,12 +264,17 @@ class StyledConv(nn.Module):
         if self.up == 1:
             x = F.conv2d(x, weight if fmt == torch.contiguous_format else weight.contiguous(memory_format=fmt), padding=1, groups=groups)
             return (x, False) if epilogue is not None else x
+        if weight_t is not None and not torch.is_tensor(weight_t):          # ('phases', packed): the x2 layer on csrc/conv3x3.hip's transposed form
+            import gnerf_hip
+            x = gnerf_hip.conv_transpose3x3_s2(x, weight_t[1])
+            weight_t = False
         if weight_t is None:
             o, i = weight.shape[0] // groups, weight.shape[1]
             weight_t = weight.reshape(groups, o, i, 3, 3).transpose(1, 2).reshape(groups * i, o, 3, 3)
             if fmt == torch.channels_last:
                 weight_t = weight_t.contiguous(memory_format=fmt)
-        x = F.conv_transpose2d(x, weight_t, stride=2, groups=groups)
+        if weight_t is not False:
+            x = F.conv_transpose2d(x, weight_t, stride=2, groups=groups)
         if epilogue is not None and groups == 1 and _is_channels_last(x) and x.shape[1] % 8 == 0:
             import gnerf_hip                                # blur + epilogue in one pass over the activations (csrc/upfirdn2d.hip)
             return gnerf_hip.blur_epilogue_channels_last(x, self.resample_filter, [1, 1, 1, 1], blur_gain=4, **epilogue), True
@@ -312,8 +319,11 @@ class StyledConv(nn.Module):
                                                    round_noise=True, gain=LRELU_GAIN * gain, clamp=clamp, next_scale=nxt)
                     return (x, folded) if next_layer is not None else x
                 epi = dict(bias=_cast_param(self, 'bias', x.dtype), scale=dco, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp, next_scale=nxt) if noise is None else None
-                out = self._resampled_conv(x, _prenormalised_weight(self, x.dtype, cl), 1,
-                                           weight_t=_prenormalised_weight(self, x.dtype, cl, transposed=True) if self.up == 2 else None, epilogue=epi)
+                if self.up == 2 and _FUSED_CONV and cl and gnerf_hip.conv_transpose3x3_s2_supported(x, c_out):
+                    w_t = ('phases', _packed_prenormalised_weight(self, x.dtype, transposed=True))        # the x2 layer's transposed convolution on our own kernel
+                else:
+                    w_t = _prenormalised_weight(self, x.dtype, cl, transposed=True) if self.up == 2 else None
+                out = self._resampled_conv(x, _prenormalised_weight(self, x.dtype, cl), 1, weight_t=w_t, epilogue=epi)
                 x, done = out if epi is not None else (out, False)
                 if not done:
                     if nxt is not None and not _is_channels_last(x):          # (the convolution gave back another layout: scale separately)

@@ -101,6 +101,7 @@ SIGNATURES = {
     'gnerf_scale_channels': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_modconv_epilogue': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p, _c_i, _c_f, _c_f, _c_f, _c_p]),
     'gnerf_conv3x3_epilogue_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_p, _c_f, _c_f, _c_f, _c_p, _c_p]),
+    'gnerf_conv_transpose3x3_s2_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_upsample2x_add_nhwc': (_c_i, [_c_p, _c_p, ctypes.POINTER(_c_f), _c_i, _c_f, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
     'gnerf_scale_channels_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_modconv_epilogue_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p, _c_i, _c_f, _c_f, _c_f, _c_p, _c_p]),
@@ -721,6 +722,38 @@ def conv3x3_epilogue(x, w_packed, bias=None, scale=None, noise=None, round_noise
         code = load().gnerf_conv3x3_epilogue_nhwc(_ptr(x), _ptr(w_packed), _ptr(y), n, h, w, c, o, _ptr(s32), _ptr(nz), 1 if round_noise else 0, _ptr(b),
                                                   float(alpha), float(gain), float(-1 if clamp is None else clamp), _ptr(nx), _stream(x))
     _check(code, 'gnerf_conv3x3_epilogue_nhwc')
+    return y
+
+
+def pack_conv_transpose3x3_weights(weight, dtype=torch.float16):
+    """[O, I, 3, 3] (the correlation-form weight of a x2 layer: conv_transpose2d(x, weight.transpose(0, 1), stride=2)) -> the [9, O, I] form
+    gnerf_conv_transpose3x3_s2_nhwc reads: the taps grouped by OUTPUT PHASE (py, px) = (oy & 1, ox & 1) -- phase (0,0): (ky, kx) = (0,0),
+    (0,2), (2,0), (2,2); phase (0,1): (0,1), (2,1); phase (1,0): (1,0), (1,2); phase (1,1): (1,1)."""
+    order = [(0, 0), (0, 2), (2, 0), (2, 2), (0, 1), (2, 1), (1, 0), (1, 2), (1, 1)]
+    w = weight.detach().to(dtype)
+    return torch.stack([w[:, :, ky, kx] for ky, kx in order]).contiguous()
+
+
+def conv_transpose3x3_s2_supported(x, c_out):
+    """Does the phase-decomposed transposed convolution take this activation tensor?  (float16, channels_last, input channels in blocks of
+    64, output channels in blocks of 128; any height and width.)"""
+    return (x.is_cuda and x.dtype == torch.float16 and x.ndim == 4 and is_channels_last(x) and x.shape[1] % 64 == 0 and c_out % 128 == 0
+            and x.shape[1] * x.shape[2] * x.shape[3] * 2 < (1 << 31))
+
+
+@profiled('gnerf_hip::conv_transpose3x3_s2')
+def conv_transpose3x3_s2(x, w_phases):
+    """conv_transpose2d(x, w.transpose(0, 1), stride=2) for a 3x3 kernel (csrc/conv3x3.hip, MODE 1): x [N,C,H,W] float16 channels_last,
+    w_phases = pack_conv_transpose3x3_weights(w) [9,O,C] float16.  Returns a channels_last [N,O,2H+1,2W+1] float16 tensor."""
+    _require_cuda(x, w_phases)
+    n, c, h, w = x.shape
+    o = w_phases.shape[1]
+    if not is_channels_last(x) or x.dtype != torch.float16 or tuple(w_phases.shape) != (9, o, c) or w_phases.dtype != torch.float16 or not w_phases.is_contiguous():
+        raise RuntimeError('conv_transpose3x3_s2: x must be channels_last float16 [N,C,H,W] and w_phases contiguous float16 [9,O,C]')
+    y = torch.empty([n, o, 2 * h + 1, 2 * w + 1], dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    with _on_device(x.device):
+        code = load().gnerf_conv_transpose3x3_s2_nhwc(_ptr(x), _ptr(w_phases), _ptr(y), n, h, w, c, o, _stream(x))
+    _check(code, 'gnerf_conv_transpose3x3_s2_nhwc')
     return y
 
 

@@ -138,6 +138,13 @@ int gnerf_blur4_epilogue_nhwc(const void* x, const float* f, void* y, int dtype,
 int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, void* y, int n, int h, int w, int cin, int cout,
                                 const float* scale, const float* noise, int round_noise, const void* bias,
                                 float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream);
+/* (ABI 9) The stride-2 transposed 3x3 convolution of the x2 layers -- conv_transpose2d(x, w, stride = 2), what conv2d_resample.py:109-119
+ * hands to the framework for up = 2 -- for float16 channels_last activations, as its four output phases on the matrix cores (the kernel
+ * of gnerf_conv3x3_epilogue_nhwc with 4 / 2 / 2 / 1 of its taps; fp32 accumulation, the result rounded to float16 once).
+ * x: [n, h, w, cin]; w_phases: [9, cout, cin] float16, the taps grouped by output phase (py, px) = (oy & 1, ox & 1):
+ * (ky, kx) = (0,0), (0,2), (2,0), (2,2) | (0,1), (2,1) | (1,0), (1,2) | (1,1), with w_phases[t, o, c] = weight[c, o, ky, kx] of the transposed
+ * convolution; y: [n, 2h + 1, 2w + 1, cout].  All 16-byte aligned.  GNERF_E_UNSUPPORTED unless cin % 64 == 0 and cout % 128 == 0. */
+int gnerf_conv_transpose3x3_s2_nhwc(const void* x, const void* w_phases, void* y, int n, int h, int w, int cin, int cout, gnerf_stream_t stream);
 /* ToRGBLayer with three output channels on a channels_last float16 tensor (networks_stylegan2.py:349-367, modulation as in the
  * fused form :89-96): y[n, o, p] = clamp(half(sum_c x[n, p, c] * half(weight[o, c] * styles[n, c])) + bias[o]), products exact, fp32
  * accumulation.  x: float16 [n, pixels, channels] (channels 32, 64, 128, 256 or 512, 16-byte aligned); weight float32 [3, channels];

@@ -1712,6 +1712,30 @@ def test_modconv_kernels_vs_composed_ops(dev, dtype):
         gnerf_hip.modconv_epilogue(x, b, act='relu')
 
 
+def test_conv_transpose3x3_s2_vs_framework(dev):
+    """csrc/conv3x3.hip MODE 1: the stride-2 transposed 3x3 convolution of the x2 layers as four phase convolutions on the matrix cores,
+    against conv_transpose2d (MIOpen) and against the same product in fp32 on the same fp16 operands: odd sizes (the 8 x 32 position tiles
+    overhang), several images, several output-channel groups, one to four input chunks."""
+    import gnerf_hip
+    import torch.nn.functional as F
+    for (n, cin, cout, h, w) in [(1, 64, 128, 8, 32), (2, 128, 128, 5, 7), (1, 64, 256, 16, 40), (3, 192, 128, 9, 33), (1, 256, 128, 2, 1)]:
+        g = torch.Generator(device='cpu').manual_seed(n + h)
+        x = (torch.randn(n, cin, h, w, generator=g) * 0.5).to(dev).half().contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) / (2 * cin ** 0.5)).to(dev)
+        assert gnerf_hip.conv_transpose3x3_s2_supported(x, cout)
+        got = gnerf_hip.conv_transpose3x3_s2(x, gnerf_hip.pack_conv_transpose3x3_weights(wt))
+        want = F.conv_transpose2d(x, wt.half().transpose(0, 1).contiguous(memory_format=torch.channels_last), stride=2)
+        ref = F.conv_transpose2d(x.float(), wt.half().float().transpose(0, 1), stride=2)
+        assert got.shape == (n, cout, 2 * h + 1, 2 * w + 1) and got.dtype == torch.float16 and gnerf_hip.is_channels_last(got)
+        top = float(ref.abs().max())
+        e_got, e_want = float((got.float() - ref).abs().max()), float((want.float() - ref).abs().max())
+        assert e_got <= max(1.5 * e_want, 2e-3 * top), (n, cin, cout, h, w, e_got, e_want, top)
+    bad = torch.zeros(1, 32, 8, 32, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    assert not gnerf_hip.conv_transpose3x3_s2_supported(bad, 128)
+    with pytest.raises(RuntimeError):
+        gnerf_hip.conv_transpose3x3_s2(bad, torch.zeros(9, 128, 32, device=dev, dtype=torch.float16))
+
+
 def test_conv3x3_epilogue_vs_composed_ops(dev):
     """csrc/conv3x3.hip -- the 3x3 convolution of a modulated-convolution layer and its epilogue in one launch (SURVEY 8(f)3;
     networks_stylegan2.py:41-98 as SynthesisLayer.forward calls it, :315-334) -- against the two launches it replaces: torch's
