@@ -66,6 +66,7 @@ struct ConvArgs {
     const __half* bias;         // [cout] or NULL
     const float* next_scale;    // [n, cout] or NULL
     int n, h, w, cin, cout;
+    int cin_pad;                // input channels of the packed weights: cin rounded up to a multiple of 64 (the extra channels are zeros)
     int tiles_x, tiles_y, n_tiles;
     int out_h, out_w;           // transposed form: 2 h + 1, 2 w + 1 (the convolution: h, w)
     int round_noise;
@@ -133,18 +134,19 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             const int pix = q >> 3, slot = q & 7;
             const int py = pix / kIW, px = pix - py * kIW;
             const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-            const bool ok = pix < kIH * kIW && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const unsigned off = ok ? unsigned(((iy * W + ix) * Cin + cin0 + ((slot ^ (pix & 7)) << 3)) * 2) : 0x80000000u;     // out of range: zeros
+            const int cg = cin0 + ((slot ^ (pix & 7)) << 3);        // first of this piece's eight input channels
+            const bool ok = pix < kIH * kIW && iy >= 0 && iy < H && ix >= 0 && ix < W && cg < Cin;      // (cin below a multiple of 64: the last chunk's tail reads as zeros)
+            const unsigned off = ok ? unsigned(((iy * W + ix) * Cin + cg) * 2) : 0x80000000u;     // out of range: zeros
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(xs + (it * kConvThreads + wv * 64) * 16), 16, off, 0, 0, 0);
         }
     };
     auto stage_w = [&](int tap, int cin0, int buf) {
-        const _Float16* src = a.wpk + (size_t(tap_base + tap) * Cout + co0) * Cin + cin0;
+        const _Float16* src = a.wpk + (size_t(tap_base + tap) * Cout + co0) * a.cin_pad + cin0;
 #pragma unroll
         for (int it = 0; it < kWRounds; it++) {
             const int q = it * kConvThreads + tid;
             const int co = q >> 3, slot = q & 7;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + size_t(co) * Cin + ((slot ^ ((co >> 1) & 7)) << 3)),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + size_t(co) * a.cin_pad + ((slot ^ ((co >> 1) & 7)) << 3)),
                                              (lds_ptr_t)(wb + buf * kWBytes + (it * kConvThreads + wv * 64) * 16), 16, 0, 0);
         }
     };
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     }
     if (wv == 0 && a.bias) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + co0 + 2 * tid),
                                                             (lds_ptr_t)(ep + 1024), 4, 0, 0);
-    const int n_chunks = Cin / kCK, total = n_chunks * n_taps;
+    const int n_chunks = a.cin_pad / kCK, total = n_chunks * n_taps;
     // ---- main loop, software-pipelined ACROSS steps.  A step (one tap of one 64-channel chunk) is two k-steps of 32 MFMAs; while
     // the MFMAs of one k-step issue, the twelve fragments of the NEXT k-step are read -- the second k-step of this step, or the first
     // of the next step.  The one barrier of a step sits between its two k-steps: there the next step's weights (requested a step
@@ -317,8 +319,8 @@ extern "C" int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, 
     using namespace gnerf;
     if (!x || !w_packed || !y) return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: null pointer");
     if (n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: empty tensor");
-    if (h % kTH || w % kTW || cin % kCK || cout % kCO)
-        return fail(GNERF_E_UNSUPPORTED, "conv3x3_epilogue_nhwc: needs height %% 8 == 0, width %% 32 == 0, input channels %% 64 == 0, output channels %% 128 == 0 (got %dx%d, %d -> %d)", h, w, cin, cout);
+    if (h % kTH || w % kTW || cin % 8 || cout % kCO)
+        return fail(GNERF_E_UNSUPPORTED, "conv3x3_epilogue_nhwc: needs height %% 8 == 0, width %% 32 == 0, input channels %% 8 == 0, output channels %% 128 == 0 (got %dx%d, %d -> %d)", h, w, cin, cout);
     if (size_t(h) * w * cin * 2 >= (size_t(1) << 31)) return fail(GNERF_E_UNSUPPORTED, "conv3x3_epilogue_nhwc: one image of x must stay below 2 GB");
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(y)) & 15)
         return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: x, w and y must be 16-byte aligned");
@@ -330,6 +332,7 @@ extern "C" int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, 
     a.x = static_cast<const _Float16*>(x); a.wpk = static_cast<const _Float16*>(w_packed); a.y = static_cast<_Float16*>(y);
     a.scale = scale; a.noise = noise; a.bias = static_cast<const __half*>(bias); a.next_scale = next_scale;
     a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
+    a.cin_pad = (cin + kCK - 1) / kCK * kCK;
     a.tiles_x = w / kTW; a.tiles_y = h / kTH; a.n_tiles = n * a.tiles_x * a.tiles_y;
     a.out_h = h; a.out_w = w;
     a.round_noise = round_noise; a.alpha = alpha; a.gain = gain; a.clamp = clamp;
@@ -365,8 +368,8 @@ extern "C" int gnerf_conv_transpose3x3_s2_nhwc(const void* x, const void* w_phas
     using namespace gnerf;
     if (!x || !w_phases || !y) return fail(GNERF_E_ARG, "conv_transpose3x3_s2_nhwc: null pointer");
     if (n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return fail(GNERF_E_ARG, "conv_transpose3x3_s2_nhwc: empty tensor");
-    if (cin % kCK || cout % kCO)
-        return fail(GNERF_E_UNSUPPORTED, "conv_transpose3x3_s2_nhwc: needs input channels %% 64 == 0, output channels %% 128 == 0 (got %d -> %d)", cin, cout);
+    if (cin % 8 || cout % kCO)
+        return fail(GNERF_E_UNSUPPORTED, "conv_transpose3x3_s2_nhwc: needs input channels %% 8 == 0, output channels %% 128 == 0 (got %d -> %d)", cin, cout);
     if (size_t(h) * w * cin * 2 >= (size_t(1) << 31)) return fail(GNERF_E_UNSUPPORTED, "conv_transpose3x3_s2_nhwc: one image of x must stay below 2 GB");
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_phases) | reinterpret_cast<uintptr_t>(y)) & 15)
         return fail(GNERF_E_ARG, "conv_transpose3x3_s2_nhwc: x, w and y must be 16-byte aligned");
@@ -374,6 +377,7 @@ extern "C" int gnerf_conv_transpose3x3_s2_nhwc(const void* x, const void* w_phas
     a.x = static_cast<const _Float16*>(x); a.wpk = static_cast<const _Float16*>(w_phases); a.y = static_cast<_Float16*>(y);
     a.scale = nullptr; a.noise = nullptr; a.bias = nullptr; a.next_scale = nullptr;
     a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
+    a.cin_pad = (cin + kCK - 1) / kCK * kCK;
     a.tiles_x = (w + 1 + kTW - 1) / kTW; a.tiles_y = (h + 1 + kTH - 1) / kTH;         // tiles over the (h + 1) x (w + 1) positions of the even phases
     const int64_t jobs = int64_t(4) * n * a.tiles_x * a.tiles_y;
     if (jobs > (int64_t(1) << 30)) return fail(GNERF_E_UNSUPPORTED, "conv_transpose3x3_s2_nhwc: too many tiles");

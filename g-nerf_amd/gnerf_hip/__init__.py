@@ -683,28 +683,36 @@ def clock_under_load(run, microseconds=3000.0, device=None):
     return 100.0 * cyc / ticks if ticks else None
 
 
+def _pad_input_channels(w9):
+    """[9, O, I] -> [9, O, I rounded up to a multiple of 64] with zeros (the kernels read the weights in 64-channel chunks; the activations'
+    missing channels are masked to zero by the kernel)."""
+    i = w9.shape[2]
+    pad = -i % 64
+    return (torch.nn.functional.pad(w9, (0, pad)) if pad else w9).contiguous()
+
+
 def pack_conv3x3_weights(weight, dtype=torch.float16):
     """[O, I, 3, 3] -> the tap-major [9, O, I] form gnerf_conv3x3_epilogue_nhwc reads (w_packed[ky * 3 + kx, o, c] = weight[o, c, ky, kx])."""
     o, i = weight.shape[:2]
-    return weight.detach().to(dtype).permute(2, 3, 0, 1).reshape(9, o, i).contiguous()
+    return _pad_input_channels(weight.detach().to(dtype).permute(2, 3, 0, 1).reshape(9, o, i))
 
 
 def conv3x3_epilogue_supported(x, c_out):
     """Does the fused convolution + epilogue kernel take this activation tensor?  (float16, channels_last, 8 x 32 pixel tiles, input channels
-    in blocks of 64, output channels in blocks of 128.)"""
+    in multiples of 8 -- the last 64-channel chunk is zero-padded --, output channels in blocks of 128.)"""
     return (x.is_cuda and x.dtype == torch.float16 and x.ndim == 4 and is_channels_last(x) and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0
-            and x.shape[1] % 64 == 0 and c_out % 128 == 0 and x.shape[1] * x.shape[2] * x.shape[3] * 2 < (1 << 31))
+            and x.shape[1] % 8 == 0 and c_out % 128 == 0 and x.shape[1] * x.shape[2] * x.shape[3] * 2 < (1 << 31))
 
 
 @profiled('gnerf_hip::conv3x3_epilogue')
 def conv3x3_epilogue(x, w_packed, bias=None, scale=None, noise=None, round_noise=False, alpha=0.2, gain=1.0, clamp=None, next_scale=None):
     """conv2d(x, w, padding=1) followed by modconv_epilogue(act='lrelu') in ONE launch (csrc/conv3x3.hip): x [N,C,H,W] float16
-    channels_last, w_packed = pack_conv3x3_weights(w) [9,O,C] float16; scale / next_scale [N,O] float32, noise float32 [H,W], bias [O].
+    channels_last, w_packed = pack_conv3x3_weights(w) [9,O,C padded to a multiple of 64] float16; scale / next_scale [N,O] float32, noise float32 [H,W], bias [O].
     Returns a channels_last [N,O,H,W] float16 tensor.  Shapes outside conv3x3_epilogue_supported raise (GNERF_E_UNSUPPORTED)."""
     _require_cuda(x, w_packed, bias, scale, noise, next_scale)
     n, c, h, w = x.shape
     o = w_packed.shape[1]
-    if not is_channels_last(x) or x.dtype != torch.float16 or tuple(w_packed.shape) != (9, o, c) or w_packed.dtype != torch.float16 or not w_packed.is_contiguous():
+    if not is_channels_last(x) or x.dtype != torch.float16 or tuple(w_packed.shape) != (9, o, -(-c // 64) * 64) or w_packed.dtype != torch.float16 or not w_packed.is_contiguous():
         raise RuntimeError('conv3x3_epilogue: x must be channels_last float16 [N,C,H,W] and w_packed contiguous float16 [9,O,C]')
     def f32(t, numel, what):
         if t is None:
@@ -731,24 +739,24 @@ def pack_conv_transpose3x3_weights(weight, dtype=torch.float16):
     (0,2), (2,0), (2,2); phase (0,1): (0,1), (2,1); phase (1,0): (1,0), (1,2); phase (1,1): (1,1)."""
     order = [(0, 0), (0, 2), (2, 0), (2, 2), (0, 1), (2, 1), (1, 0), (1, 2), (1, 1)]
     w = weight.detach().to(dtype)
-    return torch.stack([w[:, :, ky, kx] for ky, kx in order]).contiguous()
+    return _pad_input_channels(torch.stack([w[:, :, ky, kx] for ky, kx in order]))
 
 
 def conv_transpose3x3_s2_supported(x, c_out):
-    """Does the phase-decomposed transposed convolution take this activation tensor?  (float16, channels_last, input channels in blocks of
-    64, output channels in blocks of 128; any height and width.)"""
-    return (x.is_cuda and x.dtype == torch.float16 and x.ndim == 4 and is_channels_last(x) and x.shape[1] % 64 == 0 and c_out % 128 == 0
+    """Does the phase-decomposed transposed convolution take this activation tensor?  (float16, channels_last, input channels in
+    multiples of 8, output channels in blocks of 128; any height and width.)"""
+    return (x.is_cuda and x.dtype == torch.float16 and x.ndim == 4 and is_channels_last(x) and x.shape[1] % 8 == 0 and c_out % 128 == 0
             and x.shape[1] * x.shape[2] * x.shape[3] * 2 < (1 << 31))
 
 
 @profiled('gnerf_hip::conv_transpose3x3_s2')
 def conv_transpose3x3_s2(x, w_phases):
     """conv_transpose2d(x, w.transpose(0, 1), stride=2) for a 3x3 kernel (csrc/conv3x3.hip, MODE 1): x [N,C,H,W] float16 channels_last,
-    w_phases = pack_conv_transpose3x3_weights(w) [9,O,C] float16.  Returns a channels_last [N,O,2H+1,2W+1] float16 tensor."""
+    w_phases = pack_conv_transpose3x3_weights(w) [9,O,C padded to a multiple of 64] float16.  Returns a channels_last [N,O,2H+1,2W+1] float16 tensor."""
     _require_cuda(x, w_phases)
     n, c, h, w = x.shape
     o = w_phases.shape[1]
-    if not is_channels_last(x) or x.dtype != torch.float16 or tuple(w_phases.shape) != (9, o, c) or w_phases.dtype != torch.float16 or not w_phases.is_contiguous():
+    if not is_channels_last(x) or x.dtype != torch.float16 or tuple(w_phases.shape) != (9, o, -(-c // 64) * 64) or w_phases.dtype != torch.float16 or not w_phases.is_contiguous():
         raise RuntimeError('conv_transpose3x3_s2: x must be channels_last float16 [N,C,H,W] and w_phases contiguous float16 [9,O,C]')
     y = torch.empty([n, o, 2 * h + 1, 2 * w + 1], dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
     with _on_device(x.device):

@@ -134,16 +134,18 @@ int gnerf_blur4_epilogue_nhwc(const void* x, const float* f, void* y, int dtype,
  * x: [n, h, w, cin] float16; w_packed: [9, cout, cin] float16, tap-major (tap = ky * 3 + kx of the correlation form torch's conv2d
  * computes: w_packed[t, o, c] = weight[o, c, t / 3, t % 3]); y: [n, h, w, cout] float16; scale / next_scale: float32 [n, cout] or
  * NULL; noise: float32 [h * w] or NULL; bias: float16 [cout] or NULL; clamp < 0: none.  All 16-byte aligned.
- * GNERF_E_UNSUPPORTED unless h % 8 == 0, w % 32 == 0, cin % 64 == 0, cout % 128 == 0 (the caller runs the two-launch form). */
+ * w_packed's input-channel axis is cin ROUNDED UP to a multiple of 64, zero-filled (the kernel reads weights in 64-channel chunks and
+ * masks the activations' missing channels).  GNERF_E_UNSUPPORTED unless h % 8 == 0, w % 32 == 0, cin % 8 == 0, cout % 128 == 0 (the caller
+ * runs the two-launch form). */
 int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, void* y, int n, int h, int w, int cin, int cout,
                                 const float* scale, const float* noise, int round_noise, const void* bias,
                                 float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream);
 /* (ABI 9) The stride-2 transposed 3x3 convolution of the x2 layers -- conv_transpose2d(x, w, stride = 2), what conv2d_resample.py:109-119
  * hands to the framework for up = 2 -- for float16 channels_last activations, as its four output phases on the matrix cores (the kernel
  * of gnerf_conv3x3_epilogue_nhwc with 4 / 2 / 2 / 1 of its taps; fp32 accumulation, the result rounded to float16 once).
- * x: [n, h, w, cin]; w_phases: [9, cout, cin] float16, the taps grouped by output phase (py, px) = (oy & 1, ox & 1):
+ * x: [n, h, w, cin]; w_phases: [9, cout, cin rounded up to a multiple of 64, zero-filled] float16, the taps grouped by output phase (py, px) = (oy & 1, ox & 1):
  * (ky, kx) = (0,0), (0,2), (2,0), (2,2) | (0,1), (2,1) | (1,0), (1,2) | (1,1), with w_phases[t, o, c] = weight[c, o, ky, kx] of the transposed
- * convolution; y: [n, 2h + 1, 2w + 1, cout].  All 16-byte aligned.  GNERF_E_UNSUPPORTED unless cin % 64 == 0 and cout % 128 == 0. */
+ * convolution; y: [n, 2h + 1, 2w + 1, cout].  All 16-byte aligned.  GNERF_E_UNSUPPORTED unless cin % 8 == 0 and cout % 128 == 0. */
 int gnerf_conv_transpose3x3_s2_nhwc(const void* x, const void* w_phases, void* y, int n, int h, int w, int cin, int cout, gnerf_stream_t stream);
 /* ToRGBLayer with three output channels on a channels_last float16 tensor (networks_stylegan2.py:349-367, modulation as in the
  * fused form :89-96): y[n, o, p] = clamp(half(sum_c x[n, p, c] * half(weight[o, c] * styles[n, c])) + bias[o]), products exact, fp32

@@ -16,10 +16,27 @@ def test_weight_packing_is_tap_major_with_the_taps_of_the_correlation():
     o, c = 5, 7
     w = torch.arange(o * c * 9, dtype=torch.float32).reshape(o, c, 3, 3)
     pk = gnerf_hip.pack_conv3x3_weights(w)
-    assert pk.shape == (9, o, c) and pk.dtype == torch.float16 and pk.is_contiguous()
+    assert pk.shape == (9, o, 64) and pk.dtype == torch.float16 and pk.is_contiguous()      # input channels padded with zeros to the kernels' 64-channel chunks
+    assert not pk[:, :, c:].any()
+    pk = pk[:, :, :c]
     for ky in range(3):
         for kx in range(3):
             assert torch.equal(pk[ky * 3 + kx].float(), w[:, :, ky, kx].half().float())
+    assert gnerf_hip.pack_conv3x3_weights(torch.zeros(2, 128, 3, 3)).shape == (9, 2, 128)
+    # the transposed form groups the same taps by output phase: (0,0) (0,2) (2,0) (2,2) | (0,1) (2,1) | (1,0) (1,2) | (1,1)
+    pt = gnerf_hip.pack_conv_transpose3x3_weights(w)[:, :, :c]
+    for t, (ky, kx) in enumerate([(0, 0), (0, 2), (2, 0), (2, 2), (0, 1), (2, 1), (1, 0), (1, 2), (1, 1)]):
+        assert torch.equal(pt[t].float(), w[:, :, ky, kx].half().float())
+    # ... and those are the phases of conv_transpose2d(x, w.transpose(0, 1), stride=2): output (2m + py, 2n + px) sums x[m - a, n - b] w[py + 2a, px + 2b]
+    xs = torch.randn(1, c, 3, 4)
+    full = torch.nn.functional.conv_transpose2d(xs, w.half().float().transpose(0, 1), stride=2)
+    xp = torch.nn.functional.pad(xs, (1, 1, 1, 1))
+    base = {(0, 0): 0, (0, 1): 4, (1, 0): 6, (1, 1): 8}
+    for (py, px), t0 in base.items():
+        taps = [(a, b) for a in ((0, 1) if py == 0 else (0,)) for b in ((0, 1) if px == 0 else (0,))]
+        hp, wp = 3 + 1 - py, 4 + 1 - px
+        acc = sum(torch.einsum('oc,nchw->nohw', pt[t0 + i].float(), xp[:, :, 1 - a:1 - a + hp, 1 - b:1 - b + wp]) for i, (a, b) in enumerate(taps))
+        assert torch.allclose(acc, full[:, :, py::2, px::2], rtol=1e-5, atol=1e-2), (py, px)
     # ... i.e. conv2d(x, w, padding=1)[n, o, y, x] = sum over taps t and channels c of pk[t, o, c] * x[n, c, y + t // 3 - 1, x + t % 3 - 1]
     x = torch.randn(1, c, 6, 9)
     want = torch.nn.functional.conv2d(x, w.half().float(), padding=1)

@@ -1718,7 +1718,7 @@ def test_conv_transpose3x3_s2_vs_framework(dev):
     overhang), several images, several output-channel groups, one to four input chunks."""
     import gnerf_hip
     import torch.nn.functional as F
-    for (n, cin, cout, h, w) in [(1, 64, 128, 8, 32), (2, 128, 128, 5, 7), (1, 64, 256, 16, 40), (3, 192, 128, 9, 33), (1, 256, 128, 2, 1)]:
+    for (n, cin, cout, h, w) in [(1, 64, 128, 8, 32), (2, 128, 128, 5, 7), (1, 64, 256, 16, 40), (3, 192, 128, 9, 33), (1, 256, 128, 2, 1), (2, 32, 256, 6, 9), (1, 72, 128, 3, 35)]:
         g = torch.Generator(device='cpu').manual_seed(n + h)
         x = (torch.randn(n, cin, h, w, generator=g) * 0.5).to(dev).half().contiguous(memory_format=torch.channels_last)
         wt = (torch.randn(cout, cin, 3, 3, generator=g) / (2 * cin ** 0.5)).to(dev)
@@ -1730,10 +1730,10 @@ def test_conv_transpose3x3_s2_vs_framework(dev):
         top = float(ref.abs().max())
         e_got, e_want = float((got.float() - ref).abs().max()), float((want.float() - ref).abs().max())
         assert e_got <= max(1.5 * e_want, 2e-3 * top), (n, cin, cout, h, w, e_got, e_want, top)
-    bad = torch.zeros(1, 32, 8, 32, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
-    assert not gnerf_hip.conv_transpose3x3_s2_supported(bad, 128)
+    bad = torch.zeros(1, 64, 8, 32, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    assert not gnerf_hip.conv_transpose3x3_s2_supported(bad, 64)                          # output channels come in blocks of 128
     with pytest.raises(RuntimeError):
-        gnerf_hip.conv_transpose3x3_s2(bad, torch.zeros(9, 128, 32, device=dev, dtype=torch.float16))
+        gnerf_hip.conv_transpose3x3_s2(bad, torch.zeros(9, 64, 64, device=dev, dtype=torch.float16))
 
 
 def test_conv3x3_epilogue_vs_composed_ops(dev):
@@ -1746,12 +1746,12 @@ def test_conv3x3_epilogue_vs_composed_ops(dev):
     import gnerf_hip
     from torch_utils.ops import bias_act
     gen = torch.Generator().manual_seed(2)
-    for (n, cin, cout, h, w) in [(2, 128, 128, 16, 64), (1, 256, 128, 8, 32), (3, 128, 256, 24, 32), (2, 64, 128, 8, 64)]:
+    for (n, cin, cout, h, w) in [(2, 128, 128, 16, 64), (1, 256, 128, 8, 32), (3, 128, 256, 24, 32), (2, 64, 128, 8, 64), (1, 32, 128, 8, 32), (1, 104, 128, 8, 32)]:
         x = (torch.randn(n, cin, h, w, generator=gen) * 0.7).to(dev).half().contiguous(memory_format=torch.channels_last)
         wt = (torch.randn(cout, cin, 3, 3, generator=gen) / (3 * cin ** 0.5)).to(dev)
         w16 = wt.half().contiguous(memory_format=torch.channels_last)
         wpk = gnerf_hip.pack_conv3x3_weights(wt)
-        assert wpk.shape == (9, cout, cin) and torch.equal(wpk[5], wt.half()[:, :, 1, 2])
+        assert wpk.shape == (9, cout, -(-cin // 64) * 64) and torch.equal(wpk[5][:, :cin], wt.half()[:, :, 1, 2]) and not wpk[:, :, cin:].any()
         assert gnerf_hip.conv3x3_epilogue_supported(x, cout)
         sc, nx = (torch.rand(n, cout, generator=gen) + 0.5).to(dev), (torch.rand(n, cout, generator=gen) + 0.5).to(dev)
         bias = (torch.randn(cout, generator=gen) * 0.2).to(dev)
@@ -1774,10 +1774,10 @@ def test_conv3x3_epilogue_vs_composed_ops(dev):
                         diff = (got.float() - want.float()).abs()
                         assert float(diff.max()) <= 6e-3 * top and float((diff > 2e-3 * top).float().mean()) < 1e-3
     # shapes the kernel does not tile are refused, not approximated
-    bad = torch.zeros(1, 32, 8, 32, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
-    assert not gnerf_hip.conv3x3_epilogue_supported(bad, 128)
+    bad = torch.zeros(1, 64, 8, 24, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    assert not gnerf_hip.conv3x3_epilogue_supported(bad, 128)                             # widths come in tiles of 32
     with pytest.raises(RuntimeError):
-        gnerf_hip.conv3x3_epilogue(bad, torch.zeros(9, 128, 32, device=dev, dtype=torch.float16))
+        gnerf_hip.conv3x3_epilogue(bad, torch.zeros(9, 128, 64, device=dev, dtype=torch.float16))
 
 
 def test_generator_fast_modconv_path_equals_plain_path(dev, monkeypatch):
