@@ -473,7 +473,8 @@ def realistic_planes_step(dev, c2w, intr, steps, rank=0):
                 'opacity': {'mean_weight_sum': float(wsum.mean()), 'frac_rays_weight_sum_above_0.5': float((wsum > 0.5).float().mean())}}
 
 
-ORBIT_VIEWS = 4                   # cameras per synthesis call of the batched orbit (tools/bench_generator.py --frames-per-call: 2 / 4 / 8 -> 1235 / 1357 / 1327 frames/s)
+ORBIT_VIEWS = 8                   # cameras per synthesis call of the batched orbit (tools/orbit_marked.py --frames-per-call 4 / 6 / 8 / 12 -> 2304 / 2354 / 2387 / 2298
+                                  # frames/s with plain launches on the final library, profiles/r05_orbit_views_k.jsonl; round 3, on MIOpen's convolutions: 2 / 4 / 8 -> 1235 / 1357 / 1327)
 PEAK_ATOMIC_GBS = 1330.0          # chip-wide float-atomic rate: 20.8 G 64-byte requests/s on this device (profiles/r04_atomic_scope_probe.txt; MI355X_MICROARCH.md gives 1.26-1.36 TB/s of added bytes)
 FLOP_BWD_PER_SAMPLE = 3 * FLOP_MLP_PER_SAMPLE       # one forward recomputation + dX / dW products of both layers (fp32 MFMA)
 
