@@ -80,7 +80,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // conv2d_resample.py:109-119 hands to the framework's transposed convolution), as its four output phases: output (2m + py, 2n + px) =
 // sum over a in A(py), b in A(px) of x[m - a, n - b] . w[ky = py + 2a, kx = px + 2b], A(0) = {0, 1}, A(1) = {0} -- an ordinary
 // convolution over the INPUT grid with 4, 2, 2 or 1 of the taps (dy, dx) = (1 - a, 1 - b) of the 3x3 stencil, so the staging, the
-// fragment addressing and the MFMA loop are the convolution's; a job is (phase, tile of 8 x 32 positions (m, n)), the result goes out
+// fragment addressing and the MFMA loop are the convolution's; a job is (tile of 8 x 32 positions (m, n), phase), the result goes out
 // as plain fp16 at stride 2 (the blur + epilogue pass that follows reads it).  Weights arrive packed per phase: [9][cout][cin] in the order
 // phase (0,0): taps (a,b) = (0,0), (0,1), (1,0), (1,1); phase (0,1): a = 0, 1; phase (1,0): b = 0, 1; phase (1,1): the one tap.
 template <int MODE, bool SCALE, bool NOISE, bool NEXT>
@@ -98,9 +98,14 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     if (tile >= a.n_tiles) return;
     const int tiles_img = a.tiles_x * a.tiles_y;
     const int H = a.h, W = a.w, Cin = a.cin, Cout = a.cout;
-    // transposed form: the phase is the slowest index of the job sequence (the four-tap phase first: the longest jobs start first)
-    const int ph = MODE == 1 ? tile / (a.n * tiles_img) : 0;
-    const int tile_p = MODE == 1 ? tile - ph * (a.n * tiles_img) : tile;
+    // transposed form: a job is a position tile, and the workgroup walks its four phases one after the other (16, 8, 8, 4 steps): they read
+    // the same input tile (L2 hits), every job is the same length, and three of four workgroup launches are gone.  (History,
+    // profiles/r05_conv_transpose_phases.txt: a job per (phase, tile) with the phase slowest put ALL the four-tap jobs, 4/9 of the work, on
+    // XCDs 0 and 1 -- an XCD owns a contiguous eighth of the job sequence -- : 0.287 ms; phase fastest: 0.262; a 4-step job costs 13 us on
+    // its own, of which the MFMAs are 4.)
+    const int tile_p = tile;
+#pragma unroll
+    for (int ph = 0; ph < (MODE == 1 ? 4 : 1); ph++) {
     const int ph_y = ph >> 1, ph_x = ph & 1;                            // (py, px)
     const int n_taps = MODE == 1 ? (2 - ph_y) * (2 - ph_x) : 9;
     const int tap_base = MODE == 1 ? (ph == 0 ? 0 : ph == 1 ? 4 : ph == 2 ? 6 : 8) : 0;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     const int y0 = ty * kTH, x0 = tx * kTW;
     const int co0 = blockIdx.y * kCO;
     const int Hp = MODE == 1 ? H + 1 - ph_y : H, Wp = MODE == 1 ? W + 1 - ph_x : W;      // positions of this phase per axis
-    if (MODE == 1 && (y0 >= Hp || x0 >= Wp)) return;                   // a tile of the 8 x 32 grid over (H + 1) x (W + 1) that an odd phase does not have
+    if (MODE == 1 && (y0 >= Hp || x0 >= Wp)) continue;                 // a tile of the 8 x 32 grid over (H + 1) x (W + 1) that an odd phase does not have (uniform: no barrier is skipped by a part of the workgroup)
     // (dy, dx) of tap t of this job in the staged input tile (whose origin is one pixel up and left of the tile's first position)
     auto tap_shift = [&](int t, int& dy, int& dx) {
         if (MODE == 1) {
@@ -308,6 +313,10 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             *reinterpret_cast<uint4*>(a.y + (size_t(n) * H * W + size_t(yy) * W + xx) * Cout + co0 + slot * 8) = v;
         }
     }
+    if (MODE == 1) __syncthreads();                                  // the next phase's input tile overwrites the staged output
+    // (stores straight from the accumulators -- 8 bytes per lane, no LDS staging, no barrier pair -- were measured: 0.237 -> 0.247 ms, the
+    //  partial lines cost more than the staging)
+    }
 }
 
 }  // namespace
@@ -379,7 +388,7 @@ extern "C" int gnerf_conv_transpose3x3_s2_nhwc(const void* x, const void* w_phas
     a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
     a.cin_pad = (cin + kCK - 1) / kCK * kCK;
     a.tiles_x = (w + 1 + kTW - 1) / kTW; a.tiles_y = (h + 1 + kTH - 1) / kTH;         // tiles over the (h + 1) x (w + 1) positions of the even phases
-    const int64_t jobs = int64_t(4) * n * a.tiles_x * a.tiles_y;
+    const int64_t jobs = int64_t(n) * a.tiles_x * a.tiles_y;
     if (jobs > (int64_t(1) << 30)) return fail(GNERF_E_UNSUPPORTED, "conv_transpose3x3_s2_nhwc: too many tiles");
     a.n_tiles = int(jobs);
     a.out_h = 2 * h + 1; a.out_w = 2 * w + 1;

@@ -10,4 +10,4 @@ grep -q "1 passed" $O/parity.txt || { echo "stopping: the kernel's own test did 
 timeout -k 10 700 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fast_modconv or config3 or config5 or orbit or views or generator or overlay or inference_mode or latent" 2>&1 | tail -4 | tee -a $O/parity.txt
 timeout -k 10 300 python3 tools/bench_conv_transpose.py 2>&1 | tail -2 | cut -c1-400 | tee $O/timing.txt
 timeout -k 10 300 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "conv3x3" 2>&1 | tail -3 | tee -a $O/parity.txt
-timeout -k 10 500 bash tools/prof_orbit.sh r05_orbit_fast_views4_t --frames-per-call 4 2>&1 | tail -3 | tee $O/orbit.txt
+timeout -k 10 500 bash tools/prof_orbit.sh r05_orbit_fast_views8 --frames-per-call 8 2>&1 | tail -3 | tee $O/orbit.txt
