@@ -351,6 +351,20 @@ def gen_videos_secondary(rank, world, dev, n_frames=240, flows=('fast', 'referen
         G = gv.build_random_generator(0, dev)
         z = torch.randn(1, G.z_dim, generator=torch.Generator().manual_seed(1)).to(dev)
         last = G.backbone.synthesis.b256
+        if world > 1:
+            # every convolution shape of the run (both flows, one camera per call and ORBIT_VIEWS), searched by rank 0 alone; the other ranks
+            # have not issued a convolution yet (building the generator only allocates and initialises) -- see one_solver_search
+            def warm_all():
+                for f in flows:
+                    GG._MODCONV_FAST = f == 'fast'
+                    last.emit_channels_last = f == 'fast'
+                    gv.render_orbit(G, z, n_frames, 64, dev, rank=0, world=n_frames, double_depth=(f == 'fast'))
+                    if f == 'fast':
+                        gv.render_orbit(G, z, ORBIT_VIEWS, 64, dev, double_depth=False, frames_per_call=ORBIT_VIEWS)
+                torch.cuda.synchronize()
+            t_search = time.perf_counter()
+            one_solver_search(rank, world, warm_all, dist.barrier, sync=torch.cuda.synchronize)
+            out['solver_search_s'] = time.perf_counter() - t_search
         for flow, fast in [(f, f == 'fast') for f in flows]:
             GG._MODCONV_FAST = fast
             last.emit_channels_last = fast
@@ -409,6 +423,7 @@ def gen_videos_secondary(rank, world, dev, n_frames=240, flows=('fast', 'referen
             'eager_value': out['fast', 'eager'], 'hip_graph_value': out['fast', 'hip_graph'],
             'eager_views_value': out['fast', 'eager_views'], 'hip_graph_views_value': out['fast', 'hip_graph_views'], 'views_per_call': ORBIT_VIEWS, 'miopen_solver_search': searched,
             'backbone_ms_per_rank': backbone_all,
+            'solver_search': ({'shared': True, 'rank0_then_copy_s': out.get('solver_search_s')} if world > 1 else {'shared': False}),
             'reference_flow_value': max(out['reference', 'eager'], out['reference', 'hip_graph']) if 'reference' in flows else None,
             'reference_flow_eager_value': out.get(('reference', 'eager')), 'reference_flow_hip_graph_value': out.get(('reference', 'hip_graph')),
             'flows_measured': list(flows), 'n_gpus': world,
@@ -605,6 +620,39 @@ def per_rank_miopen_env(rank, env=None):
     return env
 
 
+def one_solver_search(rank, world, warm, barrier, env=None, sync=None):
+    """MIOpen's solver search ONCE per node instead of once per rank (round 6).  Every rank has MIOpen directories of its own
+    (per_rank_miopen_env), so left alone eight ranks run eight identical searches at the same time -- each of them a few dozen kernel
+    compilations and timing runs on a host that gives a process 16 cores: the likeliest way for a first 8-GPU run to meet its time limit.
+    Here rank 0 runs `warm` (the untimed warm-up frames: every convolution shape of the run) ALONE while the other ranks wait in
+    `barrier` -- which they enter before they have issued a single convolution, i.e. before MIOpen has opened any database --, then its
+    user database and kernel cache are copied into every other rank's directories (one host, plain files), the barrier releases, and the
+    other ranks' `warm` finds every solver and every compiled kernel cached.  Directories the caller set by hand are left alone (a shared
+    directory needs no copy).  The reference starts its per-GPU processes the same way and lets each search (train.py:40-56,104-111,
+    training_loop.py:133,144).  Returns warm()'s value."""
+    import shutil
+    env = os.environ if env is None else env
+    if world <= 1:
+        return warm()
+    result = None
+    if rank == 0:
+        result = warm()
+        if sync is not None:
+            sync()
+        for var in ('MIOPEN_USER_DB_PATH', 'MIOPEN_CUSTOM_CACHE_DIR'):
+            src = env.get(var)
+            marker = os.sep + 'rank0' + os.sep
+            if not src or marker not in src + os.sep or not os.path.isdir(src):
+                continue                                    # not one of per_rank_miopen_env's directories
+            for k in range(1, world):
+                dst = (src + os.sep).replace(marker, f'{os.sep}rank{k}{os.sep}').rstrip(os.sep)
+                shutil.copytree(src, dst, dirs_exist_ok=True)
+    barrier()
+    if rank != 0:
+        result = warm()
+    return result
+
+
 def self_launch(n_ranks, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: this process -- which has made NO GPU call and makes none --
     starts N fresh children of this same script, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what
@@ -679,6 +727,26 @@ def stub_main(args, rank, world, result_fd):
     x = torch.zeros(64)
     for _ in range(args.warmup):
         x += 1
+    # rehearsal of one_solver_search: the stub "convolution" finds its solver in this rank's MIOpen user directory or "searches" for
+    # GNERF_BENCH_STUB_SEARCH_S seconds and records it there; with the shared search only rank 0 pays, whatever the number of ranks
+    search = {'hit_before_first_conv': None, 'searched_s': 0.0}
+
+    def stub_conv():
+        d = os.environ.get('MIOPEN_USER_DB_PATH')
+        rec = os.path.join(d, 'stub_solver.ufdb.txt') if d else None
+        hit = bool(rec and os.path.isfile(rec))
+        if search['hit_before_first_conv'] is None:
+            search['hit_before_first_conv'] = hit
+        if not hit:
+            t = float(os.environ.get('GNERF_BENCH_STUB_SEARCH_S', '0.5'))
+            time.sleep(t)
+            search['searched_s'] += t
+            if rec:
+                with open(rec, 'w') as f:
+                    f.write(f'searched by rank {rank}\n')
+    t_search = time.perf_counter()
+    one_solver_search(rank, world, stub_conv, (dist.barrier if world > 1 else (lambda: None)))
+    search['wall_s'] = time.perf_counter() - t_search
     if os.environ.get('GNERF_BENCH_STUB_FAIL_RANK') == str(rank):       # rehearsal of a rank that dies while its peers wait in a collective
         os._exit(3)
     if world > 1:
@@ -691,6 +759,13 @@ def stub_main(args, rank, world, result_fd):
         dist.barrier()
     elapsed = gnerf_harness.max_over_ranks(time.perf_counter() - t0, dev)
     ranks = rank_identity(rank, world, dev)
+    if world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, search)
+    else:
+        everyone = [search]
+    for r_, s_ in zip(ranks, everyone):
+        r_['solver_search'] = s_
     assert float(x[0]) == args.steps + args.warmup and elapsed >= mine
     if rank == 0:
         line = {'metric': 'stub (no rendering): launcher / rendezvous / reduction rehearsal', 'stub': True, 'value': None, 'unit': None,

@@ -30,6 +30,22 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(gnerf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipFuncSetAttribute is per device: remember which devices of this process have had a kernel's dynamic-LDS limit raised.  One static
+// instance per kernel instantiation.  A device index outside the table (or a failing hipGetDevice) raises the limit on every call rather
+// than sharing a slot with another device; two threads racing on the first call both raise it (idempotent).
+struct PerDeviceOnce {
+    bool done[64] = {};
+    template <class K> int raise_lds(K kernel, const char* what, int bytes = 160 * 1024) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+        if (dev >= 0 && done[dev]) return GNERF_OK;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+            return fail(GNERF_E_LAUNCH, "%s: cannot raise the dynamic LDS limit", what);
+        if (dev >= 0) done[dev] = true;
+        return GNERF_OK;
+    }
+};
+
 // Storage type -> arithmetic type (half computes in float, like the reference's InternalType).
 template <class T> struct Arith { typedef float type; };
 template <> struct Arith<double> { typedef double type; };

@@ -74,6 +74,9 @@ struct ConvArgs {
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#ifndef GNERF_CONV_EPILOGUE_F32
+#define GNERF_CONV_EPILOGUE_F32 1
+#endif
 
 // MODE 0: the 3x3 convolution (padding 1) with the epilogue.
 // MODE 1 (round 5): the stride-2 TRANSPOSED 3x3 convolution of the x2 layers (conv_transpose2d(x, w, stride 2): 2H + 1 outputs per axis; what
@@ -267,6 +270,72 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     auto registers_to_lds = [&](auto has_clamp) {
     const float clampv = decltype(has_clamp)::value ? fabsf(a.clamp) : -1.f;
     if constexpr (decltype(has_clamp)::value) __builtin_assume(clampv >= 0.f);
+#if GNERF_CONV_EPILOGUE_F32
+    // Round 6: the epilogue in fp32 on the accumulators, ONE rounding at the end.
+    //     y = clamp(lrelu((acc * dcoef + noise + bias)) * gain) * next_scale
+    //       = med3(max(u, alpha u), -c, c) * next_scale,   u = acc * (dcoef gain) + (bias gain) + (noise gain)       (gain > 0, 0 <= alpha <= 1)
+    // Per value: one fused multiply-add, one add, the lrelu's multiply and max, the clamp's v_med3, the next layer's multiply -- the three
+    // fp32 multiply / add steps as packed instructions on accumulator pairs -- and half a v_cvt_pk_f16_f32: 4.5 vector instructions where
+    // the form that reproduced the two-launch route's fp16 roundings (conv output, demodulated value, activated value: GNERF_CONV_EPILOGUE_F32=0)
+    // took 18, most of them conversions.  Against the reference's fp32 arithmetic (networks_stylegan2.py:41-98, bias_act.py:92-122) this is
+    // CLOSER than the fp16 chain it replaces: the only rounding left is the output's.  Per-channel operands are scaled by the gain once per
+    // channel block, the lane's four noise values once per tile.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const float g = a.gain;
+    float nzg[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (NOISE && MODE == 0) {
+#pragma unroll
+        for (int pb = 0; pb < 4; pb++) {
+            float nz = a.noise[(y0 + 2 * wv + (pb >> 1)) * W + x0 + (pb & 1) * 16 + r];
+            if (a.round_noise) nz = round_to<__half>(nz);             // (the caller's noise tensor was fp16: noise.to(x.dtype), networks_stylegan2.py:313)
+            nzg[pb] = nz * g;
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 8; cb++) {
+        const int c4 = cb * 16 + hq * 4;                           // this lane's four consecutive output channels (of the workgroup's 128)
+        v2f scg[2] = {{g, g}, {g, g}}, nx[2] = {{1.f, 1.f}, {1.f, 1.f}}, bg[2] = {{0.f, 0.f}, {0.f, 0.f}};
+        if constexpr (SCALE) { const float4 v = *reinterpret_cast<const float4*>(ep + c4 * 4); scg[0] = (v2f){v.x, v.y} * g; scg[1] = (v2f){v.z, v.w} * g; }
+        if constexpr (NEXT) { const float4 v = *reinterpret_cast<const float4*>(ep + 512 + c4 * 4); nx[0] = (v2f){v.x, v.y}; nx[1] = (v2f){v.z, v.w}; }
+        if (a.bias) {
+            typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+            const h4v hb = __builtin_bit_cast(h4v, *reinterpret_cast<const uint2*>(ep + 1024 + c4 * 2));
+            bg[0] = (v2f){float(hb[0]), float(hb[1])} * g; bg[1] = (v2f){float(hb[2]), float(hb[3])} * g;
+        }
+#pragma unroll
+        for (int pb = 0; pb < 4; pb++) {
+            const int prow = 2 * wv + (pb >> 1), pcol = (pb & 1) * 16 + r;
+            const int p = prow * kTW + pcol;
+            unsigned words[2];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++) {
+                const v2f av = {acc[cb][pb][2 * k2], acc[cb][pb][2 * k2 + 1]};
+                h2 out;
+                if constexpr (MODE == 1) {
+                    out = (h2){(_Float16)av[0], (_Float16)av[1]};      // the transposed convolution leaves as plain fp16 (blur + epilogue follow)
+                } else {
+                    v2f u = __builtin_elementwise_fma(av, scg[k2], bg[k2]);
+                    if constexpr (NOISE) u = u + (v2f){nzg[pb], nzg[pb]};
+                    const v2f ua = u * a.alpha;
+                    // lrelu with a slope in [0, 1] (checked by the launcher) = max(u, alpha u).  The bare instruction: fmaxf() on the packed
+                    // operations' results costs a canonicalising v_max_f32 x, x apiece in IEEE mode (256 of them per lane here); the
+                    // instruction itself returns the other operand for a NaN, like fmaxf
+                    float r0, r1;
+                    asm("v_max_f32 %0, %1, %2" : "=v"(r0) : "v"(u[0]), "v"(ua[0]));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(r1) : "v"(u[1]), "v"(ua[1]));
+                    if constexpr (decltype(has_clamp)::value) { r0 = __builtin_amdgcn_fmed3f(r0, -clampv, clampv); r1 = __builtin_amdgcn_fmed3f(r1, -clampv, clampv); }
+                    v2f rr = {r0, r1};
+                    if constexpr (NEXT) rr = rr * nx[k2];
+                    out = (h2){(_Float16)rr[0], (_Float16)rr[1]};
+                }
+                words[k2] = __builtin_bit_cast(unsigned, out);
+            }
+            // (c4 >> 3 = 2 cb + (hq >> 1) and 2 cb only touches the slot's upper bits: the address is the cb = 0 one with cb << 5 XORed in)
+            *reinterpret_cast<uint2*>(os + ((p * 256 + ((((hq >> 1) ^ (p & 15)) << 4) + (hq & 1) * 8)) ^ (cb << 5))) = make_uint2(words[0], words[1]);
+        }
+    }
+#else
 #pragma unroll
     for (int cb = 0; cb < 8; cb++) {
         const int c4 = cb * 16 + hq * 4;                           // this lane's four consecutive output channels (of the workgroup's 128)
@@ -297,6 +366,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             *reinterpret_cast<uint2*>(os + p * 256 + (((c4 >> 3) ^ (p & 15)) << 4) + ((c4 >> 2) & 1) * 8) = __builtin_bit_cast(uint2, out);
         }
     }
+#endif
     };
     if (MODE == 0 && a.clamp >= 0.f) registers_to_lds(std::true_type{}); else registers_to_lds(std::false_type{});
     __syncthreads();
@@ -336,6 +406,7 @@ extern "C" int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, 
     if ((scale && (reinterpret_cast<uintptr_t>(scale) & 15)) || (next_scale && (reinterpret_cast<uintptr_t>(next_scale) & 15)))
         return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: scale and next_scale must be 16-byte aligned");
     if (!(alpha >= 0.f && alpha <= 1.f)) return fail(GNERF_E_UNSUPPORTED, "conv3x3_epilogue_nhwc: the lrelu slope must lie in [0, 1] (got %g)", double(alpha));
+    if (!(gain > 0.f)) return fail(GNERF_E_UNSUPPORTED, "conv3x3_epilogue_nhwc: the gain must be positive (got %g): it is folded into the lrelu's operands", double(gain));
     if (bias && (reinterpret_cast<uintptr_t>(bias) & 3)) return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: bias must be 4-byte aligned");
     ConvArgs a;
     a.x = static_cast<const _Float16*>(x); a.wpk = static_cast<const _Float16*>(w_packed); a.y = static_cast<_Float16*>(y);
@@ -348,14 +419,8 @@ extern "C" int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, 
     const dim3 grid((a.n_tiles + kNumXCD - 1) / kNumXCD * kNumXCD, cout / kCO), block(kConvThreads);
     hipStream_t s = as_stream(stream);
 #define GNERF_CONV(SC, NZ, NX) do { \
-        static bool raised[64] = {}; \
-        int dev = 0; \
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0; \
-        if (!raised[dev]) { \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_epilogue_kernel<0, SC, NZ, NX>), hipFuncAttributeMaxDynamicSharedMemorySize, kConvLds) != hipSuccess) \
-                return fail(GNERF_E_LAUNCH, "conv3x3_epilogue_nhwc: cannot raise the dynamic LDS limit"); \
-            raised[dev] = true; \
-        } \
+        static PerDeviceOnce once; \
+        if (int rc = once.raise_lds(conv3x3_epilogue_kernel<0, SC, NZ, NX>, "conv3x3_epilogue_nhwc", kConvLds)) return rc; \
         hipLaunchKernelGGL((conv3x3_epilogue_kernel<0, SC, NZ, NX>), grid, block, kConvLds, s, a); } while (0)
     const int key = (scale ? 4 : 0) | (noise ? 2 : 0) | (next_scale ? 1 : 0);
     switch (key) {
@@ -394,14 +459,8 @@ extern "C" int gnerf_conv_transpose3x3_s2_nhwc(const void* x, const void* w_phas
     a.out_h = 2 * h + 1; a.out_w = 2 * w + 1;
     a.round_noise = 0; a.alpha = 0.f; a.gain = 1.f; a.clamp = -1.f;
     const dim3 grid((a.n_tiles + kNumXCD - 1) / kNumXCD * kNumXCD, cout / kCO), block(kConvThreads);
-    static bool raised[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!raised[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_epilogue_kernel<1, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kConvLds) != hipSuccess)
-            return fail(GNERF_E_LAUNCH, "conv_transpose3x3_s2_nhwc: cannot raise the dynamic LDS limit");
-        raised[dev] = true;
-    }
+    static PerDeviceOnce once;
+    if (int rc = once.raise_lds(conv3x3_epilogue_kernel<1, false, false, false>, "conv_transpose3x3_s2_nhwc", kConvLds)) return rc;
     hipLaunchKernelGGL((conv3x3_epilogue_kernel<1, false, false, false>), grid, block, kConvLds, as_stream(stream), a);
     return check_launch("conv_transpose3x3_s2_nhwc");
 }

@@ -106,24 +106,70 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_mov(float old, float src) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xf, false));
 }
+// Round 6: every step is ONE instruction that reads and writes the same register -- `v_op_dpp v, v, v <shift>`: lanes the shift gives
+// no source (and rows the row_mask leaves out) are simply not written, i.e. keep their own value, which is the scan's identity step.
+// Written through update_dpp + an arithmetic instruction the compiler can only fold the full-mask row shifts of the sum (old = 0 is
+// its bound_ctrl zero); every row_bcast step and every step of the product scan came out as v_mov (old) + v_mov_dpp + op: 10 / 18
+// vector instructions per scan instead of 6, on the wave whose per-ray pass is 476 of them (GNERF_DPP_INPLACE=0 is that form).
+// The s_nop 1 are the two wait states a DPP read needs after the VALU write of its source; the compiler's hazard recogniser does not
+// look inside (or behind) inline assembly, so the blocks begin and end with one as well.
+#ifndef GNERF_DPP_INPLACE
+#define GNERF_DPP_INPLACE 1
+#endif
+#define GNERF_SCAN6(OP, ZF)                                                                 \
+    "s_nop 1\n\t"                                                                           \
+    OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" ZF "\n\ts_nop 1\n\t"              \
+    OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" ZF "\n\ts_nop 1\n\t"              \
+    OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" ZF "\n\ts_nop 1\n\t"              \
+    OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" ZF "\n\ts_nop 1\n\t"              \
+    OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"                 \
+    OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
 __device__ __forceinline__ float wave_scan_add(float v, int /*lane*/) {         // inclusive
+#if GNERF_DPP_INPLACE
+    asm(GNERF_SCAN6("v_add_f32_dpp", " bound_ctrl:1") : "+v"(v));
+#else
     v += dpp_mov<0x111, 0xf>(0.f, v);
     v += dpp_mov<0x112, 0xf>(0.f, v);
     v += dpp_mov<0x114, 0xf>(0.f, v);
     v += dpp_mov<0x118, 0xf>(0.f, v);
     v += dpp_mov<0x142, 0xa>(0.f, v);
     v += dpp_mov<0x143, 0xc>(0.f, v);
+#endif
     return v;
 }
 __device__ __forceinline__ float wave_scan_mul(float v, int /*lane*/) {         // inclusive
+#if GNERF_DPP_INPLACE
+    asm(GNERF_SCAN6("v_mul_f32_dpp", "") : "+v"(v));
+#else
     v *= dpp_mov<0x111, 0xf>(1.f, v);
     v *= dpp_mov<0x112, 0xf>(1.f, v);
     v *= dpp_mov<0x114, 0xf>(1.f, v);
     v *= dpp_mov<0x118, 0xf>(1.f, v);
     v *= dpp_mov<0x142, 0xa>(1.f, v);
     v *= dpp_mov<0x143, 0xc>(1.f, v);
+#endif
     return v;
 }
+// two independent sums at once: the steps of one fill a wait state of the other
+__device__ __forceinline__ void wave_scan_add2(float& a, float& b) {
+#if GNERF_DPP_INPLACE
+#define GNERF_STEP2(CTRL)                                                       \
+    "v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
+    asm("s_nop 1\n\t"
+        GNERF_STEP2("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        GNERF_STEP2("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        GNERF_STEP2("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        GNERF_STEP2("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        GNERF_STEP2("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        GNERF_STEP2("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        "s_nop 0"
+        : "+v"(a), "+v"(b));
+#undef GNERF_STEP2
+#else
+    a = wave_scan_add(a, 0); b = wave_scan_add(b, 0);
+#endif
+}
+#undef GNERF_SCAN6
 __device__ __forceinline__ float wave_last(float v) {                            // lane 63's value, in every lane
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
@@ -402,8 +448,9 @@ __device__ __forceinline__ void march(const float* t, const float* sig, float* w
         carry *= wave_last(incl);
         if (ok) { w[k] = wk; acc_w += wk; acc_wt += wk * tmid; }
     }
-    w_sum = wave_sum(acc_w);
-    wt_sum = wave_sum(acc_wt);
+    wave_scan_add2(acc_w, acc_wt);
+    w_sum = wave_last(acc_w);
+    wt_sum = wave_last(acc_wt);
 }
 
 // ---- the call-wide depth range (ray_marcher.py:49-50).
@@ -756,19 +803,7 @@ __device__ __forceinline__ int choose_mlp(const Params& P, float* smem, bool* so
 #include "render_pipe.inl"
 #include "render_bwd.inl"
 
-// hipFuncSetAttribute is per device: remember which devices of this process have had a kernel's dynamic-LDS limit raised
-struct PerDeviceOnce {
-    bool done[64] = {};
-    template <class K> int raise_lds(K kernel, const char* what) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
-        if (dev >= 0 && done[dev]) return GNERF_OK;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return fail(GNERF_E_LAUNCH, "%s: cannot raise the dynamic LDS limit", what);
-        if (dev >= 0) done[dev] = true;
-        return GNERF_OK;
-    }
-};
+// (PerDeviceOnce: csrc/common.h)
 
 int check_common(const gnerf_render_params* p) {
     if (!p) return fail(GNERF_E_ARG, "render: params is null");

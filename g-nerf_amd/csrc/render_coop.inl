@@ -98,13 +98,15 @@ __device__ __forceinline__ h8 as_h8(u4v v) { return __builtin_bit_cast(h8, v); }
 // conflicted reads of a tile); time-neutral at config 2 (A/B on one box: 0.5845 vs 0.5852 ms per step), the LDS unit was ~44 % busy.
 constexpr int kW1FragHalves = 4 * 64 * 8;   // halves of W1 hi (or lo): [m = 4 hidden blocks][lane][8 channels]
 constexpr int kWeightFloatsF32 = 64 * 36 + 33 * 68;
-constexpr int kWeightFloatsF16 = (2 * kW1FragHalves + 2 * 2048) / 2 + 64;     // W1 hi+lo, W2 hi+lo (fragment order), density row fp32
+constexpr int kWeightFloatsF16 = (2 * kW1FragHalves + 2 * 2048) / 2 + 64 + 128; // W1 hi+lo, W2 hi+lo (fragment order), density row fp32, colour biases x4
 __host__ __device__ constexpr int weight_floats(int mlp) {
     return mlp == kMlpF32 ? kWeightFloatsF32 : (mlp == kMlpF16x3 ? kWeightFloatsF16 : (kWeightFloatsF32 > kWeightFloatsF16 ? kWeightFloatsF32 : kWeightFloatsF16));
 }
 
 struct CoopLds {
     float* w1; float* w2; float* b1; float* b2;
+    float* b2c;      // f16x3 decoder: [32][4] the colour biases, each four times -- layer 2's accumulator initialisation is then two ds_read_b128
+                     // per tile instead of a two-word read and eight v_mov_b32 (round 6)
     float* t_e; float* sig_e; float* v_e; int* rank_e; float* s_t; float* s_sig; float* w_s; float* cdf;
     float* taps;     // [waves][16][24]           wave w's records at taps + w * wave_pitch_taps
     float* stage;    // [waves][16][kStagePitch]  wave w's rows at stage + w * wave_pitch_stage
@@ -160,6 +162,9 @@ __device__ __forceinline__ float sigmoid_rgb_hw(float x) {      // sigmoid(x) * 
 // Byte addressing of a texel: y * row_pitch + x * tex_pitch + plane offset (Params::tex_pitch / row_pitch / plane_pitch):
 // [3N,H,W,32] planes have tex_pitch 128, plane offset pl * H * W * 128; the interleaved [N,H,W,96] form (channels_last of the
 // backbone's [N,96,H,W] output) has tex_pitch 384, plane offset pl * 128.  Pitches and coordinates are < 2^24: 24-bit multiplies.
+#ifndef GNERF_TAPS_LEAN
+#define GNERF_TAPS_LEAN 1
+#endif
 __device__ __forceinline__ void plane_taps(int H, int W, float u, float v, unsigned tex_pitch, unsigned row_pitch, unsigned plane_bytes_off, uint4& off, v4f& wgt) {
     float ix = ((u + 1.f) * float(W) - 1.f) * 0.5f;
     float iy = ((v + 1.f) * float(H) - 1.f) * 0.5f;
@@ -168,11 +173,25 @@ __device__ __forceinline__ void plane_taps(int H, int W, float u, float v, unsig
     const float x0f = floorf(ix), y0f = floorf(iy);
     const float fx = ix - x0f, fy = iy - y0f;
     const int x0 = int(x0f), y0 = int(y0f), x1 = x0 + 1, y1 = y0 + 1;
+#if GNERF_TAPS_LEAN
+    // round 6, same values from fewer instructions: "0 <= x < W" is ONE unsigned compare (a negative index is a huge unsigned one; the
+    // compiler cannot make that step itself, it does not know W > 0), and the clamp to the last texel one v_med3_i32 instead of
+    // v_max_i32 + v_min_i32 (it only folds the pair when both bounds are constants): 8 compares + 4 mask ands + 8 min / max -> 4 + 0 + 4
+    // per (sample, plane), all of them half-rate instructions (tools/probes/valu_issue_probe)
+    auto inside = [](int i, int n) { return unsigned(i) < unsigned(n); };
+    auto clamp0 = [](int i, int last) { int r; asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(i), "s"(last)); return r; };
+    const float wx0 = inside(x0, W) ? 1.f - fx : 0.f, wx1 = inside(x1, W) ? fx : 0.f;
+    const float wy0 = inside(y0, H) ? (1.f - fy) * (1.f / 3.f) : 0.f, wy1 = inside(y1, H) ? fy * (1.f / 3.f) : 0.f;
+    const unsigned cx0 = __umul24(unsigned(clamp0(x0, W - 1)), tex_pitch), cx1 = __umul24(unsigned(clamp0(x1, W - 1)), tex_pitch);
+    const unsigned cy0 = __umul24(unsigned(clamp0(y0, H - 1)), row_pitch) + plane_bytes_off;
+    const unsigned cy1 = __umul24(unsigned(clamp0(y1, H - 1)), row_pitch) + plane_bytes_off;
+#else
     const float wx0 = (x0 >= 0 && x0 < W) ? 1.f - fx : 0.f, wx1 = (x1 >= 0 && x1 < W) ? fx : 0.f;
     const float wy0 = (y0 >= 0 && y0 < H) ? (1.f - fy) * (1.f / 3.f) : 0.f, wy1 = (y1 >= 0 && y1 < H) ? fy * (1.f / 3.f) : 0.f;
     const unsigned cx0 = __umul24(unsigned(min(max(x0, 0), W - 1)), tex_pitch), cx1 = __umul24(unsigned(min(max(x1, 0), W - 1)), tex_pitch);
     const unsigned cy0 = __umul24(unsigned(min(max(y0, 0), H - 1)), row_pitch) + plane_bytes_off;
     const unsigned cy1 = __umul24(unsigned(min(max(y1, 0), H - 1)), row_pitch) + plane_bytes_off;
+#endif
     off = make_uint4(cy0 + cx0, cy0 + cx1, cy1 + cx0, cy1 + cx1);
     wgt = (v4f){wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
 }
@@ -240,6 +259,8 @@ __device__ __forceinline__ void stage_decoder(CoopLds& L, float* base, const gne
         w2h[2048 + dst] = (_Float16)(x - (float)hi);
     }
     for (int i = tid; i < 64; i += nthreads) L.w2[i] = p.w2[i] * kLn2;
+    L.b2c = L.w2 + 64;
+    for (int i = tid; i < 128; i += nthreads) L.b2c[i] = p.b2[1 + (i >> 2)] * -kLog2e;
     for (int i = tid; i < 64; i += nthreads) L.b1[i] = p.b1[i] * kLog2e;
     for (int i = tid; i < 33; i += nthreads) L.b2[i] = i == 0 ? p.b2[0] : p.b2[i] * -kLog2e;
     }
@@ -266,9 +287,19 @@ __device__ __forceinline__ float row_total(float v) {
     return v;
 }
 
+// Round 6: a lane of the tap set-up (sample j, plane pl = lane >> 4) needs two coordinates of the point, u = (ou + t du) s and
+// v = (ov + t dv) s with (u, v) = (x, y), (x, z), (z, x) for planes 0, 1, 2 (renderer.py:23-53).  It used to form all three of
+// x, y, z and pick two with three v_cndmask per tile; now the ray arrives as the lane's own (ou, du, ov, dv) -- the cooperative kernel
+// selects once per ray, the pipelined kernels' scalar wave parks the twelve values per plane in the slot and a lane reads its four in
+// one ds_read_b128 (render_pipe.inl: kMiscUV).  Same operations on the same operands: bit-identical.
 struct CoopRay {
     const char* planes_item;    // uniform
-    float ox, oy, oz, dx, dy, dz;
+    float ou, du, ov, dv;       // per lane (by plane)
+    __device__ __forceinline__ void set(float ox, float oy, float oz, float dx, float dy, float dz, int lane) {
+        const int pl = lane >> 4;
+        ou = pl == 2 ? oz : ox; du = pl == 2 ? dz : dx;
+        ov = pl == 0 ? oy : (pl == 1 ? oz : ox); dv = pl == 0 ? dy : (pl == 1 ? dz : dx);
+    }
 };
 
 // Shade one 16-sample tile: depths t_list[16*tile ...] (clamped to count-1) -> density into sig_list (if
@@ -300,11 +331,12 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
         const int j = lane & 15, pl = lane >> 4;
         const int idx = min(16 * tile + j, count - 1);
         const float depth = have_depth ? depth_in : t_list[idx];       // (the pipelined kernels fetch it with the ray's parameters, one round trip)
-        const float px = __fadd_rn(R.ox, __fmul_rn(depth, R.dx)) * P.box_scale;
-        const float py = __fadd_rn(R.oy, __fmul_rn(depth, R.dy)) * P.box_scale;
-        const float pz = __fadd_rn(R.oz, __fmul_rn(depth, R.dz)) * P.box_scale;
-        const float u = pl == 2 ? pz : px;                               // plane 0 (x,y), 1 (x,z), 2 (z,x)
-        const float v = pl == 0 ? py : (pl == 1 ? pz : px);
+        // plane 0 (x,y), 1 (x,z), 2 (z,x): see CoopRay.  The roundings are the ones this code has always had -- o + t d as one fused
+        // operation, the box scale as a multiply of its own -- pinned: with the per-plane select gone, fp contraction would otherwise
+        // merge the scale into plane_taps' `u + 1` (an empty asm is opaque to it and costs nothing)
+        float u = __builtin_fmaf(depth, R.du, R.ou) * P.box_scale;
+        float v = __builtin_fmaf(depth, R.dv, R.ov) * P.box_scale;
+        asm("" : "+v"(u), "+v"(v));
         uint4 off; v4f wgt;
         plane_taps(H, W, u, v, P.tex_pitch, P.row_pitch, unsigned(pl) * P.plane_pitch, off, wgt);
         float* rec = taps + j * kFwdTapStride + pl * 8;
@@ -591,8 +623,7 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     }
     // Layer 2: O [16 samples x 16 outs] = H [16 x 64] . W2^T: two k-steps of 32; this lane contributes, at k-step s,
     // its activations of blocks 2s and 2s+1 (weights were stored in the matching order by stage_decoder).
-    const float bc0 = L.b2[1 + j], bc1 = L.b2[17 + j];
-    o[0] = (v4f){bc0, bc0, bc0, bc0}; o[1] = (v4f){bc1, bc1, bc1, bc1};
+    o[0] = *reinterpret_cast<const v4f*>(L.b2c + 4 * j); o[1] = *reinterpret_cast<const v4f*>(L.b2c + 64 + 4 * j);
     h8 x_hi[2], x_lo[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
@@ -692,8 +723,8 @@ __device__ __forceinline__ void render_coop_body(const Params& P, float* smem, b
         const int item = int(ray / p.rays_per_item);
         CoopRay R;
         R.planes_item = reinterpret_cast<const char*>(p.planes_nhwc) + int64_t(item) * P.item_bytes;
-        R.ox = p.ray_origins[ray * 3 + 0]; R.oy = p.ray_origins[ray * 3 + 1]; R.oz = p.ray_origins[ray * 3 + 2];
-        R.dx = p.ray_dirs[ray * 3 + 0];    R.dy = p.ray_dirs[ray * 3 + 1];    R.dz = p.ray_dirs[ray * 3 + 2];
+        R.set(p.ray_origins[ray * 3 + 0], p.ray_origins[ray * 3 + 1], p.ray_origins[ray * 3 + 2],
+              p.ray_dirs[ray * 3 + 0], p.ray_dirs[ray * 3 + 1], p.ray_dirs[ray * 3 + 2], lane);
         float* dbg = p.debug ? p.debug + ray * GNERF_DEBUG_SLOTS * n_all : nullptr;
 
         // ---- stratified depth proposals (renderer.py:169-192)

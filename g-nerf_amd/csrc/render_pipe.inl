@@ -46,8 +46,15 @@ struct PipeSlot {
     float* t_e; float* sig_e; float* v_e; int* rank_e; float* s_t; float* s_sig; float* w_s; float* cdf;
     float* nf;      // [kMaxS] fine noise of this ray
     float* part;    // [3][32] colour partial sums of the shader waves
-    float* misc;    // [0..5] origin, direction  [6] item (int)  [7] ray (int)  [8] w_sum  [9] wt_sum
+    float* misc;    // [0..11] the ray per plane: (ou, du, ov, dv) x 3 (CoopRay, render_coop.inl)  [12] item (int)  [13] ray (int)  [14] w_sum  [15] wt_sum
 };
+constexpr int kMiscItem = 12, kMiscRay = 13, kMiscWsum = 14, kMiscWtsum = 15;
+// lane l < 12 of the scalar wave carries component misc_comp(l) of (origin xyz, direction xyz): plane l / 4, then ou, du, ov, dv
+__device__ __forceinline__ int misc_comp(int l) {
+    const int pl = l >> 2, q = l & 3;
+    const int axis = q < 2 ? (pl == 2 ? 2 : 0) : (pl == 0 ? 1 : (pl == 1 ? 2 : 0));       // u: x, x, z   v: y, z, x
+    return (q & 1) * 3 + axis;
+}
 
 template <int TP>
 __device__ __forceinline__ PipeSlot pipe_slot(float* base, int slot) {
@@ -86,6 +93,9 @@ __device__ __forceinline__ int pipe_seq_to_ray(const Params& P, int64_t seq) {
 #endif
 #ifndef GNERF_PIPE_WAVES_PER_SIMD
 #define GNERF_PIPE_WAVES_PER_SIMD 4
+#endif
+#ifndef GNERF_PIPE_ROTATE
+#define GNERF_PIPE_ROTATE 1
 #endif
 // FULL: the call fills the kernel's sample slots exactly (depth_resolution = depth_resolution_importance = 48 TP: the reference's 48+48
 // default, gen_videos.py's doubled 96+96) with plain stratified sampling (no disparity spacing, no per-ray limits) and no stage dump.
@@ -135,10 +145,15 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
     const int n_all = S + F;
     CoopLds L;
     float* slots = smem + weight_floats(MLP) + 64 + 36;
-    // A wave's tap records (16 x 24 floats) and its staging rows (16 x 36) share one area: coop_shade_tile has every record in
-    // registers before it writes the first staging row, and has read the rows back before the next tile's records are written
-    // (LDS operations of a wave execute in order).  Those 4.6 KB are what lets FOUR workgroups share a CU's 160 KB.
-    static_assert(kStagePitch >= kTapDwords, "tap records must fit in the staging rows");
+    // A wave's tap records (16 records of kFwdTapStride = 28 dwords, 24 of them used) and its staging rows (16 rows of kFwdStagePitch
+    // = 32 dwords, swizzled) share one area of 16 x kStagePitch dwords.  What makes that safe is an ORDER inside coop_shade_tile, not a
+    // layout: every read of a record -- the offsets of both lookup steps and, last, step 1's weights (`w1`, fetched right before `row0`
+    // is stored and kept in front of that store by pin()) -- is issued before the first row is written, and the rows have been read back
+    // (f_lo / f_hi) before the next tile's records are written; LDS operations of one wave execute in issue order.  Both layouts must fit
+    // the area whatever tools/build_variants.sh sets GNERF_TAP_STRIDE / GNERF_STAGE_SWZ to.  Those 4.6 KB are what lets FOUR workgroups
+    // share a CU's 160 KB.
+    static_assert(16 * kFwdTapStride <= 16 * kStagePitch && 16 * kFwdStagePitch <= 16 * kStagePitch && kFwdTapStride >= kTapDwords,
+                  "tap records and staging rows share 16 x kStagePitch dwords per wave");
     L.taps = slots + kPipeSlots * kSlotFloats;
     L.stage = L.taps;
     L.wave_pitch_taps = L.wave_pitch_stage = 16 * kStagePitch;
@@ -210,10 +225,9 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
             }
         }
         if (GEN && p.cam2world) {
-            if (lane < 6) pre_ray = unit_rays[(r % unit) * 8 + lane];       // (LDS operations of one wave execute in order)
+            if (lane < 12) pre_ray = unit_rays[(r % unit) * 8 + misc_comp(lane)];       // (LDS operations of one wave execute in order)
         } else {
-            if (lane < 3) pre_ray = p.ray_origins[ray * 3 + lane];
-            else if (lane < 6) pre_ray = p.ray_dirs[ray * 3 + lane - 3];
+            if (lane < 12) { const int c = misc_comp(lane); pre_ray = c < 3 ? p.ray_origins[ray * 3 + c] : p.ray_dirs[ray * 3 + c - 3]; }
         }
         if (!FULL && p.ray_start_per_ray) { pre_rs = p.ray_start_per_ray[ray]; pre_re = p.ray_end_per_ray[ray]; }
         if constexpr (BWD) {        // the ray's incoming gradients: rgb = 2 * composite - 1 (ray_marcher.py:55), depth, weight sum
@@ -226,7 +240,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
     auto propose_finish = [&](int r) {          // P(r), second half: depth proposals (renderer.py:169-192) into the slot
         if (r < 0 || r >= nr) return;
         PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
-        if (lane == 7) sl.misc[7] = __int_as_float(pre_ray_id);
+        if (lane == kMiscRay) sl.misc[kMiscRay] = __int_as_float(pre_ray_id);
         if (pre_ray_id < 0) return;
 #pragma unroll
         for (int q = 0; q < RND; q++) {
@@ -256,11 +270,10 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
 #pragma unroll
         for (int q = 0; q < RND; q++)
             if (lane + 64 * q < F) sl.nf[lane + 64 * q] = pre_uf[q];
-        if (lane < 6) sl.misc[lane] = pre_ray;
-        if (lane == 6) sl.misc[6] = __int_as_float(pre_ray_id / p.rays_per_item);
+        if (lane < 12) sl.misc[lane] = pre_ray;
+        if (lane == kMiscItem) sl.misc[kMiscItem] = __int_as_float(pre_ray_id / p.rays_per_item);
         if constexpr (BWD) {
-            if (lane < 32) sl.part[lane] = pre_g;
-            else if (lane < 34) sl.misc[10 + lane - 32] = pre_g;
+            if (lane < 34) sl.part[lane] = pre_g;            // [0..31] dL/d(colour sum), [32] dL/ddepth, [33] dL/dwsum (the forward's other partials are unused here)
         }
         for (int e = lane; e < s_pad; e += 64) {
             sl.v_e[e] = 0.f;
@@ -270,7 +283,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
     auto importance = [&](int r) {              // B(r): coarse march (ray_marcher.py:26-42) + importance depths (renderer.py:194-253)
         if (r < 0 || r >= nr) return;
         PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
-        const int ray_id = __float_as_int(sl.misc[7]);
+        const int ray_id = __float_as_int(sl.misc[kMiscRay]);
         if (ray_id < 0) return;
         float* dbg = debug ? debug + int64_t(ray_id) * GNERF_DEBUG_SLOTS * n_all : nullptr;
         float ws, wts;
@@ -339,7 +352,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
     auto finalize = [&](int r) {                // D(r): merge by depth (renderer.py:157-167) + final march + per-sample colour weights
         if (r < 0 || r >= nr) return;
         PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
-        const int ray_id = __float_as_int(sl.misc[7]);
+        const int ray_id = __float_as_int(sl.misc[kMiscRay]);
         if (ray_id < 0) return;
         float* dbg = debug ? debug + int64_t(ray_id) * GNERF_DEBUG_SLOTS * n_all : nullptr;
         // Stable rank in cat([coarse, fine]).  Coarse depths ascend by construction, so
@@ -497,7 +510,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
             lds_wave_sync();
             //   dL/dw_k = (q_k + q_{k+1}) / 2 - [white_back] sum_c G[c] + g_depth (tmid_k - depth) / W + g_wsum
             //   dL/dalpha_k = dL/dw_k T_k - (sum_{m>k} dL/dw_m w_m) / (1 - alpha_k + 1e-10)
-            const float g_depth = sl.misc[10], g_wsum = sl.misc[11];
+            const float g_depth = sl.part[32], g_wsum = sl.part[33];
             const float g_sum = p.white_back ? wave_sum(lane < 32 ? sl.part[lane] : 0.f) : 0.f;
             const float depth = wt_sum / w_sum;
             const float gd_scale = (w_sum > 0.f && depth == depth) ? g_depth / w_sum : 0.f;     // nan_to_num'd rays pass no depth gradient
@@ -553,9 +566,9 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
             sl.v_e[e] = (wl + wr) * 0.5f;                       // midpoint colours (ray_marcher.py:27) regrouped per sample
         }
         if (lane == 0) {
-            sl.misc[8] = ws;
-            sl.misc[9] = wts;
-            range.add(P, __float_as_int(sl.misc[6]), sl.s_t[0], sl.s_t[n_all - 1]);
+            sl.misc[kMiscWsum] = ws;
+            sl.misc[kMiscWtsum] = wts;
+            range.add(P, __float_as_int(sl.misc[kMiscItem]), sl.s_t[0], sl.s_t[n_all - 1]);
         }
         if (dbg) {
             for (int k = lane; k < F; k += 64) dbg[GNERF_DBG_SIGMA_FINE * n_all + k] = sl.sig_e[fine_e0 + k];
@@ -566,9 +579,9 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
     auto output = [&](int r) {                  // out(r): sum the shader waves' colour partials, write the three outputs
         if (r < 0 || r >= nr) return;
         PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
-        const int ray_id = __float_as_int(sl.misc[7]);
+        const int ray_id = __float_as_int(sl.misc[kMiscRay]);
         if (ray_id < 0) return;
-        const float ws = sl.misc[8], wts = sl.misc[9];
+        const float ws = sl.misc[kMiscWsum], wts = sl.misc[kMiscWtsum];
         if (lane < 32) {
             float c = sl.part[lane] + sl.part[32 + lane] + sl.part[64 + lane];
             if (p.white_back) c = c + 1.f - ws;
@@ -592,15 +605,19 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
         PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
         const float* t_list = fine ? sl.t_e + fine_e0 : sl.t_e;
         const int count = fine ? F : S;
-        const v4f m0 = *reinterpret_cast<const v4f*>(sl.misc), m1 = *reinterpret_cast<const v4f*>(sl.misc + 4);
-        const float depth0 = t_list[min(16 * wv + (lane & 15), count - 1)];          // tile wv (the first of this wave's tiles)
-        const int ray_id = __builtin_amdgcn_readfirstlane(__float_as_int(m1[3]));
+        const v4f uv = *reinterpret_cast<const v4f*>(sl.misc + 4 * min(lane >> 4, 2));        // this lane's plane: (ou, du, ov, dv)
+        const float2 ids = *reinterpret_cast<const float2*>(sl.misc + kMiscItem);
+        float depth0 = t_list[min(16 * wv + (lane & 15), count - 1)];                // tile wv (the first of this wave's tiles)
+        float id_item = ids.x, id_ray = ids.y, r_ou = uv[0], r_du = uv[1], r_ov = uv[2], r_dv = uv[3];
+        // (all three reads leave together, in front of the branch on the ray id: left alone the compiler sinks the ray's words behind that
+        //  branch and the item's word behind the next -- three dependent LDS round trips at the head of every tile)
+        asm volatile("" : "+v"(id_item), "+v"(id_ray), "+v"(r_ou), "+v"(r_du), "+v"(r_ov), "+v"(r_dv), "+v"(depth0));
+        const int ray_id = __builtin_amdgcn_readfirstlane(__float_as_int(id_ray));
         if (ray_id < 0) return false;
         CoopRay R;
-        const int item = __builtin_amdgcn_readfirstlane(__float_as_int(m1[2]));
+        const int item = __builtin_amdgcn_readfirstlane(__float_as_int(id_item));
         R.planes_item = reinterpret_cast<const char*>(p.planes_nhwc) + int64_t(item) * P.item_bytes;
-        R.ox = m0[0]; R.oy = m0[1]; R.oz = m0[2];
-        R.dx = m0[3]; R.dy = m1[0]; R.dz = m1[1];
+        R.ou = r_ou; R.du = r_du; R.ov = r_ov; R.dv = r_dv;
         GNERF_STAMP(st, 0);     // ray parameters from the slot
 #pragma unroll
         for (int i = 0; i < TP; i++) {
@@ -644,7 +661,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
     auto emit_q = [&](int r, bool fine, const v4f (&col)[TP][2]) {        // BWD: q = sum_c G[c] colour[c] of the samples just shaded -> v_e
         if (r < 0 || r >= nr) return;
         PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
-        if (__float_as_int(sl.misc[7]) < 0) return;
+        if (__float_as_int(sl.misc[kMiscRay]) < 0) return;
         const int j = lane & 15, g = lane >> 4;
         const float G0 = sl.part[j], G1 = sl.part[16 + j];
 #pragma unroll
@@ -702,6 +719,53 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
         }
         return;
     }
+#if GNERF_PIPE_ROTATE
+    // Round 6: the three coarse colour sets change ROLES instead of registers.  Ray k+1's coarse colours are produced in step 2k+2 and
+    // consumed in step 2k+7, so three sets are live; the loop used to shift them along every iteration (cc0 = cc1, cc1 = cc2: 16
+    // v_mov_b32 at the bottom and 8 at the top, where the compiler parks the loop-carried set -- 72 vector instructions per ray over the
+    // three waves).  Unrolled three times, iteration k + i writes set (i + 2) % 3 and reads set i % 3: no copies.  Both roles run
+    // the same number of iterations, rounded up to a multiple of three (the extra ones find no ray and only meet at the barriers).
+    const int k_last = -1 + 3 * ((nr + 3 + 2) / 3) - 1;
+    if (wv < 3) {
+        v4f ca[TP][2] = {}, cb[TP][2] = {}, cd[TP][2] = {}, cf[TP][2] = {};
+        bool la = false, lb = false, ld = false;
+        auto iter = [&](int k, v4f (&c0)[TP][2], v4f (&c2)[TP][2], bool l0, bool& l2) {
+            l2 = shade(k + 1, false, c2);
+            GNERF_STAMP(st, 5);
+            __syncthreads();
+            GNERF_STAMP(st, 6);         // barrier wait, even step
+            accumulate(k - 1, l0, c0, cf);
+            GNERF_STAMP(st, 10);        // colour accumulate
+            shade(k, true, cf);
+            GNERF_STAMP(st, 5);
+            __syncthreads();
+            GNERF_STAMP(st, 7);         // barrier wait, odd step
+        };
+        for (int k = -1; k <= k_last; k += 3) {         // sets (k-1, k, k+1) = (a, b, d), then (b, d, a), then (d, a, b)
+            iter(k, ca, cd, la, ld);
+            iter(k + 1, cb, ca, lb, la);
+            iter(k + 2, cd, cb, ld, lb);
+        }
+    } else {
+        for (int k = -1; k <= k_last; k++) {
+            finalize(k - 1);
+            GNERF_STAMP(st, 8);         // merge + final march
+            output(k - 2);
+            GNERF_STAMP(st, 9);         // outputs
+            GNERF_STAMP(st, 5);         // rounding
+            __syncthreads();
+            GNERF_STAMP(st, 6);         // barrier wait, even step
+            propose_issue(k + 2);
+            importance(k + 1);
+            GNERF_STAMP(st, 11);        // coarse march + importance
+            propose_finish(k + 2);
+            GNERF_STAMP(st, 12);        // depth proposals
+            GNERF_STAMP(st, 5);
+            __syncthreads();
+            GNERF_STAMP(st, 7);         // barrier wait, odd step
+        }
+    }
+#else
     if (wv < 3) {
         v4f cc0[TP][2] = {}, cc1[TP][2] = {}, cc2[TP][2] = {}, cf[TP][2] = {};      // coarse colours of rays k-1, k, k+1; fine colours of ray k-1
         bool live0 = false, live1 = false, live2 = false;                            // do rays k-1, k, k+1 exist (from their coarse pass)
@@ -746,6 +810,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
             GNERF_STAMP(st, 7);         // barrier wait, odd step
         }
     }
+#endif
 #ifdef GNERF_STAMPS
     if (lane == 0 && p.debug) {
         unsigned long long* out = reinterpret_cast<unsigned long long*>(p.debug) + (size_t(blockIdx.x) * 4 + wv) * 16;

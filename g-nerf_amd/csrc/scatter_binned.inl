@@ -358,10 +358,19 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(BinArgs A) {
     }
 }
 
-// fp32 -> 64-bit fixed point: floor of t (|t| < 2^61) as {low word, high word}
+// fp32 -> 64-bit fixed point: floor of t (|t| < 2^61) as {low word, high word}.
+// Two things this leans on, both properties of the conversion instructions and both deterministic:
+//  * lo = t - hi 2^32 lies in [0, 2^32] -- CLOSED at the top: for a small negative t (t = -1.5: hi = -1) the exact difference 2^32 - 1.5
+//    is not a float and rounds up to 2^32.  v_cvt_u32_f32 saturates, so the low word becomes 0xFFFFFFFF and the sum is one unit of
+//    2^-s (<= 2^-49 of the tile's bound) above floor(t); an explicit clamp to 4294967040.f would cost a half-rate instruction per
+//    record and lane in the kernel's inner loop and give the same word.
+//  * the conversions send NaN to 0.  The padding records of a segment (bin_scan_kernel) carry weight zero and point at row 0 of the
+//    staging buffer -- the first ray's depths, not a row known to be finite; a non-finite depth there gives 0 * inf = NaN as the
+//    contribution, which this conversion turns into the zero a padding record must add (such a ray's own records go down the fp32
+//    ds_add_f32 path of its tile, where the NaN propagates as in the reference).
 __device__ __forceinline__ unsigned long long bin_to_fixed(float t) {
     const float hi = floorf(t * 2.3283064365386963e-10f);                 // floor(t / 2^32): |hi| < 2^29, exact
-    const float lo = fmaf(hi, -4294967296.f, t);                          // t - hi 2^32 in [0, 2^32): exact (a 24-bit value minus its upper part)
+    const float lo = fmaf(hi, -4294967296.f, t);                          // t - hi 2^32 (a 24-bit value minus its upper part; see above for the top end)
     const unsigned lo_u = __float2uint_rz(lo);
     const int hi_i = __float2int_rz(hi);
     return (static_cast<unsigned long long>(static_cast<unsigned>(hi_i)) << 32) | lo_u;

@@ -111,6 +111,8 @@ def _packed_prenormalised_weight(module, dtype, transposed=False):
 # GNERF_FUSED_CONV=0: the 3x3 layers of the shared-weight form go to MIOpen + gnerf_modconv_epilogue_nhwc (round 4's flow) instead of
 # the one-launch kernel of csrc/conv3x3.hip
 _FUSED_CONV = os.environ.get('GNERF_FUSED_CONV', '1') != '0'
+# GNERF_SHARED_AT_ONE=0: a batch of one keeps round 5's route (per-sample modulated weights into the framework's convolution)
+_SHARED_AT_ONE = os.environ.get('GNERF_SHARED_AT_ONE', '1') != '0'
 
 
 def _latent_token(w):
@@ -296,7 +298,7 @@ class StyledConv(nn.Module):
         elif noise_mode == 'const':
             noise = self.noise_const * self.noise_strength
         folded = False
-        assert not prescaled or (fast and x.dtype == torch.float16 and n > 1)
+        assert not prescaled or (fast and x.dtype == torch.float16 and (n > 1 or _SHARED_AT_ONE))
         if fast:
             import gnerf_hip
             half = x.dtype == torch.float16
@@ -304,7 +306,10 @@ class StyledConv(nn.Module):
             c_out = self.weight.shape[0]
             clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
             mine = aff + (self.weight,)
-            if half and n > 1:          # shared-weight form: activations scaled by the styles, demodulation in the epilogue
+            # shared-weight form: activations scaled by the styles, demodulation in the epilogue.  Round 6: also at n == 1 -- one latent is
+            # trivially "shared", and it is the call gen_videos.py makes (one camera per synthesis, gen_videos.py:154-171): the frame-by-frame
+            # orbit then runs its 3x3 layers on csrc/conv3x3.hip like the batched one instead of per-sample weights + MIOpen
+            if half and (n > 1 or _SHARED_AT_ONE):
                 dco = _per_latent(self, w, 'dco', mine, lambda: gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=x.dtype, want_weights=False, want_dcoefs=True)[1])
                 if not prescaled:
                     x = gnerf_hip.scale_channels(x, _per_latent(self, w, 'nstyles', aff, lambda: gnerf_hip.normalise_styles(styles)))

@@ -12,6 +12,13 @@ WHERE the pieces run on a GPU:
   reference's block entry (`x.to(memory_format=contiguous_format)`, networks_stylegan2.py:438) changes it back.
 * the 1x1 three-channel convolution of ToRGBLayer on such a tensor is one streaming read of x (gnerf_torgb_nhwc) instead of a
   MIOpen 1x1 convolution (74 -> 172 us when channels_last).
+* round 6: the 3x3 convolutions themselves.  An fp16 image at a time with `groups == 1` -- what `modulated_conv2d` hands over for
+  every frame of gen_videos.py, which renders ONE camera per synthesis call (gen_videos.py:154-171) -- goes to this repo's own
+  implicit-GEMM kernel (csrc/conv3x3.hip: gnerf_conv3x3_epilogue_nhwc with every epilogue operand off for `up == 1`, the stride-2
+  transposed form gnerf_conv_transpose3x3_s2_nhwc for `up == 2`, the blur following through the overlay's upfirdn2d as before)
+  where its shape gate admits the layer (input channels in eights, output channels in blocks of 128: the four 3x3 layers of the
+  256^2 / 512^2 superresolution blocks; block64's 32 -> 32 layers stay with MIOpen).  Forward only -- a tensor that feeds an
+  autograd graph never comes here (`_wants_channels_last`) --, GNERF_FUSED_CONV=0 switches it off.
 * CPU tensors, fp32 and anything under autograd take exactly the reference's route through torch's convolutions.
 
 `conv2d_gradfix` stays the reference's module (resolved through the overlay's extended package path); where the reference tree is
@@ -34,6 +41,8 @@ except ImportError:                     # GPU box / stand-alone use: plain torch
 
 # GNERF_CONV_CHANNELS_LAST=0 keeps the activations' layout as it arrives (A/B runs)
 _CHANNELS_LAST_FP16 = os.environ.get('GNERF_CONV_CHANNELS_LAST', '1') != '0'
+# GNERF_FUSED_CONV=0: every convolution goes to the framework's (MIOpen), as before round 6
+_FUSED_CONV = os.environ.get('GNERF_FUSED_CONV', '1') != '0'
 
 
 def _get_weight_shape(w):
@@ -69,12 +78,30 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
                 ones = _ones(x.shape[1], x.device)
                 return gnerf_hip.torgb_channels_last(x, w.reshape(3, -1), ones)
         x = x.contiguous(memory_format=torch.channels_last)
+        if _FUSED_CONV and kh == 3 and kw == 3:
+            y = _own_conv3x3(x, w, stride, padding, transpose)
+            if y is not None:
+                return y
         w = w.contiguous(memory_format=torch.channels_last)
     if conv2d_gradfix is not None:
         op = conv2d_gradfix.conv_transpose2d if transpose else conv2d_gradfix.conv2d
     else:
         op = torch.nn.functional.conv_transpose2d if transpose else torch.nn.functional.conv2d
     return op(x, w, stride=stride, padding=padding, groups=groups)
+
+
+def _own_conv3x3(x, w, stride, padding, transpose):
+    """x: channels_last fp16 [N, C, H, W] outside autograd, w: the weight in the form torch's operator would have taken ([O, I, 3, 3]
+    correlation taps for conv2d; [I, O, 3, 3] for conv_transpose2d).  The result of csrc/conv3x3.hip's kernel, or None where its shape
+    gate does not admit the call (the caller then goes to the framework as before)."""
+    import gnerf_hip
+    pad = [int(p) for p in padding] if isinstance(padding, (list, tuple)) else [int(padding)] * 2
+    if not transpose and stride == 1 and pad == [1, 1] and gnerf_hip.conv3x3_epilogue_supported(x, w.shape[0]):
+        # the bare convolution: lrelu with slope 1 and gain 1 is the identity, every other epilogue operand is absent
+        return gnerf_hip.conv3x3_epilogue(x, gnerf_hip.pack_conv3x3_weights(w), alpha=1.0, gain=1.0)
+    if transpose and stride == 2 and pad == [0, 0] and gnerf_hip.conv_transpose3x3_s2_supported(x, w.shape[1]):
+        return gnerf_hip.conv_transpose3x3_s2(x, gnerf_hip.pack_conv_transpose3x3_weights(w.transpose(0, 1)))
+    return None
 
 
 _ones_cache = {}

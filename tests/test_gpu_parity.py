@@ -265,6 +265,7 @@ def test_render_zero_weight_ray_takes_global_max_depth(dev):
     np.testing.assert_allclose(rgb.cpu().numpy(), ref_rgb.numpy(), atol=1e-6)
 
 
+@pytest.mark.production_path
 def test_render_full_size_properties(dev):
     """BASELINE.json config 2 (N=4, 128x128 rays, 48+48 samples, 256x256 planes): too big for the oracle in a
     unit test, so check properties: determinism, bounds, item independence (a batch renders each item
@@ -312,6 +313,7 @@ def test_render_full_size_properties(dev):
         assert torch.equal(x, y) and torch.equal(x, z)
 
 
+@pytest.mark.production_path
 def test_render_full_size_on_backbone_planes(dev):
     """Config 2 on planes a generator produces (SURVEY 8d's "second run with real backbone output"; bench.py realistic_planes_step):
     the random-init FFHQ backbone's [4,96,256,256] channels_last output with the generator's default-init decoder.  Properties at
@@ -611,6 +613,7 @@ def test_importance_renderer_reads_channels_last_planes_in_place(dev, monkeypatc
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * float(grads[0].abs().max())
 
 
+@pytest.mark.production_path
 @pytest.mark.parametrize('S', [48, 96, 144])
 def test_pipe_kernel_instantiations_agree(dev, monkeypatch, S):
     """render_kernel_pipe<TP, MLP, FULL>: the instantiation with compile-time sample counts (what a 48+48 / 96+96 / 144+144 call
@@ -709,6 +712,7 @@ def test_native_torch_rand_matches_torch_rand(dev):
             assert float(mine.min()) >= 0.0 and float(mine.max()) < 1.0
 
 
+@pytest.mark.production_path
 @pytest.mark.parametrize('S', [48, 96])
 def test_render_with_inkernel_rays_and_draws(dev, S):
     """The render kernel making its rays (from the cameras) and its two uniform draws (torch's Philox stream) itself: outputs equal
@@ -766,6 +770,7 @@ def test_render_with_inkernel_rays_and_draws(dev, S):
                                  **dict(kw, depth_resolution=40, depth_resolution_importance=40))
 
 
+@pytest.mark.production_path
 def test_views_of_one_item_equal_separate_calls(dev):
     """Frame batching (an orbit's frames are N cameras on ONE latent's planes): one launch over N views of one set of planes --
     gnerf_render_params.planes_shared + depth_clamp_per_item -- gives every view bit-identically what a launch of its own
@@ -1105,6 +1110,7 @@ def test_render_backward_f16_tile_kernel_agrees_with_fp32_on_every_run(dev, monk
     assert float((out_p - ref_p).abs().max() / ref_p.abs().max()) < 1e-5
 
 
+@pytest.mark.production_path
 @pytest.mark.parametrize('layout', ['planes', 'interleaved'])
 def test_plane_gradients_are_bit_reproducible(dev, monkeypatch, layout):
     """The binned plane-gradient scatter (csrc/scatter_binned.inl) sums every plane tile in 64-bit fixed point in LDS: integer addition
@@ -1770,9 +1776,13 @@ def test_conv3x3_epilogue_vs_composed_ops(dev):
                         ref = bias_act.bias_act(t, bias, act='lrelu', gain=1.3, clamp=clamp) * (nxt[:, :, None, None] if nxt is not None else 1.0)
                         top = float(ref.abs().max())
                         e_got, e_want = float((got.float() - ref).abs().max()), float((want.float() - ref).abs().max())
-                        assert e_got <= max(1.5 * e_want, 4e-3 * top), (n, cin, cout, scale is not None, nz is not None, nxt is not None, clamp, e_got, e_want, top)
-                        diff = (got.float() - want.float()).abs()
-                        assert float(diff.max()) <= 6e-3 * top and float((diff > 2e-3 * top).float().mean()) < 1e-3
+                        # round 6: the fused epilogue runs in fp32 on the accumulators and rounds ONCE (the output); the two-launch form rounds
+                        # the convolution, the demodulated value and the activated value to fp16 on the way.  The bar is the fp32 chain: the
+                        # fused result may be no further from it than the two-launch form is, and no further than one output rounding (half an
+                        # fp16 ulp of the largest value = 2^-11 top, with the convolution's own summation order on top).  Bit-equality with the
+                        # two-launch form is NOT required (it was the round-5 criterion); the two only have to agree to the latter's error.
+                        assert e_got <= e_want and e_got <= 1.2e-3 * top, (n, cin, cout, scale is not None, nz is not None, nxt is not None, clamp, e_got, e_want, top)
+                        assert float((got.float() - want.float()).abs().max()) <= 6e-3 * top
     # shapes the kernel does not tile are refused, not approximated
     bad = torch.zeros(1, 64, 8, 24, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
     assert not gnerf_hip.conv3x3_epilogue_supported(bad, 128)                             # widths come in tiles of 32
@@ -1908,7 +1918,7 @@ def test_generator_forward_gpu_vs_cpu(dev):
     assert float((out['image_depth'].cpu() - ref['image_depth']).abs().max()) < 2e-3
 
 
-def test_config3_n4_gpu_vs_reference_fixture(dev, golden):
+def test_config3_n4_gpu_vs_reference_fixture(dev, golden, monkeypatch):
     """BASELINE config 3 as SURVEY section 8d defines it: the full generator forward at N=4, render resolution 64, constant
     noise, on the GPU (fused renderer, native ops, fp16 superresolution) against the fixture made from the REFERENCE's
     TriPlaneGenerator on the CPU in fp32 (tests/golden/make_golden.py; same weights, noise and batch through det_init).
@@ -1917,8 +1927,23 @@ def test_config3_n4_gpu_vs_reference_fixture(dev, golden):
     import gen_cases as C
     g = golden('generator_n4.npz')
     G, _ = C.build(dev)
+    import gnerf_hip
+    import gnerf_generator as GG
+    own = {'conv3x3_epilogue': [], 'conv_transpose3x3_s2': []}
+    real_fns = {name: getattr(gnerf_hip, name) for name in own}
+    for name in own:
+        monkeypatch.setattr(gnerf_hip, name, (lambda real_fn, name: lambda x, w, *a, **kw: (own[name].append((x.shape[0], x.shape[1], w.shape[1], x.shape[2])), real_fn(x, w, *a, **kw))[1])(real_fns[name], name))
     for force_fp32, tol in ((False, 1e-4), (True, 1e-7)):
+        for name in own:
+            own[name].clear()
         ws, out = C.run_config3(G, dev, **(dict(force_fp32=True) if force_fp32 else {}))
+        # round 6: the ROUTE is part of the test.  fp16 superresolution: every 3x3 layer the kernel's shape gate admits runs on csrc/conv3x3.hip
+        # (block0.conv1, block1.conv1 fused with their epilogues; block0.conv0, block1.conv0 as the transposed form); fp32: none does.
+        if force_fp32:
+            assert not own['conv3x3_epilogue'] and not own['conv_transpose3x3_s2'], own
+        else:
+            assert sorted(own['conv3x3_epilogue']) == [(4, 128, 128, 512), (4, 256, 256, 256)], own
+            assert sorted(own['conv_transpose3x3_s2']) == [(4, 32, 256, 128), (4, 256, 128, 256)], own
         np.testing.assert_allclose(ws[:, 0, :8].cpu().numpy(), g['ws_first'], atol=1e-4)
         assert out['image'].shape == (4, 3, 512, 512) and out['image'].dtype == torch.float32
         mse = {'image': float(((out['image'][:, :, 4::8, 4::8].cpu().numpy() - g['image_sub']) ** 2).mean()),
@@ -1930,6 +1955,22 @@ def test_config3_n4_gpu_vs_reference_fixture(dev, golden):
     with torch.no_grad(), C.DI.DetNoise('config3'):
         d = G.synthesis(G.mapping(b['z'], b['c']), b['c'], noise_mode='const', neural_rendering_resolution=64, only_depth=True)
     assert d['image'] is d['image_depth'] and torch.equal(d['image'], out['image_depth'])
+    # GNERF_FUSED_CONV=0 (MIOpen + the stand-alone epilogue) gives the same fp16 image within the fixture's tolerance, and takes the other route
+    monkeypatch.setattr(GG, '_FUSED_CONV', False)
+    for name in own:
+        own[name].clear()
+    _, out_plain = C.run_config3(G, dev)
+    assert not own['conv3x3_epilogue'] and not own['conv_transpose3x3_s2'], own
+    assert float(((out_plain['image'][:, :, 4::8, 4::8].cpu().numpy() - g['image_sub']) ** 2).mean()) < 1e-4
+    _, out_fused = (monkeypatch.setattr(GG, '_FUSED_CONV', True), C.run_config3(G, dev))[1]
+    assert float(((out_plain['image'] - out_fused['image']) ** 2).mean()) < 1e-5
+    # a batch of ONE takes the shared-weight form and the same kernels (the frame-by-frame orbit)
+    for name in own:
+        own[name].clear()
+    with torch.no_grad(), C.DI.DetNoise('config3'):
+        one = G.synthesis(G.mapping(b['z'][:1], b['c'][:1]), b['c'][:1], noise_mode='const', neural_rendering_resolution=64)
+    assert sorted(own['conv3x3_epilogue']) == [(1, 128, 128, 512), (1, 256, 256, 256)] and len(own['conv_transpose3x3_s2']) == 2, own
+    assert float(((one['image'][:, :, 4::8, 4::8].cpu().numpy() - g['image_sub'][:1]) ** 2).mean()) < 1e-4
 
 
 def test_config3_reference_flow_through_overlay_gpu_vs_fixture(dev, golden, monkeypatch):
@@ -1968,6 +2009,27 @@ def test_config3_reference_flow_through_overlay_gpu_vs_fixture(dev, golden, monk
     assert seen['calls'] == 29 and seen['channels_last_out'] == 6 and seen['torgb_kernel'] == 3, seen      # the six fp16 convolutions stay channels_last
     assert float(((one['image'][:, :, 4::8, 4::8].cpu().numpy() - g['image_sub'][:1]) ** 2).mean()) < 1e-4
     np.testing.assert_allclose(one['image_depth'].cpu().numpy(), g['image_depth'][:1], atol=1e-3)
+    # round 6: of those six, the four 3x3 layers of the 256^2 / 512^2 blocks (32 -> 256 x2, 256 -> 256, 256 -> 128 x2, 128 -> 128) run on
+    # csrc/conv3x3.hip -- the call gen_videos.py makes, one camera per synthesis (gen_videos.py:154-171); block64's two 32 -> 32 layers
+    # are outside the kernel's 128-output-channel blocks and stay with the framework.  Spied at the library's Python entry points.
+    import gnerf_hip
+    own = {'conv3x3_epilogue': [], 'conv_transpose3x3_s2': []}
+    for name in own:
+        real_fn = getattr(gnerf_hip, name)
+        monkeypatch.setattr(gnerf_hip, name, (lambda real_fn, name: lambda x, w, *a, **kw: (own[name].append((x.shape[1], w.shape[1], x.shape[2])), real_fn(x, w, *a, **kw))[1])(real_fn, name))
+    with torch.no_grad(), C.DI.DetNoise('config3'):
+        again = G.synthesis(G.mapping(b['z'][:1], b['c'][:1]), b['c'][:1], noise_mode='const', neural_rendering_resolution=64)
+    assert sorted(own['conv3x3_epilogue']) == [(128, 128, 512), (256, 256, 256)] and sorted(own['conv_transpose3x3_s2']) == [(32, 256, 128), (256, 128, 256)], own
+    assert float(((again['image'] - one['image']) ** 2).mean()) < 1e-5          # (the renderer's uniform draws differ from call to call)
+    # ... and with the route switched off (GNERF_FUSED_CONV=0: MIOpen convolves) the frame is the same image within the fixture's tolerance
+    monkeypatch.setattr(CR, '_FUSED_CONV', False)
+    for name in own:
+        own[name].clear()
+    with torch.no_grad(), C.DI.DetNoise('config3'):
+        plain = G.synthesis(G.mapping(b['z'][:1], b['c'][:1]), b['c'][:1], noise_mode='const', neural_rendering_resolution=64)
+    assert not own['conv3x3_epilogue'] and not own['conv_transpose3x3_s2']
+    assert float(((plain['image'] - one['image']) ** 2).mean()) < 1e-5
+    assert float(((plain['image'][:, :, 4::8, 4::8].cpu().numpy() - g['image_sub'][:1]) ** 2).mean()) < 1e-4
 
 
 def test_config5_training_step_gpu_vs_reference_fixture(dev, golden):
@@ -2012,6 +2074,7 @@ def test_config5_training_step_gpu_vs_reference_fixture(dev, golden):
     assert not any(p.requires_grad for p in G.parameters()) and not any(p.requires_grad for p in D.parameters())
 
 
+@pytest.mark.production_path
 def test_render_backward_full_size_properties(dev):
     """gnerf_render_backward at the training shape of BASELINE config 5 (4 items x 64x64 rays, 48+48 samples, 256x256 planes),
     too big for the float64 oracle in a unit test: finite; deterministic up to the order of its float atomics (repeat runs
