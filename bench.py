@@ -400,6 +400,12 @@ def gen_videos_secondary(rank, world, dev, n_frames=240, flows=('fast', 'referen
                 del program_k
         GG._MODCONV_FAST = os.environ.get('GNERF_MODCONV_FAST', '1') != '0'
         last.emit_channels_last = True
+        sec_roofline = None
+        if rank == 0:
+            try:
+                sec_roofline = secondary_roofline(dev, G, z, ORBIT_VIEWS)
+            except Exception as e:
+                sec_roofline = {'error': f'{type(e).__name__}: {e}'[:300]}
         # the backbone pass every rank runs once per orbit before its frames (ws is constant, gen_videos.py:150): the serial term of
         # config 4's scaling -- 240 frames on one GPU against (backbone + 240 / N frames + gather) on N
         ws = gv.orbit_latents(G, z, dev)
@@ -422,7 +428,7 @@ def gen_videos_secondary(rank, world, dev, n_frames=240, flows=('fast', 'referen
     return {'metric': 'frames/sec gen_videos', 'value': out['fast', best], 'unit': 'frames/s', 'value_is': 'fast flow, ' + best,
             'eager_value': out['fast', 'eager'], 'hip_graph_value': out['fast', 'hip_graph'],
             'eager_views_value': out['fast', 'eager_views'], 'hip_graph_views_value': out['fast', 'hip_graph_views'], 'views_per_call': ORBIT_VIEWS, 'miopen_solver_search': searched,
-            'backbone_ms_per_rank': backbone_all,
+            'backbone_ms_per_rank': backbone_all, 'roofline': sec_roofline,
             'solver_search': ({'shared': True, 'rank0_then_copy_s': out.get('solver_search_s')} if world > 1 else {'shared': False}),
             'reference_flow_value': max(out['reference', 'eager'], out['reference', 'hip_graph']) if 'reference' in flows else None,
             'reference_flow_eager_value': out.get(('reference', 'eager')), 'reference_flow_hip_graph_value': out.get(('reference', 'hip_graph')),
@@ -433,6 +439,85 @@ def gen_videos_secondary(rank, world, dev, n_frames=240, flows=('fast', 'referen
                         'eager_views = plain launches with views_per_call cameras per synthesis call, hip_graph_views = that call captured once and replayed; '
                         'fast = this repo\'s generator path (modconv kernels, channels_last planes), reference_flow = the reference\'s layer code '
                         '(PyTorch-op modulation, conv2d_resample / fma / bias_act / upfirdn2d from the overlay, NCHW planes): what a G-NeRF checkout gets'}
+
+
+F16_MATRIX_PEAK_PFLOPS = 2.5          # dense f16 MFMA peak of one MI355X at 2.4 GHz (MI355X_MICROARCH.md; AMD's headline 5 PF includes 2:1 sparsity)
+
+
+def secondary_roofline(dev, G, z, views):
+    """Round 6: the roofline of the SECONDARY metric's dominant kernel in the driver's own line.  Half of an orbit frame's GPU time is the
+    superresolution's 3x3 convolutions on csrc/conv3x3.hip (profiles/r05_orbit_fast_views8_summary.json), a matrix-core kernel: it is timed
+    here, live, with HIP events on the two hot shapes of the plain form and the larger one of the transposed form, at the batch the orbit's
+    best run uses (`views` cameras per call) -- `frac` = PFLOP/s over the 2.5 PFLOP/s f16 peak.  Then ONE more pass over 30 frames under
+    torch's profiler (roctracer) splits a frame's GPU time by kernel family; it is skipped (null) when an outer profiler owns the tracer."""
+    import gnerf_hip
+    import gen_videos_mi355x as gv
+    out = {'bound': 'mfma', 'peak': F16_MATRIX_PEAK_PFLOPS, 'unit': 'PFLOP/s', 'dtype': 'f16 operands, fp32 accumulate', 'batch': views, 'kernels': []}
+    g = torch.Generator().manual_seed(3)
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for _ in range(3):
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / reps)
+        return best
+    for kind, (c, o, h, w) in (('conv3x3_epilogue', (128, 128, 512, 512)), ('conv3x3_epilogue', (256, 256, 256, 256)), ('conv_transpose3x3_s2', (256, 128, 256, 256))):
+        x = (torch.randn(views, c, h, w, generator=g) * 0.5).to(dev).half().contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn(o, c, 3, 3, generator=g) / (3 * c ** 0.5)).to(dev)
+        if kind == 'conv3x3_epilogue':
+            wpk = gnerf_hip.pack_conv3x3_weights(wt)
+            sc, nx, bias = (torch.rand(views, o, generator=g) + 0.5).to(dev), (torch.rand(views, o, generator=g) + 0.5).to(dev), torch.zeros(o, device=dev)
+            ms = timed(lambda: gnerf_hip.conv3x3_epilogue(x, wpk, bias, scale=sc, next_scale=nx, gain=2 ** 0.5, clamp=256.0))
+            flop = 2.0 * views * h * w * o * c * 9
+        else:
+            wpk = gnerf_hip.pack_conv_transpose3x3_weights(wt)
+            ms = timed(lambda: gnerf_hip.conv_transpose3x3_s2(x, wpk))
+            flop = 2.0 * views * h * w * o * c * 9                   # every input pixel meets each of the nine taps once
+        pf = flop / (ms * 1e-3) / 1e15
+        out['kernels'].append({'kernel': kind, 'shape': {'n': views, 'cin': c, 'cout': o, 'h': h, 'w': w}, 'ms': ms, 'achieved': pf, 'frac': pf / F16_MATRIX_PEAK_PFLOPS,
+                               'algorithmic_GFLOP': flop / 1e9})
+        del x
+    out['achieved'] = out['kernels'][0]['achieved']
+    out['frac'] = out['kernels'][0]['frac']
+    out['kernel'] = 'conv3x3_epilogue_kernel<0, ...> (csrc/conv3x3.hip), 128 -> 128 @ 512^2'
+    # a frame's GPU time by kernel family
+    fam = None
+    if not (any(k.startswith(('ROCP_', 'ROCPROF')) or k == 'HSA_TOOLS_LIB' for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', '')):
+        try:
+            from torch.profiler import profile, ProfilerActivity
+            n_frames = 32 // views * views
+            gv.render_orbit(G, z, n_frames, 64, dev, double_depth=False, frames_per_call=views)
+            torch.cuda.synchronize()
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                gv.render_orbit(G, z, n_frames, 64, dev, double_depth=False, frames_per_call=views)
+                torch.cuda.synchronize()
+            fam = {}
+            rules = (('conv3x3 (csrc/conv3x3.hip)', ('conv3x3_epilogue_kernel',)), ('fused renderer', ('render_kernel', 'clamp_depth', 'make_rays')),
+                     ('blur / upfirdn2d', ('upfirdn', 'blur')), ('modulated-convolution surroundings, bias_act, ToRGB, uint8', ('modconv', 'bias_act', 'torgb', 'scale_channels', 'to_uint8', 'upsample2x', 'modulate_weights', 'normalise')),
+                     ('MIOpen / rocBLAS', ('miopen', 'Cijk', 'igemm', 'naive_conv', 'ck::', 'gemm', 'Conv', 'batched_transpose')), ('uniform draws', ('philox', 'distribution', 'rand')))
+            total = 0.0
+            for ev in prof.key_averages():
+                t = float(getattr(ev, 'device_time_total', 0.0) or getattr(ev, 'cuda_time_total', 0.0) or 0.0)
+                if t <= 0:
+                    continue
+                name = ev.key
+                key = next((f for f, pats in rules if any(p_ in name for p_ in pats)), 'torch elementwise / other')
+                fam[key] = fam.get(key, 0.0) + t / n_frames
+                total += t / n_frames
+            fam = {k: round(v, 2) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])}
+            fam['total'] = round(total, 2)
+        except Exception as e:
+            fam = {'error': f'{type(e).__name__}: {e}'[:200]}
+    out['gpu_time_us_per_frame'] = fam
+    out['gpu_time_source'] = f'torch.profiler (roctracer), {views} cameras per synthesis call, eager launches, 32 frames' if fam and 'error' not in fam else None
+    return out
 
 
 def realistic_planes_step(dev, c2w, intr, steps, rank=0):

@@ -65,6 +65,8 @@ struct ConvArgs {
     const float* noise;         // [h * w] or NULL
     const __half* bias;         // [cout] or NULL
     const float* next_scale;    // [n, cout] or NULL
+    float* y32;                 // OUT32: [n, h, w, cout] float32 result (y unused)
+    const float* bias32;        // OUT32: [cout] float32 or NULL (bias unused)
     int n, h, w, cin, cout;
     int cin_pad;                // input channels of the packed weights: cin rounded up to a multiple of 64 (the extra channels are zeros)
     int tiles_x, tiles_y, n_tiles;
@@ -86,7 +88,14 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // fragment addressing and the MFMA loop are the convolution's; a job is (tile of 8 x 32 positions (m, n), phase), the result goes out
 // as plain fp16 at stride 2 (the blur + epilogue pass that follows reads it).  Weights arrive packed per phase: [9][cout][cin] in the order
 // phase (0,0): taps (a,b) = (0,0), (0,1), (1,0), (1,1); phase (0,1): a = 0, 1; phase (1,0): b = 0, 1; phase (1,1): the one tap.
-template <int MODE, bool SCALE, bool NOISE, bool NEXT>
+// OUT32 (round 6): the fp32-GRADE form for the backbone's float32 layers (networks_stylegan2.py:41-98 on float32 activations).  The
+// arithmetic is the fused renderer's decoder's: every product x w as hi(x) hi(w) + lo(x) hi(w) + hi(x) lo(w) with hi = f16(v), lo = f16(v - hi)
+// and fp32 accumulation -- which for a convolution is this very kernel on three times the input channels, x' = [hi | lo | hi] (written by
+// gnerf_split_f16x3_nhwc) against w' = [hi | hi | lo] (packed once per weight version).  What changes here is the way out: the epilogue's
+// fp32 values are stored as they are (16 bytes per lane straight from the accumulators: a 256 x 128 fp32 tile does not fit the staging
+// LDS), and the bias arrives as float32.  MIOpen's fp32 kernels reach 0.82-0.86 of the 157 TFLOP/s fp32 matrix peak on these shapes; three
+// f16 matrix instructions per product at 16x the rate are 2.5-3.3x faster (profiles/r06_conv_f32grade_gate.jsonl).
+template <int MODE, bool SCALE, bool NOISE, bool NEXT, bool OUT32 = false>
 __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvArgs a) {
     extern __shared__ __align__(16) char lds[];
     char* const xs = lds;                           // [340 pixels][8 slots of 16 bytes], slot ^= pixel & 7
@@ -107,7 +116,10 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     // XCDs 0 and 1 -- an XCD owns a contiguous eighth of the job sequence -- : 0.287 ms; phase fastest: 0.262; a 4-step job costs 13 us on
     // its own, of which the MFMAs are 4.)
     const int tile_p = tile;
-#pragma unroll
+    // (round 6: the four phases are a ROLLED loop -- the taps of a phase, their shifts and the step counters below are scalar run-time
+    //  values.  Unrolled, every phase had its own copy of the main loop and the epilogue, and the values the compiler hoisted across
+    //  them cost the transposed form 34 spilled registers and 92 bytes of scratch per lane.)
+#pragma nounroll
     for (int ph = 0; ph < (MODE == 1 ? 4 : 1); ph++) {
     const int ph_y = ph >> 1, ph_x = ph & 1;                            // (py, px)
     const int n_taps = MODE == 1 ? (2 - ph_y) * (2 - ph_x) : 9;
@@ -148,13 +160,15 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(xs + (it * kConvThreads + wv * 64) * 16), 16, off, 0, 0, 0);
         }
     };
+    // weights of (tap, 64 input channels) -> buffer `buf`.  Lane (co = 32 it + tid / 8, slot = tid % 8) of trip `it` reads 16 bytes of output
+    // channel co; the swizzle key (co >> 1) & 7 = (tid >> 4) & 7 does not depend on the trip, so the lane contributes ONE 32-bit offset and
+    // everything else -- tap, chunk, trip -- is a scalar base (round 6: as four 64-bit lane pointers these were eight v_lshl_add_u64 per step)
+    const unsigned w_lane = unsigned(((tid >> 3) * a.cin_pad + (((tid & 7) ^ ((tid >> 4) & 7)) << 3)) * 2);
     auto stage_w = [&](int tap, int cin0, int buf) {
-        const _Float16* src = a.wpk + (size_t(tap_base + tap) * Cout + co0) * a.cin_pad + cin0;
+        const char* src = reinterpret_cast<const char*>(a.wpk + (size_t(tap_base + tap) * Cout + co0) * a.cin_pad + cin0);
 #pragma unroll
         for (int it = 0; it < kWRounds; it++) {
-            const int q = it * kConvThreads + tid;
-            const int co = q >> 3, slot = q & 7;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + size_t(co) * a.cin_pad + ((slot ^ ((co >> 1) & 7)) << 3)),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + size_t(it) * 32 * a.cin_pad * 2 + w_lane),
                                              (lds_ptr_t)(wb + buf * kWBytes + (it * kConvThreads + wv * 64) * 16), 16, 0, 0);
         }
     };
@@ -176,8 +190,13 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
         if constexpr (NEXT) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.next_scale + size_t(n) * Cout + co0 + tid),
                                                              (lds_ptr_t)(ep + 512 + wv * 256), 4, 0, 0);
     }
-    if (wv == 0 && a.bias) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + co0 + 2 * tid),
-                                                            (lds_ptr_t)(ep + 1024), 4, 0, 0);
+    if constexpr (OUT32) {
+        if (wv < 2 && a.bias32) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias32 + co0 + tid),
+                                                                 (lds_ptr_t)(ep + 1024 + wv * 256), 4, 0, 0);
+    } else {
+        if (wv == 0 && a.bias) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + co0 + 2 * tid),
+                                                                (lds_ptr_t)(ep + 1024), 4, 0, 0);
+    }
     const int n_chunks = a.cin_pad / kCK, total = n_chunks * n_taps;
     // ---- main loop, software-pipelined ACROSS steps.  A step (one tap of one 64-channel chunk) is two k-steps of 32 MFMAs; while
     // the MFMAs of one k-step issue, the twelve fragments of the NEXT k-step are read -- the second k-step of this step, or the first
@@ -192,16 +211,16 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     // fragments sit at constant offsets (16 pixels / 16 channels further: the swizzle's period is 8 rows), k-step 1 flips bit 6.
     const int xlane = (2 * wv * kIW + r) * kRow;                   // byte offset of this lane's pixel row (tile row 2 wv, column r) without the tap's shift
     const int alane = r * kRow + ((hq ^ ((r >> 1) & 7)) << 4);
-    auto load_frag = [&](int s, int kc, int f, h8 (&Af)[8], h8 (&Bf)[4]) {
+    // (tap, buf): the step's tap within its chunk and the parity of its weight buffer -- running counters of the loop below, no divisions
+    auto load_frag = [&](int tap, int buf, int kc, int f, h8 (&Af)[8], h8 (&Bf)[4]) {
         if (f < 4) {
-            const int chunk = s / n_taps, tap = s - chunk * n_taps;
             int dy, dx;
             tap_shift(tap, dy, dx);
             const int row = xlane + (((f >> 1) + dy) * kIW + dx) * kRow;          // pixel index * 128
             const int slot = (hq ^ (row >> 7)) & 7;
             Bf[f] = *reinterpret_cast<const h8*>(xs + ((row + (slot << 4)) ^ (kc << 6)) + (f & 1) * 16 * kRow);
         } else {
-            Af[f - 4] = *reinterpret_cast<const h8*>(wb + (s & 1) * kWBytes + (alane ^ (kc << 6)) + (f - 4) * 16 * kRow);
+            Af[f - 4] = *reinterpret_cast<const h8*>(wb + buf * kWBytes + (alane ^ (kc << 6)) + (f - 4) * 16 * kRow);
         }
     };
     auto mfma_group = [&](int g, const h8 (&Af)[8], const h8 (&Bf)[4]) {
@@ -212,53 +231,59 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     };
     // 32 MFMAs from (Ac, Bc) with the twelve reads of (s2, kc2) into (An, Bn) among them: {8 MFMAs, six reads} twice, then 16 MFMAs --
     // fenced so that the compiler keeps the order; the last read has 24 MFMAs to come back behind
-    auto phase = [&](const h8 (&Ac)[8], const h8 (&Bc)[4], bool reads, int s2, int kc2, h8 (&An)[8], h8 (&Bn)[4]) {
+    auto phase = [&](const h8 (&Ac)[8], const h8 (&Bc)[4], bool reads, int tap2, int buf2, int kc2, h8 (&An)[8], h8 (&Bn)[4]) {
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(0, Ac, Bc);
         __builtin_amdgcn_sched_barrier(0);
         if (reads) {
 #pragma unroll
-            for (int f = 0; f < 6; f++) load_frag(s2, kc2, f, An, Bn);
+            for (int f = 0; f < 6; f++) load_frag(tap2, buf2, kc2, f, An, Bn);
         }
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(1, Ac, Bc);
         __builtin_amdgcn_sched_barrier(0);
         if (reads) {
 #pragma unroll
-            for (int f = 6; f < 12; f++) load_frag(s2, kc2, f, An, Bn);
+            for (int f = 6; f < 12; f++) load_frag(tap2, buf2, kc2, f, An, Bn);
         }
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(2, Ac, Bc);
         mfma_group(3, Ac, Bc);
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto stage_w_step = [&](int s) { const int c = s / n_taps; stage_w(s - c * n_taps, c * kCK, s & 1); };
+    // step s = (chunk, tap); s + 1 and s + 2 are kept alongside as running counters
+    auto next_step = [&](int& tp, int& ck) { if (++tp == n_taps) { tp = 0; ck++; } };
+    int tap = 0, chunk = 0, tap1 = 0, chunk1 = 0, tap2, chunk2;
+    next_step(tap1, chunk1);
+    tap2 = tap1; chunk2 = chunk1;
+    next_step(tap2, chunk2);
     stage_x(0);
-    stage_w_step(0);
+    stage_w(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (total > 1) stage_w_step(1);
+    if (total > 1) stage_w(tap1, chunk1 * kCK, 1);
 #pragma unroll
-    for (int f = 0; f < 12; f++) load_frag(0, 0, f, A[0], B[0]);
+    for (int f = 0; f < 12; f++) load_frag(0, 0, 0, f, A[0], B[0]);
     for (int s = 0; s < total; s++) {
-        const int chunk = s / n_taps, tap = s - chunk * n_taps;
-        phase(A[0], B[0], true, s, 1, A[1], B[1]);
+        phase(A[0], B[0], true, tap, s & 1, 1, A[1], B[1]);
         // (bare waits and barrier: __syncthreads() would drain vmcnt where the compiler sees fit)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const bool more = s + 1 < total, new_chunk = more && tap == n_taps - 1;
-        if (s + 2 < total) stage_w_step(s + 2);
+        if (s + 2 < total) stage_w(tap2, chunk2 * kCK, s & 1);
         if (new_chunk) stage_x((chunk + 1) * kCK);
-        phase(A[1], B[1], more && !new_chunk, s + 1, 0, A[0], B[0]);
+        phase(A[1], B[1], more && !new_chunk, tap1, (s + 1) & 1, 0, A[0], B[0]);
         if (new_chunk) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int f = 0; f < 12; f++) load_frag(s + 1, 0, f, A[0], B[0]);
+            for (int f = 0; f < 12; f++) load_frag(tap1, (s + 1) & 1, 0, f, A[0], B[0]);
         }
+        tap = tap1; chunk = chunk1; tap1 = tap2; chunk1 = chunk2;
+        next_step(tap2, chunk2);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                                                // the input tile is dead: its LDS takes the output tile
@@ -283,6 +308,10 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     typedef float v2f __attribute__((ext_vector_type(2)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const float g = a.gain;
+    int lr = r;
+    asm volatile("" : "+v"(lr));                                       // (per phase, see the store loop)
+    const unsigned os_lane = unsigned(lr * 256 + (((hq >> 1) ^ lr) << 4) + (hq & 1) * 8);
+    const unsigned y32_lane = unsigned((MODE == 1 ? 2 * lr : lr) * Cout + hq * 4);
     float nzg[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (NOISE && MODE == 0) {
 #pragma unroll
@@ -298,7 +327,9 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
         v2f scg[2] = {{g, g}, {g, g}}, nx[2] = {{1.f, 1.f}, {1.f, 1.f}}, bg[2] = {{0.f, 0.f}, {0.f, 0.f}};
         if constexpr (SCALE) { const float4 v = *reinterpret_cast<const float4*>(ep + c4 * 4); scg[0] = (v2f){v.x, v.y} * g; scg[1] = (v2f){v.z, v.w} * g; }
         if constexpr (NEXT) { const float4 v = *reinterpret_cast<const float4*>(ep + 512 + c4 * 4); nx[0] = (v2f){v.x, v.y}; nx[1] = (v2f){v.z, v.w}; }
-        if (a.bias) {
+        if constexpr (OUT32) {
+            if (a.bias32) { const float4 v = *reinterpret_cast<const float4*>(ep + 1024 + c4 * 4); bg[0] = (v2f){v.x, v.y} * g; bg[1] = (v2f){v.z, v.w} * g; }
+        } else if (a.bias) {
             typedef _Float16 h4v __attribute__((ext_vector_type(4)));
             const h4v hb = __builtin_bit_cast(h4v, *reinterpret_cast<const uint2*>(ep + 1024 + c4 * 2));
             bg[0] = (v2f){float(hb[0]), float(hb[1])} * g; bg[1] = (v2f){float(hb[2]), float(hb[3])} * g;
@@ -308,12 +339,14 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             const int prow = 2 * wv + (pb >> 1), pcol = (pb & 1) * 16 + r;
             const int p = prow * kTW + pcol;
             unsigned words[2];
+            float full[4];
 #pragma unroll
             for (int k2 = 0; k2 < 2; k2++) {
                 const v2f av = {acc[cb][pb][2 * k2], acc[cb][pb][2 * k2 + 1]};
                 h2 out;
                 if constexpr (MODE == 1) {
                     out = (h2){(_Float16)av[0], (_Float16)av[1]};      // the transposed convolution leaves as plain fp16 (blur + epilogue follow)
+                    full[2 * k2] = av[0]; full[2 * k2 + 1] = av[1];
                 } else {
                     v2f u = __builtin_elementwise_fma(av, scg[k2], bg[k2]);
                     if constexpr (NOISE) u = u + (v2f){nzg[pb], nzg[pb]};
@@ -328,11 +361,27 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
                     v2f rr = {r0, r1};
                     if constexpr (NEXT) rr = rr * nx[k2];
                     out = (h2){(_Float16)rr[0], (_Float16)rr[1]};
+                    full[2 * k2] = rr[0]; full[2 * k2 + 1] = rr[1];
                 }
                 words[k2] = __builtin_bit_cast(unsigned, out);
             }
-            // (c4 >> 3 = 2 cb + (hq >> 1) and 2 cb only touches the slot's upper bits: the address is the cb = 0 one with cb << 5 XORed in)
-            *reinterpret_cast<uint2*>(os + ((p * 256 + ((((hq >> 1) ^ (p & 15)) << 4) + (hq & 1) * 8)) ^ (cb << 5))) = make_uint2(words[0], words[1]);
+            if constexpr (OUT32) {
+                // four consecutive channels of one pixel = 16 bytes, straight from the accumulators (the lanes of a 16-lane row group cover 64
+                // contiguous bytes of a pixel, channel blocks cb and cb ^ 1 its 128-byte line)
+                const int yy = y0 + prow, xc = x0 + (pb & 1) * 16;      // (uniform) the pixel's row, the first column of its block of sixteen
+                const float4 o4 = make_float4(full[0], full[1], full[2], full[3]);
+                if constexpr (MODE == 1) {
+                    float* const row = a.y32 + ((size_t(n) * a.out_h + size_t(2 * yy + ph_y)) * a.out_w + size_t(2 * xc + ph_x)) * Cout + co0 + cb * 16;
+                    if (yy < Hp && xc + lr < Wp) *reinterpret_cast<float4*>(row + y32_lane) = o4;
+                } else {
+                    float* const row = a.y32 + (size_t(n) * H * W + size_t(yy) * W + xc) * Cout + co0 + cb * 16;
+                    *reinterpret_cast<float4*>(row + y32_lane) = o4;
+                }
+                continue;
+            }
+            // (p = 32 prow + 16 (pb & 1) + r: the lane's part of the address is r * 256 + its slot, the rest is wave-uniform; c4 >> 3 = 2 cb +
+            //  (hq >> 1) and 2 cb only touches the slot's upper bits, so channel block cb is the cb = 0 address with cb << 5 XORed in)
+            *reinterpret_cast<uint2*>(os + ((os_lane ^ unsigned(cb << 5)) + unsigned(prow * 8192 + (pb & 1) * 4096))) = make_uint2(words[0], words[1]);
         }
     }
 #else
@@ -369,18 +418,31 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
 #endif
     };
     if (MODE == 0 && a.clamp >= 0.f) registers_to_lds(std::true_type{}); else registers_to_lds(std::false_type{});
+    if constexpr (OUT32) {
+        if (MODE == 1) __syncthreads();                              // (uniform) the next phase's input tile must not land while a wave still reads this one's operands
+        continue;
+    }
     __syncthreads();
+    {
+        // 256 lanes move 16 pixels x 16 slots per trip: pixel (it >> 1, (it & 1) * 16 + lane / 16) of the tile, slot lane % 16.  Everything that
+        // depends on the trip is wave-uniform (a scalar base pointer, an immediate LDS offset); the lane contributes ONE 32-bit offset to each
+        // side.  (Written as 64-bit addresses per trip the sixteen of them were hoisted out of the phase loop and spilled.)
+        int lp = tid >> 4;
+        asm volatile("" : "+v"(lp));                                   // (per phase: nothing of this is kept across the main loop)
+        const int slot = tid & 15;
+        const unsigned lds_lane = unsigned(lp * 256 + ((slot ^ lp) << 4));
+        const unsigned out_lane = unsigned((MODE == 1 ? 2 * lp : lp) * Cout + slot * 8);
 #pragma unroll
-    for (int it = 0; it < kTH * kTW * 16 / kConvThreads; it++) {
-        const int q = it * kConvThreads + tid;
-        const int p = q >> 4, slot = q & 15;
-        const uint4 v = *reinterpret_cast<const uint4*>(os + p * 256 + ((slot ^ (p & 15)) << 4));
-        const int yy = y0 + p / kTW, xx = x0 + (p & (kTW - 1));
-        if constexpr (MODE == 1) {                                     // position (yy, xx) of phase (py, px) -> output pixel (2 yy + py, 2 xx + px); the grid of tiles overhangs
-            if (yy < Hp && xx < Wp)
-                *reinterpret_cast<uint4*>(a.y + ((size_t(n) * a.out_h + size_t(2 * yy + ph_y)) * a.out_w + size_t(2 * xx + ph_x)) * Cout + co0 + slot * 8) = v;
-        } else {
-            *reinterpret_cast<uint4*>(a.y + (size_t(n) * H * W + size_t(yy) * W + xx) * Cout + co0 + slot * 8) = v;
+        for (int it = 0; it < kTH * kTW * 16 / kConvThreads; it++) {
+            const uint4 v = *reinterpret_cast<const uint4*>(os + lds_lane + it * 4096);
+            const int yy = y0 + (it >> 1), xc = x0 + (it & 1) * 16;   // (uniform) row of the tile, first of this trip's sixteen columns
+            if constexpr (MODE == 1) {                                 // position (yy, xx) of phase (py, px) -> output pixel (2 yy + py, 2 xx + px); the grid of tiles overhangs
+                _Float16* const row = a.y + ((size_t(n) * a.out_h + size_t(2 * yy + ph_y)) * a.out_w + size_t(2 * xc + ph_x)) * Cout + co0;
+                if (yy < Hp && xc + lp < Wp) *reinterpret_cast<uint4*>(row + out_lane) = v;
+            } else {
+                _Float16* const row = a.y + (size_t(n) * H * W + size_t(yy) * W + xc) * Cout + co0;
+                *reinterpret_cast<uint4*>(row + out_lane) = v;
+            }
         }
     }
     if (MODE == 1) __syncthreads();                                  // the next phase's input tile overwrites the staged output
@@ -389,28 +451,75 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     }
 }
 
+// x [n, pixels, c] float32 channels_last, scale [n, c] or NULL -> y [n, pixels, 3 c] float16 = [hi | lo | hi] of v = x * scale, hi = f16(v),
+// lo = f16(v - hi): the activation operand of the fp32-grade convolution (OUT32 above).  A lane owns eight channels of a pixel: 32 bytes
+// in, three 16-byte pieces out; a workgroup's lanes walk the pixels of one image with a grid stride that is a multiple of the lanes per
+// pixel, so a lane meets the same channels every trip and keeps its eight scales in registers.  |v| beyond f16's range saturates to the
+// largest finite half (the products then are wrong but finite) and raises the sticky word `overflow` (one atomic per workgroup that saw
+// one): the convolution's range is f16's, like the renderer's f16 decoder body, and callers that cannot bound their activations check it.
+__global__ __launch_bounds__(256) void split_f16x3_kernel(const float* __restrict__ x, const float* __restrict__ scale, _Float16* __restrict__ y,
+                                                           int pixels, int c, int* overflow) {
+    const int n = blockIdx.y;
+    const int per_pixel = c >> 3;                                   // lanes per pixel
+    const int64_t total = int64_t(pixels) * per_pixel;
+    const int64_t stride = int64_t(gridDim.x) * 256 / per_pixel * per_pixel;         // a multiple of per_pixel: the channel group of a lane never changes
+    int64_t q = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (q >= stride) return;                                        // (the lanes beyond the last whole pixel group of the stride)
+    const int cg = int(q % per_pixel) * 8;
+    float sc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) sc[k] = scale ? scale[size_t(n) * c + cg + k] : 1.f;
+    const float* xn = x + size_t(n) * pixels * c;
+    _Float16* yn = y + size_t(n) * pixels * 3 * c;
+    bool over = false;
+    typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+    for (; q < total; q += stride) {
+        const int64_t pix = q / per_pixel;
+        const float4 a0 = *reinterpret_cast<const float4*>(xn + pix * c + cg), a1 = *reinterpret_cast<const float4*>(xn + pix * c + cg + 4);
+        const float v[8] = {a0.x * sc[0], a0.y * sc[1], a0.z * sc[2], a0.w * sc[3], a1.x * sc[4], a1.y * sc[5], a1.z * sc[6], a1.w * sc[7]};
+        h8v hi, lo;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float vc = __builtin_amdgcn_fmed3f(v[k], -65504.f, 65504.f);
+            over = over || vc != v[k];                              // (a NaN compares unequal too: it is reported, and travels on as a NaN)
+            const float vv = v[k] == v[k] ? vc : v[k];
+            hi[k] = (_Float16)vv;
+            lo[k] = (_Float16)(vv - float(hi[k]));
+        }
+        _Float16* o = yn + pix * 3 * c + cg;
+        *reinterpret_cast<h8v*>(o) = hi;
+        *reinterpret_cast<h8v*>(o + c) = lo;
+        *reinterpret_cast<h8v*>(o + 2 * c) = hi;
+    }
+    if (overflow && __any(over) && (threadIdx.x & 63) == 0) atomicOr(overflow, 1);
+}
+
 }  // namespace
 
 // y = epilogue(conv3x3(x, w)) on float16 channels_last tensors; see include/gnerf_hip.h.
-extern "C" int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, void* y, int n, int h, int w, int cin, int cout,
-                                           const float* scale, const float* noise, int round_noise, const void* bias,
-                                           float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream) {
+namespace {
+template <bool OUT32>
+int launch_conv3x3(const char* what, const void* x, const void* w_packed, void* y, int n, int h, int w, int cin, int cout,
+                   const float* scale, const float* noise, int round_noise, const void* bias,
+                   float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream) {
     using namespace gnerf;
-    if (!x || !w_packed || !y) return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: null pointer");
-    if (n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: empty tensor");
+    if (!x || !w_packed || !y) return fail(GNERF_E_ARG, "%s: null pointer", what);
+    if (n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return fail(GNERF_E_ARG, "%s: empty tensor", what);
     if (h % kTH || w % kTW || cin % 8 || cout % kCO)
-        return fail(GNERF_E_UNSUPPORTED, "conv3x3_epilogue_nhwc: needs height %% 8 == 0, width %% 32 == 0, input channels %% 8 == 0, output channels %% 128 == 0 (got %dx%d, %d -> %d)", h, w, cin, cout);
-    if (size_t(h) * w * cin * 2 >= (size_t(1) << 31)) return fail(GNERF_E_UNSUPPORTED, "conv3x3_epilogue_nhwc: one image of x must stay below 2 GB");
+        return fail(GNERF_E_UNSUPPORTED, "%s: needs height %% 8 == 0, width %% 32 == 0, input channels %% 8 == 0, output channels %% 128 == 0 (got %dx%d, %d -> %d)", what, h, w, cin, cout);
+    if (size_t(h) * w * cin * 2 >= (size_t(1) << 31)) return fail(GNERF_E_UNSUPPORTED, "%s: one image of x must stay below 2 GB", what);
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(y)) & 15)
-        return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: x, w and y must be 16-byte aligned");
+        return fail(GNERF_E_ARG, "%s: x, w and y must be 16-byte aligned", what);
     if ((scale && (reinterpret_cast<uintptr_t>(scale) & 15)) || (next_scale && (reinterpret_cast<uintptr_t>(next_scale) & 15)))
-        return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: scale and next_scale must be 16-byte aligned");
-    if (!(alpha >= 0.f && alpha <= 1.f)) return fail(GNERF_E_UNSUPPORTED, "conv3x3_epilogue_nhwc: the lrelu slope must lie in [0, 1] (got %g)", double(alpha));
-    if (!(gain > 0.f)) return fail(GNERF_E_UNSUPPORTED, "conv3x3_epilogue_nhwc: the gain must be positive (got %g): it is folded into the lrelu's operands", double(gain));
-    if (bias && (reinterpret_cast<uintptr_t>(bias) & 3)) return fail(GNERF_E_ARG, "conv3x3_epilogue_nhwc: bias must be 4-byte aligned");
+        return fail(GNERF_E_ARG, "%s: scale and next_scale must be 16-byte aligned", what);
+    if (!(alpha >= 0.f && alpha <= 1.f)) return fail(GNERF_E_UNSUPPORTED, "%s: the lrelu slope must lie in [0, 1] (got %g)", what, double(alpha));
+    if (!(gain > 0.f)) return fail(GNERF_E_UNSUPPORTED, "%s: the gain must be positive (got %g): it is folded into the lrelu's operands", what, double(gain));
+    if (bias && (reinterpret_cast<uintptr_t>(bias) & 3)) return fail(GNERF_E_ARG, "%s: bias must be 4-byte aligned", what);
     ConvArgs a;
-    a.x = static_cast<const _Float16*>(x); a.wpk = static_cast<const _Float16*>(w_packed); a.y = static_cast<_Float16*>(y);
-    a.scale = scale; a.noise = noise; a.bias = static_cast<const __half*>(bias); a.next_scale = next_scale;
+    a.x = static_cast<const _Float16*>(x); a.wpk = static_cast<const _Float16*>(w_packed);
+    a.y = OUT32 ? nullptr : static_cast<_Float16*>(y); a.y32 = OUT32 ? static_cast<float*>(y) : nullptr;
+    a.scale = scale; a.noise = noise; a.next_scale = next_scale;
+    a.bias = OUT32 ? nullptr : static_cast<const __half*>(bias); a.bias32 = OUT32 ? static_cast<const float*>(bias) : nullptr;
     a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
     a.cin_pad = (cin + kCK - 1) / kCK * kCK;
     a.tiles_x = w / kTW; a.tiles_y = h / kTH; a.n_tiles = n * a.tiles_x * a.tiles_y;
@@ -420,8 +529,8 @@ extern "C" int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, 
     hipStream_t s = as_stream(stream);
 #define GNERF_CONV(SC, NZ, NX) do { \
         static PerDeviceOnce once; \
-        if (int rc = once.raise_lds(conv3x3_epilogue_kernel<0, SC, NZ, NX>, "conv3x3_epilogue_nhwc", kConvLds)) return rc; \
-        hipLaunchKernelGGL((conv3x3_epilogue_kernel<0, SC, NZ, NX>), grid, block, kConvLds, s, a); } while (0)
+        if (int rc = once.raise_lds(conv3x3_epilogue_kernel<0, SC, NZ, NX, OUT32>, what, kConvLds)) return rc; \
+        hipLaunchKernelGGL((conv3x3_epilogue_kernel<0, SC, NZ, NX, OUT32>), grid, block, kConvLds, s, a); } while (0)
     const int key = (scale ? 4 : 0) | (noise ? 2 : 0) | (next_scale ? 1 : 0);
     switch (key) {
         case 0: GNERF_CONV(false, false, false); break;
@@ -434,33 +543,74 @@ extern "C" int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, 
         default: GNERF_CONV(true, true, true); break;
     }
 #undef GNERF_CONV
-    return check_launch("conv3x3_epilogue_nhwc");
+    return check_launch(what);
 }
 
-// y = conv_transpose2d(x, w, stride = 2) for 3x3 kernels on float16 channels_last tensors, as four phase convolutions; see include/gnerf_hip.h.
-extern "C" int gnerf_conv_transpose3x3_s2_nhwc(const void* x, const void* w_phases, void* y, int n, int h, int w, int cin, int cout, gnerf_stream_t stream) {
+template <bool OUT32>
+int launch_conv_transpose(const char* what, const void* x, const void* w_phases, void* y, int n, int h, int w, int cin, int cout, gnerf_stream_t stream) {
     using namespace gnerf;
-    if (!x || !w_phases || !y) return fail(GNERF_E_ARG, "conv_transpose3x3_s2_nhwc: null pointer");
-    if (n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return fail(GNERF_E_ARG, "conv_transpose3x3_s2_nhwc: empty tensor");
+    if (!x || !w_phases || !y) return fail(GNERF_E_ARG, "%s: null pointer", what);
+    if (n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return fail(GNERF_E_ARG, "%s: empty tensor", what);
     if (cin % 8 || cout % kCO)
-        return fail(GNERF_E_UNSUPPORTED, "conv_transpose3x3_s2_nhwc: needs input channels %% 8 == 0, output channels %% 128 == 0 (got %d -> %d)", cin, cout);
-    if (size_t(h) * w * cin * 2 >= (size_t(1) << 31)) return fail(GNERF_E_UNSUPPORTED, "conv_transpose3x3_s2_nhwc: one image of x must stay below 2 GB");
+        return fail(GNERF_E_UNSUPPORTED, "%s: needs input channels %% 8 == 0, output channels %% 128 == 0 (got %d -> %d)", what, cin, cout);
+    if (size_t(h) * w * cin * 2 >= (size_t(1) << 31)) return fail(GNERF_E_UNSUPPORTED, "%s: one image of x must stay below 2 GB", what);
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_phases) | reinterpret_cast<uintptr_t>(y)) & 15)
-        return fail(GNERF_E_ARG, "conv_transpose3x3_s2_nhwc: x, w and y must be 16-byte aligned");
+        return fail(GNERF_E_ARG, "%s: x, w and y must be 16-byte aligned", what);
     ConvArgs a;
-    a.x = static_cast<const _Float16*>(x); a.wpk = static_cast<const _Float16*>(w_phases); a.y = static_cast<_Float16*>(y);
-    a.scale = nullptr; a.noise = nullptr; a.bias = nullptr; a.next_scale = nullptr;
+    a.x = static_cast<const _Float16*>(x); a.wpk = static_cast<const _Float16*>(w_phases);
+    a.y = OUT32 ? nullptr : static_cast<_Float16*>(y); a.y32 = OUT32 ? static_cast<float*>(y) : nullptr;
+    a.scale = nullptr; a.noise = nullptr; a.bias = nullptr; a.bias32 = nullptr; a.next_scale = nullptr;
     a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
     a.cin_pad = (cin + kCK - 1) / kCK * kCK;
     a.tiles_x = (w + 1 + kTW - 1) / kTW; a.tiles_y = (h + 1 + kTH - 1) / kTH;         // tiles over the (h + 1) x (w + 1) positions of the even phases
     const int64_t jobs = int64_t(n) * a.tiles_x * a.tiles_y;
-    if (jobs > (int64_t(1) << 30)) return fail(GNERF_E_UNSUPPORTED, "conv_transpose3x3_s2_nhwc: too many tiles");
+    if (jobs > (int64_t(1) << 30)) return fail(GNERF_E_UNSUPPORTED, "%s: too many tiles", what);
     a.n_tiles = int(jobs);
     a.out_h = 2 * h + 1; a.out_w = 2 * w + 1;
     a.round_noise = 0; a.alpha = 0.f; a.gain = 1.f; a.clamp = -1.f;
     const dim3 grid((a.n_tiles + kNumXCD - 1) / kNumXCD * kNumXCD, cout / kCO), block(kConvThreads);
     static PerDeviceOnce once;
-    if (int rc = once.raise_lds(conv3x3_epilogue_kernel<1, false, false, false>, "conv_transpose3x3_s2_nhwc", kConvLds)) return rc;
-    hipLaunchKernelGGL((conv3x3_epilogue_kernel<1, false, false, false>), grid, block, kConvLds, as_stream(stream), a);
-    return check_launch("conv_transpose3x3_s2_nhwc");
+    if (int rc = once.raise_lds(conv3x3_epilogue_kernel<1, false, false, false, OUT32>, what, kConvLds)) return rc;
+    hipLaunchKernelGGL((conv3x3_epilogue_kernel<1, false, false, false, OUT32>), grid, block, kConvLds, as_stream(stream), a);
+    return check_launch(what);
+}
+}  // namespace
+
+extern "C" int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, void* y, int n, int h, int w, int cin, int cout,
+                                           const float* scale, const float* noise, int round_noise, const void* bias,
+                                           float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream) {
+    return launch_conv3x3<false>("conv3x3_epilogue_nhwc", x, w_packed, y, n, h, w, cin, cout, scale, noise, round_noise, bias, alpha, gain, clamp, next_scale, stream);
+}
+
+// (ABI 10) the fp32-grade form: x3 = [hi | lo | hi] float16 from gnerf_split_f16x3_nhwc, w3 = [hi | hi | lo] packed like w_packed, float32 bias and result
+extern "C" int gnerf_conv3x3_f32x3_epilogue_nhwc(const void* x3, const void* w3_packed, float* y, int n, int h, int w, int cin3, int cout,
+                                                 const float* scale, const float* noise, const float* bias,
+                                                 float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream) {
+    return launch_conv3x3<true>("conv3x3_f32x3_epilogue_nhwc", x3, w3_packed, y, n, h, w, cin3, cout, scale, noise, 0, bias, alpha, gain, clamp, next_scale, stream);
+}
+
+extern "C" int gnerf_conv_transpose3x3_s2_f32x3_nhwc(const void* x3, const void* w3_phases, float* y, int n, int h, int w, int cin3, int cout, gnerf_stream_t stream) {
+    return launch_conv_transpose<true>("conv_transpose3x3_s2_f32x3_nhwc", x3, w3_phases, y, n, h, w, cin3, cout, stream);
+}
+
+extern "C" int gnerf_split_f16x3_nhwc(const float* x, const float* scale, void* y, int n, int pixels, int channels, int* overflow, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!x || !y) return fail(GNERF_E_ARG, "split_f16x3_nhwc: null pointer");
+    if (n < 1 || pixels < 1 || channels < 8 || channels % 8) return fail(GNERF_E_UNSUPPORTED, "split_f16x3_nhwc: channels must be a positive multiple of 8 (got %d)", channels);
+    if (n > 65535) return fail(GNERF_E_UNSUPPORTED, "split_f16x3_nhwc: at most 65535 images per call");
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return fail(GNERF_E_ARG, "split_f16x3_nhwc: x and y must be 16-byte aligned");
+    const int per_pixel = channels / 8;
+    const int64_t total = int64_t(pixels) * per_pixel;
+    // enough workgroups to fill the chip a few times over, whole pixels per grid stride (the kernel rounds the stride down to one)
+    int64_t blocks = (total + 255) / 256;
+    const int64_t cap = int64_t(kNumCU) * 8 / (n < 8 ? 1 : 2);
+    if (blocks > cap) blocks = cap;
+    if (blocks * 256 < per_pixel) blocks = (per_pixel + 255) / 256;
+    hipLaunchKernelGGL(split_f16x3_kernel, dim3(unsigned(blocks), unsigned(n)), dim3(256), 0, as_stream(stream), x, scale, static_cast<_Float16*>(y), pixels, channels, overflow);
+    return check_launch("split_f16x3_nhwc");
+}
+
+// y = conv_transpose2d(x, w, stride = 2) for 3x3 kernels on float16 channels_last tensors, as four phase convolutions; see include/gnerf_hip.h.
+extern "C" int gnerf_conv_transpose3x3_s2_nhwc(const void* x, const void* w_phases, void* y, int n, int h, int w, int cin, int cout, gnerf_stream_t stream) {
+    return launch_conv_transpose<false>("conv_transpose3x3_s2_nhwc", x, w_phases, y, n, h, w, cin, cout, stream);
 }

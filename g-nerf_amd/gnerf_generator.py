@@ -113,6 +113,27 @@ def _packed_prenormalised_weight(module, dtype, transposed=False):
 _FUSED_CONV = os.environ.get('GNERF_FUSED_CONV', '1') != '0'
 # GNERF_SHARED_AT_ONE=0: a batch of one keeps round 5's route (per-sample modulated weights into the framework's convolution)
 _SHARED_AT_ONE = os.environ.get('GNERF_SHARED_AT_ONE', '1') != '0'
+# GNERF_F32X3=0: the backbone's float32 3x3 layers stay with the framework's fp32 convolution (MIOpen) instead of the fp32-grade form of
+# csrc/conv3x3.hip (round 6: every product as three f16 matrix products of hi / lo splits, 2.5-3.3x MIOpen on the backbone's hot shapes)
+_F32X3 = os.environ.get('GNERF_F32X3', '1') != '0'
+# smallest image the fp32-grade form takes: the convolution at H, W >= 64, the x2 layers from H, W >= 32 (at 32^2 the kernel's 8 x 32 pixel
+# tiles leave most of the chip idle and MIOpen is faster: profiles/r06_conv_f32grade_gate.jsonl)
+_F32X3_MIN_CONV, _F32X3_MIN_UP = 64, 32
+
+
+def _packed_weight_f32x3(module, transposed=False):
+    """The RAW float32 weight (no pre-normalisation: float32 layers have none, networks_stylegan2.py:61-64) split as [hi | hi | lo] and packed for
+    gnerf_hip.conv3x3_f32x3_epilogue (or, transposed, conv_transpose3x3_s2_f32x3); cached per weight version."""
+    w = module.weight
+    key = (w.data_ptr(), w._version if not w.is_inference() else None)
+    name = '_gnerf_f32x3_packed_t' if transposed else '_gnerf_f32x3_packed'
+    hit = module.__dict__.get(name)
+    if hit is None or hit[0] != key:
+        import gnerf_hip
+        pack = gnerf_hip.pack_conv_transpose3x3_weights_f32x3 if transposed else gnerf_hip.pack_conv3x3_weights_f32x3
+        hit = (key, pack(w))
+        module.__dict__[name] = hit
+    return hit[1]
 
 
 def _latent_token(w):
@@ -306,6 +327,25 @@ class StyledConv(nn.Module):
             c_out = self.weight.shape[0]
             clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
             mine = aff + (self.weight,)
+            if (not half and _F32X3 and c_out % 128 == 0 and c_in % 8 == 0 and (noise is None or noise.numel() == (h * self.up) * (wd * self.up))
+                    and ((self.up == 1 and min(h, wd) >= _F32X3_MIN_CONV and gnerf_hip.conv3x3_f32x3_supported(x, c_out))
+                         or (self.up == 2 and min(h, wd) >= _F32X3_MIN_UP and gnerf_hip.conv_transpose3x3_s2_f32x3_supported(x, c_out)))):
+                # float32 layer in fp32-GRADE arithmetic on the f16 matrix cores (csrc/conv3x3.hip, OUT32): the reference's un-fused form --
+                # x * styles, convolution with the layer's weight, demodulation coefficients after it (networks_stylegan2.py:76-83) -- with the
+                # scaling folded into the hi / lo split of the activations and everything behind the convolution in its epilogue
+                dco = _per_latent(self, w, 'dco32', mine, lambda: gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=torch.float32, want_weights=False, want_dcoefs=True)[1])
+                x3 = gnerf_hip.split_f16x3(x if cl else x.contiguous(memory_format=torch.channels_last), styles)
+                if self.up == 1:
+                    x = gnerf_hip.conv3x3_f32x3_epilogue(x3, _packed_weight_f32x3(self), self.bias, scale=dco, noise=noise, gain=LRELU_GAIN * gain, clamp=clamp)
+                else:
+                    x = gnerf_hip.conv_transpose3x3_s2_f32x3(x3, _packed_weight_f32x3(self, transposed=True))
+                    if noise is None:
+                        x = gnerf_hip.blur_epilogue_channels_last(x, self.resample_filter, [1, 1, 1, 1], blur_gain=4, bias=self.bias, scale=dco, act='lrelu',
+                                                                  gain=LRELU_GAIN * gain, clamp=clamp)
+                    else:
+                        x = upfirdn2d.upfirdn2d(x, self.resample_filter, padding=[1, 1, 1, 1], gain=4)
+                        x = gnerf_hip.modconv_epilogue(x, self.bias, scale=dco, noise=noise, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp)
+                return (x, folded) if next_layer is not None else x
             # shared-weight form: activations scaled by the styles, demodulation in the epilogue.  Round 6: also at n == 1 -- one latent is
             # trivially "shared", and it is the call gen_videos.py makes (one camera per synthesis, gen_videos.py:154-171): the frame-by-frame
             # orbit then runs its 3x3 layers on csrc/conv3x3.hip like the batched one instead of per-sample weights + MIOpen
@@ -405,7 +445,18 @@ class ToRGB(nn.Module):
             if x.dtype == torch.float16 and _is_channels_last(x) and self.weight.shape[0] == 3 and c_in in gnerf_hip.TORGB_CHANNELS:
                 return gnerf_hip.torgb_channels_last(x, self.weight, styles, _cast_param(self, 'bias', x.dtype), clamp=self.conv_clamp,
                                                      accumulate_into=accumulate_into)      # one streaming read of x
-            if x.dtype == torch.float16 and n > 1:
+            if x.dtype == torch.float32 and _is_channels_last(x):
+                # float32 channels_last (what the fp32-grade convolution hands over): the 1x1 modulated convolution is a GEMM on the tensor's own
+                # memory, [H W, C] x [C, O] per sample with the styles folded into the small operand -- no scaling pass over x, no layout change,
+                # and bit-reproducible (MIOpen's fp32 channels_last 1x1 kernels for 512 -> 96 and 256 -> 96 are not: they differ by an ulp from
+                # call to call, tools/dbg_f32x3_det.py; the grouped per-sample form below would copy a batch back to NCHW for its reshape)
+                wmod = _per_latent(self, w, 'wmod_t', aff + (self.weight,), lambda: (self.weight.reshape(1, -1, c_in) * styles[:, None, :]).transpose(1, 2).contiguous())
+                xv = x.permute(0, 2, 3, 1).reshape(n, h * wd, c_in)
+                if self.conv_clamp is None:
+                    y = torch.baddbmm(self.bias.reshape(1, 1, -1), xv, wmod)
+                    return y.reshape(n, h, wd, -1).permute(0, 3, 1, 2)
+                x = torch.bmm(xv, wmod).reshape(n, h, wd, -1).permute(0, 3, 1, 2)
+            elif x.dtype == torch.float16 and n > 1:
                 x = F.conv2d(gnerf_hip.scale_channels(x, styles), self.weight.to(x.dtype))
             else:
                 wts = _per_latent(self, w, ('wts', x.dtype), aff + (self.weight,), lambda: gnerf_hip.modulate_weights(self.weight, styles, False, out_dtype=x.dtype)[0])
@@ -464,7 +515,7 @@ class Block(nn.Module):
             return x, img.add_(y)
         y = self.torgb(x, ws[-1], fused=fused).float()
         if img is not None and self.up == 2 and self.emit_channels_last and img.is_cuda:
-            return x, upfirdn2d.upsample2d_add_channels_last(img, y, self.resample_filter)
+            return x, upfirdn2d.upsample2d_add_channels_last(img, y.contiguous(), self.resample_filter)
         if img is not None and self.up == 2:
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         if img is None:

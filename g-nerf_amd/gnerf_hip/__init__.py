@@ -23,7 +23,7 @@ _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.float64: F64}
 
 MAX_SAMPLES = 256
 DEBUG_SLOTS = 8
-ABI_VERSION = 9
+ABI_VERSION = 10
 # decoder arithmetic of the fused renderer (GNERF_MLP_* in include/gnerf_hip.h)
 MLP_MODES = {'auto': 0, 'f16x3': 1, 'f32': 2}
 
@@ -102,6 +102,9 @@ SIGNATURES = {
     'gnerf_modconv_epilogue': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p, _c_i, _c_f, _c_f, _c_f, _c_p]),
     'gnerf_conv3x3_epilogue_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_p, _c_f, _c_f, _c_f, _c_p, _c_p]),
     'gnerf_conv_transpose3x3_s2_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),
+    'gnerf_split_f16x3_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
+    'gnerf_conv3x3_f32x3_epilogue_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_p, _c_p]),
+    'gnerf_conv_transpose3x3_s2_f32x3_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_upsample2x_add_nhwc': (_c_i, [_c_p, _c_p, ctypes.POINTER(_c_f), _c_i, _c_f, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
     'gnerf_scale_channels_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_modconv_epilogue_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p, _c_i, _c_f, _c_f, _c_f, _c_p, _c_p]),
@@ -730,6 +733,107 @@ def conv3x3_epilogue(x, w_packed, bias=None, scale=None, noise=None, round_noise
         code = load().gnerf_conv3x3_epilogue_nhwc(_ptr(x), _ptr(w_packed), _ptr(y), n, h, w, c, o, _ptr(s32), _ptr(nz), 1 if round_noise else 0, _ptr(b),
                                                   float(alpha), float(gain), float(-1 if clamp is None else clamp), _ptr(nx), _stream(x))
     _check(code, 'gnerf_conv3x3_epilogue_nhwc')
+    return y
+
+
+def _split_weights_f16x3(weight):
+    """[O, I, kh, kw] float32 -> [O, 3 I, kh, kw] float32 holding [hi | hi | lo] along the input channels, hi = half(w), lo = half(w - hi): the
+    weight operand of the fp32-grade convolution (gnerf_conv3x3_f32x3_epilogue_nhwc), against activations split as [hi | lo | hi]."""
+    w = weight.detach().to(torch.float32)
+    hi = w.to(torch.float16).to(torch.float32)
+    lo = (w - hi).to(torch.float16).to(torch.float32)
+    return torch.cat([hi, hi, lo], 1)
+
+
+def pack_conv3x3_weights_f32x3(weight):
+    """pack_conv3x3_weights of the [hi | hi | lo] split of a float32 weight [O, I, 3, 3]: float16 [9, O, 3 I padded to a multiple of 64]."""
+    return pack_conv3x3_weights(_split_weights_f16x3(weight))
+
+
+def pack_conv_transpose3x3_weights_f32x3(weight):
+    """pack_conv_transpose3x3_weights of the [hi | hi | lo] split of a float32 weight [O, I, 3, 3] (correlation form)."""
+    return pack_conv_transpose3x3_weights(_split_weights_f16x3(weight))
+
+
+_split_overflow = {}
+
+
+def split_overflow_flag(device):
+    """The sticky device int split_f16x3 reports out-of-range activations in (one per device; read it with .item() when a check is wanted)."""
+    f = _split_overflow.get(device)
+    if f is None:
+        f = _split_overflow[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return f
+
+
+@profiled('gnerf_hip::split_f16x3')
+def split_f16x3(x, scale=None):
+    """x float32 channels_last [N, C, H, W] (C % 8 == 0), scale float32 [N, C] or None -> float16 channels_last [N, 3C, H, W] = [hi | lo | hi] of
+    x * scale (csrc/conv3x3.hip): the activation operand of conv3x3_f32x3_epilogue / conv_transpose3x3_s2_f32x3."""
+    _require_cuda(x, scale)
+    n, c, h, w = x.shape
+    if x.dtype != torch.float32 or not is_channels_last(x) or c % 8:
+        raise RuntimeError('split_f16x3: x must be a channels_last float32 [N,C,H,W] tensor with C % 8 == 0')
+    s32 = None if scale is None else scale.detach().to(torch.float32).contiguous()
+    if s32 is not None and s32.numel() != n * c:
+        raise RuntimeError('split_f16x3: scale must have N * C elements')
+    y = torch.empty([n, 3 * c, h, w], dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    with _on_device(x.device):
+        code = load().gnerf_split_f16x3_nhwc(_ptr(x), _ptr(s32), _ptr(y), n, h * w, c, _ptr(split_overflow_flag(x.device)), _stream(x))
+    _check(code, 'gnerf_split_f16x3_nhwc')
+    return y
+
+
+def conv3x3_f32x3_supported(x, c_out):
+    """Does the fp32-grade convolution take this float32 activation tensor (as its [hi | lo | hi] split)?  channels_last is not required of x:
+    the caller converts; 8 x 32 pixel tiles, input channels in eights, output channels in blocks of 128."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.ndim == 4 and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0 and x.shape[1] % 8 == 0
+            and c_out % 128 == 0 and 3 * x.shape[1] * x.shape[2] * x.shape[3] * 2 < (1 << 31))
+
+
+def conv_transpose3x3_s2_f32x3_supported(x, c_out):
+    return (x.is_cuda and x.dtype == torch.float32 and x.ndim == 4 and x.shape[1] % 8 == 0 and c_out % 128 == 0
+            and 3 * x.shape[1] * x.shape[2] * x.shape[3] * 2 < (1 << 31))
+
+
+@profiled('gnerf_hip::conv3x3_f32x3_epilogue')
+def conv3x3_f32x3_epilogue(x3, w3_packed, bias=None, scale=None, noise=None, alpha=0.2, gain=1.0, clamp=None, next_scale=None):
+    """The fp32-grade form of conv3x3_epilogue: x3 = split_f16x3(x) [N,3C,H,W] float16 channels_last, w3_packed = pack_conv3x3_weights_f32x3(w);
+    bias float32 [O]; returns a channels_last float32 [N,O,H,W] tensor (nothing is rounded on the way out)."""
+    _require_cuda(x3, w3_packed, bias, scale, noise, next_scale)
+    n, c3, h, w = x3.shape
+    o = w3_packed.shape[1]
+    if not is_channels_last(x3) or x3.dtype != torch.float16 or tuple(w3_packed.shape) != (9, o, -(-c3 // 64) * 64) or w3_packed.dtype != torch.float16 or not w3_packed.is_contiguous():
+        raise RuntimeError('conv3x3_f32x3_epilogue: x3 must be channels_last float16 [N,3C,H,W] and w3_packed contiguous float16 [9,O,3C]')
+    def f32(t, numel, what):
+        if t is None:
+            return None
+        t = t.detach().to(torch.float32).contiguous()
+        if t.numel() != numel:
+            raise RuntimeError(f'conv3x3_f32x3_epilogue: {what} must have {numel} elements')
+        return t if t.data_ptr() % 16 == 0 else t.clone()
+    s32, nx, nz, b = f32(scale, n * o, 'scale'), f32(next_scale, n * o, 'next_scale'), f32(noise, h * w, 'noise'), f32(bias, o, 'bias')
+    y = torch.empty([n, o, h, w], dtype=torch.float32, device=x3.device, memory_format=torch.channels_last)
+    with _on_device(x3.device):
+        code = load().gnerf_conv3x3_f32x3_epilogue_nhwc(_ptr(x3), _ptr(w3_packed), _ptr(y), n, h, w, c3, o, _ptr(s32), _ptr(nz), _ptr(b),
+                                                        float(alpha), float(gain), float(-1 if clamp is None else clamp), _ptr(nx), _stream(x3))
+    _check(code, 'gnerf_conv3x3_f32x3_epilogue_nhwc')
+    return y
+
+
+@profiled('gnerf_hip::conv_transpose3x3_s2_f32x3')
+def conv_transpose3x3_s2_f32x3(x3, w3_phases):
+    """The fp32-grade form of conv_transpose3x3_s2: x3 = split_f16x3(x), w3_phases = pack_conv_transpose3x3_weights_f32x3(w); returns a
+    channels_last float32 [N,O,2H+1,2W+1] tensor."""
+    _require_cuda(x3, w3_phases)
+    n, c3, h, w = x3.shape
+    o = w3_phases.shape[1]
+    if not is_channels_last(x3) or x3.dtype != torch.float16 or tuple(w3_phases.shape) != (9, o, -(-c3 // 64) * 64) or w3_phases.dtype != torch.float16 or not w3_phases.is_contiguous():
+        raise RuntimeError('conv_transpose3x3_s2_f32x3: x3 must be channels_last float16 [N,3C,H,W] and w3_phases contiguous float16 [9,O,3C]')
+    y = torch.empty([n, o, 2 * h + 1, 2 * w + 1], dtype=torch.float32, device=x3.device, memory_format=torch.channels_last)
+    with _on_device(x3.device):
+        code = load().gnerf_conv_transpose3x3_s2_f32x3_nhwc(_ptr(x3), _ptr(w3_phases), _ptr(y), n, h, w, c3, o, _stream(x3))
+    _check(code, 'gnerf_conv_transpose3x3_s2_f32x3_nhwc')
     return y
 
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GNERF_ABI_VERSION 9
+#define GNERF_ABI_VERSION 10
 
 /* error codes */
 #define GNERF_OK            0
@@ -147,6 +147,26 @@ int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, void* y, in
  * (ky, kx) = (0,0), (0,2), (2,0), (2,2) | (0,1), (2,1) | (1,0), (1,2) | (1,1), with w_phases[t, o, c] = weight[c, o, ky, kx] of the transposed
  * convolution; y: [n, 2h + 1, 2w + 1, cout].  All 16-byte aligned.  GNERF_E_UNSUPPORTED unless cin % 8 == 0 and cout % 128 == 0. */
 int gnerf_conv_transpose3x3_s2_nhwc(const void* x, const void* w_phases, void* y, int n, int h, int w, int cin, int cout, gnerf_stream_t stream);
+/* (ABI 10) The same two convolutions in fp32-GRADE arithmetic, for the backbone's float32 layers (networks_stylegan2.py:41-98 and
+ * conv2d_resample.py:48-143 on float32 activations; the reference hands them to the framework's fp32 convolution): every product x w is
+ * evaluated as hi(x) hi(w) + lo(x) hi(w) + hi(x) lo(w) with hi(v) = half(v), lo(v) = half(v - hi(v)) on the f16 matrix instruction with
+ * float32 accumulation -- the arithmetic of the fused renderer's decoder (dropped term and split roundings ~2^-21 relative, i.e. float32-
+ * grade as long as the operands stay inside float16's RANGE: |x| < 65504) --, which for a convolution is the float16 kernel on three times
+ * the input channels.
+ *   gnerf_split_f16x3_nhwc: x float32 [n, pixels, channels] (channels_last), scale float32 [n, channels] or NULL -> y float16
+ *     [n, pixels, 3 channels] = [hi | lo | hi] of v = x * scale (the layer's `x * styles`, :77, folded in).  channels % 8 == 0, 16-byte
+ *     aligned.  |v| >= 65504 saturates to the largest finite half and sets *overflow (a device int the caller zeroed; NULL: not reported)
+ *     to 1 -- the result of a convolution on such an operand is finite but wrong, and a caller that cannot bound its activations checks it.
+ *   gnerf_conv3x3_f32x3_epilogue_nhwc: x3 as above with cin3 = 3 channels; w3_packed float16 [9, cout, cin3 rounded up to a multiple of 64,
+ *     zero-filled] = [hi(w) | hi(w) | lo(w)] along the input-channel axis, tap-major like w_packed; bias float32 [cout] or NULL; y float32
+ *     [n, h, w, cout]; epilogue operands and shape rules as gnerf_conv3x3_epilogue_nhwc (the epilogue runs in float32, nothing is rounded).
+ *   gnerf_conv_transpose3x3_s2_f32x3_nhwc: likewise for the stride-2 transposed form, w3_phases in gnerf_conv_transpose3x3_s2_nhwc's tap
+ *     order; y float32 [n, 2h + 1, 2w + 1, cout]. */
+int gnerf_split_f16x3_nhwc(const float* x, const float* scale, void* y, int n, int pixels, int channels, int* overflow, gnerf_stream_t stream);
+int gnerf_conv3x3_f32x3_epilogue_nhwc(const void* x3, const void* w3_packed, float* y, int n, int h, int w, int cin3, int cout,
+                                      const float* scale, const float* noise, const float* bias,
+                                      float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream);
+int gnerf_conv_transpose3x3_s2_f32x3_nhwc(const void* x3, const void* w3_phases, float* y, int n, int h, int w, int cin3, int cout, gnerf_stream_t stream);
 /* ToRGBLayer with three output channels on a channels_last float16 tensor (networks_stylegan2.py:349-367, modulation as in the
  * fused form :89-96): y[n, o, p] = clamp(half(sum_c x[n, p, c] * half(weight[o, c] * styles[n, c])) + bias[o]), products exact, fp32
  * accumulation.  x: float16 [n, pixels, channels] (channels 32, 64, 128, 256 or 512, 16-byte aligned); weight float32 [3, channels];

@@ -202,6 +202,52 @@ def test_bench_self_launch_eight_ranks_stub():
     assert [x['rank'] for x in line['ranks']] == list(range(8)) and len({x['pid'] for x in line['ranks']}) == 8
 
 
+def test_one_solver_search_per_node_eight_ranks_stub(tmp_path):
+    """Round 6 (bench.one_solver_search): rank 0 runs the warm-up -- MIOpen's solver search -- alone, its user database / kernel cache are
+    copied into every other rank's own directories, and only then do the other ranks issue their first convolution.  Rehearsed with the
+    stub step: the stub "convolution" searches for GNERF_BENCH_STUB_SEARCH_S seconds unless its rank's MIOPEN_USER_DB_PATH already holds
+    the solver record.  With eight ranks exactly one search is paid (rank 0's), every other rank finds the record BEFORE its first
+    convolution, and the wall time of the phase does not grow with the number of ranks."""
+    env = {'TMPDIR': str(tmp_path), 'GNERF_BENCH_STUB_SEARCH_S': '1.5'}
+    walls = {}
+    for n in (2, 8):
+        import shutil
+        shutil.rmtree(os.path.join(str(tmp_path), f'gnerf_miopen_{os.getuid()}'), ignore_errors=True)
+        r, lines = _run_bench(['--gpus', str(n), '--steps', '2', '--warmup', '1', '--stub-step'], env)
+        assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
+        ranks = lines[0]['ranks']
+        assert [x['rank'] for x in ranks] == list(range(n))
+        assert ranks[0]['solver_search']['hit_before_first_conv'] is False and ranks[0]['solver_search']['searched_s'] == 1.5
+        for x in ranks[1:]:
+            assert x['solver_search']['hit_before_first_conv'] is True and x['solver_search']['searched_s'] == 0.0, x
+        walls[n] = max(x['solver_search']['wall_s'] for x in ranks)
+    assert walls[8] < walls[2] + 1.0 and walls[8] < 2 * 1.5, walls            # one search, not eight (eight in a row would be 12 s)
+
+
+def test_one_solver_search_leaves_hand_set_directories_alone(tmp_path):
+    """A MIOPEN_USER_DB_PATH the caller chose (not per_rank_miopen_env's rank<k> layout) is not copied anywhere: a shared directory needs none."""
+    import bench
+    mine = tmp_path / 'shared_db'
+    mine.mkdir()
+    (mine / 'x.ufdb.txt').write_text('record')
+    calls = []
+    out = bench.one_solver_search(0, 3, lambda: calls.append('warm') or 7, lambda: calls.append('barrier'), env={'MIOPEN_USER_DB_PATH': str(mine)})
+    assert out == 7 and calls == ['warm', 'barrier'] and sorted(os.listdir(tmp_path)) == ['shared_db']
+    # the per-rank layout IS copied, before the barrier releases the others
+    base = tmp_path / 'gnerf_miopen_0'
+    for k in range(3):
+        (base / f'rank{k}' / 'db').mkdir(parents=True)
+    (base / 'rank0' / 'db' / 'gfx950.ufdb.txt').write_text('searched')
+    order = []
+    bench.one_solver_search(0, 3, lambda: order.append('warm'), lambda: order.append(sorted(os.listdir(base / 'rank2' / 'db'))),
+                            env={'MIOPEN_USER_DB_PATH': str(base / 'rank0' / 'db')})
+    assert order == ['warm', ['gfx950.ufdb.txt']]
+    # a rank other than 0 waits first, then warms
+    order = []
+    bench.one_solver_search(2, 3, lambda: order.append('warm'), lambda: order.append('barrier'), env={})
+    assert order == ['barrier', 'warm']
+
+
 def test_bench_self_launch_reports_a_dead_rank():
     """A rank that dies leaves its peers in a collective: the launcher must end them and exit non-zero, with no result line."""
     r, lines = _run_bench(['--gpus', '3', '--steps', '2', '--warmup', '1', '--stub-step'],

@@ -1790,6 +1790,65 @@ def test_conv3x3_epilogue_vs_composed_ops(dev):
         gnerf_hip.conv3x3_epilogue(bad, torch.zeros(9, 128, 64, device=dev, dtype=torch.float16))
 
 
+def test_conv_f32x3_vs_float64(dev):
+    """Round 6: the fp32-GRADE convolutions for the backbone's float32 layers (csrc/conv3x3.hip OUT32; networks_stylegan2.py:41-98 and
+    conv2d_resample.py:109-131 on float32 activations).  gnerf_split_f16x3_nhwc + gnerf_conv3x3_f32x3_epilogue_nhwc / the transposed form against
+    a float64 evaluation of the same chain, next to the framework's own float32 convolution: the three-f16-products form must be float32-
+    grade.  Its error has two parts: the splits (dropped lo * lo term, roundings of the lo halves: ~2^-21 relative per product, random) and the
+    ACCUMULATION, which on the matrix instruction is a float32 chain over the products one after the other (tools/probes/mfma_rounding_probe.hip)
+    -- sqrt(K) 2^-24 |partial sum| for K = 9 cin terms, where a blocked float32 summation (what MIOpen's kernel amounts to) has 2^-24 sqrt(K / 32).
+    A numpy model of the two orders on K = 4608 gives 1.1e-3 against 1.5e-4 at |sum| <= 470: the test's bound is the chain's, and no more than
+    four times the framework's where that is larger."""
+    import gnerf_hip
+    from torch_utils.ops import bias_act
+    gen = torch.Generator().manual_seed(5)
+    gnerf_hip.split_overflow_flag(dev).zero_()
+    for (n, cin, cout, h, w) in [(2, 128, 128, 16, 64), (1, 64, 256, 8, 32), (1, 512, 128, 8, 32), (2, 24, 128, 8, 64)]:
+        x = (torch.randn(n, cin, h, w, generator=gen) * 1.5).to(dev).contiguous(memory_format=torch.channels_last)
+        wt = torch.randn(cout, cin, 3, 3, generator=gen).to(dev)                        # raw N(0, 1) weights, as a float32 layer holds them
+        st = (torch.rand(n, cin, generator=gen) + 0.5).to(dev)
+        sc = (torch.rand(n, cout, generator=gen) * 0.05 + 0.01).to(dev)
+        bias = (torch.randn(cout, generator=gen) * 0.2).to(dev)
+        noise = (torch.randn(h, w, generator=gen) * 0.1).to(dev)
+        x3 = gnerf_hip.split_f16x3(x, st)
+        assert x3.shape == (n, 3 * cin, h, w) and x3.dtype == torch.float16 and gnerf_hip.is_channels_last(x3)
+        xs = x * st[:, :, None, None]
+        hi = x3[:, :cin].float()
+        assert torch.equal(hi, xs.half().float()) and torch.equal(x3[:, 2 * cin:], x3[:, :cin]) and torch.equal(x3[:, cin:2 * cin].float(), (xs - hi).half().float())
+        w3 = gnerf_hip.pack_conv3x3_weights_f32x3(wt)
+        assert w3.shape == (9, cout, -(-3 * cin // 64) * 64)
+        ref = torch.nn.functional.conv2d(xs.double(), wt.double(), padding=1)
+        top = float(ref.abs().max())
+        e_fw = float((torch.nn.functional.conv2d(xs, wt, padding=1).double() - ref).abs().max())
+        got = gnerf_hip.conv3x3_f32x3_epilogue(x3, w3, alpha=1.0)
+        assert got.shape == (n, cout, h, w) and got.dtype == torch.float32 and gnerf_hip.is_channels_last(got)
+        e_own = float((got.double() - ref).abs().max())
+        chain = 2.0 ** -24 * (9 * cin) ** 0.5                          # float32 chain over K = 9 cin products, relative to the largest partial sum
+        assert e_own <= max(4 * e_fw, chain * top), ('plain', n, cin, cout, e_own, e_fw, top)
+        # the whole layer: demodulation, noise, bias, lrelu * gain, clamp
+        for scale, nz, clamp in ((sc, noise, None), (sc, None, 2.0), (None, noise, None)):
+            got = gnerf_hip.conv3x3_f32x3_epilogue(x3, w3, bias, scale=scale, noise=nz, gain=1.3, clamp=clamp)
+            t = ref * (scale[:, :, None, None].double() if scale is not None else 1.0) + (nz.double() if nz is not None else 0.0)
+            want = bias_act.bias_act(t, bias.double(), act='lrelu', gain=1.3, clamp=clamp)
+            e = float((got.double() - want).abs().max())
+            amp = (float(scale.max()) if scale is not None else 1.0) * 1.3
+            assert e <= max(4 * e_fw, chain * top) * amp + 1e-6 * float(want.abs().max()), ('layer', n, cin, cout, scale is not None, nz is not None, clamp, e, e_fw)
+        # the stride-2 transposed form
+        wp = gnerf_hip.pack_conv_transpose3x3_weights_f32x3(wt)
+        ref_t = torch.nn.functional.conv_transpose2d(xs.double(), wt.transpose(0, 1).double(), stride=2)
+        e_fw_t = float((torch.nn.functional.conv_transpose2d(xs, wt.transpose(0, 1).contiguous(), stride=2).double() - ref_t).abs().max())
+        got_t = gnerf_hip.conv_transpose3x3_s2_f32x3(x3, wp)
+        assert got_t.shape == (n, cout, 2 * h + 1, 2 * w + 1) and got_t.dtype == torch.float32
+        e_t = float((got_t.double() - ref_t).abs().max())
+        assert e_t <= max(4 * e_fw_t, 2.0 ** -24 * (4 * cin) ** 0.5 * float(ref_t.abs().max())), ('transposed', n, cin, cout, e_t, e_fw_t)
+    assert int(gnerf_hip.split_overflow_flag(dev).item()) == 0
+    # an operand outside float16's range: saturated, finite, and REPORTED
+    big = torch.full((1, 8, 8, 32), 1e5, device=dev).contiguous(memory_format=torch.channels_last)
+    b3 = gnerf_hip.split_f16x3(big)
+    assert torch.isfinite(b3.float()).all() and int(gnerf_hip.split_overflow_flag(dev).item()) == 1
+    gnerf_hip.split_overflow_flag(dev).zero_()
+
+
 def test_generator_fast_modconv_path_equals_plain_path(dev, monkeypatch):
     """The generator with csrc/modconv.hip around its convolutions (and the shared-weight convolution form for fp16 batches)
     against the same generator on the plain PyTorch-op chains: batch 1 (grouped form) and batch 3 (shared-weight form)."""
@@ -1933,17 +1992,32 @@ def test_config3_n4_gpu_vs_reference_fixture(dev, golden, monkeypatch):
     real_fns = {name: getattr(gnerf_hip, name) for name in own}
     for name in own:
         monkeypatch.setattr(gnerf_hip, name, (lambda real_fn, name: lambda x, w, *a, **kw: (own[name].append((x.shape[0], x.shape[1], w.shape[1], x.shape[2])), real_fn(x, w, *a, **kw))[1])(real_fns[name], name))
+    own32 = {'conv3x3_f32x3_epilogue': [], 'conv_transpose3x3_s2_f32x3': []}
+    for name in own32:
+        monkeypatch.setattr(gnerf_hip, name, (lambda real_fn, name: lambda x, w, *a, **kw: (own32[name].append((x.shape[0], x.shape[1], w.shape[1], x.shape[2])), real_fn(x, w, *a, **kw))[1])(getattr(gnerf_hip, name), name))
+    gnerf_hip.split_overflow_flag(dev).zero_()
     for force_fp32, tol in ((False, 1e-4), (True, 1e-7)):
         for name in own:
             own[name].clear()
+        for name in own32:
+            own32[name].clear()
         ws, out = C.run_config3(G, dev, **(dict(force_fp32=True) if force_fp32 else {}))
         # round 6: the ROUTE is part of the test.  fp16 superresolution: every 3x3 layer the kernel's shape gate admits runs on csrc/conv3x3.hip
         # (block0.conv1, block1.conv1 fused with their epilogues; block0.conv0, block1.conv0 as the transposed form); fp32: none does.
         if force_fp32:
             assert not own['conv3x3_epilogue'] and not own['conv_transpose3x3_s2'], own
+            # ... the float32 layers from 64^2 up run in fp32-grade arithmetic on the same kernel (gnerf_hip.conv3x3_f32x3_epilogue: x3 has three
+            # times the layer's input channels): backbone b64.conv1, b128.conv1, b256.conv1 and the superresolution's block0.conv1, block1.conv1;
+            # the x2 layers b64.conv0 ... b256.conv0, block0.conv0, block1.conv0 on its transposed form
+            assert sorted(own32['conv3x3_f32x3_epilogue']) == [(4, 384, 128, 256), (4, 384, 128, 512), (4, 768, 256, 128), (4, 768, 256, 256), (4, 1536, 512, 64)], own32
+            assert sorted(own32['conv_transpose3x3_s2_f32x3']) == [(4, 96, 256, 128), (4, 768, 128, 128), (4, 768, 128, 256), (4, 1536, 256, 64), (4, 1536, 512, 32)], own32
+            assert int(gnerf_hip.split_overflow_flag(dev).item()) == 0
         else:
             assert sorted(own['conv3x3_epilogue']) == [(4, 128, 128, 512), (4, 256, 256, 256)], own
             assert sorted(own['conv_transpose3x3_s2']) == [(4, 32, 256, 128), (4, 256, 128, 256)], own
+            # (the backbone is float32 in both legs: its six layers from 64^2 up)
+            assert sorted(own32['conv3x3_f32x3_epilogue']) == [(4, 384, 128, 256), (4, 768, 256, 128), (4, 1536, 512, 64)], own32
+            assert sorted(own32['conv_transpose3x3_s2_f32x3']) == [(4, 768, 128, 128), (4, 1536, 256, 64), (4, 1536, 512, 32)], own32
         np.testing.assert_allclose(ws[:, 0, :8].cpu().numpy(), g['ws_first'], atol=1e-4)
         assert out['image'].shape == (4, 3, 512, 512) and out['image'].dtype == torch.float32
         mse = {'image': float(((out['image'][:, :, 4::8, 4::8].cpu().numpy() - g['image_sub']) ** 2).mean()),

@@ -1,11 +1,14 @@
 #!/bin/bash
 # Per-frame kernel statistics of the gen_videos orbit with the warm-up (MIOpen solver search) excluded (run on the GPU box):
 #   bash tools/prof_orbit.sh <tag> [orbit_marked.py arguments]  ->  gpurun_out/<tag>_kernel_stats.csv + gpurun_out/<tag>_summary.json
+# MARKED_SCRIPT=tools/config3_marked.py: the same for config 3 / config 5's generator passes (any script that brackets its timed part with the marker kernel
+# and prints a JSON line with "frames")
 tag=$1; shift
+script=${MARKED_SCRIPT:-tools/orbit_marked.py}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
-timeout -k 10 400 rocprofv3 --kernel-trace -d /tmp/prof_$tag -o run -- python3 $R/tools/orbit_marked.py "$@" > /tmp/prof_$tag.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace -d /tmp/prof_$tag -o run -- python3 $R/$script "$@" > /tmp/prof_$tag.log 2>&1
 tail -1 /tmp/prof_$tag.log
 cd $R && python3 - "$tag" /tmp/prof_$tag /tmp/prof_$tag.log <<'PY'
 import collections, csv, glob, json, re, sqlite3, sys
@@ -23,7 +26,7 @@ frames = run['frames']
 def family(name):
     n = name
     if 'render_kernel' in n: return 'ours: fused renderer'
-    if 'conv3x3_epilogue_kernel' in n: return 'ours: fused 3x3 convolution + epilogue (MFMA)'
+    if 'conv3x3_epilogue_kernel' in n or 'split_f16x3' in n: return 'ours: 3x3 convolution (+ epilogue; fp32-grade form with its hi/lo split) on MFMA'
     if 'clamp_depth' in n or 'make_rays' in n or 'to_uint8' in n or 'planes_absmax' in n or 'absmax_kernel' in n: return 'ours: renderer side kernels'
     if 'blur4' in n or 'upfirdn' in n: return 'ours: upfirdn2d / blur (+ epilogue)'
     if 'bias_act' in n: return 'ours: bias_act'
