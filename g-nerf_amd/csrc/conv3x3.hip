@@ -72,6 +72,7 @@ struct ConvArgs {
     int tiles_x, tiles_y, n_tiles;
     int out_h, out_w;           // transposed form: 2 h + 1, 2 w + 1 (the convolution: h, w)
     int round_noise;
+    int phase_jobs;             // transposed form: 1 = a workgroup computes ONE phase of its position tile (blockIdx.z), 0 = all four
     float alpha, gain, clamp;
 };
 
@@ -119,8 +120,12 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     // (round 6: the four phases are a ROLLED loop -- the taps of a phase, their shifts and the step counters below are scalar run-time
     //  values.  Unrolled, every phase had its own copy of the main loop and the epilogue, and the values the compiler hoisted across
     //  them cost the transposed form 34 spilled registers and 92 bytes of scratch per lane.)
+    // phase_jobs (round 6): launches that do not fill the chip's 512 workgroup slots with whole position tiles -- the backbone's x2 layers from
+    // 32^2 and 64^2 are 160 and 216 jobs -- run one phase per workgroup instead (blockIdx.z, the slowest grid index: the four-tap phase's jobs are
+    // dispatched first and round-robin over the XCDs): four times the workgroups for the same work, jobs of 4 : 2 : 2 : 1 length
+    const int ph_first = (MODE == 1 && a.phase_jobs) ? int(blockIdx.z) : 0, ph_end = MODE == 1 ? (a.phase_jobs ? ph_first + 1 : 4) : 1;
 #pragma nounroll
-    for (int ph = 0; ph < (MODE == 1 ? 4 : 1); ph++) {
+    for (int ph = ph_first; ph < ph_end; ph++) {
     const int ph_y = ph >> 1, ph_x = ph & 1;                            // (py, px)
     const int n_taps = MODE == 1 ? (2 - ph_y) * (2 - ph_x) : 9;
     const int tap_base = MODE == 1 ? (ph == 0 ? 0 : ph == 1 ? 4 : ph == 2 ? 6 : 8) : 0;
@@ -336,8 +341,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
         }
 #pragma unroll
         for (int pb = 0; pb < 4; pb++) {
-            const int prow = 2 * wv + (pb >> 1), pcol = (pb & 1) * 16 + r;
-            const int p = prow * kTW + pcol;
+            const int prow = 2 * wv + (pb >> 1);                      // (the pixel: row prow, column (pb & 1) * 16 + r of the tile)
             unsigned words[2];
             float full[4];
 #pragma unroll
@@ -524,7 +528,7 @@ int launch_conv3x3(const char* what, const void* x, const void* w_packed, void* 
     a.cin_pad = (cin + kCK - 1) / kCK * kCK;
     a.tiles_x = w / kTW; a.tiles_y = h / kTH; a.n_tiles = n * a.tiles_x * a.tiles_y;
     a.out_h = h; a.out_w = w;
-    a.round_noise = round_noise; a.alpha = alpha; a.gain = gain; a.clamp = clamp;
+    a.round_noise = round_noise; a.alpha = alpha; a.gain = gain; a.clamp = clamp; a.phase_jobs = 0;
     const dim3 grid((a.n_tiles + kNumXCD - 1) / kNumXCD * kNumXCD, cout / kCO), block(kConvThreads);
     hipStream_t s = as_stream(stream);
 #define GNERF_CONV(SC, NZ, NX) do { \
@@ -568,7 +572,8 @@ int launch_conv_transpose(const char* what, const void* x, const void* w_phases,
     a.n_tiles = int(jobs);
     a.out_h = 2 * h + 1; a.out_w = 2 * w + 1;
     a.round_noise = 0; a.alpha = 0.f; a.gain = 1.f; a.clamp = -1.f;
-    const dim3 grid((a.n_tiles + kNumXCD - 1) / kNumXCD * kNumXCD, cout / kCO), block(kConvThreads);
+    a.phase_jobs = (jobs * (cout / kCO) < 2 * kNumCU) ? 1 : 0;
+    const dim3 grid((a.n_tiles + kNumXCD - 1) / kNumXCD * kNumXCD, cout / kCO, a.phase_jobs ? 4 : 1), block(kConvThreads);
     static PerDeviceOnce once;
     if (int rc = once.raise_lds(conv3x3_epilogue_kernel<1, false, false, false, OUT32>, what, kConvLds)) return rc;
     hipLaunchKernelGGL((conv3x3_epilogue_kernel<1, false, false, false, OUT32>), grid, block, kConvLds, as_stream(stream), a);

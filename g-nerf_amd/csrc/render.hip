@@ -265,7 +265,7 @@ __device__ __forceinline__ void lookup_plane(v4f& acc, const float* __restrict__
 // lds.colors tiles tile0 ...
 __device__ __forceinline__ void shade(const Params& P, const Weights& w, const Scratch& lds, const float* __restrict__ planes_item,
                                       float ox, float oy, float oz, float dx, float dy, float dz,
-                                      int e0, int count, int ntiles, int tile0, int lane) {
+                                      int e0, int count, int ntiles, int tile0, int lane, const float* sig_noise = nullptr) {
     const int H = P.p.plane_h, W = P.p.plane_w;
     const int64_t plane_stride = P.plane_pitch / 4;
     const unsigned tex_q = P.tex_pitch / 16, row_q = P.row_pitch / 16;
@@ -314,7 +314,7 @@ __device__ __forceinline__ void shade(const Params& P, const Weights& w, const S
         sig += __shfl_xor(sig, 16);
         sig += __shfl_xor(sig, 32);
         sig += w.b2s;
-        if (g == 0 && 16 * t + j < count) lds.sig_e[e0 + 16 * t + j] = sig;
+        if (g == 0 && 16 * t + j < count) lds.sig_e[e0 + 16 * t + j] = sig + (sig_noise ? sig_noise[16 * t + j] : 0.f);      // renderer.py:146-147
         // ---- layer 2: O[16 x 32] = H[16 x 64] . W2^T[64 x 32]
         v4f o[2];
 #pragma unroll
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
         __syncthreads();
 
         // ---- coarse pass
-        shade(P, w, lds, planes_item, ox, oy, oz, dx, dy, dz, 0, S, P.tiles_c, 0, lane);
+        shade(P, w, lds, planes_item, ox, oy, oz, dx, dy, dz, 0, S, P.tiles_c, 0, lane, p.sigma_noise_coarse ? p.sigma_noise_coarse + ray * S : nullptr);
         if (dbg) for (int k = lane; k < S; k += 64) dbg[GNERF_DBG_SIGMA_COARSE * n_all + k] = lds.sig_e[k];
 
         float w_sum, wt_sum;
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(64, 2) void render_kernel_generic(Params P) {
             resample_fine(P, ray, lds.t_e, lds.w_s, lds.s_sig, lds.cdf, lds.t_e + fine_e0, dbg, n_all, lane, [] { __syncthreads(); });
 
             // ---- fine pass
-            shade(P, w, lds, planes_item, ox, oy, oz, dx, dy, dz, fine_e0, F, P.tiles_f, P.tiles_c, lane);
+            shade(P, w, lds, planes_item, ox, oy, oz, dx, dy, dz, fine_e0, F, P.tiles_f, P.tiles_c, lane, p.sigma_noise_fine ? p.sigma_noise_fine + ray * F : nullptr);
             if (dbg) for (int k = lane; k < F; k += 64) dbg[GNERF_DBG_SIGMA_FINE * n_all + k] = lds.sig_e[fine_e0 + k];
 
             merge_by_depth(lds.t_e, lds.sig_e, lds.rank_e, lds.s_t, lds.s_sig, S, F, fine_e0, lane);
@@ -848,6 +848,9 @@ static int fill_params(const gnerf_render_params* p, Params& P) {
     if (F < 0 || F > GNERF_MAX_SAMPLES) return fail(GNERF_E_ARG, "render: depth_resolution_importance %d outside [0, %d]", F, GNERF_MAX_SAMPLES);
     if (F > 0 && S < 4) return fail(GNERF_E_ARG, "render: importance sampling needs depth_resolution >= 4");
     if (F > 0 && !p->noise_fine && p->rng_mode == GNERF_RNG_TENSORS) return fail(GNERF_E_ARG, "render: noise_fine is null but depth_resolution_importance > 0");
+    if (p->sigma_noise_fine && !p->sigma_noise_coarse) return fail(GNERF_E_ARG, "render: sigma_noise_fine without sigma_noise_coarse");
+    if (p->sigma_noise_coarse && F > 0 && !p->sigma_noise_fine) return fail(GNERF_E_ARG, "render: sigma_noise_coarse is given but sigma_noise_fine is null with depth_resolution_importance > 0");
+    if (p->sigma_noise_coarse && (own_rays || p->rng_mode != GNERF_RNG_TENSORS)) return fail(GNERF_E_UNSUPPORTED, "render: density noise comes with ray and noise tensors (not with in-kernel rays / draws)");
     if (p->rays_per_item < 1) return fail(GNERF_E_ARG, "render: rays_per_item must be positive");
     if ((p->ray_start_per_ray == nullptr) != (p->ray_end_per_ray == nullptr)) return fail(GNERF_E_ARG, "render: per-ray start and end must be given together");
     const int64_t total = int64_t(p->n_items) * p->rays_per_item;
@@ -970,7 +973,7 @@ extern "C" int gnerf_render_forward(const gnerf_render_params* p, gnerf_stream_t
         const size_t lds_bytes = pipe_lds_floats(pipe_tp, mlp, gen) * sizeof(float);
         const dim3 gd((unsigned)g), bd(kPipeThreads);
         // the instantiation with compile-time sample counts (render_pipe_body<.., FULL>) where the call fills the slots exactly
-        bool full = S == 48 * pipe_tp && F == 48 * pipe_tp && !p->disparity_space_sampling && !p->ray_start_per_ray && !p->debug;
+        bool full = S == 48 * pipe_tp && F == 48 * pipe_tp && !p->disparity_space_sampling && !p->ray_start_per_ray && !p->debug && !p->sigma_noise_coarse;
 #ifdef GNERF_STAMPS
         full = full || (S == 48 * pipe_tp && F == 48 * pipe_tp && !p->disparity_space_sampling && !p->ray_start_per_ray);     // the timing build's `debug` is its stamp buffer
 #endif
@@ -1040,6 +1043,7 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
     if (!g) return fail(GNERF_E_ARG, "render_backward: grads is null");
     if (p->planes_shared) return fail(GNERF_E_UNSUPPORTED, "render_backward: planes_shared is a forward-only option");
     if (!p->ray_origins || p->rng_mode != GNERF_RNG_TENSORS) return fail(GNERF_E_UNSUPPORTED, "render_backward: in-kernel rays / draws are forward-only options");
+    if (p->sigma_noise_coarse || p->sigma_noise_fine) return fail(GNERF_E_UNSUPPORTED, "render_backward: density noise is a forward-only option");
     const int n_dec = (g->grad_w1 != nullptr) + (g->grad_b1 != nullptr) + (g->grad_w2 != nullptr) + (g->grad_b2 != nullptr);
     if (n_dec != 0 && n_dec != 4) return fail(GNERF_E_ARG, "render_backward: the four decoder gradients are given together or not at all");
     if (!g->grad_planes_nhwc && n_dec == 0) return GNERF_OK;

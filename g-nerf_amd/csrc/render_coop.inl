@@ -294,6 +294,7 @@ __device__ __forceinline__ float row_total(float v) {
 // one ds_read_b128 (render_pipe.inl: kMiscUV).  Same operations on the same operands: bit-identical.
 struct CoopRay {
     const char* planes_item;    // uniform
+    const float* sig_noise = nullptr;   // uniform: this ray's and this pass's density noise (gnerf_render_params.sigma_noise_*), or null
     float ou, du, ov, dv;       // per lane (by plane)
     __device__ __forceinline__ void set(float ox, float oy, float oz, float dx, float dy, float dz, int lane) {
         const int pl = lane >> 4;
@@ -650,7 +651,10 @@ __device__ __forceinline__ void coop_shade_tile(const Params& P, const CoopLds& 
     }
     }
     sig = row_sum4(sig) + L.b2[0];
-    if (active && g == 0 && 16 * tile + j < count) sig_list[16 * tile + j] = sig;
+    if (active && g == 0 && 16 * tile + j < count) {
+        if (R.sig_noise) sig += R.sig_noise[16 * tile + j];           // renderer.py:146-147 (wave-uniform; never set in the compile-time-count instantiations)
+        sig_list[16 * tile + j] = sig;
+    }
     // rgb = sigmoid(o) * 1.002 - 0.001 (triplane.py:134), again in 4-wide groups
 #pragma unroll
     for (int n = 0; n < 2; n++) {
@@ -761,6 +765,7 @@ __device__ __forceinline__ void render_coop_body(const Params& P, float* smem, b
 #pragma unroll
         for (int i = 0; i < TC1; i++) {
             const int t = wv + kCoopWaves * i;
+            R.sig_noise = p.sigma_noise_coarse ? p.sigma_noise_coarse + ray * S : nullptr;
             coop_shade_tile<true, MLP>(P, L, R, L.t_e, S, t, t < P.tiles_c, L.sig_e, lane, wv, col_c[i], st, sp_direct);
         }
         __syncthreads();
@@ -818,6 +823,7 @@ __device__ __forceinline__ void render_coop_body(const Params& P, float* smem, b
 #pragma unroll
             for (int i = 0; i < TF1; i++) {
                 const int t = wv + kCoopWaves * i;
+                R.sig_noise = p.sigma_noise_fine ? p.sigma_noise_fine + ray * F : nullptr;
                 coop_shade_tile<true, MLP>(P, L, R, L.t_e + fine_e0, F, t, t < P.tiles_f, L.sig_e + fine_e0, lane, wv, col_f[i], st, sp_direct);
             }
             __syncthreads();

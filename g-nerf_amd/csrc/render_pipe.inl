@@ -70,7 +70,9 @@ __device__ __forceinline__ PipeSlot pipe_slot(float* base, int slot) {
 __host__ __device__ inline size_t pipe_lds_floats(int tp, int mlp, bool gen = false) {
     const size_t slot_floats = tp == 1 ? PipeDims<1>::kSlotFloats : (tp == 2 ? PipeDims<2>::kSlotFloats : PipeDims<3>::kSlotFloats);
     return size_t(weight_floats(mlp)) + 64 + 36 + size_t(kPipeSlots) * slot_floats + 3 * 16 * kStagePitch       // (tap records live in the staging rows)
-           + (gen ? kPipeUnit * 8 : 0);                                                                            // GEN: the dealing unit's rays
+           + kPipeUnit * 8                                                                                         // GEN: the dealing unit's rays
+           + 4;                                                                                                    // GNERF_PIPE_FLAGS: the four progress counters
+    (void)gen;
 }
 
 // position `seq` of the locality-ordered ray sequence -> ray index (or -1 past the end)
@@ -96,6 +98,15 @@ __device__ __forceinline__ int pipe_seq_to_ray(const Params& P, int64_t seq) {
 #endif
 #ifndef GNERF_PIPE_ROTATE
 #define GNERF_PIPE_ROTATE 1
+#endif
+// GNERF_PIPE_FLAGS (round 6 experiment): the step barriers as role-to-role hand-offs through four LDS counters instead of s_barrier.
+// A half-step of a shader wave depends on the SCALAR wave's previous half-step only (depth proposals, importance depths, colour weights),
+// and the scalar wave's on all three shader waves' previous one (densities, colour partials); the three shader waves never exchange
+// anything.  s_barrier makes each of them wait for the slowest of the three every half-step (stamps: 11 % of a shader wave's time);
+// with counters a shader wave that is done goes on as soon as the scalar wave has finished its part -- which it has, it is the one
+// that waits (38 % of its time) -- so the three SIMDs' different loads average out over two half-steps instead of none.
+#ifndef GNERF_PIPE_FLAGS
+#define GNERF_PIPE_FLAGS 0
 #endif
 // FULL: the call fills the kernel's sample slots exactly (depth_resolution = depth_resolution_importance = 48 TP: the reference's 48+48
 // default, gen_videos.py's doubled 96+96) with plain stratified sampling (no disparity spacing, no per-ray limits) and no stage dump.
@@ -618,6 +629,10 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
         const int item = __builtin_amdgcn_readfirstlane(__float_as_int(id_item));
         R.planes_item = reinterpret_cast<const char*>(p.planes_nhwc) + int64_t(item) * P.item_bytes;
         R.ou = r_ou; R.du = r_du; R.ov = r_ov; R.dv = r_dv;
+        if constexpr (!FULL) {                                     // density noise: a cold option, like disparity sampling and per-ray limits
+            const float* const sn = fine ? p.sigma_noise_fine : p.sigma_noise_coarse;
+            R.sig_noise = sn ? sn + int64_t(ray_id) * count : nullptr;
+        }
         GNERF_STAMP(st, 0);     // ray parameters from the slot
 #pragma unroll
         for (int i = 0; i < TP; i++) {
@@ -680,6 +695,9 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
     // waves, and every step ends when it does: give it issue priority (costs the shaders little, it is mostly waiting
     // on LDS round trips).
     if (wv == 3) __builtin_amdgcn_s_setprio(GNERF_SCALAR_PRIO);
+#if GNERF_PIPE_FLAGS && GNERF_PIPE_ROTATE
+    if (tid < 4) reinterpret_cast<int*>(unit_rays + kPipeUnit * 8)[tid] = 0;
+#endif
     __syncthreads();                                            // weights are in LDS
     if (wv == 3) { propose_issue(0); propose_finish(0); }
     __syncthreads();
@@ -726,19 +744,50 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
     // three waves).  Unrolled three times, iteration k + i writes set (i + 2) % 3 and reads set i % 3: no copies.  Both roles run
     // the same number of iterations, rounded up to a multiple of three (the extra ones find no ray and only meet at the barriers).
     const int k_last = -1 + 3 * ((nr + 3 + 2) / 3) - 1;
+#if GNERF_PIPE_FLAGS
+    // progress[0..2]: half-steps the shader waves have finished; progress[3]: the scalar wave's.  One lane writes, every lane of a waiting
+    // wave reads the same word(s).  LDS operations of a wave are performed in issue order and the LDS serves one request at a time, so a
+    // counter written after a wave's data is seen after that data, and data read before a counter is written has been read by then.
+    volatile int* const progress = reinterpret_cast<volatile int*>(unit_rays + kPipeUnit * 8);
+    int my_steps = 0;
+    auto step_done_shader = [&]() {
+        my_steps++;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) progress[wv] = my_steps;
+        // go on once the scalar wave has finished the same half-step
+        while (__builtin_amdgcn_readfirstlane(progress[3]) < my_steps) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    auto step_done_scalar = [&]() {
+        my_steps++;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) progress[3] = my_steps;
+        while (true) {
+            const int a0 = progress[0], a1 = progress[1], a2 = progress[2];
+            if (__builtin_amdgcn_readfirstlane(min(a0, min(a1, a2))) >= my_steps) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+    };
+#define GNERF_STEP_SYNC_SHADER() step_done_shader()
+#define GNERF_STEP_SYNC_SCALAR() step_done_scalar()
+#else
+#define GNERF_STEP_SYNC_SHADER() __syncthreads()
+#define GNERF_STEP_SYNC_SCALAR() __syncthreads()
+#endif
     if (wv < 3) {
         v4f ca[TP][2] = {}, cb[TP][2] = {}, cd[TP][2] = {}, cf[TP][2] = {};
         bool la = false, lb = false, ld = false;
         auto iter = [&](int k, v4f (&c0)[TP][2], v4f (&c2)[TP][2], bool l0, bool& l2) {
             l2 = shade(k + 1, false, c2);
             GNERF_STAMP(st, 5);
-            __syncthreads();
+            GNERF_STEP_SYNC_SHADER();
             GNERF_STAMP(st, 6);         // barrier wait, even step
             accumulate(k - 1, l0, c0, cf);
             GNERF_STAMP(st, 10);        // colour accumulate
             shade(k, true, cf);
             GNERF_STAMP(st, 5);
-            __syncthreads();
+            GNERF_STEP_SYNC_SHADER();
             GNERF_STAMP(st, 7);         // barrier wait, odd step
         };
         for (int k = -1; k <= k_last; k += 3) {         // sets (k-1, k, k+1) = (a, b, d), then (b, d, a), then (d, a, b)
@@ -753,7 +802,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
             output(k - 2);
             GNERF_STAMP(st, 9);         // outputs
             GNERF_STAMP(st, 5);         // rounding
-            __syncthreads();
+            GNERF_STEP_SYNC_SCALAR();
             GNERF_STAMP(st, 6);         // barrier wait, even step
             propose_issue(k + 2);
             importance(k + 1);
@@ -761,10 +810,12 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
             propose_finish(k + 2);
             GNERF_STAMP(st, 12);        // depth proposals
             GNERF_STAMP(st, 5);
-            __syncthreads();
+            GNERF_STEP_SYNC_SCALAR();
             GNERF_STAMP(st, 7);         // barrier wait, odd step
         }
     }
+#undef GNERF_STEP_SYNC_SHADER
+#undef GNERF_STEP_SYNC_SCALAR
 #else
     if (wv < 3) {
         v4f cc0[TP][2] = {}, cc1[TP][2] = {}, cc2[TP][2] = {}, cf[TP][2] = {};      // coarse colours of rays k-1, k, k+1; fine colours of ray k-1

@@ -450,12 +450,13 @@ class ToRGB(nn.Module):
                 # memory, [H W, C] x [C, O] per sample with the styles folded into the small operand -- no scaling pass over x, no layout change,
                 # and bit-reproducible (MIOpen's fp32 channels_last 1x1 kernels for 512 -> 96 and 256 -> 96 are not: they differ by an ulp from
                 # call to call, tools/dbg_f32x3_det.py; the grouped per-sample form below would copy a batch back to NCHW for its reshape)
-                wmod = _per_latent(self, w, 'wmod_t', aff + (self.weight,), lambda: (self.weight.reshape(1, -1, c_in) * styles[:, None, :]).transpose(1, 2).contiguous())
-                xv = x.permute(0, 2, 3, 1).reshape(n, h * wd, c_in)
+                # [O, C] x [C, H W] per sample, the activations as the TRANSPOSED operand (their channels_last memory is [H W, C]): the result is
+                # a dense NCHW image, which is what it is added to (the block's running image, upsample2d_add_channels_last's `y`)
+                wmod = _per_latent(self, w, 'wmod', aff + (self.weight,), lambda: (self.weight.reshape(1, -1, c_in) * styles[:, None, :]).contiguous())
+                xt = x.permute(0, 2, 3, 1).reshape(n, h * wd, c_in).transpose(1, 2)
                 if self.conv_clamp is None:
-                    y = torch.baddbmm(self.bias.reshape(1, 1, -1), xv, wmod)
-                    return y.reshape(n, h, wd, -1).permute(0, 3, 1, 2)
-                x = torch.bmm(xv, wmod).reshape(n, h, wd, -1).permute(0, 3, 1, 2)
+                    return torch.baddbmm(self.bias.reshape(1, -1, 1), wmod, xt).reshape(n, -1, h, wd)
+                x = torch.bmm(wmod, xt).reshape(n, -1, h, wd)
             elif x.dtype == torch.float16 and n > 1:
                 x = F.conv2d(gnerf_hip.scale_channels(x, styles), self.weight.to(x.dtype))
             else:

@@ -51,6 +51,7 @@ class RenderParams(ctypes.Structure):
         ('cam2world', _c_p), ('intrinsics', _c_p), ('rng_mode', ctypes.c_int32), ('rng_per_item', ctypes.c_int32),
         ('rng_seed', ctypes.c_uint64), ('rng_offset_coarse', ctypes.c_uint64), ('rng_offset_fine', ctypes.c_uint64),
         ('rng_offset_item_stride', ctypes.c_uint64), ('rng_threads_coarse', ctypes.c_uint32), ('rng_threads_fine', ctypes.c_uint32),
+        ('sigma_noise_coarse', _c_p), ('sigma_noise_fine', _c_p),
     ]
 
 
@@ -1225,8 +1226,10 @@ def render_generated_supported(S, F, ray_start=0.0, ray_end=1.0, disparity_space
 def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_coarse, noise_fine, *,
                    depth_resolution, depth_resolution_importance, ray_start, ray_end, box_warp,
                    white_back=False, disparity_space_sampling=False, image_width=0, debug=False, planes_absmax=None, mlp='auto',
-                   planes_shared=False, depth_clamp_per_item=False, cameras=None, rng=None):
+                   planes_shared=False, depth_clamp_per_item=False, cameras=None, rng=None, sigma_noise=None):
     """planes_nhwc [3N,H,W,32]; decoder = (w1,b1,w2,b2) effective fp32 weights; rays [N,M,3];
+    sigma_noise = (coarse [N*M,S], fine [N*M,F] or None): density noise ALREADY multiplied by density_noise, added to the two passes'
+    densities before their ray marches (renderer.py:146-147); forward only, tensor rays and draws only.
     cameras = (cam2world [N,4,4], intrinsics [N,3,3], res) with ray_origins = ray_dirs = None: the kernel makes the rays gnerf_make_rays
     would (RaySampler.forward); rng = torch_philox_plan(...) with noise_coarse = noise_fine = None: the kernel makes the draws torch.rand
     would (both: render_generated_supported; bit-identical to the tensor forms, tests/test_gpu_parity.py).
@@ -1238,7 +1241,7 @@ def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
     with_absmax=True) returns; measured by the call itself when None -- and the decoder's weights), 'f16x3' or 'f32'.
     Returns (rgb [N,M,32], depth [N,M,1], wsum [N,M,1][, debug [N*M,8,S+F]])."""
     e = ext()
-    if e is not None and not debug and planes_nhwc.dtype == torch.float32 and planes_nhwc.is_contiguous() and cameras is None and rng is None:
+    if e is not None and not debug and planes_nhwc.dtype == torch.float32 and planes_nhwc.is_contiguous() and cameras is None and rng is None and sigma_noise is None:
         # the C++ binding: same validation and the same C ABI call, without ctypes marshalling
         def f32c(t):
             return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
@@ -1274,6 +1277,15 @@ def render_forward(planes_nhwc, n_items, decoder, ray_origins, ray_dirs, noise_c
     ws = _workspace(dev)
     p.out_rgb, p.out_depth, p.out_wsum = rgb.data_ptr(), depth.data_ptr(), wsum.data_ptr()
     p.workspace = ws.data_ptr(); p.debug = None if dbg is None else dbg.data_ptr()
+    if sigma_noise is not None:
+        sc, sf = sigma_noise
+        _require_cuda(sc, sf)
+        sc = sc.detach().to(torch.float32).contiguous()
+        sf = None if sf is None else sf.detach().to(torch.float32).contiguous()
+        if sc.numel() != n_items * m * p.depth_resolution or (p.depth_resolution_importance > 0 and (sf is None or sf.numel() != n_items * m * p.depth_resolution_importance)):
+            raise RuntimeError('render_forward: sigma_noise must be ([N*M,S], [N*M,F]) tensors')
+        p.sigma_noise_coarse, p.sigma_noise_fine = sc.data_ptr(), None if sf is None else sf.data_ptr()
+        keep = keep + (sc, sf)
     with _on_device(dev):
         code = load().gnerf_render_forward(ctypes.byref(p), _stream(planes_nhwc))
     _check(code, 'gnerf_render_forward')

@@ -208,6 +208,8 @@ def main():
     ap.add_argument('--bucket-mb', type=float, default=0.0, help='exchange the flat vector in pieces of this size (0 = one collective)')
     ap.add_argument('--force-fp32', action='store_true', help='full mode: no fp16 in the super-resolution and discriminator blocks')
     ap.add_argument('--device', default=None)
+    ap.add_argument('--marked', action='store_true', help='bracket the timed steps with the marker kernel of tools/orbit_marked.py (MARKED_SCRIPT=... tools/prof_orbit.sh: '
+                                                          'per-kernel statistics of the steps alone, warm-up excluded)')
     ap.add_argument('--solver-search', action='store_true',
                     help='torch.backends.cudnn.benchmark on, as training_loop.py:133,144 has it.  Off by default here: MIOpen then times every solver of every '
                          'forward / backward-data / backward-weights shape of G and D on first use, and the first step takes more than seven minutes')
@@ -275,12 +277,19 @@ def main():
     for _ in range(args.warmup):
         one()
     sync()
+    if args.marked and use_gpu:
+        import gnerf_hip
+        gnerf_hip.torch_rand(424242, dev, 1, 0)
+        torch.cuda.synchronize()
     timers = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         parts = one(timers)
     sync()
     elapsed = H.max_over_ranks(time.perf_counter() - t0, dev)
+    if args.marked and use_gpu:
+        gnerf_hip.torch_rand(424242, dev, 1, 0)
+        torch.cuda.synchronize()
     for m in modules:
         H.check_ddp_consistency(m)                                          # misc.py:202-213
     if rank == 0:
@@ -288,7 +297,7 @@ def main():
         for name, a, b in timers:
             phases[name] = phases.get(name, 0.0) + a.elapsed_time(b) / args.steps
         print(json.dumps({
-            'workload': what, 'n_gpus': world, 'steps': args.steps, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'workload': what, 'n_gpus': world, 'steps': args.steps, 'frames': args.steps * args.batch, 'ms_per_step': 1e3 * elapsed / args.steps,
             'images_per_s': world * args.batch * args.steps / elapsed,
             'rays_per_s': world * args.batch * args.res ** 2 * args.steps / elapsed,
             'phase_ms_rank0': {k: round(v, 3) for k, v in phases.items()},

@@ -262,9 +262,10 @@ class ImportanceRenderer(torch.nn.Module):
         if planes.device.type == 'cuda':
             fcs = _osg_decoder_weights(decoder)
             rays_need_grad = torch.is_grad_enabled() and (ray_origins.requires_grad or ray_directions.requires_grad)
+            needs_graph = torch.is_grad_enabled() and (planes.requires_grad or any(p.requires_grad for p in decoder.parameters()))
+            noisy = rendering_options.get('density_noise', 0) != 0             # renderer.py:146-147: inside the kernels for forward calls (round 6)
             if fcs is not None and not rays_need_grad and planes.ndim == 5 and planes.shape[1] == 3 and planes.shape[2] == 32 \
-                    and rendering_options.get('density_noise', 0) == 0:
-                needs_graph = torch.is_grad_enabled() and (planes.requires_grad or any(p.requires_grad for p in decoder.parameters()))
+                    and not (noisy and needs_graph):
                 if views and needs_graph:
                     # the several-views launch is forward-only: with a graph, one differentiable call per view (same draws, same order)
                     outs = [self._forward_hip(planes, fcs, ray_origins[i:i + 1], ray_directions[i:i + 1], rendering_options, differentiable=True)
@@ -274,7 +275,7 @@ class ImportanceRenderer(torch.nn.Module):
             # A GPU call that leaves the fused kernel says so, once per reason (none of these occurs in gen_videos.py / train.py)
             _warn_gpu_fallback('the decoder is not the OSGDecoder 32->64->33 MLP' if fcs is None else
                                'the rays need a gradient' if rays_need_grad else
-                               'density_noise > 0 (renderer.py:146-147)' if rendering_options.get('density_noise', 0) != 0 else
+                               'density_noise > 0 (renderer.py:146-147) under autograd: the kernels take it for forward calls only' if noisy else
                                f'planes of shape {tuple(planes.shape)} are not [N,3,32,H,W]')
         if views:
             outs = [self._forward_torch(planes, decoder, ray_origins[i:i + 1], ray_directions[i:i + 1], rendering_options)
@@ -378,7 +379,9 @@ class ImportanceRenderer(torch.nn.Module):
         cfg = dict(depth_resolution=S, depth_resolution_importance=F, box_warp=opts['box_warp'],
                    white_back=bool(opts.get('white_back', False)), disparity_space_sampling=bool(opts.get('disparity_space_sampling', False)),
                    image_width=side if side * side == M else 0)
-        if _INKERNEL_RNG and not differentiable and gnerf_hip.render_generated_supported(S, F, ray_start, ray_end, cfg['disparity_space_sampling']) \
+        dn = float(opts.get('density_noise', 0) or 0)
+        assert not (dn and differentiable)                   # forward() sends that combination to the PyTorch-op form
+        if _INKERNEL_RNG and not differentiable and not dn and gnerf_hip.render_generated_supported(S, F, ray_start, ray_end, cfg['disparity_space_sampling']) \
                 and not torch.cuda.is_current_stream_capturing():
             # the same two draws (per view: the draws of a call of its own), made by the render kernel from the generator's state.  The
             # generator moves only once the launch has been accepted: a geometry the kernel does not reproduce (a device whose CU count
@@ -398,13 +401,19 @@ class ImportanceRenderer(torch.nn.Module):
                     gnerf_hip.commit_philox_plan(plan)
                     return out
         # the reference's two draws, same shapes, same order (renderer.py:176/186/190 then :241)
+        # ... and with density_noise the two normal draws of run_model between and behind them: rand_like, randn_like (coarse), rand, randn_like (fine)
+        def draw(n):
+            c = torch.rand([n, M, S, 1], device=dev, dtype=torch.float32)
+            sc = torch.randn([n, M * S, 1], device=dev, dtype=torch.float32) if dn else None
+            f = torch.rand(n * M, F, device=dev) if F > 0 else None
+            sf = torch.randn([n, M * F, 1], device=dev, dtype=torch.float32) if (dn and F > 0) else None
+            return c, sc, f, sf
         if views:
-            draws = [(torch.rand([1, M, S, 1], device=dev, dtype=torch.float32), torch.rand(M, F, device=dev) if F > 0 else None) for _ in range(N)]
-            noise_c = torch.cat([c for c, _ in draws])
-            noise_f = torch.cat([f for _, f in draws]) if F > 0 else None
+            draws = [draw(1) for _ in range(N)]
+            noise_c, sig_c, noise_f, sig_f = (torch.cat(t) if t[0] is not None else None for t in zip(*draws))
         else:
-            noise_c = torch.rand([N, M, S, 1], device=dev, dtype=torch.float32)
-            noise_f = torch.rand(N * M, F, device=dev) if F > 0 else None
+            noise_c, sig_c, noise_f, sig_f = draw(N)
+        sigma_noise = (sig_c.reshape(N * M, S) * dn, None if sig_f is None else sig_f.reshape(N * M, F) * dn) if dn else None
         if differentiable:
             fc1, fc2 = fcs
             eff = (fc1.weight.float() * fc1.weight_gain, fc1.bias.float() * fc1.bias_gain,          # networks_stylegan2.py:121-127
@@ -414,7 +423,7 @@ class ImportanceRenderer(torch.nn.Module):
         nhwc, amax = self._planes_nhwc(planes)
         return gnerf_hip.render_forward(nhwc, N, self._decoder_cache(fcs), ray_origins.detach(), ray_directions.detach(),
                                         noise_c, noise_f, ray_start=ray_start, ray_end=ray_end, planes_absmax=amax,
-                                        planes_shared=views, depth_clamp_per_item=views, **cfg)
+                                        planes_shared=views, depth_clamp_per_item=views, sigma_noise=sigma_noise, **cfg)
 
     # ------------------------------------------------------------------ PyTorch-op path
 

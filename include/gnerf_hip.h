@@ -377,6 +377,12 @@ typedef struct gnerf_render_params {
     uint64_t rng_seed;
     uint64_t rng_offset_coarse, rng_offset_fine, rng_offset_item_stride;
     uint32_t rng_threads_coarse, rng_threads_fine;
+    /* (ABI 10) density noise (renderer.py:146-147: `sigma += randn_like(sigma) * density_noise` in run_model, i.e. once on the coarse
+       pass's densities and once on the fine pass's, before either ray march): the two tensors ALREADY multiplied by density_noise,
+       float32 [n_items * rays_per_item, depth_resolution] and [.., depth_resolution_importance], or NULL (off).  Forward only
+       (gnerf_render_backward returns GNERF_E_UNSUPPORTED); not with in-kernel rays / draws. */
+    const float* sigma_noise_coarse;
+    const float* sigma_noise_fine;
 } gnerf_render_params;
 
 #define GNERF_RNG_TENSORS      0

@@ -252,10 +252,13 @@ def importance_depths(depths_c, weights_c, noise_f, eps=1e-5):
 # Whole renderer.  renderer.py:88-140
 
 
-def render(planes, decoder, origins, dirs, options, noise_c, noise_f, stages=None):
+def render(planes, decoder, origins, dirs, options, noise_c, noise_f, stages=None, sigma_noise=None):
     """planes [N,3,C,H,W]; decoder = effective (W1,b1,W2,b2) from fold_decoder;
     origins, dirs [N,M,3]; noise_c [N,M,S] (the reference's first draw,
     rand_like([N,M,S,1])); noise_f [N*M,F] (its second draw, rand(N*M,F)).
+    sigma_noise = (coarse [N*M,S], fine [N*M,F]): the two randn_like draws of
+    run_model (renderer.py:146-147) ALREADY multiplied by options['density_noise'],
+    added to the respective pass's densities; None = density_noise off.
 
     Returns rgb [N,M,C], depth [N,M,1], weight_sum [N,M,1] like
     ImportanceRenderer.forward.  If `stages` is a dict it receives the
@@ -291,12 +294,16 @@ def render(planes, decoder, origins, dirs, options, noise_c, noise_f, stages=Non
 
     depths_c = stratified_depths(noise_c.reshape(R, S), ray_start, ray_end, disparity)
     sig_c, col_c = shade(depths_c)
+    if sigma_noise is not None:
+        sig_c = sig_c + sigma_noise[0].reshape(R, S).to(dt)                  # renderer.py:146-147, coarse run_model
     if stages is not None:
         stages.update(depths_coarse=depths_c, sigma_coarse=sig_c, colors_coarse=col_c)
     if F > 0:
         w_c, _ = march_weights(sig_c, depths_c)                              # renderer.py:118
         depths_f = importance_depths(depths_c, w_c, noise_f.reshape(R, F)).detach()    # renderer.py:198 no_grad, :211 detach
         sig_f, col_f = shade(depths_f)
+        if sigma_noise is not None:
+            sig_f = sig_f + sigma_noise[1].reshape(R, F).to(dt)              # ... and the fine one
         all_d = torch.cat([depths_c, depths_f], 1)                           # renderer.py:157-167
         all_d, order = torch.sort(all_d, dim=1, stable=True)
         all_s = torch.gather(torch.cat([sig_c, sig_f], 1), 1, order)

@@ -37,11 +37,18 @@ def _import_reference():
 
 
 class RecordNoise:
-    """Context manager recording every torch.rand_like / torch.rand result."""
+    """Context manager recording every torch.rand_like / torch.rand result (and, apart, every torch.randn_like one: the density noise
+    of renderer.py:146-147)."""
 
     def __enter__(self):
-        self.draws = []
-        self._rl, self._r = torch.rand_like, torch.rand
+        self.draws, self.normal = [], []
+        self._rl, self._r, self._nl = torch.rand_like, torch.rand, torch.randn_like
+
+        def randn_like(*a, **k):
+            t = self._nl(*a, **k)
+            self.normal.append(t.clone())
+            return t
+        torch.randn_like = randn_like
 
         def rand_like(*a, **k):
             t = self._rl(*a, **k)
@@ -57,7 +64,7 @@ class RecordNoise:
         return self
 
     def __exit__(self, *exc):
-        torch.rand_like, torch.rand = self._rl, self._r
+        torch.rand_like, torch.rand, torch.randn_like = self._rl, self._r, self._nl
 
 
 def np_(t):
@@ -129,6 +136,12 @@ def make_render_case(name, seed, N, res, S, F, plane_hw, plane_scale, extra_opts
         sigma_coarse=np_(calls[0]['sigma']).reshape(N, res * res, S),
         depths_coarse=np_(captured['march_depths'][0]).reshape(N, res * res, S),
     )
+    if opts.get('density_noise', 0) > 0:
+        # the two randn_like draws of run_model, in call order (coarse pass, fine pass), as the reference ADDS them: times density_noise
+        assert len(rec.normal) == (2 if F > 0 else 1)
+        out.update(density_noise=np.float32(opts['density_noise']), sigma_noise_coarse=np_(rec.normal[0] * opts['density_noise']).reshape(N * res * res, S))
+        if F > 0:
+            out.update(sigma_noise_fine=np_(rec.normal[1] * opts['density_noise']).reshape(N * res * res, F))
     if F > 0:
         out.update(
             noise_fine=np_(rec.draws[1]),
@@ -390,6 +403,10 @@ def main():
     sys.path.insert(0, HERE)
     if len(sys.argv) > 1 and sys.argv[1] == 'generator':          # the two slow ones alone
         return make_generator_cases()
+    # density noise (renderer.py:146-147; rendering_kwargs carries no such key in train.py / gen_videos.py: the option exists upstream)
+    make_render_case('render_dnoise.npz', seed=5, N=2, res=4, S=12, F=12, plane_hw=(12, 12), plane_scale=2.0, extra_opts=dict(density_noise=0.5))
+    if len(sys.argv) > 1 and sys.argv[1] == 'dnoise':
+        return
     make_render_case('render_s12.npz', seed=1, N=2, res=8, S=12, F=12, plane_hw=(16, 16), plane_scale=2.0)
     make_render_case('render_s48.npz', seed=2, N=1, res=4, S=48, F=48, plane_hw=(20, 24), plane_scale=1.0)
     make_render_case('render_misc.npz', seed=3, N=1, res=4, S=8, F=8, plane_hw=(8, 8), plane_scale=3.0,

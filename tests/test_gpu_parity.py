@@ -16,7 +16,7 @@ from conftest import has_gpu
 
 pytestmark = pytest.mark.gpu
 
-RENDER_CASES = ['render_s12.npz', 'render_s48.npz', 'render_misc.npz', 'render_nofine.npz']
+RENDER_CASES = ['render_s12.npz', 'render_s48.npz', 'render_misc.npz', 'render_nofine.npz', 'render_dnoise.npz']       # (the last: density noise, renderer.py:146-147)
 
 
 @pytest.fixture(scope='module')
@@ -38,6 +38,16 @@ def _fold(g):
     return R.fold_decoder(_t(g['w1']), _t(g['b1']), _t(g['w2']), _t(g['b2']), float(g['lr_mul']))
 
 
+def _decoder_module(g, dev):
+    """gnerf_harness.TriPlaneDecoder (the OSGDecoder of triplane.py:113-136) holding a fixture's raw weights."""
+    import gnerf_harness as H
+    dec = H.TriPlaneDecoder(decoder_lr_mul=float(g['lr_mul'])).to(dev).requires_grad_(False)
+    with torch.no_grad():
+        dec.net[0].weight.copy_(_t(g['w1'], dev)); dec.net[0].bias.copy_(_t(g['b1'], dev))
+        dec.net[2].weight.copy_(_t(g['w2'], dev)); dec.net[2].bias.copy_(_t(g['b2'], dev))
+    return dec
+
+
 def _hip_render(g, dev, debug=False, image_width=None):
     import gnerf_hip
     dec = [t.to(dev) for t in _fold(g)]
@@ -50,7 +60,8 @@ def _hip_render(g, dev, debug=False, image_width=None):
         depth_resolution=int(g['depth_resolution']), depth_resolution_importance=int(g['depth_resolution_importance']),
         ray_start=float(g['ray_start']), ray_end=float(g['ray_end']), box_warp=float(g['box_warp']),
         white_back=bool(g['white_back']), disparity_space_sampling=bool(g['disparity']),
-        image_width=res if image_width is None else image_width, debug=debug)
+        image_width=res if image_width is None else image_width, debug=debug,
+        sigma_noise=(_t(g['sigma_noise_coarse'], dev), _t(g['sigma_noise_fine'], dev)) if 'sigma_noise_coarse' in g else None)
 
 
 # ---------------------------------------------------------------------------- layout + rays
@@ -110,6 +121,55 @@ def test_render_golden_stage_by_stage(dev, golden, case):
     np.testing.assert_allclose(depth.cpu().numpy(), g['out_depth'], rtol=0, atol=1e-4)
     np.testing.assert_allclose(wsum.cpu().numpy(), g['out_wsum'], rtol=0, atol=1e-4)
     assert float(((rgb.cpu().numpy() - g['out_rgb']) ** 2).mean()) < 1e-8
+
+
+@pytest.mark.parametrize('kernel', ['pipe', 'coop', 'generic'])
+def test_render_density_noise_in_every_kernel(dev, golden, monkeypatch, kernel):
+    """renderer.py:146-147 (`sigma += randn_like(sigma) * density_noise` in run_model) inside the fused kernels (round 6: it used to send a
+    GPU call to the PyTorch-op form): the recorded draws of the reference-made fixture through each forward kernel, against the fixture,
+    and the drop-in class -- which must consume the generator in the reference's order: rand_like, randn_like, rand, randn_like."""
+    import gnerf_hip
+    g = golden('render_dnoise.npz')
+    monkeypatch.setenv('GNERF_RENDER_KERNEL', kernel)
+    rgb, depth, wsum = _hip_render(g, dev)
+    np.testing.assert_allclose(rgb.cpu().numpy(), g['out_rgb'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(depth.cpu().numpy(), g['out_depth'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(wsum.cpu().numpy(), g['out_wsum'], rtol=0, atol=1e-4)
+    assert float(((rgb.cpu().numpy() - g['out_rgb']) ** 2).mean()) < 1e-8
+    # without the noise the result is another one (the option is not silently dropped)
+    g0 = {k: v for k, v in g.items() if not k.startswith('sigma_noise')}
+    assert float((_hip_render(g0, dev)[0] - rgb).abs().max()) > 1e-3
+    if kernel != 'pipe':
+        return
+    # the class: no fallback warning, the reference's draw order (replayed from the recorded draws through the global generator's hooks)
+    import warnings
+    from training.volumetric_rendering.renderer import ImportanceRenderer
+    from oracle import render_ref as R
+    dec = _decoder_module(g, dev)
+    draws = [_t(g['noise_coarse'], dev).reshape(g['noise_coarse'].shape + (1,)), _t(g['sigma_noise_coarse'], dev) / float(g['density_noise']),
+             _t(g['noise_fine'], dev), _t(g['sigma_noise_fine'], dev) / float(g['density_noise'])]
+    kinds = []
+    real_rand, real_randn = torch.rand, torch.randn
+
+    def fake_rand(*a, **k):
+        kinds.append('rand')
+        return draws[len(kinds) - 1].reshape(*(a[0] if isinstance(a[0], (list, tuple)) else a))
+    def fake_randn(*a, **k):
+        kinds.append('randn')
+        return draws[len(kinds) - 1].reshape(*(a[0] if isinstance(a[0], (list, tuple)) else a))
+    monkeypatch.setattr(torch, 'rand', fake_rand)
+    monkeypatch.setattr(torch, 'randn', fake_randn)
+    opts = dict(depth_resolution=int(g['depth_resolution']), depth_resolution_importance=int(g['depth_resolution_importance']), ray_start=float(g['ray_start']),
+                ray_end=float(g['ray_end']), box_warp=float(g['box_warp']), clamp_mode='softplus', disparity_space_sampling=False, white_back=False,
+                density_noise=float(g['density_noise']))
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter('error')
+        out = ImportanceRenderer()(_t(g['planes'], dev), dec, _t(g['ray_origins'], dev), _t(g['ray_dirs'], dev), opts)
+    monkeypatch.setattr(torch, 'rand', real_rand)
+    monkeypatch.setattr(torch, 'randn', real_randn)
+    assert kinds == ['rand', 'randn', 'rand', 'randn'], kinds
+    np.testing.assert_allclose(out[0].cpu().numpy(), g['out_rgb'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out[1].cpu().numpy(), g['out_depth'], rtol=0, atol=1e-4)
 
 
 @pytest.mark.parametrize('case', RENDER_CASES[:2])
@@ -636,8 +696,8 @@ def test_pipe_kernel_instantiations_agree(dev, monkeypatch, S):
 
 
 def test_gpu_fallback_to_pytorch_ops_is_visible(dev):
-    """The three GPU calls that leave the fused kernel (rays with a gradient, density_noise > 0, a decoder that is not the OSGDecoder
-    MLP) run the PyTorch-op form -- and say so with a RuntimeWarning, once per reason (What's weak 9)."""
+    """The three GPU calls that leave the fused kernel (rays with a gradient, density_noise > 0 under autograd, a decoder that is not the
+    OSGDecoder MLP) run the PyTorch-op form -- and say so with a RuntimeWarning, once per reason (What's weak 9)."""
     import warnings
     import gnerf_harness as H
     from training.volumetric_rendering import renderer as RM
@@ -651,8 +711,12 @@ def test_gpu_fallback_to_pytorch_ops_is_visible(dev):
         warnings.simplefilter('always')
         r(planes, dec, o, d, opts)                                                  # the fused kernel: silent
         assert not [w for w in rec if issubclass(w.category, RuntimeWarning)]
-        r(planes, dec, o, d, dict(opts, density_noise=0.5))
-        r(planes, dec, o, d, dict(opts, density_noise=0.5))                         # second time: no second warning
+        r(planes, dec, o, d, dict(opts, density_noise=0.5))                         # round 6: inside the fused kernel too -- silent
+        assert not [w for w in rec if issubclass(w.category, RuntimeWarning)]
+        with torch.enable_grad():                                                   # ... unless a gradient has to flow through it (forward-only option)
+            pg = planes.clone().requires_grad_(True)
+            r(pg, dec, o, d, dict(opts, density_noise=0.5))
+            r(pg, dec, o, d, dict(opts, density_noise=0.5))                         # second time: no second warning
         r(planes, dec, o.clone().requires_grad_(True), d, opts)
 
         class Other(torch.nn.Module):

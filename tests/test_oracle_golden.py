@@ -11,7 +11,7 @@ import torch
 from oracle import render_ref as R
 from oracle import ops_ref as O
 
-RENDER_CASES = ['render_s12.npz', 'render_s48.npz', 'render_misc.npz', 'render_nofine.npz']
+RENDER_CASES = ['render_s12.npz', 'render_s48.npz', 'render_misc.npz', 'render_nofine.npz', 'render_dnoise.npz']       # (the last: density_noise = 0.5, renderer.py:146-147)
 
 
 def _t(a, dt=torch.float32):
@@ -28,8 +28,9 @@ def _run(g, dt):
     dec = R.fold_decoder(_t(g['w1'], dt), _t(g['b1'], dt), _t(g['w2'], dt), _t(g['b2'], dt), float(g['lr_mul']))
     stages = {}
     noise_f = _t(g['noise_fine'], dt) if 'noise_fine' in g else None
+    sn = (_t(g['sigma_noise_coarse'], dt), _t(g['sigma_noise_fine'], dt)) if 'sigma_noise_coarse' in g else None
     out = R.render(_t(g['planes'], dt), dec, _t(g['ray_origins'], dt), _t(g['ray_dirs'], dt), _options(g),
-                   _t(g['noise_coarse'], dt), noise_f, stages)
+                   _t(g['noise_coarse'], dt), noise_f, stages, sigma_noise=sn)
     return out, stages
 
 
