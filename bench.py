@@ -35,6 +35,8 @@ import torch  # noqa: E402
 
 # config 2 (BASELINE.json / SURVEY.md section 8d)
 N_ITEMS, RES, S_COARSE, S_FINE, PLANE = 4, 128, 48, 48, 256
+# GNERF_BENCH_FUSED_PREP=0: the step's rays and draws as three launches (gnerf_make_rays + two torch.rand), as until round 5
+FUSED_PREP = os.environ.get('GNERF_BENCH_FUSED_PREP', '1') != '0'
 RAY_START, RAY_END, BOX_WARP = 2.25, 3.3, 1.0
 
 # Algorithmic work per ray (DESIGN.md section 4 "Roofline accounting")
@@ -946,6 +948,11 @@ def main():
         if generated:
             o = d = noise_c = noise_f = None
             extra = dict(cameras=(c2w, intr, RES), rng=gnerf_hip.torch_philox_plan(dev, N_ITEMS, RES * RES, S_COARSE, S_FINE))
+        elif FUSED_PREP:
+            # round 6: the rays and the two draws in ONE launch -- gnerf_make_rays_and_draws: make_rays' rays, torch.rand's values bit for bit
+            # (tests/test_gpu_parity.py::test_make_rays_and_draws_equal_the_three_launches), the generator advanced as the two calls would
+            o, d, noise_c, noise_f = gnerf_hip.make_rays_and_draws(c2w, intr, RES, S_COARSE, S_FINE)
+            extra = {}
         else:
             o, d = gnerf_hip.make_rays(c2w, intr, RES)
             noise_c = torch.rand([N_ITEMS, RES * RES, S_COARSE, 1], device=dev)
@@ -1129,7 +1136,7 @@ def main():
                                                     'value': rays_per_call * n_long * world / long_elapsed}},
             'config': {'workload': 'config 2: 128x128 rays x (48+48) samples, 3x32x256x256 fp32 tri-planes, batch 4 per GPU; '
                                    + ('NCHW planes, repacked in every step' if headline_nchw else 'channels_last planes read in place'),
-                       'step': 'make_rays + ' + ('NCHW->NHWC repack with max|planes| + ' if headline_nchw else '') + '2 torch.rand draws + fused render kernel (device-side decoder-arithmetic choice) + depth clamp',
+                       'step': ('NCHW->NHWC repack with max|planes| + ' if headline_nchw else '') + ('make_rays and the 2 torch.rand draws in one launch (gnerf_make_rays_and_draws: torch.rand\'s values bit for bit, generator advanced alike)' if FUSED_PREP else 'make_rays + 2 torch.rand draws') + ' + fused render kernel (device-side decoder-arithmetic choice) + depth clamp',
                        'planes': nchw_name if headline_nchw else cl_name,
                        'rays_per_step_per_gpu': rays_per_call, 'parallelism': f'rays sharded over {world} GPU(s), no data-path collective',
                        'producer_layout_value' if headline_nchw else 'nchw_input_value': other_step['value'],

@@ -211,6 +211,50 @@ __global__ __launch_bounds__(256) void make_rays_kernel(const float* __restrict_
     }
 }
 
+// Round 6: what a render step needs in front of the fused kernel -- the rays of n cameras and the reference's two uniform draws (renderer.py:
+// 190 `rand_like([N,M,S,1])`, :241 `rand(N*M, F)`) -- in ONE launch instead of three (gnerf_make_rays + two torch.rand).  The draws are
+// torch.rand's, bit for bit: thread t of a draw evaluates the Philox block of (counter ctr + call, subsequence t) and stores its four words
+// at elements t + threads * (4 call + word), exactly as ATen's grid-stride kernel does (raygen.h: torch_rand_element is the per-element view of
+// the same map) -- one block per four elements, where the stand-alone gnerf_torch_rand evaluates one per element.
+__global__ __launch_bounds__(256) void rays_and_draws_kernel(const float* __restrict__ c2w, const float* __restrict__ intr, int n, int res,
+                                                             float* __restrict__ origins, float* __restrict__ dirs,
+                                                             float* __restrict__ out_a, int64_t numel_a, TorchRandDraw da, uint32_t threads_a,
+                                                             float* __restrict__ out_b, int64_t numel_b, TorchRandDraw db, uint32_t threads_b) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t m_total = int64_t(res) * res;
+    if (i < m_total * n) {
+        const int item = int(i / m_total);
+        const int m = int(i % m_total);
+        const float* M = c2w + item * 16;
+        float d[3];
+        camera_ray(M, intr + item * 9, res, m / res, m % res, d);
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            dirs[i * 3 + r] = d[r];
+            origins[i * 3 + r] = M[r * 4 + 3];
+        }
+    }
+    auto draw = [&](float* __restrict__ out, int64_t numel, const TorchRandDraw& d, uint32_t threads) {
+        if (!out || i >= int64_t(threads)) return;
+        const int64_t per_thread = (numel - i + int64_t(threads) - 1) / int64_t(threads);      // elements of this thread: i, i + threads, ...
+        for (int64_t call = 0; 4 * call < per_thread; call++) {
+            const uint64_t c = d.ctr + uint64_t(call);
+            uint32_t w[4];
+            philox4x32_10_block(uint32_t(c), uint32_t(c >> 32), uint32_t(i), 0u, d.k0, d.k1, w);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int64_t li = i + int64_t(threads) * (4 * call + k);
+                if (li < numel) {
+                    const float u = __fmaf_rn(float(w[k]), 0x1p-32f, 0x1p-32f);
+                    out[li] = u == 1.0f ? 0.0f : u;
+                }
+            }
+        }
+    };
+    draw(out_a, numel_a, da, threads_a);
+    draw(out_b, numel_b, db, threads_b);
+}
+
 // torch.rand(numel) at (seed, offset) as a stand-alone kernel: one element per lane, grid-stride free (numel <= 2^32 checked by the host)
 __global__ __launch_bounds__(256) void torch_rand_kernel(float* __restrict__ out, int64_t numel, TorchRandDraw d) {
     const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
@@ -351,6 +395,25 @@ extern "C" int gnerf_torch_rand_plan(int64_t numel, int multi_processor_count, i
     *threads = uint32_t(blocks * 256);
     *offset_increment = ((uint64_t(numel) - 1) / (uint64_t(*threads) * 4) + 1) * 4;
     return GNERF_OK;
+}
+
+extern "C" int gnerf_make_rays_and_draws(const float* cam2world, const float* intrinsics, int n, int res, float* origins, float* dirs,
+                                         float* draw_a, int64_t numel_a, uint64_t offset_a, uint32_t threads_a,
+                                         float* draw_b, int64_t numel_b, uint64_t offset_b, uint32_t threads_b, uint64_t seed, gnerf_stream_t stream) {
+    using namespace gnerf;
+    if (!cam2world || !intrinsics || !origins || !dirs) return fail(GNERF_E_ARG, "make_rays_and_draws: null pointer");
+    if (n < 1 || res < 1) return fail(GNERF_E_ARG, "make_rays_and_draws: n and res must be positive");
+    if (!draw_a || numel_a < 1 || (draw_b && numel_b < 1)) return fail(GNERF_E_ARG, "make_rays_and_draws: the first draw must be given, and a second one must not be empty");
+    TorchRandDraw da, db = TorchRandDraw{};
+    if (!torch_rand_draw(seed, offset_a, threads_a, numel_a, da) || (draw_b && !torch_rand_draw(seed, offset_b, threads_b, numel_b, db)))
+        return fail(GNERF_E_UNSUPPORTED, "make_rays_and_draws: the generator geometry (threads %u / %u at offsets %llu / %llu) is not one these kernels reproduce",
+                    threads_a, threads_b, (unsigned long long)offset_a, (unsigned long long)offset_b);
+    int64_t lanes = int64_t(n) * res * res;
+    if (int64_t(threads_a) > lanes) lanes = threads_a;
+    if (draw_b && int64_t(threads_b) > lanes) lanes = threads_b;
+    hipLaunchKernelGGL(rays_and_draws_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, as_stream(stream), cam2world, intrinsics, n, res, origins, dirs,
+                       draw_a, numel_a, da, threads_a, draw_b, draw_b ? numel_b : 0, db, draw_b ? threads_b : 0u);
+    return check_launch("make_rays_and_draws");
 }
 
 extern "C" int gnerf_torch_rand(float* out, int64_t numel, uint64_t seed, uint64_t offset, uint32_t threads, gnerf_stream_t stream) {

@@ -50,6 +50,18 @@ __device__ __forceinline__ uint32_t philox4x32_10_word(uint32_t c0, uint32_t c1,
     return pick == 0 ? c0 : (pick == 1 ? c1 : (pick == 2 ? c2 : c3));
 }
 
+// The whole block (the four output words of one counter value): what one thread of ATen's kernel computes per call
+__device__ __forceinline__ void philox4x32_10_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int round = 0; round < 10; round++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
 // One draw of `torch.rand(numel, device)` with the device generator at (seed, philox offset): launch-uniform description.
 // ctr = offset / 4 (the generator hands out offsets in multiples of four 32-bit words); threads = ATen's grid size in threads,
 // either a power of two (log2 in `shift`) or >= numel (`shift` = 63: every element is its own thread's first word).

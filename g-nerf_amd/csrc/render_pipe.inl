@@ -616,13 +616,15 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
         PipeSlot sl = pipe_slot<TP>(slots, r & (kPipeSlots - 1));
         const float* t_list = fine ? sl.t_e + fine_e0 : sl.t_e;
         const int count = fine ? F : S;
-        const v4f uv = *reinterpret_cast<const v4f*>(sl.misc + 4 * min(lane >> 4, 2));        // this lane's plane: (ou, du, ov, dv)
-        const float2 ids = *reinterpret_cast<const float2*>(sl.misc + kMiscItem);
+        typedef float v2f_t __attribute__((ext_vector_type(2)));
+        v4f uv = *reinterpret_cast<const v4f*>(sl.misc + 4 * min(lane >> 4, 2));              // this lane's plane: (ou, du, ov, dv)
+        v2f_t ids = *reinterpret_cast<const v2f_t*>(sl.misc + kMiscItem);
         float depth0 = t_list[min(16 * wv + (lane & 15), count - 1)];                // tile wv (the first of this wave's tiles)
-        float id_item = ids.x, id_ray = ids.y, r_ou = uv[0], r_du = uv[1], r_ov = uv[2], r_dv = uv[3];
         // (all three reads leave together, in front of the branch on the ray id: left alone the compiler sinks the ray's words behind that
-        //  branch and the item's word behind the next -- three dependent LDS round trips at the head of every tile)
-        asm volatile("" : "+v"(id_item), "+v"(id_ray), "+v"(r_ou), "+v"(r_du), "+v"(r_ov), "+v"(r_dv), "+v"(depth0));
+        //  branch and the item's word behind the next -- three dependent LDS round trips at the head of every tile.  The operands are the
+        //  loaded register tuples themselves: as seven scalars the pin cost three v_mov_b32 per tile)
+        asm volatile("" : "+v"(uv), "+v"(ids), "+v"(depth0));
+        const float id_item = ids[0], id_ray = ids[1], r_ou = uv[0], r_du = uv[1], r_ov = uv[2], r_dv = uv[3];
         const int ray_id = __builtin_amdgcn_readfirstlane(__float_as_int(id_ray));
         if (ray_id < 0) return false;
         CoopRay R;

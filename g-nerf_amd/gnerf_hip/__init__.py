@@ -104,6 +104,8 @@ SIGNATURES = {
     'gnerf_conv3x3_epilogue_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_p, _c_f, _c_f, _c_f, _c_p, _c_p]),
     'gnerf_conv_transpose3x3_s2_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_split_f16x3_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
+    'gnerf_make_rays_and_draws': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_p, _c_p, _c_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32,
+                                         _c_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, _c_p]),
     'gnerf_conv3x3_f32x3_epilogue_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_p, _c_p]),
     'gnerf_conv_transpose3x3_s2_f32x3_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),
     'gnerf_upsample2x_add_nhwc': (_c_i, [_c_p, _c_p, ctypes.POINTER(_c_f), _c_i, _c_f, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p]),
@@ -530,6 +532,34 @@ def make_rays(cam2world, intrinsics, resolution):
         code = load().gnerf_make_rays(_ptr(c2w), _ptr(k), n, int(resolution), _ptr(o), _ptr(d), _stream(c2w))
     _check(code, 'gnerf_make_rays')
     return o, d
+
+
+@profiled('gnerf_hip::make_rays_and_draws')
+def make_rays_and_draws(cam2world, intrinsics, resolution, S, F, generator=None):
+    """make_rays(cam2world, intrinsics, resolution) AND the renderer's two uniform draws -- torch.rand([N,M,S,1]) then torch.rand(N*M, F)
+    (renderer.py:190,241) -- in ONE launch (gnerf_make_rays_and_draws).  The draws are the device generator's: the values torch.rand would
+    have returned, bit for bit, and the generator is left where those two calls would have left it (torch_philox_plan).  Returns
+    (origins [N,M,3], dirs [N,M,3], noise_coarse [N,M,S,1], noise_fine [N*M,F] or None).  Not inside a graph capture (the generator's
+    offset lives on the device then): the caller draws with torch.rand."""
+    _require_cuda(cam2world, intrinsics)
+    c2w = cam2world.to(torch.float32).contiguous()
+    k = intrinsics.to(torch.float32).contiguous()
+    n, dev = c2w.shape[0], c2w.device
+    if c2w.shape != (n, 4, 4) or k.shape != (n, 3, 3):
+        raise RuntimeError('make_rays_and_draws: expected cam2world [N,4,4] and intrinsics [N,3,3]')
+    m = int(resolution) * int(resolution)
+    plan = torch_philox_plan(dev, n, m, int(S), int(F), generator=generator, advance=False)
+    o = torch.empty([n, m, 3], dtype=torch.float32, device=dev)
+    d = torch.empty_like(o)
+    nc = torch.empty([n, m, int(S), 1], dtype=torch.float32, device=dev)
+    nf = torch.empty([n * m, int(F)], dtype=torch.float32, device=dev) if F > 0 else None
+    with _on_device(dev):
+        code = load().gnerf_make_rays_and_draws(_ptr(c2w), _ptr(k), n, int(resolution), _ptr(o), _ptr(d),
+                                                _ptr(nc), nc.numel(), plan.offset_coarse, plan.threads_coarse,
+                                                _ptr(nf), 0 if nf is None else nf.numel(), plan.offset_fine, plan.threads_fine, plan.seed, _stream(c2w))
+    _check(code, 'gnerf_make_rays_and_draws')
+    commit_philox_plan(plan)
+    return o, d, nc, nf
 
 
 _workspaces = {}

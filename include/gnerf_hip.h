@@ -396,6 +396,13 @@ int gnerf_torch_rand_plan(int64_t numel, int multi_processor_count, int max_thre
 /* The draw itself as a stand-alone kernel: out[i] = element i of torch.rand(numel) at (seed, offset) -- the same device function the
  * render kernels use, exposed so that it can be held to torch.rand directly (tests) and for callers that want tensors. */
 int gnerf_torch_rand(float* out, int64_t numel, uint64_t seed, uint64_t offset, uint32_t threads, gnerf_stream_t stream);
+/* (ABI 10) The rays of gnerf_make_rays AND the renderer's two uniform draws in one launch: draw_a / draw_b = what torch.rand(numel_a) then
+ * torch.rand(numel_b) return with the device generator at seed and philox offsets offset_a / offset_b (threads_* from gnerf_torch_rand_plan;
+ * the caller advances its generator by the two increments, as for gnerf_render_params.rng_mode).  draw_b may be NULL.  One Philox block per
+ * four elements, ATen's own thread-to-element map: the same values as gnerf_torch_rand, i.e. as torch.rand, bit for bit. */
+int gnerf_make_rays_and_draws(const float* cam2world, const float* intrinsics, int n, int res, float* origins, float* dirs,
+                              float* draw_a, int64_t numel_a, uint64_t offset_a, uint32_t threads_a,
+                              float* draw_b, int64_t numel_b, uint64_t offset_b, uint32_t threads_b, uint64_t seed, gnerf_stream_t stream);
 
 #define GNERF_MLP_AUTO  0
 #define GNERF_MLP_F16X3 1

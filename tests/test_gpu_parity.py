@@ -734,6 +734,30 @@ def test_gpu_fallback_to_pytorch_ops_is_visible(dev):
 _RAND_CASES = [(0, (7,)), (123, (1000,)), (5, (4, 16384, 48, 1)), (5, (65536, 48)), (2 ** 40 + 17, (3, 333, 12)), (9, (1, 4096, 96, 1)), (11, (524288 + 3,))]
 
 
+def test_make_rays_and_draws_equal_the_three_launches(dev):
+    """gnerf_make_rays_and_draws (round 6: what bench.py's step runs in front of the render kernel): the rays of gnerf_make_rays and the two
+    draws of torch.rand -- same values bit for bit, same generator offset afterwards -- from ONE launch; several sizes, a seed with high
+    bits, a draw smaller than ATen's grid and one many times larger."""
+    import gnerf_hip
+    import gnerf_harness as H
+    for seed, n, res, S, F in [(0, 4, 128, 48, 48), (2 ** 40 + 17, 2, 16, 12, 12), (7, 1, 8, 8, 0), (3, 3, 64, 96, 96), (11, 1, 5, 5, 3)]:
+        c2w = torch.cat([H.orbit_pose(3 + 5 * i, 120) for i in range(n)]).to(dev)
+        intr = torch.tensor(H.FFHQ_INTRINSICS, device=dev).reshape(1, 3, 3).repeat(n, 1, 1)
+        torch.cuda.manual_seed(seed)
+        torch.rand(5, device=dev)                                              # (an offset that is not zero)
+        state = torch.cuda.get_rng_state(dev)
+        o0, d0 = gnerf_hip.make_rays(c2w, intr, res)
+        a0 = torch.rand([n, res * res, S, 1], device=dev)
+        b0 = torch.rand(n * res * res, F, device=dev) if F > 0 else None
+        after = int(torch.cuda.default_generators[dev.index].get_offset())
+        tail0 = torch.rand(3, device=dev)
+        torch.cuda.set_rng_state(state, dev)
+        o1, d1, a1, b1 = gnerf_hip.make_rays_and_draws(c2w, intr, res, S, F)
+        assert int(torch.cuda.default_generators[dev.index].get_offset()) == after
+        assert torch.equal(o0, o1) and torch.equal(d0, d1) and torch.equal(a0, a1) and (b0 is None) == (b1 is None) and (b0 is None or torch.equal(b0, b1))
+        assert torch.equal(torch.rand(3, device=dev), tail0)                   # the stream of draws goes on as if torch.rand had been called
+
+
 def test_philox_restatement_matches_torch_rand(dev):
     """oracle/philox_ref.py -- ATen's uniform kernel over Philox4x32-10, restated in numpy -- against the device generator itself:
     every element of two consecutive torch.rand draws, and the generator's offset after each.  This is the pin of the restatement
@@ -1800,6 +1824,18 @@ def test_conv_transpose3x3_s2_vs_framework(dev):
         top = float(ref.abs().max())
         e_got, e_want = float((got.float() - ref).abs().max()), float((want.float() - ref).abs().max())
         assert e_got <= max(1.5 * e_want, 2e-3 * top), (n, cin, cout, h, w, e_got, e_want, top)
+    # the HOT shape at full size (round 6): block1.conv0 of the superresolution at a batch of four, 256 -> 128 from 256^2 to 513^2 -- every
+    # 64th output pixel against the fp32 product of the same fp16 operands (the whole tensor is 2 x 135 M values; the rest must be finite)
+    g = torch.Generator(device='cpu').manual_seed(11)
+    x = (torch.randn(4, 256, 256, 256, generator=g) * 0.5).to(dev).half().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(128, 256, 3, 3, generator=g) / (2 * 256 ** 0.5)).to(dev)
+    got = gnerf_hip.conv_transpose3x3_s2(x, gnerf_hip.pack_conv_transpose3x3_weights(wt))
+    assert got.shape == (4, 128, 513, 513) and bool(torch.isfinite(got).all())
+    ref = F.conv_transpose2d(x.float(), wt.half().float().transpose(0, 1), stride=2)[:, :, 3::8, 5::8]
+    want = F.conv_transpose2d(x, wt.half().transpose(0, 1).contiguous(memory_format=torch.channels_last), stride=2)[:, :, 3::8, 5::8]
+    e_got, e_want = float((got[:, :, 3::8, 5::8].float() - ref).abs().max()), float((want.float() - ref).abs().max())
+    assert e_got <= max(1.5 * e_want, 2e-3 * float(ref.abs().max())), (e_got, e_want)
+    del x, got, ref, want
     bad = torch.zeros(1, 64, 8, 32, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
     assert not gnerf_hip.conv_transpose3x3_s2_supported(bad, 64)                          # output channels come in blocks of 128
     with pytest.raises(RuntimeError):
@@ -1847,6 +1883,22 @@ def test_conv3x3_epilogue_vs_composed_ops(dev):
                         # two-launch form is NOT required (it was the round-5 criterion); the two only have to agree to the latter's error.
                         assert e_got <= e_want and e_got <= 1.2e-3 * top, (n, cin, cout, scale is not None, nz is not None, nxt is not None, clamp, e_got, e_want, top)
                         assert float((got.float() - want.float()).abs().max()) <= 6e-3 * top
+    # the HOT shape at full size (round 6): block1.conv1 of the superresolution at a batch of four, 128 -> 128 @ 512^2, with everything the
+    # layer's epilogue does -- every 64th pixel against the fp32 chain on the same fp16 operands, the rest finite
+    x = (torch.randn(4, 128, 512, 512, generator=gen) * 0.7).to(dev).half().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(128, 128, 3, 3, generator=gen) / (3 * 128 ** 0.5)).to(dev)
+    w16 = wt.half().contiguous(memory_format=torch.channels_last)
+    sc, nx = (torch.rand(4, 128, generator=gen) + 0.5).to(dev), (torch.rand(4, 128, generator=gen) + 0.5).to(dev)
+    bias, noise = (torch.randn(128, generator=gen) * 0.2).to(dev), (torch.randn(512, 512, generator=gen) * 0.1).to(dev)
+    kw = dict(scale=sc, noise=noise, round_noise=True, gain=2 ** 0.5, clamp=256.0, next_scale=nx)
+    got = gnerf_hip.conv3x3_epilogue(x, gnerf_hip.pack_conv3x3_weights(wt), bias, **kw)
+    assert got.shape == (4, 128, 512, 512) and bool(torch.isfinite(got).all())
+    y32 = torch.nn.functional.conv2d(x.float(), w16.float(), padding=1)[:, :, 3::8, 5::8]
+    ref = bias_act.bias_act(y32 * sc[:, :, None, None] + noise[3::8, 5::8], bias, act='lrelu', gain=2 ** 0.5, clamp=256.0) * nx[:, :, None, None]
+    want = gnerf_hip.modconv_epilogue(torch.nn.functional.conv2d(x, w16, padding=1), bias, act='lrelu', **kw)[:, :, 3::8, 5::8]
+    e_got, e_want = float((got[:, :, 3::8, 5::8].float() - ref).abs().max()), float((want.float() - ref).abs().max())
+    assert e_got <= e_want and e_got <= 1.2e-3 * float(ref.abs().max()), (e_got, e_want)
+    del x, got, y32, ref, want
     # shapes the kernel does not tile are refused, not approximated
     bad = torch.zeros(1, 64, 8, 24, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
     assert not gnerf_hip.conv3x3_epilogue_supported(bad, 128)                             # widths come in tiles of 32

@@ -52,10 +52,17 @@ for (n, cin, cout, h, w) in SHAPES:
         torch.cuda.synchronize()
         assert b.shape == a.shape and gnerf_hip.is_channels_last(b)
         err = float((a.float() - b.float()).abs().max()); ref = float(a.float().abs().max())
-        # against an fp32 convolution of the same fp16 inputs (the arbiter between the two fp16 results)
+        # against the whole chain in fp32 on the same fp16 operands (the arbiter between the two fp16 results; round 6: the fused form rounds
+        # once, at the output, the two-launch form three times on the way)
         y32 = F.conv2d(x.float(), w16.float(), padding=1)
+        t32 = y32 * (kw['scale'][:, :, None, None] if 'scale' in kw else 1.0) + (kw['noise'] if 'noise' in kw else 0.0)
+        t32 = t32 + bias.half().float()[None, :, None, None]
+        ref32 = (torch.nn.functional.leaky_relu(t32, 0.2) * 2 ** 0.5).clamp(-256.0, 256.0) * (kw['next_scale'][:, :, None, None] if 'next_scale' in kw else 1.0)
         row[name] = {'max_abs_diff': err, 'max_abs_ref': ref, 'mismatch_frac_above_2ulp': float(((a.float() - b.float()).abs() > 2 ** -9 * a.float().abs().clamp_min(2 ** -6)).float().mean()),
-                     'conv_err_fused_vs_fp32': None, 'conv_err_miopen_vs_fp32': float((F.conv2d(x, w16, padding=1).float() - y32).abs().max())}
+                     'chain_err_fused_vs_fp32': float((b.float() - ref32).abs().max()), 'chain_err_two_launch_vs_fp32': float((a.float() - ref32).abs().max()),
+                     'conv_err_fused_vs_fp32': float((gnerf_hip.conv3x3_epilogue(x, wpk, alpha=1.0).float() - y32).abs().max()),
+                     'conv_err_miopen_vs_fp32': float((F.conv2d(x, w16, padding=1).float() - y32).abs().max())}
+        del y32, t32, ref32
     t_conv = timeit(lambda: F.conv2d(x, w16, padding=1), args.reps)
     y_tmp = F.conv2d(x, w16, padding=1)
     t_epi = timeit(lambda: gnerf_hip.modconv_epilogue(y_tmp, bias.half(), scale=dco, next_scale=nxt, act='lrelu', gain=2 ** 0.5, clamp=256.0), args.reps)

@@ -6,7 +6,7 @@
 # Results land in gpurun_out/profiles/ and gpurun_out/$RND/ (copied into profiles/ afterwards).  RND defaults to r05.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
-export RND=${RND:-r05}
+export RND=${RND:-r06}
 part=${1:-a}
 mkdir -p gpurun_out/profiles gpurun_out/$RND
 case $part in
