@@ -10,9 +10,9 @@
 // epilogue in registers (the same device function as the stand-alone pass, csrc/common.h: same roundings, in the same order) and
 // leave as fp16 channels_last.
 //
-// Decomposition.  A workgroup (4 waves; 77.5 KB of LDS and 256 registers per lane, so TWO workgroups share a CU: two waves per SIMD, and
-// one workgroup's barriers, input-tile loads and epilogue hide under the other's MFMAs) computes an 8 x 32 tile of output pixels for 128
-// output channels.  The 10 x 34 input pixels the tile's nine taps touch are staged once per 64 input channels (43.5 KB; image borders
+// Decomposition.  A workgroup (round 6: 8 waves, <= 128 registers per lane, 76.5 KB of LDS, so TWO workgroups share a CU: FOUR waves per
+// SIMD, and one workgroup's barriers, input-tile loads and epilogue hide under the other's MFMAs; rounds 5: 4 waves with 256 registers,
+// GNERF_CONV_WAVES=4) computes an 8 x 32 tile of output pixels for 128 output channels.  The 10 x 34 input pixels the tile's nine taps touch are staged once per 64 input channels (43.5 KB; image borders
 // come in as zeros from the buffer load's range check) and every tap reads them at a shifted position; the weights of one (tap, 64
 // input channels) -- 16 KB -- stream through a double buffer while the previous tap is being multiplied.  Both are filled by LDS-DMA
 // (buffer_load / global_load ... lds: no registers, no ds_write), whose LDS image is lane-linear, so the bank swizzle is applied to
@@ -27,7 +27,8 @@
 // SIMD's, and no hand-built pipeline beat two independent workgroups.)
 // Orientation: A = weights (M = 16 output channels), B = input (N = 16 pixels of a row), K = 32 input channels per instruction; a lane's
 // four accumulator registers are then four CONSECUTIVE output channels of one pixel -- an 8-byte piece of the channels_last result.
-// A wave owns two rows of the tile: 64 pixels x 128 channels = 128 accumulator registers, 32 MFMAs per 12 ds_read_b128.
+// A wave owns two rows of the tile and 64 of the 128 channels: 64 accumulator registers, 16 MFMAs per 8 ds_read_b128 (GNERF_CONV_WAVES=4: two
+// rows x 128 channels, 128 accumulator registers, 32 MFMAs per 12 ds_read_b128, fragment reads software-pipelined among the MFMAs).
 
 #include "common.h"
 #include <type_traits>
@@ -44,13 +45,40 @@ constexpr int kTH = 8, kTW = 32;                    // output pixels of a tile
 constexpr int kIH = kTH + 2, kIW = kTW + 2;         // input pixels incl. the one-pixel halo
 constexpr int kCK = 64;                             // input channels resident in LDS (a chunk)
 constexpr int kCO = 128;                            // output channels per workgroup
-constexpr int kConvThreads = 256;
+// GNERF_CONV_WAVES: waves of a workgroup.  4 (round 5): a wave owns two rows of the tile -- 128 accumulator registers, fragments double-buffered
+// and read among the previous k-step's MFMAs, 252 registers: two waves per SIMD.  8 (round 6, shipped): 64 accumulator registers per wave,
+// fragments single-buffered, <= 128 registers: FOUR waves per SIMD on the same 76 KB of LDS per workgroup, the latency hiding left to the
+// hardware's wave scheduler instead of the hand-built pipeline.  In-kernel clock stamps (tools/conv_clock.py, profiles/r06_conv_clock.jsonl):
+// 7-9 % fewer cycles than the four-wave form, of which the chip's power management takes most back as a lower clock (1.98 -> 1.85 GHz on
+// random operands); wall time -1.5 % (plain) ... -9 % (transposed, fp32-grade at small sizes).
+#ifndef GNERF_CONV_WAVES
+#define GNERF_CONV_WAVES 8
+#endif
+// GNERF_CONV_COSPLIT (with eight waves): 1 = a wave owns one tile row x 128 output channels (8 weight + 2 pixel fragments per 16 MFMAs), 2
+// (shipped) = two rows x 64 output channels (4 + 4 fragments per 16 MFMAs: a fifth fewer LDS bytes for the same matrix work; 1-2 % faster).
+// GNERF_CONV_COUNTED_WAITS=1 (a pair of channel blocks starts when its own fragments have landed): measured, no gain, off.
+#ifndef GNERF_CONV_COSPLIT
+#define GNERF_CONV_COSPLIT (GNERF_CONV_WAVES == 8 ? 2 : 1)
+#endif
+#ifndef GNERF_CONV_COUNTED_WAITS
+#define GNERF_CONV_COUNTED_WAITS 0
+#endif
+constexpr int kWaves = GNERF_CONV_WAVES;
+constexpr int kCoSplit = GNERF_CONV_COSPLIT;
+static_assert(kWaves == 4 || kWaves == 8, "4 or 8 waves per workgroup");
+static_assert(kCoSplit == 1 || (kCoSplit == 2 && kWaves == 8), "the output channels are split over wave pairs in the eight-wave form only");
+constexpr int kConvThreads = 64 * kWaves;
+constexpr int kRowsPW = kTH / (kWaves / kCoSplit);  // tile rows of a wave
+constexpr int kPB = 2 * kRowsPW;                    // 16-pixel blocks of a wave
+constexpr int kCB = 8 / kCoSplit;                   // 16-channel blocks of a wave
 constexpr int kRow = kCK * 2;                       // bytes of a pixel's / an output channel's row in LDS: 8 slots of 16 bytes
 constexpr int kXPieces = kIH * kIW * (kCK / 8);     // 16-byte pieces of the input tile
 constexpr int kXRounds = (kXPieces + kConvThreads - 1) / kConvThreads;
-constexpr int kXBytes = kXRounds * kConvThreads * 16;
+constexpr int kXPiecesPad = (kXPieces + 63) / 64 * 64;      // whole waves of LDS-DMA (a wave writes 64 consecutive pieces); waves beyond them skip the last round
+constexpr int kXBytes = kXPiecesPad * 16;
 constexpr int kWBytes = kCO * kCK * 2;
 constexpr int kWRounds = kWBytes / 16 / kConvThreads;
+constexpr int kStorePix = kConvThreads / 16;        // pixels a trip of the store loop moves (16 slots of 16 bytes each)
 constexpr int kOperands = kXBytes + 2 * kWBytes;                  // LDS offset of the epilogue's per-channel operands
 constexpr int kConvLds = kOperands + 1536;                        // [128] float scale, [128] float next_scale, [128] half bias
 static_assert(kTH * kTW * kCO * 2 <= kOperands, "the output tile is staged where the input tile and the weights were");
@@ -96,14 +124,25 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // fp32 values are stored as they are (16 bytes per lane straight from the accumulators: a 256 x 128 fp32 tile does not fit the staging
 // LDS), and the bias arrives as float32.  MIOpen's fp32 kernels reach 0.82-0.86 of the 157 TFLOP/s fp32 matrix peak on these shapes; three
 // f16 matrix instructions per product at 16x the rate are 2.5-3.3x faster (profiles/r06_conv_f32grade_gate.jsonl).
+#ifdef GNERF_CONV_STAMPS
+// Diagnostic build (tools/build_variants.sh 'D:GNERF_CONV_STAMPS', tools/conv_clock.py): the first lane of every workgroup stamps the shader
+// clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) at its start and end; their quotient is the clock the chip HOLDS under this
+// kernel (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps leave through a buffer of their own that nothing else reads.
+__device__ unsigned long long g_conv_stamps[16384][4];
+#endif
+
 template <int MODE, bool SCALE, bool NOISE, bool NEXT, bool OUT32 = false>
-__global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvArgs a) {
+__global__ __launch_bounds__(kConvThreads, kWaves == 8 ? 4 : 2) void conv3x3_epilogue_kernel(ConvArgs a) {
     extern __shared__ __align__(16) char lds[];
+#ifdef GNERF_CONV_STAMPS
+    const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     char* const xs = lds;                           // [340 pixels][8 slots of 16 bytes], slot ^= pixel & 7
     char* const wb = lds + kXBytes;                 // 2 x [128 output channels][8 slots], slot ^= (channel >> 1) & 7
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, hq = lane >> 4;
+    const int wrow = wv / kCoSplit, wco = wv % kCoSplit;                // the wave's rows are kRowsPW * wrow ..., its channel blocks kCB * wco ...
 
     // tile of this workgroup: XCD b % 8 gets a contiguous eighth of the tile sequence (neighbouring tiles share halo pixels in its L2)
     const int per_xcd = (a.n_tiles + kNumXCD - 1) / kNumXCD;
@@ -155,6 +194,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
         asm volatile("" : "+v"(t));
 #pragma unroll
         for (int it = 0; it < kXRounds; it++) {
+            if (it * kConvThreads + wv * 64 >= kXPiecesPad) break;      // (wave-uniform: the last round's waves past the tile)
             const int q = it * kConvThreads + t;
             const int pix = q >> 3, slot = q & 7;
             const int py = pix / kIW, px = pix - py * kIW;
@@ -165,7 +205,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(xs + (it * kConvThreads + wv * 64) * 16), 16, off, 0, 0, 0);
         }
     };
-    // weights of (tap, 64 input channels) -> buffer `buf`.  Lane (co = 32 it + tid / 8, slot = tid % 8) of trip `it` reads 16 bytes of output
+    // weights of (tap, 64 input channels) -> buffer `buf`.  Lane (co = (threads / 8) it + tid / 8, slot = tid % 8) of trip `it` reads 16 bytes of output
     // channel co; the swizzle key (co >> 1) & 7 = (tid >> 4) & 7 does not depend on the trip, so the lane contributes ONE 32-bit offset and
     // everything else -- tap, chunk, trip -- is a scalar base (round 6: as four 64-bit lane pointers these were eight v_lshl_add_u64 per step)
     const unsigned w_lane = unsigned(((tid >> 3) * a.cin_pad + (((tid & 7) ^ ((tid >> 4) & 7)) << 3)) * 2);
@@ -173,16 +213,16 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
         const char* src = reinterpret_cast<const char*>(a.wpk + (size_t(tap_base + tap) * Cout + co0) * a.cin_pad + cin0);
 #pragma unroll
         for (int it = 0; it < kWRounds; it++) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + size_t(it) * 32 * a.cin_pad * 2 + w_lane),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + size_t(it) * (kConvThreads / 8) * a.cin_pad * 2 + w_lane),
                                              (lds_ptr_t)(wb + buf * kWBytes + (it * kConvThreads + wv * 64) * 16), 16, 0, 0);
         }
     };
 
-    v4f acc[8][4];
+    v4f acc[kCB][kPB];
 #pragma unroll
-    for (int cb = 0; cb < 8; cb++)
+    for (int cb = 0; cb < kCB; cb++)
 #pragma unroll
-        for (int pb = 0; pb < 4; pb++) acc[cb][pb] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int pb = 0; pb < kPB; pb++) acc[cb][pb] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     // The epilogue's per-channel operands (demodulation scale, next layer's scale, bias of this workgroup's 128 channels: 1.25 KB) come in
     // by LDS-DMA right here and are read from LDS at the end.  (As ordinary loads at the point of use they were up to 24 dependent
@@ -210,33 +250,33 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     // chunk's last tap, the last of the input tile (the next chunk is requested right there and arrives under 32 MFMAs).
     // (Round 5's first two-workgroup loop read a step's first twelve fragments at the step's top, behind the barrier: 2 % slower -- the
     // other workgroup of the CU already covered most of that; commit b13915a has both loops and the timing-only ablation macros.)
-    h8 A[2][8], B[2][4];
+    h8 A[kWaves == 4 ? 2 : 1][kCB], B[kWaves == 4 ? 2 : 1][kPB];
     // fragment f of k-step kc of step s: f = 0..3 the input fragments of the wave's four pixel blocks, f = 4..11 the eight weight fragments.
     // Addresses from two lane constants and wave-uniform terms (the tap's shift, the weight buffer); pixel block f ^ 1 and the weight
     // fragments sit at constant offsets (16 pixels / 16 channels further: the swizzle's period is 8 rows), k-step 1 flips bit 6.
-    const int xlane = (2 * wv * kIW + r) * kRow;                   // byte offset of this lane's pixel row (tile row 2 wv, column r) without the tap's shift
-    const int alane = r * kRow + ((hq ^ ((r >> 1) & 7)) << 4);
+    const int xlane = (kRowsPW * wrow * kIW + r) * kRow;             // byte offset of this lane's pixel row (the wave's first tile row, column r) without the tap's shift
+    const int alane = (wco * kCB * 16 + r) * kRow + ((hq ^ ((r >> 1) & 7)) << 4);
     // (tap, buf): the step's tap within its chunk and the parity of its weight buffer -- running counters of the loop below, no divisions
-    auto load_frag = [&](int tap, int buf, int kc, int f, h8 (&Af)[8], h8 (&Bf)[4]) {
-        if (f < 4) {
+    auto load_frag = [&](int tap, int buf, int kc, int f, h8 (&Af)[kCB], h8 (&Bf)[kPB]) {
+        if (f < kPB) {
             int dy, dx;
             tap_shift(tap, dy, dx);
             const int row = xlane + (((f >> 1) + dy) * kIW + dx) * kRow;          // pixel index * 128
             const int slot = (hq ^ (row >> 7)) & 7;
             Bf[f] = *reinterpret_cast<const h8*>(xs + ((row + (slot << 4)) ^ (kc << 6)) + (f & 1) * 16 * kRow);
         } else {
-            Af[f - 4] = *reinterpret_cast<const h8*>(wb + buf * kWBytes + (alane ^ (kc << 6)) + (f - 4) * 16 * kRow);
+            Af[f - kPB] = *reinterpret_cast<const h8*>(wb + buf * kWBytes + (alane ^ (kc << 6)) + (f - kPB) * 16 * kRow);
         }
     };
-    auto mfma_group = [&](int g, const h8 (&Af)[8], const h8 (&Bf)[4]) {
+    auto mfma_group = [&](int g, const h8 (&Af)[kCB], const h8 (&Bf)[kPB]) {
 #pragma unroll
         for (int cb = 2 * g; cb < 2 * g + 2; cb++)
 #pragma unroll
-            for (int pb = 0; pb < 4; pb++) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[cb], Bf[pb], acc[cb][pb], 0, 0, 0);
+            for (int pb = 0; pb < kPB; pb++) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[cb], Bf[pb], acc[cb][pb], 0, 0, 0);
     };
     // 32 MFMAs from (Ac, Bc) with the twelve reads of (s2, kc2) into (An, Bn) among them: {8 MFMAs, six reads} twice, then 16 MFMAs --
     // fenced so that the compiler keeps the order; the last read has 24 MFMAs to come back behind
-    auto phase = [&](const h8 (&Ac)[8], const h8 (&Bc)[4], bool reads, int tap2, int buf2, int kc2, h8 (&An)[8], h8 (&Bn)[4]) {
+    auto phase = [&](const h8 (&Ac)[kCB], const h8 (&Bc)[kPB], bool reads, int tap2, int buf2, int kc2, h8 (&An)[kCB], h8 (&Bn)[kPB]) {
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(0, Ac, Bc);
         __builtin_amdgcn_sched_barrier(0);
@@ -268,6 +308,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (total > 1) stage_w(tap1, chunk1 * kCK, 1);
+    if constexpr (kWaves == 4) {
 #pragma unroll
     for (int f = 0; f < 12; f++) load_frag(0, 0, 0, f, A[0], B[0]);
     for (int s = 0; s < total; s++) {
@@ -289,6 +330,54 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
         }
         tap = tap1; chunk = chunk1; tap1 = tap2; chunk1 = chunk2;
         next_step(tap2, chunk2);
+    }
+    } else {
+    // Eight waves: per k-step the wave reads its ten fragments, waits for them and issues its sixteen MFMAs; nothing is double-buffered in
+    // registers -- three other waves of the SIMD have MFMAs to issue while this one waits.  The step's barrier sits where BOTH k-steps'
+    // fragments of this step's weight buffer are in registers (behind the second read): the buffer then takes the step after next.
+    for (int s = 0; s < total; s++) {
+#pragma unroll
+        for (int f = 0; f < kCB + kPB; f++) load_frag(tap, s & 1, 0, f, A[0], B[0]);
+#if GNERF_CONV_COUNTED_WAITS
+        // (the reads return in order: a pair of channel blocks starts as soon as ITS two weight fragments are there)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < kCB / 2; g++) {
+            if (kCB - 2 - 2 * g == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            else if (kCB - 2 - 2 * g == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            else if (kCB - 2 - 2 * g == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(g, A[0], B[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < kCB / 2; g++) mfma_group(g, A[0], B[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int f = 0; f < kCB + kPB; f++) load_frag(tap, s & 1, 1, f, A[0], B[0]);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool more = s + 1 < total, new_chunk = more && tap == n_taps - 1;
+        if (s + 2 < total) stage_w(tap2, chunk2 * kCK, s & 1);
+        if (new_chunk) stage_x((chunk + 1) * kCK);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < kCB / 2; g++) mfma_group(g, A[0], B[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (new_chunk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        tap = tap1; chunk = chunk1; tap1 = tap2; chunk1 = chunk2;
+        next_step(tap2, chunk2);
+    }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                                                // the input tile is dead: its LDS takes the output tile
@@ -317,17 +406,18 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     asm volatile("" : "+v"(lr));                                       // (per phase, see the store loop)
     const unsigned os_lane = unsigned(lr * 256 + (((hq >> 1) ^ lr) << 4) + (hq & 1) * 8);
     const unsigned y32_lane = unsigned((MODE == 1 ? 2 * lr : lr) * Cout + hq * 4);
-    float nzg[4] = {0.f, 0.f, 0.f, 0.f};
+    float nzg[kPB] = {};
     if constexpr (NOISE && MODE == 0) {
 #pragma unroll
-        for (int pb = 0; pb < 4; pb++) {
-            float nz = a.noise[(y0 + 2 * wv + (pb >> 1)) * W + x0 + (pb & 1) * 16 + r];
+        for (int pb = 0; pb < kPB; pb++) {
+            float nz = a.noise[(y0 + kRowsPW * wrow + (pb >> 1)) * W + x0 + (pb & 1) * 16 + r];
             if (a.round_noise) nz = round_to<__half>(nz);             // (the caller's noise tensor was fp16: noise.to(x.dtype), networks_stylegan2.py:313)
             nzg[pb] = nz * g;
         }
     }
 #pragma unroll
-    for (int cb = 0; cb < 8; cb++) {
+    for (int cbw = 0; cbw < kCB; cbw++) {
+        const int cb = wco * kCB + cbw;                            // (the channel block among the workgroup's eight)
         const int c4 = cb * 16 + hq * 4;                           // this lane's four consecutive output channels (of the workgroup's 128)
         v2f scg[2] = {{g, g}, {g, g}}, nx[2] = {{1.f, 1.f}, {1.f, 1.f}}, bg[2] = {{0.f, 0.f}, {0.f, 0.f}};
         if constexpr (SCALE) { const float4 v = *reinterpret_cast<const float4*>(ep + c4 * 4); scg[0] = (v2f){v.x, v.y} * g; scg[1] = (v2f){v.z, v.w} * g; }
@@ -340,13 +430,13 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             bg[0] = (v2f){float(hb[0]), float(hb[1])} * g; bg[1] = (v2f){float(hb[2]), float(hb[3])} * g;
         }
 #pragma unroll
-        for (int pb = 0; pb < 4; pb++) {
-            const int prow = 2 * wv + (pb >> 1);                      // (the pixel: row prow, column (pb & 1) * 16 + r of the tile)
+        for (int pb = 0; pb < kPB; pb++) {
+            const int prow = kRowsPW * wrow + (pb >> 1);              // (the pixel: row prow, column (pb & 1) * 16 + r of the tile)
             unsigned words[2];
             float full[4];
 #pragma unroll
             for (int k2 = 0; k2 < 2; k2++) {
-                const v2f av = {acc[cb][pb][2 * k2], acc[cb][pb][2 * k2 + 1]};
+                const v2f av = {acc[cbw][pb][2 * k2], acc[cbw][pb][2 * k2 + 1]};
                 h2 out;
                 if constexpr (MODE == 1) {
                     out = (h2){(_Float16)av[0], (_Float16)av[1]};      // the transposed convolution leaves as plain fp16 (blur + epilogue follow)
@@ -390,7 +480,8 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     }
 #else
 #pragma unroll
-    for (int cb = 0; cb < 8; cb++) {
+    for (int cbw = 0; cbw < kCB; cbw++) {
+        const int cb = wco * kCB + cbw;
         const int c4 = cb * 16 + hq * 4;                           // this lane's four consecutive output channels (of the workgroup's 128)
         float sc[4] = {1.f, 1.f, 1.f, 1.f}, nx[4] = {1.f, 1.f, 1.f, 1.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (SCALE) { const float4 v = *reinterpret_cast<const float4*>(ep + c4 * 4); sc[0] = v.x; sc[1] = v.y; sc[2] = v.z; sc[3] = v.w; }
@@ -405,12 +496,12 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             for (int k = 0; k < 4; k++) bv[k] = float(hb[k]);
         }
 #pragma unroll
-        for (int pb = 0; pb < 4; pb++) {
-            const int prow = 2 * wv + (pb >> 1), pcol = (pb & 1) * 16 + r;
+        for (int pb = 0; pb < kPB; pb++) {
+            const int prow = kRowsPW * wrow + (pb >> 1), pcol = (pb & 1) * 16 + r;
             const int p = prow * kTW + pcol;
             Pk<__half, 4> in;
 #pragma unroll
-            for (int k = 0; k < 4; k++) in.v[k] = __float2half(acc[cb][pb][k]);          // what the convolution alone would have stored
+            for (int k = 0; k < 4; k++) in.v[k] = __float2half(acc[cbw][pb][k]);          // what the convolution alone would have stored
             float nz = 0.f;
             if constexpr (NOISE) nz = a.noise[(y0 + prow) * W + x0 + pcol];
             Pk<__half, 4> out;
@@ -428,18 +519,18 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
     }
     __syncthreads();
     {
-        // 256 lanes move 16 pixels x 16 slots per trip: pixel (it >> 1, (it & 1) * 16 + lane / 16) of the tile, slot lane % 16.  Everything that
+        // The lanes move kStorePix (16 or 32) pixels x 16 slots per trip: pixel it * kStorePix + lane / 16 of the tile, slot lane % 16.  Everything that
         // depends on the trip is wave-uniform (a scalar base pointer, an immediate LDS offset); the lane contributes ONE 32-bit offset to each
         // side.  (Written as 64-bit addresses per trip the sixteen of them were hoisted out of the phase loop and spilled.)
         int lp = tid >> 4;
         asm volatile("" : "+v"(lp));                                   // (per phase: nothing of this is kept across the main loop)
         const int slot = tid & 15;
-        const unsigned lds_lane = unsigned(lp * 256 + ((slot ^ lp) << 4));
+        const unsigned lds_lane = unsigned(lp * 256 + ((slot ^ (lp & 15)) << 4));
         const unsigned out_lane = unsigned((MODE == 1 ? 2 * lp : lp) * Cout + slot * 8);
 #pragma unroll
         for (int it = 0; it < kTH * kTW * 16 / kConvThreads; it++) {
-            const uint4 v = *reinterpret_cast<const uint4*>(os + lds_lane + it * 4096);
-            const int yy = y0 + (it >> 1), xc = x0 + (it & 1) * 16;   // (uniform) row of the tile, first of this trip's sixteen columns
+            const uint4 v = *reinterpret_cast<const uint4*>(os + lds_lane + it * kStorePix * 256);
+            const int yy = y0 + it * kStorePix / kTW, xc = x0 + it * kStorePix % kTW;     // (uniform) row of the tile, first of this trip's columns
             if constexpr (MODE == 1) {                                 // position (yy, xx) of phase (py, px) -> output pixel (2 yy + py, 2 xx + px); the grid of tiles overhangs
                 _Float16* const row = a.y + ((size_t(n) * a.out_h + size_t(2 * yy + ph_y)) * a.out_w + size_t(2 * xc + ph_x)) * Cout + co0;
                 if (yy < Hp && xc + lp < Wp) *reinterpret_cast<uint4*>(row + out_lane) = v;
@@ -449,6 +540,13 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv3x3_epilogue_kernel(ConvA
             }
         }
     }
+#ifdef GNERF_CONV_STAMPS
+    if (threadIdx.x == 0 && ph == ph_end - 1) {
+        const unsigned slot = (blockIdx.y * gridDim.x + blockIdx.x) & 16383u;
+        g_conv_stamps[slot][0] = stamp_c0; g_conv_stamps[slot][1] = __builtin_amdgcn_s_memtime();
+        g_conv_stamps[slot][2] = stamp_r0; g_conv_stamps[slot][3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     if (MODE == 1) __syncthreads();                                  // the next phase's input tile overwrites the staged output
     // (stores straight from the accumulators -- 8 bytes per lane, no LDS staging, no barrier pair -- were measured: 0.237 -> 0.247 ms, the
     //  partial lines cost more than the staging)
@@ -619,3 +717,10 @@ extern "C" int gnerf_split_f16x3_nhwc(const float* x, const float* scale, void* 
 extern "C" int gnerf_conv_transpose3x3_s2_nhwc(const void* x, const void* w_phases, void* y, int n, int h, int w, int cin, int cout, gnerf_stream_t stream) {
     return launch_conv_transpose<false>("conv_transpose3x3_s2_nhwc", x, w_phases, y, n, h, w, cin, cout, stream);
 }
+
+#ifdef GNERF_CONV_STAMPS
+extern "C" int gnerf_debug_conv_stamps(unsigned long long* host, int slots) {
+    if (slots > 16384) slots = 16384;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_stamps), size_t(slots) * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
