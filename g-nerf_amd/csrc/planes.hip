@@ -14,7 +14,12 @@ namespace {
 
 using namespace gnerf;
 
-constexpr int CT = 32, PT = 64;   // channel x pixel tile
+// (Round 6, profiles/r06_repack_tile_ab.jsonl: 32 x 128 and 32 x 256 tiles -- 16 / 32 dword loads in flight per lane instead of 8 -- move the
+//  headline step by -0.4 %: the pass is not short of bytes in flight; at 200 MB in 50 us it runs at the rate HBM gives a read + write stream.)
+#ifndef GNERF_REPACK_PX
+#define GNERF_REPACK_PX 64
+#endif
+constexpr int CT = 32, PT = GNERF_REPACK_PX;   // channel x pixel tile (PT / 8 dword loads in flight per lane)
 
 // max |x| as an unsigned compare of the sign-stripped bits: orders like the floats for finite values and +inf, and any
 // NaN compares above +inf, so a NaN in the input survives as a NaN in the result.
@@ -51,7 +56,9 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     const float* s = src + plane * c * hw;
     float* d = dst + plane * hw * c;
     unsigned amax = 0u;
-    for (int e = threadIdx.x; e < CT * PT; e += 256) {
+#pragma unroll
+    for (int i = 0; i < CT * PT / 256; i++) {
+        const int e = threadIdx.x + 256 * i;
         const int ch = e / PT, px = e % PT;
         float v = 0.f;
         if (c0 + ch < c && p0 + px < hw) v = s[int64_t(c0 + ch) * hw + p0 + px];
@@ -59,7 +66,9 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         if (STATS) amax = max(amax, abs_bits(v));
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < CT * PT; e += 256) {
+#pragma unroll
+    for (int i = 0; i < CT * PT / 256; i++) {
+        const int e = threadIdx.x + 256 * i;
         const int px = e / CT, ch = e % CT;
         if (c0 + ch < c && p0 + px < hw) d[(p0 + px) * c + c0 + ch] = tile[ch][px];
     }
