@@ -128,7 +128,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // Diagnostic build (tools/build_variants.sh 'D:GNERF_CONV_STAMPS', tools/conv_clock.py): the first lane of every workgroup stamps the shader
 // clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) at its start and end; their quotient is the clock the chip HOLDS under this
 // kernel (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps leave through a buffer of their own that nothing else reads.
-__device__ unsigned long long g_conv_stamps[16384][4];
+__device__ unsigned long long g_conv_stamps[16384][8];
+#define GNERF_CONV_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); stamp_c[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GNERF_CONV_STAMP(k) do { } while (0)
 #endif
 
 template <int MODE, bool SCALE, bool NOISE, bool NEXT, bool OUT32 = false>
@@ -136,6 +139,7 @@ __global__ __launch_bounds__(kConvThreads, kWaves == 8 ? 4 : 2) void conv3x3_epi
     extern __shared__ __align__(16) char lds[];
 #ifdef GNERF_CONV_STAMPS
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long stamp_c[4] = {0, 0, 0, 0};                       // before the first loads / behind the prologue's barrier / at the main loop's end / in front of the store loop
 #endif
     char* const xs = lds;                           // [340 pixels][8 slots of 16 bytes], slot ^= pixel & 7
     char* const wb = lds + kXBytes;                 // 2 x [128 output channels][8 slots], slot ^= (channel >> 1) & 7
@@ -302,11 +306,13 @@ __global__ __launch_bounds__(kConvThreads, kWaves == 8 ? 4 : 2) void conv3x3_epi
     next_step(tap1, chunk1);
     tap2 = tap1; chunk2 = chunk1;
     next_step(tap2, chunk2);
+    GNERF_CONV_STAMP(0);
     stage_x(0);
     stage_w(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    GNERF_CONV_STAMP(1);
     if (total > 1) stage_w(tap1, chunk1 * kCK, 1);
     if constexpr (kWaves == 4) {
 #pragma unroll
@@ -380,6 +386,7 @@ __global__ __launch_bounds__(kConvThreads, kWaves == 8 ? 4 : 2) void conv3x3_epi
     }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    GNERF_CONV_STAMP(2);
     __syncthreads();                                                // the input tile is dead: its LDS takes the output tile
 
     // ---- epilogue in registers, then through LDS for 16-byte coalesced stores.  Output image: [256 pixels][16 slots], slot ^= pixel & 15.
@@ -522,6 +529,7 @@ __global__ __launch_bounds__(kConvThreads, kWaves == 8 ? 4 : 2) void conv3x3_epi
         // The lanes move kStorePix (16 or 32) pixels x 16 slots per trip: pixel it * kStorePix + lane / 16 of the tile, slot lane % 16.  Everything that
         // depends on the trip is wave-uniform (a scalar base pointer, an immediate LDS offset); the lane contributes ONE 32-bit offset to each
         // side.  (Written as 64-bit addresses per trip the sixteen of them were hoisted out of the phase loop and spilled.)
+        GNERF_CONV_STAMP(3);
         int lp = tid >> 4;
         asm volatile("" : "+v"(lp));                                   // (per phase: nothing of this is kept across the main loop)
         const int slot = tid & 15;
@@ -545,6 +553,7 @@ __global__ __launch_bounds__(kConvThreads, kWaves == 8 ? 4 : 2) void conv3x3_epi
         const unsigned slot = (blockIdx.y * gridDim.x + blockIdx.x) & 16383u;
         g_conv_stamps[slot][0] = stamp_c0; g_conv_stamps[slot][1] = __builtin_amdgcn_s_memtime();
         g_conv_stamps[slot][2] = stamp_r0; g_conv_stamps[slot][3] = __builtin_amdgcn_s_memrealtime();
+        for (int k = 0; k < 4; k++) g_conv_stamps[slot][4 + k] = stamp_c[k];
     }
 #endif
     if (MODE == 1) __syncthreads();                                  // the next phase's input tile overwrites the staged output
@@ -721,6 +730,6 @@ extern "C" int gnerf_conv_transpose3x3_s2_nhwc(const void* x, const void* w_phas
 #ifdef GNERF_CONV_STAMPS
 extern "C" int gnerf_debug_conv_stamps(unsigned long long* host, int slots) {
     if (slots > 16384) slots = 16384;
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_stamps), size_t(slots) * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_stamps), size_t(slots) * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
 #endif

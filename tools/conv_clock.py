@@ -39,7 +39,7 @@ for (n, cin, cout, h, w) in [(4, 128, 128, 512, 512), (4, 256, 256, 256, 256)]:
     ms = e0.elapsed_time(e1) / 200
     wgs = n * (h // 8) * (w // 32) * (cout // 128)
     slots = min(wgs, 16384)
-    st = np.zeros((slots, 4), dtype=np.uint64)
+    st = np.zeros((slots, 8), dtype=np.uint64)
     assert fn(st.ctypes.data, slots) == 0
     st = st.astype(np.float64)
     cyc, ticks = st[:, 1] - st[:, 0], st[:, 3] - st[:, 2]
@@ -49,10 +49,13 @@ for (n, cin, cout, h, w) in [(4, 128, 128, 512, 512), (4, 256, 256, 256, 256)]:
     simds = 256 * 4
     mfma_cycles = flop / 16384 * 16 / simds                  # v_mfma_f32_16x16x32_f16: 16 384 FLOP, 16 cycles of its SIMD's matrix pipe
     kernel_cycles = ms * 1e-3 * clock
+    seg = {'setup': st[ok, 4] - st[ok, 0], 'first_tile_and_weights_arrive': st[ok, 5] - st[ok, 4], 'main_loop': st[ok, 6] - st[ok, 5],
+           'barrier_and_epilogue_to_lds': st[ok, 7] - st[ok, 6], 'store_loop_to_end': st[ok, 1] - st[ok, 7]}
     span = (st[ok, 3].max() - st[ok, 2].min()) / 100.0       # us from the first workgroup's start to the last one's end (last launch)
     print(json.dumps({'shape': [n, cin, cout, h, w], 'operands': 'zeros' if args.zeros else 'random', 'launches_before': launches, 'ms': round(ms, 4),
                       'PFLOPs': round(flop / ms * 1e-12, 4), 'in_kernel_clock_GHz': round(clock * 1e-9, 3),
                       'peak_at_that_clock_PFLOPs': round(2.5 * clock / 2.4e9, 3), 'frac_of_peak_at_that_clock': round(flop / ms * 1e-12 / (2.5 * clock / 2.4e9), 3),
                       'frac_of_2.5_PFLOPs': round(flop / ms * 1e-12 / 2.5, 3), 'matrix_pipe_cycles_per_simd': round(mfma_cycles), 'kernel_cycles': round(kernel_cycles),
                       'workgroup_cycles_median': float(np.median(cyc[ok])), 'workgroup_us_median': float(np.median(ticks[ok])) / 100.0, 'first_start_to_last_end_us': round(span, 1),
+                      'workgroup_segments_cycles_median': {k: float(np.median(v)) for k, v in seg.items()},
                       'note': 'diagnostic build: the stamps cost two scalar memory-clock reads per workgroup; ms is this build\'s'}))
