@@ -100,7 +100,7 @@ struct ConvArgs {
     int tiles_x, tiles_y, n_tiles;
     int out_h, out_w;           // transposed form: 2 h + 1, 2 w + 1 (the convolution: h, w)
     int round_noise;
-    int phase_jobs;             // transposed form: 1 = a workgroup computes ONE phase of its position tile (blockIdx.z), 0 = all four
+    int phase_jobs;             // transposed form: 0 = a workgroup computes all four phases of its position tile, 1 = ONE phase (blockIdx.z), 2 = two: {0, 3} or {1, 2}
     float alpha, gain, clamp;
 };
 
@@ -166,9 +166,13 @@ __global__ __launch_bounds__(kConvThreads, kWaves == 8 ? 4 : 2) void conv3x3_epi
     // phase_jobs (round 6): launches that do not fill the chip's 512 workgroup slots with whole position tiles -- the backbone's x2 layers from
     // 32^2 and 64^2 are 160 and 216 jobs -- run one phase per workgroup instead (blockIdx.z, the slowest grid index: the four-tap phase's jobs are
     // dispatched first and round-robin over the XCDs): four times the workgroups for the same work, jobs of 4 : 2 : 2 : 1 length
-    const int ph_first = (MODE == 1 && a.phase_jobs) ? int(blockIdx.z) : 0, ph_end = MODE == 1 ? (a.phase_jobs ? ph_first + 1 : 4) : 1;
+    // phase_jobs = 2 (round 6): phase PAIRS per workgroup -- {four taps, one tap} for blockIdx.z = 0 (dispatched first), {two taps, two taps} for 1:
+    // jobs of 5 : 4 length, half as long as a whole position tile's.  A launch of J whole-tile jobs takes ceil(J / 512) rounds of the chip's 512
+    // workgroup slots (4 x 256^2 positions: 1 188 jobs = 2.3 -> 3 rounds, the last one a third full); in halves it is 4.6 -> 5 rounds of half the length.
+    const int n_ph = MODE == 1 ? (a.phase_jobs == 0 ? 4 : a.phase_jobs) : 1;
 #pragma nounroll
-    for (int ph = ph_first; ph < ph_end; ph++) {
+    for (int pi = 0; pi < n_ph; pi++) {
+    const int ph = MODE == 1 ? (a.phase_jobs == 0 ? pi : a.phase_jobs == 1 ? int(blockIdx.z) : (blockIdx.z == 0 ? 3 * pi : 1 + pi)) : 0;
     const int ph_y = ph >> 1, ph_x = ph & 1;                            // (py, px)
     const int n_taps = MODE == 1 ? (2 - ph_y) * (2 - ph_x) : 9;
     const int tap_base = MODE == 1 ? (ph == 0 ? 0 : ph == 1 ? 4 : ph == 2 ? 6 : 8) : 0;
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(kConvThreads, kWaves == 8 ? 4 : 2) void conv3x3_epi
         }
     }
 #ifdef GNERF_CONV_STAMPS
-    if (threadIdx.x == 0 && ph == ph_end - 1) {
+    if (threadIdx.x == 0 && pi == n_ph - 1) {
         const unsigned slot = (blockIdx.y * gridDim.x + blockIdx.x) & 16383u;
         g_conv_stamps[slot][0] = stamp_c0; g_conv_stamps[slot][1] = __builtin_amdgcn_s_memtime();
         g_conv_stamps[slot][2] = stamp_r0; g_conv_stamps[slot][3] = __builtin_amdgcn_s_memrealtime();
@@ -679,8 +683,17 @@ int launch_conv_transpose(const char* what, const void* x, const void* w_phases,
     a.n_tiles = int(jobs);
     a.out_h = 2 * h + 1; a.out_w = 2 * w + 1;
     a.round_noise = 0; a.alpha = 0.f; a.gain = 1.f; a.clamp = -1.f;
-    a.phase_jobs = (jobs * (cout / kCO) < 2 * kNumCU) ? 1 : 0;
-    const dim3 grid((a.n_tiles + kNumXCD - 1) / kNumXCD * kNumXCD, cout / kCO, a.phase_jobs ? 4 : 1), block(kConvThreads);
+    // Job shape (profiles/r06_convt_phase_jobs.jsonl): launches below the chip's 512 workgroup slots run one phase per workgroup; above it whole
+    // position tiles when they fill their last round of slots to within 8 % (8 frames of 256^2: 4.64 rounds, +2.6 % for the pairs), phase pairs
+    // otherwise (4 frames: 2.32 rounds -> 3; pairs -7 %), single phases where a phase is only a few steps long (<= 128 input channels: -10...-20 %)
+    {
+        const int64_t wgs = jobs * (cout / kCO), slots = 2 * kNumCU, rounds = (wgs + slots - 1) / slots;
+        if (wgs < slots) a.phase_jobs = 1;
+        else if ((rounds * slots - wgs) * 100 <= 8 * rounds * slots) a.phase_jobs = 0;
+        else a.phase_jobs = a.cin_pad / kCK <= 2 ? 1 : 2;
+    }
+    if (const char* f = getenv("GNERF_CONVT_PHASE_JOBS")) { const int v = atoi(f); if (v >= 0 && v <= 2) a.phase_jobs = v; }      // (A/B runs)
+    const dim3 grid((a.n_tiles + kNumXCD - 1) / kNumXCD * kNumXCD, cout / kCO, a.phase_jobs == 0 ? 1 : a.phase_jobs == 1 ? 4 : 2), block(kConvThreads);
     static PerDeviceOnce once;
     if (int rc = once.raise_lds(conv3x3_epilogue_kernel<1, false, false, false, OUT32>, what, kConvLds)) return rc;
     hipLaunchKernelGGL((conv3x3_epilogue_kernel<1, false, false, false, OUT32>), grid, block, kConvLds, as_stream(stream), a);
