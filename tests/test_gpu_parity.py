@@ -1842,6 +1842,42 @@ def test_conv_transpose3x3_s2_vs_framework(dev):
         gnerf_hip.conv_transpose3x3_s2(bad, torch.zeros(9, 64, 64, device=dev, dtype=torch.float16))
 
 
+def test_conv_transpose_job_shapes_agree(dev, monkeypatch):
+    """The transposed convolution's launcher picks a job shape per call (whole position tiles / phase pairs / single phases per workgroup,
+    csrc/conv3x3.hip launch_conv_transpose): the three give the SAME bits -- a phase's sum is taken in one order whoever computes it -- on a
+    launch above the chip's 512 workgroup slots (odd sizes: the tile grid overhangs the odd phases), in the fp16 and the fp32-grade form, and
+    the launcher's own choice is one of them."""
+    import gnerf_hip
+    import torch.nn.functional as F
+    for (n, cin, cout, h, w) in [(8, 64, 128, 127, 129), (10, 136, 256, 70, 65)]:
+        g = torch.Generator(device='cpu').manual_seed(h)
+        x32 = (torch.randn(n, cin, h, w, generator=g) * 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+        x = x32.half()
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) / (2 * cin ** 0.5)).to(dev)
+        wp = gnerf_hip.pack_conv_transpose3x3_weights(wt)
+        assert n * ((h + 8) // 8) * ((w + 32) // 32) * (cout // 128) > 512
+        monkeypatch.delenv('GNERF_CONVT_PHASE_JOBS', raising=False)
+        own = gnerf_hip.conv_transpose3x3_s2(x, wp)
+        outs = []
+        for mode in ('0', '1', '2'):
+            monkeypatch.setenv('GNERF_CONVT_PHASE_JOBS', mode)
+            outs.append(gnerf_hip.conv_transpose3x3_s2(x, wp))
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], own), (n, cin, cout, h, w)
+        ref = F.conv_transpose2d(x.float(), wt.half().float().transpose(0, 1), stride=2)
+        assert float((own.float() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+        if cin % 8 == 0 and gnerf_hip.conv_transpose3x3_s2_f32x3_supported(x32, cout):
+            w3 = gnerf_hip.pack_conv_transpose3x3_weights_f32x3(wt)
+            x3 = gnerf_hip.split_f16x3(x32)
+            o32 = []
+            for mode in ('0', '1', '2'):
+                monkeypatch.setenv('GNERF_CONVT_PHASE_JOBS', mode)
+                o32.append(gnerf_hip.conv_transpose3x3_s2_f32x3(x3, w3))
+            assert torch.equal(o32[0], o32[1]) and torch.equal(o32[0], o32[2])
+            ref64 = F.conv_transpose2d(x32.double(), wt.double().transpose(0, 1), stride=2)
+            assert float((o32[0].double() - ref64).abs().max()) <= 2e-5 * float(ref64.abs().max())
+        monkeypatch.delenv('GNERF_CONVT_PHASE_JOBS', raising=False)
+
+
 def test_conv3x3_epilogue_vs_composed_ops(dev):
     """csrc/conv3x3.hip -- the 3x3 convolution of a modulated-convolution layer and its epilogue in one launch (SURVEY 8(f)3;
     networks_stylegan2.py:41-98 as SynthesisLayer.forward calls it, :315-334) -- against the two launches it replaces: torch's
