@@ -297,6 +297,12 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
         const int ray_id = __float_as_int(sl.misc[kMiscRay]);
         if (ray_id < 0) return;
         float* dbg = debug ? debug + int64_t(ray_id) * GNERF_DEBUG_SLOTS * n_all : nullptr;
+#ifdef GNERF_ABLATE_PIPESCALAR  // timing-only build: the scalar wave does NONE of its per-ray passes (fine depths = coarse depths; outputs are wrong):
+        // the upper bound of what any reformulation of them -- the lane-per-ray pass included -- could return
+        for (int i = lane; i < F; i += 64) { sl.t_e[fine_e0 + i] = sl.t_e[min(i, S - 1)]; sl.rank_e[fine_e0 + i] = 0; }
+        (void)dbg;
+        return;
+#endif
         float ws, wts;
         march(sl.t_e, sl.sig_e, sl.w_s, S, lane, ws, wts);
         lds_wave_sync();
@@ -380,6 +386,14 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
         // "#fine before i" is a compare + add-with-carry scan over the fine keys read four at a time as LDS broadcasts, first
         // taken as #{fine < t_i}; two fine samples with bit-identical depth then collide on a rank, which is detected through
         // an owner table and repaired by a tie-broken recount (rare: needs two equal uniform draws or rounding collisions).
+#ifdef GNERF_ABLATE_PIPESCALAR
+        if constexpr (!BWD) {
+            for (int q = lane; q < n_all; q += 64) sl.v_e[q < S ? q : fine_e0 + (q - S)] = 1.f / float(n_all);
+            if (lane == 0) { sl.misc[kMiscWsum] = 1.f; sl.misc[kMiscWtsum] = sl.t_e[0]; range.add(P, __float_as_int(sl.misc[kMiscItem]), sl.t_e[0], sl.t_e[S - 1]); }
+            (void)dbg;
+            return;
+        }
+#endif
         int rank_f[RND], rank_c[RND];
         float key_f[RND], key_c[RND];
         float q_c[RND] = {}, q_f[RND] = {};           // BWD: this lane's samples' q, read before v_e is reused below
