@@ -129,3 +129,37 @@ with torch.no_grad():
         report(f'grid_sample adjoint (image + grid gradients) [8,64,256,256] {nm}', ms, 2 * img.numel() * es + img.numel() * 4 * 2 + 2 * grid.numel() * 4)
         ms_t = timeit(lambda: torch.ops.aten.grid_sampler_2d_backward(go, img, grid.to(dt), 0, 0, False, [True, True]))
         report(f'(aten grid_sampler_2d_backward, for scale) {nm}', ms_t, 2 * img.numel() * es + img.numel() * 4 * 2 + 2 * grid.numel() * 4)
+
+# The matrix-bound kernels (csrc/conv3x3.hip), live since round 6: PFLOP/s against the dense f16 peak of 2.5 PFLOP/s (for the fp32-grade forms:
+# the f16 work they execute -- three products per fp32 product -- and the fp32-equivalent TFLOP/s next to it).  Comparisons with MIOpen need its
+# solver search and live in tools/bench_conv3x3.py, bench_conv_transpose.py, bench_conv_f32grade.py.
+with torch.no_grad():
+    def conv_line(name, ms, gflop_f16, extra=None):
+        row = {'op': name, 'ms': round(ms, 4), 'GFLOP_f16_executed': round(gflop_f16, 2), 'PFLOPs': round(gflop_f16 / ms * 1e-3, 3), 'frac_of_2.5PF': round(gflop_f16 / ms * 1e-3 / 2.5, 3)}
+        row.update(extra or {})
+        print(json.dumps(row))
+    g = torch.Generator(device='cpu').manual_seed(1)
+    for (n, cin, cout, h, w) in [(4, 128, 128, 512, 512), (4, 256, 256, 256, 256), (8, 128, 128, 512, 512), (8, 256, 256, 256, 256), (1, 128, 128, 512, 512)]:
+        x = (torch.randn(n, cin, h, w, generator=g) * 0.5).to(dev).half().contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev)
+        wpk = gnerf_hip.pack_conv3x3_weights(wt)
+        dco = (torch.rand(n, cout, generator=g) + 0.5).to(dev); nxt = (torch.rand(n, cout, generator=g) + 0.5).to(dev); bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+        ms = timeit(lambda: gnerf_hip.conv3x3_epilogue(x, wpk, bias, scale=dco, next_scale=nxt, gain=2 ** 0.5, clamp=256.0))
+        conv_line(f'fused 3x3 convolution + epilogue [{n},{cin}->{cout},{h},{w}] f16 channels_last', ms, 2e-9 * n * h * w * cin * cout * 9)
+        del x
+    for (n, cin, cout, h, w) in [(4, 256, 128, 256, 256), (4, 128, 128, 256, 256), (8, 256, 128, 256, 256), (1, 256, 128, 256, 256), (4, 32, 256, 128, 128)]:
+        x = (torch.randn(n, cin, h, w, generator=g) * 0.5).to(dev).half().contiguous(memory_format=torch.channels_last)
+        wp = gnerf_hip.pack_conv_transpose3x3_weights((torch.randn(cout, cin, 3, 3, generator=g) / (2 * cin ** 0.5)).to(dev))
+        ms = timeit(lambda: gnerf_hip.conv_transpose3x3_s2(x, wp))
+        conv_line(f'stride-2 transposed 3x3 convolution as phase convolutions [{n},{cin}->{cout},{h},{w} -> {2 * h + 1},{2 * w + 1}] f16 channels_last', ms, 2e-9 * n * h * w * cin * cout * 9)
+        del x
+    for (n, cin, cout, h, w) in [(4, 512, 512, 64, 64), (4, 256, 256, 128, 128), (4, 128, 128, 256, 256)]:
+        x32 = (torch.randn(n, cin, h, w, generator=g) * 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+        w3 = gnerf_hip.pack_conv3x3_weights_f32x3((torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev))
+        x3 = gnerf_hip.split_f16x3(x32)
+        ms = timeit(lambda: gnerf_hip.conv3x3_f32x3_epilogue(x3, w3))
+        gf = 2e-9 * n * h * w * cin * cout * 9
+        conv_line(f'fp32-grade 3x3 convolution (f16 hi/lo x 3) [{n},{cin}->{cout},{h},{w}] f32 channels_last', ms, 3 * gf, {'TFLOPs_fp32_equivalent': round(gf / ms, 1), 'frac_of_157.3TF_fp32_matrix_peak': round(gf / ms / 157.3, 2)})
+        ms_s = timeit(lambda: gnerf_hip.split_f16x3(x32))
+        report(f'split_f16x3 (fp32 -> [hi | lo | hi] f16) [{n},{cin},{h},{w}]', ms_s, x32.numel() * 10)
+        del x32, x3
