@@ -108,6 +108,21 @@ def _packed_prenormalised_weight(module, dtype, transposed=False):
     return hit[1]
 
 
+def _packed_modulated_weight(module, nstyles, dtype, transposed=False):
+    """pack(f16(pre-normalised weight x the ONE latent's normalised styles)): the input scaling of a layer folded into its packed weights, which is
+    the order the reference's own inference path takes it in (the fused form modulates the WEIGHTS, networks_stylegan2.py:66-75) -- one rounding
+    per weight instead of one per activation, and no scaling pass over the activations.  A constant of (latent, weight): cached by _per_latent."""
+    import gnerf_hip
+    w = module.weight
+    with torch.no_grad():
+        v = w * (1 / math.sqrt(w[0].numel()) / w.norm(float('inf'), dim=[1, 2, 3], keepdim=True)) * nstyles.reshape(1, -1, 1, 1).to(w.dtype)
+    pack = gnerf_hip.pack_conv_transpose3x3_weights if transposed else gnerf_hip.pack_conv3x3_weights
+    return pack(v.to(dtype), dtype)
+
+
+# GNERF_LATENT_WEIGHTS=0: a layer whose input scaling no earlier epilogue carries (the first layer of a block) scales its activations in a launch
+# of its own (gnerf_scale_channels), as until round 6, also when the whole batch shares ONE latent (an orbit: k views of one object)
+_LATENT_WEIGHTS = os.environ.get('GNERF_LATENT_WEIGHTS', '1') != '0'
 # GNERF_FUSED_CONV=0: the 3x3 layers of the shared-weight form go to MIOpen + gnerf_modconv_epilogue_nhwc (round 4's flow) instead of
 # the one-launch kernel of csrc/conv3x3.hip
 _FUSED_CONV = os.environ.get('GNERF_FUSED_CONV', '1') != '0'
@@ -166,6 +181,29 @@ def _per_latent(module, w, tag, params, fn):
         val = fn()
     cache[tag] = (ref, key, val)
     return val
+
+
+# Latent tensors whose rows are copies of ONE latent (Generator.synthesis makes them for k views of one object; the superresolution's `ws3` inherits
+# the mark): what lets a layer fold per-latent constants into its weights without reading the rows back from the device.
+_ONE_LATENT = {}                   # id(tensor) -> weak reference (tensors compare element-wise: no WeakSet)
+
+
+def _mark_one_latent(t):
+    key = id(t)
+    if key not in _ONE_LATENT or _ONE_LATENT[key]() is not t:
+        _ONE_LATENT[key] = weakref.ref(t, lambda _, k=key: _ONE_LATENT.pop(k, None))
+
+
+def _rows_share_latent(w):
+    base = w._base if w._base is not None else w
+    ref = _ONE_LATENT.get(id(base))
+    return w.shape[0] == 1 or (ref is not None and ref() is base)
+
+
+def _latent_cacheable(w, params):
+    """True when _per_latent(module, w, tag, params, fn) would keep fn()'s value (the conditions of its first lines)."""
+    return (_latent_token(w) is not None and not (torch.is_grad_enabled() and any(p.requires_grad for p in params))
+            and not any(p.is_inference() for p in params))
 
 
 def clear_latent_caches(root):
@@ -351,21 +389,28 @@ class StyledConv(nn.Module):
             # orbit then runs its 3x3 layers on csrc/conv3x3.hip like the batched one instead of per-sample weights + MIOpen
             if half and (n > 1 or _SHARED_AT_ONE):
                 dco = _per_latent(self, w, 'dco', mine, lambda: gnerf_hip.modulate_weights(self.weight, styles, True, out_dtype=x.dtype, want_weights=False, want_dcoefs=True)[1])
+                own_plain = _FUSED_CONV and self.up == 1 and cl and gnerf_hip.conv3x3_epilogue_supported(x, c_out) and (noise is None or noise.numel() == h * wd)
+                own_up = self.up == 2 and _FUSED_CONV and cl and gnerf_hip.conv_transpose3x3_s2_supported(x, c_out)
+                packed = None           # the layer's packed weights when they carry its input scaling (round 6: ONE latent for the whole batch)
                 if not prescaled:
-                    x = gnerf_hip.scale_channels(x, _per_latent(self, w, 'nstyles', aff, lambda: gnerf_hip.normalise_styles(styles)))
+                    nst = _per_latent(self, w, 'nstyles', aff, lambda: gnerf_hip.normalise_styles(styles))
+                    if _LATENT_WEIGHTS and _rows_share_latent(w) and (own_plain or own_up) and _latent_cacheable(w, mine):     # (packing per call would cost more than the scaling pass)
+                        packed = _per_latent(self, w, ('packed_mod', x.dtype), mine, lambda: _packed_modulated_weight(self, nst[:1], x.dtype, transposed=self.up == 2))
+                    else:
+                        x = gnerf_hip.scale_channels(x, nst)
                 nxt = None
                 if next_layer is not None and cl and _fast_path(x, next_w, next_layer.weight, next_layer.bias, next_layer.noise_strength, next_layer.affine.weight, next_layer.affine.bias):
                     nxt_aff = (next_layer.affine.weight, next_layer.affine.bias)
                     nxt = _per_latent(next_layer, next_w, 'nstyles', nxt_aff, lambda: gnerf_hip.normalise_styles(next_layer.affine(next_w)))
                     folded = True
-                if _FUSED_CONV and self.up == 1 and cl and gnerf_hip.conv3x3_epilogue_supported(x, c_out) and (noise is None or noise.numel() == h * wd):
+                if own_plain:
                     # convolution + demodulation + noise + bias + lrelu + clamp (+ the next layer's input scaling) in one launch
-                    x = gnerf_hip.conv3x3_epilogue(x, _packed_prenormalised_weight(self, x.dtype), _cast_param(self, 'bias', x.dtype), scale=dco, noise=noise,
+                    x = gnerf_hip.conv3x3_epilogue(x, packed if packed is not None else _packed_prenormalised_weight(self, x.dtype), _cast_param(self, 'bias', x.dtype), scale=dco, noise=noise,
                                                    round_noise=True, gain=LRELU_GAIN * gain, clamp=clamp, next_scale=nxt)
                     return (x, folded) if next_layer is not None else x
                 epi = dict(bias=_cast_param(self, 'bias', x.dtype), scale=dco, act='lrelu', gain=LRELU_GAIN * gain, clamp=clamp, next_scale=nxt) if noise is None else None
-                if self.up == 2 and _FUSED_CONV and cl and gnerf_hip.conv_transpose3x3_s2_supported(x, c_out):
-                    w_t = ('phases', _packed_prenormalised_weight(self, x.dtype, transposed=True))        # the x2 layer's transposed convolution on our own kernel
+                if own_up:
+                    w_t = ('phases', packed if packed is not None else _packed_prenormalised_weight(self, x.dtype, transposed=True))        # the x2 layer's transposed convolution on our own kernel
                 else:
                     w_t = _prenormalised_weight(self, x.dtype, cl, transposed=True) if self.up == 2 else None
                 out = self._resampled_conv(x, _prenormalised_weight(self, x.dtype, cl), 1, weight_t=w_t, epilogue=epi)
@@ -578,7 +623,10 @@ class SuperRes8XDC(nn.Module):
 
     def forward(self, rgb, x, ws, noise_mode='none', **block_kwargs):
         # (the same tensor OBJECT for the same ws: the layers below cache what depends on their latent slice by its identity)
+        ws_in = ws
         ws = _per_latent(self, ws, 'ws3', (), lambda: ws[:, -1:, :].repeat(1, 3, 1))
+        if _rows_share_latent(ws_in):
+            _mark_one_latent(ws)
         x_raw, image_raw = self.block64(x, rgb, ws, noise_mode, **block_kwargs)
         if x.shape[-1] != 128:
             x = F.interpolate(x_raw, size=(128, 128), mode='bilinear', align_corners=False, antialias=self.antialias)
@@ -631,6 +679,7 @@ class Generator(nn.Module):
             # several cameras for ONE latent (an orbit's frames, gen_videos.py:150-166, batched): the renderer reads the one set of
             # planes for every view and gives each the results of a call of its own; the superresolution sees a batch of the latent
             ws = _per_latent(self, ws, ('views', o.shape[0]), (), lambda: ws.expand(o.shape[0], -1, -1).contiguous())
+            _mark_one_latent(ws)
         feat, depth, _ = self.renderer(planes.view(n, 3, 32, *planes.shape[-2:]), self.decoder, o, d, self.rendering_kwargs)
         n = o.shape[0]
         feature_image = feat.permute(0, 2, 1).reshape(n, 32, res, res).contiguous()

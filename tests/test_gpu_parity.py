@@ -991,6 +991,43 @@ def test_orbit_frames_per_call(dev):
         GV.render_orbit(G, torch.randn(2, G.z_dim, device=dev), 4, 32, dev, double_depth=False, frames_per_call=2)
 
 
+def test_one_latent_folds_input_scaling_into_packed_weights(dev, monkeypatch):
+    """An orbit renders k views of ONE latent: the layers whose input scaling no earlier epilogue carries (the first layer of a superresolution
+    block) then fold it into their packed weights, per latent (gnerf_generator._packed_modulated_weight: the order the reference's fused
+    inference form takes, networks_stylegan2.py:66-75), instead of a scaling pass over the activations.  The route is taken (fewer
+    gnerf_scale_channels launches, the packed weights cached: a second call packs nothing), GNERF_LATENT_WEIGHTS=0 gives the same image to the
+    fp16 layers' rounding, and the renderer's share of the frame does not change at all."""
+    import gnerf_generator as GG
+    import gnerf_harness as H
+    import gen_videos_mi355x as GV
+    import gnerf_hip
+    G = GV.build_random_generator(3, dev)
+    z = torch.randn(1, G.z_dim, device=dev)
+    calls = {'scale': 0, 'pack': 0}
+    real_scale, real_pack = gnerf_hip.scale_channels, GG._packed_modulated_weight
+    monkeypatch.setattr(gnerf_hip, 'scale_channels', lambda *a, **k: (calls.__setitem__('scale', calls['scale'] + 1), real_scale(*a, **k))[1])
+    monkeypatch.setattr(GG, '_packed_modulated_weight', lambda *a, **k: (calls.__setitem__('pack', calls['pack'] + 1), real_pack(*a, **k))[1])
+    with torch.no_grad():
+        ws = GV.orbit_latents(G, z, dev)
+        cams = torch.cat([H.camera_label(H.orbit_pose(i, 10, G.rendering_kwargs['avg_camera_radius'])) for i in range(4)]).to(dev)
+        G.synthesis(ws=ws, c=cams[:1], noise_mode='const', neural_rendering_resolution=32, cache_backbone=True)
+        out = {}
+        for on in (True, False, True):
+            monkeypatch.setattr(GG, '_LATENT_WEIGHTS', on)
+            calls['scale'] = calls['pack'] = 0
+            torch.manual_seed(3)
+            o = G.synthesis(ws=ws, c=cams, noise_mode='const', neural_rendering_resolution=32, use_cached_backbone=True)
+            out.setdefault(on, (o, dict(calls)))
+            last = dict(calls)
+    (img_on, c_on), (img_off, c_off) = out[True], out[False]
+    assert c_off['pack'] == 0 and c_on['scale'] < c_off['scale'], (c_on, c_off)
+    assert last['pack'] == 0                                             # the third call found every packed weight in the per-latent cache
+    assert torch.equal(img_on['image_depth'], img_off['image_depth']) and torch.equal(img_on['image_raw'], img_off['image_raw'])
+    d = (img_on['image'].float() - img_off['image'].float()).abs()
+    scale = float(img_off['image'].float().abs().max())
+    assert float(d.max()) < 0.03 * max(scale, 1.0) and float(d.mean()) < 2e-3 * max(scale, 1.0), (float(d.max()), float(d.mean()), scale)
+
+
 def test_to_uint8_nhwc_matches_the_pytorch_ops(dev):
     """gnerf_to_uint8_nhwc == (img * 127.5 + 128).clamp(0, 255).to(uint8).permute(0, 2, 3, 1) (gen_videos.py:173), byte for byte: random
     images, values on and around every half-integer boundary of the product, +-inf, out-of-range values; NaN -> 0."""
