@@ -80,7 +80,7 @@ constexpr int kWBytes = kCO * kCK * 2;
 constexpr int kWRounds = kWBytes / 16 / kConvThreads;
 constexpr int kStorePix = kConvThreads / 16;        // pixels a trip of the store loop moves (16 slots of 16 bytes each)
 constexpr int kOperands = kXBytes + 2 * kWBytes;                  // LDS offset of the epilogue's per-channel operands
-constexpr int kConvLds = kOperands + 1536;                        // [128] float scale, [128] float next_scale, [128] half bias
+constexpr int kConvLds = kOperands + 1536 + 768;                  // [128] float scale, [128] float next_scale, [128] half / float bias, RGB: [3][128] half ToRGB weights
 static_assert(kTH * kTW * kCO * 2 <= kOperands, "the output tile is staged where the input tile and the weights were");
 static_assert(2 * kConvLds <= 160 * 1024, "two workgroups per CU");
 static_assert(kCK == 64, "two k-steps per tap; the swizzles assume 128-byte rows");
@@ -102,6 +102,12 @@ struct ConvArgs {
     int round_noise;
     int phase_jobs;             // transposed form: 0 = a workgroup computes all four phases of its position tile, 1 = ONE phase (blockIdx.z), 2 = two: {0, 3} or {1, 2}
     float alpha, gain, clamp;
+    // RGB (ABI 11): the layer's ToRGB (networks_stylegan2.py:348-366, a modulated 1 x 1 convolution to three channels) taken in the epilogue, its result
+    // ADDED to the block's running image -- no y is written at all (the superresolution's last block: nothing else reads its x)
+    const _Float16* rgb_w;      // [n, 3, 128] float16: the ToRGB weight x its styles per sample (what gnerf_torgb_nhwc multiplies by)
+    const float* rgb_bias;      // [3] float32 or NULL
+    float rgb_clamp;            // < 0: none
+    float* img;                 // [n, 3, h, w] float32, accumulated in place
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -134,8 +140,9 @@ __device__ unsigned long long g_conv_stamps[16384][8];
 #define GNERF_CONV_STAMP(k) do { } while (0)
 #endif
 
-template <int MODE, bool SCALE, bool NOISE, bool NEXT, bool OUT32 = false>
+template <int MODE, bool SCALE, bool NOISE, bool NEXT, bool OUT32 = false, bool RGB = false>
 __global__ __launch_bounds__(kConvThreads, kWaves == 8 ? 4 : 2) void conv3x3_epilogue_kernel(ConvArgs a) {
+    static_assert(!RGB || (MODE == 0 && !OUT32 && !NEXT && GNERF_CONV_EPILOGUE_F32), "the ToRGB tail belongs to the plain fp16 convolution of a block's last layer");
     extern __shared__ __align__(16) char lds[];
 #ifdef GNERF_CONV_STAMPS
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
@@ -249,6 +256,10 @@ __global__ __launch_bounds__(kConvThreads, kWaves == 8 ? 4 : 2) void conv3x3_epi
     } else {
         if (wv == 0 && a.bias) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + co0 + 2 * tid),
                                                                 (lds_ptr_t)(ep + 1024), 4, 0, 0);
+    }
+    if constexpr (RGB) {                                           // [3][128] halves = 3 x 256 bytes, four bytes per lane
+        if (wv < 3) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(a.rgb_w) + size_t(n) * 768 + wv * 256 + lane * 4),
+                                                     (lds_ptr_t)(ep + 1536 + wv * 256), 4, 0, 0);
     }
     const int n_chunks = a.cin_pad / kCK, total = n_chunks * n_taps;
     // ---- main loop, software-pipelined ACROSS steps.  A step (one tap of one 64-channel chunk) is two k-steps of 32 MFMAs; while
@@ -397,6 +408,9 @@ __global__ __launch_bounds__(kConvThreads, kWaves == 8 ? 4 : 2) void conv3x3_epi
     char* const os = lds;
     // (two copies of the register part, chosen once per workgroup: with the clamp's presence a run-time value the compiler keeps a
     //  compare-and-select per element behind every v_med3_f32 -- 128 of a wave's ~2 000 epilogue instructions)
+#ifdef GNERF_ABLATE_CONVNOSTORE
+    unsigned ablate_sink = 0;
+#endif
     auto registers_to_lds = [&](auto has_clamp) {
     const float clampv = decltype(has_clamp)::value ? fabsf(a.clamp) : -1.f;
     if constexpr (decltype(has_clamp)::value) __builtin_assume(clampv >= 0.f);
@@ -486,7 +500,12 @@ __global__ __launch_bounds__(kConvThreads, kWaves == 8 ? 4 : 2) void conv3x3_epi
             }
             // (p = 32 prow + 16 (pb & 1) + r: the lane's part of the address is r * 256 + its slot, the rest is wave-uniform; c4 >> 3 = 2 cb +
             //  (hq >> 1) and 2 cb only touches the slot's upper bits, so channel block cb is the cb = 0 address with cb << 5 XORed in)
+#ifdef GNERF_ABLATE_CONVNOSTORE  // timing-only build: the epilogue's values go nowhere (no staging, no store loop): what a consumer fused into the epilogue could save
+            ablate_sink ^= words[0] ^ words[1];
+            (void)os_lane;
+#else
             *reinterpret_cast<uint2*>(os + ((os_lane ^ unsigned(cb << 5)) + unsigned(prow * 8192 + (pb & 1) * 4096))) = make_uint2(words[0], words[1]);
+#endif
         }
     }
 #else
@@ -524,6 +543,49 @@ __global__ __launch_bounds__(kConvThreads, kWaves == 8 ? 4 : 2) void conv3x3_epi
 #endif
     };
     if (MODE == 0 && a.clamp >= 0.f) registers_to_lds(std::true_type{}); else registers_to_lds(std::false_type{});
+#ifdef GNERF_ABLATE_CONVNOSTORE
+    if (MODE == 0 && !OUT32 && !RGB) { if (ablate_sink == 0x12345679u) a.y[tid] = (_Float16)0; continue; }
+#endif
+    if constexpr (RGB) {
+        // ToRGB from the STAGED tile (the layer's fp16 result, as the stand-alone ToRGB reads it from memory -- gnerf_torgb_nhwc_accumulate,
+        // csrc/modconv.hip: f16 weights x styles, v_dot2_f32_f16, the sum rounded to fp16, bias + clamp, rounded again, added to the fp32 image):
+        // two lanes per pixel, 64 channels each = eight 16-byte slots of the pixel's swizzled 256-byte row; the weights, [3][128] halves, are
+        // read from LDS as broadcasts.  A wave covers one tile row: a plane's 32 consecutive pixels are 128 contiguous bytes of the NCHW image.
+        // (From the accumulators instead -- every value multiplied into three per-lane sums before it is rounded -- the epilogue, already at the
+        // register limit, spilled 70-93 registers.)
+        __syncthreads();
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const char* const wrgb = ep + 1536;
+        for (int t2 = tid; t2 < 2 * kTH * kTW; t2 += kConvThreads) {
+            const int pp = t2 >> 1, half = t2 & 1;
+            float acc3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sl = 0; sl < 8; sl++) {
+                const int slot = 8 * half + sl;
+                const uint4 xv = *reinterpret_cast<const uint4*>(os + pp * 256 + ((slot ^ (pp & 15)) << 4));
+                const unsigned xq[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const uint4 wv4 = *reinterpret_cast<const uint4*>(wrgb + k * 256 + slot * 16);
+                    const unsigned wq[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc3[k] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, xq[e]), __builtin_bit_cast(h2, wq[e]), acc3[k], false);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) acc3[k] += __shfl_xor(acc3[k], 1);
+            if (half == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    float rv = round_to<__half>(acc3[k]) + (a.rgb_bias ? a.rgb_bias[k] : 0.f);
+                    if (a.rgb_clamp >= 0.f) rv = __builtin_amdgcn_fmed3f(rv, -a.rgb_clamp, a.rgb_clamp);
+                    float* const dst = a.img + ((size_t(n) * 3 + k) * H + y0 + pp / kTW) * W + x0 + pp % kTW;
+                    *dst += round_to<__half>(rv);
+                }
+            }
+        }
+        continue;
+    }
     if constexpr (OUT32) {
         if (MODE == 1) __syncthreads();                              // (uniform) the next phase's input tile must not land while a wave still reads this one's operands
         continue;
@@ -616,8 +678,15 @@ namespace {
 template <bool OUT32>
 int launch_conv3x3(const char* what, const void* x, const void* w_packed, void* y, int n, int h, int w, int cin, int cout,
                    const float* scale, const float* noise, int round_noise, const void* bias,
-                   float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream) {
+                   float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream,
+                   const void* rgb_w = nullptr, const float* rgb_bias = nullptr, float rgb_clamp = -1.f, float* img = nullptr) {
     using namespace gnerf;
+    if (img) {
+        if (OUT32 || !rgb_w || !scale || next_scale || cout != kCO)
+            return fail(GNERF_E_UNSUPPORTED, "%s: the ToRGB tail needs 128 output channels, a demodulation scale and no next-layer scale", what);
+        if ((reinterpret_cast<uintptr_t>(rgb_w) | reinterpret_cast<uintptr_t>(img)) & 3) return fail(GNERF_E_ARG, "%s: rgb_w and img must be 4-byte aligned", what);
+        y = const_cast<void*>(x);                                   // (never written: the checks below want a pointer)
+    }
     if (!x || !w_packed || !y) return fail(GNERF_E_ARG, "%s: null pointer", what);
     if (n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return fail(GNERF_E_ARG, "%s: empty tensor", what);
     if (h % kTH || w % kTW || cin % 8 || cout % kCO)
@@ -640,8 +709,22 @@ int launch_conv3x3(const char* what, const void* x, const void* w_packed, void* 
     a.tiles_x = w / kTW; a.tiles_y = h / kTH; a.n_tiles = n * a.tiles_x * a.tiles_y;
     a.out_h = h; a.out_w = w;
     a.round_noise = round_noise; a.alpha = alpha; a.gain = gain; a.clamp = clamp; a.phase_jobs = 0;
+    a.rgb_w = static_cast<const _Float16*>(rgb_w); a.rgb_bias = rgb_bias; a.rgb_clamp = rgb_clamp; a.img = img;
     const dim3 grid((a.n_tiles + kNumXCD - 1) / kNumXCD * kNumXCD, cout / kCO), block(kConvThreads);
     hipStream_t s = as_stream(stream);
+    if constexpr (!OUT32) {
+        if (img) {
+            static PerDeviceOnce once_rgb[2];
+            if (noise) {
+                if (int rc = once_rgb[1].raise_lds(conv3x3_epilogue_kernel<0, true, true, false, false, true>, what, kConvLds)) return rc;
+                hipLaunchKernelGGL((conv3x3_epilogue_kernel<0, true, true, false, false, true>), grid, block, kConvLds, s, a);
+            } else {
+                if (int rc = once_rgb[0].raise_lds(conv3x3_epilogue_kernel<0, true, false, false, false, true>, what, kConvLds)) return rc;
+                hipLaunchKernelGGL((conv3x3_epilogue_kernel<0, true, false, false, false, true>), grid, block, kConvLds, s, a);
+            }
+            return check_launch(what);
+        }
+    }
 #define GNERF_CONV(SC, NZ, NX) do { \
         static PerDeviceOnce once; \
         if (int rc = once.raise_lds(conv3x3_epilogue_kernel<0, SC, NZ, NX, OUT32>, what, kConvLds)) return rc; \
@@ -675,6 +758,7 @@ int launch_conv_transpose(const char* what, const void* x, const void* w_phases,
     a.x = static_cast<const _Float16*>(x); a.wpk = static_cast<const _Float16*>(w_phases);
     a.y = OUT32 ? nullptr : static_cast<_Float16*>(y); a.y32 = OUT32 ? static_cast<float*>(y) : nullptr;
     a.scale = nullptr; a.noise = nullptr; a.bias = nullptr; a.bias32 = nullptr; a.next_scale = nullptr;
+    a.rgb_w = nullptr; a.rgb_bias = nullptr; a.rgb_clamp = -1.f; a.img = nullptr;
     a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
     a.cin_pad = (cin + kCK - 1) / kCK * kCK;
     a.tiles_x = (w + 1 + kTW - 1) / kTW; a.tiles_y = (h + 1 + kTH - 1) / kTH;         // tiles over the (h + 1) x (w + 1) positions of the even phases
@@ -705,6 +789,16 @@ extern "C" int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, 
                                            const float* scale, const float* noise, int round_noise, const void* bias,
                                            float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream) {
     return launch_conv3x3<false>("conv3x3_epilogue_nhwc", x, w_packed, y, n, h, w, cin, cout, scale, noise, round_noise, bias, alpha, gain, clamp, next_scale, stream);
+}
+
+// (ABI 11) the convolution of a block's LAST layer with the block's ToRGB in its epilogue: img[n, 3, h, w] (float32) += ToRGB(layer(x)); no y at all
+extern "C" int gnerf_conv3x3_epilogue_torgb_nhwc(const void* x, const void* w_packed, int n, int h, int w, int cin,
+                                                 const float* scale, const float* noise, int round_noise, const void* bias,
+                                                 float alpha, float gain, float clamp,
+                                                 const void* rgb_w, const float* rgb_bias, float rgb_clamp, float* img, gnerf_stream_t stream) {
+    if (!img || !rgb_w) return gnerf::fail(GNERF_E_ARG, "conv3x3_epilogue_torgb_nhwc: null pointer");
+    return launch_conv3x3<false>("conv3x3_epilogue_torgb_nhwc", x, w_packed, nullptr, n, h, w, cin, kCO, scale, noise, round_noise, bias, alpha, gain, clamp, nullptr, stream,
+                                 rgb_w, rgb_bias, rgb_clamp, img);
 }
 
 // (ABI 10) the fp32-grade form: x3 = [hi | lo | hi] float16 from gnerf_split_f16x3_nhwc, w3 = [hi | hi | lo] packed like w_packed, float32 bias and result

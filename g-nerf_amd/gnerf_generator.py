@@ -123,6 +123,10 @@ def _packed_modulated_weight(module, nstyles, dtype, transposed=False):
 # GNERF_LATENT_WEIGHTS=0: a layer whose input scaling no earlier epilogue carries (the first layer of a block) scales its activations in a launch
 # of its own (gnerf_scale_channels), as until round 6, also when the whole batch shares ONE latent (an orbit: k views of one object)
 _LATENT_WEIGHTS = os.environ.get('GNERF_LATENT_WEIGHTS', '1') != '0'
+# GNERF_FUSED_TORGB=0: the last block of the superresolution keeps its three launches (layer, ToRGB added to the running image) instead of the
+# layer's convolution with the ToRGB in its epilogue and no layer output at all (gnerf_conv3x3_epilogue_torgb_nhwc, round 6)
+_FUSED_TORGB = os.environ.get('GNERF_FUSED_TORGB', '1') != '0'
+_TORGB_DONE = object()             # what StyledConv.forward(..., torgb_tail=...) returns when the tail ran in the convolution's launch
 # GNERF_FUSED_CONV=0: the 3x3 layers of the shared-weight form go to MIOpen + gnerf_modconv_epilogue_nhwc (round 4's flow) instead of
 # the one-launch kernel of csrc/conv3x3.hip
 _FUSED_CONV = os.environ.get('GNERF_FUSED_CONV', '1') != '0'
@@ -342,10 +346,13 @@ class StyledConv(nn.Module):
         x = upfirdn2d.upfirdn2d(x, self.resample_filter, padding=[1, 1, 1, 1], gain=4)
         return (x, False) if epilogue is not None else x
 
-    def forward(self, x, w, noise_mode='random', gain=1.0, fused=True, prescaled=False, next_layer=None, next_w=None):
+    def forward(self, x, w, noise_mode='random', gain=1.0, fused=True, prescaled=False, next_layer=None, next_w=None, torgb_tail=None):
         """prescaled: x already carries this layer's input scaling (see next_layer).  next_layer / next_w: the StyledConv that
         consumes the result and its w; where the shared-weight channels_last form applies, that layer's `x * styles` is folded
-        into this layer's epilogue, and the call returns (x, folded) instead of x."""
+        into this layer's epilogue, and the call returns (x, folded) instead of x.
+        torgb_tail = (ToRGB module, its w, img): the caller needs only `img += torgb(layer(x))` (a block whose x nothing else reads); where the
+        one-launch form applies (gnerf_hip.conv3x3_epilogue_torgb) it runs, img is updated in place and the call returns _TORGB_DONE --
+        otherwise x as always, and the caller goes on as without the argument."""
         assert noise_mode in ('random', 'const', 'none')
         n, c_in, h, wd = x.shape
         aff = (self.affine.weight, self.affine.bias)
@@ -403,6 +410,16 @@ class StyledConv(nn.Module):
                     nxt_aff = (next_layer.affine.weight, next_layer.affine.bias)
                     nxt = _per_latent(next_layer, next_w, 'nstyles', nxt_aff, lambda: gnerf_hip.normalise_styles(next_layer.affine(next_w)))
                     folded = True
+                if own_plain and torgb_tail is not None and nxt is None and gnerf_hip.conv3x3_epilogue_torgb_supported(x, c_out):
+                    # ... and the block's ToRGB, added to the running image, in the same launch; no layer output is written (round 6)
+                    tg, w_rgb, img = torgb_tail
+                    rgb_aff = (tg.affine.weight, tg.affine.bias)
+                    rgb_styles = _per_latent(tg, w_rgb, 'styles', rgb_aff, lambda: tg.affine(w_rgb) * tg.weight_gain)
+                    rgb_w = _per_latent(tg, w_rgb, 'rgbw16', rgb_aff + (tg.weight,), lambda: gnerf_hip.torgb_weights(tg.weight, rgb_styles))
+                    gnerf_hip.conv3x3_epilogue_torgb(x, packed if packed is not None else _packed_prenormalised_weight(self, x.dtype), img, rgb_w, _cast_param(tg, 'bias', x.dtype),
+                                                     tg.conv_clamp, bias=_cast_param(self, 'bias', x.dtype), scale=dco, noise=noise, round_noise=True,
+                                                     gain=LRELU_GAIN * gain, clamp=clamp)
+                    return _TORGB_DONE
                 if own_plain:
                     # convolution + demodulation + noise + bias + lrelu + clamp (+ the next layer's input scaling) in one launch
                     x = gnerf_hip.conv3x3_epilogue(x, packed if packed is not None else _packed_prenormalised_weight(self, x.dtype), _cast_param(self, 'bias', x.dtype), scale=dco, noise=noise,
@@ -535,8 +552,10 @@ class Block(nn.Module):
         self.torgb = ToRGB(c_out, img_channels, w_dim, conv_clamp=conv_clamp)
         self.num_conv, self.num_torgb = (1 if c_in == 0 else 2), 1
 
-    def forward(self, x, img, ws, noise_mode='random', force_fp32=False, fused_modconv=None):
+    def forward(self, x, img, ws, noise_mode='random', force_fp32=False, fused_modconv=None, discard_x=False):
+        """discard_x: the caller reads only the image (the superresolution's last block): x may come back as None."""
         dtype = torch.float16 if self.use_fp16 and ws.is_cuda and not force_fp32 else torch.float32
+        upsampled = False
         fused = (not self.training) if fused_modconv in (None, 'inference_only') else bool(fused_modconv)      # networks_stylegan2.py:433-434
         ws = ws.unbind(dim=1)
         if self.c_in == 0:
@@ -549,11 +568,21 @@ class Block(nn.Module):
             if dtype == torch.float16 and _FP16_CHANNELS_LAST and x.is_cuda and x.shape[1] % 8 == 0 and fast:
                 x = x.contiguous(memory_format=torch.channels_last)
             x, folded = self.conv0(x, ws[0], noise_mode, fused=fused, next_layer=self.conv1, next_w=ws[1])
-            x = self.conv1(x, ws[1], noise_mode, fused=fused, prescaled=folded)
+            tail = None
+            if (discard_x and _FUSED_TORGB and img is not None and img.is_cuda and img.dtype == torch.float32 and not self.emit_channels_last
+                    and self.torgb.streams_into_image(x, ws[-1]) and not torch.is_grad_enabled()):
+                # the layer's convolution takes the ToRGB into its epilogue and adds the result to the (upsampled) running image: no x is written
+                if self.up == 2:
+                    img, upsampled = upfirdn2d.upsample2d(img, self.resample_filter), True
+                if img.is_contiguous() and tuple(img.shape) == (x.shape[0], 3, x.shape[2], x.shape[3]):
+                    tail = (self.torgb, ws[-1], img)
+            x = self.conv1(x, ws[1], noise_mode, fused=fused, prescaled=folded, torgb_tail=tail)
+            if x is _TORGB_DONE:
+                return None, img
         if (img is not None and img.is_cuda and img.dtype == torch.float32 and not self.emit_channels_last and self.torgb.streams_into_image(x, ws[-1])
                 and not (torch.is_grad_enabled() and img.requires_grad)):
             # upsample the running image, then let ToRGB add its output to it in its own launch (no fp16 y, no conversion, no add kernel)
-            if self.up == 2:
+            if self.up == 2 and not upsampled:
                 img = upfirdn2d.upsample2d(img, self.resample_filter)
             if img.is_contiguous() and tuple(img.shape) == (x.shape[0], 3, x.shape[2], x.shape[3]):
                 return x, self.torgb(x, ws[-1], fused=fused, accumulate_into=img)
@@ -632,7 +661,7 @@ class SuperRes8XDC(nn.Module):
             x = F.interpolate(x_raw, size=(128, 128), mode='bilinear', align_corners=False, antialias=self.antialias)
             rgb = F.interpolate(image_raw, size=(128, 128), mode='bilinear', align_corners=False, antialias=self.antialias)
         x, rgb = self.block0(x, rgb, ws, noise_mode, **block_kwargs)
-        x, rgb = self.block1(x, rgb, ws, noise_mode, **block_kwargs)
+        x, rgb = self.block1(x, rgb, ws, noise_mode, discard_x=True, **block_kwargs)
         return rgb, image_raw
 
 

@@ -23,7 +23,7 @@ _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.float64: F64}
 
 MAX_SAMPLES = 256
 DEBUG_SLOTS = 8
-ABI_VERSION = 10
+ABI_VERSION = 11
 # decoder arithmetic of the fused renderer (GNERF_MLP_* in include/gnerf_hip.h)
 MLP_MODES = {'auto': 0, 'f16x3': 1, 'f32': 2}
 
@@ -103,6 +103,7 @@ SIGNATURES = {
     'gnerf_modconv_epilogue': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_i, _c_p, _c_i, _c_f, _c_f, _c_f, _c_p]),
     'gnerf_conv3x3_epilogue_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_p, _c_f, _c_f, _c_f, _c_p, _c_p]),
     'gnerf_conv_transpose3x3_s2_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p]),
+    'gnerf_conv3x3_epilogue_torgb_nhwc': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p, _c_i, _c_p, _c_f, _c_f, _c_f, _c_p, _c_p, _c_f, _c_p, _c_p]),
     'gnerf_split_f16x3_nhwc': (_c_i, [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p]),
     'gnerf_make_rays_and_draws': (_c_i, [_c_p, _c_p, _c_i, _c_i, _c_p, _c_p, _c_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32,
                                          _c_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, _c_p]),
@@ -765,6 +766,49 @@ def conv3x3_epilogue(x, w_packed, bias=None, scale=None, noise=None, round_noise
                                                   float(alpha), float(gain), float(-1 if clamp is None else clamp), _ptr(nx), _stream(x))
     _check(code, 'gnerf_conv3x3_epilogue_nhwc')
     return y
+
+
+def torgb_weights(weight, styles):
+    """float16 [N, 3, C] = half(weight[o, c] * styles[n, c]): the 1 x 1 weights gnerf_torgb_nhwc forms per workgroup, as conv3x3_epilogue_torgb takes
+    them (a constant of (latent, weight): cache it).  weight [3, C(, 1, 1)] float32, styles [N, C] float32 (ToRGB's affine output x its weight gain)."""
+    w = weight.detach().to(torch.float32).reshape(1, 3, -1)
+    return (w * styles.detach().to(torch.float32)[:, None, :]).to(torch.float16).contiguous()
+
+
+def conv3x3_epilogue_torgb_supported(x, c_out):
+    return conv3x3_epilogue_supported(x, c_out) and c_out == 128
+
+
+@profiled('gnerf_hip::conv3x3_epilogue_torgb')
+def conv3x3_epilogue_torgb(x, w_packed, img, rgb_w, rgb_bias=None, rgb_clamp=None, bias=None, scale=None, noise=None, round_noise=False, alpha=0.2, gain=1.0, clamp=None):
+    """img += ToRGB(conv3x3_epilogue(x, ...)) in ONE launch that stores no layer output (csrc/conv3x3.hip, ABI 11): the last layer of a block whose x
+    nothing else reads, with the block's ToRGB (rgb_w = torgb_weights(weight, styles) float16 [N,3,128], rgb_bias [3], rgb_clamp) in its epilogue and
+    the result added to the running image img float32 [N,3,H,W] (dense NCHW) in place -- conv3x3_epilogue followed by torgb_channels_last(...,
+    accumulate_into=img) with the same roundings.  x [N,C,H,W] float16 channels_last, w_packed [9,128,C padded] float16, scale [N,128] float32 (required)."""
+    _require_cuda(x, w_packed, img, rgb_w, rgb_bias, bias, scale, noise)
+    n, c, h, w = x.shape
+    o = w_packed.shape[1]
+    if not is_channels_last(x) or x.dtype != torch.float16 or tuple(w_packed.shape) != (9, 128, -(-c // 64) * 64) or w_packed.dtype != torch.float16 or not w_packed.is_contiguous():
+        raise RuntimeError('conv3x3_epilogue_torgb: x must be channels_last float16 [N,C,H,W] and w_packed contiguous float16 [9,128,C]')
+    if img.dtype != torch.float32 or tuple(img.shape) != (n, 3, h, w) or not img.is_contiguous():
+        raise RuntimeError('conv3x3_epilogue_torgb: img must be a dense float32 [N,3,H,W] tensor')
+    if rgb_w.dtype != torch.float16 or tuple(rgb_w.shape) != (n, 3, 128) or not rgb_w.is_contiguous() or scale is None:
+        raise RuntimeError('conv3x3_epilogue_torgb: rgb_w must be float16 [N,3,128] (torgb_weights) and a demodulation scale is required')
+    s32 = scale.detach().to(torch.float32).contiguous()
+    nz = None if noise is None else noise.detach().to(torch.float32).contiguous()
+    if s32.numel() != n * o or (nz is not None and nz.numel() != h * w):
+        raise RuntimeError('conv3x3_epilogue_torgb: scale must have N x 128 elements, noise H x W')
+    s32 = s32 if s32.data_ptr() % 16 == 0 else s32.clone()
+    b = None if bias is None else bias.detach().to(torch.float16).contiguous()
+    rb = None if rgb_bias is None else rgb_bias.detach().to(torch.float16).to(torch.float32).contiguous()       # (the stand-alone layer adds its float16 bias)
+    if (b is not None and b.numel() != o) or (rb is not None and rb.numel() != 3):
+        raise RuntimeError('conv3x3_epilogue_torgb: bias must have 128 elements, rgb_bias 3')
+    with _on_device(x.device):
+        code = load().gnerf_conv3x3_epilogue_torgb_nhwc(_ptr(x), _ptr(w_packed), n, h, w, c, _ptr(s32), _ptr(nz), 1 if round_noise else 0, _ptr(b),
+                                                        float(alpha), float(gain), float(-1 if clamp is None else clamp),
+                                                        _ptr(rgb_w), _ptr(rb), float(-1 if rgb_clamp is None else rgb_clamp), _ptr(img), _stream(x))
+    _check(code, 'gnerf_conv3x3_epilogue_torgb_nhwc')
+    return img
 
 
 def _split_weights_f16x3(weight):

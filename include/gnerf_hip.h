@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GNERF_ABI_VERSION 10
+#define GNERF_ABI_VERSION 11
 
 /* error codes */
 #define GNERF_OK            0
@@ -140,6 +140,18 @@ int gnerf_blur4_epilogue_nhwc(const void* x, const float* f, void* y, int dtype,
 int gnerf_conv3x3_epilogue_nhwc(const void* x, const void* w_packed, void* y, int n, int h, int w, int cin, int cout,
                                 const float* scale, const float* noise, int round_noise, const void* bias,
                                 float alpha, float gain, float clamp, const float* next_scale, gnerf_stream_t stream);
+/* (ABI 11) The convolution of a block's LAST layer with the block's ToRGB taken in its epilogue -- SynthesisBlock.forward's
+ * `x = conv1(x); y = torgb(x); img = img.add_(y)` (networks_stylegan2.py:452-463) where nothing else reads x (the superresolution's final block,
+ * superresolution.py:285-303) -- as ONE launch that writes no x at all:
+ *   img[n, o, p] += half( clamp( half( sum_c half(layer(x))[n, p, c] * rgb_w[n, o, c] ) + rgb_bias[o] ) )
+ * i.e. gnerf_conv3x3_epilogue_nhwc (cout = 128, next_scale = NULL, a demodulation scale given) followed by gnerf_torgb_nhwc_accumulate, with the
+ * same roundings: the layer's result is rounded to float16 where it would have been stored, the 1 x 1 products are v_dot2_f32_f16 on it.
+ * rgb_w: float16 [n, 3, 128] = half(ToRGB weight[o, c] * ToRGB styles[n, c]); rgb_bias: float32 [3] (the float16 bias's values) or NULL;
+ * rgb_clamp < 0: none; img: float32 [n, 3, h, w], dense, accumulated in place.  Other arguments and shape rules as gnerf_conv3x3_epilogue_nhwc. */
+int gnerf_conv3x3_epilogue_torgb_nhwc(const void* x, const void* w_packed, int n, int h, int w, int cin,
+                                      const float* scale, const float* noise, int round_noise, const void* bias,
+                                      float alpha, float gain, float clamp,
+                                      const void* rgb_w, const float* rgb_bias, float rgb_clamp, float* img, gnerf_stream_t stream);
 /* (ABI 9) The stride-2 transposed 3x3 convolution of the x2 layers -- conv_transpose2d(x, w, stride = 2), what conv2d_resample.py:109-119
  * hands to the framework for up = 2 -- for float16 channels_last activations, as its four output phases on the matrix cores (the kernel
  * of gnerf_conv3x3_epilogue_nhwc with 4 / 2 / 2 / 1 of its taps; fp32 accumulation, the result rounded to float16 once).

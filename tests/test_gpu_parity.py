@@ -1915,6 +1915,43 @@ def test_conv_transpose_job_shapes_agree(dev, monkeypatch):
         monkeypatch.delenv('GNERF_CONVT_PHASE_JOBS', raising=False)
 
 
+def test_conv3x3_epilogue_torgb_vs_two_launches(dev):
+    """gnerf_conv3x3_epilogue_torgb_nhwc (ABI 11) -- a block's last layer with the block's ToRGB in its epilogue, the result added to the running
+    image, no layer output stored (networks_stylegan2.py:452-463 for the superresolution's final block) -- against the two launches it replaces,
+    conv3x3_epilogue then torgb_channels_last(accumulate_into=img): the same roundings (the layer's result rounded to fp16, f16 weights x styles,
+    v_dot2_f32_f16, the sum rounded to fp16, bias + clamp, rounded again), so the images agree to the order of an fp32 sum in front of an fp16
+    rounding; with and without noise / ToRGB bias / clamps, several images and input-channel chunks, tiles at every border."""
+    import gnerf_hip
+    gen = torch.Generator().manual_seed(5)
+    for (n, cin, h, w, with_noise, with_rgb_bias, clamps) in [(2, 64, 16, 64, False, True, True), (1, 128, 8, 32, True, False, False), (3, 256, 24, 32, False, True, False),
+                                                               (2, 72, 8, 96, True, True, True)]:
+        x = (torch.randn(n, cin, h, w, generator=gen) * 0.7).to(dev).half().contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn(128, cin, 3, 3, generator=gen) / (3 * cin ** 0.5)).to(dev)
+        wpk = gnerf_hip.pack_conv3x3_weights(wt)
+        dco = (torch.rand(n, 128, generator=gen) + 0.5).to(dev)
+        bias = (torch.randn(128, generator=gen) * 0.1).to(dev)
+        noise = (torch.randn(h, w, generator=gen) * 0.05).to(dev) if with_noise else None
+        rgb_weight = torch.randn(3, 128, 1, 1, generator=gen).to(dev)
+        rgb_styles = ((torch.rand(n, 128, generator=gen) + 0.5) / 128 ** 0.5).to(dev)
+        rgb_bias = (torch.randn(3, generator=gen) * 0.2).to(dev) if with_rgb_bias else None
+        img0 = torch.randn(n, 3, h, w, generator=gen).to(dev)
+        kw = dict(bias=bias, scale=dco, noise=noise, round_noise=True, gain=2 ** 0.5, clamp=256.0 if clamps else None)
+        y = gnerf_hip.conv3x3_epilogue(x, wpk, **kw)
+        want = gnerf_hip.torgb_channels_last(y, rgb_weight, rgb_styles, rgb_bias, clamp=0.4 if clamps else None, accumulate_into=img0.clone())
+        assert gnerf_hip.conv3x3_epilogue_torgb_supported(x, 128)
+        got = gnerf_hip.conv3x3_epilogue_torgb(x, wpk, img0.clone(), gnerf_hip.torgb_weights(rgb_weight, rgb_styles), rgb_bias, 0.4 if clamps else None, **kw)
+        delta_want = (want - img0)
+        top = float(delta_want.abs().max())
+        diff = (got - want).abs()
+        assert top > 0.05 and float(diff.max()) <= 2 ** -9 * max(top, 1.0), (n, cin, h, w, float(diff.max()), top)       # an fp16 ulp of the layer's output at most
+        assert float((diff > 0).float().mean()) < 0.05, float((diff > 0).float().mean())
+        if clamps:
+            assert float(delta_want.abs().max()) <= 0.4 + 1e-3
+    assert not gnerf_hip.conv3x3_epilogue_torgb_supported(x, 256)
+    with pytest.raises(RuntimeError):                           # a demodulation scale is part of the form
+        gnerf_hip.conv3x3_epilogue_torgb(x, wpk, img0.clone(), gnerf_hip.torgb_weights(rgb_weight, rgb_styles), scale=None)
+
+
 def test_conv3x3_epilogue_vs_composed_ops(dev):
     """csrc/conv3x3.hip -- the 3x3 convolution of a modulated-convolution layer and its epilogue in one launch (SURVEY 8(f)3;
     networks_stylegan2.py:41-98 as SynthesisLayer.forward calls it, :315-334) -- against the two launches it replaces: torch's
@@ -2177,7 +2214,7 @@ def test_config3_n4_gpu_vs_reference_fixture(dev, golden, monkeypatch):
     G, _ = C.build(dev)
     import gnerf_hip
     import gnerf_generator as GG
-    own = {'conv3x3_epilogue': [], 'conv_transpose3x3_s2': []}
+    own = {'conv3x3_epilogue': [], 'conv_transpose3x3_s2': [], 'conv3x3_epilogue_torgb': []}
     real_fns = {name: getattr(gnerf_hip, name) for name in own}
     for name in own:
         monkeypatch.setattr(gnerf_hip, name, (lambda real_fn, name: lambda x, w, *a, **kw: (own[name].append((x.shape[0], x.shape[1], w.shape[1], x.shape[2])), real_fn(x, w, *a, **kw))[1])(real_fns[name], name))
@@ -2194,7 +2231,7 @@ def test_config3_n4_gpu_vs_reference_fixture(dev, golden, monkeypatch):
         # round 6: the ROUTE is part of the test.  fp16 superresolution: every 3x3 layer the kernel's shape gate admits runs on csrc/conv3x3.hip
         # (block0.conv1, block1.conv1 fused with their epilogues; block0.conv0, block1.conv0 as the transposed form); fp32: none does.
         if force_fp32:
-            assert not own['conv3x3_epilogue'] and not own['conv_transpose3x3_s2'], own
+            assert not own['conv3x3_epilogue'] and not own['conv_transpose3x3_s2'] and not own['conv3x3_epilogue_torgb'], own
             # ... the float32 layers from 64^2 up run in fp32-grade arithmetic on the same kernel (gnerf_hip.conv3x3_f32x3_epilogue: x3 has three
             # times the layer's input channels): backbone b64.conv1, b128.conv1, b256.conv1 and the superresolution's block0.conv1, block1.conv1;
             # the x2 layers b64.conv0 ... b256.conv0, block0.conv0, block1.conv0 on its transposed form
@@ -2202,7 +2239,8 @@ def test_config3_n4_gpu_vs_reference_fixture(dev, golden, monkeypatch):
             assert sorted(own32['conv_transpose3x3_s2_f32x3']) == [(4, 96, 256, 128), (4, 768, 128, 128), (4, 768, 128, 256), (4, 1536, 256, 64), (4, 1536, 512, 32)], own32
             assert int(gnerf_hip.split_overflow_flag(dev).item()) == 0
         else:
-            assert sorted(own['conv3x3_epilogue']) == [(4, 128, 128, 512), (4, 256, 256, 256)], own
+            # (the LAST block's conv1 with the block's ToRGB in its epilogue, no layer output: gnerf_conv3x3_epilogue_torgb_nhwc)
+            assert sorted(own['conv3x3_epilogue']) == [(4, 256, 256, 256)] and own['conv3x3_epilogue_torgb'] == [(4, 128, 128, 512)], own
             assert sorted(own['conv_transpose3x3_s2']) == [(4, 32, 256, 128), (4, 256, 128, 256)], own
             # (the backbone is float32 in both legs: its six layers from 64^2 up)
             assert sorted(own32['conv3x3_f32x3_epilogue']) == [(4, 384, 128, 256), (4, 768, 256, 128), (4, 1536, 512, 64)], own32
@@ -2223,16 +2261,25 @@ def test_config3_n4_gpu_vs_reference_fixture(dev, golden, monkeypatch):
     for name in own:
         own[name].clear()
     _, out_plain = C.run_config3(G, dev)
-    assert not own['conv3x3_epilogue'] and not own['conv_transpose3x3_s2'], own
+    assert not own['conv3x3_epilogue'] and not own['conv_transpose3x3_s2'] and not own['conv3x3_epilogue_torgb'], own
     assert float(((out_plain['image'][:, :, 4::8, 4::8].cpu().numpy() - g['image_sub']) ** 2).mean()) < 1e-4
     _, out_fused = (monkeypatch.setattr(GG, '_FUSED_CONV', True), C.run_config3(G, dev))[1]
     assert float(((out_plain['image'] - out_fused['image']) ** 2).mean()) < 1e-5
+    # GNERF_FUSED_TORGB=0: the last block as three launches (layer, ToRGB into the image) -- the same roundings, so the same image up to the order
+    # of an fp32 sum in front of an fp16 rounding
+    monkeypatch.setattr(GG, '_FUSED_TORGB', False)
+    for name in own:
+        own[name].clear()
+    _, out_three = C.run_config3(G, dev)
+    assert sorted(own['conv3x3_epilogue']) == [(4, 128, 128, 512), (4, 256, 256, 256)] and not own['conv3x3_epilogue_torgb'], own
+    assert float((out_three['image'] - out_fused['image']).abs().max()) < 4e-3 and float(((out_three['image'] - out_fused['image']) ** 2).mean()) < 1e-8
+    monkeypatch.setattr(GG, '_FUSED_TORGB', True)
     # a batch of ONE takes the shared-weight form and the same kernels (the frame-by-frame orbit)
     for name in own:
         own[name].clear()
     with torch.no_grad(), C.DI.DetNoise('config3'):
         one = G.synthesis(G.mapping(b['z'][:1], b['c'][:1]), b['c'][:1], noise_mode='const', neural_rendering_resolution=64)
-    assert sorted(own['conv3x3_epilogue']) == [(1, 128, 128, 512), (1, 256, 256, 256)] and len(own['conv_transpose3x3_s2']) == 2, own
+    assert sorted(own['conv3x3_epilogue']) == [(1, 256, 256, 256)] and own['conv3x3_epilogue_torgb'] == [(1, 128, 128, 512)] and len(own['conv_transpose3x3_s2']) == 2, own
     assert float(((one['image'][:, :, 4::8, 4::8].cpu().numpy() - g['image_sub'][:1]) ** 2).mean()) < 1e-4
 
 
