@@ -63,6 +63,14 @@ constexpr int kCO = 128;                            // output channels per workg
 #ifndef GNERF_CONV_COUNTED_WAITS
 #define GNERF_CONV_COUNTED_WAITS 0
 #endif
+// GNERF_CONV_NT: 1 = the input tile's LDS-DMA loads non-temporal, 2 = the output stores non-temporal, 3 = both, 4 (shipped, round 6) = the plain
+// convolution's output stores only.  The output is streamed (written once, read by the NEXT kernel) and should not evict the weights that every
+// workgroup of an XCD re-reads from its L2: alone the kernel is 1-5 % faster with 2 (profiles/r06_conv_nt_ab.txt), in the orbit's pipeline -- the
+// next kernel reads what was stored -- 8 views per call go from 2 838-2 856 to 2 879-2 884 frames/s.  The input tile is NOT stream-once (halos,
+// the transposed form's four phases): 1 is 10-20 % slower on the transposed form; the transposed form's stores are a wash.
+#ifndef GNERF_CONV_NT
+#define GNERF_CONV_NT 4
+#endif
 constexpr int kWaves = GNERF_CONV_WAVES;
 constexpr int kCoSplit = GNERF_CONV_COSPLIT;
 static_assert(kWaves == 4 || kWaves == 8, "4 or 8 waves per workgroup");
@@ -111,6 +119,7 @@ struct ConvArgs {
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef unsigned u4nt __attribute__((ext_vector_type(4)));     // (what __builtin_nontemporal_store takes: GNERF_CONV_NT)
 #ifndef GNERF_CONV_EPILOGUE_F32
 #define GNERF_CONV_EPILOGUE_F32 1
 #endif
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(kConvThreads, kWaves == 8 ? 4 : 2) void conv3x3_epi
             const int cg = cin0 + ((slot ^ (pix & 7)) << 3);        // first of this piece's eight input channels
             const bool ok = pix < kIH * kIW && iy >= 0 && iy < H && ix >= 0 && ix < W && cg < Cin;      // (cin below a multiple of 64: the last chunk's tail reads as zeros)
             const unsigned off = ok ? unsigned(((iy * W + ix) * Cin + cg) * 2) : 0x80000000u;     // out of range: zeros
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(xs + (it * kConvThreads + wv * 64) * 16), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(xs + (it * kConvThreads + wv * 64) * 16), 16, off, 0, 0, (GNERF_CONV_NT & 1) ? 2 : 0);
         }
     };
     // weights of (tap, 64 input channels) -> buffer `buf`.  Lane (co = (threads / 8) it + tid / 8, slot = tid % 8) of trip `it` reads 16 bytes of output
@@ -607,10 +616,10 @@ __global__ __launch_bounds__(kConvThreads, kWaves == 8 ? 4 : 2) void conv3x3_epi
             const int yy = y0 + it * kStorePix / kTW, xc = x0 + it * kStorePix % kTW;     // (uniform) row of the tile, first of this trip's columns
             if constexpr (MODE == 1) {                                 // position (yy, xx) of phase (py, px) -> output pixel (2 yy + py, 2 xx + px); the grid of tiles overhangs
                 _Float16* const row = a.y + ((size_t(n) * a.out_h + size_t(2 * yy + ph_y)) * a.out_w + size_t(2 * xc + ph_x)) * Cout + co0;
-                if (yy < Hp && xc + lp < Wp) *reinterpret_cast<uint4*>(row + out_lane) = v;
+                if (yy < Hp && xc + lp < Wp) { if (GNERF_CONV_NT & 2) __builtin_nontemporal_store(__builtin_bit_cast(u4nt, v), reinterpret_cast<u4nt*>(row + out_lane)); else *reinterpret_cast<uint4*>(row + out_lane) = v; }
             } else {
                 _Float16* const row = a.y + (size_t(n) * H * W + size_t(yy) * W + xc) * Cout + co0;
-                *reinterpret_cast<uint4*>(row + out_lane) = v;
+                if (GNERF_CONV_NT & 6) __builtin_nontemporal_store(__builtin_bit_cast(u4nt, v), reinterpret_cast<u4nt*>(row + out_lane)); else *reinterpret_cast<uint4*>(row + out_lane) = v;
             }
         }
     }
