@@ -16,6 +16,12 @@ using namespace gnerf;
 
 // (Round 6, profiles/r06_repack_tile_ab.jsonl: 32 x 128 and 32 x 256 tiles -- 16 / 32 dword loads in flight per lane instead of 8 -- move the
 //  headline step by -0.4 %: the pass is not short of bytes in flight; at 200 MB in 50 us it runs at the rate HBM gives a read + write stream.)
+// GNERF_REPACK_NT (experiment, profiles/r06_repack_nt_ab.jsonl): 1 = the NCHW source read non-temporal, 2 = the result stored so, 3 = both: the
+// headline step gets SLOWER by 15 / 14 / 31 us of 553 -- at the default policy a part of the source still comes from the Infinity Cache and the
+// render kernel finds the result there; off
+#ifndef GNERF_REPACK_NT
+#define GNERF_REPACK_NT 0
+#endif
 #ifndef GNERF_REPACK_PX
 #define GNERF_REPACK_PX 64
 #endif
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         const int e = threadIdx.x + 256 * i;
         const int ch = e / PT, px = e % PT;
         float v = 0.f;
-        if (c0 + ch < c && p0 + px < hw) v = s[int64_t(c0 + ch) * hw + p0 + px];
+        if (c0 + ch < c && p0 + px < hw) v = (GNERF_REPACK_NT & 1) ? __builtin_nontemporal_load(s + int64_t(c0 + ch) * hw + p0 + px) : s[int64_t(c0 + ch) * hw + p0 + px];
         tile[ch][px] = v;
         if (STATS) amax = max(amax, abs_bits(v));
     }
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     for (int i = 0; i < CT * PT / 256; i++) {
         const int e = threadIdx.x + 256 * i;
         const int px = e / CT, ch = e % CT;
-        if (c0 + ch < c && p0 + px < hw) d[(p0 + px) * c + c0 + ch] = tile[ch][px];
+        if (c0 + ch < c && p0 + px < hw) { if (GNERF_REPACK_NT & 2) __builtin_nontemporal_store(tile[ch][px], d + (p0 + px) * c + c0 + ch); else d[(p0 + px) * c + c0 + ch] = tile[ch][px]; }
     }
     if (STATS) publish_absmax(amax, absmax);
 }
