@@ -721,6 +721,9 @@ int launch_conv3x3(const char* what, const void* x, const void* w_packed, void* 
     a.rgb_w = static_cast<const _Float16*>(rgb_w); a.rgb_bias = rgb_bias; a.rgb_clamp = rgb_clamp; a.img = img;
     const dim3 grid((a.n_tiles + kNumXCD - 1) / kNumXCD * kNumXCD, cout / kCO), block(kConvThreads);
     hipStream_t s = as_stream(stream);
+#if !GNERF_CONV_EPILOGUE_F32
+    if (img) return fail(GNERF_E_UNSUPPORTED, "%s: this build (GNERF_CONV_EPILOGUE_F32=0) has no ToRGB tail", what);
+#else
     if constexpr (!OUT32) {
         if (img) {
             static PerDeviceOnce once_rgb[2];
@@ -734,6 +737,7 @@ int launch_conv3x3(const char* what, const void* x, const void* w_packed, void* 
             return check_launch(what);
         }
     }
+#endif
 #define GNERF_CONV(SC, NZ, NX) do { \
         static PerDeviceOnce once; \
         if (int rc = once.raise_lds(conv3x3_epilogue_kernel<0, SC, NZ, NX, OUT32>, what, kConvLds)) return rc; \
