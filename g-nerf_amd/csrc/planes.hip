@@ -15,7 +15,8 @@ namespace {
 using namespace gnerf;
 
 // (Round 6, profiles/r06_repack_tile_ab.jsonl: 32 x 128 and 32 x 256 tiles -- 16 / 32 dword loads in flight per lane instead of 8 -- move the
-//  headline step by -0.4 %: the pass is not short of bytes in flight; at 200 MB in 50 us it runs at the rate HBM gives a read + write stream.)
+//  headline step by -0.4 %: the pass is not short of bytes in flight; at 200 MB in 50 us it runs at the rate HBM gives a read + write stream --
+//  profiles/r06_step_copy_bound.json: in the step it costs 51.8 us incl. its memset where torch's copy kernel on the same 100 MB costs 45.3.)
 // GNERF_REPACK_NT (experiment, profiles/r06_repack_nt_ab.jsonl): 1 = the NCHW source read non-temporal, 2 = the result stored so, 3 = both: the
 // headline step gets SLOWER by 15 / 14 / 31 us of 553 -- at the default policy a part of the source still comes from the Infinity Cache and the
 // render kernel finds the result there; off
