@@ -54,7 +54,10 @@ struct Params {
     float inv_start, inv_end, disp_delta;
     int tiles_c, tiles_f;   // 16-sample MLP tiles
     int n_tiles;            // ray tiles in the grid
-    int tiles_per_item, tiles_y;   // image tiling (0 when rays are not an image)
+    int tiles_per_item, tiles_y;   // image tiling (0 when rays are not an image).  tiles_per_item == 0 with tiles_y > 0 (set by the staged backward
+                            // of RAGGED calls only: several items, rays per item not a multiple of 16): every item's rays are padded to tiles_y,
+                            // a multiple of 16, in the ray SEQUENCE, so that no 16-ray tile straddles items -- linear_pad() below.  (Kept in a
+                            // field the forward already has: one more kernel argument cost the headline kernel eight spilled SGPRs.)
     int total_rays;
     int split_shift;        // small launches: a 16-ray tile is shared by 1 << split_shift workgroups (coop / generic / backward kernels)
     int pipe_unit;          // pipelined kernel: rays dealt to a workgroup at a time (kPipeUnit; fewer for launches that do not fill the chip)
@@ -68,6 +71,8 @@ struct Params {
     int64_t bwd_ray_stride;
     int bwd_tile_pitch;
 };
+__host__ __device__ __forceinline__ int linear_pad(const Params& P) { return P.tiles_per_item == 0 ? P.tiles_y : 0; }
+
 
 // ---- order-preserving float <-> uint so that integer atomics give float min/max
 __device__ __forceinline__ unsigned ord_encode(float f) {
@@ -1062,7 +1067,23 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
     // Staged scatter (see plane_scatter_kernel): needs the caller's staging buffer, a plane gradient to make, and ray tiles that do
     // not straddle items.  GNERF_BWD_SCATTER=direct|staged forces one route (A/B runs and tests).
     const char* route = getenv("GNERF_BWD_SCATTER");
-    const bool tiles_ok = P.tiles_per_item > 0 || p->n_items == 1 || p->rays_per_item % kBwdRaysPerWave == 0;
+    bool tiles_ok = P.tiles_per_item > 0 || p->n_items == 1 || p->rays_per_item % kBwdRaysPerWave == 0;
+    {
+        // Round 6: a ragged call (several items whose ray count is no multiple of 16) no longer drops to the one-wave-per-ray kernel with
+        // float atomics: where the pipelined kernels and the binned scatter cover the shape, the ray SEQUENCE pads every item to whole 16-ray
+        // tiles (pipe_seq_to_ray / bin_tile_ray answer -1 for the padding, which every kernel of the path already skips)
+        const char* bk = getenv("GNERF_BWD_KERNEL");
+        const int n_all_r = p->depth_resolution + p->depth_resolution_importance;
+        const bool piped_shape = P.tiles_c <= 9 && P.tiles_f >= 1 && P.tiles_f <= 9 && !(bk && !strcmp(bk, "wave")) && !(route && (!strcmp(route, "direct") || !strcmp(route, "sorted")));
+        const bool binned_shape = int64_t(P.total_rays) * n_all_r * 33 < (int64_t(1) << 32) &&
+                                  (2 * size_t(3) * ((p->plane_h + kBinTile - 1) / kBinTile) * ((p->plane_w + kBinTile - 1) / kBinTile) + 128) * 4 <= 150 * 1024;
+        const int pad = (p->rays_per_item + kBwdRaysPerWave - 1) / kBwdRaysPerWave * kBwdRaysPerWave;
+        if (!tiles_ok && g->scatter_stage && g->grad_planes_nhwc && piped_shape && binned_shape && int64_t(p->n_items) * pad < INT32_MAX) {
+            P.tiles_y = pad;                                        // (tiles_per_item == 0: linear_pad(P))
+            P.n_tiles = p->n_items * (pad / kBwdRaysPerWave);
+            tiles_ok = true;
+        }
+    }
     bool staged = g->scatter_stage != nullptr && g->grad_planes_nhwc != nullptr && tiles_ok;
     if (route && !strcmp(route, "direct")) staged = false;
     if (route && !strcmp(route, "staged") && !staged) return fail(GNERF_E_ARG, "render_backward: the staged scatter needs scatter_stage, a plane gradient and whole tiles per item");
@@ -1102,7 +1123,7 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
         P.p.mlp_mode = mode_of(getenv("GNERF_BWD_MLP_K1"), P.p.mlp_mode);
         P2.p.mlp_mode = mode_of(getenv("GNERF_BWD_MLP_K2"), P2.p.mlp_mode);
         const int pipe_tp = (P.tiles_c <= 3 && P.tiles_f <= 3) ? 1 : ((P.tiles_c <= 6 && P.tiles_f <= 6) ? 2 : 3);
-        const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : total;
+        const int64_t total_seq = (P.tiles_per_item > 0 || linear_pad(P) > 0) ? int64_t(P.n_tiles) * 16 : total;
         const int per_cu = pipe_tp == 1 ? GNERF_PIPE_WAVES_PER_SIMD : (pipe_tp == 2 ? GNERF_PIPE2_WAVES_PER_SIMD : 2);
         const int64_t capacity = int64_t(per_cu) * kNumCU;
         P.pipe_unit = kPipeUnit;

@@ -1038,7 +1038,7 @@ __device__ __forceinline__ void render_bwd_tiles_body(const Params& P, const gne
     // tiles of the locality-ordered ray sequence (pipe_seq_to_ray): XCD x owns a contiguous eighth (workgroups b, b+8, ... share an
     // XCD), cut into equal contiguous runs for the XCD's waves
     const int tiles_per_ray = (n_all + 15) >> 4;
-    const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : int64_t(P.total_rays);
+    const int64_t total_seq = (P.tiles_per_item > 0 || linear_pad(P) > 0) ? int64_t(P.n_tiles) * 16 : int64_t(P.total_rays);
     const int xcd = blockIdx.x % kNumXCD, wg = blockIdx.x / kNumXCD, wgs = gridDim.x / kNumXCD;
     const int64_t x0 = total_seq * xcd / kNumXCD * tiles_per_ray, x1 = total_seq * (xcd + 1) / kNumXCD * tiles_per_ray;
     const int64_t waves = int64_t(wgs) * kTileWaves, me = int64_t(wg) * kTileWaves + wv;
@@ -1046,7 +1046,7 @@ __device__ __forceinline__ void render_bwd_tiles_body(const Params& P, const gne
     for (int64_t t = t0; t < t1; t++) {
         const int64_t seq = t / tiles_per_ray;
         const int T = int(t - seq * tiles_per_ray);
-        const int ray = pipe_seq_to_ray(P, seq);
+        const int ray = pipe_seq_to_ray<true>(P, seq);
         if (ray < 0) continue;
         const int item = ray / p.rays_per_item;
         const int live = min(16, n_all - 16 * T);

@@ -76,6 +76,8 @@ __host__ __device__ inline size_t pipe_lds_floats(int tp, int mlp, bool gen = fa
 }
 
 // position `seq` of the locality-ordered ray sequence -> ray index (or -1 past the end)
+// PADDED: instantiations of the backward only (linear_pad(P) is never set on a forward call: the forward kernels do not carry the branch)
+template <bool PADDED = false>
 __device__ __forceinline__ int pipe_seq_to_ray(const Params& P, int64_t seq) {
     const gnerf_render_params& p = P.p;
     if (P.tiles_per_item > 0) {
@@ -83,6 +85,12 @@ __device__ __forceinline__ int pipe_seq_to_ray(const Params& P, int64_t seq) {
         const int item = tile / P.tiles_per_item, tt = tile % P.tiles_per_item;
         const int tx = tt / P.tiles_y, ty = tt % P.tiles_y;
         return item * p.rays_per_item + (ty * 4 + (rr >> 2)) * p.image_width + tx * 4 + (rr & 3);
+    }
+    if constexpr (PADDED) {
+        if (const int pad = linear_pad(P); pad > 0) {         // (the staged backward of ragged calls: items padded to whole 16-ray tiles)
+            const int item = int(unsigned(seq) / unsigned(pad)), local = int(unsigned(seq) - unsigned(item) * unsigned(pad));     // (seq < 2^31: checked by the launcher)
+            return (item < p.n_items && local < p.rays_per_item) ? item * p.rays_per_item + local : -1;
+        }
     }
     return seq < P.total_rays ? int(seq) : -1;
 }
@@ -175,7 +183,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
     // units of each other, i.e. on neighbouring rays, so the XCD's 4 MB L2 holds the texels they share.  (Giving each
     // workgroup one long contiguous run instead spreads the XCD over 96 distant image regions: measured 1.3 GB of L2
     // misses per launch; dealing units of 8 rays is 10 % faster, 4-16 are within 3 % of each other.)  Speed only -- any assignment is correct.
-    const int64_t total_seq = P.tiles_per_item > 0 ? int64_t(P.n_tiles) * 16 : int64_t(P.total_rays);
+    const int64_t total_seq = (P.tiles_per_item > 0 || (BWD && linear_pad(P) > 0)) ? int64_t(P.n_tiles) * 16 : int64_t(P.total_rays);
     const int W = gridDim.x / kNumXCD, xcd = blockIdx.x % kNumXCD, wg = blockIdx.x / kNumXCD;
     const int64_t x0 = total_seq * xcd / kNumXCD, x1 = total_seq * (xcd + 1) / kNumXCD;
     const int unit = P.pipe_unit;
@@ -184,7 +192,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
     const int nr = my_units * unit;
     auto local_to_ray = [&](int r) -> int {
         const int64_t seq = x0 + (int64_t(wg) + int64_t(r / unit) * W) * unit + r % unit;
-        return seq < x1 ? pipe_seq_to_ray(P, seq) : -1;
+        return seq < x1 ? pipe_seq_to_ray<BWD>(P, seq) : -1;
     };
 
     stage_decoder<MLP>(L, smem, p, tid, kPipeThreads);
@@ -202,7 +210,7 @@ __device__ __forceinline__ void render_pipe_body(const Params& P, float* smem, c
         if (GEN && p.cam2world && r >= 0 && r < nr && r % unit == 0 && lane < unit) {
             // rays of this dealing unit, one lane each (r .. r + unit - 1 are consecutive positions of the sequence)
             const int64_t seq = x0 + (int64_t(wg) + int64_t(r / unit) * W) * unit + lane;
-            const int id = seq < x1 ? pipe_seq_to_ray(P, seq) : -1;
+            const int id = seq < x1 ? pipe_seq_to_ray<BWD>(P, seq) : -1;
             if (id >= 0) {
                 const int item = id / p.rays_per_item, m = id - item * p.rays_per_item;
                 const float* M = p.cam2world + item * 16;

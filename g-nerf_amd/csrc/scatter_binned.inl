@@ -125,6 +125,11 @@ __device__ __forceinline__ int64_t bin_tile_ray(const Params& P, int tile, int i
         const int tx = tt / P.tiles_y, ty = tt % P.tiles_y;
         return int64_t(item) * p.rays_per_item + int64_t(ty * 4 + (i >> 2)) * p.image_width + tx * 4 + (i & 3);
     }
+    if (const int pad = linear_pad(P); pad > 0) {             // (ragged calls: pipe_seq_to_ray's padded order)
+        const int64_t seq = int64_t(tile) * 16 + i;
+        const int item = int(seq / pad), local = int(seq - int64_t(item) * pad);
+        return (item < p.n_items && local < p.rays_per_item) ? int64_t(item) * p.rays_per_item + local : -1;
+    }
     const int64_t ray = int64_t(tile) * 16 + i;
     return ray < P.total_rays ? ray : -1;
 }

@@ -1132,6 +1132,7 @@ def _entrywise_ok(a, b, rtol=5e-3, floor=2e-4):
     dict(N=1, res=4, S=12, F=0, hw=(8, 8)),                 # no importance pass
     dict(N=1, res=4, S=96, F=96, hw=(16, 16), white_back=True),
     dict(N=3, res=4, S=4, F=5, hw=(4, 4)),
+    dict(N=3, res=5, S=20, F=24, hw=(12, 10)),              # ragged ITEMS: 25 rays each, no image tiling -- round 6: items padded to whole ray tiles on the staged route
     dict(N=1, res=3, S=130, F=100, hw=(8, 8)),              # beyond 96+96, ragged tiles, 9 rays: partial workgroup
     dict(N=1, res=2, S=256, F=256, hw=(8, 8)),              # GNERF_MAX_SAMPLES on both passes (159 KB of LDS per workgroup)
 ])
@@ -1190,6 +1191,33 @@ def test_render_backward_vs_oracle(dev, cfg, monkeypatch):
     assert none_dec is None
     ref_planes2, _ = _oracle_grads(planes, dec, o, d, nc, nf, opts, g_rgb, torch.zeros_like(g_depth), torch.zeros_like(g_wsum))
     assert _rel(gp2.reshape(N, 3, *cfg['hw'], 32).permute(0, 1, 4, 2, 3).cpu(), ref_planes2) < 2e-3
+
+
+def test_render_backward_ragged_items_take_the_staged_route(dev, monkeypatch):
+    """Several items whose ray count is no multiple of 16 and no image tiling: until round 6 such a call left the staged route for the
+    one-wave-per-ray kernel with float atomics (a 16-ray tile would straddle items).  The ray sequence now pads every item to whole tiles:
+    GNERF_BWD_SCATTER=staged -- which REFUSES a call the staged route cannot take -- succeeds, the result agrees with the fp64 oracle, and it is
+    bit-identical from run to run (the binned scatter's property)."""
+    import gnerf_hip
+    N, res, S, F, hw = 4, 7, 48, 48, (24, 20)
+    planes, dec, o, d, nc, nf = _random_scene(23, N=N, res=res, S=S, F=F, hw=hw)
+    M = res * res
+    gen = torch.Generator().manual_seed(8)
+    g_rgb, g_depth, g_wsum = torch.randn(N, M, 32, generator=gen), torch.randn(N, M, 1, generator=gen), torch.randn(N, M, 1, generator=gen)
+    opts = dict(depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, clamp_mode='softplus', white_back=False)
+    ref_planes, ref_dec = _oracle_grads(planes, dec, o, d, nc, nf, opts, g_rgb, g_depth, g_wsum)
+    nhwc = gnerf_hip.planes_to_nhwc(planes.to(dev))
+    monkeypatch.setenv('GNERF_BWD_SCATTER', 'staged')
+    runs = []
+    for _ in range(2):
+        gp, gdec = gnerf_hip.render_backward(nhwc, N, [t.to(dev) for t in dec], o.to(dev), d.to(dev), nc.to(dev), nf.to(dev), g_rgb.to(dev), g_depth.to(dev), g_wsum.to(dev),
+                                             depth_resolution=S, depth_resolution_importance=F, ray_start=2.25, ray_end=3.3, box_warp=1.0, image_width=0, staged_scatter=True)
+        runs.append(gp)
+    assert torch.equal(runs[0], runs[1])
+    gp_nchw = runs[0].reshape(N, 3, *hw, 32).permute(0, 1, 4, 2, 3).cpu()
+    assert _rel(gp_nchw, ref_planes) < 2e-3 and _rel_l2(gp_nchw, ref_planes) < 1e-3 and _entrywise_ok(gp_nchw, ref_planes)
+    for name, a, b in zip(['w1', 'b1', 'w2', 'b2'], gdec, ref_dec):
+        assert _rel(a.cpu(), b) < 2e-3 and _rel_l2(a.cpu(), b) < 1e-3, name
 
 
 def test_render_backward_f16_tile_kernel_agrees_with_fp32_on_every_run(dev, monkeypatch):
