@@ -1074,7 +1074,7 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
         // tiles (pipe_seq_to_ray / bin_tile_ray answer -1 for the padding, which every kernel of the path already skips)
         const char* bk = getenv("GNERF_BWD_KERNEL");
         const int n_all_r = p->depth_resolution + p->depth_resolution_importance;
-        const bool piped_shape = P.tiles_c <= 9 && P.tiles_f >= 1 && P.tiles_f <= 9 && !(bk && !strcmp(bk, "wave")) && !(route && (!strcmp(route, "direct") || !strcmp(route, "sorted")));
+        const bool piped_shape = P.tiles_c <= 9 && P.tiles_f <= 9 && !(bk && !strcmp(bk, "wave")) && !(route && (!strcmp(route, "direct") || !strcmp(route, "sorted")));
         const bool binned_shape = int64_t(P.total_rays) * n_all_r * 33 < (int64_t(1) << 32) &&
                                   (2 * size_t(3) * ((p->plane_h + kBinTile - 1) / kBinTile) * ((p->plane_w + kBinTile - 1) / kBinTile) + 128) * 4 <= 150 * 1024;
         const int pad = (p->rays_per_item + kBwdRaysPerWave - 1) / kBwdRaysPerWave * kBwdRaysPerWave;
@@ -1095,7 +1095,9 @@ extern "C" int gnerf_render_backward(const gnerf_render_params* p, const gnerf_r
     // (a decoder-only request with an exchange buffer -- gnerf_render_backward_exchange_bytes -- takes the same two kernels: no dX rows,
     // no second pass)
     const bool exchange_only = g->scatter_stage != nullptr && g->grad_planes_nhwc == nullptr && n_dec == 4;
-    const bool piped = (staged || exchange_only) && P.tiles_c <= 9 && P.tiles_f >= 1 && P.tiles_f <= 9 && small_planes && !(bwd_kernel && !strcmp(bwd_kernel, "wave"))
+    // (round 6: F = 0 too -- the pipeline's steps and barriers do not depend on the sample counts; a ray without an importance pass shades no
+    //  fine tile, merges nothing and marches its coarse samples)
+    const bool piped = (staged || exchange_only) && P.tiles_c <= 9 && P.tiles_f <= 9 && small_planes && !(bwd_kernel && !strcmp(bwd_kernel, "wave"))
                        && !(route && !strcmp(route, "direct"));
     if (piped) {
         hipStream_t s = as_stream(stream);

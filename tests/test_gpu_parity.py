@@ -1129,7 +1129,9 @@ def _entrywise_ok(a, b, rtol=5e-3, floor=2e-4):
 @pytest.mark.parametrize('cfg', [
     dict(N=2, res=8, S=48, F=48, hw=(32, 32)),              # the training sample counts
     dict(N=1, res=5, S=17, F=30, hw=(9, 11)),               # ragged: partial tiles, odd ray count (idle waves in the last workgroup)
-    dict(N=1, res=4, S=12, F=0, hw=(8, 8)),                 # no importance pass
+    dict(N=1, res=4, S=12, F=0, hw=(8, 8)),                 # no importance pass (round 6: on the pipelined path like the others)
+    dict(N=2, res=8, S=48, F=0, hw=(16, 16)),               # ... at the training sample count, whole ray tiles
+    dict(N=1, res=5, S=100, F=0, hw=(8, 12)),               # ... seven coarse tiles (three per shader wave), ragged ray tiles
     dict(N=1, res=4, S=96, F=96, hw=(16, 16), white_back=True),
     dict(N=3, res=4, S=4, F=5, hw=(4, 4)),
     dict(N=3, res=5, S=20, F=24, hw=(12, 10)),              # ragged ITEMS: 25 rays each, no image tiling -- round 6: items padded to whole ray tiles on the staged route
